@@ -1,0 +1,36 @@
+"""Helpers shared by the parity tests: quantisation of source meshes exactly as the
+stream writer does it, and order-independent comparison of decoded meshes."""
+import numpy as np
+
+
+def quantize(vals, qmin, qrange, bits):
+    """float32 replica of AttributeQuantizationTransform / Quantizer."""
+    vals = np.asarray(vals, np.float32)
+    mn = np.asarray(qmin, np.float32)
+    inv = np.float32(np.float32((1 << bits) - 1) / np.float32(qrange))
+    return np.floor(((vals - mn).astype(np.float32) * inv).astype(np.float32) + np.float32(0.5)).astype(np.int64)
+
+
+def canon_face(keys):
+    r = [tuple(keys[i:] + keys[:i]) for i in range(3)]
+    return min(r)
+
+
+def face_multiset(faces, per_corner_keys):
+    """faces: (F,3) indices into per_corner_keys rows -> sorted list of rotation-canonical faces."""
+    out = []
+    for f in faces:
+        out.append(canon_face([tuple(int(x) for x in per_corner_keys[i]) for i in f]))
+    out.sort()
+    return out
+
+
+def decoded_point_keys(mesh, attr_ids=None):
+    """Per-point integer key = concatenated portable values of the chosen attributes."""
+    atts = mesh.attributes if attr_ids is None else [mesh.attributes[i] for i in attr_ids]
+    cols = []
+    for a in atts:
+        if a.portable is None:
+            continue
+        cols.append(a.portable[a.point_map] if len(a.point_map) else a.portable)
+    return np.concatenate(cols, axis=1)
