@@ -3,3 +3,6 @@ DracoDecoder / Mesh / PointCloud surface.  The decode product lives in csrc/
 (HIP kernels + C-ABI, see include/draco_mi355x.h); this package is the thin
 host-side mirror used by the tests and bench harness."""
 __version__ = "0.1.0"
+
+from .decoder import (Batch, Context, DataBuffer, DeviceException, Draco, DracoDecoder, DracoHeader,  # noqa: E402,F401
+                      InvalidDataException, Mesh, PointAttribute, PointCloud)

@@ -1,0 +1,482 @@
+// draco-sharp_amd/csrc/dsa_api.hip
+// Host side of the C-ABI declared in include/draco_mi355x.h: batch construction
+// (header pre-parse for arena sizing, upload), kernel launches on the context's
+// HIP stream, result queries and copy-out.  No torch types, no CPU decode path:
+// every byte of geometry is produced by the kernels in dsa_kernels.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/draco_mi355x.h"
+#include "dsa_kernels.h"
+
+namespace {
+
+enum { STG_LOCATE = 0, STG_CONNECTIVITY, STG_TRAVERSE, STG_OPERANDS, STG_SYMBOLS, STG_PREDICT, STG_FINALIZE, STG_TOTAL };
+static const char *kStageNames[DSA_NUM_STAGES] = {"locate", "connectivity", "traverse", "para_operands",
+                                                 "symbols", "predict", "finalize", "total"};
+
+// What the host learns from the fixed part of a stream; used only to size the arena.
+struct HostAttr { uint8_t att_type, data_type, nc, seq_type; };
+struct HostMesh {
+  int status = 0;   // failure of the sizing parse (the device parse decides the reported status)
+  uint32_t faces = 0, enc_vertices = 0, split_symbols = 0, splits = 0, num_att_data = 0;
+  std::vector<HostAttr> atts;
+};
+
+struct HRd {
+  const uint8_t *p; size_t n, pos = 0; bool ok = true;
+  HRd(const uint8_t *d, size_t len) : p(d), n(len) {}
+  uint32_t u8() { if (pos < n) return p[pos++]; ok = false; return 0; }
+  uint64_t varint() {
+    uint64_t r = 0;
+    for (int shift = 0; shift < 64; shift += 7) { uint32_t b = u8(); r |= (uint64_t)(b & 0x7F) << shift; if (!(b & 0x80)) return r; }
+    ok = false; return r;
+  }
+  void skip(uint64_t k) { if (!ok || k > n - pos) { ok = false; pos = n; } else pos += (size_t)k; }
+};
+
+static void skip_metadata_element(HRd &r, int depth) {
+  if (depth > 16) { r.ok = false; return; }
+  uint32_t ne = (uint32_t)r.varint();
+  for (uint32_t i = 0; i < ne && r.ok; ++i) { uint32_t ks = r.u8(); r.skip(ks); uint64_t vs = r.varint(); r.skip(vs); }
+  uint32_t ns = (uint32_t)r.varint();
+  for (uint32_t i = 0; i < ns && r.ok; ++i) { uint32_t ks = r.u8(); r.skip(ks); skip_metadata_element(r, depth + 1); }
+}
+
+static uint32_t dt_len(uint32_t dt) {
+  switch (dt) { case 1: case 2: case 11: return 1; case 3: case 4: return 2; case 5: case 6: case 9: return 4; case 7: case 8: case 10: return 8; default: return 0; }
+}
+
+// Mirrors the head of k_locate (same checks, same order) up to the attribute descriptors.
+static void host_parse(const uint8_t *s, size_t len, HostMesh &m) {
+  HRd r(s, len);
+  auto bad = [&](int code) { m.status = code; };
+  if (len < 11 || memcmp(s, "DRACO", 5) != 0) return bad(ST_INVALID);
+  r.pos = 5;
+  uint32_t major = r.u8(), minor = r.u8(), type = r.u8(), method = r.u8();
+  uint32_t flags = r.u8(); flags |= r.u8() << 8;
+  if (major != 2 || minor != 2) return bad(ST_INVALID);
+  if (flags & 0x8000) {
+    uint32_t natt = (uint32_t)r.varint();
+    for (uint32_t i = 0; i < natt && r.ok; ++i) { (void)r.varint(); skip_metadata_element(r, 0); }
+    skip_metadata_element(r, 0);
+    if (!r.ok) return bad(ST_INVALID);
+  }
+  if (type > 1) return bad(ST_INVALID);
+  if (type == 0) return bad(ST_NOTIMPL);
+  if (method > 1) return bad(ST_INVALID);
+  if (method == 0) return bad(ST_NOTIMPL);
+  uint32_t traversal = r.u8();
+  if (!r.ok || traversal > 2) return bad(ST_INVALID);
+  if (traversal != 0) return bad(ST_NOTIMPL);
+  uint64_t nv = r.varint(), nf = r.varint();
+  if (!r.ok || nf > 0x7FFFFFFFu / 3 || nv > nf * 3) return bad(ST_INVALID);
+  uint32_t nad = r.u8();
+  uint64_t nsym = r.varint();
+  if (!r.ok || nf < nsym || nf > nsym + nsym / 3) return bad(ST_INVALID);
+  uint64_t nss = r.varint();
+  if (!r.ok || nss > nsym || nad > DSA_MAX_ATT_DATA) return bad(ST_INVALID);
+  uint64_t nsplits = r.varint();
+  if (!r.ok || nsplits > nf) return bad(ST_INVALID);
+  m.faces = (uint32_t)nf; m.enc_vertices = (uint32_t)nv; m.split_symbols = (uint32_t)nss; m.splits = (uint32_t)nsplits; m.num_att_data = nad;
+  for (uint64_t i = 0; i < 2 * nsplits && r.ok; ++i) (void)r.varint();
+  r.skip((nsplits + 7) >> 3);
+  uint64_t sz = r.varint(); r.skip(sz);                       // symbols
+  (void)r.u8(); sz = r.varint(); r.skip(sz);                  // start faces
+  for (uint32_t i = 0; i < nad; ++i) { (void)r.u8(); sz = r.varint(); r.skip(sz); }
+  uint32_t ndec = r.u8();
+  if (!r.ok || ndec > DSA_MAX_ATT) return bad(ST_INVALID);
+  for (uint32_t i = 0; i < ndec; ++i) { (void)r.u8(); (void)r.u8(); (void)r.u8(); }
+  for (uint32_t i = 0; i < ndec; ++i) {
+    uint64_t k = r.varint();
+    if (!r.ok || m.atts.size() + k > DSA_MAX_ATT) return bad(ST_INVALID);
+    size_t first = m.atts.size();
+    for (uint64_t j = 0; j < k; ++j) {
+      HostAttr a;
+      a.att_type = (uint8_t)r.u8(); a.data_type = (uint8_t)r.u8(); a.nc = (uint8_t)r.u8(); (void)r.u8();
+      (void)r.varint();
+      a.seq_type = 0;
+      m.atts.push_back(a);
+    }
+    for (uint64_t j = 0; j < k; ++j) m.atts[first + j].seq_type = (uint8_t)r.u8();
+  }
+  if (!r.ok) return bad(ST_INVALID);
+  for (auto &a : m.atts) if (a.nc == 0 || dt_len(a.data_type) == 0 || a.seq_type > 3) return bad(ST_INVALID);
+}
+
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct dsa_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool profiling = false;
+  std::string err;
+};
+
+struct dsa_batch {
+  dsa_context *ctx = nullptr;
+  uint32_t n = 0;
+  std::vector<MeshLayout> layouts;
+  std::vector<HostMesh> host;
+  std::vector<MeshDesc> descs;       // copied back by dsa_batch_wait
+  uint8_t *arena = nullptr;
+  uint64_t arena_bytes = 0;
+  MeshLayout *d_layouts = nullptr;
+  MeshDesc *d_descs = nullptr;
+  uint32_t max_faces = 0, max_vertices = 0, max_atts = 0;
+  bool decoded = false, collected = false;
+  hipEvent_t ev[DSA_NUM_STAGES + 1] = {};
+  bool have_events = false;
+  float stage_ms[DSA_NUM_STAGES] = {};
+};
+
+namespace {
+
+dsa_status set_err(dsa_context *ctx, dsa_status st, const char *fmt, ...) {
+  if (ctx) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    ctx->err = buf;
+  }
+  return st;
+}
+#define HIP_TRY(ctx, call)                                                                         \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) return set_err((ctx), e_ == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE, \
+                                         "%s failed: %s", #call, hipGetErrorString(e_));          \
+  } while (0)
+
+dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *streams, const size_t *lengths, dsa_batch **out) {
+  if (!ctx || !out || (n && (!streams || !lengths))) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "null argument");
+  if (n > 65535) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "batch too large (max 65535 meshes)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dsa_batch *b = new (std::nothrow) dsa_batch();
+  if (!b) return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "host allocation failed");
+  b->ctx = ctx;
+  b->n = n;
+  b->layouts.resize(n);
+  b->host.resize(n);
+  b->descs.resize(n);
+  // ---- arena layout: [streams | padding | per-mesh regions]
+  uint64_t cur = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (lengths[i] > 0xFFFFFF00u) { delete b; return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "stream %u longer than 4 GiB", i); }
+    MeshLayout &L = b->layouts[i];
+    memset(&L, 0, sizeof(L));
+    L.stream = cur;
+    L.stream_len = (uint32_t)lengths[i];
+    cur = align_up(cur + lengths[i], 16);
+  }
+  cur = align_up(cur + 1024, 256);   // window over-read slack behind the last stream
+  const uint64_t streams_end = cur;
+  for (uint32_t i = 0; i < n; ++i) {
+    HostMesh &h = b->host[i];
+    host_parse(streams[i], lengths[i], h);
+    MeshLayout &L = b->layouts[i];
+    if (h.status != 0) { h.faces = 0; h.enc_vertices = 0; h.split_symbols = 0; h.splits = 0; h.atts.clear(); }
+    const uint64_t F = h.faces, V = (uint64_t)h.enc_vertices + h.split_symbols;
+    L.cap_faces = (uint32_t)F;
+    L.cap_vertices = (uint32_t)V;
+    L.cap_attributes = (uint32_t)h.atts.size();
+    L.cap_splits = h.splits;
+    auto take = [&](uint64_t bytes) { uint64_t at = cur; cur = align_up(cur + bytes + 16, 256); return at; };
+    L.opp = take(12 * F); L.c2v = take(12 * F);
+    L.vcorner = take(4 * V); L.vhole = take(V);
+    L.d2c = take(4 * V); L.v2d = take(4 * V);
+    L.fvis = take(F); L.vvis = take(V);
+    L.splits = take(16ull * h.splits);
+    L.vrank = take(4 * V); L.para = take(12 * V);
+    L.faces = take(12 * F);
+    for (size_t a = 0; a < h.atts.size(); ++a) {
+      const HostAttr &A = h.atts[a];
+      uint64_t ncp = A.seq_type == 3 ? 2 : A.nc;
+      uint64_t wcap = V * ncp, ocap = V * A.nc * dt_len(A.data_type);
+      if (ocap < V) ocap = V;                  // tag bytes of the tagged scheme are staged here
+      L.work[a] = take(4 * wcap); L.work_cap[a] = (uint32_t)wcap;
+      L.out[a] = take(ocap); L.out_cap[a] = (uint32_t)(ocap > 0xFFFFFFFFu ? 0xFFFFFFFFu : ocap);
+      L.map[a] = take(4 * V);
+    }
+    b->max_faces = std::max<uint32_t>(b->max_faces, (uint32_t)F);
+    b->max_vertices = std::max<uint32_t>(b->max_vertices, (uint32_t)V);
+    b->max_atts = std::max<uint32_t>(b->max_atts, (uint32_t)h.atts.size());
+  }
+  b->arena_bytes = cur;
+  hipError_t e = hipMalloc((void **)&b->arena, b->arena_bytes ? b->arena_bytes : 256);
+  if (e != hipSuccess) { uint64_t need = b->arena_bytes; delete b; return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "hipMalloc of %llu-byte arena failed: %s", (unsigned long long)need, hipGetErrorString(e)); }
+  e = hipMalloc((void **)&b->d_layouts, sizeof(MeshLayout) * (n ? n : 1));
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_descs, sizeof(MeshDesc) * (n ? n : 1));
+  if (e != hipSuccess) { dsa_batch_free(b); return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "hipMalloc failed: %s", hipGetErrorString(e)); }
+  // ---- upload: one staging copy of all streams, one of the layouts
+  {
+    std::vector<uint8_t> staging(streams_end, 0);
+    for (uint32_t i = 0; i < n; ++i) if (lengths[i]) memcpy(staging.data() + b->layouts[i].stream, streams[i], lengths[i]);
+    e = hipMemcpyAsync(b->arena, staging.data(), streams_end, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(b->d_layouts, b->layouts.data(), sizeof(MeshLayout) * n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { dsa_batch_free(b); return set_err(ctx, DSA_ERR_DEVICE, "upload failed: %s", hipGetErrorString(e)); }
+  }
+  *out = b;
+  return DSA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsa_abi_version(void) { return DSA_ABI_VERSION; }
+
+int dsa_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+dsa_status dsa_context_create(int device, void *stream, dsa_context **out) {
+  if (!out) return DSA_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return DSA_ERR_DEVICE;
+  dsa_context *c = new (std::nothrow) dsa_context();
+  if (!c) return DSA_ERR_OUT_OF_MEMORY;
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete c; return DSA_ERR_DEVICE; }
+  if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+  else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DSA_ERR_DEVICE; }
+    c->own_stream = true;
+  }
+  *out = c;
+  return DSA_OK;
+}
+
+void dsa_context_destroy(dsa_context *ctx) {
+  if (!ctx) return;
+  if (ctx->own_stream && ctx->stream) { (void)hipSetDevice(ctx->device); (void)hipStreamDestroy(ctx->stream); }
+  delete ctx;
+}
+
+const char *dsa_last_error(const dsa_context *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+dsa_status dsa_context_set_profiling(dsa_context *ctx, int enabled) {
+  if (!ctx) return DSA_ERR_INVALID_ARGUMENT;
+  ctx->profiling = enabled != 0;
+  return DSA_OK;
+}
+
+dsa_status dsa_batch_create(dsa_context *ctx, uint32_t n, const uint8_t *const *streams, const size_t *lengths, dsa_batch **out) {
+  return build_batch(ctx, n, streams, lengths, out);
+}
+
+dsa_status dsa_batch_create_packed(dsa_context *ctx, uint32_t n, const uint8_t *blob, const uint64_t *offsets, dsa_batch **out) {
+  if (!ctx || !out || (n && (!blob || !offsets))) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "null argument");
+  std::vector<const uint8_t *> ptrs(n);
+  std::vector<size_t> lens(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (offsets[i + 1] < offsets[i]) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+    ptrs[i] = blob + offsets[i];
+    lens[i] = (size_t)(offsets[i + 1] - offsets[i]);
+  }
+  return build_batch(ctx, n, ptrs.data(), lens.data(), out);
+}
+
+dsa_status dsa_batch_decode(dsa_batch *b) {
+  if (!b) return DSA_ERR_INVALID_ARGUMENT;
+  dsa_context *ctx = b->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = b->n;
+  b->decoded = true;
+  b->collected = false;
+  if (n == 0) return DSA_OK;
+  hipStream_t st = ctx->stream;
+  const bool prof = ctx->profiling;
+  if (prof && !b->have_events) {
+    for (int i = 0; i <= DSA_NUM_STAGES; ++i) HIP_TRY(ctx, hipEventCreate(&b->ev[i]));
+    b->have_events = true;
+  }
+  int evi = 0;
+  auto mark = [&]() -> hipError_t { return prof ? hipEventRecord(b->ev[evi++], st) : hipSuccess; };
+  HIP_TRY(ctx, hipMemsetAsync(b->d_descs, 0, sizeof(MeshDesc) * n, st));
+  HIP_TRY(ctx, mark());
+  hipLaunchKernelGGL(dsa::k_locate, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+  HIP_TRY(ctx, mark());
+  hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+  HIP_TRY(ctx, mark());
+  hipLaunchKernelGGL(dsa::k_traverse, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+  HIP_TRY(ctx, mark());
+  {
+    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 255) / 256, 64));
+    hipLaunchKernelGGL(dsa::k_para_operands, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+  }
+  HIP_TRY(ctx, mark());
+  const uint32_t na = std::max<uint32_t>(1, b->max_atts);
+  hipLaunchKernelGGL(dsa::k_symbols, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+  HIP_TRY(ctx, mark());
+  hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+  HIP_TRY(ctx, mark());
+  {
+    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 1023) / 1024, 64));
+    hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+  }
+  HIP_TRY(ctx, mark());
+  HIP_TRY(ctx, hipGetLastError());
+  return DSA_OK;
+}
+
+dsa_status dsa_batch_wait(dsa_batch *b) {
+  if (!b) return DSA_ERR_INVALID_ARGUMENT;
+  dsa_context *ctx = b->ctx;
+  if (!b->decoded) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "dsa_batch_decode was not called");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (b->n) HIP_TRY(ctx, hipMemcpy(b->descs.data(), b->d_descs, sizeof(MeshDesc) * b->n, hipMemcpyDeviceToHost));
+  if (ctx->profiling && b->have_events && b->n) {
+    for (int i = 0; i < STG_TOTAL; ++i) HIP_TRY(ctx, hipEventElapsedTime(&b->stage_ms[i], b->ev[i], b->ev[i + 1]));
+    HIP_TRY(ctx, hipEventElapsedTime(&b->stage_ms[STG_TOTAL], b->ev[0], b->ev[STG_TOTAL]));
+  }
+  b->collected = true;
+  return DSA_OK;
+}
+
+void dsa_batch_free(dsa_batch *b) {
+  if (!b) return;
+  (void)hipSetDevice(b->ctx->device);
+  if (b->have_events) for (int i = 0; i <= DSA_NUM_STAGES; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
+  if (b->arena) (void)hipFree(b->arena);
+  if (b->d_layouts) (void)hipFree(b->d_layouts);
+  if (b->d_descs) (void)hipFree(b->d_descs);
+  delete b;
+}
+
+uint32_t dsa_batch_size(const dsa_batch *b) { return b ? b->n : 0; }
+uint64_t dsa_batch_arena_bytes(const dsa_batch *b) { return b ? b->arena_bytes : 0; }
+
+uint64_t dsa_batch_algorithmic_bytes(const dsa_batch *b) {
+  if (!b || !b->collected) return 0;
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < b->n; ++i) {
+    const MeshDesc &D = b->descs[i];
+    if (D.status != ST_OK) continue;
+    total += b->layouts[i].stream_len + 12ull * D.num_faces;
+    for (uint32_t a = 0; a < D.num_attributes; ++a) {
+      const AttrDesc &A = D.att[a];
+      total += (uint64_t)A.num_entries * A.nc * dt_len(A.data_type) + 4ull * D.num_points;
+    }
+  }
+  return total;
+}
+
+#define CHECK_MESH(b, mesh)                                                                         \
+  if (!(b)) return DSA_ERR_INVALID_ARGUMENT;                                                        \
+  if (!(b)->collected) return set_err((b)->ctx, DSA_ERR_INVALID_ARGUMENT, "results not collected: call dsa_batch_wait"); \
+  if ((mesh) >= (b)->n) return set_err((b)->ctx, DSA_ERR_INVALID_ARGUMENT, "mesh index %u out of range", (unsigned)(mesh));
+#define CHECK_ATTR(b, mesh, a)                                                                      \
+  CHECK_MESH(b, mesh)                                                                               \
+  if ((b)->descs[mesh].status != ST_OK) return set_err((b)->ctx, (dsa_status)(b)->descs[mesh].status, "mesh %u failed to decode", (unsigned)(mesh)); \
+  if ((a) >= (b)->descs[mesh].num_attributes) return set_err((b)->ctx, DSA_ERR_INVALID_ARGUMENT, "attribute index %u out of range", (unsigned)(a));
+
+dsa_status dsa_batch_mesh_info(const dsa_batch *b, uint32_t mesh, dsa_mesh_info *out) {
+  CHECK_MESH(b, mesh);
+  if (!out) return DSA_ERR_INVALID_ARGUMENT;
+  const MeshDesc &D = b->descs[mesh];
+  memset(out, 0, sizeof(*out));
+  out->status = D.status; out->detail = D.detail;
+  out->major_version = D.major; out->minor_version = D.minor; out->encoder_type = D.encoder_type; out->encoder_method = D.encoder_method;
+  out->flags = D.flags;
+  out->drc_bytes = b->layouts[mesh].stream_len;
+  if (D.status == ST_OK) { out->num_faces = D.num_faces; out->num_points = D.num_points; out->num_attributes = D.num_attributes; }
+  return DSA_OK;
+}
+
+dsa_status dsa_batch_attribute_info(const dsa_batch *b, uint32_t mesh, uint32_t a, dsa_attribute_info *out) {
+  CHECK_ATTR(b, mesh, a);
+  if (!out) return DSA_ERR_INVALID_ARGUMENT;
+  const AttrDesc &A = b->descs[mesh].att[a];
+  memset(out, 0, sizeof(*out));
+  out->attribute_type = A.att_type; out->data_type = A.data_type; out->num_components = A.nc; out->normalized = A.normalized;
+  out->unique_id = A.unique_id; out->num_entries = A.num_entries; out->byte_stride = dt_len(A.data_type) * A.nc;
+  out->decoder_type = A.seq_type; out->prediction_method = A.pred_method; out->prediction_transform = A.pred_transform;
+  out->quantization_bits = A.q_bits; out->range = A.q_range;
+  for (int c = 0; c < 4; ++c) out->min_values[c] = A.q_min[c];
+  return DSA_OK;
+}
+
+static dsa_status copy_out(const dsa_batch *b, void *dst, uint64_t off, uint64_t bytes) {
+  if (!dst) return DSA_ERR_INVALID_ARGUMENT;
+  if (bytes == 0) return DSA_OK;
+  HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
+  HIP_TRY(b->ctx, hipMemcpy(dst, b->arena + off, bytes, hipMemcpyDeviceToHost));
+  return DSA_OK;
+}
+
+dsa_status dsa_batch_copy_faces(const dsa_batch *b, uint32_t mesh, int32_t *dst) {
+  CHECK_MESH(b, mesh);
+  if (b->descs[mesh].status != ST_OK) return set_err(b->ctx, (dsa_status)b->descs[mesh].status, "mesh %u failed to decode", mesh);
+  return copy_out(b, dst, b->layouts[mesh].faces, 12ull * b->descs[mesh].num_faces);
+}
+dsa_status dsa_batch_copy_attribute_values(const dsa_batch *b, uint32_t mesh, uint32_t a, void *dst) {
+  CHECK_ATTR(b, mesh, a);
+  const AttrDesc &A = b->descs[mesh].att[a];
+  return copy_out(b, dst, b->layouts[mesh].out[a], (uint64_t)A.num_entries * A.nc * dt_len(A.data_type));
+}
+dsa_status dsa_batch_copy_point_map(const dsa_batch *b, uint32_t mesh, uint32_t a, uint32_t *dst) {
+  CHECK_ATTR(b, mesh, a);
+  return copy_out(b, dst, b->layouts[mesh].map[a], 4ull * b->descs[mesh].num_points);
+}
+dsa_status dsa_batch_copy_portable_values(const dsa_batch *b, uint32_t mesh, uint32_t a, int32_t *dst) {
+  CHECK_ATTR(b, mesh, a);
+  const AttrDesc &A = b->descs[mesh].att[a];
+  if (A.source == SRC_BYTES) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "generic attributes have no portable form");
+  return copy_out(b, dst, b->layouts[mesh].work[a], 4ull * A.num_entries * A.nc_portable);
+}
+
+const int32_t *dsa_batch_device_faces(const dsa_batch *b, uint32_t mesh) {
+  if (!b || mesh >= b->n) return nullptr;
+  return (const int32_t *)(b->arena + b->layouts[mesh].faces);
+}
+const void *dsa_batch_device_attribute_values(const dsa_batch *b, uint32_t mesh, uint32_t a) {
+  if (!b || mesh >= b->n || a >= DSA_MAX_ATT) return nullptr;
+  return b->arena + b->layouts[mesh].out[a];
+}
+const uint32_t *dsa_batch_device_point_map(const dsa_batch *b, uint32_t mesh, uint32_t a) {
+  if (!b || mesh >= b->n || a >= DSA_MAX_ATT) return nullptr;
+  return (const uint32_t *)(b->arena + b->layouts[mesh].map[a]);
+}
+
+dsa_status dsa_batch_copy_debug(const dsa_batch *b, uint32_t mesh, int what, void *dst, size_t dst_bytes, size_t *written) {
+  CHECK_MESH(b, mesh);
+  const MeshDesc &D = b->descs[mesh];
+  if (D.status != ST_OK) return set_err(b->ctx, (dsa_status)D.status, "mesh %u failed to decode", mesh);
+  const MeshLayout &L = b->layouts[mesh];
+  uint64_t off = 0, bytes = 0;
+  switch (what) {
+    case 0: off = L.opp; bytes = 12ull * D.num_faces; break;
+    case 1: off = L.c2v; bytes = 12ull * D.num_faces; break;
+    case 2: off = L.d2c; bytes = 4ull * D.num_entries; break;
+    case 3: off = L.v2d; bytes = 4ull * D.num_vertices; break;
+    default: return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "unknown debug array %d", what);
+  }
+  if (bytes > dst_bytes) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "destination too small");
+  if (written) *written = (size_t)bytes;
+  return copy_out(b, dst, off, bytes);
+}
+
+dsa_status dsa_batch_stage_times(const dsa_batch *b, float ms[DSA_NUM_STAGES], const char *names[DSA_NUM_STAGES]) {
+  if (!b || !ms) return DSA_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < DSA_NUM_STAGES; ++i) { ms[i] = b->stage_ms[i]; if (names) names[i] = kStageNames[i]; }
+  return DSA_OK;
+}
+
+}  // extern "C"

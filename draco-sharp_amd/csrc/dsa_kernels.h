@@ -1,0 +1,1224 @@
+// draco-sharp_amd/csrc/dsa_kernels.h
+// HIP kernels of the Draco (bitstream 2.2) mesh-decode path for gfx950 (MI355X).
+// One wave64 owns one mesh (or one attribute stream of one mesh); a batch of
+// meshes fills the chip.  The serial recurrences the format imposes (rANS
+// state, Edgebreaker stack machine, DFS order, parallelogram chain) run with a
+// wave-uniform state, the other lanes serving as the table search / window /
+// scan engine; everything elementwise is lane-parallel.
+//
+// Reference restated (paths under /root/reference/src/Draco/IO/):
+//   k_locate       DracoDecoder.cs:44-99, Mesh/MeshEdgeBreakerDecoder.cs:25-56,136-193,
+//                  Mesh/MeshEdgeBreakerTraversalDecoder.cs:27-61, ConnectivityDecoder.cs:16-44,
+//                  Attributes/AttributesDecoder.cs:19-63, SequentialAttributeDecodersController.cs:16-27,
+//                  SequentialIntegerAttributeDecoder.cs:23-101, Entropy/SymbolDecoding.cs:7-67,
+//                  Entropy/RAnsSymbolDecoder.cs:12-59, AttributeQuantizationTransform.cs:110-121
+//   k_connectivity Mesh/MeshEdgeBreakerDecoder.cs:232-471,502-638, MeshEdgeBreakerTraversalDecoder.cs:89-107,
+//                  Entropy/AnsDecoder.cs:12-56, BitCoders/RAnsBitDecoder.cs:12-24
+//   k_traverse     Mesh/Traverser/DepthFirstTraverser.cs:9-99, MeshAttributeIndicesEncodingObserver.cs:14-21,
+//                  MeshTraversalSequencer.cs:13-31, PredictionSchemes/MeshPredictionSchemeParallelogramDecoder.cs:56-89
+//   k_symbols      Entropy/RAnsDecoder.cs:20-99, SymbolDecoding.cs:30-67, BitUtilities.cs:72-103
+//   k_predict      PredictionSchemes/PredictionSchemeDeltaDecoder.cs:23-37, MeshPredictionSchemeParallelogramDecoder.cs:29-54,
+//                  PredictionSchemeWrapDecodingTransform.cs:46-75, PredictionSchemeNormalOctahedron*DecodingTransform.cs
+//   k_finalize     AttributeQuantizationTransform.cs:179-199, Core/Dequantizer.cs:15-23,
+//                  AttributeOctahedronTransform.cs:82-102, OctahedronToolBox.cs:139-142,220-239,
+//                  SequentialIntegerAttributeDecoder.cs:103-160, MeshTraversalSequencer.cs:33-50
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dsa_types.h"
+
+namespace dsa {
+
+#define WAVE 64
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ void fail(MeshDesc *d, int code, int site) {
+  if (atomicCAS(&d->status, ST_OK, code) == ST_OK) d->detail = site;
+}
+// REQUIRE/NOTIMPL latch the first failure of a mesh and leave the current function with RET.
+#define RET
+#define REQUIRE(cond, site)                  \
+  do {                                       \
+    if (!(cond)) {                           \
+      fail(D, ST_INVALID, (site));           \
+      return RET;                            \
+    }                                        \
+  } while (0)
+#define NOTIMPL(site)                        \
+  do {                                       \
+    fail(D, ST_NOTIMPL, (site));             \
+    return RET;                              \
+  } while (0)
+// status as seen through L2 (a plain load may hit a stale L1 line after an atomic by this CU)
+__device__ __forceinline__ int status_of(MeshDesc *d) { return __hip_atomic_load(&d->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ uint32_t cnext(uint32_t c) { return (c % 3u == 2u) ? c - 2u : c + 1u; }
+__device__ __forceinline__ uint32_t cprev(uint32_t c) { return (c % 3u == 0u) ? c + 2u : c - 1u; }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+// Bounds-checked little-endian byte reader over one compressed stream
+// (DecoderBuffer.cs:26-120).  A failed read latches ok=false and returns 0.
+struct Rd {
+  const uint8_t *p;
+  uint32_t n, pos;
+  bool ok;
+  __device__ Rd(const uint8_t *d, uint32_t len, uint32_t at) : p(d), n(len), pos(at), ok(at <= len) {}
+  __device__ uint32_t u8() {
+    if (pos < n) return p[pos++];
+    ok = false;
+    return 0;
+  }
+  __device__ uint32_t u16() { uint32_t a = u8(); return a | (u8() << 8); }
+  __device__ uint32_t u32() { uint32_t a = u8(); a |= u8() << 8; a |= u8() << 16; return a | (u8() << 24); }
+  __device__ float f32() { return __uint_as_float(u32()); }
+  __device__ uint64_t varint() {
+    uint64_t r = 0;
+    for (int shift = 0; shift < 64; shift += 7) {
+      uint32_t b = u8();
+      r |= (uint64_t)(b & 0x7F) << shift;
+      if (!(b & 0x80)) return r;
+    }
+    ok = false;
+    return r;
+  }
+  __device__ void skip(uint64_t k) {
+    if (!ok || k > (uint64_t)(n - pos)) { ok = false; pos = n; }
+    else pos += (uint32_t)k;
+  }
+};
+
+// Up to 32 bits at an arbitrary bit position of an LSB-first bit section
+// (DecoderBuffer.cs:138-154); bytes past `n` read as 0.
+__device__ __forceinline__ uint32_t read_bits(const uint8_t *p, uint32_t n, uint64_t bitpos, uint32_t count) {
+  uint32_t byte = (uint32_t)(bitpos >> 3), sh = (uint32_t)(bitpos & 7);
+  uint64_t w = 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    uint32_t b = (byte + k < n) ? p[byte + k] : 0u;
+    w |= (uint64_t)b << (8 * k);
+  }
+  w >>= sh;
+  return count >= 32 ? (uint32_t)w : ((uint32_t)w & ((1u << count) - 1u));
+}
+
+// rABS binary decoder (Entropy/AnsDecoder.cs:12-56, BitCoders/RAnsBitDecoder.cs:12-24)
+struct Rabs {
+  const uint8_t *buf;
+  uint32_t off, state, p;   // p = 256 - prob_zero
+  bool ok;
+  __device__ void start(const uint8_t *s, uint32_t slen, uint32_t at, uint32_t *end_pos) {
+    Rd r(s, slen, at);
+    uint32_t prob_zero = r.u8();
+    uint64_t size = r.varint();
+    uint32_t begin = r.pos;
+    r.skip(size);
+    ok = r.ok && size >= 1;
+    *end_pos = r.pos;
+    p = 256u - prob_zero;
+    buf = s + begin;
+    off = 0; state = 4096;
+    if (!ok) return;
+    uint32_t o = (uint32_t)size;
+    uint32_t x = buf[o - 1] >> 6;
+    if (x == 0) { off = o - 1; state = buf[o - 1] & 0x3F; }
+    else if (x == 1) { if (o < 2) { ok = false; return; } off = o - 2; state = ((uint32_t)buf[o - 2] | ((uint32_t)buf[o - 1] << 8)) & 0x3FFF; }
+    else if (x == 2) { if (o < 3) { ok = false; return; } off = o - 3; state = ((uint32_t)buf[o - 3] | ((uint32_t)buf[o - 2] << 8) | ((uint32_t)buf[o - 1] << 16)) & 0x3FFFFF; }
+    else { ok = false; return; }
+    state += 4096;
+    if (state >= 4096u * 256u) ok = false;
+  }
+  __device__ uint32_t next() {
+    if (state < 4096 && off > 0) state = state * 256 + buf[--off];
+    uint32_t x = state, quot = x >> 8, rem = x & 255, xn = quot * p;
+    bool val = rem < p;
+    state = val ? xn + rem : x - xn - p;
+    return val ? 1u : 0u;
+  }
+};
+
+// rANS stream tail -> initial state (Entropy/RAnsDecoder.cs:20-54)
+__device__ __forceinline__ bool rans_init(const uint8_t *buf, uint32_t size, uint32_t l_base, uint32_t *state, uint32_t *off) {
+  if (size < 1) return false;
+  uint32_t x = buf[size - 1] >> 6, st, o;
+  if (x == 0) { o = size - 1; st = buf[size - 1] & 0x3F; }
+  else if (x == 1) { if (size < 2) return false; o = size - 2; st = ((uint32_t)buf[size - 2] | ((uint32_t)buf[size - 1] << 8)) & 0x3FFF; }
+  else if (x == 2) { if (size < 3) return false; o = size - 3; st = ((uint32_t)buf[size - 3] | ((uint32_t)buf[size - 2] << 8) | ((uint32_t)buf[size - 1] << 16)) & 0x3FFFFF; }
+  else { if (size < 4) return false; o = size - 4; st = ((uint32_t)buf[size - 4] | ((uint32_t)buf[size - 3] << 8) | ((uint32_t)buf[size - 2] << 16) | ((uint32_t)buf[size - 1] << 24)) & 0x3FFFFFFF; }
+  st += l_base;
+  if (st >= l_base * 256u) return false;
+  *state = st; *off = o;
+  return true;
+}
+
+// Reads the probability table of an rANS symbol stream into prob[0..n) (lane 0)
+// (Entropy/RAnsSymbolDecoder.cs:21-48).  Returns false on malformed input.
+__device__ bool read_prob_table(Rd &r, uint32_t n, uint32_t *prob) {
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t pd = r.u8();
+    uint32_t token = pd & 3;
+    if (token == 3) {
+      uint32_t offset = pd >> 2;
+      if (i + offset >= n) return false;
+      for (uint32_t j = 0; j <= offset; ++j) prob[i + j] = 0;
+      i += offset;
+    } else {
+      uint32_t pr = pd >> 2;
+      for (uint32_t k = 0; k < token; ++k) pr |= r.u8() << (8 * (k + 1) - 2);
+      prob[i] = pr;
+    }
+  }
+  return r.ok;
+}
+// Same walk without storing (k_locate only needs to know where the table ends).
+__device__ bool skip_prob_table(Rd &r, uint32_t n) {
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t pd = r.u8();
+    uint32_t token = pd & 3;
+    if (token == 3) {
+      uint32_t offset = pd >> 2;
+      if (i + offset >= n) return false;
+      i += offset;
+    } else {
+      r.skip(token);
+    }
+  }
+  return r.ok;
+}
+__device__ __forceinline__ uint32_t rans_precision_bits(uint32_t max_bit_length) {   // Entropy/RAnsSymbolCoding.cs:10-27
+  uint32_t p = (3 * max_bit_length) / 2;
+  return p < 12 ? 12 : (p > 20 ? 20 : p);
+}
+
+__device__ __forceinline__ uint32_t data_type_length(uint32_t dt) {   // Constants.cs:134-150
+  switch (dt) {
+    case 1: case 2: case 11: return 1;
+    case 3: case 4: return 2;
+    case 5: case 6: case 9: return 4;
+    case 7: case 8: case 10: return 8;
+    default: return 0;
+  }
+}
+
+// Wave-wide exclusive prefix sum of one value per lane; total in *total.
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total) {
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t y = __shfl_up(x, d, 64);
+    if ((int)lane_id() >= d) x += y;
+  }
+  *total = __shfl(x, 63, 64);
+  return x - v;
+}
+
+// =========================================================================
+// k_locate: one wave per mesh, lane 0 walks the stream and records where every
+// section starts.  Tag streams of the tagged symbol scheme are decoded here
+// (their bit section has no length prefix), tags stored as bytes in the
+// attribute's output buffer for k_symbols.
+// =========================================================================
+#define LOC_MAX_TAGS 64
+
+#undef RET
+#define RET false
+__device__ bool locate_attribute_values(Rd &r, MeshDesc *D, AttrDesc &a, const MeshLayout &L, int ai, uint8_t *arena,
+                                        uint32_t *s_cum, uint32_t num_entries) {
+  const uint8_t *s = r.p;
+  a.num_entries = num_entries;
+  if (a.seq_type == 0) {   // generic: raw bytes, SequentialAttributeDecoder.cs:75-86
+    a.source = SRC_BYTES;
+    a.nc_portable = a.nc;
+    a.off_raw = r.pos;
+    uint64_t bytes = (uint64_t)data_type_length(a.data_type) * a.nc * num_entries;
+    REQUIRE(bytes <= L.out_cap[ai], 140);
+    r.skip(bytes);
+    REQUIRE(r.ok, 141);
+    return true;
+  }
+  uint32_t nc = a.seq_type == 3 ? 2u : a.nc;   // normals are (s,t) in portable form
+  a.nc_portable = (uint8_t)nc;
+  uint64_t num_values = (uint64_t)num_entries * nc;
+  REQUIRE(num_values <= L.work_cap[ai], 142);
+  int method = (int8_t)r.u8();
+  REQUIRE(r.ok && method >= -2 && method < 7, 143);
+  a.pred_method = (int8_t)method;
+  a.have_scheme = 0;
+  a.pred_transform = -1;
+  if (method != -2) {
+    int tt = (int8_t)r.u8();
+    REQUIRE(r.ok && tt >= -1 && tt < 4, 144);
+    a.pred_transform = (int8_t)tt;
+    if (a.seq_type == 3) a.have_scheme = (tt == 2 || tt == 3);
+    else a.have_scheme = (tt == 1);
+  }
+  uint32_t compressed = r.u8();
+  REQUIRE(r.ok, 145);
+  if (compressed > 0) {
+    if (num_values > 0) {
+      uint32_t scheme = r.u8();
+      REQUIRE(r.ok && scheme <= 1, 146);
+      if (scheme == 1) {
+        a.source = SRC_RAW;
+        uint32_t mbl = r.u8();
+        REQUIRE(r.ok && mbl >= 1 && mbl <= 18, 147);
+        a.precision_bits = (uint8_t)rans_precision_bits(mbl);
+        uint64_t ns = r.varint();
+        REQUIRE(r.ok && ns >= 1 && ns <= (1u << 20), 148);
+        a.num_symbols = (uint32_t)ns;
+        a.off_table = r.pos;
+        REQUIRE(skip_prob_table(r, a.num_symbols), 149);
+        uint64_t size = r.varint();
+        a.off_rans = r.pos;
+        r.skip(size);
+        REQUIRE(r.ok && size >= 1, 150);
+        a.size_rans = (uint32_t)size;
+      } else {
+        a.source = SRC_TAGGED;
+        a.precision_bits = 12;   // SymbolDecoding.cs:34: tag alphabet is 5 bits wide
+        uint64_t ns = r.varint();
+        REQUIRE(r.ok && ns >= 1 && ns <= LOC_MAX_TAGS, 151);
+        a.num_symbols = (uint32_t)ns;
+        a.off_table = r.pos;
+        REQUIRE(read_prob_table(r, a.num_symbols, s_cum), 152);
+        uint32_t c = 0;
+        for (uint32_t i = 0; i < a.num_symbols; ++i) { uint32_t pr = s_cum[i]; s_cum[i] = c; c += pr; }
+        s_cum[a.num_symbols] = c;
+        REQUIRE(c == 4096, 153);
+        uint64_t size = r.varint();
+        a.off_rans = r.pos;
+        r.skip(size);
+        REQUIRE(r.ok && size >= 1, 154);
+        a.size_rans = (uint32_t)size;
+        a.off_bits = r.pos;
+        // decode the tag stream; tags -> out buffer (bytes)
+        REQUIRE(num_entries <= L.out_cap[ai], 155);
+        uint8_t *tags = arena + L.out[ai];
+        const uint8_t *buf = s + a.off_rans;
+        uint32_t state, off;
+        REQUIRE(rans_init(buf, a.size_rans, 16384, &state, &off), 156);
+        uint64_t total_bits = 0;
+        for (uint32_t e = 0; e < num_entries; ++e) {
+          while (state < 16384 && off > 0) state = state * 256 + buf[--off];
+          uint32_t rem = state & 4095, quo = state >> 12;
+          uint32_t lo = 0, hi = a.num_symbols;   // largest i with cum[i] <= rem
+          while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s_cum[mid] <= rem) lo = mid; else hi = mid; }
+          // skip zero-probability symbols that share the same cumulative value
+          uint32_t cs = s_cum[lo], f = s_cum[lo + 1] - cs;
+          state = quo * f + rem - cs;
+          REQUIRE(lo <= 32, 157);
+          tags[e] = (uint8_t)lo;
+          total_bits += (uint64_t)lo * nc;
+        }
+        r.skip((total_bits + 7) >> 3);
+        REQUIRE(r.ok, 158);
+      }
+    } else {
+      a.source = SRC_RAW;
+      a.num_symbols = 0;
+    }
+  } else {
+    a.source = SRC_FIXED;
+    uint32_t nb = r.u8();
+    REQUIRE(r.ok && nb >= 1 && nb <= 4, 159);
+    a.fixed_bytes = (uint8_t)nb;
+    a.off_raw = r.pos;
+    r.skip((uint64_t)nb * num_values);
+    REQUIRE(r.ok, 160);
+  }
+  if (a.have_scheme) {
+    // only Difference and Parallelogram run on the device path for now
+    if (!(method == 0 || method == 1)) NOTIMPL(161);
+    if (a.pred_transform == 1) {           // PredictionSchemeWrapDecodingTransform.cs:69-75
+      a.wrap_min = (int32_t)r.u32();
+      a.wrap_max = (int32_t)r.u32();
+      REQUIRE(r.ok && a.wrap_min <= a.wrap_max, 162);
+      int64_t dif = (int64_t)a.wrap_max - (int64_t)a.wrap_min;
+      REQUIRE(dif < 0x7FFFFFFF, 163);
+    } else {                               // NormalOctahedron(+Canonicalized)DecodingTransform
+      int32_t max_q = (int32_t)r.u32();
+      if (a.pred_transform == 3) (void)r.u32();
+      REQUIRE(r.ok && max_q > 0 && (max_q & 1) == 1, 164);
+      int q = 32 - __clz(max_q);
+      REQUIRE(q >= 2 && q <= 30, 165);
+      a.oct_max_q = max_q;
+    }
+  }
+  return true;
+}
+#undef RET
+#define RET
+
+__global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  __shared__ uint32_t s_cum[LOC_MAX_TAGS + 1];
+  uint32_t mesh = blockIdx.x;
+  if (mesh >= n || threadIdx.x != 0) return;
+  const MeshLayout &L = layouts[mesh];
+  MeshDesc *D = &descs[mesh];
+  const uint8_t *s = arena + L.stream;
+  Rd r(s, L.stream_len, 0);
+  // header, DracoDecoder.cs:44-64
+  REQUIRE(L.stream_len >= 11, 100);
+  REQUIRE(s[0] == 'D' && s[1] == 'R' && s[2] == 'A' && s[3] == 'C' && s[4] == 'O', 101);
+  r.pos = 5;
+  D->major = (uint8_t)r.u8(); D->minor = (uint8_t)r.u8();
+  D->encoder_type = (uint8_t)r.u8(); D->encoder_method = (uint8_t)r.u8();
+  D->flags = (uint16_t)r.u16();
+  REQUIRE(D->major == 2 && D->minor == 2, 102);
+  if (D->flags & 0x8000) {   // metadata is skipped structurally (Metadata/MetadataDecoder.cs:5-49)
+    uint32_t natt = (uint32_t)r.varint();
+    uint32_t pending[16];
+    int depth = 0;
+    uint32_t elements_left = natt + 1;   // per-attribute elements (each preceded by an id) then the file element
+    bool first_level_ids = true;
+    (void)first_level_ids;
+    for (uint32_t e = 0; e < elements_left && r.ok; ++e) {
+      if (e < natt) (void)r.varint();
+      // one element, iteratively
+      depth = 0;
+      pending[0] = 1;
+      bool at_key = false;
+      while (depth >= 0 && r.ok) {
+        if (pending[depth] == 0) { --depth; continue; }
+        --pending[depth];
+        if (at_key || depth > 0) { uint32_t ks = r.u8(); r.skip(ks); }
+        uint32_t ne = (uint32_t)r.varint();
+        for (uint32_t i = 0; i < ne && r.ok; ++i) { uint32_t ks = r.u8(); r.skip(ks); uint64_t vs = r.varint(); r.skip(vs); }
+        uint32_t nsub = (uint32_t)r.varint();
+        if (nsub) { REQUIRE(depth < 15, 103); pending[++depth] = nsub; }
+      }
+    }
+    REQUIRE(r.ok, 104);
+  }
+  REQUIRE(D->encoder_type <= 1, 105);
+  if (D->encoder_type == 0) NOTIMPL(106);                   // point clouds: DracoDecoder.cs:70
+  REQUIRE(D->encoder_method <= 1, 107);
+  if (D->encoder_method == 0) NOTIMPL(108);                 // sequential mesh
+  D->traversal_type = (uint8_t)r.u8();
+  REQUIRE(r.ok && D->traversal_type <= 2, 109);
+  if (D->traversal_type != 0) NOTIMPL(110);                 // valence / predictive traversal
+  // MeshEdgeBreakerDecoder.cs:35-56
+  uint64_t nv = r.varint(), nf = r.varint();
+  REQUIRE(r.ok && nf <= 0x7FFFFFFFu / 3 && nv <= nf * 3, 111);
+  uint64_t min_face_edges = 3 * nf / 2, max_vertex_edges = nv * (nv - 1) / 2;
+  REQUIRE(max_vertex_edges >= min_face_edges, 112);
+  uint32_t nad = r.u8();
+  uint64_t nsym = r.varint();
+  REQUIRE(r.ok && nf >= nsym && nf <= nsym + nsym / 3, 113);
+  uint64_t nsplit_sym = r.varint();
+  REQUIRE(r.ok && nsplit_sym <= nsym, 114);
+  REQUIRE(nad <= DSA_MAX_ATT_DATA, 115);
+  D->num_enc_vertices = (uint32_t)nv; D->num_faces = (uint32_t)nf; D->num_att_data = (uint8_t)nad;
+  D->num_symbols = (uint32_t)nsym; D->num_split_symbols = (uint32_t)nsplit_sym;
+  REQUIRE(nf == L.cap_faces && nv + nsplit_sym == L.cap_vertices, 116);   // host sizing must agree
+  // topology splits, MeshEdgeBreakerDecoder.cs:136-193
+  uint64_t nsplits = r.varint();
+  REQUIRE(r.ok && nsplits <= nf && nsplits <= L.cap_splits, 117);
+  D->num_splits = (uint32_t)nsplits;
+  D->off_splits = r.pos;
+  for (uint64_t i = 0; i < 2 * nsplits; ++i) (void)r.varint();
+  D->off_split_bits = r.pos;
+  r.skip((nsplits + 7) >> 3);
+  REQUIRE(r.ok, 118);
+  // traversal sections, MeshEdgeBreakerTraversalDecoder.cs:27-61 (symbol section is `size` bytes, D-3)
+  uint64_t sym_size = r.varint();
+  D->off_symbols = r.pos;
+  r.skip(sym_size);
+  REQUIRE(r.ok, 119);
+  D->size_symbols = (uint32_t)sym_size;
+  D->off_start_faces = r.pos;
+  { (void)r.u8(); uint64_t sz = r.varint(); r.skip(sz); REQUIRE(r.ok && sz >= 1, 120); }
+  for (uint32_t i = 0; i < nad; ++i) {
+    D->off_seams[i] = r.pos;
+    (void)r.u8();
+    uint64_t sz = r.varint();
+    r.skip(sz);
+    REQUIRE(r.ok && sz >= 1, 121);
+  }
+  // attribute section, ConnectivityDecoder.cs:16-44
+  D->off_attributes = r.pos;
+  uint32_t ndec = r.u8();
+  REQUIRE(r.ok && ndec <= DSA_MAX_ATT, 122);
+  D->num_decoders = ndec;
+  int att_data_of[DSA_MAX_ATT];
+  bool pos_seen = false;
+  uint32_t data_seen = 0;
+  for (uint32_t i = 0; i < ndec; ++i) {           // MeshEdgeBreakerDecoder.cs:640-708
+    int att_data_id = (int8_t)r.u8();
+    uint32_t element_type = r.u8();
+    uint32_t traversal_method = r.u8();
+    REQUIRE(r.ok && traversal_method < 2, 123);
+    if (att_data_id >= 0) {
+      REQUIRE((uint32_t)att_data_id < nad && !((data_seen >> att_data_id) & 1), 124);
+      data_seen |= 1u << att_data_id;
+    } else {
+      REQUIRE(!pos_seen, 125);
+      pos_seen = true;
+    }
+    if (element_type != 0) { REQUIRE(att_data_id >= 0 && traversal_method == 0, 126); NOTIMPL(127); }   // corner attributes (seams)
+    if (traversal_method != 0) NOTIMPL(128);                                                        // prediction-degree traversal
+    att_data_of[i] = att_data_id;
+  }
+  (void)att_data_of;
+  uint32_t natt = 0;
+  uint32_t first_att[DSA_MAX_ATT + 1];
+  for (uint32_t i = 0; i < ndec; ++i) {           // AttributesDecoder.cs:19-63 + controller :16-27
+    first_att[i] = natt;
+    uint64_t k = r.varint();
+    REQUIRE(r.ok && natt + k <= DSA_MAX_ATT && natt + k <= L.cap_attributes, 129);
+    for (uint32_t j = 0; j < (uint32_t)k; ++j) {
+      AttrDesc &a = D->att[natt + j];
+      a.att_type = (uint8_t)r.u8(); a.data_type = (uint8_t)r.u8(); a.nc = (uint8_t)r.u8(); a.normalized = r.u8() != 0;
+      REQUIRE(r.ok && a.att_type < 5 && a.data_type != 0 && a.data_type < 12 && a.nc != 0, 130);
+      a.unique_id = (uint32_t)r.varint();
+      a.decoder_id = (int8_t)i;
+    }
+    for (uint32_t j = 0; j < (uint32_t)k; ++j) {
+      AttrDesc &a = D->att[natt + j];
+      a.seq_type = (uint8_t)r.u8();
+      REQUIRE(r.ok && a.seq_type <= 3, 131);
+      if (a.seq_type == 2) REQUIRE(a.data_type == 9 && a.nc <= 4, 132);
+      if (a.seq_type == 3) REQUIRE(a.data_type == 9 && a.nc == 3, 133);
+      if (a.seq_type == 1) { uint32_t w = data_type_length(a.data_type); REQUIRE(w == 1 || w == 2 || w == 4, 134); }
+    }
+    natt += (uint32_t)k;
+  }
+  first_att[ndec] = natt;
+  D->num_attributes = natt;
+  // every vertex attribute of a valid stream carries one entry per encoded vertex
+  uint32_t num_entries = D->num_enc_vertices;
+  for (uint32_t i = 0; i < ndec; ++i) {           // AttributesDecoder.cs:65-70
+    for (uint32_t ai = first_att[i]; ai < first_att[i + 1]; ++ai) {
+      if (!locate_attribute_values(r, D, D->att[ai], L, (int)ai, arena, s_cum, num_entries)) return;
+    }
+    for (uint32_t ai = first_att[i]; ai < first_att[i + 1]; ++ai) {
+      AttrDesc &a = D->att[ai];
+      if (a.seq_type == 2) {                      // AttributeQuantizationTransform.cs:110-121
+        for (uint32_t c = 0; c < a.nc; ++c) a.q_min[c] = r.f32();
+        a.q_range = r.f32();
+        a.q_bits = (uint8_t)r.u8();
+        REQUIRE(r.ok && a.q_bits >= 1 && a.q_bits <= 30, 135);
+      } else if (a.seq_type == 3) {               // AttributeOctahedronTransform.cs:39-42 (D-5)
+        a.q_bits = (uint8_t)r.u8();
+        REQUIRE(r.ok && a.q_bits >= 2 && a.q_bits <= 30, 136);
+      }
+    }
+  }
+  D->end_pos = r.pos;
+}
+
+// =========================================================================
+// k_connectivity: standard Edgebreaker stack machine, one wave per mesh.
+// =========================================================================
+struct SymbolBits {   // LSB-first reader over the traversal symbol section
+  const uint8_t *p;
+  uint32_t n;
+  uint64_t bit;
+  __device__ uint32_t get(uint32_t count) {
+    uint32_t v = read_bits(p, n, bit, count);
+    bit += count;
+    return v;
+  }
+};
+
+__global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  uint32_t mesh = blockIdx.x;
+  if (mesh >= n) return;
+  const MeshLayout &L = layouts[mesh];
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK) return;
+  const uint8_t *s = arena + L.stream;
+  uint32_t *opp = (uint32_t *)(arena + L.opp), *c2v = (uint32_t *)(arena + L.c2v);
+  uint32_t *vcorner = (uint32_t *)(arena + L.vcorner);
+  uint8_t *vhole = arena + L.vhole;
+  uint32_t *stack = (uint32_t *)(arena + L.v2d);          // active-corner stack (<= #E <= cap_vertices/3)
+  uint32_t *invalid_list = (uint32_t *)(arena + L.d2c);   // merged-away vertices (<= num_split_symbols)
+  uint32_t *events = (uint32_t *)(arena + L.splits);      // (source, split | edge<<31) per topology split event
+  uint32_t *pairs = events + 2 * (size_t)L.cap_splits;    // topologySplitActiveCorners: (decoder symbol id, corner)
+  const uint32_t F = D->num_faces, VMAX = L.cap_vertices;
+  const uint32_t num_symbols = D->num_symbols;
+  const bool remove_invalid = D->num_att_data == 0;
+
+  if (threadIdx.x == 0) {
+    // topology split events, MeshEdgeBreakerDecoder.cs:164-193
+    const uint32_t nsplits = D->num_splits;
+    {
+      Rd r(s, L.stream_len, D->off_splits);
+      uint32_t last = 0;
+      for (uint32_t i = 0; i < nsplits; ++i) {
+        uint32_t source = (uint32_t)r.varint() + last;
+        uint32_t delta = (uint32_t)r.varint();
+        REQUIRE(r.ok && delta <= source, 200);
+        uint32_t edge = read_bits(s + D->off_split_bits, L.stream_len - D->off_split_bits, i, 1);
+        events[2 * i] = source;
+        events[2 * i + 1] = ((source - delta) & 0x7FFFFFFFu) | (edge << 31);
+        last = source;
+      }
+    }
+    uint32_t splits_left = nsplits;     // consumed from the back (IsTopologySplit, :450-471)
+    uint32_t active_n = 0;
+    SymbolBits sb{s + D->off_symbols, D->size_symbols, 0};
+    Rabs start_faces;
+    uint32_t endp;
+    start_faces.start(s, L.stream_len, D->off_start_faces, &endp);
+    REQUIRE(start_faces.ok, 201);
+
+    uint32_t sp = 0, num_faces = 0, num_verts = 0, num_invalid = 0;
+    for (uint32_t sid = 0; sid < num_symbols; ++sid) {
+      uint32_t face = num_faces++;
+      uint32_t corner = 3 * face;
+      uint32_t sym = sb.get(1);
+      if (sym) sym |= sb.get(2) << 1;
+      bool check_split = false;
+      opp[corner] = DSA_INVALID; opp[corner + 1] = DSA_INVALID; opp[corner + 2] = DSA_INVALID;
+      if (sym == 0) {              // C, :247-267
+        REQUIRE(sp > 0, 210);
+        uint32_t ca = stack[sp - 1];
+        uint32_t vx = c2v[cnext(ca)];
+        REQUIRE(vx < num_verts, 211);
+        uint32_t lm = vcorner[vx];
+        REQUIRE(lm != DSA_INVALID, 212);
+        uint32_t cb = cnext(lm);
+        REQUIRE(ca != cb && opp[ca] == DSA_INVALID && opp[cb] == DSA_INVALID, 213);
+        opp[ca] = corner + 1; opp[corner + 1] = ca;
+        opp[cb] = corner + 2; opp[corner + 2] = cb;
+        uint32_t va_prev = c2v[cprev(ca)], vb_next = c2v[cnext(cb)];
+        REQUIRE(vx != va_prev && vx != vb_next, 214);
+        c2v[corner] = vx; c2v[corner + 1] = vb_next; c2v[corner + 2] = va_prev;
+        vcorner[va_prev] = corner + 2;
+        vhole[vx] = 0;
+        stack[sp - 1] = corner;
+      } else if (sym == 5 || sym == 3) {   // R / L, :268-299
+        REQUIRE(sp > 0, 220);
+        uint32_t ca = stack[sp - 1];
+        REQUIRE(opp[ca] == DSA_INVALID, 221);
+        uint32_t oc, cl, cr;
+        if (sym == 5) { oc = corner + 2; cl = corner + 1; cr = corner; }
+        else { oc = corner + 1; cl = corner; cr = corner + 2; }
+        opp[oc] = ca; opp[ca] = oc;
+        REQUIRE(num_verts < VMAX, 222);
+        uint32_t nv = num_verts++;
+        vhole[nv] = 1;
+        c2v[oc] = nv;
+        vcorner[nv] = oc;
+        uint32_t vr = c2v[cprev(ca)];
+        c2v[cr] = vr;
+        vcorner[vr] = cr;
+        c2v[cl] = c2v[cnext(ca)];
+        stack[sp - 1] = corner;
+        check_split = true;
+      } else if (sym == 1) {       // S, :300-343
+        REQUIRE(sp > 0, 230);
+        uint32_t cb = stack[--sp];
+        for (uint32_t k = 0; k < active_n; ++k)          // topologySplitActiveCorners lookup (:305)
+          if (pairs[2 * k] == sid) { REQUIRE(sp < VMAX, 231); stack[sp++] = pairs[2 * k + 1]; break; }
+        REQUIRE(sp > 0, 232);
+        uint32_t ca = stack[sp - 1];
+        REQUIRE(ca != cb && opp[ca] == DSA_INVALID && opp[cb] == DSA_INVALID, 233);
+        opp[ca] = corner + 2; opp[corner + 2] = ca;
+        opp[cb] = corner + 1; opp[corner + 1] = cb;
+        uint32_t vp = c2v[cprev(ca)];
+        c2v[corner] = vp;
+        c2v[corner + 1] = c2v[cnext(ca)];
+        uint32_t vb_prev = c2v[cprev(cb)];
+        c2v[corner + 2] = vb_prev;
+        vcorner[vb_prev] = corner + 2;
+        uint32_t cn = cnext(cb);
+        uint32_t vn = c2v[cn];
+        REQUIRE(vn < num_verts && vp < num_verts, 234);
+        vcorner[vp] = vcorner[vn];
+        uint32_t first = cn, guard = 0;
+        while (cn != DSA_INVALID) {
+          c2v[cn] = vp;
+          uint32_t o = opp[cnext(cn)];          // SwingLeft
+          cn = o == DSA_INVALID ? DSA_INVALID : cnext(o);
+          REQUIRE(cn != first && ++guard <= 3 * F, 235);
+        }
+        vcorner[vn] = DSA_INVALID;
+        if (remove_invalid) { REQUIRE(num_invalid < VMAX, 236); invalid_list[num_invalid++] = vn; }
+        stack[sp - 1] = corner;
+      } else if (sym == 7) {       // E, :344-357
+        REQUIRE(num_verts + 3 <= VMAX, 240);
+        uint32_t v0 = num_verts;
+        num_verts += 3;
+        for (uint32_t k = 0; k < 3; ++k) { c2v[corner + k] = v0 + k; vcorner[v0 + k] = corner + k; vhole[v0 + k] = 1; }
+        REQUIRE(sp < VMAX, 241);
+        stack[sp++] = corner;
+        check_split = true;
+      } else {
+        REQUIRE(false, 242);
+      }
+      if (check_split) {           // :363-375
+        uint32_t enc_id = num_symbols - sid - 1;
+        while (splits_left > 0) {
+          uint32_t source = events[2 * (splits_left - 1)];
+          uint32_t packed = events[2 * (splits_left - 1) + 1];
+          REQUIRE(source <= enc_id, 243);            // encoderSplitSymbolId < 0 in the reference
+          if (source != enc_id) break;
+          --splits_left;
+          uint32_t edge = packed >> 31, enc_split = packed & 0x7FFFFFFFu;
+          REQUIRE(enc_split < num_symbols, 244);
+          uint32_t top = stack[sp - 1];
+          uint32_t nc = edge == 1 ? cnext(top) : cprev(top);   // 1 = RightFaceEdge (Constants.cs:56-60)
+          uint32_t key = num_symbols - enc_split - 1;
+          uint32_t k = 0;
+          for (; k < active_n; ++k) if (pairs[2 * k] == key) break;   // dictionary semantics: overwrite
+          REQUIRE(k < L.cap_splits, 245);
+          pairs[2 * k] = key; pairs[2 * k + 1] = nc;
+          if (k == active_n) ++active_n;
+        }
+      }
+    }
+    REQUIRE(num_verts <= VMAX, 250);
+    // start faces, :378-415
+    while (sp > 0) {
+      uint32_t corner = stack[--sp];
+      bool interior = start_faces.next() != 0;
+      if (interior) {
+        REQUIRE(num_faces < F, 251);
+        uint32_t ca = corner;
+        uint32_t vn = c2v[cnext(ca)];
+        REQUIRE(vn < num_verts && vcorner[vn] != DSA_INVALID, 252);
+        uint32_t cb = cnext(vcorner[vn]);
+        uint32_t vx = c2v[cnext(cb)];
+        REQUIRE(vx < num_verts && vcorner[vx] != DSA_INVALID, 253);
+        uint32_t cc = cnext(vcorner[vx]);
+        REQUIRE(ca != cb && ca != cc && cb != cc, 254);
+        REQUIRE(opp[ca] == DSA_INVALID && opp[cb] == DSA_INVALID && opp[cc] == DSA_INVALID, 255);
+        uint32_t vp = c2v[cnext(cc)];
+        REQUIRE(vp < num_verts, 262);
+        uint32_t face = num_faces++;
+        uint32_t nc = 3 * face;
+        opp[nc] = ca; opp[ca] = nc; opp[nc + 1] = cb; opp[cb] = nc + 1; opp[nc + 2] = cc; opp[cc] = nc + 2;
+        c2v[nc] = vx; c2v[nc + 1] = vp; c2v[nc + 2] = vn;
+        vhole[vx] = 0; vhole[vp] = 0; vhole[vn] = 0;
+      }
+    }
+    REQUIRE(num_faces == F, 256);
+    // isolated-vertex compaction, :417-441
+    uint32_t nvert = num_verts;
+    for (uint32_t k = 0; k < num_invalid; ++k) {
+      uint32_t inv = invalid_list[k];
+      REQUIRE(nvert > 0, 257);
+      uint32_t src = nvert - 1;
+      while (vcorner[src] == DSA_INVALID) { REQUIRE(nvert > 1, 258); src = --nvert - 1; }
+      if (src < inv) continue;
+      uint32_t start = vcorner[src], c = start, guard = 0;
+      bool left = true;
+      while (c != DSA_INVALID) {   // VertexCornersIterator (D-10: starts at the left-most corner itself)
+        REQUIRE(c2v[c] == src && ++guard <= 3 * F, 259);
+        c2v[c] = inv;
+        if (left) {
+          uint32_t o = opp[cnext(c)];
+          c = o == DSA_INVALID ? DSA_INVALID : cnext(o);
+          if (c == DSA_INVALID) { uint32_t o2 = opp[cprev(start)]; c = o2 == DSA_INVALID ? DSA_INVALID : cprev(o2); left = false; }
+          else if (c == start) c = DSA_INVALID;
+        } else {
+          uint32_t o = opp[cprev(c)];
+          c = o == DSA_INVALID ? DSA_INVALID : cprev(o);
+        }
+      }
+      vcorner[inv] = vcorner[src];
+      vcorner[src] = DSA_INVALID;
+      vhole[inv] = vhole[src];
+      vhole[src] = 0;
+      nvert--;
+    }
+    D->num_vertices = remove_invalid ? nvert : num_verts;
+    __threadfence_block();
+  }
+  __syncthreads();
+  if (status_of(D) != ST_OK) return;
+  const uint32_t NV = __hip_atomic_load(&D->num_vertices, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  // ---- attribute seams (MeshEdgeBreakerDecoder.cs:502-535): lane i decodes the rABS
+  // stream of attribute data i.  Only seam-free attribute connectivity is handled on
+  // the device; any set bit is reported as not implemented.
+  const uint32_t nad = D->num_att_data;
+  const uint32_t lane = lane_id();
+  if (nad > 0) {
+    uint32_t interior_corners = 0;   // one seam bit per interior edge and attribute data
+    for (uint32_t c = lane; c < 3 * F; c += WAVE) interior_corners += (opp[c] != DSA_INVALID) ? 1u : 0u;
+    for (int d = 32; d >= 1; d >>= 1) interior_corners += __shfl_xor(interior_corners, d, 64);
+    uint32_t edges = interior_corners / 2;
+    uint32_t any = 0;
+    if (lane < nad) {
+      Rabs rb;
+      uint32_t endp;
+      rb.start(s, L.stream_len, D->off_seams[lane], &endp);
+      if (!rb.ok) any = 2;
+      else for (uint32_t i = 0; i < edges; ++i) any |= rb.next();
+    }
+    uint64_t bad = __ballot(any == 2), seam = __ballot(any == 1);
+    if (bad) { if (lane == 0) fail(D, ST_INVALID, 260); return; }
+    if (seam) { if (lane == 0) fail(D, ST_NOTIMPL, 261); return; }
+  }
+
+  // ---- vertex -> point id (AssignPointsToCorners, :537-638, seam-free case):
+  // single connectivity: point == vertex; per-attribute connectivity: rank among vertices that own a corner.
+  uint32_t *vrank = (uint32_t *)(arena + L.vrank);
+  if (nad == 0) {
+    for (uint32_t v = lane; v < NV; v += WAVE) vrank[v] = v;
+    if (lane == 0) D->num_points = NV;
+  } else {
+    uint32_t base = 0;
+    for (uint32_t v0 = 0; v0 < NV; v0 += WAVE) {
+      uint32_t v = v0 + lane;
+      uint32_t has = (v < NV && vcorner[v] != DSA_INVALID) ? 1u : 0u;
+      uint64_t m = __ballot(has);
+      uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (v < NV) vrank[v] = base + before;
+      base += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) D->num_points = base;
+  }
+}
+
+// =========================================================================
+// k_traverse: depth-first attribute sequencing on the position corner table,
+// then (lane-parallel) the parallelogram operands of every entry.
+// =========================================================================
+__global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  uint32_t mesh = blockIdx.x;
+  if (mesh >= n) return;
+  const MeshLayout &L = layouts[mesh];
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK) return;
+  const uint32_t *opp = (const uint32_t *)(arena + L.opp), *c2v = (const uint32_t *)(arena + L.c2v);
+  const uint32_t *vcorner = (const uint32_t *)(arena + L.vcorner);
+  uint32_t *d2c = (uint32_t *)(arena + L.d2c);
+  int32_t *v2d = (int32_t *)(arena + L.v2d);
+  uint8_t *fvis = arena + L.fvis, *vvis = arena + L.vvis;
+  const uint32_t F = D->num_faces, NV = D->num_vertices;
+  uint32_t *stack = (uint32_t *)(arena + L.faces);   // DFS stack: the faces output is only written by k_finalize
+  const uint32_t stack_cap = 3 * F;
+
+  for (uint32_t i = lane_id(); i < F; i += WAVE) fvis[i] = 0;
+  for (uint32_t i = lane_id(); i < L.cap_vertices; i += WAVE) { vvis[i] = 0; v2d[i] = -1; }
+  __syncthreads();
+
+  if (threadIdx.x == 0) {
+    uint32_t count = 0;
+#define VISIT(v, c) do { vvis[v] = 1; d2c[count] = (c); v2d[v] = (int32_t)count; ++count; } while (0)
+    for (uint32_t f0 = 0; f0 < F; ++f0) {
+      if (fvis[f0]) continue;
+      uint32_t corner = 3 * f0;
+      uint32_t sp = 0;
+      stack[sp++] = corner;
+      uint32_t nv = c2v[cnext(corner)], pv = c2v[cprev(corner)];
+      REQUIRE(nv < NV && pv < NV, 300);
+      if (!vvis[nv]) VISIT(nv, cnext(corner));
+      if (!vvis[pv]) VISIT(pv, cprev(corner));
+      while (sp > 0) {
+        corner = stack[sp - 1];
+        if (corner == DSA_INVALID || fvis[corner / 3]) { --sp; continue; }
+        uint32_t face = corner / 3;
+        for (;;) {
+          fvis[face] = 1;
+          uint32_t v = c2v[corner];
+          REQUIRE(v < NV, 301);
+          uint32_t rc = opp[cnext(corner)], lc = opp[cprev(corner)];
+          if (!vvis[v]) {
+            // IsOnBoundary: SwingLeft(LeftMostCorner(v)) == invalid (CornerTable.cs:174-178)
+            uint32_t lm = vcorner[v];
+            bool on_boundary = opp[cnext(lm)] == DSA_INVALID;
+            REQUIRE(count < L.cap_vertices, 302);
+            VISIT(v, corner);
+            if (!on_boundary) { corner = rc; REQUIRE(corner != DSA_INVALID, 303); face = corner / 3; continue; }
+          }
+          bool rdone = rc == DSA_INVALID || fvis[rc / 3];
+          bool ldone = lc == DSA_INVALID || fvis[lc / 3];
+          if (rdone) {
+            if (ldone) { --sp; break; }
+            corner = lc; face = lc / 3;
+          } else {
+            if (ldone) { corner = rc; face = rc / 3; }
+            else { REQUIRE(sp < stack_cap, 304); stack[sp - 1] = lc; stack[sp++] = rc; break; }
+          }
+        }
+      }
+    }
+#undef VISIT
+    D->num_entries = count;
+    // a valid stream carries exactly one entry per encoded vertex (k_locate sized the symbol streams on that)
+    REQUIRE(count == D->num_enc_vertices, 305);
+  }
+}
+
+// Parallelogram operands per entry (MeshPredictionSchemeParallelogramDecoder.cs:56-89):
+// para[3p..3p+2] = entries (next, prev, opposite) or next = INVALID when the entry falls back to delta.
+__global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n) {
+  uint32_t mesh = blockIdx.y;
+  if (mesh >= n) return;
+  const MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK) return;
+  const MeshLayout &L = layouts[mesh];
+  const uint32_t *opp = (const uint32_t *)(arena + L.opp), *c2v = (const uint32_t *)(arena + L.c2v);
+  const uint32_t *d2c = (const uint32_t *)(arena + L.d2c);
+  const int32_t *v2d = (const int32_t *)(arena + L.v2d);
+  uint32_t *para = (uint32_t *)(arena + L.para);
+  uint32_t entries = D->num_entries;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < entries; p += gridDim.x * blockDim.x) {
+    uint32_t en = DSA_INVALID, ep = 0, eo = 0;
+    if (p > 0) {
+      uint32_t oci = opp[d2c[p]];
+      if (oci != DSA_INVALID) {
+        int32_t vo = v2d[c2v[oci]], vn = v2d[c2v[cnext(oci)]], vp = v2d[c2v[cprev(oci)]];
+        if (vo >= 0 && vn >= 0 && vp >= 0 && (uint32_t)vo < p && (uint32_t)vn < p && (uint32_t)vp < p) { en = (uint32_t)vn; ep = (uint32_t)vp; eo = (uint32_t)vo; }
+      }
+    }
+    para[3 * p] = en; para[3 * p + 1] = ep; para[3 * p + 2] = eo;
+  }
+}
+
+// =========================================================================
+// k_symbols: one wave per (mesh, attribute) value stream -> int32 corrections.
+// =========================================================================
+#define SYM_MAX_LDS 4032   // 63 blocks of 64 cumulative entries
+
+// Wave-uniform rANS symbol decode (Entropy/RAnsDecoder.cs:56-99).  The state and the
+// stream offset are wave-uniform; the cumulative-frequency table is spread over the
+// lanes (first 64 boundaries in a register, the rest in LDS) and a symbol is found with
+// one or two ballot+popcount steps instead of the reference's 2^precision-entry LUT.
+__device__ void rans_decode_wave(MeshDesc *D, const uint8_t *stream, uint32_t stream_len, const AttrDesc &a, uint32_t num_values,
+                                 uint32_t *out, uint32_t *lds_cum) {
+  const uint32_t lane = lane_id();
+  const uint32_t nsym = a.num_symbols;
+  const uint32_t P = a.precision_bits, precision = 1u << P, l_base = precision * 4;
+  // 1. probability table -> LDS (lane 0), then cumulative in place
+  if (lane == 0) {
+    Rd r(stream, stream_len, a.off_table);
+    if (!read_prob_table(r, nsym, lds_cum)) fail(D, ST_INVALID, 400);
+  }
+  __syncthreads();
+  if (status_of(D) != ST_OK) return;
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 < nsym; b0 += WAVE) {
+    uint32_t i = b0 + lane;
+    uint32_t pr = i < nsym ? lds_cum[i] : 0u;
+    uint32_t tot;
+    uint32_t ex = wave_excl_scan(pr, &tot);
+    if (i < nsym) lds_cum[i] = carry + ex;
+    carry += tot;
+  }
+  if (carry != precision) { if (lane == 0) fail(D, ST_INVALID, 401); return; }
+  const uint32_t nblocks = (nsym + WAVE - 1) / WAVE;
+  for (uint32_t i = nsym + lane; i < nblocks * WAVE + 1; i += WAVE) lds_cum[i] = precision;   // padding compares false, last next == precision
+  __syncthreads();
+  // coarse boundaries: lane l holds cum[64*l]
+  uint32_t coarse = (lane < nblocks) ? lds_cum[lane * WAVE] : precision;
+  uint32_t fine0 = lds_cum[lane];   // block 0, used when the alphabet fits one block
+  // 2. initial state from the stream tail
+  const uint8_t *buf = stream + a.off_rans;
+  uint32_t x, off;
+  {
+    uint32_t st = 0, o = 0;
+    bool ok = rans_init(buf, a.size_rans, l_base, &st, &o);
+    if (!ok) { if (lane == 0) fail(D, ST_INVALID, 402); return; }
+    x = uni(st); off = uni(o);
+  }
+  // 3. byte window: lane l holds the dword at aligned byte (chunk*256 + 4l) of the arena-relative stream
+  const uintptr_t base_addr = (uintptr_t)buf;
+  const uint32_t mis = (uint32_t)(base_addr & 3u);            // buf = aligned + mis
+  const uint32_t *abuf = (const uint32_t *)(base_addr - mis);
+  uint32_t chunk = 0xFFFFFFFFu, W = 0;
+  const uint32_t mask = precision - 1;
+  uint32_t mine = 0;
+  for (uint32_t i = 0; i < num_values; ++i) {
+    while (x < l_base && off > 0) {
+      --off;
+      uint32_t q = off + mis;                                  // byte index from abuf
+      uint32_t ch = q >> 8;
+      if (ch != chunk) { chunk = ch; W = abuf[(size_t)ch * 64 + lane]; }   // arena padding makes the over-read safe
+      uint32_t byte = (rdlane(W, (q & 255u) >> 2) >> ((q & 3u) * 8)) & 0xFFu;
+      x = (x << 8) | byte;
+    }
+    uint32_t rem = x & mask;
+    uint32_t s, cs, nx;
+    if (nblocks == 1) {
+      uint32_t j = (uint32_t)__popcll(__ballot(fine0 <= rem)) - 1u;
+      cs = rdlane(fine0, j);
+      nx = (j < 63) ? rdlane(fine0, j + 1) : precision;
+      s = j;
+    } else {
+      uint32_t b = (uint32_t)__popcll(__ballot(coarse <= rem)) - 1u;
+      uint32_t v = lds_cum[b * WAVE + lane];
+      uint32_t j = (uint32_t)__popcll(__ballot(v <= rem)) - 1u;
+      cs = rdlane(v, j);
+      nx = (j < 63) ? rdlane(v, j + 1) : rdlane(coarse, b + 1);
+      s = b * WAVE + j;
+    }
+    x = (nx - cs) * (x >> P) + rem - cs;
+    if ((i & 63u) == lane) mine = s;
+    if ((i & 63u) == 63u) out[i - 63u + lane] = mine;
+  }
+  uint32_t tail = num_values & 63u;
+  if (tail && lane < tail) out[num_values - tail + lane] = mine;
+}
+
+// Generic (large alphabet) fallback: cumulative table in global scratch, lane 0, binary search.
+__device__ void rans_decode_serial(MeshDesc *D, const uint8_t *stream, uint32_t stream_len, const AttrDesc &a, uint32_t num_values,
+                                   uint32_t *out, uint32_t *cum /* nsym+1 entries of global scratch */) {
+  if (threadIdx.x != 0) return;
+  const uint32_t nsym = a.num_symbols, P = a.precision_bits, precision = 1u << P, l_base = precision * 4;
+  Rd r(stream, stream_len, a.off_table);
+  if (!read_prob_table(r, nsym, cum)) { fail(D, ST_INVALID, 410); return; }
+  uint32_t c = 0;
+  for (uint32_t i = 0; i < nsym; ++i) { uint32_t pr = cum[i]; cum[i] = c; c += pr; if (c > precision) break; }
+  if (c != precision) { fail(D, ST_INVALID, 411); return; }
+  cum[nsym] = precision;
+  const uint8_t *buf = stream + a.off_rans;
+  uint32_t x, off;
+  if (!rans_init(buf, a.size_rans, l_base, &x, &off)) { fail(D, ST_INVALID, 412); return; }
+  for (uint32_t i = 0; i < num_values; ++i) {
+    while (x < l_base && off > 0) x = (x << 8) | buf[--off];
+    uint32_t rem = x & (precision - 1);
+    uint32_t lo = 0, hi = nsym;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= rem) lo = mid; else hi = mid; }
+    // zero-probability symbols share cum with their successor: the search lands on the last index with cum <= rem,
+    // which is the (unique) symbol whose range contains rem.
+    uint32_t cs = cum[lo];
+    x = (cum[lo + 1] - cs) * (x >> P) + rem - cs;
+    out[i] = lo;
+  }
+}
+
+__global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  __shared__ uint32_t lds_cum[SYM_MAX_LDS + WAVE + 1];
+  uint32_t mesh = blockIdx.x, ai = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || ai >= D->num_attributes) return;
+  const MeshLayout &L = layouts[mesh];
+  const AttrDesc &a = D->att[ai];
+  if (a.source == SRC_BYTES) return;
+  const uint8_t *s = arena + L.stream;
+  uint32_t *work = (uint32_t *)(arena + L.work[ai]);
+  const uint32_t lane = lane_id();
+  const uint32_t nc = a.nc_portable;
+  const uint32_t num_values = a.num_entries * nc;
+  if (num_values == 0) return;
+  if (a.source == SRC_RAW) {
+    if (a.num_symbols <= SYM_MAX_LDS) rans_decode_wave(D, s, L.stream_len, a, num_values, work, lds_cum);
+    else {
+      // scratch for the table: the attribute's output buffer (free until k_finalize)
+      if ((uint64_t)(a.num_symbols + 1) * 4 > L.out_cap[ai]) { if (lane == 0) fail(D, ST_NOTIMPL, 420); return; }
+      rans_decode_serial(D, s, L.stream_len, a, num_values, work, (uint32_t *)(arena + L.out[ai]));
+    }
+  } else if (a.source == SRC_TAGGED) {
+    // SymbolDecoding.cs:38-47: entry e owns nc fields of tags[e] bits, packed LSB-first in entry order
+    const uint8_t *tags = arena + L.out[ai];
+    const uint8_t *bits = s + a.off_bits;
+    const uint32_t nbytes = L.stream_len - a.off_bits;
+    uint64_t base_bits = 0;
+    for (uint32_t e0 = 0; e0 < a.num_entries; e0 += WAVE) {
+      uint32_t e = e0 + lane;
+      uint32_t t = e < a.num_entries ? tags[e] : 0u;
+      uint32_t tot;
+      uint32_t ex = wave_excl_scan(t * nc, &tot);
+      if (e < a.num_entries) {
+        uint64_t bp = base_bits + ex;
+        for (uint32_t c = 0; c < nc; ++c) { work[e * nc + c] = t ? read_bits(bits, nbytes, bp, t) : 0u; bp += t; }
+      }
+      base_bits += tot;
+    }
+  } else {   // SRC_FIXED
+    const uint8_t *raw = s + a.off_raw;
+    for (uint32_t i = lane; i < num_values; i += WAVE) {
+      uint32_t v = 0;
+      for (uint32_t k = 0; k < a.fixed_bytes; ++k) v |= (uint32_t)raw[(size_t)i * a.fixed_bytes + k] << (8 * k);
+      work[i] = v;
+    }
+  }
+  __syncthreads();
+  if (status_of(D) != ST_OK) return;
+  // zig-zag unless the transform's corrections are positive (D-4); BitUtilities.cs:94-103
+  bool positive = a.have_scheme && (a.pred_transform == 2 || a.pred_transform == 3);
+  if (!positive)
+    for (uint32_t i = lane; i < num_values; i += WAVE) {
+      uint32_t v = work[i];
+      work[i] = (v & 1u) ? (uint32_t)(-(int32_t)(v >> 1) - 1) : (v >> 1);
+    }
+}
+
+// =========================================================================
+// k_predict: inverse prediction, in place on the work buffer.
+// =========================================================================
+struct OctParams { int32_t max_q, center; };
+
+__device__ __forceinline__ void oct_invert_diamond(int32_t center, int32_t &s, int32_t &t) {   // OctahedronToolBox.cs:152-196
+  int32_t ss, st;
+  if (s >= 0 && t >= 0) { ss = 1; st = 1; }
+  else if (s <= 0 && t <= 0) { ss = -1; st = -1; }
+  else { ss = s > 0 ? 1 : -1; st = t > 0 ? 1 : -1; }
+  int32_t cs = ss * center, ct = st * center;
+  int32_t us = s + s - cs, ut = t + t - ct, tmp = us;
+  if (ss * st >= 0) { us = -ut; ut = -tmp; } else { us = ut; ut = tmp; }
+  us += cs; ut += ct;
+  s = us / 2; t = ut / 2;
+}
+__device__ __forceinline__ int32_t oct_mod_max(const OctParams &o, int32_t x) {   // OctahedronToolBox.cs:206-213
+  if (x > o.center) return x - o.max_q;
+  return x < -o.center ? x + o.max_q : x;
+}
+__device__ __forceinline__ void oct_rotate(int32_t &x, int32_t &y, int rot) {
+  int32_t a = x, b = y;
+  if (rot == 1) { x = b; y = -a; } else if (rot == 2) { x = -a; y = -b; } else if (rot == 3) { x = -b; y = a; }
+}
+// PredictionSchemeNormalOctahedron(Canonicalized)DecodingTransform.ComputeOriginalValue
+__device__ __forceinline__ void oct_original(const OctParams &o, bool canonical, int32_t ps, int32_t pt, int32_t c0, int32_t c1,
+                                             int32_t &os, int32_t &ot) {
+  ps -= o.center; pt -= o.center;
+  int32_t aps = ps < 0 ? -ps : ps, apt = pt < 0 ? -pt : pt;
+  bool in_d = (uint32_t)aps + (uint32_t)apt <= (uint32_t)o.center;
+  if (!in_d) oct_invert_diamond(o.center, ps, pt);
+  bool bottom_left = true;
+  int rot = 0;
+  if (canonical) {
+    bottom_left = (ps == 0 && pt == 0) || (ps < 0 && pt <= 0);
+    if (ps == 0) rot = pt == 0 ? 0 : (pt > 0 ? 3 : 1);
+    else if (ps > 0) rot = pt >= 0 ? 2 : 1;
+    else rot = pt <= 0 ? 0 : 3;
+    if (!bottom_left) oct_rotate(ps, pt, rot);
+  }
+  os = oct_mod_max(o, (int32_t)((uint32_t)ps + (uint32_t)c0));
+  ot = oct_mod_max(o, (int32_t)((uint32_t)pt + (uint32_t)c1));
+  if (canonical && !bottom_left) oct_rotate(os, ot, (4 - rot) % 4);
+  if (!in_d) oct_invert_diamond(o.center, os, ot);
+  os += o.center; ot += o.center;
+}
+__device__ __forceinline__ int32_t wrap_original(int32_t pred, int32_t corr, int32_t mn, int32_t mx, int32_t max_dif) {
+  int32_t p = pred > mx ? mx : (pred < mn ? mn : pred);       // PredictionSchemeWrapTransform.cs:67-86
+  int32_t o = (int32_t)((uint32_t)p + (uint32_t)corr);       // PredictionSchemeWrapDecodingTransform.cs:46-67
+  if (o > mx) o -= max_dif; else if (o < mn) o += max_dif;
+  return o;
+}
+
+__global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  uint32_t mesh = blockIdx.x, ai = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || ai >= D->num_attributes) return;
+  const AttrDesc &a = D->att[ai];
+  if (!a.have_scheme || a.source == SRC_BYTES) return;
+  if (threadIdx.x != 0) return;
+  const MeshLayout &L = layouts[mesh];
+  int32_t *w = (int32_t *)(arena + L.work[ai]);
+  const uint32_t nc = a.nc_portable, entries = a.num_entries;
+  if (entries == 0) return;
+  if (a.pred_transform == 1) {
+    const int32_t mn = a.wrap_min, mx = a.wrap_max, max_dif = 1 + mx - mn;
+    if (a.pred_method == 1) {
+      const uint32_t *para = (const uint32_t *)(arena + L.para);
+      for (uint32_t c = 0; c < nc; ++c) w[c] = wrap_original(0, w[c], mn, mx, max_dif);
+      for (uint32_t p = 1; p < entries; ++p) {
+        uint32_t en = para[3 * p];
+        if (en != DSA_INVALID) {
+          uint32_t ep = para[3 * p + 1], eo = para[3 * p + 2];
+          for (uint32_t c = 0; c < nc; ++c) {
+            int32_t pred = (int32_t)((uint32_t)w[en * nc + c] + (uint32_t)w[ep * nc + c] - (uint32_t)w[eo * nc + c]);
+            w[p * nc + c] = wrap_original(pred, w[p * nc + c], mn, mx, max_dif);
+          }
+        } else {
+          for (uint32_t c = 0; c < nc; ++c) w[p * nc + c] = wrap_original(w[(p - 1) * nc + c], w[p * nc + c], mn, mx, max_dif);
+        }
+      }
+    } else {   // Difference, PredictionSchemeDeltaDecoder.cs:23-37
+      int32_t prev[4] = {0, 0, 0, 0};
+      if (nc > 4) { fail(D, ST_NOTIMPL, 500); return; }
+      for (uint32_t p = 0; p < entries; ++p)
+        for (uint32_t c = 0; c < nc; ++c) { prev[c] = wrap_original(prev[c], w[p * nc + c], mn, mx, max_dif); w[p * nc + c] = prev[c]; }
+    }
+  } else {
+    // normal octahedron transforms are 2-component; only Difference reaches here (k_locate rejects the rest)
+    if (a.pred_method != 0) { fail(D, ST_NOTIMPL, 501); return; }
+    OctParams o;
+    o.max_q = a.oct_max_q;
+    int q = 32 - __clz(a.oct_max_q);
+    int32_t max_value = (1 << q) - 2;
+    o.center = max_value / 2;
+    o.max_q = (1 << q) - 1;
+    bool canonical = a.pred_transform == 3;
+    int32_t ps = 0, pt = 0;
+    for (uint32_t p = 0; p < entries; ++p) {
+      int32_t os, ot;
+      oct_original(o, canonical, ps, pt, w[2 * p], w[2 * p + 1], os, ot);
+      w[2 * p] = os; w[2 * p + 1] = ot;
+      ps = os; pt = ot;
+    }
+  }
+}
+
+// =========================================================================
+// k_finalize: portable ints -> attribute values, point->entry maps.
+// =========================================================================
+__global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n) {
+  uint32_t mesh = blockIdx.y, ai = blockIdx.z;
+  if (mesh >= n) return;
+  const MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || ai >= D->num_attributes) return;
+  const MeshLayout &L = layouts[mesh];
+  const AttrDesc &a = D->att[ai];
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  const int32_t *w = (const int32_t *)(arena + L.work[ai]);
+  const uint32_t entries = a.num_entries;
+  if (a.seq_type == 2) {            // AttributeQuantizationTransform.cs:179-199, Dequantizer.cs:15-23: two f32 roundings
+    float *out = (float *)(arena + L.out[ai]);
+    const uint32_t nc = a.nc;
+    const float delta = __fdiv_rn(a.q_range, (float)(int32_t)((1u << a.q_bits) - 1u));
+    for (uint32_t i = tid; i < entries * nc; i += stride) {
+      float prod = __fmul_rn((float)w[i], delta);
+      out[i] = __fadd_rn(prod, a.q_min[i % nc]);
+    }
+  } else if (a.seq_type == 3) {     // OctahedronToolBox.cs:139-142,220-239 (D-8 corrected)
+    float *out = (float *)(arena + L.out[ai]);
+    const int32_t max_value = (1 << a.q_bits) - 2;
+    const float scale = __fdiv_rn(2.0f, (float)max_value);
+    for (uint32_t e = tid; e < entries; e += stride) {
+      float y = __fsub_rn(__fmul_rn((float)w[2 * e], scale), 1.0f);
+      float z = __fsub_rn(__fmul_rn((float)w[2 * e + 1], scale), 1.0f);
+      float x = __fsub_rn(__fsub_rn(1.0f, fabsf(y)), fabsf(z));
+      float x_off = -x < 0.0f ? 0.0f : -x;
+      y = __fadd_rn(y, y < 0.0f ? x_off : -x_off);
+      z = __fadd_rn(z, z < 0.0f ? x_off : -x_off);
+      float norm2 = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+      float ox = 0.0f, oy = 0.0f, oz = 0.0f;
+      if ((double)norm2 >= 1e-6) {
+        double d = __ddiv_rn(1.0, __dsqrt_rn((double)norm2));
+        ox = (float)__dmul_rn((double)x, d); oy = (float)__dmul_rn((double)y, d); oz = (float)__dmul_rn((double)z, d);
+      }
+      out[3 * e] = ox; out[3 * e + 1] = oy; out[3 * e + 2] = oz;
+    }
+  } else if (a.seq_type == 1) {     // SequentialIntegerAttributeDecoder.cs:142-160: narrowing store
+    const uint32_t width = data_type_length(a.data_type), total = entries * a.nc;
+    uint8_t *out = arena + L.out[ai];
+    for (uint32_t i = tid; i < total; i += stride) {
+      int32_t v = w[i];
+      if (width == 1) out[i] = (uint8_t)v;
+      else if (width == 2) ((uint16_t *)out)[i] = (uint16_t)v;
+      else ((uint32_t *)out)[i] = (uint32_t)v;
+    }
+  } else {                          // generic: bytes as stored
+    const uint8_t *src = arena + L.stream + a.off_raw;
+    uint8_t *out = arena + L.out[ai];
+    const uint32_t total = entries * a.nc * data_type_length(a.data_type);
+    for (uint32_t i = tid; i < total; i += stride) out[i] = src[i];
+  }
+  // faces as point ids (Mesh.cs faces; MeshEdgeBreakerDecoder.cs:537-553,627-637) and the
+  // point -> entry map (MeshTraversalSequencer.cs:33-50; vertex attributes on the position corner table)
+  const uint32_t *c2v = (const uint32_t *)(arena + L.c2v);
+  const uint32_t *vrank = (const uint32_t *)(arena + L.vrank);
+  const int32_t *v2d = (const int32_t *)(arena + L.v2d);
+  int32_t *faces = (int32_t *)(arena + L.faces);
+  uint32_t *map = (uint32_t *)(arena + L.map[ai]);
+  for (uint32_t c = tid; c < 3 * D->num_faces; c += stride) {
+    uint32_t v = c2v[c];
+    uint32_t point = vrank[v];
+    if (ai == 0) faces[c] = (int32_t)point;
+    map[point] = (uint32_t)v2d[v];
+  }
+}
+
+}  // namespace dsa

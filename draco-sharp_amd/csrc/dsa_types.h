@@ -1,0 +1,98 @@
+// draco-sharp_amd/csrc/dsa_types.h
+// Structures shared by the host side of the C-ABI and the HIP kernels.
+#pragma once
+#include <stdint.h>
+
+#define DSA_MAX_ATT 8        // attributes per mesh on the device path
+#define DSA_MAX_ATT_DATA 7   // non-position connectivity data (num_attribute_data)
+#define DSA_INVALID 0xFFFFFFFFu
+
+// status codes written by kernels (== dsa_status for 0..2)
+#define ST_OK 0
+#define ST_INVALID 1
+#define ST_NOTIMPL 2
+
+// symbol source of an attribute's value section
+#define SRC_TAGGED 0   // tagged rANS scheme      (Entropy/SymbolDecoding.cs:30-50)
+#define SRC_RAW 1      // raw rANS scheme         (Entropy/SymbolDecoding.cs:52-67)
+#define SRC_FIXED 2    // uncompressed fixed-width ints (SequentialIntegerAttributeDecoder.cs:68-84)
+#define SRC_BYTES 3    // generic attribute: raw bytes  (SequentialAttributeDecoder.cs:75-86)
+
+// Per-attribute descriptor, filled by k_locate from the stream.
+struct AttrDesc {
+  uint8_t att_type, data_type, nc, normalized;
+  uint8_t seq_type;        // SequentialAttributeEncoderType 0..3
+  int8_t decoder_id;
+  int8_t pred_method;      // PredictionSchemeMethod
+  int8_t pred_transform;   // PredictionSchemeTransformType
+  uint8_t nc_portable;
+  uint8_t source;          // SRC_*
+  uint8_t fixed_bytes;     // SRC_FIXED width
+  uint8_t have_scheme;     // prediction scheme instantiated
+  uint8_t precision_bits;  // rANS precision of the symbol (raw) or tag (tagged) stream
+  uint8_t q_bits;          // quantisation bits / octahedron bits
+  uint8_t pad0, pad1;
+  uint32_t unique_id;
+  uint32_t num_symbols;    // alphabet size
+  uint32_t off_table;      // stream offset of the first probability-table byte
+  uint32_t off_rans;       // rANS payload offset / size
+  uint32_t size_rans;
+  uint32_t off_bits;       // tagged: byte offset of the value bit section
+  uint32_t off_raw;        // SRC_FIXED / SRC_BYTES payload
+  int32_t wrap_min, wrap_max;
+  int32_t oct_max_q;
+  float q_min[4];
+  float q_range;
+  uint32_t num_entries;
+};
+
+// Per-mesh descriptor, filled by k_locate / k_connectivity / k_traverse.
+struct MeshDesc {
+  int32_t status;          // ST_*
+  int32_t detail;          // site code of the first failing check
+  uint8_t major, minor, encoder_type, encoder_method;
+  uint16_t flags;
+  uint8_t traversal_type;
+  uint8_t num_att_data;
+  uint32_t num_enc_vertices, num_faces, num_symbols, num_split_symbols, num_splits;
+  uint32_t off_splits;     // first topology-split varint
+  uint32_t off_split_bits; // source-edge bit section
+  uint32_t off_symbols, size_symbols;
+  uint32_t off_start_faces;                 // rABS block (prob_zero byte first)
+  uint32_t off_seams[DSA_MAX_ATT_DATA];     // rABS blocks
+  uint32_t off_attributes;                  // num_attributes_decoders byte
+  uint32_t num_decoders, num_attributes;
+  uint32_t end_pos;
+  // results
+  uint32_t num_vertices;   // corner-table vertices incl. isolated ones
+  uint32_t num_points;
+  uint32_t num_entries;    // traversal length
+  AttrDesc att[DSA_MAX_ATT];
+};
+
+// Host-computed placement of one mesh inside the batch arena (byte offsets from
+// the arena base) and the capacities the kernels must respect.
+struct MeshLayout {
+  uint64_t stream;         // compressed bytes (16-byte aligned)
+  uint32_t stream_len;
+  uint32_t cap_faces;      // F from the header
+  uint32_t cap_vertices;   // num_encoded_vertices + num_split_symbols
+  uint32_t cap_attributes;
+  uint64_t opp, c2v;       // u32[3F]
+  uint64_t vcorner;        // u32[cap_vertices]
+  uint64_t vhole;          // u8[cap_vertices]
+  uint64_t d2c;            // u32[cap_vertices]
+  uint64_t v2d;            // i32[cap_vertices]
+  uint64_t fvis, vvis;     // u8[F], u8[cap_vertices]
+  uint64_t splits;         // u32[4*cap_splits]: events (source, split|edge<<31), then active pairs (decoder symbol id, corner)
+  uint32_t cap_splits;
+  uint32_t pad;
+  uint64_t vrank;          // u32[cap_vertices] vertex -> point id (per-attribute connectivity layout)
+  uint64_t para;           // u32[3*cap_vertices] parallelogram operand entries per entry
+  uint64_t faces;          // i32[3F] output (DFS stack scratch until k_finalize)
+  uint64_t work[DSA_MAX_ATT];   // i32[cap_vertices*nc_portable] symbols -> corrections -> portable values
+  uint64_t out[DSA_MAX_ATT];    // attribute values, final format
+  uint64_t map[DSA_MAX_ATT];    // u32[cap_vertices] point -> entry
+  uint32_t work_cap[DSA_MAX_ATT];  // capacity in int32 elements
+  uint32_t out_cap[DSA_MAX_ATT];   // capacity in bytes
+};

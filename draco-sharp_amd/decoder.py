@@ -1,0 +1,327 @@
+"""Host-side mirror of draco-sharp's decode surface over the C-ABI.
+
+Names, argument meaning and error behaviour follow the reference:
+  DracoDecoder.Decode(path | stream | bytes)      src/Draco/IO/DracoDecoder.cs:8-42
+  Draco{Header, Metadata, ConnectedData, Attributes}   src/Draco/Draco.cs:9-15
+  DracoHeader                                      src/Draco/DracoHeader.cs:5-23
+  Mesh : PointCloud                                src/Draco/IO/Mesh/Mesh.cs:15-69, IO/PointCloud/PointCloud.cs:11-133
+  PointAttribute : GeometryAttribute               src/Draco/IO/Attributes/PointAttribute.cs:5-63
+Malformed streams raise InvalidDataException, unsupported stream features
+NotImplementedException (src/Draco/IO/Extensions/Assertions.cs:5-24, DracoDecoder.cs:70).
+The C# binding of the same C-ABI is in csharp/ (it cannot be compiled in this image)."""
+import ctypes as C
+import io
+
+import numpy as np
+
+from . import native
+
+_DT_NUMPY = {1: np.int8, 2: np.uint8, 3: np.int16, 4: np.uint16, 5: np.int32, 6: np.uint32,
+             7: np.int64, 8: np.uint64, 9: np.float32, 10: np.float64, 11: np.uint8}
+
+
+class InvalidDataException(Exception):
+    """System.IO.InvalidDataException"""
+
+
+class DeviceException(RuntimeError):
+    """HIP runtime failure / missing GPU library"""
+
+
+def _raise(status, msg):
+    if status == native.DSA_ERR_INVALID_DATA:
+        raise InvalidDataException(msg)
+    if status == native.DSA_ERR_NOT_IMPLEMENTED:
+        raise NotImplementedError(msg)
+    if status == native.DSA_ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)
+    if status == native.DSA_ERR_OUT_OF_MEMORY:
+        raise MemoryError(msg)
+    raise DeviceException(msg)
+
+
+class DracoHeader:
+    def __init__(self, info):
+        self.MajorVersion = info.major_version
+        self.MinorVersion = info.minor_version
+        self.EncoderType = info.encoder_type
+        self.EncoderMethod = info.encoder_method
+        self.Flags = info.flags
+
+    @property
+    def Version(self):
+        return (self.MajorVersion << 8) | self.MinorVersion
+
+
+class DataBuffer:
+    """Core/DataBuffer.cs:5-111 -- byte store of an attribute; here a numpy view of the decoded values."""
+
+    def __init__(self, values):
+        self._values = values
+
+    @property
+    def DataSize(self):
+        return self._values.nbytes
+
+    def Read(self, dtype, byte_offset):
+        return np.frombuffer(self._values.tobytes(), dtype=dtype, count=1, offset=byte_offset)[0]
+
+    def AsArray(self):
+        return self._values
+
+
+class PointAttribute:
+    def __init__(self, info, values, point_map, portable):
+        self.AttributeType = info.attribute_type
+        self.DataType = info.data_type
+        self.NumComponents = info.num_components
+        self.Normalized = bool(info.normalized)
+        self.ByteStride = info.byte_stride
+        self.ByteOffset = 0
+        self.UniqueId = info.unique_id
+        self.UniqueEntriesCount = info.num_entries
+        self.IsMappingIdentity = False          # mesh attributes always carry an explicit map (MeshTraversalSequencer.cs:35)
+        self.DecoderType = info.decoder_type
+        self.PredictionMethod = info.prediction_method
+        self.PredictionTransform = info.prediction_transform
+        self.QuantizationBits = info.quantization_bits
+        self.Range = info.range
+        self.MinValues = list(info.min_values)[: info.num_components]
+        self.Buffer = DataBuffer(values)
+        self.Values = values                    # (entries, components) in traversal order
+        self.PointMap = point_map               # point -> entry
+        self.PortableValues = portable          # int32 (entries, portable components) or None
+
+    def MappedIndex(self, point):
+        return int(self.PointMap[point])
+
+    def GetValue(self, entry):
+        return self.Values[entry]
+
+
+class PointCloud:
+    def __init__(self, attributes, num_points):
+        self.Attributes = attributes
+        self.PointsCount = num_points
+
+    def GetNamedAttributeId(self, attribute_type, i=0):
+        ids = [k for k, a in enumerate(self.Attributes) if a.AttributeType == attribute_type]
+        return ids[i] if i < len(ids) else -1
+
+    def GetNamedAttribute(self, attribute_type, i=0):
+        k = self.GetNamedAttributeId(attribute_type, i)
+        return None if k < 0 else self.Attributes[k]
+
+    def GetAttributeById(self, k):
+        return self.Attributes[k]
+
+    def GetAttributeByUniqueId(self, uid):
+        for a in self.Attributes:
+            if a.UniqueId == uid:
+                return a
+        return None
+
+
+class Mesh(PointCloud):
+    def __init__(self, attributes, num_points, faces):
+        super().__init__(attributes, num_points)
+        self.Faces = faces                      # (F,3) int32 point ids
+
+    @property
+    def FacesCount(self):
+        return len(self.Faces)
+
+    def GetFace(self, f):
+        return [int(x) for x in self.Faces[f]]
+
+    def CornerToPointId(self, corner):
+        return int(self.Faces[corner // 3][corner % 3])
+
+
+class Draco:
+    def __init__(self, header, connected, metadata=None):
+        self.Header = header
+        self.Metadata = metadata
+        self.ConnectedData = connected
+        self.Attributes = connected.Attributes
+
+
+class Context:
+    """One GPU.  stream: optional hipStream_t handle (int) to run on."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = native.lib()
+        h = C.c_void_p()
+        st = self._L.dsa_context_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if st != 0:
+            raise DeviceException("dsa_context_create(device=%d) failed with status %d (is a GPU visible?)" % (device, st))
+        self._h = h
+        self.device = device
+
+    def error(self):
+        return self._L.dsa_last_error(self._h).decode()
+
+    def set_profiling(self, on=True):
+        self._L.dsa_context_set_profiling(self._h, 1 if on else 0)
+
+    def close(self):
+        if self._h:
+            self._L.dsa_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """A batch of independent .drc streams resident on one GPU."""
+
+    def __init__(self, ctx, streams=None, blob=None, offsets=None):
+        self.ctx = ctx
+        L = self._L = ctx._L
+        h = C.c_void_p()
+        if blob is not None:
+            blob = np.ascontiguousarray(blob, np.uint8)
+            offsets = np.ascontiguousarray(offsets, np.uint64)
+            n = len(offsets) - 1
+            st = L.dsa_batch_create_packed(ctx._h, n, blob.ctypes.data, offsets.ctypes.data, C.byref(h))
+        else:
+            n = len(streams)
+            bufs = [(C.c_uint8 * max(1, len(s))).from_buffer_copy(s if len(s) else b"\0") for s in streams]
+            ptrs = (C.c_void_p * max(1, n))(*[C.addressof(b) for b in bufs])
+            lens = (C.c_size_t * max(1, n))(*[len(s) for s in streams])
+            st = L.dsa_batch_create(ctx._h, n, ptrs, lens, C.byref(h))
+        if st != 0:
+            _raise(st, ctx.error())
+        self._h = h
+        self.n = n
+
+    def decode(self, wait=True):
+        st = self._L.dsa_batch_decode(self._h)
+        if st != 0:
+            _raise(st, self.ctx.error())
+        if wait:
+            self.wait()
+
+    def wait(self):
+        st = self._L.dsa_batch_wait(self._h)
+        if st != 0:
+            _raise(st, self.ctx.error())
+
+    @property
+    def algorithmic_bytes(self):
+        return int(self._L.dsa_batch_algorithmic_bytes(self._h))
+
+    @property
+    def arena_bytes(self):
+        return int(self._L.dsa_batch_arena_bytes(self._h))
+
+    def stage_times(self):
+        ms = (C.c_float * native.DSA_NUM_STAGES)()
+        names = (C.c_char_p * native.DSA_NUM_STAGES)()
+        self._L.dsa_batch_stage_times(self._h, C.byref(ms), C.byref(names))
+        return {names[i].decode(): float(ms[i]) for i in range(native.DSA_NUM_STAGES)}
+
+    def mesh_info(self, i):
+        info = native.MeshInfo()
+        st = self._L.dsa_batch_mesh_info(self._h, i, C.byref(info))
+        if st != 0:
+            _raise(st, self.ctx.error())
+        return info
+
+    def status(self, i):
+        return self.mesh_info(i).status
+
+    def debug_array(self, i, what, dtype, count):
+        out = np.zeros(count, dtype)
+        written = C.c_size_t()
+        st = self._L.dsa_batch_copy_debug(self._h, i, what, out.ctypes.data, out.nbytes, C.byref(written))
+        if st != 0:
+            _raise(st, self.ctx.error())
+        return out[: written.value // out.itemsize]
+
+    def result(self, i):
+        """Draco object of mesh i; raises what the reference would for a bad stream."""
+        L = self._L
+        info = self.mesh_info(i)
+        if info.status != 0:
+            _raise(info.status, "stream %d: decode failed (status %d, site %d)" % (i, info.status, info.detail))
+        faces = np.zeros((info.num_faces, 3), np.int32)
+        if info.num_faces:
+            st = L.dsa_batch_copy_faces(self._h, i, faces.ctypes.data)
+            if st != 0:
+                _raise(st, self.ctx.error())
+        atts = []
+        for a in range(info.num_attributes):
+            ai = native.AttributeInfo()
+            st = L.dsa_batch_attribute_info(self._h, i, a, C.byref(ai))
+            if st != 0:
+                _raise(st, self.ctx.error())
+            vals = np.zeros((ai.num_entries, ai.num_components), _DT_NUMPY[ai.data_type])
+            pmap = np.zeros(info.num_points, np.uint32)
+            if ai.num_entries:
+                L.dsa_batch_copy_attribute_values(self._h, i, a, vals.ctypes.data)
+            if info.num_points:
+                L.dsa_batch_copy_point_map(self._h, i, a, pmap.ctypes.data)
+            portable = None
+            if ai.decoder_type != 0:
+                ncp = 2 if ai.decoder_type == 3 else ai.num_components
+                portable = np.zeros((ai.num_entries, ncp), np.int32)
+                if ai.num_entries:
+                    L.dsa_batch_copy_portable_values(self._h, i, a, portable.ctypes.data)
+            atts.append(PointAttribute(ai, vals, pmap, portable))
+        return Draco(DracoHeader(info), Mesh(atts, info.num_points, faces))
+
+    def close(self):
+        if self._h:
+            self._L.dsa_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class DracoDecoder:
+    """DracoDecoder.Decode: one stream -> Draco (a batch of one on the default GPU)."""
+
+    def __init__(self, context=None):
+        self._ctx = context
+
+    def Decode(self, source):
+        if isinstance(source, str):
+            with open(source, "rb") as f:
+                data = f.read()
+        elif isinstance(source, (bytes, bytearray, memoryview)):
+            data = bytes(source)
+        elif isinstance(source, io.IOBase) or hasattr(source, "read"):
+            data = source.read()
+            if hasattr(source, "close"):
+                source.close()      # the reference disposes the caller's reader (DecoderBuffer.cs:186-189)
+        else:
+            raise TypeError("Decode expects a path, bytes or a binary stream")
+        return self.DecodeBatch([data])[0]
+
+    def DecodeBatch(self, streams):
+        ctx = self._ctx or default_context()
+        b = Batch(ctx, streams)
+        try:
+            b.decode()
+            return [b.result(i) for i in range(b.n)]
+        finally:
+            b.close()

@@ -5,6 +5,7 @@ directory."""
 import os as _os
 
 __path__ = [_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "draco-sharp_amd")]
+__package__ = "draco_sharp_amd"
 __file__ = _os.path.join(__path__[0], "__init__.py")
 with open(__file__) as _f:
     exec(compile(_f.read(), __file__, "exec"))

@@ -1,0 +1,144 @@
+/* include/draco_mi355x.h
+ *
+ * C-ABI of libdraco_mi355x.so: batched Draco (bitstream 2.2) mesh decode on one
+ * MI355X per context.  This is the drop-in boundary under draco-sharp's
+ *     DracoDecoder.Decode(BinaryReader)            src/Draco/IO/DracoDecoder.cs:19-42
+ * The reference has no FFI layer (everything is managed code), so these entry
+ * points are what a P/Invoke binding for that method binds instead of running
+ *     ConnectivityDecoder.DecodeConnectivity       src/Draco/IO/Mesh/MeshEdgeBreakerDecoder.cs:25-134
+ *     ConnectivityDecoder.DecodeAttributes         src/Draco/IO/ConnectivityDecoder.cs:16-44
+ * in-process.  The C# binding is in draco-sharp_amd/csharp/ and INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes, blittable structs, no callbacks into
+ * the caller, library-owned result memory with explicit release.  Every call
+ * returns a dsa_status; the per-mesh status of a batch mirrors the exception
+ * the C# would raise for that stream (InvalidDataException /
+ * NotImplementedException, src/Draco/IO/Extensions/Assertions.cs:5-24,
+ * src/Draco/IO/DracoDecoder.cs:49,70,87-97).  One bad stream never poisons the
+ * rest of the batch.
+ *
+ * Threading: a context is bound to one GPU and may be used from one host thread
+ * at a time; different contexts (one per GPU) are independent.
+ */
+#ifndef DRACO_MI355X_H_
+#define DRACO_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSA_ABI_VERSION 1
+#define DSA_MAX_ATTRIBUTES 8   /* attributes per mesh handled by the device path */
+#define DSA_NUM_STAGES 8
+
+typedef enum dsa_status {
+  DSA_OK = 0,
+  DSA_ERR_INVALID_DATA = 1,     /* -> System.IO.InvalidDataException */
+  DSA_ERR_NOT_IMPLEMENTED = 2,  /* -> System.NotImplementedException (stream feature outside the device path) */
+  DSA_ERR_INVALID_ARGUMENT = 3, /* -> System.ArgumentException */
+  DSA_ERR_DEVICE = 4,           /* HIP runtime failure; see dsa_last_error */
+  DSA_ERR_OUT_OF_MEMORY = 5
+} dsa_status;
+
+typedef struct dsa_context dsa_context;
+typedef struct dsa_batch dsa_batch;
+
+/* DracoHeader (src/Draco/DracoHeader.cs:5-23) + Mesh/PointCloud counts
+ * (src/Draco/IO/Mesh/Mesh.cs:15-69, src/Draco/IO/PointCloud/PointCloud.cs:11-133). */
+typedef struct dsa_mesh_info {
+  int32_t status;            /* dsa_status of this stream */
+  int32_t detail;            /* internal site code of the first failing check (diagnostics) */
+  uint8_t major_version, minor_version, encoder_type, encoder_method;
+  uint16_t flags;
+  uint16_t reserved;
+  uint32_t num_faces;
+  uint32_t num_points;
+  uint32_t num_attributes;
+  uint64_t drc_bytes;        /* length of the compressed stream */
+} dsa_mesh_info;
+
+/* PointAttribute / GeometryAttribute (src/Draco/IO/Attributes/PointAttribute.cs:5-63,
+ * GeometryAttribute.cs:8-67) + AttributeTransformData. */
+typedef struct dsa_attribute_info {
+  int32_t attribute_type;    /* GeometryAttributeType: 0 position, 1 normal, 2 color, 3 texcoord, 4 generic */
+  int32_t data_type;         /* DataType enum (src/Draco/IO/Enums/DataType.cs) */
+  int32_t num_components;
+  int32_t normalized;
+  uint32_t unique_id;
+  uint32_t num_entries;      /* UniqueEntriesCount: values in traversal order */
+  uint32_t byte_stride;      /* packed AoS: size(data_type) * num_components */
+  int32_t decoder_type;      /* SequentialAttributeEncoderType: 0 generic, 1 integer, 2 quantization, 3 normals */
+  int32_t prediction_method; /* PredictionSchemeMethod */
+  int32_t prediction_transform;
+  int32_t quantization_bits; /* quantization / octahedron transform parameter */
+  float range;               /* quantization transform */
+  float min_values[4];
+} dsa_attribute_info;
+
+int dsa_abi_version(void);
+int dsa_device_count(void);
+
+/* Creates a context on `device`.  `stream` is a hipStream_t to run on (NULL =
+ * the context creates its own non-blocking stream). */
+dsa_status dsa_context_create(int device, void *stream, dsa_context **out);
+void dsa_context_destroy(dsa_context *ctx);
+/* Message of the last failing call on this context (valid until the next call). */
+const char *dsa_last_error(const dsa_context *ctx);
+
+/* Builds a batch from n host-resident .drc streams: parses the fixed headers to
+ * size the device arena, allocates it and uploads the compressed bytes.  The
+ * streams are copied; the caller's buffers are not referenced afterwards. */
+dsa_status dsa_batch_create(dsa_context *ctx, uint32_t n, const uint8_t *const *streams, const size_t *lengths,
+                            dsa_batch **out);
+/* Same, for streams stored back to back in one blob: stream i is
+ * blob[offsets[i] .. offsets[i+1]). */
+dsa_status dsa_batch_create_packed(dsa_context *ctx, uint32_t n, const uint8_t *blob, const uint64_t *offsets,
+                                   dsa_batch **out);
+/* Enqueues the device-resident decode of the whole batch (compressed bytes in
+ * HBM -> faces, attribute values and point maps in HBM) on the context's
+ * stream.  Asynchronous. */
+dsa_status dsa_batch_decode(dsa_batch *batch);
+/* Waits for the decode and collects the per-mesh results. */
+dsa_status dsa_batch_wait(dsa_batch *batch);
+void dsa_batch_free(dsa_batch *batch);
+
+uint32_t dsa_batch_size(const dsa_batch *batch);
+/* Algorithmic bytes of the decoded batch: compressed
+ * bytes read + faces + attribute values + explicit point maps written. */
+uint64_t dsa_batch_algorithmic_bytes(const dsa_batch *batch);
+/* Device bytes of the batch arena (inputs + outputs + scratch). */
+uint64_t dsa_batch_arena_bytes(const dsa_batch *batch);
+
+dsa_status dsa_batch_mesh_info(const dsa_batch *batch, uint32_t mesh, dsa_mesh_info *out);
+dsa_status dsa_batch_attribute_info(const dsa_batch *batch, uint32_t mesh, uint32_t attribute, dsa_attribute_info *out);
+
+/* Copy-out (device -> caller memory). */
+dsa_status dsa_batch_copy_faces(const dsa_batch *batch, uint32_t mesh, int32_t *dst /* num_faces*3, point ids */);
+dsa_status dsa_batch_copy_attribute_values(const dsa_batch *batch, uint32_t mesh, uint32_t attribute, void *dst);
+dsa_status dsa_batch_copy_point_map(const dsa_batch *batch, uint32_t mesh, uint32_t attribute, uint32_t *dst /* num_points */);
+/* Portable (pre-transform) int32 values, for integer-exactness checks. */
+dsa_status dsa_batch_copy_portable_values(const dsa_batch *batch, uint32_t mesh, uint32_t attribute, int32_t *dst);
+
+/* Device pointers of the results, for consumers that stay on the GPU.  Valid
+ * until dsa_batch_free. */
+const int32_t *dsa_batch_device_faces(const dsa_batch *batch, uint32_t mesh);
+const void *dsa_batch_device_attribute_values(const dsa_batch *batch, uint32_t mesh, uint32_t attribute);
+const uint32_t *dsa_batch_device_point_map(const dsa_batch *batch, uint32_t mesh, uint32_t attribute);
+
+/* Diagnostics for the parity tests: intermediate products of the path.
+ * what: 0 opposite[3F], 1 corner_to_vertex[3F], 2 data_to_corner[entries], 3 vertex_to_data[vertices]. */
+dsa_status dsa_batch_copy_debug(const dsa_batch *batch, uint32_t mesh, int what, void *dst, size_t dst_bytes, size_t *written);
+
+/* Per-stage device time of the last dsa_batch_decode, in ms (HIP events on the
+ * context's stream; enabled with dsa_context_set_profiling).  names[] receives
+ * static strings. */
+dsa_status dsa_context_set_profiling(dsa_context *ctx, int enabled);
+dsa_status dsa_batch_stage_times(const dsa_batch *batch, float ms[DSA_NUM_STAGES], const char *names[DSA_NUM_STAGES]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRACO_MI355X_H_ */

@@ -1,0 +1,186 @@
+"""Parity of the HIP decode path (through the C-ABI) with the CPU oracle on the same bytes:
+connectivity, traversal order, integer attributes and point maps bit-exact; dequantised
+floats bit-equal (the north star allows 1 ulp)."""
+import numpy as np
+import pytest
+
+import oracle
+import draco_sharp_amd as dsa
+import draco_sharp_amd.synth as synth
+
+pytestmark = pytest.mark.gpu
+
+KINDS = [(synth.GRID, 9, 7), (synth.TORUS, 8, 6), (synth.SPHERE, 8, 7), (synth.HOLES, 20, 16), (synth.TWO_PARTS, 9, 6),
+         (synth.GRID, 40, 33), (synth.TORUS, 24, 40)]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = dsa.Context(0)
+    yield c
+    c.close()
+
+
+def assert_same(got, ref, batch=None, i=None):
+    """got: dsa.Draco from the GPU, ref: oracle.OracleMesh."""
+    m = got.ConnectedData
+    assert (got.Header.MajorVersion, got.Header.MinorVersion, got.Header.EncoderType, got.Header.EncoderMethod,
+            got.Header.Flags) == (ref.major, ref.minor, ref.encoder_type, ref.encoder_method, ref.flags)
+    assert m.FacesCount == ref.num_faces and m.PointsCount == ref.num_points
+    assert np.array_equal(m.Faces, ref.faces)
+    assert len(m.Attributes) == len(ref.attributes)
+    for a, r in zip(m.Attributes, ref.attributes):
+        assert (a.AttributeType, a.DataType, a.NumComponents, a.UniqueId, a.DecoderType) == \
+               (r.att_type, r.data_type, r.num_components, r.unique_id, r.seq_type)
+        assert a.UniqueEntriesCount == r.num_entries
+        assert np.array_equal(a.PointMap, r.point_map)
+        if r.portable is not None:
+            assert np.array_equal(a.PortableValues, r.portable)
+        if a.Values.dtype == np.float32:
+            assert np.array_equal(a.Values.view(np.uint32), r.values.view(np.uint32))   # bit-equal (<= 1 ulp required)
+        else:
+            assert np.array_equal(a.Values, r.values)
+    if batch is not None:
+        nf = ref.num_faces
+        assert np.array_equal(batch.debug_array(i, 0, np.uint32, 3 * nf), ref.opposite)
+        assert np.array_equal(batch.debug_array(i, 1, np.uint32, 3 * nf), ref.corner_to_vertex)
+        assert np.array_equal(batch.debug_array(i, 2, np.uint32, ref.num_vertices), ref.decoders[0]["data_to_corner"])
+
+
+def run_batch(ctx, streams):
+    b = dsa.Batch(ctx, streams)
+    b.decode()
+    return b
+
+
+@pytest.mark.parametrize("single", [0, 1])
+def test_topologies_match_oracle(ctx, single):
+    streams = []
+    for kind, nx, ny in KINDS:
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 3)
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(single_connectivity=single)))
+    b = run_batch(ctx, streams)
+    for i, s in enumerate(streams):
+        assert b.status(i) == 0, (i, b.mesh_info(i).detail)
+        assert_same(b.result(i), oracle.decode(s), b, i)
+    b.close()
+
+
+@pytest.mark.parametrize("scheme", [0, 1])
+@pytest.mark.parametrize("pred", [0, 1])
+def test_symbol_schemes_and_predictions(ctx, scheme, pred):
+    streams = []
+    for seed in range(4):
+        pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 14 + seed, 12, 10 + seed)
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(force_scheme=scheme, pos_prediction=pred,
+                                                                                uv_prediction=pred)))
+    b = run_batch(ctx, streams)
+    for i, s in enumerate(streams):
+        assert b.status(i) == 0, (i, b.mesh_info(i).detail)
+        assert_same(b.result(i), oracle.decode(s), b, i)
+    b.close()
+
+
+@pytest.mark.parametrize("bits", [(8, 8, 4), (14, 12, 10), (16, 16, 12), (20, 18, 14)])
+def test_bit_depths(ctx, bits):
+    # deeper quantisation -> wider alphabets: exercises the multi-block table search and the large-alphabet path
+    pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 48, 40, 5)
+    s = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_bits=bits[0], uv_bits=bits[1], normal_bits=bits[2]))
+    b = run_batch(ctx, [s])
+    assert b.status(0) == 0, b.mesh_info(0).detail
+    assert_same(b.result(0), oracle.decode(s), b, 0)
+    b.close()
+
+
+def test_generic_and_positions_only(ctx):
+    pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 9, 9, 8)
+    gen = (np.arange(len(pos)) % 251).astype(np.uint8)
+    streams = [synth.encode_mesh(pos, faces, None, None, generic=gen), synth.encode_mesh(pos, faces)]
+    b = run_batch(ctx, streams)
+    for i, s in enumerate(streams):
+        assert b.status(i) == 0, (i, b.mesh_info(i).detail)
+        assert_same(b.result(i), oracle.decode(s), b, i)
+    b.close()
+
+
+def test_64k_triangle_meshes(ctx):
+    # BASELINE.json config 2: one 64k-triangle Edgebreaker mesh, bit-exact (grid and torus topologies)
+    streams = []
+    for kind in (synth.GRID, synth.TORUS):
+        pos, nrm, uv, faces = synth.make_mesh(kind, 128, 256, 2)
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv))
+    b = run_batch(ctx, streams)
+    for i, s in enumerate(streams):
+        assert b.status(i) == 0, (i, b.mesh_info(i).detail)
+        ref = oracle.decode(s)
+        assert ref.num_faces == 65536
+        assert_same(b.result(i), ref, b, i)
+    b.close()
+
+
+def test_bad_streams_do_not_poison_the_batch(ctx):
+    pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 9, 7, 3)
+    good = synth.encode_mesh(pos, faces, nrm, uv)
+    streams = [good, b"", b"DRACX" + good[5:], good[:40], good[: len(good) // 2], good[:-1], good]
+    v1 = bytearray(good); v1[5] = 1
+    streams.append(bytes(v1))
+    pc = synth.encode_point_cloud(pos)
+    streams.append(pc)                    # point cloud: NotImplementedException in the reference (DracoDecoder.cs:70)
+    b = run_batch(ctx, streams)
+    ref = oracle.decode(good)
+    for i in (0, 6):
+        assert b.status(i) == 0
+        assert_same(b.result(i), ref, b, i)
+    for i in (1, 2, 3, 4, 5, 7):
+        assert b.status(i) == 1, (i, b.status(i))
+        with pytest.raises(dsa.InvalidDataException):
+            b.result(i)
+    assert b.status(8) == 2
+    with pytest.raises(NotImplementedError):
+        b.result(8)
+    b.close()
+
+
+def test_reference_sample_reports_not_implemented(ctx, house04_bytes):
+    # house_04 uses valence traversal + UV seams + TexCoordsPortable: SURVEY.md section 8f "next" rows.
+    b = run_batch(ctx, [house04_bytes])
+    assert b.status(0) == 2
+    b.close()
+
+
+def test_single_decode_api(ctx):
+    pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 12, 9, 4)
+    s = synth.encode_mesh(pos, faces, nrm, uv)
+    got = dsa.DracoDecoder(ctx).Decode(s)
+    assert_same(got, oracle.decode(s))
+    mesh = got.ConnectedData
+    p = mesh.GetNamedAttribute(0)
+    assert p.MappedIndex(mesh.GetFace(0)[0]) == int(p.PointMap[mesh.Faces[0, 0]])
+    with pytest.raises(dsa.InvalidDataException):
+        dsa.DracoDecoder(ctx).Decode(s[:100])
+
+
+def test_batch_properties_full_size(ctx):
+    # size-independent properties on a batch of 64k-triangle meshes: every face references valid points,
+    # every point map entry is in range, unit normals, positions inside the quantisation box.
+    blob, offsets = synth.make_batch(synth.GRID, 128, 256, 1000, 16)
+    b = dsa.Batch(ctx, blob=blob, offsets=offsets)
+    b.decode()
+    for i in range(b.n):
+        assert b.status(i) == 0
+    for i in (0, 7, 15):
+        d = b.result(i)
+        m = d.ConnectedData
+        assert m.FacesCount == 65536 and m.PointsCount == 33153
+        assert m.Faces.min() >= 0 and m.Faces.max() == m.PointsCount - 1
+        pos, nrm, uv = m.Attributes
+        for a in m.Attributes:
+            assert a.PointMap.max() < a.UniqueEntriesCount
+            assert np.array_equal(np.sort(np.unique(a.PointMap)), np.arange(a.UniqueEntriesCount))
+        assert np.allclose(np.linalg.norm(nrm.Values, axis=1), 1.0, atol=1e-5)
+        lo = np.array(pos.MinValues, np.float32)
+        assert np.all(pos.Values >= lo - 1e-6) and np.all(pos.Values <= lo + pos.Range * 1.0001)
+        s = bytes(blob[int(offsets[i]):int(offsets[i + 1])])
+        assert_same(d, oracle.decode(s), b, i)
+    assert b.algorithmic_bytes > 16 * (65536 * 12 + 33153 * 32)
+    b.close()
