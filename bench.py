@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decoded meshes/s (+ GB/s) on a batch of 64k-triangle Edgebreaker .drc.
+
+A "step" is one device-resident decode of the whole per-GPU batch (compressed bytes already
+in HBM -> faces, attribute values and point maps in HBM).  N > 1: one process per GPU, every
+rank decodes its own batch of the same size (meshes are independent: no data-path collective,
+weak scaling); the timed region is bracketed by a barrier + synchronize and the MAX over ranks
+is reported.  Rank 0 prints one JSON line.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(blob, offsets, budget_s=12.0, max_meshes=1024):
+    """Single-thread CPU oracle (C++ scalar restatement of the reference path) on a bounded sample."""
+    import oracle
+    n = len(offsets) - 1
+    done, t0 = 0, time.perf_counter()
+    while done < min(n, max_meshes):
+        oracle.decode(bytes(blob[int(offsets[done]):int(offsets[done + 1])]))
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "meshes/s", "cores": 1, "kind": "port",
+            "sample": "first %d meshes of the rank-0 batch, full decode incl. numpy export, %.1f s" % (done, dt),
+            "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--meshes", type=int, default=4096, help="meshes per GPU (BASELINE.json configs[2]: 4096)")
+    ap.add_argument("--grid", type=int, nargs=2, default=[128, 256], help="grid cells (128x256 -> 65 536 triangles)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import draco_sharp_amd as dsa
+    import draco_sharp_amd.synth as synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- synthetic batch: SURVEY.md section 8d config 3 (positions 11 bit + normals 8 bit oct + UVs 10 bit,
+    # standard Edgebreaker, parallelogram + wrap, per-attribute connectivity), seeds 1000 + rank*meshes ...
+    nx, ny = args.grid
+    threads = max(1, (os.cpu_count() or 8) // max(1, world))
+    t0 = time.perf_counter()
+    blob, offsets = synth.make_batch(synth.GRID, nx, ny, 1000 + rank * args.meshes, args.meshes, normals=True, uvs=True, threads=threads)
+    t_gen = time.perf_counter() - t0
+
+    ctx = dsa.Context(local_rank)
+    ctx.set_profiling(True)
+    t0 = time.perf_counter()
+    batch = dsa.Batch(ctx, blob=blob, offsets=offsets)
+    t_upload = time.perf_counter() - t0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.decode(wait=True)
+    stage_sum = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.decode(wait=True)
+        for k, v in batch.stage_times().items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    bad = [i for i in range(batch.n) if batch.status(i) != 0]
+    if bad:
+        raise SystemExit("rank %d: %d meshes failed to decode (first %d: status %d site %d)" %
+                         (rank, len(bad), bad[0], batch.status(bad[0]), batch.mesh_info(bad[0]).detail))
+    alg_bytes = batch.algorithmic_bytes
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        bts = torch.tensor([alg_bytes], dtype=torch.float64, device="cuda")
+        dist.all_reduce(bts, op=dist.ReduceOp.SUM)
+        alg_bytes_all = float(bts.item())
+    else:
+        alg_bytes_all = float(alg_bytes)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        total_meshes = args.meshes * world
+        stages = {k: v / args.steps for k, v in stage_sum.items()}
+        kernel_stages = {k: v for k, v in stages.items() if k != "total"}
+        dom = max(kernel_stages, key=kernel_stages.get)
+        achieved = alg_bytes / (kernel_stages[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "decoded_meshes_per_sec",
+            "value": total_meshes / (elapsed / args.steps),
+            "unit": "meshes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": "batch of %d x %d-triangle Edgebreaker .drc per GPU (positions 11b + octahedral normals 8b + UVs 10b), device-resident decode"
+                                   % (args.meshes, 2 * nx * ny),
+                       "meshes_per_gpu": args.meshes, "triangles_per_mesh": 2 * nx * ny, "parallelism": "independent meshes, one batch per GPU, no collectives"},
+            "gb_per_s": alg_bytes_all / (elapsed / args.steps) / 1e9,
+            "algorithmic_bytes_per_gpu_step": alg_bytes,
+            "compressed_bytes_per_gpu": int(offsets[-1]),
+            "arena_bytes_per_gpu": batch.arena_bytes,
+            "stage_ms": stages,
+            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+            "setup_s": {"generate": t_gen, "upload_and_layout": t_upload},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(blob, offsets)
+        print(json.dumps(out))
+    batch.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,6 +132,8 @@ struct dsa_batch {
   uint64_t arena_bytes = 0;
   MeshLayout *d_layouts = nullptr;
   MeshDesc *d_descs = nullptr;
+  BatchGlobals *d_globals = nullptr;
+  BatchGlobals globals = {};
   uint32_t max_faces = 0, max_vertices = 0, max_atts = 0;
   bool decoded = false, collected = false;
   hipEvent_t ev[DSA_NUM_STAGES + 1] = {};
@@ -213,11 +215,20 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
     b->max_vertices = std::max<uint32_t>(b->max_vertices, (uint32_t)V);
     b->max_atts = std::max<uint32_t>(b->max_atts, (uint32_t)h.atts.size());
   }
+  // pool for the cumulative tables of large-alphabet streams (bump-allocated by k_locate)
+  {
+    uint64_t streams_total = 0;
+    for (uint32_t i = 0; i < n; ++i) streams_total += b->layouts[i].cap_attributes;
+    b->globals.pool = cur;
+    b->globals.pool_bytes = (64ull << 20) + 8192ull * streams_total;
+    cur = align_up(cur + b->globals.pool_bytes, 256);
+  }
   b->arena_bytes = cur;
   hipError_t e = hipMalloc((void **)&b->arena, b->arena_bytes ? b->arena_bytes : 256);
   if (e != hipSuccess) { uint64_t need = b->arena_bytes; delete b; return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "hipMalloc of %llu-byte arena failed: %s", (unsigned long long)need, hipGetErrorString(e)); }
   e = hipMalloc((void **)&b->d_layouts, sizeof(MeshLayout) * (n ? n : 1));
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_descs, sizeof(MeshDesc) * (n ? n : 1));
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_globals, sizeof(BatchGlobals));
   if (e != hipSuccess) { dsa_batch_free(b); return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "hipMalloc failed: %s", hipGetErrorString(e)); }
   // ---- upload: one staging copy of all streams, one of the layouts
   {
@@ -309,8 +320,9 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   int evi = 0;
   auto mark = [&]() -> hipError_t { return prof ? hipEventRecord(b->ev[evi++], st) : hipSuccess; };
   HIP_TRY(ctx, hipMemsetAsync(b->d_descs, 0, sizeof(MeshDesc) * n, st));
+  HIP_TRY(ctx, hipMemcpyAsync(b->d_globals, &b->globals, sizeof(BatchGlobals), hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, mark());
-  hipLaunchKernelGGL(dsa::k_locate, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+  hipLaunchKernelGGL(dsa::k_locate, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, b->d_globals);
   HIP_TRY(ctx, mark());
   hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, mark());
@@ -357,6 +369,7 @@ void dsa_batch_free(dsa_batch *b) {
   if (b->arena) (void)hipFree(b->arena);
   if (b->d_layouts) (void)hipFree(b->d_layouts);
   if (b->d_descs) (void)hipFree(b->d_descs);
+  if (b->d_globals) (void)hipFree(b->d_globals);
   delete b;
 }
 

@@ -221,11 +221,12 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total) 
 // attribute's output buffer for k_symbols.
 // =========================================================================
 #define LOC_MAX_TAGS 64
+#define SYM_MAX_LDS 4032   // 63 blocks of 64 cumulative entries searched in LDS by k_symbols
 
 #undef RET
 #define RET false
 __device__ bool locate_attribute_values(Rd &r, MeshDesc *D, AttrDesc &a, const MeshLayout &L, int ai, uint8_t *arena,
-                                        uint32_t *s_cum, uint32_t num_entries) {
+                                        uint32_t *s_cum, uint32_t num_entries, BatchGlobals *G) {
   const uint8_t *s = r.p;
   a.num_entries = num_entries;
   if (a.seq_type == 0) {   // generic: raw bytes, SequentialAttributeDecoder.cs:75-86
@@ -270,6 +271,13 @@ __device__ bool locate_attribute_values(Rd &r, MeshDesc *D, AttrDesc &a, const M
         a.num_symbols = (uint32_t)ns;
         a.off_table = r.pos;
         REQUIRE(skip_prob_table(r, a.num_symbols), 149);
+        if (a.num_symbols > SYM_MAX_LDS) {   // alphabet too large for the LDS search: cumulative table from the batch pool
+          unsigned long long bytes = ((unsigned long long)a.num_symbols + 2) * 4;
+          bytes = (bytes + 15) & ~15ull;
+          unsigned long long at = atomicAdd(&G->pool_cursor, bytes);
+          if (at + bytes > G->pool_bytes) NOTIMPL(166);
+          a.table = G->pool + at;
+        }
         uint64_t size = r.varint();
         a.off_rans = r.pos;
         r.skip(size);
@@ -351,7 +359,7 @@ __device__ bool locate_attribute_values(Rd &r, MeshDesc *D, AttrDesc &a, const M
 #undef RET
 #define RET
 
-__global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+__global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, BatchGlobals *G) {
   __shared__ uint32_t s_cum[LOC_MAX_TAGS + 1];
   uint32_t mesh = blockIdx.x;
   if (mesh >= n || threadIdx.x != 0) return;
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayou
   uint32_t num_entries = D->num_enc_vertices;
   for (uint32_t i = 0; i < ndec; ++i) {           // AttributesDecoder.cs:65-70
     for (uint32_t ai = first_att[i]; ai < first_att[i + 1]; ++ai) {
-      if (!locate_attribute_values(r, D, D->att[ai], L, (int)ai, arena, s_cum, num_entries)) return;
+      if (!locate_attribute_values(r, D, D->att[ai], L, (int)ai, arena, s_cum, num_entries, G)) return;
     }
     for (uint32_t ai = first_att[i]; ai < first_att[i + 1]; ++ai) {
       AttrDesc &a = D->att[ai];
@@ -876,7 +884,6 @@ __global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const Mes
 // =========================================================================
 // k_symbols: one wave per (mesh, attribute) value stream -> int32 corrections.
 // =========================================================================
-#define SYM_MAX_LDS 4032   // 63 blocks of 64 cumulative entries
 
 // Wave-uniform rANS symbol decode (Entropy/RAnsDecoder.cs:56-99).  The state and the
 // stream offset are wave-uniform; the cumulative-frequency table is spread over the
@@ -1002,11 +1009,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayo
   if (num_values == 0) return;
   if (a.source == SRC_RAW) {
     if (a.num_symbols <= SYM_MAX_LDS) rans_decode_wave(D, s, L.stream_len, a, num_values, work, lds_cum);
-    else {
-      // scratch for the table: the attribute's output buffer (free until k_finalize)
-      if ((uint64_t)(a.num_symbols + 1) * 4 > L.out_cap[ai]) { if (lane == 0) fail(D, ST_NOTIMPL, 420); return; }
-      rans_decode_serial(D, s, L.stream_len, a, num_values, work, (uint32_t *)(arena + L.out[ai]));
-    }
+    else rans_decode_serial(D, s, L.stream_len, a, num_values, work, (uint32_t *)(arena + a.table));
   } else if (a.source == SRC_TAGGED) {
     // SymbolDecoding.cs:38-47: entry e owns nc fields of tags[e] bits, packed LSB-first in entry order
     const uint8_t *tags = arena + L.out[ai];

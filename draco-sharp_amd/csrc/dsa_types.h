@@ -44,6 +44,7 @@ struct AttrDesc {
   float q_min[4];
   float q_range;
   uint32_t num_entries;
+  uint64_t table;          // arena offset of a cumulative table taken from the batch pool (large alphabets), else 0
 };
 
 // Per-mesh descriptor, filled by k_locate / k_connectivity / k_traverse.
@@ -68,6 +69,14 @@ struct MeshDesc {
   uint32_t num_points;
   uint32_t num_entries;    // traversal length
   AttrDesc att[DSA_MAX_ATT];
+};
+
+// Batch-wide device state.
+struct BatchGlobals {
+  uint64_t pool;                    // arena offset of the table pool
+  uint64_t pool_bytes;
+  unsigned long long pool_cursor;   // bump allocator, reset before every decode
+  unsigned long long pad;
 };
 
 // Host-computed placement of one mesh inside the batch arena (byte offsets from
