@@ -117,6 +117,8 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 struct dsa_context {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;     // symbol decode runs here, concurrently with connectivity + traversal
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool own_stream = false;
   bool profiling = false;
   std::string err;
@@ -137,6 +139,7 @@ struct dsa_batch {
   uint32_t max_faces = 0, max_vertices = 0, max_atts = 0;
   bool decoded = false, collected = false;
   hipEvent_t ev[DSA_NUM_STAGES + 1] = {};
+  hipEvent_t ev_sym[2] = {};
   bool have_events = false;
   float stage_ms[DSA_NUM_STAGES] = {};
 };
@@ -195,8 +198,8 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
     L.cap_attributes = (uint32_t)h.atts.size();
     L.cap_splits = h.splits;
     auto take = [&](uint64_t bytes) { uint64_t at = cur; cur = align_up(cur + bytes + 16, 256); return at; };
-    L.opp = take(12 * F); L.c2v = take(12 * F);
-    L.vcorner = take(4 * V); L.vhole = take(V);
+    L.frec = take(32 * F);
+    L.vrec = take(8 * V);
     L.d2c = take(4 * V); L.v2d = take(4 * V);
     L.fvis = take(F); L.vvis = take(V);
     L.splits = take(16ull * h.splits);
@@ -269,13 +272,20 @@ dsa_status dsa_context_create(int device, void *stream, dsa_context **out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DSA_ERR_DEVICE; }
     c->own_stream = true;
   }
+  if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
   *out = c;
   return DSA_OK;
 }
 
 void dsa_context_destroy(dsa_context *ctx) {
   if (!ctx) return;
-  if (ctx->own_stream && ctx->stream) { (void)hipSetDevice(ctx->device); (void)hipStreamDestroy(ctx->stream); }
+  (void)hipSetDevice(ctx->device);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
@@ -315,6 +325,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   const bool prof = ctx->profiling;
   if (prof && !b->have_events) {
     for (int i = 0; i <= DSA_NUM_STAGES; ++i) HIP_TRY(ctx, hipEventCreate(&b->ev[i]));
+    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreate(&b->ev_sym[i]));
     b->have_events = true;
   }
   int evi = 0;
@@ -324,6 +335,17 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   HIP_TRY(ctx, mark());
   hipLaunchKernelGGL(dsa::k_locate, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, b->d_globals);
   HIP_TRY(ctx, mark());
+  const uint32_t na = std::max<uint32_t>(1, b->max_atts);
+  // fork: entropy decode of every attribute stream on the second stream (it only needs k_locate's offsets)
+  hipStream_t st2 = ctx->stream2;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+  HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_fork, 0));
+  if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[0], st2));
+  hipLaunchKernelGGL(dsa::k_symbols<1>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
+  hipLaunchKernelGGL(dsa::k_symbols<0>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
+  hipLaunchKernelGGL(dsa::k_symbols<2>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
+  if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[1], st2));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_join, st2));
   hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, mark());
   hipLaunchKernelGGL(dsa::k_traverse, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
@@ -333,8 +355,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_para_operands, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   }
   HIP_TRY(ctx, mark());
-  const uint32_t na = std::max<uint32_t>(1, b->max_atts);
-  hipLaunchKernelGGL(dsa::k_symbols, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));   // join: corrections are ready
   HIP_TRY(ctx, mark());
   hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, mark());
@@ -353,9 +374,12 @@ dsa_status dsa_batch_wait(dsa_batch *b) {
   if (!b->decoded) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "dsa_batch_decode was not called");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
   if (b->n) HIP_TRY(ctx, hipMemcpy(b->descs.data(), b->d_descs, sizeof(MeshDesc) * b->n, hipMemcpyDeviceToHost));
   if (ctx->profiling && b->have_events && b->n) {
     for (int i = 0; i < STG_TOTAL; ++i) HIP_TRY(ctx, hipEventElapsedTime(&b->stage_ms[i], b->ev[i], b->ev[i + 1]));
+    // the symbol stage runs on the second stream: its own event pair (the slot on the main stream is the join wait)
+    HIP_TRY(ctx, hipEventElapsedTime(&b->stage_ms[STG_SYMBOLS], b->ev_sym[0], b->ev_sym[1]));
     HIP_TRY(ctx, hipEventElapsedTime(&b->stage_ms[STG_TOTAL], b->ev[0], b->ev[STG_TOTAL]));
   }
   b->collected = true;
@@ -366,6 +390,7 @@ void dsa_batch_free(dsa_batch *b) {
   if (!b) return;
   (void)hipSetDevice(b->ctx->device);
   if (b->have_events) for (int i = 0; i <= DSA_NUM_STAGES; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
+  if (b->have_events) for (int i = 0; i < 2; ++i) if (b->ev_sym[i]) (void)hipEventDestroy(b->ev_sym[i]);
   if (b->arena) (void)hipFree(b->arena);
   if (b->d_layouts) (void)hipFree(b->d_layouts);
   if (b->d_descs) (void)hipFree(b->d_descs);
@@ -471,14 +496,40 @@ const uint32_t *dsa_batch_device_point_map(const dsa_batch *b, uint32_t mesh, ui
 dsa_status dsa_batch_copy_debug(const dsa_batch *b, uint32_t mesh, int what, void *dst, size_t dst_bytes, size_t *written) {
   CHECK_MESH(b, mesh);
   const MeshDesc &D = b->descs[mesh];
-  if (D.status != ST_OK) return set_err(b->ctx, (dsa_status)D.status, "mesh %u failed to decode", mesh);
+  if (D.status != ST_OK && what != 4) return set_err(b->ctx, (dsa_status)D.status, "mesh %u failed to decode", mesh);
   const MeshLayout &L = b->layouts[mesh];
   uint64_t off = 0, bytes = 0;
+  auto unquad = [](uint32_t c) { return c == DSA_INVALID ? c : 3u * (c >> 2) + (c & 3u); };   // internal 4f+k -> reference 3f+k
   switch (what) {
-    case 0: off = L.opp; bytes = 12ull * D.num_faces; break;
-    case 1: off = L.c2v; bytes = 12ull * D.num_faces; break;
-    case 2: off = L.d2c; bytes = 4ull * D.num_entries; break;
+    case 0:
+    case 1: {   // de-interleave the 32-byte face records into the reference's opposite[] / corner_to_vertex[] arrays
+      bytes = 12ull * D.num_faces;
+      if (bytes > dst_bytes) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "destination too small");
+      std::vector<uint32_t> rec((size_t)D.num_faces * 8);
+      dsa_status st = copy_out(b, rec.data(), L.frec, 32ull * D.num_faces);
+      if (st != DSA_OK) return st;
+      uint32_t *o = (uint32_t *)dst;
+      for (uint32_t f = 0; f < D.num_faces; ++f)
+        for (uint32_t k = 0; k < 3; ++k) o[3 * f + k] = what == 0 ? unquad(rec[(size_t)f * 8 + 4 + k]) : rec[(size_t)f * 8 + k];
+      if (written) *written = (size_t)bytes;
+      return DSA_OK;
+    }
+    case 2: {
+      bytes = 4ull * D.num_entries;
+      if (bytes > dst_bytes) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "destination too small");
+      dsa_status st = copy_out(b, dst, L.d2c, bytes);
+      if (st != DSA_OK) return st;
+      uint32_t *o = (uint32_t *)dst;
+      for (uint32_t i = 0; i < D.num_entries; ++i) o[i] = unquad(o[i]);
+      if (written) *written = (size_t)bytes;
+      return DSA_OK;
+    }
     case 3: off = L.v2d; bytes = 4ull * D.num_vertices; break;
+    case 4:   // phase clocks recorded by the kernels (host copy)
+      if (dst_bytes < sizeof(D.dbg)) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "destination too small");
+      memcpy(dst, D.dbg, sizeof(D.dbg));
+      if (written) *written = sizeof(D.dbg);
+      return DSA_OK;
     default: return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "unknown debug array %d", what);
   }
   if (bytes > dst_bytes) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "destination too small");

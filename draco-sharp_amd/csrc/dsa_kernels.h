@@ -58,6 +58,11 @@ __device__ __forceinline__ uint32_t cprev(uint32_t c) { return (c % 3u == 0u) ? 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint64_t clk() { return __builtin_amdgcn_s_memtime(); }
+// s_waitcnt vmcnt(0) only (expcnt/lgkmcnt left at max).  On gfx950 loads and stores share vmcnt, so a
+// load consumed at a loop merge point makes the compiler drain every outstanding store each iteration;
+// rare loads are therefore completed inside their own branch with this.
+#define WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
 
 // Bounds-checked little-endian byte reader over one compressed stream
 // (DecoderBuffer.cs:26-120).  A failed read latches ok=false and returns 0.
@@ -225,7 +230,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total) 
 
 #undef RET
 #define RET false
-__device__ bool locate_attribute_values(Rd &r, MeshDesc *D, AttrDesc &a, const MeshLayout &L, int ai, uint8_t *arena,
+__device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, AttrDesc &a, const MeshLayout &L, int ai, uint8_t *arena,
                                         uint32_t *s_cum, uint32_t num_entries, BatchGlobals *G) {
   const uint8_t *s = r.p;
   a.num_entries = num_entries;
@@ -520,235 +525,436 @@ __global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayou
 // =========================================================================
 // k_connectivity: standard Edgebreaker stack machine, one wave per mesh.
 // =========================================================================
-struct SymbolBits {   // LSB-first reader over the traversal symbol section
-  const uint8_t *p;
-  uint32_t n;
-  uint64_t bit;
-  __device__ uint32_t get(uint32_t count) {
-    uint32_t v = read_bits(p, n, bit, count);
-    bit += count;
-    return v;
-  }
-};
+// Internal corner ids are "quad coded": corner k of face f is 4*f + k, so face = c >> 2, k = c & 3 with no
+// division, and a face record is 32 bytes: {v0, v1, v2, flags, o0, o1, o2, 0} (vertices, opposite corners).
+// The host converts to the reference's 3*f + k numbering where a corner id leaves the library.
+__device__ __forceinline__ uint32_t qnext(uint32_t c) { return (c & 3u) == 2u ? c - 2u : c + 1u; }
+__device__ __forceinline__ uint32_t qprev(uint32_t c) { return (c & 3u) == 0u ? c + 2u : c - 1u; }
+__device__ __forceinline__ uint32_t fv_idx(uint32_t c) { return 2u * c - (c & 3u); }        // dword index of the vertex slot
+__device__ __forceinline__ uint32_t fo_idx(uint32_t c) { return 2u * c - (c & 3u) + 4u; }   // dword index of the opposite slot
+
+// k_connectivity runs the Edgebreaker stack machine on wave-uniform state: every lane executes the same
+// scalar program (values broadcast with readfirstlane live in SGPRs, branches are scalar, no exec-mask
+// juggling), because with one wave per mesh the chip is instruction-issue bound and the per-symbol path
+// has to stay at a few dozen instructions.  Single words are written by all lanes to the same address
+// (one LDS / memory transaction); the 64 lanes become useful for
+//   * flushing 64 staged face records (2 KB of LDS) to global memory with full-width stores,
+//   * filling / writing back a block of the per-vertex record cache (64 x {left-most corner, vertex
+//     before it}, write-back, direct mapped) with one coalesced access,
+//   * refilling the 256-byte window of symbol bits.
+// What keeps the common symbols short: the active corner is always corner 0 of the previous face, whose
+// vertices stay in registers; C reads one per-vertex record from the LDS cache; R/L/E read nothing.
+// "corner already has an opposite" is checked after the loop by a lane-parallel symmetry pass.
+// Rare events (S, topology splits, start faces, vertex compaction) sync everything to global memory and
+// run there on lane 0.
+#define CN_REC_BLOCKS 16     // 16 blocks x 64 records x 8 B = 8 KB of LDS, write-back
+#define CN_STAGE 64          // faces per staging block
+#define CN_WIN 64            // dwords of symbol bits per window
 
 __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  __shared__ __attribute__((aligned(16))) uint32_t sh_stage[CN_STAGE * 8];
+  __shared__ __attribute__((aligned(16))) uint32_t sh_rec[CN_REC_BLOCKS * 64 * 2];
+  __shared__ uint32_t sh_win[CN_WIN];
   uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
   const MeshLayout &L = layouts[mesh];
   MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK) return;
   const uint8_t *s = arena + L.stream;
-  uint32_t *opp = (uint32_t *)(arena + L.opp), *c2v = (uint32_t *)(arena + L.c2v);
-  uint32_t *vcorner = (uint32_t *)(arena + L.vcorner);
-  uint8_t *vhole = arena + L.vhole;
-  uint32_t *stack = (uint32_t *)(arena + L.v2d);          // active-corner stack (<= #E <= cap_vertices/3)
+  uint32_t *frec = (uint32_t *)(arena + L.frec);
+  uint2 *vrec = (uint2 *)(arena + L.vrec);
+  uint32_t *stack_mem = (uint32_t *)(arena + L.v2d);      // active corners below the top (<= #E <= cap_vertices/3)
   uint32_t *invalid_list = (uint32_t *)(arena + L.d2c);   // merged-away vertices (<= num_split_symbols)
   uint32_t *events = (uint32_t *)(arena + L.splits);      // (source, split | edge<<31) per topology split event
   uint32_t *pairs = events + 2 * (size_t)L.cap_splits;    // topologySplitActiveCorners: (decoder symbol id, corner)
-  const uint32_t F = D->num_faces, VMAX = L.cap_vertices;
-  const uint32_t num_symbols = D->num_symbols;
-  const bool remove_invalid = D->num_att_data == 0;
+  const uint32_t F = uni(D->num_faces), VMAX = uni(L.cap_vertices);
+  const uint32_t num_symbols = uni(D->num_symbols);
+  const bool remove_invalid = uni(D->num_att_data) == 0;
+  const uint32_t lane = lane_id();
+  const uint32_t nsplits = uni(D->num_splits);
 
-  if (threadIdx.x == 0) {
-    // topology split events, MeshEdgeBreakerDecoder.cs:164-193
-    const uint32_t nsplits = D->num_splits;
-    {
-      Rd r(s, L.stream_len, D->off_splits);
-      uint32_t last = 0;
-      for (uint32_t i = 0; i < nsplits; ++i) {
-        uint32_t source = (uint32_t)r.varint() + last;
-        uint32_t delta = (uint32_t)r.varint();
-        REQUIRE(r.ok && delta <= source, 200);
-        uint32_t edge = read_bits(s + D->off_split_bits, L.stream_len - D->off_split_bits, i, 1);
-        events[2 * i] = source;
-        events[2 * i + 1] = ((source - delta) & 0x7FFFFFFFu) | (edge << 31);
-        last = source;
-      }
+  // ---- topology split events, MeshEdgeBreakerDecoder.cs:164-193 (lane 0, rare)
+  if (lane == 0 && nsplits) {
+    Rd r(s, L.stream_len, D->off_splits);
+    uint32_t last = 0;
+    for (uint32_t i = 0; i < nsplits; ++i) {
+      uint32_t source = (uint32_t)r.varint() + last;
+      uint32_t delta = (uint32_t)r.varint();
+      if (!r.ok || delta > source) { fail(D, ST_INVALID, 200); break; }
+      uint32_t edge = read_bits(s + D->off_split_bits, L.stream_len - D->off_split_bits, i, 1);
+      events[2 * i] = source;
+      events[2 * i + 1] = ((source - delta) & 0x7FFFFFFFu) | (edge << 31);
+      last = source;
     }
-    uint32_t splits_left = nsplits;     // consumed from the back (IsTopologySplit, :450-471)
-    uint32_t active_n = 0;
-    SymbolBits sb{s + D->off_symbols, D->size_symbols, 0};
-    Rabs start_faces;
-    uint32_t endp;
-    start_faces.start(s, L.stream_len, D->off_start_faces, &endp);
-    REQUIRE(start_faces.ok, 201);
+  }
+  uint32_t tagv = DSA_INVALID;          // lane i < CN_REC_BLOCKS: block resident in record-cache slot i
+#define TAG(slot_) rdlane(tagv, (slot_))
+  __syncthreads();
+  if (status_of(D) != ST_OK) return;
+  const uint64_t t_start = clk();
 
-    uint32_t sp = 0, num_faces = 0, num_verts = 0, num_invalid = 0;
-    for (uint32_t sid = 0; sid < num_symbols; ++sid) {
-      uint32_t face = num_faces++;
-      uint32_t corner = 3 * face;
-      uint32_t sym = sb.get(1);
-      if (sym) sym |= sb.get(2) << 1;
-      bool check_split = false;
-      opp[corner] = DSA_INVALID; opp[corner + 1] = DSA_INVALID; opp[corner + 2] = DSA_INVALID;
-      if (sym == 0) {              // C, :247-267
-        REQUIRE(sp > 0, 210);
-        uint32_t ca = stack[sp - 1];
-        uint32_t vx = c2v[cnext(ca)];
-        REQUIRE(vx < num_verts, 211);
-        uint32_t lm = vcorner[vx];
-        REQUIRE(lm != DSA_INVALID, 212);
-        uint32_t cb = cnext(lm);
-        REQUIRE(ca != cb && opp[ca] == DSA_INVALID && opp[cb] == DSA_INVALID, 213);
-        opp[ca] = corner + 1; opp[corner + 1] = ca;
-        opp[cb] = corner + 2; opp[corner + 2] = cb;
-        uint32_t va_prev = c2v[cprev(ca)], vb_next = c2v[cnext(cb)];
-        REQUIRE(vx != va_prev && vx != vb_next, 214);
-        c2v[corner] = vx; c2v[corner + 1] = vb_next; c2v[corner + 2] = va_prev;
-        vcorner[va_prev] = corner + 2;
-        vhole[vx] = 0;
-        stack[sp - 1] = corner;
-      } else if (sym == 5 || sym == 3) {   // R / L, :268-299
-        REQUIRE(sp > 0, 220);
-        uint32_t ca = stack[sp - 1];
-        REQUIRE(opp[ca] == DSA_INVALID, 221);
-        uint32_t oc, cl, cr;
-        if (sym == 5) { oc = corner + 2; cl = corner + 1; cr = corner; }
-        else { oc = corner + 1; cl = corner; cr = corner + 2; }
-        opp[oc] = ca; opp[ca] = oc;
-        REQUIRE(num_verts < VMAX, 222);
-        uint32_t nv = num_verts++;
-        vhole[nv] = 1;
-        c2v[oc] = nv;
-        vcorner[nv] = oc;
-        uint32_t vr = c2v[cprev(ca)];
-        c2v[cr] = vr;
-        vcorner[vr] = cr;
-        c2v[cl] = c2v[cnext(ca)];
-        stack[sp - 1] = corner;
-        check_split = true;
-      } else if (sym == 1) {       // S, :300-343
-        REQUIRE(sp > 0, 230);
-        uint32_t cb = stack[--sp];
-        for (uint32_t k = 0; k < active_n; ++k)          // topologySplitActiveCorners lookup (:305)
-          if (pairs[2 * k] == sid) { REQUIRE(sp < VMAX, 231); stack[sp++] = pairs[2 * k + 1]; break; }
-        REQUIRE(sp > 0, 232);
-        uint32_t ca = stack[sp - 1];
-        REQUIRE(ca != cb && opp[ca] == DSA_INVALID && opp[cb] == DSA_INVALID, 233);
-        opp[ca] = corner + 2; opp[corner + 2] = ca;
-        opp[cb] = corner + 1; opp[corner + 1] = cb;
-        uint32_t vp = c2v[cprev(ca)];
-        c2v[corner] = vp;
-        c2v[corner + 1] = c2v[cnext(ca)];
-        uint32_t vb_prev = c2v[cprev(cb)];
-        c2v[corner + 2] = vb_prev;
-        vcorner[vb_prev] = corner + 2;
-        uint32_t cn = cnext(cb);
-        uint32_t vn = c2v[cn];
-        REQUIRE(vn < num_verts && vp < num_verts, 234);
-        vcorner[vp] = vcorner[vn];
-        uint32_t first = cn, guard = 0;
-        while (cn != DSA_INVALID) {
-          c2v[cn] = vp;
-          uint32_t o = opp[cnext(cn)];          // SwingLeft
-          cn = o == DSA_INVALID ? DSA_INVALID : cnext(o);
-          REQUIRE(cn != first && ++guard <= 3 * F, 235);
+  // symbol section as 4-byte aligned words (the arena pads streams, so whole-window reads stay in bounds)
+  const uint32_t sym_off = uni(D->off_symbols);
+  const uint32_t sym_mis = (uint32_t)((L.stream + sym_off) & 3u);
+  const uint32_t *sym_words = (const uint32_t *)(arena + (L.stream + sym_off - sym_mis));
+  const uint64_t bit_end = ((uint64_t)sym_mis + uni(D->size_symbols)) * 8;
+
+  // ---- wave-uniform machine state
+  uint32_t sid = 0, stage_base = 0;
+  uint32_t T1 = 0, T2 = 0;              // vertices at corners 1,2 of the top face (the top is corner 0 of face sid-1)
+  bool have_top = false;
+  uint32_t sp = 0;                      // entries of stack_mem below the top
+  uint32_t num_verts = 0, num_invalid = 0;
+  uint32_t splits_left = nsplits, active_n = 0;
+  uint32_t next_src = nsplits ? uni(events[2 * (nsplits - 1)]) : DSA_INVALID;
+  uint32_t dirty = 0;                   // bit per record-cache slot
+  uint64_t bb = 0;                      // bit buffer (LSB first)
+  uint32_t bcnt = 0, widx = 0, wbase = 0x7FFFFF00u;   // next dword to take, first dword of the LDS window
+  uint32_t drop_bits = sym_mis * 8;     // bits of the first word that precede the section
+  uint64_t bits_used = (uint64_t)sym_mis * 8;
+  bool failed = false;
+
+  // write back one dirty block of the record cache (all lanes)
+  auto rec_writeback = [&](uint32_t slot) {
+    uint32_t v = TAG(slot) * 64 + lane;
+    if (v < VMAX) vrec[v] = make_uint2(sh_rec[(slot * 64 + lane) * 2], sh_rec[(slot * 64 + lane) * 2 + 1]);
+  };
+  // make `blk` resident in its slot; fill=false claims the block for freshly created vertices
+  auto rec_make_resident = [&](uint32_t blk, bool fill) {
+    const uint32_t slot = blk & (CN_REC_BLOCKS - 1);
+    if ((dirty >> slot) & 1u) { rec_writeback(slot); dirty &= ~(1u << slot); }
+    if (fill) {
+      WAIT_VM0();                       // this wave's own record stores must have landed
+      uint32_t v = blk * 64 + lane;
+      uint2 rr = v < VMAX ? vrec[v] : make_uint2(DSA_INVALID, DSA_INVALID);
+      sh_rec[(slot * 64 + lane) * 2] = rr.x; sh_rec[(slot * 64 + lane) * 2 + 1] = rr.y;
+      WAIT_VM0();
+    }
+    if (lane == slot) tagv = blk;
+    __syncthreads();
+  };
+  // Single-word stores are issued by lane 0 only (one `if (lane == 0)` region per symbol): 64 lanes
+  // writing one LDS address serialise in the LDS pipeline.  Whether a record / opposite slot lives in
+  // LDS or in global memory is decided on uniform values, so the branches inside stay scalar.
+  // record store: LDS if the block is resident, else straight to global memory
+#define REC_HIT(v_) (TAG(((v_) >> 6) & (CN_REC_BLOCKS - 1)) == ((v_) >> 6))
+#define REC_STORE(v_, hit_, lm_, nv_)                                                                         \
+  { if (hit_) *(uint2 *)&sh_rec[((((v_) >> 6) & (CN_REC_BLOCKS - 1)) * 64 + ((v_) & 63u)) * 2] = make_uint2((lm_), (nv_)); \
+    else vrec[(v_)] = make_uint2((lm_), (nv_)); }
+#define REC_DIRTY(v_, hit_) { if (hit_) dirty |= 1u << (((v_) >> 6) & (CN_REC_BLOCKS - 1)); }
+  // opposite slot of corner c: staged or already in global memory
+#define SET_OPP(c_, val_)                                                                \
+  { if ((c_) >= 4 * stage_base) sh_stage[fo_idx(c_) - 8 * stage_base] = (val_);          \
+    else frec[fo_idx(c_)] = (val_); }
+  // staged faces [stage_base, upto) -> global memory, 16 bytes per lane and store
+  auto flush_stage = [&](uint32_t upto) {
+    const uint32_t quads = (upto - stage_base) * 2;
+    __syncthreads();
+    for (uint32_t i = lane; i < quads; i += WAVE) ((uint4 *)frec)[(size_t)stage_base * 2 + i] = ((const uint4 *)sh_stage)[i];
+    stage_base = upto;
+  };
+  // everything to global memory, record cache emptied (before lane 0 works on global memory directly)
+  auto sync_all = [&]() {
+    flush_stage(sid);
+    for (uint32_t slot = 0; slot < CN_REC_BLOCKS; ++slot) if ((dirty >> slot) & 1u) rec_writeback(slot);
+    dirty = 0;
+    tagv = DSA_INVALID;
+    WAIT_VM0();
+    __syncthreads();
+  };
+#define CN_FAIL(site) { if (lane == 0) fail(D, ST_INVALID, (site)); failed = true; break; }
+
+#ifdef DSA_LOOP_PROFILE
+  uint64_t acc_c = 0, acc_rl = 0, acc_fetch = 0, tp = clk();
+  uint32_t n_c = 0, n_rl = 0;
+#define PROF(acc, cnt) { uint64_t t_ = clk(); acc += t_ - tp; tp = t_; ++cnt; }
+#else
+#define PROF(acc, cnt)
+#endif
+  while (sid < num_symbols) {
+    if (sid - stage_base == CN_STAGE) flush_stage(sid);
+#ifdef DSA_LOOP_PROFILE
+    { uint32_t dummy = 0; PROF(acc_fetch, dummy); }
+#endif
+    if (bcnt < 3) {                       // refill the bit buffer from the LDS window
+      if (widx - wbase >= CN_WIN) {
+        __syncthreads();
+        sh_win[lane] = sym_words[(size_t)widx + lane];
+        wbase = widx;
+        WAIT_VM0();
+        __syncthreads();
+      }
+      uint32_t w = uni(sh_win[widx - wbase]);
+      ++widx;
+      if (drop_bits) { w >>= drop_bits; bb |= (uint64_t)w << bcnt; bcnt += 32 - drop_bits; drop_bits = 0; }
+      else { bb |= (uint64_t)w << bcnt; bcnt += 32; }
+      if (bcnt < 3) continue;
+    }
+    // MeshEdgeBreakerTraversalDecoder.cs:89-99: 1 bit, then 2 more unless C
+    const uint32_t b3 = (uint32_t)bb & 7u;
+    const uint32_t face = sid, corner = 4 * face, ca = corner - 4;
+    const uint32_t so = (face - stage_base) * 8;
+    if ((b3 & 1u) == 0) {                 // C, :247-267
+      if (!have_top) CN_FAIL(210);
+      const uint32_t vx = T1, va_prev = T2;
+      const uint32_t blk = vx >> 6, slot = blk & (CN_REC_BLOCKS - 1);
+      if (TAG(slot) != blk) rec_make_resident(blk, true);
+      const uint2 rr = *(const uint2 *)&sh_rec[(slot * 64 + (vx & 63u)) * 2];
+      const uint32_t lm = uni(rr.x), vb_next = uni(rr.y);
+      const uint32_t cb = qnext(lm);
+      if (lm >= corner || (lm & 3u) == 3u || ca == cb || vx == va_prev || vx == vb_next || vb_next >= num_verts) CN_FAIL(213);
+      bb >>= 1; bcnt -= 1; bits_used += 1;
+      const bool hit_a = REC_HIT(va_prev);
+      if (lane == 0) {
+        *(uint4 *)&sh_stage[so] = make_uint4(vx, vb_next, va_prev, 0u);
+        *(uint4 *)&sh_stage[so + 4] = make_uint4(DSA_INVALID, ca, cb, 0u);
+        SET_OPP(ca, corner + 1);
+        SET_OPP(cb, corner + 2);
+        REC_STORE(va_prev, hit_a, corner + 2, vb_next);   // SetLeftMostCorner(va_prev, corner + 2) + the vertex before that corner
+      }
+      REC_DIRTY(va_prev, hit_a);
+      T1 = vb_next;                              // face (vx, vb_next, va_prev)
+      ++sid;
+      PROF(acc_c, n_c);
+      continue;
+    }
+    if (b3 == 1u) {                       // S, :300-343 -- rare: on global memory, lane 0
+      if (!have_top) CN_FAIL(230);
+      bb >>= 3; bcnt -= 3; bits_used += 3;
+      sync_all();
+      uint32_t ok = 0, r_sp = sp, r_inv = num_invalid, rT1 = 0, rT2 = 0;
+      if (lane == 0) {
+        do {
+          uint32_t cb = ca, ca2 = DSA_INVALID, sp2 = sp;
+          bool pushed = false;
+          for (uint32_t k = 0; k < active_n; ++k)     // topologySplitActiveCorners lookup (:305)
+            if (pairs[2 * k] == sid) { ca2 = pairs[2 * k + 1]; pushed = true; break; }
+          if (!pushed) { if (sp2 == 0) { fail(D, ST_INVALID, 232); break; } ca2 = stack_mem[--sp2]; }
+          if (ca2 >= corner || (ca2 & 3u) == 3u) { fail(D, ST_INVALID, 237); break; }
+          if (ca2 == cb || frec[fo_idx(ca2)] != DSA_INVALID || frec[fo_idx(cb)] != DSA_INVALID) { fail(D, ST_INVALID, 233); break; }
+          uint32_t vp = frec[fv_idx(qprev(ca2))], vq = frec[fv_idx(qnext(ca2))], vb_prev = frec[fv_idx(qprev(cb))];
+          uint32_t cn = qnext(cb);
+          uint32_t vn = frec[fv_idx(cn)];
+          if (vn >= num_verts || vp >= num_verts || vq >= num_verts || vb_prev >= num_verts) { fail(D, ST_INVALID, 234); break; }
+          frec[fo_idx(ca2)] = corner + 2; frec[fo_idx(cb)] = corner + 1;
+          frec[8 * face + 0] = vp; frec[8 * face + 1] = vq; frec[8 * face + 2] = vb_prev; frec[8 * face + 3] = 0;
+          frec[8 * face + 4] = DSA_INVALID; frec[8 * face + 5] = cb; frec[8 * face + 6] = ca2; frec[8 * face + 7] = 0;
+          vrec[vb_prev] = make_uint2(corner + 2, vq);
+          uint32_t lm_n = vrec[vn].x;
+          uint32_t first = cn, guard = 0;
+          bool bad = false;
+          while (cn != DSA_INVALID) {
+            frec[fv_idx(cn)] = vp;
+            // the record of the vertex whose left-most corner follows cn caches the vertex at cn
+            uint32_t w = frec[fv_idx(qnext(cn))];
+            if (w < num_verts && vrec[w].x == qnext(cn)) vrec[w].y = vp;
+            uint32_t o = frec[fo_idx(qnext(cn))];          // SwingLeft
+            cn = o == DSA_INVALID ? DSA_INVALID : qnext(o);
+            if (cn == first || ++guard > 3 * F) { bad = true; break; }
+          }
+          if (bad) { fail(D, ST_INVALID, 235); break; }
+          if (lm_n >= corner + 4 || (lm_n & 3u) == 3u) { fail(D, ST_INVALID, 238); break; }
+          vrec[vp] = make_uint2(lm_n, frec[fv_idx(qprev(lm_n))]);
+          vrec[vn] = make_uint2(DSA_INVALID, DSA_INVALID);
+          if (remove_invalid) { if (r_inv >= VMAX) { fail(D, ST_INVALID, 236); break; } invalid_list[r_inv++] = vn; }
+          r_sp = sp2;                     // the new top replaces the pushed or the exposed entry
+          rT1 = vq; rT2 = vb_prev;
+          ok = 1;
+        } while (0);
+        WAIT_VM0();
+      }
+      if (!uni(ok)) { failed = true; break; }
+      sp = uni(r_sp); num_invalid = uni(r_inv); T1 = uni(rT1); T2 = uni(rT2);
+      ++sid;
+      stage_base = sid;                   // the new face went straight to global memory
+      __syncthreads();
+      continue;
+    }
+    if (b3 != 7u) {                       // R (5) / L (3), :268-299
+      if (!have_top || num_verts >= VMAX) CN_FAIL(220);
+      const uint32_t nv = num_verts;
+      if ((nv & 63u) == 0 && !REC_HIT(nv)) rec_make_resident(nv >> 6, false);
+      bb >>= 3; bcnt -= 3; bits_used += 3;
+      ++num_verts;
+      const bool hit_n = REC_HIT(nv), hit_2 = REC_HIT(T2);
+      if (b3 == 5u) {
+        if (lane == 0) {
+          *(uint4 *)&sh_stage[so] = make_uint4(T2, T1, nv, 0u);
+          *(uint4 *)&sh_stage[so + 4] = make_uint4(DSA_INVALID, DSA_INVALID, ca, 0u);
+          SET_OPP(ca, corner + 2);
+          REC_STORE(nv, hit_n, corner + 2, T1);
+          REC_STORE(T2, hit_2, corner, nv);
         }
-        vcorner[vn] = DSA_INVALID;
-        if (remove_invalid) { REQUIRE(num_invalid < VMAX, 236); invalid_list[num_invalid++] = vn; }
-        stack[sp - 1] = corner;
-      } else if (sym == 7) {       // E, :344-357
-        REQUIRE(num_verts + 3 <= VMAX, 240);
-        uint32_t v0 = num_verts;
-        num_verts += 3;
-        for (uint32_t k = 0; k < 3; ++k) { c2v[corner + k] = v0 + k; vcorner[v0 + k] = corner + k; vhole[v0 + k] = 1; }
-        REQUIRE(sp < VMAX, 241);
-        stack[sp++] = corner;
-        check_split = true;
+        REC_DIRTY(nv, hit_n); REC_DIRTY(T2, hit_2);
+        T2 = nv;                          // face (T2, T1, nv): corner 1 keeps T1
       } else {
-        REQUIRE(false, 242);
-      }
-      if (check_split) {           // :363-375
-        uint32_t enc_id = num_symbols - sid - 1;
-        while (splits_left > 0) {
-          uint32_t source = events[2 * (splits_left - 1)];
-          uint32_t packed = events[2 * (splits_left - 1) + 1];
-          REQUIRE(source <= enc_id, 243);            // encoderSplitSymbolId < 0 in the reference
-          if (source != enc_id) break;
-          --splits_left;
-          uint32_t edge = packed >> 31, enc_split = packed & 0x7FFFFFFFu;
-          REQUIRE(enc_split < num_symbols, 244);
-          uint32_t top = stack[sp - 1];
-          uint32_t nc = edge == 1 ? cnext(top) : cprev(top);   // 1 = RightFaceEdge (Constants.cs:56-60)
-          uint32_t key = num_symbols - enc_split - 1;
-          uint32_t k = 0;
-          for (; k < active_n; ++k) if (pairs[2 * k] == key) break;   // dictionary semantics: overwrite
-          REQUIRE(k < L.cap_splits, 245);
-          pairs[2 * k] = key; pairs[2 * k + 1] = nc;
-          if (k == active_n) ++active_n;
+        if (lane == 0) {
+          *(uint4 *)&sh_stage[so] = make_uint4(T1, nv, T2, 0u);
+          *(uint4 *)&sh_stage[so + 4] = make_uint4(DSA_INVALID, ca, DSA_INVALID, 0u);
+          SET_OPP(ca, corner + 1);
+          REC_STORE(nv, hit_n, corner + 1, T1);
+          REC_STORE(T2, hit_2, corner + 2, nv);
         }
+        REC_DIRTY(nv, hit_n); REC_DIRTY(T2, hit_2);
+        T1 = nv;                          // face (T1, nv, T2)
+      }
+    } else {                              // E, :344-357
+      if (num_verts + 3 > VMAX || sp >= VMAX) CN_FAIL(240);
+      const uint32_t v0 = num_verts;
+      bb >>= 3; bcnt -= 3; bits_used += 3;
+      num_verts += 3;
+      const bool h0 = REC_HIT(v0), h1 = REC_HIT(v0 + 1), h2 = REC_HIT(v0 + 2);
+      if (lane == 0) {
+        *(uint4 *)&sh_stage[so] = make_uint4(v0, v0 + 1, v0 + 2, 0u);
+        *(uint4 *)&sh_stage[so + 4] = make_uint4(DSA_INVALID, DSA_INVALID, DSA_INVALID, 0u);
+        REC_STORE(v0, h0, corner, v0 + 2);
+        REC_STORE(v0 + 1, h1, corner + 1, v0);
+        REC_STORE(v0 + 2, h2, corner + 2, v0 + 1);
+        if (have_top) stack_mem[sp] = ca;
+      }
+      REC_DIRTY(v0, h0); REC_DIRTY(v0 + 1, h1); REC_DIRTY(v0 + 2, h2);
+      if (have_top) ++sp;
+      have_top = true;
+      T1 = v0 + 1; T2 = v0 + 2;
+    }
+    ++sid;
+    PROF(acc_rl, n_rl);
+    if (splits_left > 0) {                // :363-375 (sid already advanced: the symbol just decoded is sid-1)
+      const uint32_t enc_id = num_symbols - sid;
+      if (next_src > enc_id) CN_FAIL(243);   // encoderSplitSymbolId < 0 in the reference
+      if (next_src == enc_id) {
+        uint32_t r_left = splits_left, r_act = active_n, r_next = DSA_INVALID, ok = 1;
+        if (lane == 0) {
+          while (r_left > 0) {
+            uint32_t source = events[2 * (r_left - 1)];
+            uint32_t packed = events[2 * (r_left - 1) + 1];
+            if (source != enc_id) break;
+            --r_left;
+            uint32_t edge = packed >> 31, enc_split = packed & 0x7FFFFFFFu;
+            if (enc_split >= num_symbols) { ok = 0; break; }
+            uint32_t nc = edge == 1 ? corner + 1 : corner + 2;   // Next / Previous of the new top (1 = RightFaceEdge)
+            uint32_t key = num_symbols - enc_split - 1;
+            uint32_t k = 0;
+            for (; k < r_act; ++k) if (pairs[2 * k] == key) break;   // dictionary semantics: overwrite
+            if (k >= L.cap_splits) { ok = 0; break; }
+            pairs[2 * k] = key; pairs[2 * k + 1] = nc;
+            if (k == r_act) ++r_act;
+          }
+          r_next = r_left ? events[2 * (r_left - 1)] : DSA_INVALID;
+          WAIT_VM0();
+        }
+        if (!uni(ok)) CN_FAIL(244);
+        splits_left = uni(r_left); active_n = uni(r_act); next_src = uni(r_next);
       }
     }
-    REQUIRE(num_verts <= VMAX, 250);
-    // start faces, :378-415
-    while (sp > 0) {
-      uint32_t corner = stack[--sp];
-      bool interior = start_faces.next() != 0;
-      if (interior) {
-        REQUIRE(num_faces < F, 251);
+  }
+  if (failed) return;
+  if (bits_used > bit_end) { if (lane == 0) fail(D, ST_INVALID, 246); return; }   // symbols ran past their section
+  sync_all();
+  const uint64_t t_loop = clk();
+
+  // ---- start faces (:378-415) and isolated-vertex compaction (:417-441): lane 0 on global memory
+  uint32_t final_nv = 0;
+  if (lane == 0) {
+    do {
+      Rabs start_faces;
+      uint32_t endp;
+      start_faces.start(s, L.stream_len, D->off_start_faces, &endp);
+      if (!start_faces.ok) { fail(D, ST_INVALID, 201); break; }
+      uint32_t num_faces = num_symbols;
+      bool top_pending = have_top, bad = false;
+      uint32_t spx = sp;
+      while (top_pending || spx > 0) {
+        uint32_t corner;
+        if (top_pending) { corner = 4 * (num_symbols - 1); top_pending = false; }
+        else corner = stack_mem[--spx];
+        bool interior = start_faces.next() != 0;
+        if (!interior) continue;
+        if (num_faces >= F || corner >= 4 * num_faces) { fail(D, ST_INVALID, 251); bad = true; break; }
         uint32_t ca = corner;
-        uint32_t vn = c2v[cnext(ca)];
-        REQUIRE(vn < num_verts && vcorner[vn] != DSA_INVALID, 252);
-        uint32_t cb = cnext(vcorner[vn]);
-        uint32_t vx = c2v[cnext(cb)];
-        REQUIRE(vx < num_verts && vcorner[vx] != DSA_INVALID, 253);
-        uint32_t cc = cnext(vcorner[vx]);
-        REQUIRE(ca != cb && ca != cc && cb != cc, 254);
-        REQUIRE(opp[ca] == DSA_INVALID && opp[cb] == DSA_INVALID && opp[cc] == DSA_INVALID, 255);
-        uint32_t vp = c2v[cnext(cc)];
-        REQUIRE(vp < num_verts, 262);
+        uint32_t vn = frec[fv_idx(qnext(ca))];
+        if (vn >= num_verts || vrec[vn].x >= 4 * num_faces) { fail(D, ST_INVALID, 252); bad = true; break; }
+        uint32_t cb = qnext(vrec[vn].x);
+        uint32_t vx = frec[fv_idx(qnext(cb))];
+        if (vx >= num_verts || vrec[vx].x >= 4 * num_faces) { fail(D, ST_INVALID, 253); bad = true; break; }
+        uint32_t cc = qnext(vrec[vx].x);
+        if (ca == cb || ca == cc || cb == cc) { fail(D, ST_INVALID, 254); bad = true; break; }
+        if (frec[fo_idx(ca)] != DSA_INVALID || frec[fo_idx(cb)] != DSA_INVALID || frec[fo_idx(cc)] != DSA_INVALID) { fail(D, ST_INVALID, 255); bad = true; break; }
+        uint32_t vp = frec[fv_idx(qnext(cc))];
+        if (vp >= num_verts) { fail(D, ST_INVALID, 262); bad = true; break; }
         uint32_t face = num_faces++;
-        uint32_t nc = 3 * face;
-        opp[nc] = ca; opp[ca] = nc; opp[nc + 1] = cb; opp[cb] = nc + 1; opp[nc + 2] = cc; opp[cc] = nc + 2;
-        c2v[nc] = vx; c2v[nc + 1] = vp; c2v[nc + 2] = vn;
-        vhole[vx] = 0; vhole[vp] = 0; vhole[vn] = 0;
+        uint32_t nc = 4 * face;
+        frec[fo_idx(ca)] = nc; frec[fo_idx(cb)] = nc + 1; frec[fo_idx(cc)] = nc + 2;
+        frec[8 * face + 0] = vx; frec[8 * face + 1] = vp; frec[8 * face + 2] = vn; frec[8 * face + 3] = 0;
+        frec[8 * face + 4] = ca; frec[8 * face + 5] = cb; frec[8 * face + 6] = cc; frec[8 * face + 7] = 0;
       }
-    }
-    REQUIRE(num_faces == F, 256);
-    // isolated-vertex compaction, :417-441
-    uint32_t nvert = num_verts;
-    for (uint32_t k = 0; k < num_invalid; ++k) {
-      uint32_t inv = invalid_list[k];
-      REQUIRE(nvert > 0, 257);
-      uint32_t src = nvert - 1;
-      while (vcorner[src] == DSA_INVALID) { REQUIRE(nvert > 1, 258); src = --nvert - 1; }
-      if (src < inv) continue;
-      uint32_t start = vcorner[src], c = start, guard = 0;
-      bool left = true;
-      while (c != DSA_INVALID) {   // VertexCornersIterator (D-10: starts at the left-most corner itself)
-        REQUIRE(c2v[c] == src && ++guard <= 3 * F, 259);
-        c2v[c] = inv;
-        if (left) {
-          uint32_t o = opp[cnext(c)];
-          c = o == DSA_INVALID ? DSA_INVALID : cnext(o);
-          if (c == DSA_INVALID) { uint32_t o2 = opp[cprev(start)]; c = o2 == DSA_INVALID ? DSA_INVALID : cprev(o2); left = false; }
-          else if (c == start) c = DSA_INVALID;
-        } else {
-          uint32_t o = opp[cprev(c)];
-          c = o == DSA_INVALID ? DSA_INVALID : cprev(o);
+      if (bad) break;
+      if (num_faces != F) { fail(D, ST_INVALID, 256); break; }
+      uint32_t nvert = num_verts;
+      for (uint32_t k = 0; k < num_invalid && !bad; ++k) {
+        uint32_t inv = invalid_list[k];
+        if (nvert == 0) { fail(D, ST_INVALID, 257); bad = true; break; }
+        uint32_t src = nvert - 1;
+        while (vrec[src].x == DSA_INVALID) { if (nvert <= 1) { bad = true; break; } src = --nvert - 1; }
+        if (bad) { fail(D, ST_INVALID, 258); break; }
+        if (src < inv) continue;
+        uint32_t start = vrec[src].x, c = start, guard = 0;
+        bool left = true;
+        while (c != DSA_INVALID) {   // VertexCornersIterator (D-10: starts at the left-most corner itself)
+          if (c >= 4 * F || (c & 3u) == 3u || frec[fv_idx(c)] != src || ++guard > 3 * F) { fail(D, ST_INVALID, 259); bad = true; break; }
+          frec[fv_idx(c)] = inv;
+          if (left) {
+            uint32_t o = frec[fo_idx(qnext(c))];
+            c = o == DSA_INVALID ? DSA_INVALID : qnext(o);
+            if (c == DSA_INVALID) { uint32_t o2 = frec[fo_idx(qprev(start))]; c = o2 == DSA_INVALID ? DSA_INVALID : qprev(o2); left = false; }
+            else if (c == start) c = DSA_INVALID;
+          } else {
+            uint32_t o = frec[fo_idx(qprev(c))];
+            c = o == DSA_INVALID ? DSA_INVALID : qprev(o);
+          }
         }
+        vrec[inv] = vrec[src];
+        vrec[src] = make_uint2(DSA_INVALID, DSA_INVALID);
+        nvert--;
       }
-      vcorner[inv] = vcorner[src];
-      vcorner[src] = DSA_INVALID;
-      vhole[inv] = vhole[src];
-      vhole[src] = 0;
-      nvert--;
-    }
-    D->num_vertices = remove_invalid ? nvert : num_verts;
+      if (bad) break;
+      final_nv = remove_invalid ? nvert : num_verts;
+      D->num_vertices = final_nv;
+    } while (0);
+    WAIT_VM0();
     __threadfence_block();
   }
   __syncthreads();
   if (status_of(D) != ST_OK) return;
-  const uint32_t NV = __hip_atomic_load(&D->num_vertices, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t NV = uni(final_nv);
+  const uint32_t NVALL = num_verts;
+  const uint64_t t_tail = clk();
 
+  // ---- every opposite link must be mutual ("corner already has an opposite", :254,272,314,392) and in range
+  {
+    uint32_t bad = 0;
+    for (uint32_t f = lane; f < F; f += WAVE) {
+      const uint4 vv = ((const uint4 *)frec)[(size_t)f * 2], oo = ((const uint4 *)frec)[(size_t)f * 2 + 1];
+      const uint32_t ov[3] = {oo.x, oo.y, oo.z};
+      for (uint32_t k = 0; k < 3; ++k) {
+        uint32_t o = ov[k];
+        if (o != DSA_INVALID && (o >= 4 * F || (o & 3u) == 3u || frec[fo_idx(o)] != 4 * f + k)) bad = 1;
+      }
+      if (vv.x >= NV || vv.y >= NV || vv.z >= NV) bad = 1;
+    }
+    if (__ballot(bad)) { if (lane == 0) fail(D, ST_INVALID, 263); return; }
+  }
+  const uint64_t t_sym = clk();
   // ---- attribute seams (MeshEdgeBreakerDecoder.cs:502-535): lane i decodes the rABS
   // stream of attribute data i.  Only seam-free attribute connectivity is handled on
   // the device; any set bit is reported as not implemented.
   const uint32_t nad = D->num_att_data;
-  const uint32_t lane = lane_id();
   if (nad > 0) {
     uint32_t interior_corners = 0;   // one seam bit per interior edge and attribute data
-    for (uint32_t c = lane; c < 3 * F; c += WAVE) interior_corners += (opp[c] != DSA_INVALID) ? 1u : 0u;
+    for (uint32_t f = lane; f < F; f += WAVE) {
+      const uint4 oo = ((const uint4 *)frec)[(size_t)f * 2 + 1];
+      interior_corners += (oo.x != DSA_INVALID) + (oo.y != DSA_INVALID) + (oo.z != DSA_INVALID);
+    }
     for (int d = 32; d >= 1; d >>= 1) interior_corners += __shfl_xor(interior_corners, d, 64);
     uint32_t edges = interior_corners / 2;
     uint32_t any = 0;
@@ -763,7 +969,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
     if (bad) { if (lane == 0) fail(D, ST_INVALID, 260); return; }
     if (seam) { if (lane == 0) fail(D, ST_NOTIMPL, 261); return; }
   }
-
+  const uint64_t t_seam = clk();
   // ---- vertex -> point id (AssignPointsToCorners, :537-638, seam-free case):
   // single connectivity: point == vertex; per-attribute connectivity: rank among vertices that own a corner.
   uint32_t *vrank = (uint32_t *)(arena + L.vrank);
@@ -772,21 +978,34 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
     if (lane == 0) D->num_points = NV;
   } else {
     uint32_t base = 0;
-    for (uint32_t v0 = 0; v0 < NV; v0 += WAVE) {
+    for (uint32_t v0 = 0; v0 < NVALL; v0 += WAVE) {
       uint32_t v = v0 + lane;
-      uint32_t has = (v < NV && vcorner[v] != DSA_INVALID) ? 1u : 0u;
+      uint32_t has = (v < NVALL && vrec[v].x != DSA_INVALID) ? 1u : 0u;
       uint64_t m = __ballot(has);
       uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if (v < NV) vrank[v] = base + before;
+      if (v < NVALL) vrank[v] = base + before;
       base += (uint32_t)__popcll(m);
     }
     if (lane == 0) D->num_points = base;
   }
+  if (lane == 0) {
+    D->dbg[0] = (uint32_t)(t_loop - t_start); D->dbg[1] = (uint32_t)(t_tail - t_loop); D->dbg[2] = (uint32_t)(t_sym - t_tail);
+    D->dbg[3] = (uint32_t)(t_seam - t_sym); D->dbg[4] = (uint32_t)(clk() - t_seam);
+#ifdef DSA_LOOP_PROFILE
+    D->dbg[5] = (uint32_t)(acc_c / (n_c ? n_c : 1)); D->dbg[6] = (uint32_t)(acc_rl / (n_rl ? n_rl : 1));
+    D->dbg[7] = (uint32_t)(acc_fetch / (n_c + n_rl + 1)); D->dbg[8] = n_c; D->dbg[9] = n_rl;
+#endif
+  }
+#undef CN_FAIL
+#undef TAG
+#undef REC_HIT
+#undef REC_STORE
+#undef REC_DIRTY
+#undef SET_OPP
 }
 
 // =========================================================================
-// k_traverse: depth-first attribute sequencing on the position corner table,
-// then (lane-parallel) the parallelogram operands of every entry.
+// k_traverse: depth-first attribute sequencing on the position corner table.
 // =========================================================================
 __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   uint32_t mesh = blockIdx.x;
@@ -794,8 +1013,8 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   const MeshLayout &L = layouts[mesh];
   MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK) return;
-  const uint32_t *opp = (const uint32_t *)(arena + L.opp), *c2v = (const uint32_t *)(arena + L.c2v);
-  const uint32_t *vcorner = (const uint32_t *)(arena + L.vcorner);
+  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
+  const uint2 *vrec = (const uint2 *)(arena + L.vrec);
   uint32_t *d2c = (uint32_t *)(arena + L.d2c);
   int32_t *v2d = (int32_t *)(arena + L.v2d);
   uint8_t *fvis = arena + L.fvis, *vvis = arena + L.vvis;
@@ -812,37 +1031,37 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
 #define VISIT(v, c) do { vvis[v] = 1; d2c[count] = (c); v2d[v] = (int32_t)count; ++count; } while (0)
     for (uint32_t f0 = 0; f0 < F; ++f0) {
       if (fvis[f0]) continue;
-      uint32_t corner = 3 * f0;
+      uint32_t corner = 4 * f0;
       uint32_t sp = 0;
       stack[sp++] = corner;
-      uint32_t nv = c2v[cnext(corner)], pv = c2v[cprev(corner)];
+      uint32_t nv = frec[fv_idx(qnext(corner))], pv = frec[fv_idx(qprev(corner))];
       REQUIRE(nv < NV && pv < NV, 300);
-      if (!vvis[nv]) VISIT(nv, cnext(corner));
-      if (!vvis[pv]) VISIT(pv, cprev(corner));
+      if (!vvis[nv]) VISIT(nv, qnext(corner));
+      if (!vvis[pv]) VISIT(pv, qprev(corner));
       while (sp > 0) {
         corner = stack[sp - 1];
-        if (corner == DSA_INVALID || fvis[corner / 3]) { --sp; continue; }
-        uint32_t face = corner / 3;
+        if (corner == DSA_INVALID || fvis[corner >> 2]) { --sp; continue; }
+        uint32_t face = corner >> 2;
         for (;;) {
           fvis[face] = 1;
-          uint32_t v = c2v[corner];
+          uint32_t v = frec[fv_idx(corner)];
           REQUIRE(v < NV, 301);
-          uint32_t rc = opp[cnext(corner)], lc = opp[cprev(corner)];
+          uint32_t rc = frec[fo_idx(qnext(corner))], lc = frec[fo_idx(qprev(corner))];
           if (!vvis[v]) {
             // IsOnBoundary: SwingLeft(LeftMostCorner(v)) == invalid (CornerTable.cs:174-178)
-            uint32_t lm = vcorner[v];
-            bool on_boundary = opp[cnext(lm)] == DSA_INVALID;
+            uint32_t lm = vrec[v].x;
+            bool on_boundary = frec[fo_idx(qnext(lm))] == DSA_INVALID;
             REQUIRE(count < L.cap_vertices, 302);
             VISIT(v, corner);
-            if (!on_boundary) { corner = rc; REQUIRE(corner != DSA_INVALID, 303); face = corner / 3; continue; }
+            if (!on_boundary) { corner = rc; REQUIRE(corner != DSA_INVALID, 303); face = corner >> 2; continue; }
           }
-          bool rdone = rc == DSA_INVALID || fvis[rc / 3];
-          bool ldone = lc == DSA_INVALID || fvis[lc / 3];
+          bool rdone = rc == DSA_INVALID || fvis[rc >> 2];
+          bool ldone = lc == DSA_INVALID || fvis[lc >> 2];
           if (rdone) {
             if (ldone) { --sp; break; }
-            corner = lc; face = lc / 3;
+            corner = lc; face = lc >> 2;
           } else {
-            if (ldone) { corner = rc; face = rc / 3; }
+            if (ldone) { corner = rc; face = rc >> 2; }
             else { REQUIRE(sp < stack_cap, 304); stack[sp - 1] = lc; stack[sp++] = rc; break; }
           }
         }
@@ -863,7 +1082,7 @@ __global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const Mes
   const MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK) return;
   const MeshLayout &L = layouts[mesh];
-  const uint32_t *opp = (const uint32_t *)(arena + L.opp), *c2v = (const uint32_t *)(arena + L.c2v);
+  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
   const uint32_t *d2c = (const uint32_t *)(arena + L.d2c);
   const int32_t *v2d = (const int32_t *)(arena + L.v2d);
   uint32_t *para = (uint32_t *)(arena + L.para);
@@ -871,9 +1090,11 @@ __global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const Mes
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < entries; p += gridDim.x * blockDim.x) {
     uint32_t en = DSA_INVALID, ep = 0, eo = 0;
     if (p > 0) {
-      uint32_t oci = opp[d2c[p]];
+      uint32_t oci = frec[fo_idx(d2c[p])];
       if (oci != DSA_INVALID) {
-        int32_t vo = v2d[c2v[oci]], vn = v2d[c2v[cnext(oci)]], vp = v2d[c2v[cprev(oci)]];
+        const uint32_t *fr = frec + 8 * (oci >> 2);
+        const uint32_t k = oci & 3u;
+        int32_t vo = v2d[fr[k]], vn = v2d[fr[k == 2 ? 0 : k + 1]], vp = v2d[fr[k == 0 ? 2 : k - 1]];
         if (vo >= 0 && vn >= 0 && vp >= 0 && (uint32_t)vo < p && (uint32_t)vn < p && (uint32_t)vp < p) { en = (uint32_t)vn; ep = (uint32_t)vp; eo = (uint32_t)vo; }
       }
     }
@@ -889,7 +1110,7 @@ __global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const Mes
 // stream offset are wave-uniform; the cumulative-frequency table is spread over the
 // lanes (first 64 boundaries in a register, the rest in LDS) and a symbol is found with
 // one or two ballot+popcount steps instead of the reference's 2^precision-entry LUT.
-__device__ void rans_decode_wave(MeshDesc *D, const uint8_t *stream, uint32_t stream_len, const AttrDesc &a, uint32_t num_values,
+__device__ __forceinline__ void rans_decode_wave(MeshDesc *D, const uint8_t *stream, uint32_t stream_len, const AttrDesc &a, uint32_t num_values,
                                  uint32_t *out, uint32_t *lds_cum) {
   const uint32_t lane = lane_id();
   const uint32_t nsym = a.num_symbols;
@@ -966,7 +1187,7 @@ __device__ void rans_decode_wave(MeshDesc *D, const uint8_t *stream, uint32_t st
 }
 
 // Generic (large alphabet) fallback: cumulative table in global scratch, lane 0, binary search.
-__device__ void rans_decode_serial(MeshDesc *D, const uint8_t *stream, uint32_t stream_len, const AttrDesc &a, uint32_t num_values,
+__device__ __forceinline__ void rans_decode_serial(MeshDesc *D, const uint8_t *stream, uint32_t stream_len, const AttrDesc &a, uint32_t num_values,
                                    uint32_t *out, uint32_t *cum /* nsym+1 entries of global scratch */) {
   if (threadIdx.x != 0) return;
   const uint32_t nsym = a.num_symbols, P = a.precision_bits, precision = 1u << P, l_base = precision * 4;
@@ -992,8 +1213,13 @@ __device__ void rans_decode_serial(MeshDesc *D, const uint8_t *stream, uint32_t 
   }
 }
 
+// Launched once per tier so that the LDS footprint of the cumulative table does not cap occupancy:
+//   TIER 0: alphabets <= 64 (table in one register per lane) + tagged / fixed-width sources
+//   TIER 1: alphabets <= 960      TIER 2: alphabets <= SYM_MAX_LDS and the large-alphabet fallback
+template <int TIER>
 __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
-  __shared__ uint32_t lds_cum[SYM_MAX_LDS + WAVE + 1];
+  constexpr uint32_t LDS_SYMS = TIER == 0 ? 64 : (TIER == 1 ? 960 : SYM_MAX_LDS);
+  __shared__ uint32_t lds_cum[LDS_SYMS + WAVE + 1];
   uint32_t mesh = blockIdx.x, ai = blockIdx.y;
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
@@ -1001,6 +1227,11 @@ __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayo
   const MeshLayout &L = layouts[mesh];
   const AttrDesc &a = D->att[ai];
   if (a.source == SRC_BYTES) return;
+  {
+    const uint32_t ns = a.source == SRC_RAW ? a.num_symbols : 0u;
+    const int tier = ns <= 64 ? 0 : (ns <= 960 ? 1 : 2);
+    if (tier != TIER) return;
+  }
   const uint8_t *s = arena + L.stream;
   uint32_t *work = (uint32_t *)(arena + L.work[ai]);
   const uint32_t lane = lane_id();
@@ -1211,13 +1442,14 @@ __global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayo
   }
   // faces as point ids (Mesh.cs faces; MeshEdgeBreakerDecoder.cs:537-553,627-637) and the
   // point -> entry map (MeshTraversalSequencer.cs:33-50; vertex attributes on the position corner table)
-  const uint32_t *c2v = (const uint32_t *)(arena + L.c2v);
+  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
   const uint32_t *vrank = (const uint32_t *)(arena + L.vrank);
   const int32_t *v2d = (const int32_t *)(arena + L.v2d);
   int32_t *faces = (int32_t *)(arena + L.faces);
   uint32_t *map = (uint32_t *)(arena + L.map[ai]);
   for (uint32_t c = tid; c < 3 * D->num_faces; c += stride) {
-    uint32_t v = c2v[c];
+    uint32_t f = c / 3u, k = c - 3u * f;
+    uint32_t v = frec[8 * f + k];
     uint32_t point = vrank[v];
     if (ai == 0) faces[c] = (int32_t)point;
     map[point] = (uint32_t)v2d[v];

@@ -68,6 +68,7 @@ struct MeshDesc {
   uint32_t num_vertices;   // corner-table vertices incl. isolated ones
   uint32_t num_points;
   uint32_t num_entries;    // traversal length
+  uint32_t dbg[12];        // shader-clock deltas between phases of the per-mesh kernels (diagnostics)
   AttrDesc att[DSA_MAX_ATT];
 };
 
@@ -87,9 +88,8 @@ struct MeshLayout {
   uint32_t cap_faces;      // F from the header
   uint32_t cap_vertices;   // num_encoded_vertices + num_split_symbols
   uint32_t cap_attributes;
-  uint64_t opp, c2v;       // u32[3F]
-  uint64_t vcorner;        // u32[cap_vertices]
-  uint64_t vhole;          // u8[cap_vertices]
+  uint64_t frec;           // face records, 32 B each: {v0, v1, v2, flags, o0, o1, o2, 0}; corners are quad coded (4*face + k)
+  uint64_t vrec;           // uint2[cap_vertices]: .x left-most corner of the vertex, .y vertex at Previous(left-most corner)
   uint64_t d2c;            // u32[cap_vertices]
   uint64_t v2d;            // i32[cap_vertices]
   uint64_t fvis, vvis;     // u8[F], u8[cap_vertices]

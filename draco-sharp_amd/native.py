@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_DIR, "libdraco_mi355x.so")
+LIB_PATH = os.environ.get("DSA_LIB") or os.path.join(_DIR, "libdraco_mi355x.so")   # DSA_LIB: kernel-ablation builds
 
 DSA_OK, DSA_ERR_INVALID_DATA, DSA_ERR_NOT_IMPLEMENTED, DSA_ERR_INVALID_ARGUMENT, DSA_ERR_DEVICE, DSA_ERR_OUT_OF_MEMORY = range(6)
 DSA_NUM_STAGES = 8

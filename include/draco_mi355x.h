@@ -129,7 +129,8 @@ const void *dsa_batch_device_attribute_values(const dsa_batch *batch, uint32_t m
 const uint32_t *dsa_batch_device_point_map(const dsa_batch *batch, uint32_t mesh, uint32_t attribute);
 
 /* Diagnostics for the parity tests: intermediate products of the path.
- * what: 0 opposite[3F], 1 corner_to_vertex[3F], 2 data_to_corner[entries], 3 vertex_to_data[vertices]. */
+ * what: 0 opposite[3F], 1 corner_to_vertex[3F], 2 data_to_corner[entries], 3 vertex_to_data[vertices],
+ *       4 uint32[12] shader-clock deltas between kernel phases. */
 dsa_status dsa_batch_copy_debug(const dsa_batch *batch, uint32_t mesh, int what, void *dst, size_t dst_bytes, size_t *written);
 
 /* Per-stage device time of the last dsa_batch_decode, in ms (HIP events on the

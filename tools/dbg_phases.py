@@ -1,0 +1,10 @@
+import sys; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import numpy as np, draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
+n = int(sys.argv[1]) if len(sys.argv)>1 else 512
+blob, offs = synth.make_batch(synth.GRID,128,256,1000,n)
+ctx = dsa.Context(0); ctx.set_profiling(True)
+b = dsa.Batch(ctx, blob=blob, offsets=offs)
+for _ in range(2): b.decode()
+print({k: round(v,2) for k,v in b.stage_times().items()})
+d = np.array([b.debug_array(i,4,np.uint32,12) for i in range(0,n,max(1,n//16))])
+print("dbg clocks (median over sampled meshes) x1e6:", np.round(np.median(d,axis=0)/1e6,2)); print("raw median:", np.median(d,axis=0).astype(int))
