@@ -59,6 +59,8 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ uint64_t clk() { return __builtin_amdgcn_s_memtime(); }
+// number of leading lanes (from lane 0) whose predicate is set
+__device__ __forceinline__ uint32_t leading_lanes(bool pred) { uint64_t m = ~__ballot(pred); return m ? (uint32_t)__builtin_ctzll(m) : 64u; }
 // s_waitcnt vmcnt(0) only (expcnt/lgkmcnt left at max).  On gfx950 loads and stores share vmcnt, so a
 // load consumed at a loop merge point makes the compiler drain every outstanding store each iteration;
 // rare loads are therefore completed inside their own branch with this.
@@ -533,6 +535,8 @@ __device__ __forceinline__ uint32_t qprev(uint32_t c) { return (c & 3u) == 0u ? 
 __device__ __forceinline__ uint32_t fv_idx(uint32_t c) { return 2u * c - (c & 3u); }        // dword index of the vertex slot
 __device__ __forceinline__ uint32_t fo_idx(uint32_t c) { return 2u * c - (c & 3u) + 4u; }   // dword index of the opposite slot
 
+// Runs of the strip pattern (C R)^k are retired up to 64 pairs per step (see cr_run below); everything
+// else goes through the scalar machine.
 // k_connectivity runs the Edgebreaker stack machine on wave-uniform state: every lane executes the same
 // scalar program (values broadcast with readfirstlane live in SGPRs, branches are scalar, no exec-mask
 // juggling), because with one wave per mesh the chip is instruction-issue bound and the per-symbol path
@@ -640,8 +644,8 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
 #define REC_HIT(v_) (TAG(((v_) >> 6) & (CN_REC_BLOCKS - 1)) == ((v_) >> 6))
 #define REC_STORE(v_, hit_, lm_, nv_)                                                                         \
   { if (hit_) *(uint2 *)&sh_rec[((((v_) >> 6) & (CN_REC_BLOCKS - 1)) * 64 + ((v_) & 63u)) * 2] = make_uint2((lm_), (nv_)); \
-    else vrec[(v_)] = make_uint2((lm_), (nv_)); }
-#define REC_DIRTY(v_, hit_) { if (hit_) dirty |= 1u << (((v_) >> 6) & (CN_REC_BLOCKS - 1)); }
+    vrec[(v_)] = make_uint2((lm_), (nv_)); }   /* write-through: global memory is always current */
+#define REC_DIRTY(v_, hit_) {}
   // opposite slot of corner c: staged or already in global memory
 #define SET_OPP(c_, val_)                                                                \
   { if ((c_) >= 4 * stage_base) sh_stage[fo_idx(c_) - 8 * stage_base] = (val_);          \
@@ -675,6 +679,97 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
     if (sid - stage_base == CN_STAGE) flush_stage(sid);
 #ifdef DSA_LOOP_PROFILE
     { uint32_t dummy = 0; PROF(acc_fetch, dummy); }
+#endif
+#ifndef DSA_NO_CR_RUNS
+    // ---------------------------------------------------------------- (C R)^k run, up to 64 pairs per step
+    // Symbol bits of "C R" are 0,1,0,1 (LSB first): a run is a string of 0xA nibbles.  Pair j closes old
+    // boundary vertex vx_j and creates vertex nv0+j.  vx_{j+1} is the vertex stored behind vx_j's left-most
+    // corner; along a regular strip these ids are consecutive, which each lane verifies on its own record.
+    // Then every face record, opposite link and vertex record of the run is a closed form of j.
+    if (have_top && bcnt >= 16 && ((uint32_t)bb & 0xFFFFu) == 0xAAAAu) {
+      // candidate pairs: nibbles still in the bit buffer, then in the LDS window
+      const uint32_t buf_pairs = bcnt >> 2;
+      uint32_t nib;
+      {
+        const uint32_t bitoff = 4 * lane;
+        if (lane < buf_pairs) nib = (uint32_t)(bb >> bitoff) & 0xFu;
+        else {
+          // bits beyond the buffer start at window dword widx (bit 0) -- only when the buffer holds whole nibbles
+          const uint32_t rel = bitoff - (bcnt & ~3u);
+          const uint32_t wi = widx - wbase + (rel >> 5);
+          nib = ((bcnt & 3u) == 0 && drop_bits == 0 && wi < CN_WIN) ? ((sh_win[wi] >> (rel & 31u)) & 0xFu) : 0u;
+        }
+      }
+      uint32_t cand = leading_lanes(nib == 0xAu);       // leading 0xA nibbles
+      if (2 * cand > num_symbols - sid) cand = (num_symbols - sid) / 2;
+      if (cand > VMAX - num_verts) cand = VMAX - num_verts;
+      if (splits_left > 0) {               // stop before the symbol that carries the next topology-split event
+        const uint32_t sid_evt = num_symbols - 1 - next_src;
+        if (sid_evt < sid + 2 * cand) cand = sid_evt > sid ? (sid_evt - sid) / 2 : 0;
+      }
+      if (cand >= 4) {
+        flush_stage(sid);                  // the run writes face records straight to global memory
+        WAIT_VM0();
+        const uint32_t f0 = sid, nv0 = num_verts;
+        const uint32_t vx0 = T1, va0 = T2;
+        const uint2 r0 = vrec[vx0];
+        const int32_t delta = (int32_t)uni(r0.y) - (int32_t)vx0;
+        uint32_t k = 0;
+        uint2 rj = make_uint2(DSA_INVALID, DSA_INVALID);
+        uint32_t vxj = 0;
+        if (delta == 1 || delta == -1) {
+          const int64_t id = (int64_t)vx0 + (int64_t)delta * (int64_t)lane;
+          const bool idok = lane < cand && id >= 0 && id < (int64_t)nv0 && (uint32_t)id != va0;
+          vxj = (uint32_t)id;
+          if (idok) rj = vrec[vxj];
+          const uint32_t prev_nv = __shfl_up(rj.y, 1, 64);
+          // own record must be sane, and the previous pair must hand over exactly this vertex
+          bool ok = idok && rj.x < 4 * f0 && (rj.x & 3u) != 3u && rj.y < nv0 && rj.y != vxj && (lane == 0 || prev_nv == vxj);
+          k = leading_lanes(ok);
+        }
+        if (k >= 2) {
+          if (lane < k) {
+            const uint32_t j = lane;
+            const uint32_t fc = f0 + 2 * j, fr = fc + 1;                 // faces of C_j and R_j
+            const uint32_t cc = 4 * fc, cr = 4 * fr;                     // their corner 0
+            const uint32_t vb = rj.y, cb = qnext(rj.x);
+            const uint32_t va = j == 0 ? va0 : nv0 + j - 1, nvj = nv0 + j;
+            // C_j: face (vx, vb, va), opposites (R_j corner 2, previous face corner 0, cb)
+            ((uint4 *)frec)[(size_t)fc * 2] = make_uint4(vxj, vb, va, 0u);
+            ((uint4 *)frec)[(size_t)fc * 2 + 1] = make_uint4(cr + 2, cc - 4, cb, 0u);
+            // R_j: face (va, vb, nv), opposites (next C corner 1 | open, open, C_j corner 0)
+            ((uint4 *)frec)[(size_t)fr * 2] = make_uint4(va, vb, nvj, 0u);
+            ((uint4 *)frec)[(size_t)fr * 2 + 1] = make_uint4(j + 1 < k ? cr + 4 + 1 : DSA_INVALID, DSA_INVALID, cc, 0u);
+            frec[fo_idx(cb)] = cc + 2;                                   // old boundary edge now faces C_j corner 2
+            if (j == 0) frec[fo_idx(cc - 4)] = cc + 1;                   // the previous top faces C_0 corner 1
+            // vertex records after the run (the last SetLeftMostCorner of each vertex wins)
+            vrec[va] = make_uint2(cr, nvj);                              // R_j: left-most corner = R_j corner 0
+            if (j + 1 == k) vrec[nvj] = make_uint2(cr + 2, vb);          // later pairs overwrite this for j < k-1
+          }
+          // keep the LDS copy of touched record blocks coherent: drop them (write-through makes this safe)
+          {
+            const uint32_t b_lo = (va0 < nv0 ? va0 : nv0) >> 6, b_hi = (nv0 + k) >> 6;
+            if (lane < CN_REC_BLOCKS) { const uint32_t t = tagv; if (t != DSA_INVALID && ((t >= (nv0 >> 6) && t <= b_hi) || t == (va0 >> 6))) tagv = DSA_INVALID; }
+            (void)b_lo;
+          }
+          // advance the machine past 2k symbols
+          const uint32_t vb_last = rdlane(rj.y, k - 1);
+          T1 = vb_last; T2 = nv0 + k - 1;
+          num_verts = nv0 + k;
+          sid += 2 * k;
+          stage_base = sid;
+          bits_used += 4ull * k;
+          {                                 // consume 4k bits: first from the buffer, the rest from the window
+            uint32_t need = 4 * k;
+            if (need <= bcnt) { bb = need >= 64 ? 0 : bb >> need; bcnt -= need; }
+            else { need -= bcnt; bb = 0; bcnt = 0; widx += need >> 5; const uint32_t rem = need & 31u; if (rem) { const uint32_t wv = uni(sh_win[widx - wbase]); bb = (uint64_t)(wv >> rem); bcnt = 32 - rem; ++widx; } }
+          }
+          WAIT_VM0();
+          __syncthreads();
+          continue;
+        }
+      }
+    }
 #endif
     if (bcnt < 3) {                       // refill the bit buffer from the LDS window
       if (widx - wbase >= CN_WIN) {
@@ -1330,6 +1425,20 @@ __device__ __forceinline__ int32_t wrap_original(int32_t pred, int32_t corr, int
   return o;
 }
 
+// Wrap-transform schemes (Difference / Parallelogram + Wrap) are decoded 64 entries per step:
+//   * lane i owns entry p0+i.  Lane 0's prediction only uses finished entries and is computed with the
+//     reference's exact formula.  Lane i >= 1 joins the run if its prediction is "previous entry +
+//     (finished entry - finished entry)" (parallelogram whose Next or Previous operand is entry p-1, or
+//     the delta fallback), so that along the run   o[p] = adjust(o[p-1] + g[p] + corr[p]).
+//   * while no prediction is clamped this is a prefix sum modulo max_dif: one wave scan gives every
+//     o[p] of the run;
+//   * every lane then re-evaluates the reference's sequential step (clamp, add, single +-max_dif) from
+//     its neighbour's value and the run is cut at the first lane that disagrees -- so the result is the
+//     sequential result by induction, and each step finishes at least one entry.
+// The octahedral normal transform is decoded 64 entries per chunk with the corrections in registers
+// (readlane) and coalesced loads/stores; its step is a short scalar program.
+__device__ __forceinline__ uint32_t addmod(uint32_t a, uint32_t b, uint32_t m) { uint32_t r = a + b; return r >= m ? r - m : r; }
+
 __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   uint32_t mesh = blockIdx.x, ai = blockIdx.y;
   if (mesh >= n) return;
@@ -1337,50 +1446,121 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
   if (D->status != ST_OK || ai >= D->num_attributes) return;
   const AttrDesc &a = D->att[ai];
   if (!a.have_scheme || a.source == SRC_BYTES) return;
-  if (threadIdx.x != 0) return;
   const MeshLayout &L = layouts[mesh];
   int32_t *w = (int32_t *)(arena + L.work[ai]);
   const uint32_t nc = a.nc_portable, entries = a.num_entries;
+  const uint32_t lane = lane_id();
   if (entries == 0) return;
   if (a.pred_transform == 1) {
+    if (nc > 4) { if (lane == 0) fail(D, ST_NOTIMPL, 500); return; }
     const int32_t mn = a.wrap_min, mx = a.wrap_max, max_dif = 1 + mx - mn;
-    if (a.pred_method == 1) {
-      const uint32_t *para = (const uint32_t *)(arena + L.para);
-      for (uint32_t c = 0; c < nc; ++c) w[c] = wrap_original(0, w[c], mn, mx, max_dif);
-      for (uint32_t p = 1; p < entries; ++p) {
-        uint32_t en = para[3 * p];
-        if (en != DSA_INVALID) {
-          uint32_t ep = para[3 * p + 1], eo = para[3 * p + 2];
-          for (uint32_t c = 0; c < nc; ++c) {
-            int32_t pred = (int32_t)((uint32_t)w[en * nc + c] + (uint32_t)w[ep * nc + c] - (uint32_t)w[eo * nc + c]);
-            w[p * nc + c] = wrap_original(pred, w[p * nc + c], mn, mx, max_dif);
+    const uint32_t M = (uint32_t)max_dif;
+    const bool para_mode = a.pred_method == 1;
+    const uint32_t *para = (const uint32_t *)(arena + L.para);
+    uint32_t p0 = 0;
+    while (p0 < entries) {
+      const uint32_t p = p0 + lane;
+      const bool live = p < entries;
+      // operands: chain on p-1 plus (ga - gb), or a full prediction for lane 0
+      uint32_t en = DSA_INVALID, ep = 0, eo = 0;
+      if (live && para_mode && p > 0) { en = para[3 * p]; ep = para[3 * p + 1]; eo = para[3 * p + 2]; }
+      bool chain = false;       // lane can join the run
+      uint32_t ga = DSA_INVALID, gb = DSA_INVALID;   // finished entries: g = o[ga] - o[gb] (INVALID -> 0)
+      if (live && lane > 0) {
+        if (en == DSA_INVALID) chain = true;                                       // delta fallback: pred = o[p-1]
+        else if (en == p - 1 && ep < p0 && eo < p0) { chain = true; ga = ep; gb = eo; }
+        else if (ep == p - 1 && en < p0 && eo < p0) { chain = true; ga = en; gb = eo; }
+      }
+      // run = lane 0 + leading chain lanes
+      uint64_t not_chain = __ballot(!chain) & ~1ull;
+      uint32_t run = not_chain ? (uint32_t)__builtin_ctzll(not_chain) : WAVE;
+      if (p0 + run > entries) run = entries - p0;
+      const bool in_run = lane < run;
+      int32_t corr[4], g[4], o[4];
+      uint32_t red[4];
+#pragma unroll
+      for (uint32_t c = 0; c < 4; ++c) { corr[c] = 0; g[c] = 0; o[c] = 0; red[c] = 0; }
+      if (in_run) {
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) if (c < nc) corr[c] = w[p * nc + c];
+        if (lane == 0) {
+          // exact reference step for the first entry of the run
+          int32_t pred[4] = {0, 0, 0, 0};
+          if (p > 0) {
+            if (en != DSA_INVALID) {
+#pragma unroll
+              for (uint32_t c = 0; c < 4; ++c) if (c < nc) pred[c] = (int32_t)((uint32_t)w[en * nc + c] + (uint32_t)w[ep * nc + c] - (uint32_t)w[eo * nc + c]);
+            } else {
+#pragma unroll
+              for (uint32_t c = 0; c < 4; ++c) if (c < nc) pred[c] = w[(p - 1) * nc + c];
+            }
           }
-        } else {
-          for (uint32_t c = 0; c < nc; ++c) w[p * nc + c] = wrap_original(w[(p - 1) * nc + c], w[p * nc + c], mn, mx, max_dif);
+#pragma unroll
+          for (uint32_t c = 0; c < 4; ++c) if (c < nc) o[c] = wrap_original(pred[c], corr[c], mn, mx, max_dif);
+        } else if (ga != DSA_INVALID) {
+#pragma unroll
+          for (uint32_t c = 0; c < 4; ++c) if (c < nc) g[c] = (int32_t)((uint32_t)w[ga * nc + c] - (uint32_t)w[gb * nc + c]);
         }
       }
-    } else {   // Difference, PredictionSchemeDeltaDecoder.cs:23-37
-      int32_t prev[4] = {0, 0, 0, 0};
-      if (nc > 4) { fail(D, ST_NOTIMPL, 500); return; }
-      for (uint32_t p = 0; p < entries; ++p)
-        for (uint32_t c = 0; c < nc; ++c) { prev[c] = wrap_original(prev[c], w[p * nc + c], mn, mx, max_dif); w[p * nc + c] = prev[c]; }
+      // modular prefix sum of (g + corr) over lanes 1..run-1, seeded with lane 0's value
+#pragma unroll
+      for (uint32_t c = 0; c < 4; ++c) {
+        if (c >= nc) continue;
+        uint32_t x;
+        if (lane == 0) x = (uint32_t)(((int64_t)o[c] - mn) % (int64_t)M + ((((int64_t)o[c] - mn) % (int64_t)M) < 0 ? (int64_t)M : 0));
+        else { int64_t e = ((int64_t)g[c] + (int64_t)corr[c]) % (int64_t)M; if (e < 0) e += M; x = in_run ? (uint32_t)e : 0u; }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          uint32_t y = __shfl_up(x, d, 64);
+          if ((int)lane >= d) x = addmod(x, y, M);
+        }
+        red[c] = x;
+        if (lane > 0) o[c] = (int32_t)((uint32_t)mn + x);
+      }
+      // verify against the sequential step: pred = o[p-1] + g (uint32 arithmetic), clamp must be a no-op
+      bool good = true;
+#pragma unroll
+      for (uint32_t c = 0; c < 4; ++c) {
+        if (c >= nc) continue;
+        int32_t prev = __shfl_up(o[c], 1, 64);
+        if (lane > 0 && in_run) {
+          int32_t pred = (int32_t)((uint32_t)prev + (uint32_t)g[c]);
+          if (pred < mn || pred > mx || wrap_original(pred, corr[c], mn, mx, max_dif) != o[c]) good = false;
+        }
+      }
+      uint64_t bad = __ballot(in_run && !good);
+      if (bad) run = (uint32_t)__builtin_ctzll(bad);     // >= 1: lane 0 is always exact
+      if (lane < run) {
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) if (c < nc) w[p * nc + c] = o[c];
+      }
+      p0 += run;
     }
+    (void)para_mode;
   } else {
     // normal octahedron transforms are 2-component; only Difference reaches here (k_locate rejects the rest)
-    if (a.pred_method != 0) { fail(D, ST_NOTIMPL, 501); return; }
+    if (a.pred_method != 0) { if (lane == 0) fail(D, ST_NOTIMPL, 501); return; }
     OctParams o;
-    o.max_q = a.oct_max_q;
     int q = 32 - __clz(a.oct_max_q);
     int32_t max_value = (1 << q) - 2;
     o.center = max_value / 2;
     o.max_q = (1 << q) - 1;
-    bool canonical = a.pred_transform == 3;
+    const bool canonical = a.pred_transform == 3;
     int32_t ps = 0, pt = 0;
-    for (uint32_t p = 0; p < entries; ++p) {
-      int32_t os, ot;
-      oct_original(o, canonical, ps, pt, w[2 * p], w[2 * p + 1], os, ot);
-      w[2 * p] = os; w[2 * p + 1] = ot;
-      ps = os; pt = ot;
+    for (uint32_t p0 = 0; p0 < entries; p0 += WAVE) {
+      const uint32_t p = p0 + lane;
+      int2 cv = make_int2(0, 0);
+      if (p < entries) cv = ((const int2 *)w)[p];
+      int32_t rs = 0, rt = 0;
+      const uint32_t cnt = entries - p0 < WAVE ? entries - p0 : WAVE;
+      for (uint32_t i = 0; i < cnt; ++i) {
+        const int32_t c0 = (int32_t)rdlane((uint32_t)cv.x, i), c1 = (int32_t)rdlane((uint32_t)cv.y, i);
+        int32_t os, ot;
+        oct_original(o, canonical, ps, pt, c0, c1, os, ot);
+        if (lane == i) { rs = os; rt = ot; }
+        ps = os; pt = ot;
+      }
+      if (p < entries) ((int2 *)w)[p] = make_int2(rs, rt);
     }
   }
 }
