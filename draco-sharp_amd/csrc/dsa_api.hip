@@ -118,7 +118,7 @@ struct dsa_context {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;     // symbol decode runs here, concurrently with connectivity + traversal
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_conn = nullptr;
   bool own_stream = false;
   bool profiling = false;
   std::string err;
@@ -274,7 +274,8 @@ dsa_status dsa_context_create(int device, void *stream, dsa_context **out) {
   }
   if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_conn, hipEventDisableTiming) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
   *out = c;
   return DSA_OK;
 }
@@ -284,6 +285,7 @@ void dsa_context_destroy(dsa_context *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_conn) (void)hipEventDestroy(ctx->ev_conn);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -345,8 +347,12 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   hipLaunchKernelGGL(dsa::k_symbols<0>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
   hipLaunchKernelGGL(dsa::k_symbols<2>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[1], st2));
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_join, st2));
   hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+  // link symmetry + seam streams are checked on the second stream while the traversal runs here
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st));
+  HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_conn, 0));
+  hipLaunchKernelGGL(dsa::k_conn_checks, dim3(n), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_join, st2));
   HIP_TRY(ctx, mark());
   hipLaunchKernelGGL(dsa::k_traverse, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, mark());

@@ -1025,45 +1025,8 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
   const uint32_t NVALL = num_verts;
   const uint64_t t_tail = clk();
 
-  // ---- every opposite link must be mutual ("corner already has an opposite", :254,272,314,392) and in range
-  {
-    uint32_t bad = 0;
-    for (uint32_t f = lane; f < F; f += WAVE) {
-      const uint4 vv = ((const uint4 *)frec)[(size_t)f * 2], oo = ((const uint4 *)frec)[(size_t)f * 2 + 1];
-      const uint32_t ov[3] = {oo.x, oo.y, oo.z};
-      for (uint32_t k = 0; k < 3; ++k) {
-        uint32_t o = ov[k];
-        if (o != DSA_INVALID && (o >= 4 * F || (o & 3u) == 3u || frec[fo_idx(o)] != 4 * f + k)) bad = 1;
-      }
-      if (vv.x >= NV || vv.y >= NV || vv.z >= NV) bad = 1;
-    }
-    if (__ballot(bad)) { if (lane == 0) fail(D, ST_INVALID, 263); return; }
-  }
   const uint64_t t_sym = clk();
-  // ---- attribute seams (MeshEdgeBreakerDecoder.cs:502-535): lane i decodes the rABS
-  // stream of attribute data i.  Only seam-free attribute connectivity is handled on
-  // the device; any set bit is reported as not implemented.
   const uint32_t nad = D->num_att_data;
-  if (nad > 0) {
-    uint32_t interior_corners = 0;   // one seam bit per interior edge and attribute data
-    for (uint32_t f = lane; f < F; f += WAVE) {
-      const uint4 oo = ((const uint4 *)frec)[(size_t)f * 2 + 1];
-      interior_corners += (oo.x != DSA_INVALID) + (oo.y != DSA_INVALID) + (oo.z != DSA_INVALID);
-    }
-    for (int d = 32; d >= 1; d >>= 1) interior_corners += __shfl_xor(interior_corners, d, 64);
-    uint32_t edges = interior_corners / 2;
-    uint32_t any = 0;
-    if (lane < nad) {
-      Rabs rb;
-      uint32_t endp;
-      rb.start(s, L.stream_len, D->off_seams[lane], &endp);
-      if (!rb.ok) any = 2;
-      else for (uint32_t i = 0; i < edges; ++i) any |= rb.next();
-    }
-    uint64_t bad = __ballot(any == 2), seam = __ballot(any == 1);
-    if (bad) { if (lane == 0) fail(D, ST_INVALID, 260); return; }
-    if (seam) { if (lane == 0) fail(D, ST_NOTIMPL, 261); return; }
-  }
   const uint64_t t_seam = clk();
   // ---- vertex -> point id (AssignPointsToCorners, :537-638, seam-free case):
   // single connectivity: point == vertex; per-attribute connectivity: rank among vertices that own a corner.
@@ -1086,6 +1049,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
   if (lane == 0) {
     D->dbg[0] = (uint32_t)(t_loop - t_start); D->dbg[1] = (uint32_t)(t_tail - t_loop); D->dbg[2] = (uint32_t)(t_sym - t_tail);
     D->dbg[3] = (uint32_t)(t_seam - t_sym); D->dbg[4] = (uint32_t)(clk() - t_seam);
+    D->num_all_vertices = NVALL;
 #ifdef DSA_LOOP_PROFILE
     D->dbg[5] = (uint32_t)(acc_c / (n_c ? n_c : 1)); D->dbg[6] = (uint32_t)(acc_rl / (n_rl ? n_rl : 1));
     D->dbg[7] = (uint32_t)(acc_fetch / (n_c + n_rl + 1)); D->dbg[8] = n_c; D->dbg[9] = n_rl;
@@ -1100,9 +1064,97 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
 }
 
 // =========================================================================
-// k_traverse: depth-first attribute sequencing on the position corner table.
+// k_conn_checks: validation that does not gate the traversal, run on the second stream:
+//  * every opposite link must be mutual ("corner already has an opposite",
+//    MeshEdgeBreakerDecoder.cs:254,272,314,392) and every vertex id in range;
+//  * attribute seams (MeshEdgeBreakerDecoder.cs:502-535): lane i decodes the rABS stream of attribute
+//    data i.  Only seam-free attribute connectivity is handled on the device; a set bit is reported
+//    as not implemented.
 // =========================================================================
+__global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  uint32_t mesh = blockIdx.x;
+  if (mesh >= n) return;
+  const MeshLayout &L = layouts[mesh];
+  MeshDesc *D = &descs[mesh];
+  if (status_of(D) != ST_OK) return;
+  const uint8_t *s = arena + L.stream;
+  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
+  const uint32_t F = D->num_faces, NV = D->num_vertices;
+  const uint32_t lane = lane_id();
+  const uint64_t t0 = clk();
+  uint32_t interior_corners = 0;
+  {
+    uint32_t bad = 0;
+    for (uint32_t f = lane; f < F; f += WAVE) {
+      const uint4 vv = ((const uint4 *)frec)[(size_t)f * 2], oo = ((const uint4 *)frec)[(size_t)f * 2 + 1];
+      const uint32_t ov[3] = {oo.x, oo.y, oo.z};
+#pragma unroll
+      for (uint32_t k = 0; k < 3; ++k) {
+        uint32_t o = ov[k];
+        if (o != DSA_INVALID) {
+          ++interior_corners;
+          if (o >= 4 * F || (o & 3u) == 3u || frec[fo_idx(o)] != 4 * f + k) bad = 1;
+        }
+      }
+      if (vv.x >= NV || vv.y >= NV || vv.z >= NV) bad = 1;
+    }
+    if (__ballot(bad)) { if (lane == 0) fail(D, ST_INVALID, 263); return; }
+  }
+  const uint64_t t1 = clk();
+  const uint32_t nad = D->num_att_data;
+  if (nad > 0) {
+    for (int d = 32; d >= 1; d >>= 1) interior_corners += __shfl_xor(interior_corners, d, 64);
+    const uint32_t edges = interior_corners / 2;   // one seam bit per interior edge and attribute data
+    uint32_t any = 0;
+    if (lane < nad) {
+      Rabs rb;
+      uint32_t endp;
+      rb.start(s, L.stream_len, D->off_seams[lane], &endp);
+      if (!rb.ok) any = 2;
+      else {
+        // AnsDecoder.cs:42-56, restructured so that the common case (no renormalisation) is a load-free loop
+        uint32_t state = rb.state, off = rb.off;
+        const uint32_t p = rb.p;
+        uint32_t i = 0;
+        while (i < edges) {
+          if (state < 4096 && off > 0) state = state * 256 + rb.buf[--off];
+          const uint32_t lim = edges;
+          do {
+            const uint32_t quot = state >> 8, rem = state & 255u, xn = quot * p;
+            const bool val = rem < p;
+            any |= val ? 1u : 0u;
+            state = val ? xn + rem : state - xn - p;
+            ++i;
+          } while (i < lim && (state >= 4096 || off == 0));
+        }
+      }
+    }
+    uint64_t bad = __ballot(any == 2), seam = __ballot(any == 1);
+    if (bad) { if (lane == 0) fail(D, ST_INVALID, 260); return; }
+    if (seam) { if (lane == 0) fail(D, ST_NOTIMPL, 261); return; }
+  }
+  if (lane == 0) { D->dbg[10] = (uint32_t)(t1 - t0); D->dbg[11] = (uint32_t)(clk() - t1); }
+}
+
+// =========================================================================
+// k_traverse: depth-first attribute sequencing on the position corner table
+// (DepthFirstTraverser.cs:9-99 + MeshAttributeIndicesEncodingObserver.cs:14-21 +
+// MeshTraversalSequencer.cs:13-31).  One wave per mesh, wave-uniform DFS state.
+//
+// The DFS mostly marches along triangle strips whose faces were created consecutively by the
+// connectivity decoder, so a step first *speculates* that the next faces are g0, g0+d, g0+2d, ...
+// (d = +-1): lane i loads face record g0+i*d, derives the corner it would be entered through, and
+// evaluates the reference's decision at its own element (tip new & interior -> right; tip visited ->
+// the single open side) against the faces/vertices visited before the step or earlier in the run.
+// The longest prefix of elements whose decision leads exactly to the next guessed face is retired at
+// once (face marks, new-vertex numbering by ballot prefix, coalesced d2c stores); everything else --
+// pushes, pops, boundary tips, irregular turns -- takes the scalar step, which is the reference's
+// loop body verbatim.  Either way each step is the sequential algorithm's result.
+// =========================================================================
+#define TR_TABLE 2048     // LDS slots for "first lane with this tip" (exact: indexed by vertex - min vertex of the run)
+
 __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  __shared__ uint32_t sh_first[TR_TABLE];
   uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
   const MeshLayout &L = layouts[mesh];
@@ -1112,61 +1164,205 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   const uint2 *vrec = (const uint2 *)(arena + L.vrec);
   uint32_t *d2c = (uint32_t *)(arena + L.d2c);
   int32_t *v2d = (int32_t *)(arena + L.v2d);
-  uint8_t *fvis = arena + L.fvis, *vvis = arena + L.vvis;
-  const uint32_t F = D->num_faces, NV = D->num_vertices;
+  uint8_t *fvis = arena + L.fvis;
+  uint8_t *vflag = arena + L.vvis;      // bit0 visited, bit1 on boundary
+  const uint32_t F = uni(D->num_faces), NV = uni(D->num_vertices), NVALL = uni(D->num_all_vertices);
   uint32_t *stack = (uint32_t *)(arena + L.faces);   // DFS stack: the faces output is only written by k_finalize
   const uint32_t stack_cap = 3 * F;
+  const uint32_t lane = lane_id();
+  const uint64_t t_start = clk();
 
-  for (uint32_t i = lane_id(); i < F; i += WAVE) fvis[i] = 0;
-  for (uint32_t i = lane_id(); i < L.cap_vertices; i += WAVE) { vvis[i] = 0; v2d[i] = -1; }
+  // ---- init (lane parallel): visited flags, v2d = -1, IsOnBoundary per vertex (CornerTable.cs:174-178)
+  for (uint32_t i = lane; i < F; i += WAVE) fvis[i] = 0;
+  for (uint32_t v = lane; v < L.cap_vertices; v += WAVE) {
+    v2d[v] = -1;
+    uint8_t fl = 0;
+    if (v < NVALL) {
+      uint32_t lm = vrec[v].x;
+      if (lm != DSA_INVALID && lm < 4 * F && (lm & 3u) != 3u) fl = frec[fo_idx(qnext(lm))] == DSA_INVALID ? 2 : 0;
+    }
+    vflag[v] = fl;
+  }
+  for (uint32_t i = lane; i < TR_TABLE; i += WAVE) sh_first[i] = 0xFFFFFFFFu;
+  WAIT_VM0();
   __syncthreads();
+  const uint64_t t_init = clk();
 
-  if (threadIdx.x == 0) {
-    uint32_t count = 0;
-#define VISIT(v, c) do { vvis[v] = 1; d2c[count] = (c); v2d[v] = (int32_t)count; ++count; } while (0)
-    for (uint32_t f0 = 0; f0 < F; ++f0) {
-      if (fvis[f0]) continue;
-      uint32_t corner = 4 * f0;
-      uint32_t sp = 0;
-      stack[sp++] = corner;
-      uint32_t nv = frec[fv_idx(qnext(corner))], pv = frec[fv_idx(qprev(corner))];
-      REQUIRE(nv < NV && pv < NV, 300);
-      if (!vvis[nv]) VISIT(nv, qnext(corner));
-      if (!vvis[pv]) VISIT(pv, qprev(corner));
-      while (sp > 0) {
-        corner = stack[sp - 1];
-        if (corner == DSA_INVALID || fvis[corner >> 2]) { --sp; continue; }
-        uint32_t face = corner >> 2;
-        for (;;) {
-          fvis[face] = 1;
-          uint32_t v = frec[fv_idx(corner)];
-          REQUIRE(v < NV, 301);
-          uint32_t rc = frec[fo_idx(qnext(corner))], lc = frec[fo_idx(qprev(corner))];
-          if (!vvis[v]) {
-            // IsOnBoundary: SwingLeft(LeftMostCorner(v)) == invalid (CornerTable.cs:174-178)
-            uint32_t lm = vrec[v].x;
-            bool on_boundary = frec[fo_idx(qnext(lm))] == DSA_INVALID;
-            REQUIRE(count < L.cap_vertices, 302);
-            VISIT(v, corner);
-            if (!on_boundary) { corner = rc; REQUIRE(corner != DSA_INVALID, 303); face = corner >> 2; continue; }
+  uint32_t count = 0, sp = 0, f_scan = 0;
+  int32_t dir = 1;            // last successful run direction
+  uint32_t backoff = 0;       // scalar steps to take before speculating again
+  uint32_t n_run = 0, n_run_faces = 0, n_scalar = 0;
+  bool failed = false;
+#define TR_FAIL(site) { if (lane == 0) fail(D, ST_INVALID, (site)); failed = true; break; }
+#define VISIT_SCALAR(v_, c_) { if (lane == 0) { vflag[v_] = (uint8_t)(uni_flag | 1u); d2c[count] = (c_); v2d[v_] = (int32_t)count; } ++count; }
+
+  for (;;) {
+    if (sp == 0) {
+      // next traversal start: first unvisited face at or after f_scan (MeshTraversalSequencer.cs:22-29)
+      uint32_t found = DSA_INVALID;
+      while (f_scan < F) {
+        uint32_t f = f_scan + lane;
+        uint64_t m = __ballot(f < F && fvis[f] == 0);
+        if (m) { found = f_scan + (uint32_t)__builtin_ctzll(m); break; }
+        f_scan += WAVE;
+      }
+      if (found == DSA_INVALID) break;
+      f_scan = found;
+      const uint32_t corner = 4 * found;
+      if (lane == 0) stack[0] = corner;
+      sp = 1;
+      // DepthFirstTraverser.cs:17-30: the two vertices of the start edge
+      const uint4 vv = ((const uint4 *)frec)[(size_t)found * 2];
+      const uint32_t nv = uni(vv.y), pv = uni(vv.z);       // Next(corner 0) = corner 1, Previous = corner 2
+      if (nv >= NV || pv >= NV) TR_FAIL(300);
+      { uint32_t uni_flag = uni((uint32_t)vflag[nv]); if (!(uni_flag & 1u)) { if (count >= L.cap_vertices) TR_FAIL(302); VISIT_SCALAR(nv, corner + 1); } }
+      WAIT_VM0();
+      { uint32_t uni_flag = uni((uint32_t)vflag[pv]); if (!(uni_flag & 1u)) { if (count >= L.cap_vertices) TR_FAIL(302); VISIT_SCALAR(pv, corner + 2); } }
+      WAIT_VM0();
+    }
+    uint32_t corner = uni(stack[sp - 1]);
+    if (corner == DSA_INVALID || corner >= 4 * F || uni((uint32_t)fvis[corner >> 2])) { --sp; continue; }
+
+    for (;;) {   // DepthFirstTraverser.cs:39-97 inner loop
+      // ------------------------------------------------------------------ speculative run
+      if (backoff == 0) {
+        uint32_t K = 0, new_corner = 0;
+        for (int attempt = 0; attempt < 2 && K < 2; ++attempt) {
+          const int32_t d = attempt == 0 ? dir : -dir;
+          const uint32_t g0 = corner >> 2;
+          const int64_t gi64 = (int64_t)g0 + (int64_t)d * (int64_t)lane;
+          const bool face_ok = gi64 >= 0 && gi64 < (int64_t)F;
+          const uint32_t g = face_ok ? (uint32_t)gi64 : g0;
+          const uint4 vv = ((const uint4 *)frec)[(size_t)g * 2], oo = ((const uint4 *)frec)[(size_t)g * 2 + 1];
+          const uint32_t vtx[3] = {vv.x, vv.y, vv.z}, opp3[3] = {oo.x, oo.y, oo.z};
+          // entry corner: the corner of g opposite the edge shared with the previous face of the run
+          const uint32_t gprev = g0 + (uint32_t)(d * ((int32_t)lane - 1));
+          uint32_t c = corner;
+          bool c_ok = face_ok;
+          if (lane > 0) {
+            uint32_t hits = 0, kk = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 3; ++k) if (opp3[k] != DSA_INVALID && (opp3[k] >> 2) == gprev) { ++hits; kk = k; }
+            c_ok = face_ok && hits == 1;
+            c = 4 * g + kk;
           }
-          bool rdone = rc == DSA_INVALID || fvis[rc >> 2];
-          bool ldone = lc == DSA_INVALID || fvis[lc >> 2];
-          if (rdone) {
-            if (ldone) { --sp; break; }
-            corner = lc; face = lc >> 2;
-          } else {
-            if (ldone) { corner = rc; face = rc >> 2; }
-            else { REQUIRE(sp < stack_cap, 304); stack[sp - 1] = lc; stack[sp++] = rc; break; }
+          const uint32_t kc = c & 3u;
+          const uint32_t tip = kc == 0 ? vtx[0] : (kc == 1 ? vtx[1] : vtx[2]);
+          const uint32_t rc = kc == 0 ? opp3[1] : (kc == 1 ? opp3[2] : opp3[0]);    // Opposite(Next(c))
+          const uint32_t lc = kc == 0 ? opp3[2] : (kc == 1 ? opp3[0] : opp3[1]);    // Opposite(Previous(c))
+          c_ok = c_ok && tip < NV && (rc == DSA_INVALID || rc < 4 * F) && (lc == DSA_INVALID || lc < 4 * F);
+          // state before the step
+          const uint32_t tflag = c_ok ? vflag[tip] : 0u;
+          const uint32_t f_before = (c_ok && lane > 0) ? fvis[g] : 0u;
+          const uint32_t r_before = (c_ok && rc != DSA_INVALID) ? fvis[rc >> 2] : 1u;
+          const uint32_t l_before = (c_ok && lc != DSA_INVALID) ? fvis[lc >> 2] : 1u;
+          // first lane of the run with the same tip (exact, via LDS indexed by tip - min tip)
+          uint32_t tmin = c_ok ? tip : 0xFFFFFFFFu;
+#pragma unroll
+          for (int sh = 32; sh >= 1; sh >>= 1) { uint32_t o2 = __shfl_xor(tmin, sh, 64); tmin = o2 < tmin ? o2 : tmin; }
+          const uint32_t slot = tip - tmin;
+          const bool slot_ok = c_ok && slot < TR_TABLE;
+          if (slot_ok) atomicMin(&sh_first[slot], lane);
+          __syncthreads();
+          const uint32_t first = slot_ok ? sh_first[slot] : 0u;
+          __syncthreads();
+          if (slot_ok) sh_first[slot] = 0xFFFFFFFFu;
+          const bool tip_seen = (tflag & 1u) || first < lane;
+          // faces of the run visited before element `lane` takes its decision: g0 .. g(lane)
+          auto in_run = [&](uint32_t cr) -> bool { if (cr == DSA_INVALID) return false; int64_t idx = ((int64_t)(cr >> 2) - (int64_t)g0) * d; return idx >= 0 && idx <= (int64_t)lane; };
+          const bool rdone = r_before != 0 || in_run(rc), ldone = l_before != 0 || in_run(lc);
+          // required move: 1 right, 2 left, 0 none (run ends here)
+          uint32_t need = 0;
+          if (slot_ok && f_before == 0) {
+            if (!tip_seen) need = (tflag & 2u) ? 0u : 1u;
+            else if (rdone && !ldone) need = 2u;
+            else if (!rdone && ldone) need = 1u;
           }
+          // actual move: the reference continues at Opposite(Next(c)) or Opposite(Previous(c)); it stays on the
+          // guessed path iff that corner is exactly the next lane's entry corner
+          const uint32_t c_next = __shfl_down(c, 1, 64);
+          const bool next_ok = __shfl_down(c_ok ? 1u : 0u, 1, 64) != 0 && lane < 63;
+          uint32_t actual = 0;
+          if (next_ok) actual = rc == c_next ? 1u : (lc == c_next ? 2u : 0u);
+          const bool done = need != 0 && need == actual;
+          const uint32_t Kc = leading_lanes(done);
+          if (Kc >= 2) {
+            K = Kc;
+            const bool mine = lane < K;
+            const bool is_new = mine && !tip_seen;
+            const uint64_t newmask = __ballot(is_new);
+            const uint32_t total_new = (uint32_t)__popcll(newmask);
+            if (count + total_new > L.cap_vertices) { K = 0; break; }
+            if (mine) fvis[g] = 1;
+            if (is_new) {
+              const uint32_t e = count + (uint32_t)__popcll(newmask & ((1ull << lane) - 1ull));
+              vflag[tip] = (uint8_t)(tflag | 1u);
+              d2c[e] = c;
+              v2d[tip] = (int32_t)e;
+            }
+            count += total_new;
+            new_corner = rdlane(c, K);       // lane K's entry corner (K <= 63 because lane 63 is never `done`)
+            dir = d;
+            n_run += 1; n_run_faces += K;
+            WAIT_VM0();
+            __syncthreads();
+          }
+        }
+        if (K >= 2) { corner = new_corner; continue; }
+        backoff = 3;
+      } else {
+        --backoff;
+      }
+      // ------------------------------------------------------------------ scalar step (reference loop body)
+      ++n_scalar;
+      const uint32_t face = corner >> 2;
+      const uint4 vv = ((const uint4 *)frec)[(size_t)face * 2], oo = ((const uint4 *)frec)[(size_t)face * 2 + 1];
+      const uint32_t kc = corner & 3u;
+      const uint32_t v = uni(kc == 0 ? vv.x : (kc == 1 ? vv.y : vv.z));
+      const uint32_t rc = uni(kc == 0 ? oo.y : (kc == 1 ? oo.z : oo.x));
+      const uint32_t lc = uni(kc == 0 ? oo.z : (kc == 1 ? oo.x : oo.y));
+      if (v >= NV || (rc != DSA_INVALID && rc >= 4 * F) || (lc != DSA_INVALID && lc >= 4 * F)) TR_FAIL(301);
+      if (lane == 0) fvis[face] = 1;
+      const uint32_t uni_flag = uni((uint32_t)vflag[v]);
+      if (!(uni_flag & 1u)) {
+        if (count >= L.cap_vertices) TR_FAIL(302);
+        VISIT_SCALAR(v, corner);
+        if (!(uni_flag & 2u)) {
+          if (rc == DSA_INVALID) TR_FAIL(303);
+          corner = rc;
+          WAIT_VM0();
+          continue;
+        }
+      }
+      const bool rdone = rc == DSA_INVALID || uni((uint32_t)fvis[rc >> 2]) != 0;
+      const bool ldone = lc == DSA_INVALID || uni((uint32_t)fvis[lc >> 2]) != 0;
+      WAIT_VM0();
+      if (rdone) {
+        if (ldone) { --sp; break; }
+        corner = lc;
+      } else {
+        if (ldone) corner = rc;
+        else {
+          if (sp >= stack_cap) TR_FAIL(304);
+          if (lane == 0) { stack[sp - 1] = lc; stack[sp] = rc; }
+          ++sp;
+          WAIT_VM0();
+          break;
         }
       }
     }
-#undef VISIT
-    D->num_entries = count;
-    // a valid stream carries exactly one entry per encoded vertex (k_locate sized the symbol streams on that)
-    REQUIRE(count == D->num_enc_vertices, 305);
+    if (failed) break;
   }
+  if (failed) return;
+  if (lane == 0) {
+    D->num_entries = count;
+    D->dbg[5] = (uint32_t)(t_init - t_start); D->dbg[6] = (uint32_t)(clk() - t_init);
+    D->dbg[7] = n_run; D->dbg[8] = n_run_faces; D->dbg[9] = n_scalar;
+    // a valid stream carries exactly one entry per encoded vertex (k_locate sized the symbol streams on that)
+    if (count != D->num_enc_vertices) fail(D, ST_INVALID, 305);
+  }
+#undef TR_FAIL
+#undef VISIT_SCALAR
 }
 
 // Parallelogram operands per entry (MeshPredictionSchemeParallelogramDecoder.cs:56-89):

@@ -65,7 +65,8 @@ struct MeshDesc {
   uint32_t num_decoders, num_attributes;
   uint32_t end_pos;
   // results
-  uint32_t num_vertices;   // corner-table vertices incl. isolated ones
+  uint32_t num_vertices;   // vertices after the reference's isolated-vertex compaction
+  uint32_t num_all_vertices;   // corner-table vertices incl. isolated ones
   uint32_t num_points;
   uint32_t num_entries;    // traversal length
   uint32_t dbg[12];        // shader-clock deltas between phases of the per-mesh kernels (diagnostics)
