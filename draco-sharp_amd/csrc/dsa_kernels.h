@@ -1151,31 +1151,39 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
 // pushes, pops, boundary tips, irregular turns -- takes the scalar step, which is the reference's
 // loop body verbatim.  Either way each step is the sequential algorithm's result.
 // =========================================================================
-#define TR_TABLE 2048     // LDS slots for "first lane with this tip" (exact: indexed by vertex - min vertex of the run)
-
-__global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
-  __shared__ uint32_t sh_first[TR_TABLE];
-  uint32_t mesh = blockIdx.x;
+// Lane-parallel preparation of the traversal state: visited flags, v2d = -1, IsOnBoundary per vertex
+// (CornerTable.cs:174-178), stamp arrays, and the successor table of the dominant march pattern
+// "tip new & interior -> right (N), then tip visited & right side done -> left (L)":
+//   jnl[c] = Opposite(Previous(Opposite(Next(c))))
+__global__ __launch_bounds__(256) void k_traverse_prep(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n) {
+  uint32_t mesh = blockIdx.y;
   if (mesh >= n) return;
-  const MeshLayout &L = layouts[mesh];
-  MeshDesc *D = &descs[mesh];
+  const MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK) return;
+  const MeshLayout &L = layouts[mesh];
   const uint32_t *frec = (const uint32_t *)(arena + L.frec);
   const uint2 *vrec = (const uint2 *)(arena + L.vrec);
-  uint32_t *d2c = (uint32_t *)(arena + L.d2c);
   int32_t *v2d = (int32_t *)(arena + L.v2d);
-  uint8_t *fvis = arena + L.fvis;
-  uint8_t *vflag = arena + L.vvis;      // bit0 visited, bit1 on boundary
-  const uint32_t F = uni(D->num_faces), NV = uni(D->num_vertices), NVALL = uni(D->num_all_vertices);
-  uint32_t *stack = (uint32_t *)(arena + L.faces);   // DFS stack: the faces output is only written by k_finalize
-  const uint32_t stack_cap = 3 * F;
-  const uint32_t lane = lane_id();
-  const uint64_t t_start = clk();
-
-  // ---- init (lane parallel): visited flags, v2d = -1, IsOnBoundary per vertex (CornerTable.cs:174-178)
-  for (uint32_t i = lane; i < F; i += WAVE) fvis[i] = 0;
-  for (uint32_t v = lane; v < L.cap_vertices; v += WAVE) {
+  uint8_t *fvis = arena + L.fvis, *vflag = arena + L.vvis;
+  uint32_t *jnl = (uint32_t *)(arena + L.jnl), *fstamp = (uint32_t *)(arena + L.fstamp), *vstamp = (uint32_t *)(arena + L.vstamp);
+  const uint32_t F = D->num_faces, NVALL = D->num_all_vertices;
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  for (uint32_t f = tid; f < F; f += stride) {
+    fvis[f] = 0;
+    fstamp[f] = 0xFFFFFFFFu;
+    const uint4 oo = ((const uint4 *)frec)[(size_t)f * 2 + 1];
+    const uint32_t ov[3] = {oo.x, oo.y, oo.z};
+    uint32_t j[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k) {
+      const uint32_t b = ov[k == 2 ? 0 : k + 1];       // Opposite(Next(corner k))
+      j[k] = (b != DSA_INVALID && b < 4 * F && (b & 3u) != 3u) ? frec[fo_idx(qprev(b))] : DSA_INVALID;
+    }
+    ((uint4 *)jnl)[f] = make_uint4(j[0], j[1], j[2], DSA_INVALID);
+  }
+  for (uint32_t v = tid; v < L.cap_vertices; v += stride) {
     v2d[v] = -1;
+    vstamp[v] = 0xFFFFFFFFu;
     uint8_t fl = 0;
     if (v < NVALL) {
       uint32_t lm = vrec[v].x;
@@ -1183,18 +1191,44 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
     }
     vflag[v] = fl;
   }
-  for (uint32_t i = lane; i < TR_TABLE; i += WAVE) sh_first[i] = 0xFFFFFFFFu;
-  WAIT_VM0();
-  __syncthreads();
-  const uint64_t t_init = clk();
+}
+
+// k_traverse speculation: from a corner whose tip is new and interior the DFS usually repeats
+// "N, L" (see k_traverse_prep).  The candidate path a_0, a_1 = jnl[a_0], ... is first extrapolated
+// (the corner ids along a regular strip or across the rings of a spiral follow a constant or linearly
+// changing step) and each lane verifies its own link jnl[a_(i-1)] == a_i; then lane i evaluates the
+// reference's two decisions of pair i against the faces / vertices visited before the step or earlier in
+// the run (exact membership through atomicMin stamps), and the leading pairs that all check out are
+// retired at once.  Everything else is the scalar step = the reference's loop body.
+#define TR_PAIRS 64
+
+__global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  uint32_t mesh = blockIdx.x;
+  if (mesh >= n) return;
+  const MeshLayout &L = layouts[mesh];
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK) return;
+  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
+  uint32_t *d2c = (uint32_t *)(arena + L.d2c);
+  int32_t *v2d = (int32_t *)(arena + L.v2d);
+  uint8_t *fvis = arena + L.fvis;
+  uint8_t *vflag = arena + L.vvis;      // bit0 visited, bit1 on boundary
+  const uint32_t *jnl = (const uint32_t *)(arena + L.jnl);
+  uint32_t *fstamp = (uint32_t *)(arena + L.fstamp), *vstamp = (uint32_t *)(arena + L.vstamp);
+  const uint32_t F = uni(D->num_faces), NV = uni(D->num_vertices);
+  uint32_t *stack = (uint32_t *)(arena + L.faces);   // DFS stack: the faces output is only written by k_finalize
+  const uint32_t stack_cap = 3 * F;
+  const uint32_t lane = lane_id();
+  const uint64_t t_start = clk();
 
   uint32_t count = 0, sp = 0, f_scan = 0;
-  int32_t dir = 1;            // last successful run direction
+  uint32_t run_id = 0;        // stamps of newer runs compare smaller, so atomicMin always replaces older ones
   uint32_t backoff = 0;       // scalar steps to take before speculating again
-  uint32_t n_run = 0, n_run_faces = 0, n_scalar = 0;
+  uint32_t n_run = 0, n_run_faces = 0, n_scalar = 0, n_fail = 0;
   bool failed = false;
 #define TR_FAIL(site) { if (lane == 0) fail(D, ST_INVALID, (site)); failed = true; break; }
 #define VISIT_SCALAR(v_, c_) { if (lane == 0) { vflag[v_] = (uint8_t)(uni_flag | 1u); d2c[count] = (c_); v2d[v_] = (int32_t)count; } ++count; }
+  auto corner_ok = [&](uint32_t c) -> bool { return c < 4 * F && (c & 3u) != 3u; };
 
   for (;;) {
     if (sp == 0) {
@@ -1224,106 +1258,111 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
     if (corner == DSA_INVALID || corner >= 4 * F || uni((uint32_t)fvis[corner >> 2])) { --sp; continue; }
 
     for (;;) {   // DepthFirstTraverser.cs:39-97 inner loop
-      // ------------------------------------------------------------------ speculative run
-      if (backoff == 0) {
-        uint32_t K = 0, new_corner = 0;
-        for (int attempt = 0; attempt < 2 && K < 2; ++attempt) {
-          const int32_t d = attempt == 0 ? dir : -dir;
-          const uint32_t g0 = corner >> 2;
-          const int64_t gi64 = (int64_t)g0 + (int64_t)d * (int64_t)lane;
-          const bool face_ok = gi64 >= 0 && gi64 < (int64_t)F;
-          const uint32_t g = face_ok ? (uint32_t)gi64 : g0;
-          const uint4 vv = ((const uint4 *)frec)[(size_t)g * 2], oo = ((const uint4 *)frec)[(size_t)g * 2 + 1];
-          const uint32_t vtx[3] = {vv.x, vv.y, vv.z}, opp3[3] = {oo.x, oo.y, oo.z};
-          // entry corner: the corner of g opposite the edge shared with the previous face of the run
-          const uint32_t gprev = g0 + (uint32_t)(d * ((int32_t)lane - 1));
-          uint32_t c = corner;
-          bool c_ok = face_ok;
-          if (lane > 0) {
-            uint32_t hits = 0, kk = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 3; ++k) if (opp3[k] != DSA_INVALID && (opp3[k] >> 2) == gprev) { ++hits; kk = k; }
-            c_ok = face_ok && hits == 1;
-            c = 4 * g + kk;
-          }
-          const uint32_t kc = c & 3u;
-          const uint32_t tip = kc == 0 ? vtx[0] : (kc == 1 ? vtx[1] : vtx[2]);
-          const uint32_t rc = kc == 0 ? opp3[1] : (kc == 1 ? opp3[2] : opp3[0]);    // Opposite(Next(c))
-          const uint32_t lc = kc == 0 ? opp3[2] : (kc == 1 ? opp3[0] : opp3[1]);    // Opposite(Previous(c))
-          c_ok = c_ok && tip < NV && (rc == DSA_INVALID || rc < 4 * F) && (lc == DSA_INVALID || lc < 4 * F);
-          // state before the step
-          const uint32_t tflag = c_ok ? vflag[tip] : 0u;
-          const uint32_t f_before = (c_ok && lane > 0) ? fvis[g] : 0u;
-          const uint32_t r_before = (c_ok && rc != DSA_INVALID) ? fvis[rc >> 2] : 1u;
-          const uint32_t l_before = (c_ok && lc != DSA_INVALID) ? fvis[lc >> 2] : 1u;
-          // first lane of the run with the same tip (exact, via LDS indexed by tip - min tip)
-          uint32_t tmin = c_ok ? tip : 0xFFFFFFFFu;
-#pragma unroll
-          for (int sh = 32; sh >= 1; sh >>= 1) { uint32_t o2 = __shfl_xor(tmin, sh, 64); tmin = o2 < tmin ? o2 : tmin; }
-          const uint32_t slot = tip - tmin;
-          const bool slot_ok = c_ok && slot < TR_TABLE;
-          if (slot_ok) atomicMin(&sh_first[slot], lane);
-          __syncthreads();
-          const uint32_t first = slot_ok ? sh_first[slot] : 0u;
-          __syncthreads();
-          if (slot_ok) sh_first[slot] = 0xFFFFFFFFu;
-          const bool tip_seen = (tflag & 1u) || first < lane;
-          // faces of the run visited before element `lane` takes its decision: g0 .. g(lane)
-          auto in_run = [&](uint32_t cr) -> bool { if (cr == DSA_INVALID) return false; int64_t idx = ((int64_t)(cr >> 2) - (int64_t)g0) * d; return idx >= 0 && idx <= (int64_t)lane; };
-          const bool rdone = r_before != 0 || in_run(rc), ldone = l_before != 0 || in_run(lc);
-          // required move: 1 right, 2 left, 0 none (run ends here)
-          uint32_t need = 0;
-          if (slot_ok && f_before == 0) {
-            if (!tip_seen) need = (tflag & 2u) ? 0u : 1u;
-            else if (rdone && !ldone) need = 2u;
-            else if (!rdone && ldone) need = 1u;
-          }
-          // actual move: the reference continues at Opposite(Next(c)) or Opposite(Previous(c)); it stays on the
-          // guessed path iff that corner is exactly the next lane's entry corner
-          const uint32_t c_next = __shfl_down(c, 1, 64);
-          const bool next_ok = __shfl_down(c_ok ? 1u : 0u, 1, 64) != 0 && lane < 63;
-          uint32_t actual = 0;
-          if (next_ok) actual = rc == c_next ? 1u : (lc == c_next ? 2u : 0u);
-          const bool done = need != 0 && need == actual;
-          const uint32_t Kc = leading_lanes(done);
-          if (Kc >= 2) {
-            K = Kc;
-            const bool mine = lane < K;
-            const bool is_new = mine && !tip_seen;
-            const uint64_t newmask = __ballot(is_new);
-            const uint32_t total_new = (uint32_t)__popcll(newmask);
-            if (count + total_new > L.cap_vertices) { K = 0; break; }
-            if (mine) fvis[g] = 1;
-            if (is_new) {
-              const uint32_t e = count + (uint32_t)__popcll(newmask & ((1ull << lane) - 1ull));
-              vflag[tip] = (uint8_t)(tflag | 1u);
-              d2c[e] = c;
-              v2d[tip] = (int32_t)e;
-            }
-            count += total_new;
-            new_corner = rdlane(c, K);       // lane K's entry corner (K <= 63 because lane 63 is never `done`)
-            dir = d;
-            n_run += 1; n_run_faces += K;
-            WAIT_VM0();
-            __syncthreads();
-          }
+      const uint32_t face = corner >> 2;
+      const uint4 vv0 = ((const uint4 *)frec)[(size_t)face * 2], oo0 = ((const uint4 *)frec)[(size_t)face * 2 + 1];
+      const uint32_t kc0 = corner & 3u;
+      const uint32_t v = uni(kc0 == 0 ? vv0.x : (kc0 == 1 ? vv0.y : vv0.z));
+      const uint32_t rc = uni(kc0 == 0 ? oo0.y : (kc0 == 1 ? oo0.z : oo0.x));
+      const uint32_t lc = uni(kc0 == 0 ? oo0.z : (kc0 == 1 ? oo0.x : oo0.y));
+      if (v >= NV || (rc != DSA_INVALID && !corner_ok(rc)) || (lc != DSA_INVALID && !corner_ok(lc))) TR_FAIL(301);
+      const uint32_t uni_flag = uni((uint32_t)vflag[v]);
+
+      // ------------------------------------------------------------------ speculative (N L)^k run
+      if (uni_flag == 0 && backoff == 0) {
+        ++run_id;
+        const uint32_t base = (0x00FFFFFFu - run_id) << 8;
+        // candidate path: three exact hops, then constant-second-difference extrapolation
+        const uint32_t a0 = corner;
+        const uint32_t a1 = uni(jnl[a0]);
+        const uint32_t a2 = corner_ok(a1) ? uni(jnl[a1]) : DSA_INVALID;
+        const uint32_t a3 = corner_ok(a2) ? uni(jnl[a2]) : DSA_INVALID;
+        int64_t ai;
+        {
+          const int64_t d1 = (int64_t)a1 - a0, d2 = (int64_t)a2 - a1, d3 = (int64_t)a3 - a2;
+          int64_t dd = d3 - d2;
+          if (d2 - d1 != dd) dd = 0;       // no regular step change: assume a constant step
+          const int64_t i = lane;
+          // a_i = a3 + (i-3)*d3 + dd*(i-3)*(i-2)/2 for i > 3
+          ai = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : lane == 3 ? a3 : (int64_t)a3 + (i - 3) * d3 + dd * (i - 3) * (i - 2) / 2;
         }
-        if (K >= 2) { corner = new_corner; continue; }
-        backoff = 3;
-      } else {
+        bool a_ok = ai >= 0 && ai < (int64_t)4 * F && ((uint32_t)ai & 3u) != 3u && corner_ok(a3);
+        if (lane < 4) a_ok = corner_ok((uint32_t)ai) || lane == 0;
+        const uint32_t a = a_ok ? (uint32_t)ai : 0u;
+        const uint32_t next_a = a_ok ? jnl[a] : DSA_INVALID;
+        {
+          const uint32_t prev_next = __shfl_up(next_a, 1, 64);
+          a_ok = a_ok && (lane == 0 || prev_next == a);
+        }
+        uint32_t len = leading_lanes(a_ok);                 // verified chain a_0 .. a_(len-1)
+        const bool in_chain = lane < len;
+        // pair `lane`: N element at a (face A), L element at b = Opposite(Next(a)) (face B)
+        const uint32_t fa = a >> 2, ka = a & 3u;
+        uint4 va = make_uint4(0, 0, 0, 0), oa = make_uint4(DSA_INVALID, DSA_INVALID, DSA_INVALID, 0);
+        if (in_chain) { va = ((const uint4 *)frec)[(size_t)fa * 2]; oa = ((const uint4 *)frec)[(size_t)fa * 2 + 1]; }
+        const uint32_t tipA = ka == 0 ? va.x : (ka == 1 ? va.y : va.z);
+        const uint32_t b = ka == 0 ? oa.y : (ka == 1 ? oa.z : oa.x);
+        const bool b_ok = in_chain && corner_ok(b) && tipA < NV;
+        const uint32_t fb = b >> 2, kb = b & 3u;
+        uint4 vb = make_uint4(0, 0, 0, 0), ob = make_uint4(DSA_INVALID, DSA_INVALID, DSA_INVALID, 0);
+        if (b_ok) { vb = ((const uint4 *)frec)[(size_t)fb * 2]; ob = ((const uint4 *)frec)[(size_t)fb * 2 + 1]; }
+        const uint32_t tipB = kb == 0 ? vb.x : (kb == 1 ? vb.y : vb.z);
+        const uint32_t rcB = kb == 0 ? ob.y : (kb == 1 ? ob.z : ob.x);
+        const uint32_t lcB = kb == 0 ? ob.z : (kb == 1 ? ob.x : ob.y);
+        const bool pair_ok = b_ok && tipB < NV && lcB == next_a && corner_ok(lcB) && (rcB == DSA_INVALID || corner_ok(rcB));
+        // stamps: first position of every face / tip in the candidate list
+        const uint32_t keyN = base | (2 * lane), keyL = base | (2 * lane + 1);
+        if (pair_ok) {
+          atomicMin(&fstamp[fa], keyN); atomicMin(&fstamp[fb], keyL);
+          atomicMin(&vstamp[tipA], keyN); atomicMin(&vstamp[tipB], keyL);
+        }
+        WAIT_VM0();
+        bool good = false;
+        if (pair_ok) {
+          const uint32_t sfa = __hip_atomic_load(&fstamp[fa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t sfb = __hip_atomic_load(&fstamp[fb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t sta = __hip_atomic_load(&vstamp[tipA], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t stb = __hip_atomic_load(&vstamp[tipB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t srf = rcB != DSA_INVALID ? __hip_atomic_load(&fstamp[rcB >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+          const uint32_t slf = __hip_atomic_load(&fstamp[lcB >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t fA_before = lane == 0 ? 0u : fvis[fa];
+          const uint32_t fB_before = fvis[fb];
+          const uint32_t fR_before = rcB != DSA_INVALID ? fvis[rcB >> 2] : 1u;
+          const uint32_t fL_before = fvis[lcB >> 2];
+          const uint32_t flA = vflag[tipA], flB = vflag[tipB];
+          // N element: face first seen here, tip new (not visited before, first seen here) and interior
+          const bool n_ok = fA_before == 0 && sfa == keyN && flA == 0 && sta == keyN;
+          // L element: face first seen here, tip already visited, right side done, left side open
+          const bool tipB_seen = (flB & 1u) || ((stb >> 8) == (base >> 8) && stb < keyL);
+          const bool r_done = fR_before != 0 || ((srf >> 8) == (base >> 8) && srf < keyL);
+          const bool l_open = fL_before == 0 && !((slf >> 8) == (base >> 8) && slf < keyL);
+          const bool l_ok = fB_before == 0 && sfb == keyL && tipB_seen && r_done && l_open;
+          good = n_ok && l_ok;
+        }
+        const uint32_t K = leading_lanes(good);
+        if (K >= 1 && count + K <= L.cap_vertices) {
+          if (lane < K) {
+            fvis[fa] = 1; fvis[fb] = 1;
+            vflag[tipA] = 1;
+            d2c[count + lane] = a;
+            v2d[tipA] = (int32_t)(count + lane);
+          }
+          const uint32_t nxt = rdlane(next_a, K - 1);          // Opposite(Previous(b_(K-1))): where the DFS continues
+          count += K;
+          corner = nxt;
+          n_run += 1; n_run_faces += 2 * K;
+          if (K < 4) backoff = 2;
+          WAIT_VM0();
+          continue;
+        }
+        ++n_fail;
+        backoff = 4;
+        (void)len;
+      } else if (backoff) {
         --backoff;
       }
       // ------------------------------------------------------------------ scalar step (reference loop body)
       ++n_scalar;
-      const uint32_t face = corner >> 2;
-      const uint4 vv = ((const uint4 *)frec)[(size_t)face * 2], oo = ((const uint4 *)frec)[(size_t)face * 2 + 1];
-      const uint32_t kc = corner & 3u;
-      const uint32_t v = uni(kc == 0 ? vv.x : (kc == 1 ? vv.y : vv.z));
-      const uint32_t rc = uni(kc == 0 ? oo.y : (kc == 1 ? oo.z : oo.x));
-      const uint32_t lc = uni(kc == 0 ? oo.z : (kc == 1 ? oo.x : oo.y));
-      if (v >= NV || (rc != DSA_INVALID && rc >= 4 * F) || (lc != DSA_INVALID && lc >= 4 * F)) TR_FAIL(301);
       if (lane == 0) fvis[face] = 1;
-      const uint32_t uni_flag = uni((uint32_t)vflag[v]);
       if (!(uni_flag & 1u)) {
         if (count >= L.cap_vertices) TR_FAIL(302);
         VISIT_SCALAR(v, corner);
@@ -1356,7 +1395,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   if (failed) return;
   if (lane == 0) {
     D->num_entries = count;
-    D->dbg[5] = (uint32_t)(t_init - t_start); D->dbg[6] = (uint32_t)(clk() - t_init);
+    D->dbg[5] = n_fail; D->dbg[6] = (uint32_t)(clk() - t_start);
     D->dbg[7] = n_run; D->dbg[8] = n_run_faces; D->dbg[9] = n_scalar;
     // a valid stream carries exactly one entry per encoded vertex (k_locate sized the symbol streams on that)
     if (count != D->num_enc_vertices) fail(D, ST_INVALID, 305);
