@@ -344,6 +344,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_fork, 0));
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[0], st2));
+  hipLaunchKernelGGL(dsa::k_symbols_reg, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
   hipLaunchKernelGGL(dsa::k_symbols<1>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
   hipLaunchKernelGGL(dsa::k_symbols<0>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
   hipLaunchKernelGGL(dsa::k_symbols<2>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
@@ -536,6 +537,14 @@ dsa_status dsa_batch_copy_debug(const dsa_batch *b, uint32_t mesh, int what, voi
       return DSA_OK;
     }
     case 3: off = L.v2d; bytes = 4ull * D.num_vertices; break;
+    case 5: {   // per attribute: {symbol source, alphabet size, rANS precision bits, rANS payload bytes}
+      size_t need = sizeof(uint32_t) * 4 * DSA_MAX_ATT;
+      if (dst_bytes < need) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "destination too small");
+      uint32_t *o = (uint32_t *)dst;
+      for (uint32_t a = 0; a < DSA_MAX_ATT; ++a) { o[4 * a] = D.att[a].source; o[4 * a + 1] = D.att[a].num_symbols; o[4 * a + 2] = D.att[a].precision_bits; o[4 * a + 3] = D.att[a].size_rans; }
+      if (written) *written = need;
+      return DSA_OK;
+    }
     case 4:   // phase clocks recorded by the kernels (host copy)
       if (dst_bytes < sizeof(D.dbg)) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "destination too small");
       memcpy(dst, D.dbg, sizeof(D.dbg));

@@ -1543,6 +1543,113 @@ __device__ __forceinline__ void rans_decode_serial(MeshDesc *D, const uint8_t *s
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Register-file rANS decode for 12-bit precision (what 8..11-bit quantised attributes produce):
+// the reference's 4096-entry slot -> symbol LUT (RAnsDecoder.cs:69-88) is kept in 32 VGPRs (two 16-bit
+// symbols per lane and register: slot r lives in register r>>7, lane (r>>1)&63, half r&1) and the
+// per-symbol {frequency, cumulative frequency} pairs in another 32 VGPRs (symbol s: register s>>6,
+// lane s&63).  A lookup is an M0-indexed register move plus v_readlane with wave-uniform indices, so the
+// serial state update never touches LDS or memory; LDS (8 KB) is only used to transpose the tables once.
+typedef uint32_t v32u __attribute__((ext_vector_type(32)));
+#define REG_MAX_SYMS 2048
+
+__global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  __shared__ uint32_t lds[REG_MAX_SYMS];   // probabilities -> packed {freq, cum}; then reused as u16 LUT[4096]
+  uint32_t mesh = blockIdx.x, ai = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || ai >= D->num_attributes) return;
+  const MeshLayout &L = layouts[mesh];
+  const AttrDesc &a = D->att[ai];
+  if (a.source != SRC_RAW || a.precision_bits != 12 || a.num_symbols > REG_MAX_SYMS || a.num_symbols <= 64) return;
+  const uint8_t *stream = arena + L.stream;
+  uint32_t *out = (uint32_t *)(arena + L.work[ai]);
+  const uint32_t lane = lane_id();
+  const uint32_t nsym = uni(a.num_symbols);
+  const uint32_t num_values = uni(a.num_entries) * a.nc_portable;
+  if (num_values == 0) return;
+  // 1. probability table -> LDS (lane 0), RAnsSymbolDecoder.cs:21-48
+  if (lane == 0) {
+    Rd r(stream, L.stream_len, a.off_table);
+    if (!read_prob_table(r, nsym, lds)) fail(D, ST_INVALID, 400);
+  }
+  __syncthreads();
+  if (status_of(D) != ST_OK) return;
+  // 2. cumulative frequencies; pack {freq << 12 | cum} (freq <= 4096, cum < 4096)
+  uint32_t carry = 0;
+  bool over = false;
+  for (uint32_t b0 = 0; b0 < REG_MAX_SYMS; b0 += WAVE) {
+    uint32_t i = b0 + lane;
+    uint32_t pr = i < nsym ? lds[i] : 0u;
+    if (pr > 4096) over = true;
+    uint32_t tot;
+    uint32_t ex = wave_excl_scan(pr, &tot);
+    lds[i] = (pr << 12) | ((carry + ex) & 4095u);
+    carry += tot;
+    if (carry > 4096) over = true;
+  }
+  if (__ballot(over) || carry != 4096) { if (lane == 0) fail(D, ST_INVALID, 401); return; }
+  __syncthreads();
+  v32u cf;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) cf[k] = lds[k * WAVE + lane];
+  __syncthreads();
+  // 3. slot -> symbol LUT, transposed through LDS as 16-bit entries
+  {
+    uint16_t *lut16 = (uint16_t *)lds;
+#pragma unroll 1
+    for (int k = 0; k < 32; ++k) {
+      const uint32_t e = cf[k], f = e >> 12, c = e & 4095u, sym = (uint32_t)k * WAVE + lane;
+      for (uint32_t j = 0; j < f; ++j) lut16[c + j] = (uint16_t)sym;
+    }
+  }
+  __syncthreads();
+  v32u lut;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) lut[k] = lds[k * WAVE + lane];
+  // 4. initial state from the stream tail, RAnsDecoder.cs:20-54
+  const uint8_t *buf = stream + a.off_rans;
+  uint32_t x, off;
+  {
+    uint32_t st = 0, o = 0;
+    bool ok = rans_init(buf, a.size_rans, 16384, &st, &o);
+    if (!ok) { if (lane == 0) fail(D, ST_INVALID, 402); return; }
+    x = uni(st); off = uni(o);
+  }
+  // byte window: lane l holds the dword at aligned byte (chunk*256 + 4l) of the stream
+  const uint32_t mis = (uint32_t)((L.stream + a.off_rans) & 3u);
+  const uint32_t *abuf = (const uint32_t *)(arena + (L.stream + a.off_rans - mis));
+  uint32_t chunk = 0x7FFFFFFFu, W = 0;
+  uint32_t mine = 0;
+  WAIT_VM0();
+  for (uint32_t i = 0; i < num_values; ++i) {
+    while (x < 16384 && off > 0) {           // RAnsDecoder.cs:58-61
+      --off;
+      const uint32_t q = off + mis, ch = q >> 8;
+      if (ch != chunk) { chunk = ch; W = abuf[(size_t)ch * 64 + lane]; WAIT_VM0(); }
+      const uint32_t byte = (rdlane(W, (q & 255u) >> 2) >> ((q & 3u) * 8)) & 0xFFu;
+      x = (x << 8) | byte;
+    }
+    const uint32_t rem = x & 4095u;
+    const uint32_t pair = rdlane(lut[rem >> 7], (rem >> 1) & 63u);
+    const uint32_t sym = (rem & 1u) ? pair >> 16 : pair & 0xFFFFu;
+    const uint32_t e = rdlane(cf[sym >> 6], sym & 63u);
+    x = (e >> 12) * (x >> 12) + rem - (e & 4095u);      // RAnsDecoder.cs:62-65
+    if ((i & 63u) == lane) mine = sym;
+    if ((i & 63u) == 63u) out[i - 63u + lane] = mine;
+  }
+  const uint32_t tail = num_values & 63u;
+  if (tail && lane < tail) out[num_values - tail + lane] = mine;
+  __syncthreads();
+  // zig-zag unless the transform's corrections are positive (D-4); BitUtilities.cs:94-103
+  const bool positive = a.have_scheme && (a.pred_transform == 2 || a.pred_transform == 3);
+  if (!positive)
+    for (uint32_t i = lane; i < num_values; i += WAVE) {
+      uint32_t v = out[i];
+      out[i] = (v & 1u) ? (uint32_t)(-(int32_t)(v >> 1) - 1) : (v >> 1);
+    }
+}
+
 // Launched once per tier so that the LDS footprint of the cumulative table does not cap occupancy:
 //   TIER 0: alphabets <= 64 (table in one register per lane) + tagged / fixed-width sources
 //   TIER 1: alphabets <= 960      TIER 2: alphabets <= SYM_MAX_LDS and the large-alphabet fallback
@@ -1559,6 +1666,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayo
   if (a.source == SRC_BYTES) return;
   {
     const uint32_t ns = a.source == SRC_RAW ? a.num_symbols : 0u;
+    if (a.source == SRC_RAW && a.precision_bits == 12 && ns > 64 && ns <= REG_MAX_SYMS) return;   // k_symbols_reg
     const int tier = ns <= 64 ? 0 : (ns <= 960 ? 1 : 2);
     if (tier != TIER) return;
   }
