@@ -118,6 +118,8 @@ struct dsa_context {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;     // symbol decode runs here, concurrently with connectivity + traversal
+  hipStream_t stream3 = nullptr;     // connectivity validation (link symmetry, seam streams)
+  hipEvent_t ev_join3 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_conn = nullptr;
   bool own_stream = false;
   bool profiling = false;
@@ -274,6 +276,8 @@ dsa_status dsa_context_create(int device, void *stream, dsa_context **out) {
     c->own_stream = true;
   }
   if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_conn, hipEventDisableTiming) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
@@ -288,6 +292,8 @@ void dsa_context_destroy(dsa_context *ctx) {
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_conn) (void)hipEventDestroy(ctx->ev_conn);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+  if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -349,12 +355,13 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   hipLaunchKernelGGL(dsa::k_symbols<0>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
   hipLaunchKernelGGL(dsa::k_symbols<2>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[1], st2));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_join, st2));
   hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   // link symmetry + seam streams are checked on the second stream while the traversal runs here
   HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st));
-  HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_conn, 0));
-  hipLaunchKernelGGL(dsa::k_conn_checks, dim3(n), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_join, st2));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_conn, 0));
+  hipLaunchKernelGGL(dsa::k_conn_checks, dim3(n), dim3(WAVE), 0, ctx->stream3, b->arena, b->d_layouts, b->d_descs, n);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_join3, ctx->stream3));
   HIP_TRY(ctx, mark());
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 255) / 256, 32));
@@ -368,6 +375,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   }
   HIP_TRY(ctx, mark());
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));   // join: corrections are ready
+  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join3, 0));  // join: connectivity validated
   HIP_TRY(ctx, mark());
   hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, mark());
@@ -387,6 +395,7 @@ dsa_status dsa_batch_wait(dsa_batch *b) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream3));
   if (b->n) HIP_TRY(ctx, hipMemcpy(b->descs.data(), b->d_descs, sizeof(MeshDesc) * b->n, hipMemcpyDeviceToHost));
   if (ctx->profiling && b->have_events && b->n) {
     for (int i = 0; i < STG_TOTAL; ++i) HIP_TRY(ctx, hipEventElapsedTime(&b->stage_ms[i], b->ev[i], b->ev[i + 1]));
