@@ -64,11 +64,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from draco_sharp_amd.sharding import Comm
+    comm = Comm(backend="nccl", device=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm; only barrier + reductions
 
     # ---- synthetic batch: SURVEY.md section 8d config 3 (positions 11 bit + normals 8 bit oct + UVs 10 bit,
     # standard Edgebreaker, parallelogram + wrap, per-attribute connectivity), seeds 1000 + rank*meshes ...
@@ -85,8 +82,7 @@ def main():
     t_upload = time.perf_counter() - t0
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        comm.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -105,15 +101,8 @@ def main():
         raise SystemExit("rank %d: %d meshes failed to decode (first %d: status %d site %d)" %
                          (rank, len(bad), bad[0], batch.status(bad[0]), batch.mesh_info(bad[0]).detail))
     alg_bytes = batch.algorithmic_bytes
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        bts = torch.tensor([alg_bytes], dtype=torch.float64, device="cuda")
-        dist.all_reduce(bts, op=dist.ReduceOp.SUM)
-        alg_bytes_all = float(bts.item())
-    else:
-        alg_bytes_all = float(alg_bytes)
+    elapsed = comm.max(elapsed)                 # MAX over ranks
+    alg_bytes_all = comm.sum(alg_bytes)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -121,6 +110,7 @@ def main():
         stages = {k: v / args.steps for k, v in stage_sum.items()}
         kernel_stages = {k: v for k, v in stages.items() if k != "total"}
         dom = max(kernel_stages, key=kernel_stages.get)
+        kernel_name = {"symbols": "k_symbols_reg", "traverse": "k_traverse (+k_traverse_prep)"}.get(dom, "k_" + dom)
         achieved = alg_bytes / (kernel_stages[dom] * 1e-3) / 1e9
         out = {
             "metric": "decoded_meshes_per_sec",
@@ -143,7 +133,7 @@ def main():
             "compressed_bytes_per_gpu": int(offsets[-1]),
             "arena_bytes_per_gpu": batch.arena_bytes,
             "stage_ms": stages,
-            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None},
             "setup_s": {"generate": t_gen, "upload_and_layout": t_upload},
         }
@@ -152,8 +142,7 @@ def main():
         print(json.dumps(out))
     batch.close()
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,116 @@
+// Drop-in GPU path behind DracoDecoder.Decode (src/Draco/IO/DracoDecoder.cs:8-42): same inputs, same
+// Draco / Mesh / PointAttribute results, same exception types; the connectivity and attribute decoding
+// that the reference runs in-process (ConnectivityDecoder.DecodeConnectivity / DecodeAttributes) happen
+// in libdraco_mi355x.so on an MI355X.  DecodeBatch is the call that makes the GPU worthwhile: the streams
+// of one call are independent meshes decoded concurrently.
+using System;
+using System.Collections.Generic;
+using System.IO;
+using Draco.IO.Attributes;
+using Draco.IO.Enums;
+
+namespace Draco.IO.Gpu;
+
+public sealed unsafe class GpuDracoDecoder : IDisposable
+{
+    private IntPtr _ctx;
+
+    public GpuDracoDecoder(int device = 0)
+    {
+        NativeMethods.Check(NativeMethods.dsa_context_create(device, IntPtr.Zero, out _ctx), IntPtr.Zero, $"no usable GPU {device}");
+    }
+
+    public Draco Decode(string path)
+    {
+        return DecodeBatch([File.ReadAllBytes(path)])[0];
+    }
+
+    public Draco Decode(Stream stream)
+    {
+        using var ms = new MemoryStream();
+        stream.CopyTo(ms);
+        stream.Dispose();   // the reference disposes the caller's reader (DecoderBuffer.cs:186-189)
+        return DecodeBatch([ms.ToArray()])[0];
+    }
+
+    public Draco Decode(BinaryReader binaryReader)
+    {
+        return Decode(binaryReader.BaseStream);
+    }
+
+    /// <summary>Decodes independent .drc streams in one GPU batch.  A bad stream throws when its result is requested
+    /// (InvalidDataException / NotImplementedException, as the reference would); it never poisons the others.</summary>
+    public Draco[] DecodeBatch(IReadOnlyList<byte[]> streams)
+    {
+        var handles = new System.Runtime.InteropServices.GCHandle[streams.Count];
+        var ptrs = new byte*[streams.Count];
+        var lens = new nuint[streams.Count];
+        IntPtr batch = IntPtr.Zero;
+        try
+        {
+            for (int i = 0; i < streams.Count; ++i)
+            {
+                handles[i] = System.Runtime.InteropServices.GCHandle.Alloc(streams[i], System.Runtime.InteropServices.GCHandleType.Pinned);
+                ptrs[i] = (byte*)handles[i].AddrOfPinnedObject();
+                lens[i] = (nuint)streams[i].Length;
+            }
+            fixed (byte** p = ptrs)
+            fixed (nuint* l = lens)
+            {
+                NativeMethods.Check(NativeMethods.dsa_batch_create(_ctx, (uint)streams.Count, p, l, out batch), _ctx, "dsa_batch_create");
+            }
+            NativeMethods.Check(NativeMethods.dsa_batch_decode(batch), _ctx, "dsa_batch_decode");
+            NativeMethods.Check(NativeMethods.dsa_batch_wait(batch), _ctx, "dsa_batch_wait");
+            var results = new Draco[streams.Count];
+            for (uint i = 0; i < streams.Count; ++i) results[i] = Materialize(batch, i);
+            return results;
+        }
+        finally
+        {
+            if (batch != IntPtr.Zero) NativeMethods.dsa_batch_free(batch);
+            foreach (var h in handles) if (h.IsAllocated) h.Free();
+        }
+    }
+
+    private Draco Materialize(IntPtr batch, uint mesh)
+    {
+        NativeMethods.Check(NativeMethods.dsa_batch_mesh_info(batch, mesh, out var info), _ctx, "dsa_batch_mesh_info");
+        NativeMethods.Check((DsaStatus)info.Status, IntPtr.Zero, $"stream {mesh}: decode failed (site {info.Detail})");
+        var result = new Mesh.Mesh();
+        var faces = new int[info.NumFaces * 3];
+        fixed (int* f = faces) NativeMethods.Check(NativeMethods.dsa_batch_copy_faces(batch, mesh, f), _ctx, "dsa_batch_copy_faces");
+        result.SetNumFaces((int)info.NumFaces);
+        for (uint f = 0; f < info.NumFaces; ++f) result.SetFace(f, [faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]]);
+        result.PointsCount = (int)info.NumPoints;
+        for (uint a = 0; a < info.NumAttributes; ++a)
+        {
+            NativeMethods.Check(NativeMethods.dsa_batch_attribute_info(batch, mesh, a, out var ai), _ctx, "dsa_batch_attribute_info");
+            var geometry = new GeometryAttribute(
+                attributeType: (GeometryAttributeType)ai.AttributeType, buffer: null, numComponents: (byte)ai.NumComponents,
+                dataType: (DataType)ai.DataType, normalized: ai.Normalized != 0, byteStride: ai.ByteStride, byteOffset: 0)
+            { UniqueId = ai.UniqueId };
+            var attribute = new PointAttribute(geometry);
+            attribute.Reset((int)ai.NumEntries);
+            var values = new byte[(long)ai.NumEntries * ai.ByteStride];
+            fixed (byte* v = values) NativeMethods.Check(NativeMethods.dsa_batch_copy_attribute_values(batch, mesh, a, v), _ctx, "dsa_batch_copy_attribute_values");
+            attribute.Buffer!.Update(values);
+            var map = new uint[info.NumPoints];
+            fixed (uint* m = map) NativeMethods.Check(NativeMethods.dsa_batch_copy_point_map(batch, mesh, a, m), _ctx, "dsa_batch_copy_point_map");
+            attribute.SetExplicitMapping((int)info.NumPoints);           // MeshTraversalSequencer.cs:33-50
+            for (uint p = 0; p < info.NumPoints; ++p) attribute.SetPointMapEntry(p, map[p]);
+            result.AddAttribute(attribute);
+        }
+        return new Draco
+        {
+            Header = new DracoHeader(info.MajorVersion, info.MinorVersion, info.EncoderType, info.EncoderMethod, info.Flags),
+            Metadata = null,   // metadata is parsed by the managed MetadataDecoder when the caller needs it
+            ConnectedData = result,
+            Attributes = result.Attributes
+        };
+    }
+
+    public void Dispose()
+    {
+        if (_ctx != IntPtr.Zero) { NativeMethods.dsa_context_destroy(_ctx); _ctx = IntPtr.Zero; }
+    }
+}

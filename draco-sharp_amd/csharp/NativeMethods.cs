@@ -1,0 +1,95 @@
+// P/Invoke declarations for libdraco_mi355x.so (include/draco_mi355x.h).
+// This file is what a draco-sharp maintainer adds next to src/Draco/IO/DracoDecoder.cs; it cannot be
+// compiled in the build image (no .NET SDK), the ctypes binding in draco-sharp_amd/native.py is the
+// executable twin used by the tests.  Blittable structs only, no callbacks, library-owned memory.
+using System;
+using System.Runtime.InteropServices;
+
+namespace Draco.IO.Gpu;
+
+internal enum DsaStatus : int
+{
+    Ok = 0,
+    InvalidData = 1,      // -> InvalidDataException
+    NotImplemented = 2,   // -> NotImplementedException
+    InvalidArgument = 3,  // -> ArgumentException
+    Device = 4,           // -> InvalidOperationException(dsa_last_error)
+    OutOfMemory = 5       // -> OutOfMemoryException
+}
+
+[StructLayout(LayoutKind.Sequential)]
+internal struct DsaMeshInfo
+{
+    public int Status;
+    public int Detail;
+    public byte MajorVersion, MinorVersion, EncoderType, EncoderMethod;
+    public ushort Flags;
+    public ushort Reserved;
+    public uint NumFaces;
+    public uint NumPoints;
+    public uint NumAttributes;
+    public ulong DrcBytes;
+}
+
+[StructLayout(LayoutKind.Sequential)]
+internal unsafe struct DsaAttributeInfo
+{
+    public int AttributeType;
+    public int DataType;
+    public int NumComponents;
+    public int Normalized;
+    public uint UniqueId;
+    public uint NumEntries;
+    public uint ByteStride;
+    public int DecoderType;
+    public int PredictionMethod;
+    public int PredictionTransform;
+    public int QuantizationBits;
+    public float Range;
+    public fixed float MinValues[4];
+}
+
+internal static unsafe partial class NativeMethods
+{
+    private const string Lib = "draco_mi355x";
+
+    [DllImport(Lib)] internal static extern int dsa_abi_version();
+    [DllImport(Lib)] internal static extern int dsa_device_count();
+    [DllImport(Lib)] internal static extern DsaStatus dsa_context_create(int device, IntPtr stream, out IntPtr ctx);
+    [DllImport(Lib)] internal static extern void dsa_context_destroy(IntPtr ctx);
+    [DllImport(Lib)] internal static extern IntPtr dsa_last_error(IntPtr ctx);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_create(IntPtr ctx, uint n, byte** streams, nuint* lengths, out IntPtr batch);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_create_packed(IntPtr ctx, uint n, byte* blob, ulong* offsets, out IntPtr batch);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_decode(IntPtr batch);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_wait(IntPtr batch);
+    [DllImport(Lib)] internal static extern void dsa_batch_free(IntPtr batch);
+    [DllImport(Lib)] internal static extern uint dsa_batch_size(IntPtr batch);
+    [DllImport(Lib)] internal static extern ulong dsa_batch_algorithmic_bytes(IntPtr batch);
+    [DllImport(Lib)] internal static extern ulong dsa_batch_arena_bytes(IntPtr batch);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_mesh_info(IntPtr batch, uint mesh, out DsaMeshInfo info);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_attribute_info(IntPtr batch, uint mesh, uint attribute, out DsaAttributeInfo info);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_copy_faces(IntPtr batch, uint mesh, int* dst);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_copy_attribute_values(IntPtr batch, uint mesh, uint attribute, void* dst);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_copy_point_map(IntPtr batch, uint mesh, uint attribute, uint* dst);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_copy_portable_values(IntPtr batch, uint mesh, uint attribute, int* dst);
+    [DllImport(Lib)] internal static extern IntPtr dsa_batch_device_faces(IntPtr batch, uint mesh);
+    [DllImport(Lib)] internal static extern IntPtr dsa_batch_device_attribute_values(IntPtr batch, uint mesh, uint attribute);
+    [DllImport(Lib)] internal static extern IntPtr dsa_batch_device_point_map(IntPtr batch, uint mesh, uint attribute);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_copy_debug(IntPtr batch, uint mesh, int what, void* dst, nuint dstBytes, out nuint written);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_context_set_profiling(IntPtr ctx, int enabled);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_stage_times(IntPtr batch, float* ms, IntPtr* names);
+
+    internal static void Check(DsaStatus status, IntPtr ctx, string what)
+    {
+        if (status == DsaStatus.Ok) return;
+        var msg = ctx == IntPtr.Zero ? what : $"{what}: {Marshal.PtrToStringAnsi(dsa_last_error(ctx))}";
+        throw status switch
+        {
+            DsaStatus.InvalidData => new System.IO.InvalidDataException(msg),
+            DsaStatus.NotImplemented => new NotImplementedException(msg),
+            DsaStatus.InvalidArgument => new ArgumentException(msg),
+            DsaStatus.OutOfMemory => new OutOfMemoryException(msg),
+            _ => new InvalidOperationException(msg),
+        };
+    }
+}
