@@ -204,7 +204,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
     L.vrec = take(8 * V);
     L.d2c = take(4 * V); L.v2d = take(4 * V);
     L.fvis = take(F); L.vvis = take(V);
-    L.jnl = take(16 * F); L.fstamp = take(4 * F); L.vstamp = take(4 * V);
+    L.fstamp = take(4 * F); L.vstamp = take(4 * V);
     L.splits = take(16ull * h.splits);
     L.vrank = take(4 * V); L.para = take(12 * V);
     L.faces = take(12 * F);
@@ -364,13 +364,14 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   HIP_TRY(ctx, hipEventRecord(ctx->ev_join3, ctx->stream3));
   HIP_TRY(ctx, mark());
   {
-    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 255) / 256, 32));
+    // few fat blocks: these elementwise kernels are workgroup-dispatch bound with one block per 256 elements
+    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
     hipLaunchKernelGGL(dsa::k_traverse_prep, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   }
   hipLaunchKernelGGL(dsa::k_traverse, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, mark());
   {
-    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 255) / 256, 64));
+    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 8191) / 8192, 4));
     hipLaunchKernelGGL(dsa::k_para_operands, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   }
   HIP_TRY(ctx, mark());
@@ -380,7 +381,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, mark());
   {
-    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 1023) / 1024, 64));
+    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
     hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   }
   HIP_TRY(ctx, mark());

@@ -1152,9 +1152,7 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
 // loop body verbatim.  Either way each step is the sequential algorithm's result.
 // =========================================================================
 // Lane-parallel preparation of the traversal state: visited flags, v2d = -1, IsOnBoundary per vertex
-// (CornerTable.cs:174-178), stamp arrays, and the successor table of the dominant march pattern
-// "tip new & interior -> right (N), then tip visited & right side done -> left (L)":
-//   jnl[c] = Opposite(Previous(Opposite(Next(c))))
+// (CornerTable.cs:174-178) and the stamp arrays.
 __global__ __launch_bounds__(256) void k_traverse_prep(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n) {
   uint32_t mesh = blockIdx.y;
   if (mesh >= n) return;
@@ -1165,22 +1163,11 @@ __global__ __launch_bounds__(256) void k_traverse_prep(uint8_t *arena, const Mes
   const uint2 *vrec = (const uint2 *)(arena + L.vrec);
   int32_t *v2d = (int32_t *)(arena + L.v2d);
   uint8_t *fvis = arena + L.fvis, *vflag = arena + L.vvis;
-  uint32_t *jnl = (uint32_t *)(arena + L.jnl), *fstamp = (uint32_t *)(arena + L.fstamp), *vstamp = (uint32_t *)(arena + L.vstamp);
+  uint32_t *fstamp = (uint32_t *)(arena + L.fstamp), *vstamp = (uint32_t *)(arena + L.vstamp);
   const uint32_t F = D->num_faces, NVALL = D->num_all_vertices;
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-  for (uint32_t f = tid; f < F; f += stride) {
-    fvis[f] = 0;
-    fstamp[f] = 0xFFFFFFFFu;
-    const uint4 oo = ((const uint4 *)frec)[(size_t)f * 2 + 1];
-    const uint32_t ov[3] = {oo.x, oo.y, oo.z};
-    uint32_t j[3];
-#pragma unroll
-    for (uint32_t k = 0; k < 3; ++k) {
-      const uint32_t b = ov[k == 2 ? 0 : k + 1];       // Opposite(Next(corner k))
-      j[k] = (b != DSA_INVALID && b < 4 * F && (b & 3u) != 3u) ? frec[fo_idx(qprev(b))] : DSA_INVALID;
-    }
-    ((uint4 *)jnl)[f] = make_uint4(j[0], j[1], j[2], DSA_INVALID);
-  }
+  for (uint32_t f = tid; f < F; f += stride) fstamp[f] = 0xFFFFFFFFu;
+  for (uint32_t w4 = tid; w4 < (F + 3) / 4; w4 += stride) ((uint32_t *)fvis)[w4] = 0;     // regions are 256-byte padded
   for (uint32_t v = tid; v < L.cap_vertices; v += stride) {
     v2d[v] = -1;
     vstamp[v] = 0xFFFFFFFFu;
@@ -1193,10 +1180,13 @@ __global__ __launch_bounds__(256) void k_traverse_prep(uint8_t *arena, const Mes
   }
 }
 
-// k_traverse speculation: from a corner whose tip is new and interior the DFS usually repeats
-// "N, L" (see k_traverse_prep).  The candidate path a_0, a_1 = jnl[a_0], ... is first extrapolated
-// (the corner ids along a regular strip or across the rings of a spiral follow a constant or linearly
-// changing step) and each lane verifies its own link jnl[a_(i-1)] == a_i; then lane i evaluates the
+// k_traverse speculation: from a corner whose tip is new and interior the DFS usually repeats the pair
+// "tip new & interior -> right (N), then tip visited & right side done -> left (L)", i.e. it continues at
+//   succ(a) = Opposite(Previous(Opposite(Next(a)))).
+// The candidate path a_0, a_1 = succ(a_0), ... is extrapolated (the corner ids along a regular strip or
+// across the rings of a spiral follow a constant or linearly changing step; the step parameters carry
+// over from the previous run, otherwise three exact hops seed them) and each lane verifies its own link
+// succ(a_(i-1)) == a_i from the face records it loads anyway; then lane i evaluates the
 // reference's two decisions of pair i against the faces / vertices visited before the step or earlier in
 // the run (exact membership through atomicMin stamps), and the leading pairs that all check out are
 // retired at once.  Everything else is the scalar step = the reference's loop body.
@@ -1213,7 +1203,6 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   int32_t *v2d = (int32_t *)(arena + L.v2d);
   uint8_t *fvis = arena + L.fvis;
   uint8_t *vflag = arena + L.vvis;      // bit0 visited, bit1 on boundary
-  const uint32_t *jnl = (const uint32_t *)(arena + L.jnl);
   uint32_t *fstamp = (uint32_t *)(arena + L.fstamp), *vstamp = (uint32_t *)(arena + L.vstamp);
   const uint32_t F = uni(D->num_faces), NV = uni(D->num_vertices);
   uint32_t *stack = (uint32_t *)(arena + L.faces);   // DFS stack: the faces output is only written by k_finalize
@@ -1223,6 +1212,8 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
 
   uint32_t count = 0, sp = 0, f_scan = 0;
   uint32_t run_id = 0;        // stamps of newer runs compare smaller, so atomicMin always replaces older ones
+  bool have_step = false;     // (step, dd) of the candidate path carried over from the previous run
+  int64_t step = 0, dd = 0;
   uint32_t backoff = 0;       // scalar steps to take before speculating again
   uint32_t n_run = 0, n_run_faces = 0, n_scalar = 0, n_fail = 0;
   bool failed = false;
@@ -1271,44 +1262,58 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
       if (uni_flag == 0 && backoff == 0) {
         ++run_id;
         const uint32_t base = (0x00FFFFFFu - run_id) << 8;
-        // candidate path: three exact hops, then constant-second-difference extrapolation
+        // candidate path a_i = a_0 + i*step + dd*i*(i-1)/2.  (step, dd) carry over from the previous run
+        // (its last step + dd); if the first link then fails, three exact hops re-seed them.
         const uint32_t a0 = corner;
-        const uint32_t a1 = uni(jnl[a0]);
-        const uint32_t a2 = corner_ok(a1) ? uni(jnl[a1]) : DSA_INVALID;
-        const uint32_t a3 = corner_ok(a2) ? uni(jnl[a2]) : DSA_INVALID;
+        auto succ = [&](uint32_t c) -> uint32_t {       // uniform: two dependent record loads
+          if (!corner_ok(c)) return DSA_INVALID;
+          const uint4 o1 = ((const uint4 *)frec)[(size_t)(c >> 2) * 2 + 1];
+          const uint32_t k1 = c & 3u;
+          const uint32_t b1 = uni(k1 == 0 ? o1.y : (k1 == 1 ? o1.z : o1.x));
+          if (!corner_ok(b1)) return DSA_INVALID;
+          const uint4 o2 = ((const uint4 *)frec)[(size_t)(b1 >> 2) * 2 + 1];
+          const uint32_t k2 = b1 & 3u;
+          return uni(k2 == 0 ? o2.z : (k2 == 1 ? o2.x : o2.y));
+        };
         int64_t ai;
-        {
-          const int64_t d1 = (int64_t)a1 - a0, d2 = (int64_t)a2 - a1, d3 = (int64_t)a3 - a2;
-          int64_t dd = d3 - d2;
-          if (d2 - d1 != dd) dd = 0;       // no regular step change: assume a constant step
+        bool a_ok;
+        uint32_t exact = 1;                      // lanes < exact hold hopped (exact) corners
+        if (have_step) {
           const int64_t i = lane;
-          // a_i = a3 + (i-3)*d3 + dd*(i-3)*(i-2)/2 for i > 3
-          ai = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : lane == 3 ? a3 : (int64_t)a3 + (i - 3) * d3 + dd * (i - 3) * (i - 2) / 2;
+          ai = (int64_t)a0 + i * step + dd * i * (i - 1) / 2;
+        } else {
+          const uint32_t a1 = succ(a0), a2 = succ(a1), a3 = succ(a2);
+          const int64_t d1 = (int64_t)a1 - a0, d2 = (int64_t)a2 - a1, d3 = (int64_t)a3 - a2;
+          int64_t ddh = d3 - d2;
+          if (d2 - d1 != ddh) ddh = 0;       // no regular step change: assume a constant step
+          const int64_t i = lane;
+          ai = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : lane == 3 ? a3 : (int64_t)a3 + (i - 3) * d3 + ddh * (i - 3) * (i - 2) / 2;
+          exact = corner_ok(a3) ? 4 : (corner_ok(a2) ? 3 : (corner_ok(a1) ? 2 : 1));
+          step = d1; dd = ddh;               // provisional; replaced below from the verified chain
         }
-        bool a_ok = ai >= 0 && ai < (int64_t)4 * F && ((uint32_t)ai & 3u) != 3u && corner_ok(a3);
-        if (lane < 4) a_ok = corner_ok((uint32_t)ai) || lane == 0;
+        a_ok = ai >= 0 && ai < (int64_t)4 * F && ((uint32_t)ai & 3u) != 3u && (lane < exact || have_step || exact == 4);
         const uint32_t a = a_ok ? (uint32_t)ai : 0u;
-        const uint32_t next_a = a_ok ? jnl[a] : DSA_INVALID;
-        {
-          const uint32_t prev_next = __shfl_up(next_a, 1, 64);
-          a_ok = a_ok && (lane == 0 || prev_next == a);
-        }
-        uint32_t len = leading_lanes(a_ok);                 // verified chain a_0 .. a_(len-1)
-        const bool in_chain = lane < len;
         // pair `lane`: N element at a (face A), L element at b = Opposite(Next(a)) (face B)
         const uint32_t fa = a >> 2, ka = a & 3u;
         uint4 va = make_uint4(0, 0, 0, 0), oa = make_uint4(DSA_INVALID, DSA_INVALID, DSA_INVALID, 0);
-        if (in_chain) { va = ((const uint4 *)frec)[(size_t)fa * 2]; oa = ((const uint4 *)frec)[(size_t)fa * 2 + 1]; }
+        if (a_ok) { va = ((const uint4 *)frec)[(size_t)fa * 2]; oa = ((const uint4 *)frec)[(size_t)fa * 2 + 1]; }
         const uint32_t tipA = ka == 0 ? va.x : (ka == 1 ? va.y : va.z);
         const uint32_t b = ka == 0 ? oa.y : (ka == 1 ? oa.z : oa.x);
-        const bool b_ok = in_chain && corner_ok(b) && tipA < NV;
+        const bool b_ok = a_ok && corner_ok(b) && tipA < NV;
         const uint32_t fb = b >> 2, kb = b & 3u;
         uint4 vb = make_uint4(0, 0, 0, 0), ob = make_uint4(DSA_INVALID, DSA_INVALID, DSA_INVALID, 0);
         if (b_ok) { vb = ((const uint4 *)frec)[(size_t)fb * 2]; ob = ((const uint4 *)frec)[(size_t)fb * 2 + 1]; }
         const uint32_t tipB = kb == 0 ? vb.x : (kb == 1 ? vb.y : vb.z);
         const uint32_t rcB = kb == 0 ? ob.y : (kb == 1 ? ob.z : ob.x);
         const uint32_t lcB = kb == 0 ? ob.z : (kb == 1 ? ob.x : ob.y);
-        const bool pair_ok = b_ok && tipB < NV && lcB == next_a && corner_ok(lcB) && (rcB == DSA_INVALID || corner_ok(rcB));
+        const uint32_t next_a = b_ok ? lcB : DSA_INVALID;           // succ(a)
+        {
+          const uint32_t prev_next = __shfl_up(next_a, 1, 64);
+          a_ok = a_ok && (lane == 0 || prev_next == a);
+        }
+        uint32_t len = leading_lanes(a_ok);                 // verified chain a_0 .. a_(len-1)
+        const bool in_chain = lane < len;
+        const bool pair_ok = in_chain && b_ok && tipB < NV && corner_ok(lcB) && (rcB == DSA_INVALID || corner_ok(rcB));
         // stamps: first position of every face / tip in the candidate list
         const uint32_t keyN = base | (2 * lane), keyL = base | (2 * lane + 1);
         if (pair_ok) {
@@ -1348,6 +1353,13 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           }
           const uint32_t nxt = rdlane(next_a, K - 1);          // Opposite(Previous(b_(K-1))): where the DFS continues
           count += K;
+          if (K >= 3) {       // next run: continue the verified progression
+            const int64_t aK1 = rdlane(a, K - 1), aK2 = rdlane(a, K - 2), aK3 = rdlane(a, K - 3);
+            const int64_t s1 = (int64_t)nxt - aK1, s0 = aK1 - aK2, sm = aK2 - aK3;
+            dd = (s1 - s0 == s0 - sm) ? s1 - s0 : 0;
+            step = s1 + dd;
+            have_step = true;
+          } else have_step = false;
           corner = nxt;
           n_run += 1; n_run_faces += 2 * K;
           if (K < 4) backoff = 2;
@@ -1355,6 +1367,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           continue;
         }
         ++n_fail;
+        if (have_step) { have_step = false; continue; }      // stale step parameters: retry with exact hops
         backoff = 4;
         (void)len;
       } else if (backoff) {
@@ -1544,17 +1557,18 @@ __device__ __forceinline__ void rans_decode_serial(MeshDesc *D, const uint8_t *s
 }
 
 // ---------------------------------------------------------------------------------------------
-// Register-file rANS decode for 12-bit precision (what 8..11-bit quantised attributes produce):
-// the reference's 4096-entry slot -> symbol LUT (RAnsDecoder.cs:69-88) is kept in 32 VGPRs (two 16-bit
-// symbols per lane and register: slot r lives in register r>>7, lane (r>>1)&63, half r&1) and the
-// per-symbol {frequency, cumulative frequency} pairs in another 32 VGPRs (symbol s: register s>>6,
-// lane s&63).  A lookup is an M0-indexed register move plus v_readlane with wave-uniform indices, so the
-// serial state update never touches LDS or memory; LDS (8 KB) is only used to transpose the tables once.
-typedef uint32_t v32u __attribute__((ext_vector_type(32)));
+// Register-file rANS decode for 12-bit precision (what 8..11-bit quantised attributes produce).
+// The serial state update  x' = freq[s]*(x >> 12) + (rem - cum[s])  (RAnsDecoder.cs:56-67) only needs, per
+// slot rem, the pair {freq, rem - cum}: the reference's 4096-entry slot table (RAnsDecoder.cs:69-88) is kept
+// as one packed word per slot in 64 VGPRs (slot r: register r>>6, lane r&63) and read with an M0-indexed
+// register move + v_readlane, so the chain never touches LDS or memory.  The chain records the *slot* of
+// every position; which symbol a slot belongs to is looked up afterwards by all 64 lanes in parallel
+// (slot -> symbol table in the attribute's scratch), fused with the zig-zag step.
+typedef uint32_t v32u __attribute__((ext_vector_type(32)));   // largest vector the backend indexes through M0
 #define REG_MAX_SYMS 2048
 
 __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
-  __shared__ uint32_t lds[REG_MAX_SYMS];   // probabilities -> packed {freq, cum}; then reused as u16 LUT[4096]
+  __shared__ uint32_t lds[REG_MAX_SYMS];   // probabilities, then packed {freq << 12 | cum} per symbol
   uint32_t mesh = blockIdx.x, ai = blockIdx.y;
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
@@ -1562,8 +1576,11 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
   const MeshLayout &L = layouts[mesh];
   const AttrDesc &a = D->att[ai];
   if (a.source != SRC_RAW || a.precision_bits != 12 || a.num_symbols > REG_MAX_SYMS || a.num_symbols <= 64) return;
+  if (L.out_cap[ai] < 4096 * 6) return;      // scratch for the two slot tables (k_symbols<T> takes the stream instead)
   const uint8_t *stream = arena + L.stream;
   uint32_t *out = (uint32_t *)(arena + L.work[ai]);
+  uint32_t *slot_tab = (uint32_t *)(arena + L.out[ai]);            // {freq << 12 | rem - cum} per slot
+  uint16_t *slot_sym = (uint16_t *)(arena + L.out[ai] + 4096 * 4); // symbol per slot
   const uint32_t lane = lane_id();
   const uint32_t nsym = uni(a.num_symbols);
   const uint32_t num_values = uni(a.num_entries) * a.nc_portable;
@@ -1575,38 +1592,31 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
   }
   __syncthreads();
   if (status_of(D) != ST_OK) return;
-  // 2. cumulative frequencies; pack {freq << 12 | cum} (freq <= 4096, cum < 4096)
+  // 2. cumulative frequencies; a frequency of 4096 (one-symbol alphabet) does not fit the packing
   uint32_t carry = 0;
   bool over = false;
   for (uint32_t b0 = 0; b0 < REG_MAX_SYMS; b0 += WAVE) {
     uint32_t i = b0 + lane;
     uint32_t pr = i < nsym ? lds[i] : 0u;
-    if (pr > 4096) over = true;
+    if (pr > 4095) over = true;
     uint32_t tot;
     uint32_t ex = wave_excl_scan(pr, &tot);
     lds[i] = (pr << 12) | ((carry + ex) & 4095u);
     carry += tot;
     if (carry > 4096) over = true;
   }
-  if (__ballot(over) || carry != 4096) { if (lane == 0) fail(D, ST_INVALID, 401); return; }
+  if (__ballot(over) || carry != 4096) { if (lane == 0) fail(D, carry != 4096 ? ST_INVALID : ST_NOTIMPL, 401); return; }
   __syncthreads();
-  v32u cf;
-#pragma unroll
-  for (int k = 0; k < 32; ++k) cf[k] = lds[k * WAVE + lane];
-  __syncthreads();
-  // 3. slot -> symbol LUT, transposed through LDS as 16-bit entries
-  {
-    uint16_t *lut16 = (uint16_t *)lds;
-#pragma unroll 1
-    for (int k = 0; k < 32; ++k) {
-      const uint32_t e = cf[k], f = e >> 12, c = e & 4095u, sym = (uint32_t)k * WAVE + lane;
-      for (uint32_t j = 0; j < f; ++j) lut16[c + j] = (uint16_t)sym;
-    }
+  // 3. slot tables through the attribute's scratch: every symbol writes its own slots
+  for (uint32_t sy = lane; sy < nsym; sy += WAVE) {
+    const uint32_t e = lds[sy], f = e >> 12, c = e & 4095u;
+    for (uint32_t j = 0; j < f; ++j) { slot_tab[c + j] = (f << 12) | j; slot_sym[c + j] = (uint16_t)sy; }
   }
+  WAIT_VM0();
   __syncthreads();
-  v32u lut;
+  v32u tab_lo, tab_hi;
 #pragma unroll
-  for (int k = 0; k < 32; ++k) lut[k] = lds[k * WAVE + lane];
+  for (int k = 0; k < 32; ++k) { tab_lo[k] = slot_tab[k * WAVE + lane]; tab_hi[k] = slot_tab[(k + 32) * WAVE + lane]; }
   // 4. initial state from the stream tail, RAnsDecoder.cs:20-54
   const uint8_t *buf = stream + a.off_rans;
   uint32_t x, off;
@@ -1622,32 +1632,59 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
   uint32_t chunk = 0x7FFFFFFFu, W = 0;
   uint32_t mine = 0;
   WAIT_VM0();
-  for (uint32_t i = 0; i < num_values; ++i) {
-    while (x < 16384 && off > 0) {           // RAnsDecoder.cs:58-61
-      --off;
-      const uint32_t q = off + mis, ch = q >> 8;
+  // 64 positions per outer iteration; the slot (low 12 bits of the state) of position j is parked in lane j
+  // with v_writelane and stored with one coalesced store.  Both halves of the table are read with the same
+  // M0 index and the result selected afterwards: no branch in the per-symbol path except the renormalisation.
+  // Byte reservoir: the stream is consumed from its tail, so a little-endian 64-bit word ending at the read
+  // position holds the next 8 bytes most-significant first.  res is refilled every 8 bytes from the register
+  // window (two v_readlane + funnel shift); a renormalisation step is then 4 scalar ops.
+  uint64_t res = 0;
+  uint32_t rcount = 0;                         // valid bytes in res (top-aligned)
+  auto refill = [&]() {
+    // bytes [off-8, off) relative to buf; the window is indexed from abuf = buf - mis, and never reads below abuf
+    const uint32_t take = off < 8u ? off : 8u;
+    const uint32_t end = off + mis;            // one past the last byte, in abuf coordinates
+    const uint32_t start = end - take;
+    const uint32_t d0 = start >> 2;            // first dword; the 8 bytes span at most 3 dwords
+    uint32_t w[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t d = d0 + k, ch = d >> 6;
       if (ch != chunk) { chunk = ch; W = abuf[(size_t)ch * 64 + lane]; WAIT_VM0(); }
-      const uint32_t byte = (rdlane(W, (q & 255u) >> 2) >> ((q & 3u) * 8)) & 0xFFu;
-      x = (x << 8) | byte;
+      w[k] = rdlane(W, d & 63u);
     }
-    const uint32_t rem = x & 4095u;
-    const uint32_t pair = rdlane(lut[rem >> 7], (rem >> 1) & 63u);
-    const uint32_t sym = (rem & 1u) ? pair >> 16 : pair & 0xFFFFu;
-    const uint32_t e = rdlane(cf[sym >> 6], sym & 63u);
-    x = (e >> 12) * (x >> 12) + rem - (e & 4095u);      // RAnsDecoder.cs:62-65
-    if ((i & 63u) == lane) mine = sym;
-    if ((i & 63u) == 63u) out[i - 63u + lane] = mine;
+    const uint32_t sh = (start & 3u) * 8;
+    uint64_t lo64 = ((uint64_t)w[1] << 32) | w[0];
+    uint64_t v = sh ? ((lo64 >> sh) | ((uint64_t)w[2] << (64 - sh))) : lo64;   // bytes start..start+7, little endian
+    res = take == 8 ? v : (take ? (v << (8 * (8 - take))) : 0);                  // top-align when fewer than 8 remain
+    rcount = take;
+    off -= take;
+  };
+  for (uint32_t i0 = 0; i0 < num_values; i0 += WAVE) {
+    const uint32_t cnt = num_values - i0 < WAVE ? num_values - i0 : WAVE;
+    for (uint32_t j = 0; j < cnt; ++j) {
+      while (x < 16384u) {                     // RAnsDecoder.cs:58-61
+        if (rcount == 0) { if (off == 0) break; refill(); }
+        x = (x << 8) | (uint32_t)(res >> 56);
+        res <<= 8;
+        --rcount;
+      }
+      mine = (lane == j) ? x : mine;           // slot = low 12 bits of the state
+      const uint32_t k5 = (x >> 6) & 31u, l6 = x & 63u;
+      const uint32_t e0 = rdlane(tab_lo[k5], l6), e1 = rdlane(tab_hi[k5], l6);
+      const uint32_t e = (x & 2048u) ? e1 : e0;
+      x = (e >> 12) * (x >> 12) + (e & 4095u);      // RAnsDecoder.cs:62-65
+    }
+    if (lane < cnt) out[i0 + lane] = mine;
   }
-  const uint32_t tail = num_values & 63u;
-  if (tail && lane < tail) out[num_values - tail + lane] = mine;
+  WAIT_VM0();
   __syncthreads();
-  // zig-zag unless the transform's corrections are positive (D-4); BitUtilities.cs:94-103
+  // 5. slot -> symbol (lane parallel), then zig-zag unless the transform's corrections are positive (D-4)
   const bool positive = a.have_scheme && (a.pred_transform == 2 || a.pred_transform == 3);
-  if (!positive)
-    for (uint32_t i = lane; i < num_values; i += WAVE) {
-      uint32_t v = out[i];
-      out[i] = (v & 1u) ? (uint32_t)(-(int32_t)(v >> 1) - 1) : (v >> 1);
-    }
+  for (uint32_t i = lane; i < num_values; i += WAVE) {
+    uint32_t v = slot_sym[out[i] & 4095u];
+    out[i] = positive ? v : ((v & 1u) ? (uint32_t)(-(int32_t)(v >> 1) - 1) : (v >> 1));
+  }
 }
 
 // Launched once per tier so that the LDS footprint of the cumulative table does not cap occupancy:
@@ -1666,7 +1703,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayo
   if (a.source == SRC_BYTES) return;
   {
     const uint32_t ns = a.source == SRC_RAW ? a.num_symbols : 0u;
-    if (a.source == SRC_RAW && a.precision_bits == 12 && ns > 64 && ns <= REG_MAX_SYMS) return;   // k_symbols_reg
+    if (a.source == SRC_RAW && a.precision_bits == 12 && ns > 64 && ns <= REG_MAX_SYMS && L.out_cap[ai] >= 4096 * 6) return;   // k_symbols_reg
     const int tier = ns <= 64 ? 0 : (ns <= 960 ? 1 : 2);
     if (tier != TIER) return;
   }
@@ -1889,13 +1926,69 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
     o.center = max_value / 2;
     o.max_q = (1 << q) - 1;
     const bool canonical = a.pred_transform == 3;
-    int32_t ps = 0, pt = 0;
-    for (uint32_t p0 = 0; p0 < entries; p0 += WAVE) {
+    const uint32_t M = (uint32_t)o.max_q;
+    // In the canonical frame of the predicted value (diamond inversion + rotation into the bottom-left
+    // quadrant) the delta recurrence is  w[p] = mod_max(w[p-1] + corr[p])  as long as consecutive values
+    // stay in the same class, i.e. a prefix sum modulo max_q.  Per step: lane 0 is computed exactly, lanes
+    // 1..63 take the scan value mapped back with lane 0's class, then every lane re-evaluates the exact
+    // transform from its neighbour's value and the run is cut at the first disagreement.  When runs get
+    // short (values hopping between classes) the chunk falls back to the sequential loop.
+    int32_t ps = 0, pt = 0;           // o[p0-1]
+    uint32_t p0 = 0, short_runs = 0;
+    while (p0 < entries) {
       const uint32_t p = p0 + lane;
+      const bool live = p < entries;
       int2 cv = make_int2(0, 0);
-      if (p < entries) cv = ((const int2 *)w)[p];
-      int32_t rs = 0, rt = 0;
+      if (live) cv = ((const int2 *)w)[p];
       const uint32_t cnt = entries - p0 < WAVE ? entries - p0 : WAVE;
+      if (short_runs < 2) {
+        // class of the prediction of lane 0 and its canonical value
+        int32_t us = ps - o.center, ut = pt - o.center;
+        const int32_t aus = us < 0 ? -us : us, aut = ut < 0 ? -ut : ut;
+        const bool in_d = (uint32_t)aus + (uint32_t)aut <= (uint32_t)o.center;
+        if (!in_d) oct_invert_diamond(o.center, us, ut);
+        bool bl = true;
+        int rot = 0;
+        if (canonical) {
+          bl = (us == 0 && ut == 0) || (us < 0 && ut <= 0);
+          if (us == 0) rot = ut == 0 ? 0 : (ut > 0 ? 3 : 1);
+          else if (us > 0) rot = ut >= 0 ? 2 : 1;
+          else rot = ut <= 0 ? 0 : 3;
+          if (!bl) oct_rotate(us, ut, rot);
+        }
+        // canonical values along the run: w_i = mod_max(u + corr_0 + ... + corr_i)
+        uint32_t xs = (uint32_t)(((int64_t)us + o.center) % (int64_t)M + ((((int64_t)us + o.center) % (int64_t)M) < 0 ? (int64_t)M : 0));
+        uint32_t xt = (uint32_t)(((int64_t)ut + o.center) % (int64_t)M + ((((int64_t)ut + o.center) % (int64_t)M) < 0 ? (int64_t)M : 0));
+        uint32_t ss = live ? ((uint32_t)cv.x % M) : 0u, st = live ? ((uint32_t)cv.y % M) : 0u;
+        if (lane == 0) { ss = addmod(ss, xs, M); st = addmod(st, xt, M); }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          uint32_t ys = __shfl_up(ss, d, 64), yt = __shfl_up(st, d, 64);
+          if ((int)lane >= d) { ss = addmod(ss, ys, M); st = addmod(st, yt, M); }
+        }
+        int32_t os = (int32_t)ss - o.center, ot = (int32_t)st - o.center;     // w in [-center, center]
+        if (canonical && !bl) oct_rotate(os, ot, (4 - rot) % 4);
+        if (!in_d) oct_invert_diamond(o.center, os, ot);
+        os += o.center; ot += o.center;
+        // exact re-evaluation from the neighbour's value
+        int32_t prs = __shfl_up(os, 1, 64), prt = __shfl_up(ot, 1, 64);
+        if (lane == 0) { prs = ps; prt = pt; }
+        int32_t es, et;
+        oct_original(o, canonical, prs, prt, cv.x, cv.y, es, et);
+        const bool good = live && es == os && et == ot && (uint32_t)cv.x < M && (uint32_t)cv.y < M;
+        uint32_t K = leading_lanes(good);
+        if (K == 0) {               // lane 0 disagrees only if a correction is out of range: take its exact value
+          K = 1;
+          os = es; ot = et;
+        }
+        if (lane < K) ((int2 *)w)[p] = make_int2(os, ot);
+        ps = (int32_t)rdlane((uint32_t)os, K - 1); pt = (int32_t)rdlane((uint32_t)ot, K - 1);
+        p0 += K;
+        short_runs = K < 8 ? short_runs + 1 : 0;
+        continue;
+      }
+      // sequential chunk (PredictionSchemeDeltaDecoder.cs:23-37), corrections in registers
+      int32_t rs = 0, rt = 0;
       for (uint32_t i = 0; i < cnt; ++i) {
         const int32_t c0 = (int32_t)rdlane((uint32_t)cv.x, i), c1 = (int32_t)rdlane((uint32_t)cv.y, i);
         int32_t os, ot;
@@ -1903,7 +1996,9 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
         if (lane == i) { rs = os; rt = ot; }
         ps = os; pt = ot;
       }
-      if (p < entries) ((int2 *)w)[p] = make_int2(rs, rt);
+      if (live) ((int2 *)w)[p] = make_int2(rs, rt);
+      p0 += cnt;
+      short_runs = 0;
     }
   }
 }

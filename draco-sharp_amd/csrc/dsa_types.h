@@ -94,7 +94,6 @@ struct MeshLayout {
   uint64_t d2c;            // u32[cap_vertices]
   uint64_t v2d;            // i32[cap_vertices]
   uint64_t fvis, vvis;     // u8[F], u8[cap_vertices] (vertex flags: bit0 visited, bit1 on boundary)
-  uint64_t jnl;            // u32[4F]: corner reached from a corner by "go right, then go left" (traversal successor table)
   uint64_t fstamp, vstamp; // u32[F], u32[cap_vertices]: (run id, position) stamps of the speculative traversal runs
   uint64_t splits;         // u32[4*cap_splits]: events (source, split|edge<<31), then active pairs (decoder symbol id, corner)
   uint32_t cap_splits;
