@@ -342,6 +342,10 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   HIP_TRY(ctx, hipMemsetAsync(b->d_descs, 0, sizeof(MeshDesc) * n, st));
   HIP_TRY(ctx, hipMemcpyAsync(b->d_globals, &b->globals, sizeof(BatchGlobals), hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, mark());
+  {
+    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
+    hipLaunchKernelGGL(dsa::k_init, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, n);
+  }
   hipLaunchKernelGGL(dsa::k_locate, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, b->d_globals);
   HIP_TRY(ctx, mark());
   const uint32_t na = std::max<uint32_t>(1, b->max_atts);
@@ -363,11 +367,6 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   hipLaunchKernelGGL(dsa::k_conn_checks, dim3(n), dim3(WAVE), 0, ctx->stream3, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_join3, ctx->stream3));
   HIP_TRY(ctx, mark());
-  {
-    // few fat blocks: these elementwise kernels are workgroup-dispatch bound with one block per 256 elements
-    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
-    hipLaunchKernelGGL(dsa::k_traverse_prep, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
-  }
   hipLaunchKernelGGL(dsa::k_traverse, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, mark());
   {

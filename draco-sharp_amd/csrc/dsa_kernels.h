@@ -567,8 +567,8 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
   const uint8_t *s = arena + L.stream;
   uint32_t *frec = (uint32_t *)(arena + L.frec);
   uint2 *vrec = (uint2 *)(arena + L.vrec);
-  uint32_t *stack_mem = (uint32_t *)(arena + L.v2d);      // active corners below the top (<= #E <= cap_vertices/3)
-  uint32_t *invalid_list = (uint32_t *)(arena + L.d2c);   // merged-away vertices (<= num_split_symbols)
+  uint32_t *stack_mem = (uint32_t *)(arena + L.para);     // active corners below the top (<= #E <= cap_vertices/3); para[] is written later
+  uint32_t *invalid_list = (uint32_t *)(arena + L.vrank); // merged-away vertices (<= num_split_symbols); consumed before vrank[] is written
   uint32_t *events = (uint32_t *)(arena + L.splits);      // (source, split | edge<<31) per topology split event
   uint32_t *pairs = events + 2 * (size_t)L.cap_splits;    // topologySplitActiveCorners: (decoder symbol id, corner)
   const uint32_t F = uni(D->num_faces), VMAX = uni(L.cap_vertices);
@@ -1046,6 +1046,16 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
     }
     if (lane == 0) D->num_points = base;
   }
+  // ---- IsOnBoundary per vertex (CornerTable.cs:174-178) for the traversal: bit1 of the vertex flag
+  {
+    uint8_t *vflag = arena + L.vvis;
+    for (uint32_t v = lane; v < NVALL; v += WAVE) {
+      const uint32_t lm = vrec[v].x;
+      uint8_t fl = 0;
+      if (lm != DSA_INVALID && lm < 4 * F && (lm & 3u) != 3u) fl = frec[fo_idx(qnext(lm))] == DSA_INVALID ? 2 : 0;
+      vflag[v] = fl;
+    }
+  }
   if (lane == 0) {
     D->dbg[0] = (uint32_t)(t_loop - t_start); D->dbg[1] = (uint32_t)(t_tail - t_loop); D->dbg[2] = (uint32_t)(t_sym - t_tail);
     D->dbg[3] = (uint32_t)(t_seam - t_sym); D->dbg[4] = (uint32_t)(clk() - t_seam);
@@ -1151,33 +1161,20 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
 // pushes, pops, boundary tips, irregular turns -- takes the scalar step, which is the reference's
 // loop body verbatim.  Either way each step is the sequential algorithm's result.
 // =========================================================================
-// Lane-parallel preparation of the traversal state: visited flags, v2d = -1, IsOnBoundary per vertex
-// (CornerTable.cs:174-178) and the stamp arrays.
-__global__ __launch_bounds__(256) void k_traverse_prep(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n) {
+// Scratch initialisation for the traversal (no dependence on the stream contents: runs first):
+// face-visited marks, run stamps, vertex_to_data = -1.
+__global__ __launch_bounds__(256) void k_init(uint8_t *arena, const MeshLayout *layouts, uint32_t n) {
   uint32_t mesh = blockIdx.y;
   if (mesh >= n) return;
-  const MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK) return;
   const MeshLayout &L = layouts[mesh];
-  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
-  const uint2 *vrec = (const uint2 *)(arena + L.vrec);
   int32_t *v2d = (int32_t *)(arena + L.v2d);
-  uint8_t *fvis = arena + L.fvis, *vflag = arena + L.vvis;
+  uint32_t *fvis4 = (uint32_t *)(arena + L.fvis);
   uint32_t *fstamp = (uint32_t *)(arena + L.fstamp), *vstamp = (uint32_t *)(arena + L.vstamp);
-  const uint32_t F = D->num_faces, NVALL = D->num_all_vertices;
+  const uint32_t F = L.cap_faces, V = L.cap_vertices;
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   for (uint32_t f = tid; f < F; f += stride) fstamp[f] = 0xFFFFFFFFu;
-  for (uint32_t w4 = tid; w4 < (F + 3) / 4; w4 += stride) ((uint32_t *)fvis)[w4] = 0;     // regions are 256-byte padded
-  for (uint32_t v = tid; v < L.cap_vertices; v += stride) {
-    v2d[v] = -1;
-    vstamp[v] = 0xFFFFFFFFu;
-    uint8_t fl = 0;
-    if (v < NVALL) {
-      uint32_t lm = vrec[v].x;
-      if (lm != DSA_INVALID && lm < 4 * F && (lm & 3u) != 3u) fl = frec[fo_idx(qnext(lm))] == DSA_INVALID ? 2 : 0;
-    }
-    vflag[v] = fl;
-  }
+  for (uint32_t w4 = tid; w4 < (F + 3) / 4; w4 += stride) fvis4[w4] = 0;     // regions are 256-byte padded
+  for (uint32_t v = tid; v < V; v += stride) { v2d[v] = -1; vstamp[v] = 0xFFFFFFFFu; }
 }
 
 // k_traverse speculation: from a corner whose tip is new and interior the DFS usually repeats the pair
