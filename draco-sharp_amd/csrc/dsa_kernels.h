@@ -1311,6 +1311,15 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
         uint32_t len = leading_lanes(a_ok);                 // verified chain a_0 .. a_(len-1)
         const bool in_chain = lane < len;
         const bool pair_ok = in_chain && b_ok && tipB < NV && corner_ok(lcB) && (rcB == DSA_INVALID || corner_ok(rcB));
+        // state before the step (plain loads, issued ahead of the stamp atomics)
+        uint32_t fA_before = 0, fB_before = 1, fR_before = 1, fL_before = 1, flA = 1, flB = 0;
+        if (pair_ok) {
+          fA_before = lane == 0 ? 0u : fvis[fa];
+          fB_before = fvis[fb];
+          fR_before = rcB != DSA_INVALID ? fvis[rcB >> 2] : 1u;
+          fL_before = fvis[lcB >> 2];
+          flA = vflag[tipA]; flB = vflag[tipB];
+        }
         // stamps: first position of every face / tip in the candidate list
         const uint32_t keyN = base | (2 * lane), keyL = base | (2 * lane + 1);
         if (pair_ok) {
@@ -1326,11 +1335,6 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           const uint32_t stb = __hip_atomic_load(&vstamp[tipB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const uint32_t srf = rcB != DSA_INVALID ? __hip_atomic_load(&fstamp[rcB >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
           const uint32_t slf = __hip_atomic_load(&fstamp[lcB >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t fA_before = lane == 0 ? 0u : fvis[fa];
-          const uint32_t fB_before = fvis[fb];
-          const uint32_t fR_before = rcB != DSA_INVALID ? fvis[rcB >> 2] : 1u;
-          const uint32_t fL_before = fvis[lcB >> 2];
-          const uint32_t flA = vflag[tipA], flB = vflag[tipB];
           // N element: face first seen here, tip new (not visited before, first seen here) and interior
           const bool n_ok = fA_before == 0 && sfa == keyN && flA == 0 && sta == keyN;
           // L element: face first seen here, tip already visited, right side done, left side open
@@ -1360,7 +1364,6 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           corner = nxt;
           n_run += 1; n_run_faces += 2 * K;
           if (K < 4) backoff = 2;
-          WAIT_VM0();
           continue;
         }
         ++n_fail;
@@ -1379,13 +1382,11 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
         if (!(uni_flag & 2u)) {
           if (rc == DSA_INVALID) TR_FAIL(303);
           corner = rc;
-          WAIT_VM0();
           continue;
         }
       }
       const bool rdone = rc == DSA_INVALID || uni((uint32_t)fvis[rc >> 2]) != 0;
       const bool ldone = lc == DSA_INVALID || uni((uint32_t)fvis[lc >> 2]) != 0;
-      WAIT_VM0();
       if (rdone) {
         if (ldone) { --sp; break; }
         corner = lc;
@@ -1395,7 +1396,6 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           if (sp >= stack_cap) TR_FAIL(304);
           if (lane == 0) { stack[sp - 1] = lc; stack[sp] = rc; }
           ++sp;
-          WAIT_VM0();
           break;
         }
       }
