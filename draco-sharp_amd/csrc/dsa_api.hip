@@ -119,7 +119,7 @@ struct dsa_context {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;     // symbol decode runs here, concurrently with connectivity + traversal
   hipStream_t stream3 = nullptr;     // connectivity validation (link symmetry, seam streams)
-  hipEvent_t ev_join3 = nullptr;
+  hipEvent_t ev_join3 = nullptr, ev_trav = nullptr, ev_maps = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_conn = nullptr;
   bool own_stream = false;
   bool profiling = false;
@@ -278,6 +278,8 @@ dsa_status dsa_context_create(int device, void *stream, dsa_context **out) {
   if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_trav, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_maps, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_conn, hipEventDisableTiming) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
@@ -294,6 +296,8 @@ void dsa_context_destroy(dsa_context *ctx) {
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
   if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
+  if (ctx->ev_trav) (void)hipEventDestroy(ctx->ev_trav);
+  if (ctx->ev_maps) (void)hipEventDestroy(ctx->ev_maps);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -369,6 +373,14 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   HIP_TRY(ctx, mark());
   hipLaunchKernelGGL(dsa::k_traverse, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, mark());
+  // faces + point maps need only the traversal: third stream, beside the prediction kernels
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_trav, st));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_trav, 0));
+  {
+    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
+    hipLaunchKernelGGL(dsa::k_point_maps, dim3(gx, n), dim3(256), 0, ctx->stream3, b->arena, b->d_layouts, b->d_descs, n);
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, ctx->stream3));
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 8191) / 8192, 4));
     hipLaunchKernelGGL(dsa::k_para_operands, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
@@ -383,6 +395,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
     hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   }
+  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_maps, 0));
   HIP_TRY(ctx, mark());
   HIP_TRY(ctx, hipGetLastError());
   return DSA_OK;

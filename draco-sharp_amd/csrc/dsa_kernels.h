@@ -1126,16 +1126,26 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
         uint32_t state = rb.state, off = rb.off;
         const uint32_t p = rb.p;
         uint32_t i = 0;
-        while (i < edges) {
+        while (i < edges && any == 0) {
           if (state < 4096 && off > 0) state = state * 256 + rb.buf[--off];
-          const uint32_t lim = edges;
-          do {
-            const uint32_t quot = state >> 8, rem = state & 255u, xn = quot * p;
-            const bool val = rem < p;
-            any |= val ? 1u : 0u;
-            state = val ? xn + rem : state - xn - p;
-            ++i;
-          } while (i < lim && (state >= 4096 || off == 0));
+          if (p <= 16 && state >= 8192 && i + 8 <= edges) {
+            // eight zero bits shrink the state by at most (15/16)^8 > 1/2, so none of them renormalises;
+            // a set bit ends the decode (seams are reported as not implemented), so only the zero-bit
+            // successor is computed
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const uint32_t quot = state >> 8, rem = state & 255u;
+              any |= rem < p ? 1u : 0u;
+              state = state - quot * p - p;
+            }
+            i += 8;
+            continue;
+          }
+          const uint32_t quot = state >> 8, rem = state & 255u, xn = quot * p;
+          const bool val = rem < p;
+          any |= val ? 1u : 0u;
+          state = val ? xn + rem : state - xn - p;
+          ++i;
         }
       }
     }
@@ -2055,19 +2065,38 @@ __global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayo
     const uint32_t total = entries * a.nc * data_type_length(a.data_type);
     for (uint32_t i = tid; i < total; i += stride) out[i] = src[i];
   }
-  // faces as point ids (Mesh.cs faces; MeshEdgeBreakerDecoder.cs:537-553,627-637) and the
-  // point -> entry map (MeshTraversalSequencer.cs:33-50; vertex attributes on the position corner table)
-  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
+}
+
+// =========================================================================
+// k_point_maps: faces as point ids (Mesh.cs:15-69; MeshEdgeBreakerDecoder.cs:537-553,627-637) and the
+// point -> entry map of every attribute (MeshTraversalSequencer.cs:33-50; vertex attributes on the
+// position corner table: one map value per vertex that has a corner).  Needs only the traversal, so it
+// runs beside the prediction kernels.
+// =========================================================================
+__global__ __launch_bounds__(256) void k_point_maps(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n) {
+  uint32_t mesh = blockIdx.y;
+  if (mesh >= n) return;
+  const MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK) return;
+  const MeshLayout &L = layouts[mesh];
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  const uint4 *frec = (const uint4 *)(arena + L.frec);
   const uint32_t *vrank = (const uint32_t *)(arena + L.vrank);
   const int32_t *v2d = (const int32_t *)(arena + L.v2d);
   int32_t *faces = (int32_t *)(arena + L.faces);
-  uint32_t *map = (uint32_t *)(arena + L.map[ai]);
-  for (uint32_t c = tid; c < 3 * D->num_faces; c += stride) {
-    uint32_t f = c / 3u, k = c - 3u * f;
-    uint32_t v = frec[8 * f + k];
-    uint32_t point = vrank[v];
-    if (ai == 0) faces[c] = (int32_t)point;
-    map[point] = (uint32_t)v2d[v];
+  const uint32_t NV = D->num_vertices, na = D->num_attributes;
+  for (uint32_t f = tid; f < D->num_faces; f += stride) {
+    const uint4 vv = frec[(size_t)f * 2];
+    if (vv.x < NV && vv.y < NV && vv.z < NV) {
+      faces[3 * f] = (int32_t)vrank[vv.x]; faces[3 * f + 1] = (int32_t)vrank[vv.y]; faces[3 * f + 2] = (int32_t)vrank[vv.z];
+    }
+  }
+  for (uint32_t v = tid; v < NV; v += stride) {
+    const int32_t e = v2d[v];
+    if (e < 0) continue;                 // no corner: the map keeps its initial value
+    const uint32_t point = vrank[v];
+    if (point >= D->num_points) continue;
+    for (uint32_t ai = 0; ai < na; ++ai) ((uint32_t *)(arena + L.map[ai]))[point] = (uint32_t)e;
   }
 }
 
