@@ -1640,47 +1640,80 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
   uint32_t mine = 0;
   WAIT_VM0();
   // 64 positions per outer iteration; the slot (low 12 bits of the state) of position j is parked in lane j
-  // with v_writelane and stored with one coalesced store.  Both halves of the table are read with the same
-  // M0 index and the result selected afterwards: no branch in the per-symbol path except the renormalisation.
-  // Byte reservoir: the stream is consumed from its tail, so a little-endian 64-bit word ending at the read
-  // position holds the next 8 bytes most-significant first.  res is refilled every 8 bytes from the register
-  // window (two v_readlane + funnel shift); a renormalisation step is then 4 scalar ops.
-  uint64_t res = 0;
-  uint32_t rcount = 0;                         // valid bytes in res (top-aligned)
-  auto refill = [&]() {
-    // bytes [off-8, off) relative to buf; the window is indexed from abuf = buf - mis, and never reads below abuf
-    const uint32_t take = off < 8u ? off : 8u;
-    const uint32_t end = off + mis;            // one past the last byte, in abuf coordinates
-    const uint32_t start = end - take;
-    const uint32_t d0 = start >> 2;            // first dword; the 8 bytes span at most 3 dwords
-    uint32_t w[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const uint32_t d = d0 + k, ch = d >> 6;
-      if (ch != chunk) { chunk = ch; W = abuf[(size_t)ch * 64 + lane]; WAIT_VM0(); }
-      w[k] = rdlane(W, d & 63u);
-    }
-    const uint32_t sh = (start & 3u) * 8;
-    uint64_t lo64 = ((uint64_t)w[1] << 32) | w[0];
-    uint64_t v = sh ? ((lo64 >> sh) | ((uint64_t)w[2] << (64 - sh))) : lo64;   // bytes start..start+7, little endian
-    res = take == 8 ? v : (take ? (v << (8 * (8 - take))) : 0);                  // top-align when fewer than 8 remain
-    rcount = take;
-    off -= take;
-  };
+  // and stored with one coalesced store.  The per-symbol loop is hand-scheduled (RAnsDecoder.cs:56-65):
+  //   * the state x and a 4-byte reservoir live in one SGPR pair {res, x}; a renormalisation byte is a
+  //     single s_lshl_b64 of the pair (the stream is consumed from its tail, so an aligned little-endian
+  //     dword holds the next 4 bytes most-significant first);
+  //   * both halves of the slot table are read under one s_set_gpr_idx_on and selected by bit 11;
+  //   * the block leaves to C only to refill the reservoir (once per 4 bytes) or when 64 positions are done.
+  // The tables are pinned to v[16:79] so that the indexed v_mov can name their first register.
+  uint64_t P = (uint64_t)x << 32;
+  uint32_t rc = 0;                             // valid bytes in the reservoir (top-aligned in P's low dword)
+  bool exhausted = false;
   for (uint32_t i0 = 0; i0 < num_values; i0 += WAVE) {
-    const uint32_t cnt = num_values - i0 < WAVE ? num_values - i0 : WAVE;
-    for (uint32_t j = 0; j < cnt; ++j) {
-      while (x < 16384u) {                     // RAnsDecoder.cs:58-61
-        if (rcount == 0) { if (off == 0) break; refill(); }
-        x = (x << 8) | (uint32_t)(res >> 56);
-        res <<= 8;
-        --rcount;
+    const uint32_t cnt = uni(num_values - i0 < WAVE ? num_values - i0 : WAVE);
+    uint32_t j = 0;
+    while (j < cnt) {
+      if (!exhausted) {
+        uint32_t k5, e0, e1, va, vb;
+        asm volatile(
+            "Lrtop%=:\n"
+            " s_cmpk_lt_u32 s21, 0x4000\n"
+            " s_cbranch_scc1 Lrren%=\n"
+            " v_cmp_eq_u32_e32 vcc, %[j], %[lane]\n"
+            " s_bfe_u32 %[k5], s21, 0x50006\n"
+            " v_mov_b32_e32 %[va], s21\n"
+            " v_cndmask_b32_e32 %[mine], %[mine], %[va], vcc\n"
+            " s_set_gpr_idx_on %[k5], gpr_idx(SRC0)\n"
+            " v_mov_b32_e32 %[va], v16\n"
+            " v_mov_b32_e32 %[vb], v48\n"
+            " s_set_gpr_idx_off\n"
+            " v_readlane_b32 %[e0], %[va], s21\n"
+            " v_readlane_b32 %[e1], %[vb], s21\n"
+            " s_bitcmp1_b32 s21, 11\n"
+            " s_cselect_b32 %[e0], %[e1], %[e0]\n"
+            " s_lshr_b32 %[e1], %[e0], 12\n"
+            " s_lshr_b32 %[k5], s21, 12\n"
+            " s_mul_i32 %[e1], %[e1], %[k5]\n"
+            " s_and_b32 %[e0], %[e0], 0xfff\n"
+            " s_add_i32 s21, %[e1], %[e0]\n"
+            " s_add_i32 %[j], %[j], 1\n"
+            " s_cmp_lt_u32 %[j], %[cnt]\n"
+            " s_cbranch_scc1 Lrtop%=\n"
+            " s_branch Lrend%=\n"
+            "Lrren%=:\n"
+            " s_sub_u32 %[rc], %[rc], 1\n"
+            " s_cbranch_scc1 Lrempty%=\n"
+            " s_lshl_b64 s[20:21], s[20:21], 8\n"
+            " s_branch Lrtop%=\n"
+            "Lrempty%=:\n"
+            " s_mov_b32 %[rc], 0\n"
+            "Lrend%=:\n"
+            : "+{s[20:21]}"(P), [rc] "+s"(rc), [j] "+s"(j), [mine] "+v"(mine), [k5] "=&s"(k5), [e0] "=&s"(e0), [e1] "=&s"(e1),
+              [va] "=&v"(va), [vb] "=&v"(vb)
+            : [cnt] "s"(cnt), [lane] "v"(lane), "{v[16:47]}"(tab_lo), "{v[48:79]}"(tab_hi)
+            : "vcc", "scc");
+        if (j < cnt) {                         // the state needs a byte and the reservoir is empty
+          if (off == 0) exhausted = true;      // RAnsDecoder.cs:58-61: no bytes left, the state stays as it is
+          else {
+            const uint32_t end = off + mis;    // one past the next byte, in abuf coordinates
+            const uint32_t d = (end - 1) >> 2, r = end - 4 * d, ch = d >> 6;
+            if (ch != chunk) { chunk = ch; W = abuf[(size_t)ch * 64 + lane]; WAIT_VM0(); }
+            const uint32_t res = rdlane(W, d & 63u) << (8 * (4 - r));
+            rc = uni(r < off ? r : off);
+            off -= rc;
+            P = (P & 0xFFFFFFFF00000000ull) | res;
+          }
+        }
+      } else {
+        const uint32_t xs = uni((uint32_t)(P >> 32));
+        mine = (lane == j) ? xs : mine;
+        const uint32_t k5 = (xs >> 6) & 31u, l6 = xs & 63u;
+        const uint32_t e0 = rdlane(tab_lo[k5], l6), e1 = rdlane(tab_hi[k5], l6);
+        const uint32_t e = (xs & 2048u) ? e1 : e0;
+        P = (uint64_t)((e >> 12) * (xs >> 12) + (e & 4095u)) << 32;
+        ++j;
       }
-      mine = (lane == j) ? x : mine;           // slot = low 12 bits of the state
-      const uint32_t k5 = (x >> 6) & 31u, l6 = x & 63u;
-      const uint32_t e0 = rdlane(tab_lo[k5], l6), e1 = rdlane(tab_hi[k5], l6);
-      const uint32_t e = (x & 2048u) ? e1 : e0;
-      x = (e >> 12) * (x >> 12) + (e & 4095u);      // RAnsDecoder.cs:62-65
     }
     if (lane < cnt) out[i0 + lane] = mine;
   }
