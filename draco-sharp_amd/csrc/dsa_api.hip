@@ -354,7 +354,9 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   HIP_TRY(ctx, mark());
   const uint32_t na = std::max<uint32_t>(1, b->max_atts);
   // fork: entropy decode of every attribute stream on the second stream (it only needs k_locate's offsets)
-  hipStream_t st2 = ctx->stream2;
+  // DSA_SERIAL=1 (diagnostics): everything on the main stream, so that stage times are stand-alone kernel times
+  static const bool serial = getenv("DSA_SERIAL") != nullptr;
+  hipStream_t st2 = serial ? st : ctx->stream2, st3 = serial ? st : st3;
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_fork, 0));
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[0], st2));
@@ -367,20 +369,20 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   // link symmetry + seam streams are checked on the second stream while the traversal runs here
   HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st));
-  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_conn, 0));
-  hipLaunchKernelGGL(dsa::k_conn_checks, dim3(n), dim3(WAVE), 0, ctx->stream3, b->arena, b->d_layouts, b->d_descs, n);
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_join3, ctx->stream3));
+  HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_conn, 0));
+  hipLaunchKernelGGL(dsa::k_conn_checks, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_join3, st3));
   HIP_TRY(ctx, mark());
   hipLaunchKernelGGL(dsa::k_traverse, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, mark());
   // faces + point maps need only the traversal: third stream, beside the prediction kernels
   HIP_TRY(ctx, hipEventRecord(ctx->ev_trav, st));
-  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_trav, 0));
+  HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_trav, 0));
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
-    hipLaunchKernelGGL(dsa::k_point_maps, dim3(gx, n), dim3(256), 0, ctx->stream3, b->arena, b->d_layouts, b->d_descs, n);
+    hipLaunchKernelGGL(dsa::k_point_maps, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, ctx->stream3));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st3));
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 8191) / 8192, 4));
     hipLaunchKernelGGL(dsa::k_para_operands, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
