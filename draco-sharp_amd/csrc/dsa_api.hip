@@ -356,7 +356,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // fork: entropy decode of every attribute stream on the second stream (it only needs k_locate's offsets)
   // DSA_SERIAL=1 (diagnostics): everything on the main stream, so that stage times are stand-alone kernel times
   static const bool serial = getenv("DSA_SERIAL") != nullptr;
-  hipStream_t st2 = serial ? st : ctx->stream2, st3 = serial ? st : st3;
+  hipStream_t st2 = serial ? st : ctx->stream2, st3 = serial ? st : ctx->stream3;
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_fork, 0));
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[0], st2));
@@ -370,6 +370,10 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // link symmetry + seam streams are checked on the second stream while the traversal runs here
   HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_conn, 0));
+  {
+    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
+    hipLaunchKernelGGL(dsa::k_link_check, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+  }
   hipLaunchKernelGGL(dsa::k_conn_checks, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_join3, st3));
   HIP_TRY(ctx, mark());

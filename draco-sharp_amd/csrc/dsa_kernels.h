@@ -1074,12 +1074,41 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
 }
 
 // =========================================================================
-// k_conn_checks: validation that does not gate the traversal, run on the second stream:
-//  * every opposite link must be mutual ("corner already has an opposite",
-//    MeshEdgeBreakerDecoder.cs:254,272,314,392) and every vertex id in range;
-//  * attribute seams (MeshEdgeBreakerDecoder.cs:502-535): lane i decodes the rABS stream of attribute
-//    data i.  Only seam-free attribute connectivity is handled on the device; a set bit is reported
-//    as not implemented.
+// k_link_check: every opposite link must be mutual ("corner already has an opposite",
+// MeshEdgeBreakerDecoder.cs:254,272,314,392) and every vertex id in range.  Element-parallel over the
+// faces; also counts the corners that have an opposite (two per interior edge) for the seam decode.
+// =========================================================================
+__global__ __launch_bounds__(256) void k_link_check(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  uint32_t mesh = blockIdx.y;
+  if (mesh >= n) return;
+  const MeshLayout &L = layouts[mesh];
+  MeshDesc *D = &descs[mesh];
+  if (status_of(D) != ST_OK) return;
+  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
+  const uint32_t F = D->num_faces, NV = D->num_vertices;
+  uint32_t bad = 0, interior = 0;
+  for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < F; f += gridDim.x * blockDim.x) {
+    const uint4 vv = ((const uint4 *)frec)[(size_t)f * 2], oo = ((const uint4 *)frec)[(size_t)f * 2 + 1];
+    const uint32_t ov[3] = {oo.x, oo.y, oo.z};
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k) {
+      const uint32_t o = ov[k];
+      if (o != DSA_INVALID) {
+        ++interior;
+        if (o >= 4 * F || (o & 3u) == 3u || frec[fo_idx(o)] != 4 * f + k) bad = 1;
+      }
+    }
+    if (vv.x >= NV || vv.y >= NV || vv.z >= NV) bad = 1;
+  }
+  for (int d = 32; d >= 1; d >>= 1) interior += __shfl_xor(interior, d, 64);
+  if (lane_id() == 0 && interior) atomicAdd(&D->interior_corners, interior);
+  if (__ballot(bad) && lane_id() == 0) fail(D, ST_INVALID, 263);
+}
+
+// =========================================================================
+// k_conn_checks: attribute seams (MeshEdgeBreakerDecoder.cs:502-535), on the third stream: lane i
+// decodes the rABS stream of attribute data i.  Only seam-free attribute connectivity is handled on the
+// device; a set bit is reported as not implemented.
 // =========================================================================
 __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   uint32_t mesh = blockIdx.x;
@@ -1088,33 +1117,12 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
   MeshDesc *D = &descs[mesh];
   if (status_of(D) != ST_OK) return;
   const uint8_t *s = arena + L.stream;
-  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
-  const uint32_t F = D->num_faces, NV = D->num_vertices;
   const uint32_t lane = lane_id();
   const uint64_t t0 = clk();
-  uint32_t interior_corners = 0;
-  {
-    uint32_t bad = 0;
-    for (uint32_t f = lane; f < F; f += WAVE) {
-      const uint4 vv = ((const uint4 *)frec)[(size_t)f * 2], oo = ((const uint4 *)frec)[(size_t)f * 2 + 1];
-      const uint32_t ov[3] = {oo.x, oo.y, oo.z};
-#pragma unroll
-      for (uint32_t k = 0; k < 3; ++k) {
-        uint32_t o = ov[k];
-        if (o != DSA_INVALID) {
-          ++interior_corners;
-          if (o >= 4 * F || (o & 3u) == 3u || frec[fo_idx(o)] != 4 * f + k) bad = 1;
-        }
-      }
-      if (vv.x >= NV || vv.y >= NV || vv.z >= NV) bad = 1;
-    }
-    if (__ballot(bad)) { if (lane == 0) fail(D, ST_INVALID, 263); return; }
-  }
-  const uint64_t t1 = clk();
+  const uint64_t t1 = t0;
   const uint32_t nad = D->num_att_data;
   if (nad > 0) {
-    for (int d = 32; d >= 1; d >>= 1) interior_corners += __shfl_xor(interior_corners, d, 64);
-    const uint32_t edges = interior_corners / 2;   // one seam bit per interior edge and attribute data
+    const uint32_t edges = __hip_atomic_load(&D->interior_corners, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / 2;   // one seam bit per interior edge and attribute data
     uint32_t any = 0;
     if (lane < nad) {
       Rabs rb;
