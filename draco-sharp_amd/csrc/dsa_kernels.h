@@ -559,6 +559,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
   __shared__ __attribute__((aligned(16))) uint32_t sh_stage[CN_STAGE * 8];
   __shared__ __attribute__((aligned(16))) uint32_t sh_rec[CN_REC_BLOCKS * 64 * 2];
   __shared__ uint32_t sh_win[CN_WIN];
+  __builtin_amdgcn_s_setprio(3);   // critical path: issue ahead of the entropy-decode waves sharing the CU
   uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
   const MeshLayout &L = layouts[mesh];
@@ -1208,6 +1209,7 @@ __global__ __launch_bounds__(256) void k_init(uint8_t *arena, const MeshLayout *
 #define TR_PAIRS 64
 
 __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  __builtin_amdgcn_s_setprio(3);   // critical path: issue ahead of the entropy-decode waves sharing the CU
   uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
   const MeshLayout &L = layouts[mesh];
@@ -1663,31 +1665,31 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
     uint32_t j = 0;
     while (j < cnt) {
       if (!exhausted) {
-        uint32_t k5, e0, e1, va, vb;
+        // r counts the remaining positions down (cnt-1 .. 0); position j = cnt-1-r is captured by the lane
+        // whose key is r.  The 64 rows v[16:79] are one indexed window: row = bits 11:6 of the state, lane =
+        // bits 5:0.  x' = f * (x >> 12) + (rem - cum) is evaluated on the whole row (v_mad_u32_u24: both
+        // factors < 2^12) and the state's lane is read back, which keeps the scalar pipe to 8 instructions.
+        uint32_t k6, q, va, vf;
+        uint32_t r = cnt - 1 - j;
+        const uint32_t key = cnt - 1 - lane;
         asm volatile(
             "Lrtop%=:\n"
             " s_cmpk_lt_u32 s21, 0x4000\n"
             " s_cbranch_scc1 Lrren%=\n"
-            " v_cmp_eq_u32_e32 vcc, %[j], %[lane]\n"
-            " s_bfe_u32 %[k5], s21, 0x50006\n"
+            " v_cmp_eq_u32_e32 vcc, %[r], %[key]\n"
+            " s_bfe_u32 %[k6], s21, 0x60006\n"
             " v_mov_b32_e32 %[va], s21\n"
+            " s_lshr_b32 %[q], s21, 12\n"
             " v_cndmask_b32_e32 %[mine], %[mine], %[va], vcc\n"
-            " s_set_gpr_idx_on %[k5], gpr_idx(SRC0)\n"
+            " s_set_gpr_idx_on %[k6], gpr_idx(SRC0)\n"
             " v_mov_b32_e32 %[va], v16\n"
-            " v_mov_b32_e32 %[vb], v48\n"
             " s_set_gpr_idx_off\n"
-            " v_readlane_b32 %[e0], %[va], s21\n"
-            " v_readlane_b32 %[e1], %[vb], s21\n"
-            " s_bitcmp1_b32 s21, 11\n"
-            " s_cselect_b32 %[e0], %[e1], %[e0]\n"
-            " s_lshr_b32 %[e1], %[e0], 12\n"
-            " s_lshr_b32 %[k5], s21, 12\n"
-            " s_mul_i32 %[e1], %[e1], %[k5]\n"
-            " s_and_b32 %[e0], %[e0], 0xfff\n"
-            " s_add_i32 s21, %[e1], %[e0]\n"
-            " s_add_i32 %[j], %[j], 1\n"
-            " s_cmp_lt_u32 %[j], %[cnt]\n"
-            " s_cbranch_scc1 Lrtop%=\n"
+            " v_lshrrev_b32_e32 %[vf], 12, %[va]\n"
+            " v_and_b32_e32 %[va], 0xfff, %[va]\n"
+            " v_mad_u32_u24 %[va], %[vf], %[q], %[va]\n"
+            " s_sub_u32 %[r], %[r], 1\n"          // also the wait state between the VALU write and v_readlane
+            " v_readlane_b32 s21, %[va], s21\n"
+            " s_cbranch_scc0 Lrtop%=\n"
             " s_branch Lrend%=\n"
             "Lrren%=:\n"
             " s_sub_u32 %[rc], %[rc], 1\n"
@@ -1697,10 +1699,10 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
             "Lrempty%=:\n"
             " s_mov_b32 %[rc], 0\n"
             "Lrend%=:\n"
-            : "+{s[20:21]}"(P), [rc] "+s"(rc), [j] "+s"(j), [mine] "+v"(mine), [k5] "=&s"(k5), [e0] "=&s"(e0), [e1] "=&s"(e1),
-              [va] "=&v"(va), [vb] "=&v"(vb)
-            : [cnt] "s"(cnt), [lane] "v"(lane), "{v[16:47]}"(tab_lo), "{v[48:79]}"(tab_hi)
+            : "+{s[20:21]}"(P), [rc] "+s"(rc), [r] "+s"(r), [mine] "+v"(mine), [k6] "=&s"(k6), [q] "=&s"(q), [va] "=&v"(va), [vf] "=&v"(vf)
+            : [key] "v"(key), "{v[16:47]}"(tab_lo), "{v[48:79]}"(tab_hi)
             : "vcc", "scc");
+        j = cnt - 1 - r;                       // r wrapped to 0xFFFFFFFF when the block completed: j == cnt
         if (j < cnt) {                         // the state needs a byte and the reservoir is empty
           if (off == 0) exhausted = true;      // RAnsDecoder.cs:58-61: no bytes left, the state stays as it is
           else {
