@@ -41,6 +41,21 @@ def cpu_baseline(blob, offsets, budget_s=12.0, max_meshes=1024):
             "host_cores_available": os.cpu_count()}
 
 
+def measured_traffic(kernel, meshes, triangles):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on
+    this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None if the committed
+    measurement is for another workload.  PMC counters cannot be collected from inside the process."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t["meshes_per_gpu"] == meshes and t["triangles_per_mesh"] == triangles and kernel in t["kernels"]:
+            return t["kernels"][kernel]["hbm_bytes"], "profiles/r01_traffic.json"
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,8 +125,9 @@ def main():
         stages = {k: v / args.steps for k, v in stage_sum.items()}
         kernel_stages = {k: v for k, v in stages.items() if k != "total"}
         dom = max(kernel_stages, key=kernel_stages.get)
-        kernel_name = {"symbols": "k_symbols_reg", "traverse": "k_traverse (+k_traverse_prep)"}.get(dom, "k_" + dom)
+        kernel_name = {"symbols": "k_symbols_reg"}.get(dom, "k_" + dom)
         achieved = alg_bytes / (kernel_stages[dom] * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(kernel_name, args.meshes, 2 * nx * ny)
         out = {
             "metric": "decoded_meshes_per_sec",
             "value": total_meshes / (elapsed / args.steps),
@@ -134,7 +150,8 @@ def main():
             "arena_bytes_per_gpu": batch.arena_bytes,
             "stage_ms": stages,
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel_ms": kernel_stages[dom], "algorithmic_bytes": alg_bytes},
             "setup_s": {"generate": t_gen, "upload_and_layout": t_upload},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -370,10 +370,6 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // link symmetry + seam streams are checked on the second stream while the traversal runs here
   HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_conn, 0));
-  {
-    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
-    hipLaunchKernelGGL(dsa::k_link_check, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
-  }
   hipLaunchKernelGGL(dsa::k_conn_checks, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_join3, st3));
   HIP_TRY(ctx, mark());
@@ -402,6 +398,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   }
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_maps, 0));
+  hipLaunchKernelGGL(dsa::k_seal, dim3((n + 255) / 256), dim3(256), 0, st, b->d_descs, n);
   HIP_TRY(ctx, mark());
   HIP_TRY(ctx, hipGetLastError());
   return DSA_OK;

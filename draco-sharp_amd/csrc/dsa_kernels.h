@@ -618,6 +618,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
   uint32_t drop_bits = sym_mis * 8;     // bits of the first word that precede the section
   uint64_t bits_used = (uint64_t)sym_mis * 8;
   bool failed = false;
+  uint32_t n_links = 0;                 // opposite links made (each sets two corners)
 
   // write back one dirty block of the record cache (all lanes)
   auto rec_writeback = [&](uint32_t slot) {
@@ -758,6 +759,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
           T1 = vb_last; T2 = nv0 + k - 1;
           num_verts = nv0 + k;
           sid += 2 * k;
+          n_links += 3 * k;
           stage_base = sid;
           bits_used += 4ull * k;
           {                                 // consume 4k bits: first from the buffer, the rest from the window
@@ -810,6 +812,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
       }
       REC_DIRTY(va_prev, hit_a);
       T1 = vb_next;                              // face (vx, vb_next, va_prev)
+      n_links += 2;
       ++sid;
       PROF(acc_c, n_c);
       continue;
@@ -861,6 +864,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
       }
       if (!uni(ok)) { failed = true; break; }
       sp = uni(r_sp); num_invalid = uni(r_inv); T1 = uni(rT1); T2 = uni(rT2);
+      n_links += 2;
       ++sid;
       stage_base = sid;                   // the new face went straight to global memory
       __syncthreads();
@@ -873,6 +877,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
       bb >>= 3; bcnt -= 3; bits_used += 3;
       ++num_verts;
       const bool hit_n = REC_HIT(nv), hit_2 = REC_HIT(T2);
+      n_links += 1;
       if (b3 == 5u) {
         if (lane == 0) {
           *(uint4 *)&sh_stage[so] = make_uint4(T2, T1, nv, 0u);
@@ -986,6 +991,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
       }
       if (bad) break;
       if (num_faces != F) { fail(D, ST_INVALID, 256); break; }
+      D->interior_corners = 2 * (n_links + 3 * (num_faces - num_symbols));
       uint32_t nvert = num_verts;
       for (uint32_t k = 0; k < num_invalid && !bad; ++k) {
         uint32_t inv = invalid_list[k];
@@ -1075,38 +1081,6 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
 }
 
 // =========================================================================
-// k_link_check: every opposite link must be mutual ("corner already has an opposite",
-// MeshEdgeBreakerDecoder.cs:254,272,314,392) and every vertex id in range.  Element-parallel over the
-// faces; also counts the corners that have an opposite (two per interior edge) for the seam decode.
-// =========================================================================
-__global__ __launch_bounds__(256) void k_link_check(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
-  uint32_t mesh = blockIdx.y;
-  if (mesh >= n) return;
-  const MeshLayout &L = layouts[mesh];
-  MeshDesc *D = &descs[mesh];
-  if (status_of(D) != ST_OK) return;
-  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
-  const uint32_t F = D->num_faces, NV = D->num_vertices;
-  uint32_t bad = 0, interior = 0;
-  for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < F; f += gridDim.x * blockDim.x) {
-    const uint4 vv = ((const uint4 *)frec)[(size_t)f * 2], oo = ((const uint4 *)frec)[(size_t)f * 2 + 1];
-    const uint32_t ov[3] = {oo.x, oo.y, oo.z};
-#pragma unroll
-    for (uint32_t k = 0; k < 3; ++k) {
-      const uint32_t o = ov[k];
-      if (o != DSA_INVALID) {
-        ++interior;
-        if (o >= 4 * F || (o & 3u) == 3u || frec[fo_idx(o)] != 4 * f + k) bad = 1;
-      }
-    }
-    if (vv.x >= NV || vv.y >= NV || vv.z >= NV) bad = 1;
-  }
-  for (int d = 32; d >= 1; d >>= 1) interior += __shfl_xor(interior, d, 64);
-  if (lane_id() == 0 && interior) atomicAdd(&D->interior_corners, interior);
-  if (__ballot(bad) && lane_id() == 0) fail(D, ST_INVALID, 263);
-}
-
-// =========================================================================
 // k_conn_checks: attribute seams (MeshEdgeBreakerDecoder.cs:502-535), on the third stream: lane i
 // decodes the rABS stream of attribute data i.  Only seam-free attribute connectivity is handled on the
 // device; a set bit is reported as not implemented.
@@ -1123,7 +1097,7 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
   const uint64_t t1 = t0;
   const uint32_t nad = D->num_att_data;
   if (nad > 0) {
-    const uint32_t edges = __hip_atomic_load(&D->interior_corners, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / 2;   // one seam bit per interior edge and attribute data
+    const uint32_t edges = D->interior_corners / 2;   // one seam bit per interior edge and attribute data
     uint32_t any = 0;
     if (lane < nad) {
       Rabs rb;
@@ -2116,10 +2090,10 @@ __global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayo
 // position corner table: one map value per vertex that has a corner).  Needs only the traversal, so it
 // runs beside the prediction kernels.
 // =========================================================================
-__global__ __launch_bounds__(256) void k_point_maps(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n) {
+__global__ __launch_bounds__(256) void k_point_maps(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   uint32_t mesh = blockIdx.y;
   if (mesh >= n) return;
-  const MeshDesc *D = &descs[mesh];
+  MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK) return;
   const MeshLayout &L = layouts[mesh];
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
@@ -2128,12 +2102,19 @@ __global__ __launch_bounds__(256) void k_point_maps(uint8_t *arena, const MeshLa
   const int32_t *v2d = (const int32_t *)(arena + L.v2d);
   int32_t *faces = (int32_t *)(arena + L.faces);
   const uint32_t NV = D->num_vertices, na = D->num_attributes;
+  // Every link k_connectivity makes sets two corners; a corner linked twice ("corner already has an
+  // opposite", MeshEdgeBreakerDecoder.cs:254,272,314,392) leaves fewer linked corners than 2 x links.
+  uint32_t linked = 0, bad = 0;
   for (uint32_t f = tid; f < D->num_faces; f += stride) {
-    const uint4 vv = frec[(size_t)f * 2];
+    const uint4 vv = frec[(size_t)f * 2], oo = frec[(size_t)f * 2 + 1];
+    linked += (oo.x != DSA_INVALID) + (oo.y != DSA_INVALID) + (oo.z != DSA_INVALID);
     if (vv.x < NV && vv.y < NV && vv.z < NV) {
       faces[3 * f] = (int32_t)vrank[vv.x]; faces[3 * f + 1] = (int32_t)vrank[vv.y]; faces[3 * f + 2] = (int32_t)vrank[vv.z];
-    }
+    } else bad = 1;
   }
+  for (int d = 32; d >= 1; d >>= 1) linked += __shfl_xor(linked, d, 64);
+  if (lane_id() == 0 && linked) atomicAdd(&D->linked_corners, linked);
+  if (__ballot(bad) && lane_id() == 0) fail(D, ST_INVALID, 263);
   for (uint32_t v = tid; v < NV; v += stride) {
     const int32_t e = v2d[v];
     if (e < 0) continue;                 // no corner: the map keeps its initial value
@@ -2141,6 +2122,15 @@ __global__ __launch_bounds__(256) void k_point_maps(uint8_t *arena, const MeshLa
     if (point >= D->num_points) continue;
     for (uint32_t ai = 0; ai < na; ++ai) ((uint32_t *)(arena + L.map[ai]))[point] = (uint32_t)e;
   }
+}
+
+// k_seal: last kernel of a decode, one thread per mesh: the link census of k_point_maps against k_connectivity's.
+__global__ __launch_bounds__(256) void k_seal(MeshDesc *descs, uint32_t n) {
+  const uint32_t mesh = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (status_of(D) != ST_OK) return;
+  if (__hip_atomic_load(&D->linked_corners, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != D->interior_corners) fail(D, ST_INVALID, 263);
 }
 
 }  // namespace dsa

@@ -69,7 +69,8 @@ struct MeshDesc {
   uint32_t num_all_vertices;   // corner-table vertices incl. isolated ones
   uint32_t num_points;
   uint32_t num_entries;    // traversal length
-  uint32_t interior_corners;   // corners with an opposite (k_link_check); one seam bit per pair and attribute data
+  uint32_t interior_corners;   // 2 x opposite links made by k_connectivity; one seam bit per link and attribute data
+  uint32_t linked_corners;     // corners that hold an opposite, counted by k_point_maps (k_seal compares the two)
   uint32_t dbg[12];        // shader-clock deltas between phases of the per-mesh kernels (diagnostics)
   AttrDesc att[DSA_MAX_ATT];
 };
