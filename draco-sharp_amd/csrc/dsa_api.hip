@@ -373,7 +373,14 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   hipLaunchKernelGGL(dsa::k_conn_checks, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_join3, st3));
   HIP_TRY(ctx, mark());
-  hipLaunchKernelGGL(dsa::k_traverse, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+  {
+    static const int split = getenv("DSA_TRAV_SPLIT") ? atoi(getenv("DSA_TRAV_SPLIT")) : 1;   // diagnostics
+    const uint32_t per = (n + split - 1) / split;
+    for (uint32_t m0 = 0; m0 < n; m0 += per) {
+      const uint32_t cnt = std::min(per, n - m0);
+      hipLaunchKernelGGL(dsa::k_traverse, dim3(cnt), dim3(WAVE), 0, st, b->arena, b->d_layouts + m0, b->d_descs + m0, cnt);
+    }
+  }
   HIP_TRY(ctx, mark());
   // faces + point maps need only the traversal: third stream, beside the prediction kernels
   HIP_TRY(ctx, hipEventRecord(ctx->ev_trav, st));

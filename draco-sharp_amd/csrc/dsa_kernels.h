@@ -1206,8 +1206,12 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   bool have_step = false;     // (step, dd) of the candidate path carried over from the previous run
   int64_t step = 0, dd = 0;
   uint32_t backoff = 0;       // scalar steps to take before speculating again
+  uint32_t fail_streak = 0;   // attempts in a row that retired nothing
   uint32_t n_run = 0, n_run_faces = 0, n_scalar = 0, n_fail = 0;
   bool failed = false;
+#ifdef DSA_TRAV_HIST
+  uint32_t hist[6] = {0, 0, 0, 0, 0, 0}, hist_len[6] = {0, 0, 0, 0, 0, 0}, why0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, whyK[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 #define TR_FAIL(site) { if (lane == 0) fail(D, ST_INVALID, (site)); failed = true; break; }
 #define VISIT_SCALAR(v_, c_) { if (lane == 0) { vflag[v_] = (uint8_t)(uni_flag | 1u); d2c[count] = (c_); v2d[v_] = (int32_t)count; } ++count; }
   auto corner_ok = [&](uint32_t c) -> bool { return c < 4 * F && (c & 3u) != 3u; };
@@ -1321,6 +1325,9 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           atomicMin(&vstamp[tipA], keyN); atomicMin(&vstamp[tipB], keyL);
         }
         WAIT_VM0();
+#ifdef DSA_TRAV_HIST
+        uint32_t why = pair_ok ? 0u : (in_chain ? 6u : 7u);
+#endif
         bool good = false;
         if (pair_ok) {
           const uint32_t sfa = __hip_atomic_load(&fstamp[fa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1337,8 +1344,15 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           const bool l_open = fL_before == 0 && !((slf >> 8) == (base >> 8) && slf < keyL);
           const bool l_ok = fB_before == 0 && sfb == keyL && tipB_seen && r_done && l_open;
           good = n_ok && l_ok;
+#ifdef DSA_TRAV_HIST
+          why = !n_ok ? 1u : (fB_before != 0 || sfb != keyL) ? 2u : !tipB_seen ? 3u : !r_done ? 4u : !l_open ? 5u : 0u;
+#endif
         }
         const uint32_t K = leading_lanes(good);
+#ifdef DSA_TRAV_HIST
+        if (K < 64) { const uint32_t w = rdlane(why, K); if (K == 0) why0[w]++; else whyK[w]++; }
+        { const uint32_t bin = K == 0 ? 0 : K < 4 ? 1 : K < 16 ? 2 : K < 48 ? 3 : K < 64 ? 4 : 5; hist[bin]++; hist_len[len == 0 ? 0 : len < 4 ? 1 : len < 16 ? 2 : len < 48 ? 3 : len < 64 ? 4 : 5]++; }
+#endif
         if (K >= 1 && count + K <= L.cap_vertices) {
           if (lane < K) {
             fvis[fa] = 1; fvis[fb] = 1;
@@ -1357,13 +1371,17 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           } else have_step = false;
           corner = nxt;
           n_run += 1; n_run_faces += 2 * K;
-          if (K < 4) backoff = 2;
+          fail_streak = 0;
+          // Pair K lies on the verified path but is not an (N L) pair (a turn of the spiral, a boundary
+          // vertex, a split): re-attempting from it would reach the same verdict, so step over it first.
+          if (K < WAVE && len > K) { backoff = 1; have_step = false; }
           continue;
         }
         ++n_fail;
-        if (have_step) { have_step = false; continue; }      // stale step parameters: retry with exact hops
-        backoff = 4;
-        (void)len;
+        if (have_step && len < 2) { have_step = false; continue; }   // the extrapolated path broke at once: re-seed it with exact hops
+        have_step = false;
+        backoff = fail_streak < 3 ? fail_streak : 3;                   // this step is taken by the scalar path below
+        ++fail_streak;
       } else if (backoff) {
         --backoff;
       }
@@ -1401,6 +1419,10 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
     D->num_entries = count;
     D->dbg[5] = n_fail; D->dbg[6] = (uint32_t)(clk() - t_start);
     D->dbg[7] = n_run; D->dbg[8] = n_run_faces; D->dbg[9] = n_scalar;
+#ifdef DSA_TRAV_HIST
+    for (int i = 0; i < 8; ++i) D->dbg[i] = why0[i] | (whyK[i] << 16);
+    D->dbg[10] = hist[5]; D->dbg[11] = hist_len[5];
+#endif
     // a valid stream carries exactly one entry per encoded vertex (k_locate sized the symbol streams on that)
     if (count != D->num_enc_vertices) fail(D, ST_INVALID, 305);
   }
