@@ -1251,10 +1251,17 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
       const uint32_t rc = uni(kc0 == 0 ? oo0.y : (kc0 == 1 ? oo0.z : oo0.x));
       const uint32_t lc = uni(kc0 == 0 ? oo0.z : (kc0 == 1 ? oo0.x : oo0.y));
       if (v >= NV || (rc != DSA_INVALID && !corner_ok(rc)) || (lc != DSA_INVALID && !corner_ok(lc))) TR_FAIL(301);
-      const uint32_t uni_flag = uni((uint32_t)vflag[v]);
+      // tip flag and the state of both sides, issued together (the scalar step needs them as well)
+      const uint32_t tip_flag = vflag[v];
+      const uint32_t side_r = rc != DSA_INVALID ? (uint32_t)fvis[rc >> 2] : 1u, side_l = lc != DSA_INVALID ? (uint32_t)fvis[lc >> 2] : 1u;
+      const uint32_t uni_flag = uni(tip_flag);
+      const bool rdone = rc == DSA_INVALID || (rc >> 2) == face || uni(side_r) != 0;
+      const bool ldone = lc == DSA_INVALID || (lc >> 2) == face || uni(side_l) != 0;
+      // this element moves right: tip new & interior, or only the right side is open
+      const bool moves_right = uni_flag == 0 || (!rdone && ldone);
 
-      // ------------------------------------------------------------------ speculative (N L)^k run
-      if (uni_flag == 0 && backoff == 0) {
+      // ------------------------------------------------------------------ speculative (right left)^k run
+      if (moves_right && backoff == 0) {
         ++run_id;
         const uint32_t base = (0x00FFFFFFu - run_id) << 8;
         // candidate path a_i = a_0 + i*step + dd*i*(i-1)/2.  (step, dd) carry over from the previous run
@@ -1294,7 +1301,8 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
         if (a_ok) { va = ((const uint4 *)frec)[(size_t)fa * 2]; oa = ((const uint4 *)frec)[(size_t)fa * 2 + 1]; }
         const uint32_t tipA = ka == 0 ? va.x : (ka == 1 ? va.y : va.z);
         const uint32_t b = ka == 0 ? oa.y : (ka == 1 ? oa.z : oa.x);
-        const bool b_ok = a_ok && corner_ok(b) && tipA < NV;
+        const uint32_t lcA = ka == 0 ? oa.z : (ka == 1 ? oa.x : oa.y);
+        const bool b_ok = a_ok && corner_ok(b) && tipA < NV && (lcA == DSA_INVALID || corner_ok(lcA));
         const uint32_t fb = b >> 2, kb = b & 3u;
         uint4 vb = make_uint4(0, 0, 0, 0), ob = make_uint4(DSA_INVALID, DSA_INVALID, DSA_INVALID, 0);
         if (b_ok) { vb = ((const uint4 *)frec)[(size_t)fb * 2]; ob = ((const uint4 *)frec)[(size_t)fb * 2 + 1]; }
@@ -1310,9 +1318,10 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
         const bool in_chain = lane < len;
         const bool pair_ok = in_chain && b_ok && tipB < NV && corner_ok(lcB) && (rcB == DSA_INVALID || corner_ok(rcB));
         // state before the step (plain loads, issued ahead of the stamp atomics)
-        uint32_t fA_before = 0, fB_before = 1, fR_before = 1, fL_before = 1, flA = 1, flB = 0;
+        uint32_t fA_before = 0, fB_before = 1, fR_before = 1, fL_before = 1, fLA_before = 1, flA = 1, flB = 0;
         if (pair_ok) {
           fA_before = lane == 0 ? 0u : fvis[fa];
+          fLA_before = lcA != DSA_INVALID ? fvis[lcA >> 2] : 1u;
           fB_before = fvis[fb];
           fR_before = rcB != DSA_INVALID ? fvis[rcB >> 2] : 1u;
           fL_before = fvis[lcB >> 2];
@@ -1328,7 +1337,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
 #ifdef DSA_TRAV_HIST
         uint32_t why = pair_ok ? 0u : (in_chain ? 6u : 7u);
 #endif
-        bool good = false;
+        bool good = false, newA = false, newB = false;
         if (pair_ok) {
           const uint32_t sfa = __hip_atomic_load(&fstamp[fa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const uint32_t sfb = __hip_atomic_load(&fstamp[fb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1336,16 +1345,23 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           const uint32_t stb = __hip_atomic_load(&vstamp[tipB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const uint32_t srf = rcB != DSA_INVALID ? __hip_atomic_load(&fstamp[rcB >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
           const uint32_t slf = __hip_atomic_load(&fstamp[lcB >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          // N element: face first seen here, tip new (not visited before, first seen here) and interior
-          const bool n_ok = fA_before == 0 && sfa == keyN && flA == 0 && sta == keyN;
-          // L element: face first seen here, tip already visited, right side done, left side open
-          const bool tipB_seen = (flB & 1u) || ((stb >> 8) == (base >> 8) && stb < keyL);
-          const bool r_done = fR_before != 0 || ((srf >> 8) == (base >> 8) && srf < keyL);
-          const bool l_open = fL_before == 0 && !((slf >> 8) == (base >> 8) && slf < keyL);
-          const bool l_ok = fB_before == 0 && sfb == keyL && tipB_seen && r_done && l_open;
-          good = n_ok && l_ok;
+          const uint32_t sla = lcA != DSA_INVALID ? __hip_atomic_load(&fstamp[lcA >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+          const uint32_t run_tag = base >> 8;
+          // first element (at a, face A): the face is first seen here and the DFS moves right -- because the
+          // tip is new and interior (DepthFirstTraverser.cs:53-64), or because the left side is done
+          // (:66-87; that the right side is open is the second element's "face B first seen")
+          newA = !(flA & 1u) && sta == keyN;
+          const bool la_done = lcA == DSA_INVALID || (lcA >> 2) == fa || fLA_before != 0 || ((sla >> 8) == run_tag && sla < keyN);
+          const bool x_ok = fA_before == 0 && sfa == keyN && ((newA && !(flA & 2u)) || la_done);
+          // second element (at b, face B): face first seen here, the tip does not send the DFS right (new and
+          // interior), right side done, left side open -> left
+          newB = !(flB & 1u) && stb == keyL;
+          const bool r_done = rcB == DSA_INVALID || (rcB >> 2) == fb || fR_before != 0 || ((srf >> 8) == run_tag && srf < keyL);
+          const bool l_open = (lcB >> 2) != fb && fL_before == 0 && !((slf >> 8) == run_tag && slf < keyL);
+          const bool y_ok = fB_before == 0 && sfb == keyL && !(newB && !(flB & 2u)) && r_done && l_open;
+          good = x_ok && y_ok;
 #ifdef DSA_TRAV_HIST
-          why = !n_ok ? 1u : (fB_before != 0 || sfb != keyL) ? 2u : !tipB_seen ? 3u : !r_done ? 4u : !l_open ? 5u : 0u;
+          why = !x_ok ? 1u : (fB_before != 0 || sfb != keyL) ? 2u : (newB && !(flB & 2u)) ? 3u : !r_done ? 4u : !l_open ? 5u : 0u;
 #endif
         }
         const uint32_t K = leading_lanes(good);
@@ -1353,15 +1369,20 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
         if (K < 64) { const uint32_t w = rdlane(why, K); if (K == 0) why0[w]++; else whyK[w]++; }
         { const uint32_t bin = K == 0 ? 0 : K < 4 ? 1 : K < 16 ? 2 : K < 48 ? 3 : K < 64 ? 4 : 5; hist[bin]++; hist_len[len == 0 ? 0 : len < 4 ? 1 : len < 16 ? 2 : len < 48 ? 3 : len < 64 ? 4 : 5]++; }
 #endif
-        if (K >= 1 && count + K <= L.cap_vertices) {
+        // entries made by the retired pairs: a new tip is numbered when its element is reached (:53-58)
+        const uint64_t kmask = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
+        const uint64_t mA = __ballot(newA) & kmask, mB = __ballot(newB) & kmask;
+        const uint32_t made = (uint32_t)__popcll(mA) + (uint32_t)__popcll(mB);
+        if (K >= 1 && count + made <= L.cap_vertices) {
           if (lane < K) {
+            const uint64_t lt = (1ull << lane) - 1ull;
+            const uint32_t posA = count + (uint32_t)__popcll(mA & lt) + (uint32_t)__popcll(mB & lt);
             fvis[fa] = 1; fvis[fb] = 1;
-            vflag[tipA] = 1;
-            d2c[count + lane] = a;
-            v2d[tipA] = (int32_t)(count + lane);
+            if (newA) { vflag[tipA] = (uint8_t)(flA | 1u); d2c[posA] = a; v2d[tipA] = (int32_t)posA; }
+            if (newB) { const uint32_t posB = posA + (newA ? 1u : 0u); vflag[tipB] = (uint8_t)(flB | 1u); d2c[posB] = b; v2d[tipB] = (int32_t)posB; }
           }
           const uint32_t nxt = rdlane(next_a, K - 1);          // Opposite(Previous(b_(K-1))): where the DFS continues
-          count += K;
+          count += made;
           if (K >= 3) {       // next run: continue the verified progression
             const int64_t aK1 = rdlane(a, K - 1), aK2 = rdlane(a, K - 2), aK3 = rdlane(a, K - 3);
             const int64_t s1 = (int64_t)nxt - aK1, s0 = aK1 - aK2, sm = aK2 - aK3;
@@ -1397,8 +1418,6 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           continue;
         }
       }
-      const bool rdone = rc == DSA_INVALID || uni((uint32_t)fvis[rc >> 2]) != 0;
-      const bool ldone = lc == DSA_INVALID || uni((uint32_t)fvis[lc >> 2]) != 0;
       if (rdone) {
         if (ldone) { --sp; break; }
         corner = lc;
