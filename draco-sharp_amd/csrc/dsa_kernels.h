@@ -1947,13 +1947,38 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
           for (uint32_t c = 0; c < 4; ++c) if (c < nc) g[c] = (int32_t)((uint32_t)w[ga * nc + c] - (uint32_t)w[gb * nc + c]);
         }
       }
-      // modular prefix sum of (g + corr) over lanes 1..run-1, seeded with lane 0's value
+      // modular prefix sum of (g + corr) over lanes 1..run-1, seeded with lane 0's value.  Residues are
+      // formed without division: real corrections keep |g + corr| < 2M; a lane outside that range (or a
+      // seed outside [mn, mx]) ends the run in front of it and is decoded by the exact step of the next run.
+      bool irregular = false;
+      uint32_t xr[4] = {0, 0, 0, 0};
 #pragma unroll
       for (uint32_t c = 0; c < 4; ++c) {
         if (c >= nc) continue;
-        uint32_t x;
-        if (lane == 0) x = (uint32_t)(((int64_t)o[c] - mn) % (int64_t)M + ((((int64_t)o[c] - mn) % (int64_t)M) < 0 ? (int64_t)M : 0));
-        else { int64_t e = ((int64_t)g[c] + (int64_t)corr[c]) % (int64_t)M; if (e < 0) e += M; x = in_run ? (uint32_t)e : 0u; }
+        if (lane == 0) {
+          const int64_t e = (int64_t)o[c] - mn;
+          if (e < 0 || e >= (int64_t)M) irregular = true; else xr[c] = (uint32_t)e;
+        } else if (in_run) {
+          int64_t e = (int64_t)g[c] + (int64_t)corr[c];
+          if (e <= -2 * (int64_t)M || e >= 2 * (int64_t)M) irregular = true;
+          else {
+            if (e < 0) e += M;
+            if (e < 0) e += M;
+            if (e >= (int64_t)M) e -= M;
+            xr[c] = (uint32_t)e;
+          }
+        }
+      }
+      {
+        const uint64_t irr = __ballot(irregular && in_run);
+        if (irr & 1ull) run = 1;                                   // lane 0 keeps its exact value, nobody chains on it
+        else if (irr) { const uint32_t f = (uint32_t)__builtin_ctzll(irr); if (f < run) run = f; }
+      }
+      const bool in_scan = lane < run;
+#pragma unroll
+      for (uint32_t c = 0; c < 4; ++c) {
+        if (c >= nc) continue;
+        uint32_t x = in_scan ? xr[c] : 0u;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
           uint32_t y = __shfl_up(x, d, 64);
@@ -1968,12 +1993,12 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
       for (uint32_t c = 0; c < 4; ++c) {
         if (c >= nc) continue;
         int32_t prev = __shfl_up(o[c], 1, 64);
-        if (lane > 0 && in_run) {
+        if (lane > 0 && in_scan) {
           int32_t pred = (int32_t)((uint32_t)prev + (uint32_t)g[c]);
           if (pred < mn || pred > mx || wrap_original(pred, corr[c], mn, mx, max_dif) != o[c]) good = false;
         }
       }
-      uint64_t bad = __ballot(in_run && !good);
+      uint64_t bad = __ballot(in_scan && !good);
       if (bad) run = (uint32_t)__builtin_ctzll(bad);     // >= 1: lane 0 is always exact
       if (lane < run) {
 #pragma unroll
@@ -2022,9 +2047,11 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
           if (!bl) oct_rotate(us, ut, rot);
         }
         // canonical values along the run: w_i = mod_max(u + corr_0 + ... + corr_i)
-        uint32_t xs = (uint32_t)(((int64_t)us + o.center) % (int64_t)M + ((((int64_t)us + o.center) % (int64_t)M) < 0 ? (int64_t)M : 0));
-        uint32_t xt = (uint32_t)(((int64_t)ut + o.center) % (int64_t)M + ((((int64_t)ut + o.center) % (int64_t)M) < 0 ? (int64_t)M : 0));
-        uint32_t ss = live ? ((uint32_t)cv.x % M) : 0u, st = live ? ((uint32_t)cv.y % M) : 0u;
+        // us, ut are in [-center, center] whenever the previous value is a valid octahedral coordinate, so
+        // the residues need no division; corrections outside [0, M) fail their lane's check below
+        const uint32_t xs = (uint32_t)(us + o.center), xt = (uint32_t)(ut + o.center);
+        if (xs >= M || xt >= M) { short_runs = 2; continue; }     // out-of-range state: exact sequential chunk
+        uint32_t ss = (live && (uint32_t)cv.x < M) ? (uint32_t)cv.x : 0u, st = (live && (uint32_t)cv.y < M) ? (uint32_t)cv.y : 0u;
         if (lane == 0) { ss = addmod(ss, xs, M); st = addmod(st, xt, M); }
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
