@@ -210,14 +210,27 @@ __device__ __forceinline__ uint32_t data_type_length(uint32_t dt) {   // Constan
 }
 
 // Wave-wide exclusive prefix sum of one value per lane; total in *total.
+// Cross-lane moves on the DPP path (no LDS crossbar round trip as with ds_bpermute / __shfl_up).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false); }
+// value of lane-1 (lane 0 receives 0): DPP wave_shr:1
+__device__ __forceinline__ uint32_t lane_prev(uint32_t x) { return dpp_mov<0x138>(x); }
+// inclusive wave64 scan with an associative op: row_shr 1,2,4,8 inside the 16-lane rows, then row_bcast:15 / :31
+template <class Op>
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, Op op) {
+  const uint32_t lane = lane_id(), rl = lane & 15u;
+  uint32_t t;
+  t = dpp_mov<0x111>(x); if (rl >= 1) x = op(t, x);
+  t = dpp_mov<0x112>(x); if (rl >= 2) x = op(t, x);
+  t = dpp_mov<0x114>(x); if (rl >= 4) x = op(t, x);
+  t = dpp_mov<0x118>(x); if (rl >= 8) x = op(t, x);
+  t = dpp_mov<0x142>(x); if ((lane & 31u) >= 16) x = op(t, x);
+  t = dpp_mov<0x143>(x); if (lane >= 32) x = op(t, x);
+  return x;
+}
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total) {
-  uint32_t x = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t y = __shfl_up(x, d, 64);
-    if ((int)lane_id() >= d) x += y;
-  }
-  *total = __shfl(x, 63, 64);
+  const uint32_t x = wave_incl_scan(v, [](uint32_t a, uint32_t b) { return a + b; });
+  *total = rdlane(x, 63);
   return x - v;
 }
 
@@ -724,7 +737,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
           const bool idok = lane < cand && id >= 0 && id < (int64_t)nv0 && (uint32_t)id != va0;
           vxj = (uint32_t)id;
           if (idok) rj = vrec[vxj];
-          const uint32_t prev_nv = __shfl_up(rj.y, 1, 64);
+          const uint32_t prev_nv = lane_prev(rj.y);
           // own record must be sane, and the previous pair must hand over exactly this vertex
           bool ok = idok && rj.x < 4 * f0 && (rj.x & 3u) != 3u && rj.y < nv0 && rj.y != vxj && (lane == 0 || prev_nv == vxj);
           k = leading_lanes(ok);
@@ -1311,7 +1324,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
         const uint32_t lcB = kb == 0 ? ob.z : (kb == 1 ? ob.x : ob.y);
         const uint32_t next_a = b_ok ? lcB : DSA_INVALID;           // succ(a)
         {
-          const uint32_t prev_next = __shfl_up(next_a, 1, 64);
+          const uint32_t prev_next = lane_prev(next_a);
           a_ok = a_ok && (lane == 0 || prev_next == a);
         }
         uint32_t len = leading_lanes(a_ok);                 // verified chain a_0 .. a_(len-1)
@@ -1978,12 +1991,7 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
 #pragma unroll
       for (uint32_t c = 0; c < 4; ++c) {
         if (c >= nc) continue;
-        uint32_t x = in_scan ? xr[c] : 0u;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          uint32_t y = __shfl_up(x, d, 64);
-          if ((int)lane >= d) x = addmod(x, y, M);
-        }
+        const uint32_t x = wave_incl_scan(in_scan ? xr[c] : 0u, [M](uint32_t a, uint32_t b) { return addmod(a, b, M); });
         red[c] = x;
         if (lane > 0) o[c] = (int32_t)((uint32_t)mn + x);
       }
@@ -1992,7 +2000,7 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
 #pragma unroll
       for (uint32_t c = 0; c < 4; ++c) {
         if (c >= nc) continue;
-        int32_t prev = __shfl_up(o[c], 1, 64);
+        int32_t prev = (int32_t)lane_prev((uint32_t)o[c]);
         if (lane > 0 && in_scan) {
           int32_t pred = (int32_t)((uint32_t)prev + (uint32_t)g[c]);
           if (pred < mn || pred > mx || wrap_original(pred, corr[c], mn, mx, max_dif) != o[c]) good = false;
@@ -2053,17 +2061,14 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
         if (xs >= M || xt >= M) { short_runs = 2; continue; }     // out-of-range state: exact sequential chunk
         uint32_t ss = (live && (uint32_t)cv.x < M) ? (uint32_t)cv.x : 0u, st = (live && (uint32_t)cv.y < M) ? (uint32_t)cv.y : 0u;
         if (lane == 0) { ss = addmod(ss, xs, M); st = addmod(st, xt, M); }
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          uint32_t ys = __shfl_up(ss, d, 64), yt = __shfl_up(st, d, 64);
-          if ((int)lane >= d) { ss = addmod(ss, ys, M); st = addmod(st, yt, M); }
-        }
+        ss = wave_incl_scan(ss, [M](uint32_t a, uint32_t b) { return addmod(a, b, M); });
+        st = wave_incl_scan(st, [M](uint32_t a, uint32_t b) { return addmod(a, b, M); });
         int32_t os = (int32_t)ss - o.center, ot = (int32_t)st - o.center;     // w in [-center, center]
         if (canonical && !bl) oct_rotate(os, ot, (4 - rot) % 4);
         if (!in_d) oct_invert_diamond(o.center, os, ot);
         os += o.center; ot += o.center;
         // exact re-evaluation from the neighbour's value
-        int32_t prs = __shfl_up(os, 1, 64), prt = __shfl_up(ot, 1, 64);
+        int32_t prs = (int32_t)lane_prev((uint32_t)os), prt = (int32_t)lane_prev((uint32_t)ot);
         if (lane == 0) { prs = ps; prt = pt; }
         int32_t es, et;
         oct_original(o, canonical, prs, prt, cv.x, cv.y, es, et);
