@@ -138,7 +138,7 @@ struct dsa_batch {
   MeshDesc *d_descs = nullptr;
   BatchGlobals *d_globals = nullptr;
   BatchGlobals globals = {};
-  uint32_t max_faces = 0, max_vertices = 0, max_atts = 0;
+  uint32_t max_faces = 0, max_vertices = 0, max_atts = 0, max_att_data = 0;
   bool decoded = false, collected = false;
   hipEvent_t ev[DSA_NUM_STAGES + 1] = {};
   hipEvent_t ev_sym[2] = {};
@@ -220,6 +220,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
     b->max_faces = std::max<uint32_t>(b->max_faces, (uint32_t)F);
     b->max_vertices = std::max<uint32_t>(b->max_vertices, (uint32_t)V);
     b->max_atts = std::max<uint32_t>(b->max_atts, (uint32_t)h.atts.size());
+    b->max_att_data = std::max<uint32_t>(b->max_att_data, h.num_att_data);
   }
   // pool for the cumulative tables of large-alphabet streams (bump-allocated by k_locate)
   {
@@ -370,7 +371,12 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // link symmetry + seam streams are checked on the second stream while the traversal runs here
   HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_conn, 0));
-  hipLaunchKernelGGL(dsa::k_conn_checks, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+  {
+    uint32_t lpm = 1;                                  // lanes per mesh >= attribute data per mesh (<= DSA_MAX_ATT_DATA = 7)
+    while (lpm < b->max_att_data) lpm *= 2;
+    const uint32_t per_wave = WAVE / lpm;
+    hipLaunchKernelGGL(dsa::k_conn_checks, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, lpm);
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_join3, st3));
   HIP_TRY(ctx, mark());
   {

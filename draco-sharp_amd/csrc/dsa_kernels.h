@@ -1094,62 +1094,50 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
 }
 
 // =========================================================================
-// k_conn_checks: attribute seams (MeshEdgeBreakerDecoder.cs:502-535), on the third stream: lane i
-// decodes the rABS stream of attribute data i.  Only seam-free attribute connectivity is handled on the
-// device; a set bit is reported as not implemented.
+// k_conn_checks: attribute seams (MeshEdgeBreakerDecoder.cs:502-535), on the third stream.  Only seam-free
+// attribute connectivity is handled on the device; a set bit is reported as not implemented.
 // =========================================================================
-__global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
-  uint32_t mesh = blockIdx.x;
+__global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t lanes_per_mesh) {
+  // one lane per (mesh, attribute data): the bit-serial rABS decode has no cross-lane traffic, so a wave
+  // carries 64 / lanes_per_mesh meshes and the instruction stream is shared between them
+  const uint32_t lane = lane_id();
+  const uint32_t mesh = blockIdx.x * (WAVE / lanes_per_mesh) + lane / lanes_per_mesh, d = lane % lanes_per_mesh;
   if (mesh >= n) return;
   const MeshLayout &L = layouts[mesh];
   MeshDesc *D = &descs[mesh];
-  if (status_of(D) != ST_OK) return;
+  if (status_of(D) != ST_OK || d >= D->num_att_data) return;
   const uint8_t *s = arena + L.stream;
-  const uint32_t lane = lane_id();
-  const uint64_t t0 = clk();
-  const uint64_t t1 = t0;
-  const uint32_t nad = D->num_att_data;
-  if (nad > 0) {
-    const uint32_t edges = D->interior_corners / 2;   // one seam bit per interior edge and attribute data
-    uint32_t any = 0;
-    if (lane < nad) {
-      Rabs rb;
-      uint32_t endp;
-      rb.start(s, L.stream_len, D->off_seams[lane], &endp);
-      if (!rb.ok) any = 2;
-      else {
-        // AnsDecoder.cs:42-56, restructured so that the common case (no renormalisation) is a load-free loop
-        uint32_t state = rb.state, off = rb.off;
-        const uint32_t p = rb.p;
-        uint32_t i = 0;
-        while (i < edges && any == 0) {
-          if (state < 4096 && off > 0) state = state * 256 + rb.buf[--off];
-          if (p <= 16 && state >= 8192 && i + 8 <= edges) {
-            // eight zero bits shrink the state by at most (15/16)^8 > 1/2, so none of them renormalises;
-            // a set bit ends the decode (seams are reported as not implemented), so only the zero-bit
-            // successor is computed
+  const uint32_t edges = D->interior_corners / 2;   // one seam bit per interior edge and attribute data
+  Rabs rb;
+  uint32_t endp;
+  rb.start(s, L.stream_len, D->off_seams[d], &endp);
+  if (!rb.ok) { fail(D, ST_INVALID, 260); return; }
+  // AnsDecoder.cs:42-56, restructured so that the common case (no renormalisation) is a load-free loop
+  uint32_t state = rb.state, off = rb.off, any = 0;
+  const uint32_t p = rb.p;
+  uint32_t i = 0;
+  while (i < edges && any == 0) {
+    if (state < 4096 && off > 0) state = state * 256 + rb.buf[--off];
+    if (p <= 16 && state >= 8192 && i + 8 <= edges) {
+      // eight zero bits shrink the state by at most (15/16)^8 > 1/2, so none of them renormalises;
+      // a set bit ends the decode (seams are reported as not implemented), so only the zero-bit
+      // successor is computed
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const uint32_t quot = state >> 8, rem = state & 255u;
-              any |= rem < p ? 1u : 0u;
-              state = state - quot * p - p;
-            }
-            i += 8;
-            continue;
-          }
-          const uint32_t quot = state >> 8, rem = state & 255u, xn = quot * p;
-          const bool val = rem < p;
-          any |= val ? 1u : 0u;
-          state = val ? xn + rem : state - xn - p;
-          ++i;
-        }
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t quot = state >> 8, rem = state & 255u;
+        any |= rem < p ? 1u : 0u;
+        state = state - quot * p - p;
       }
+      i += 8;
+      continue;
     }
-    uint64_t bad = __ballot(any == 2), seam = __ballot(any == 1);
-    if (bad) { if (lane == 0) fail(D, ST_INVALID, 260); return; }
-    if (seam) { if (lane == 0) fail(D, ST_NOTIMPL, 261); return; }
+    const uint32_t quot = state >> 8, rem = state & 255u, xn = quot * p;
+    const bool val = rem < p;
+    any |= val ? 1u : 0u;
+    state = val ? xn + rem : state - xn - p;
+    ++i;
   }
-  if (lane == 0) { D->dbg[10] = (uint32_t)(t1 - t0); D->dbg[11] = (uint32_t)(clk() - t1); }
+  if (any) fail(D, ST_NOTIMPL, 261);
 }
 
 // =========================================================================
