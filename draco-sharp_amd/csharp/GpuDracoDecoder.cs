@@ -76,11 +76,18 @@ public sealed unsafe class GpuDracoDecoder : IDisposable
     {
         NativeMethods.Check(NativeMethods.dsa_batch_mesh_info(batch, mesh, out var info), _ctx, "dsa_batch_mesh_info");
         NativeMethods.Check((DsaStatus)info.Status, IntPtr.Zero, $"stream {mesh}: decode failed (site {info.Detail})");
-        var result = new Mesh.Mesh();
-        var faces = new int[info.NumFaces * 3];
-        fixed (int* f = faces) NativeMethods.Check(NativeMethods.dsa_batch_copy_faces(batch, mesh, f), _ctx, "dsa_batch_copy_faces");
-        result.SetNumFaces((int)info.NumFaces);
-        for (uint f = 0; f < info.NumFaces; ++f) result.SetFace(f, [faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]]);
+        // EncodedGeometryType.PointCloud (Constants.cs) -> PointCloud, TriangularMesh -> Mesh (DracoDecoder.cs:66-99)
+        PointCloud.PointCloud result;
+        if (info.EncoderType == 0) result = new PointCloud.PointCloud();
+        else
+        {
+            var meshResult = new Mesh.Mesh();
+            var faces = new int[info.NumFaces * 3];
+            fixed (int* f = faces) NativeMethods.Check(NativeMethods.dsa_batch_copy_faces(batch, mesh, f), _ctx, "dsa_batch_copy_faces");
+            meshResult.SetNumFaces((int)info.NumFaces);
+            for (uint f = 0; f < info.NumFaces; ++f) meshResult.SetFace(f, [faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]]);
+            result = meshResult;
+        }
         result.PointsCount = (int)info.NumPoints;
         for (uint a = 0; a < info.NumAttributes; ++a)
         {

@@ -69,30 +69,38 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m) {
     if (!r.ok) return bad(ST_INVALID);
   }
   if (type > 1) return bad(ST_INVALID);
-  if (type == 0) return bad(ST_NOTIMPL);
-  if (method > 1) return bad(ST_INVALID);
-  if (method == 0) return bad(ST_NOTIMPL);
-  uint32_t traversal = r.u8();
-  if (!r.ok || traversal > 2) return bad(ST_INVALID);
-  if (traversal != 0) return bad(ST_NOTIMPL);
-  uint64_t nv = r.varint(), nf = r.varint();
-  if (!r.ok || nf > 0x7FFFFFFFu / 3 || nv > nf * 3) return bad(ST_INVALID);
-  uint32_t nad = r.u8();
-  uint64_t nsym = r.varint();
-  if (!r.ok || nf < nsym || nf > nsym + nsym / 3) return bad(ST_INVALID);
-  uint64_t nss = r.varint();
-  if (!r.ok || nss > nsym || nad > DSA_MAX_ATT_DATA) return bad(ST_INVALID);
-  uint64_t nsplits = r.varint();
-  if (!r.ok || nsplits > nf) return bad(ST_INVALID);
-  m.faces = (uint32_t)nf; m.enc_vertices = (uint32_t)nv; m.split_symbols = (uint32_t)nss; m.splits = (uint32_t)nsplits; m.num_att_data = nad;
-  for (uint64_t i = 0; i < 2 * nsplits && r.ok; ++i) (void)r.varint();
-  r.skip((nsplits + 7) >> 3);
-  uint64_t sz = r.varint(); r.skip(sz);                       // symbols
-  (void)r.u8(); sz = r.varint(); r.skip(sz);                  // start faces
-  for (uint32_t i = 0; i < nad; ++i) { (void)r.u8(); sz = r.varint(); r.skip(sz); }
+  const bool point_cloud = type == 0;
+  if (point_cloud) {
+    if (method > 1) return bad(ST_INVALID);
+    if (method != 0) return bad(ST_NOTIMPL);                  // kd-tree point clouds
+    uint32_t np = r.u8(); np |= r.u8() << 8; np |= r.u8() << 16; np |= r.u8() << 24;
+    if (!r.ok || np > 0x7FFFFFFFu) return bad(ST_INVALID);
+    m.faces = 0; m.enc_vertices = np; m.split_symbols = 0; m.splits = 0; m.num_att_data = 0;
+  } else {
+    if (method > 1) return bad(ST_INVALID);
+    if (method == 0) return bad(ST_NOTIMPL);
+    uint32_t traversal = r.u8();
+    if (!r.ok || traversal > 2) return bad(ST_INVALID);
+    if (traversal != 0) return bad(ST_NOTIMPL);
+    uint64_t nv = r.varint(), nf = r.varint();
+    if (!r.ok || nf > 0x7FFFFFFFu / 3 || nv > nf * 3) return bad(ST_INVALID);
+    uint32_t nad = r.u8();
+    uint64_t nsym = r.varint();
+    if (!r.ok || nf < nsym || nf > nsym + nsym / 3) return bad(ST_INVALID);
+    uint64_t nss = r.varint();
+    if (!r.ok || nss > nsym || nad > DSA_MAX_ATT_DATA) return bad(ST_INVALID);
+    uint64_t nsplits = r.varint();
+    if (!r.ok || nsplits > nf) return bad(ST_INVALID);
+    m.faces = (uint32_t)nf; m.enc_vertices = (uint32_t)nv; m.split_symbols = (uint32_t)nss; m.splits = (uint32_t)nsplits; m.num_att_data = nad;
+    for (uint64_t i = 0; i < 2 * nsplits && r.ok; ++i) (void)r.varint();
+    r.skip((nsplits + 7) >> 3);
+    uint64_t sz = r.varint(); r.skip(sz);                       // symbols
+    (void)r.u8(); sz = r.varint(); r.skip(sz);                  // start faces
+    for (uint32_t i = 0; i < nad; ++i) { (void)r.u8(); sz = r.varint(); r.skip(sz); }
+  }
   uint32_t ndec = r.u8();
   if (!r.ok || ndec > DSA_MAX_ATT) return bad(ST_INVALID);
-  for (uint32_t i = 0; i < ndec; ++i) { (void)r.u8(); (void)r.u8(); (void)r.u8(); }
+  if (!point_cloud) for (uint32_t i = 0; i < ndec; ++i) { (void)r.u8(); (void)r.u8(); (void)r.u8(); }
   for (uint32_t i = 0; i < ndec; ++i) {
     uint64_t k = r.varint();
     if (!r.ok || m.atts.size() + k > DSA_MAX_ATT) return bad(ST_INVALID);

@@ -359,6 +359,7 @@ __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, Attr
   if (a.have_scheme) {
     // only Difference and Parallelogram run on the device path for now
     if (!(method == 0 || method == 1)) NOTIMPL(161);
+    if (method == 1 && D->encoder_type == 0) NOTIMPL(167);   // mesh prediction scheme in a point cloud
     if (a.pred_transform == 1) {           // PredictionSchemeWrapDecodingTransform.cs:69-75
       a.wrap_min = (int32_t)r.u32();
       a.wrap_max = (int32_t)r.u32();
@@ -421,49 +422,61 @@ __global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayou
     REQUIRE(r.ok, 104);
   }
   REQUIRE(D->encoder_type <= 1, 105);
-  if (D->encoder_type == 0) NOTIMPL(106);                   // point clouds: DracoDecoder.cs:70
-  REQUIRE(D->encoder_method <= 1, 107);
-  if (D->encoder_method == 0) NOTIMPL(108);                 // sequential mesh
-  D->traversal_type = (uint8_t)r.u8();
-  REQUIRE(r.ok && D->traversal_type <= 2, 109);
-  if (D->traversal_type != 0) NOTIMPL(110);                 // valence / predictive traversal
-  // MeshEdgeBreakerDecoder.cs:35-56
-  uint64_t nv = r.varint(), nf = r.varint();
-  REQUIRE(r.ok && nf <= 0x7FFFFFFFu / 3 && nv <= nf * 3, 111);
-  uint64_t min_face_edges = 3 * nf / 2, max_vertex_edges = nv * (nv - 1) / 2;
-  REQUIRE(max_vertex_edges >= min_face_edges, 112);
-  uint32_t nad = r.u8();
-  uint64_t nsym = r.varint();
-  REQUIRE(r.ok && nf >= nsym && nf <= nsym + nsym / 3, 113);
-  uint64_t nsplit_sym = r.varint();
-  REQUIRE(r.ok && nsplit_sym <= nsym, 114);
-  REQUIRE(nad <= DSA_MAX_ATT_DATA, 115);
-  D->num_enc_vertices = (uint32_t)nv; D->num_faces = (uint32_t)nf; D->num_att_data = (uint8_t)nad;
-  D->num_symbols = (uint32_t)nsym; D->num_split_symbols = (uint32_t)nsplit_sym;
-  REQUIRE(nf == L.cap_faces && nv + nsplit_sym == L.cap_vertices, 116);   // host sizing must agree
-  // topology splits, MeshEdgeBreakerDecoder.cs:136-193
-  uint64_t nsplits = r.varint();
-  REQUIRE(r.ok && nsplits <= nf && nsplits <= L.cap_splits, 117);
-  D->num_splits = (uint32_t)nsplits;
-  D->off_splits = r.pos;
-  for (uint64_t i = 0; i < 2 * nsplits; ++i) (void)r.varint();
-  D->off_split_bits = r.pos;
-  r.skip((nsplits + 7) >> 3);
-  REQUIRE(r.ok, 118);
-  // traversal sections, MeshEdgeBreakerTraversalDecoder.cs:27-61 (symbol section is `size` bytes, D-3)
-  uint64_t sym_size = r.varint();
-  D->off_symbols = r.pos;
-  r.skip(sym_size);
-  REQUIRE(r.ok, 119);
-  D->size_symbols = (uint32_t)sym_size;
-  D->off_start_faces = r.pos;
-  { (void)r.u8(); uint64_t sz = r.varint(); r.skip(sz); REQUIRE(r.ok && sz >= 1, 120); }
-  for (uint32_t i = 0; i < nad; ++i) {
-    D->off_seams[i] = r.pos;
-    (void)r.u8();
-    uint64_t sz = r.varint();
-    r.skip(sz);
-    REQUIRE(r.ok && sz >= 1, 121);
+  const bool point_cloud = D->encoder_type == 0;
+  uint32_t nad = 0;
+  if (point_cloud) {
+    // Sequential point cloud (the reference stops at DracoDecoder.cs:70; layout of the upstream format):
+    // int32 point count, then the attribute section with a linear sequencer (entry i = point i).
+    REQUIRE(D->encoder_method <= 1, 107);
+    if (D->encoder_method != 0) NOTIMPL(106);               // kd-tree point clouds
+    const uint32_t np = r.u32();
+    REQUIRE(r.ok && np <= 0x7FFFFFFFu && np == L.cap_vertices, 116);
+    D->num_enc_vertices = np; D->num_faces = 0; D->num_att_data = 0;
+    D->num_vertices = np; D->num_all_vertices = np; D->num_points = np; D->num_entries = np;
+  } else {
+    REQUIRE(D->encoder_method <= 1, 107);
+    if (D->encoder_method == 0) NOTIMPL(108);                 // sequential mesh
+    D->traversal_type = (uint8_t)r.u8();
+    REQUIRE(r.ok && D->traversal_type <= 2, 109);
+    if (D->traversal_type != 0) NOTIMPL(110);                 // valence / predictive traversal
+    // MeshEdgeBreakerDecoder.cs:35-56
+    uint64_t nv = r.varint(), nf = r.varint();
+    REQUIRE(r.ok && nf <= 0x7FFFFFFFu / 3 && nv <= nf * 3, 111);
+    uint64_t min_face_edges = 3 * nf / 2, max_vertex_edges = nv * (nv - 1) / 2;
+    REQUIRE(max_vertex_edges >= min_face_edges, 112);
+    nad = r.u8();
+    uint64_t nsym = r.varint();
+    REQUIRE(r.ok && nf >= nsym && nf <= nsym + nsym / 3, 113);
+    uint64_t nsplit_sym = r.varint();
+    REQUIRE(r.ok && nsplit_sym <= nsym, 114);
+    REQUIRE(nad <= DSA_MAX_ATT_DATA, 115);
+    D->num_enc_vertices = (uint32_t)nv; D->num_faces = (uint32_t)nf; D->num_att_data = (uint8_t)nad;
+    D->num_symbols = (uint32_t)nsym; D->num_split_symbols = (uint32_t)nsplit_sym;
+    REQUIRE(nf == L.cap_faces && nv + nsplit_sym == L.cap_vertices, 116);   // host sizing must agree
+    // topology splits, MeshEdgeBreakerDecoder.cs:136-193
+    uint64_t nsplits = r.varint();
+    REQUIRE(r.ok && nsplits <= nf && nsplits <= L.cap_splits, 117);
+    D->num_splits = (uint32_t)nsplits;
+    D->off_splits = r.pos;
+    for (uint64_t i = 0; i < 2 * nsplits; ++i) (void)r.varint();
+    D->off_split_bits = r.pos;
+    r.skip((nsplits + 7) >> 3);
+    REQUIRE(r.ok, 118);
+    // traversal sections, MeshEdgeBreakerTraversalDecoder.cs:27-61 (symbol section is `size` bytes, D-3)
+    uint64_t sym_size = r.varint();
+    D->off_symbols = r.pos;
+    r.skip(sym_size);
+    REQUIRE(r.ok, 119);
+    D->size_symbols = (uint32_t)sym_size;
+    D->off_start_faces = r.pos;
+    { (void)r.u8(); uint64_t sz = r.varint(); r.skip(sz); REQUIRE(r.ok && sz >= 1, 120); }
+    for (uint32_t i = 0; i < nad; ++i) {
+      D->off_seams[i] = r.pos;
+      (void)r.u8();
+      uint64_t sz = r.varint();
+      r.skip(sz);
+      REQUIRE(r.ok && sz >= 1, 121);
+    }
   }
   // attribute section, ConnectivityDecoder.cs:16-44
   D->off_attributes = r.pos;
@@ -473,7 +486,7 @@ __global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayou
   int att_data_of[DSA_MAX_ATT];
   bool pos_seen = false;
   uint32_t data_seen = 0;
-  for (uint32_t i = 0; i < ndec; ++i) {           // MeshEdgeBreakerDecoder.cs:640-708
+  for (uint32_t i = 0; i < ndec && !point_cloud; ++i) {           // MeshEdgeBreakerDecoder.cs:640-708
     int att_data_id = (int8_t)r.u8();
     uint32_t element_type = r.u8();
     uint32_t traversal_method = r.u8();
@@ -577,7 +590,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
   if (mesh >= n) return;
   const MeshLayout &L = layouts[mesh];
   MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK) return;
+  if (D->status != ST_OK || D->encoder_type == 0) return;   // point clouds have no connectivity
   const uint8_t *s = arena + L.stream;
   uint32_t *frec = (uint32_t *)(arena + L.frec);
   uint2 *vrec = (uint2 *)(arena + L.vrec);
@@ -1105,7 +1118,7 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
   if (mesh >= n) return;
   const MeshLayout &L = layouts[mesh];
   MeshDesc *D = &descs[mesh];
-  if (status_of(D) != ST_OK || d >= D->num_att_data) return;
+  if (status_of(D) != ST_OK || D->encoder_type == 0 || d >= D->num_att_data) return;
   const uint8_t *s = arena + L.stream;
   const uint32_t edges = D->interior_corners / 2;   // one seam bit per interior edge and attribute data
   Rabs rb;
@@ -1189,7 +1202,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   if (mesh >= n) return;
   const MeshLayout &L = layouts[mesh];
   MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK) return;
+  if (D->status != ST_OK || D->encoder_type == 0) return;   // point clouds have no connectivity
   const uint32_t *frec = (const uint32_t *)(arena + L.frec);
   uint32_t *d2c = (uint32_t *)(arena + L.d2c);
   int32_t *v2d = (int32_t *)(arena + L.v2d);
@@ -1456,7 +1469,7 @@ __global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const Mes
   uint32_t mesh = blockIdx.y;
   if (mesh >= n) return;
   const MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK) return;
+  if (D->status != ST_OK || D->encoder_type == 0) return;   // point clouds have no connectivity
   const MeshLayout &L = layouts[mesh];
   const uint32_t *frec = (const uint32_t *)(arena + L.frec);
   const uint32_t *d2c = (const uint32_t *)(arena + L.d2c);
@@ -2163,6 +2176,11 @@ __global__ __launch_bounds__(256) void k_point_maps(uint8_t *arena, const MeshLa
   const int32_t *v2d = (const int32_t *)(arena + L.v2d);
   int32_t *faces = (int32_t *)(arena + L.faces);
   const uint32_t NV = D->num_vertices, na = D->num_attributes;
+  if (D->encoder_type == 0) {           // point cloud: linear sequencer, entry i = point i
+    for (uint32_t p = tid; p < D->num_points; p += stride)
+      for (uint32_t ai = 0; ai < na; ++ai) ((uint32_t *)(arena + L.map[ai]))[p] = p;
+    return;
+  }
   // Every link k_connectivity makes sets two corners; a corner linked twice ("corner already has an
   // opposite", MeshEdgeBreakerDecoder.cs:254,272,314,392) leaves fewer linked corners than 2 x links.
   uint32_t linked = 0, bad = 0;

@@ -273,6 +273,8 @@ class Batch:
                 if ai.num_entries:
                     L.dsa_batch_copy_portable_values(self._h, i, a, portable.ctypes.data)
             atts.append(PointAttribute(ai, vals, pmap, portable))
+        if info.encoder_type == 0:      # EncodedGeometryType.PointCloud (Constants.cs): no faces
+            return Draco(DracoHeader(info), PointCloud(atts, info.num_points))
         return Draco(DracoHeader(info), Mesh(atts, info.num_points, faces))
 
     def close(self):

@@ -28,23 +28,28 @@ def assert_same(got, ref, batch=None, i=None):
             got.Header.Flags) == (ref.major, ref.minor, ref.encoder_type, ref.encoder_method, ref.flags)
     assert m.FacesCount == ref.num_faces and m.PointsCount == ref.num_points
     assert np.array_equal(m.Faces, ref.faces)
+    assert_same_attributes(m, ref)
+    if batch is not None:
+        nf = ref.num_faces
+        assert np.array_equal(batch.debug_array(i, 0, np.uint32, 3 * nf), ref.opposite)
+        assert np.array_equal(batch.debug_array(i, 1, np.uint32, 3 * nf), ref.corner_to_vertex)
+        assert np.array_equal(batch.debug_array(i, 2, np.uint32, ref.num_vertices), ref.decoders[0]["data_to_corner"])
+
+
+def assert_same_attributes(m, ref):
     assert len(m.Attributes) == len(ref.attributes)
     for a, r in zip(m.Attributes, ref.attributes):
         assert (a.AttributeType, a.DataType, a.NumComponents, a.UniqueId, a.DecoderType) == \
                (r.att_type, r.data_type, r.num_components, r.unique_id, r.seq_type)
         assert a.UniqueEntriesCount == r.num_entries
-        assert np.array_equal(a.PointMap, r.point_map)
+        # the oracle reports an identity mapping (PointAttribute.IsMappingIdentity) as an empty map
+        assert np.array_equal(a.PointMap, r.point_map if len(r.point_map) else np.arange(m.PointsCount, dtype=np.uint32))
         if r.portable is not None:
             assert np.array_equal(a.PortableValues, r.portable)
         if a.Values.dtype == np.float32:
             assert np.array_equal(a.Values.view(np.uint32), r.values.view(np.uint32))   # bit-equal (<= 1 ulp required)
         else:
             assert np.array_equal(a.Values, r.values)
-    if batch is not None:
-        nf = ref.num_faces
-        assert np.array_equal(batch.debug_array(i, 0, np.uint32, 3 * nf), ref.opposite)
-        assert np.array_equal(batch.debug_array(i, 1, np.uint32, 3 * nf), ref.corner_to_vertex)
-        assert np.array_equal(batch.debug_array(i, 2, np.uint32, ref.num_vertices), ref.decoders[0]["data_to_corner"])
 
 
 def run_batch(ctx, streams):
@@ -124,8 +129,8 @@ def test_bad_streams_do_not_poison_the_batch(ctx):
     streams = [good, b"", b"DRACX" + good[5:], good[:40], good[: len(good) // 2], good[:-1], good]
     v1 = bytearray(good); v1[5] = 1
     streams.append(bytes(v1))
-    pc = synth.encode_point_cloud(pos)
-    streams.append(pc)                    # point cloud: NotImplementedException in the reference (DracoDecoder.cs:70)
+    kd = bytearray(synth.encode_point_cloud(pos)); kd[8] = 1
+    streams.append(bytes(kd))             # kd-tree point cloud: not on the device path
     b = run_batch(ctx, streams)
     ref = oracle.decode(good)
     for i in (0, 6):
@@ -138,6 +143,25 @@ def test_bad_streams_do_not_poison_the_batch(ctx):
     assert b.status(8) == 2
     with pytest.raises(NotImplementedError):
         b.result(8)
+    b.close()
+
+
+def test_point_cloud_sequential(ctx):
+    """BASELINE.json configs[0]: 1k-point cloud, quantised positions, sequential decoder -- plus a larger one and
+    both symbol schemes.  Entry i is point i (linear sequencer); no faces."""
+    rng = np.random.default_rng(1)
+    streams = []
+    for n, bits, scheme in ((1000, 11, -1), (1, 11, -1), (100000, 14, 1), (5000, 9, 0)):
+        pos = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+        streams.append(synth.encode_point_cloud(pos, synth.options(pos_bits=bits, force_scheme=scheme)))
+    b = run_batch(ctx, streams)
+    for i, sbytes in enumerate(streams):
+        ref = oracle.decode(sbytes)
+        got = b.result(i)
+        assert ref.encoder_type == 0 and type(got.ConnectedData) is dsa.PointCloud
+        assert got.ConnectedData.PointsCount == ref.num_points
+        assert_same_attributes(got.ConnectedData, ref)
+        assert np.array_equal(got.ConnectedData.Attributes[0].PointMap, np.arange(ref.num_points, dtype=np.uint32))
     b.close()
 
 
