@@ -358,8 +358,12 @@ __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, Attr
   }
   if (a.have_scheme) {
     // only Difference and Parallelogram run on the device path for now
-    if (!(method == 0 || method == 1)) NOTIMPL(161);
-    if (method == 1 && D->encoder_type == 0) NOTIMPL(167);   // mesh prediction scheme in a point cloud
+    // PredictionSchemeDecoderFactory.cs:24-36: without a corner table (point clouds) every method falls back to delta
+    if (D->encoder_type == 0) a.pred_kind = 0;
+    else {
+      if (!(method == 0 || method == 1)) NOTIMPL(161);
+      a.pred_kind = (int8_t)method;
+    }
     if (a.pred_transform == 1) {           // PredictionSchemeWrapDecodingTransform.cs:69-75
       a.wrap_min = (int32_t)r.u32();
       a.wrap_max = (int32_t)r.u32();
@@ -1914,7 +1918,7 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
     if (nc > 4) { if (lane == 0) fail(D, ST_NOTIMPL, 500); return; }
     const int32_t mn = a.wrap_min, mx = a.wrap_max, max_dif = 1 + mx - mn;
     const uint32_t M = (uint32_t)max_dif;
-    const bool para_mode = a.pred_method == 1;
+    const bool para_mode = a.pred_kind == 1;
     const uint32_t *para = (const uint32_t *)(arena + L.para);
     uint32_t p0 = 0;
     while (p0 < entries) {
@@ -2018,7 +2022,7 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
     (void)para_mode;
   } else {
     // normal octahedron transforms are 2-component; only Difference reaches here (k_locate rejects the rest)
-    if (a.pred_method != 0) { if (lane == 0) fail(D, ST_NOTIMPL, 501); return; }
+    if (a.pred_kind != 0) { if (lane == 0) fail(D, ST_NOTIMPL, 501); return; }
     OctParams o;
     int q = 32 - __clz(a.oct_max_q);
     int32_t max_value = (1 << q) - 2;

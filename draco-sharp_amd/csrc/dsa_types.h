@@ -23,7 +23,8 @@ struct AttrDesc {
   uint8_t att_type, data_type, nc, normalized;
   uint8_t seq_type;        // SequentialAttributeEncoderType 0..3
   int8_t decoder_id;
-  int8_t pred_method;      // PredictionSchemeMethod
+  int8_t pred_method;      // PredictionSchemeMethod as stored in the stream
+  int8_t pred_kind;        // scheme that runs: 0 delta, 1 parallelogram (PredictionSchemeDecoderFactory.cs:24-36)
   int8_t pred_transform;   // PredictionSchemeTransformType
   uint8_t nc_portable;
   uint8_t source;          // SRC_*
