@@ -14,6 +14,7 @@
 
 #include "../../include/draco_mi355x.h"
 #include "dsa_kernels.h"
+#include "dsa_general.h"
 
 namespace {
 
@@ -22,10 +23,11 @@ static const char *kStageNames[DSA_NUM_STAGES] = {"locate", "connectivity", "tra
                                                  "symbols", "predict", "finalize", "total"};
 
 // What the host learns from the fixed part of a stream; used only to size the arena.
-struct HostAttr { uint8_t att_type, data_type, nc, seq_type; };
+struct HostAttr { uint8_t att_type, data_type, nc, seq_type; bool corner = false; };
 struct HostMesh {
   int status = 0;   // failure of the sizing parse (the device parse decides the reported status)
   uint32_t faces = 0, enc_vertices = 0, split_symbols = 0, splits = 0, num_att_data = 0;
+  bool general = false;   // valence traversal or corner attributes: decoded by k_general
   std::vector<HostAttr> atts;
 };
 
@@ -47,6 +49,63 @@ static void skip_metadata_element(HRd &r, int depth) {
   for (uint32_t i = 0; i < ne && r.ok; ++i) { uint32_t ks = r.u8(); r.skip(ks); uint64_t vs = r.varint(); r.skip(vs); }
   uint32_t ns = (uint32_t)r.varint();
   for (uint32_t i = 0; i < ns && r.ok; ++i) { uint32_t ks = r.u8(); r.skip(ks); skip_metadata_element(r, depth + 1); }
+}
+
+
+// Skips one SymbolDecoding.DecodeSymbols block (Entropy/SymbolDecoding.cs:7-67).  The bit section of the tagged
+// scheme has no length field, so its tags are decoded here (sizing only; the device decodes everything again).
+static void host_skip_symbols(HRd &r, uint64_t num_values, uint32_t nc) {
+  if (num_values == 0 || !r.ok) return;
+  const uint32_t scheme = r.u8();
+  auto read_table = [&](std::vector<uint32_t> &prob) {
+    const uint64_t ns = r.varint();
+    if (!r.ok || ns > (1u << 20)) { r.ok = false; return; }
+    prob.assign((size_t)ns, 0);
+    for (uint64_t i = 0; i < ns && r.ok; ++i) {
+      const uint32_t pd = r.u8(), token = pd & 3;
+      if (token == 3) { const uint64_t off = pd >> 2; if (i + off >= ns) { r.ok = false; return; } i += off; }
+      else { uint32_t p = pd >> 2; for (uint32_t k = 0; k < token; ++k) p |= r.u8() << (8 * (k + 1) - 2); prob[(size_t)i] = p; }
+    }
+  };
+  std::vector<uint32_t> prob;
+  if (scheme == 1) {
+    const uint32_t mbl = r.u8();
+    if (mbl < 1 || mbl > 18) { r.ok = false; return; }
+    read_table(prob);
+    const uint64_t size = r.varint();
+    r.skip(size);
+  } else if (scheme == 0) {
+    read_table(prob);
+    if (!r.ok || prob.empty()) { r.ok = false; return; }
+    const uint64_t size = r.varint();
+    if (!r.ok || size < 1 || size > r.n - r.pos) { r.ok = false; return; }
+    const uint8_t *buf = r.p + r.pos;
+    r.skip(size);
+    // rANS, precision 12 (RAnsSymbolCoding.cs:10-27 for 5-bit tags)
+    std::vector<uint32_t> cum(prob.size() + 1, 0), lut(4096, 0);
+    for (size_t i = 0; i < prob.size(); ++i) {
+      cum[i + 1] = cum[i] + prob[i];
+      if (cum[i + 1] > 4096) { r.ok = false; return; }
+      for (uint32_t j = cum[i]; j < cum[i + 1]; ++j) lut[j] = (uint32_t)i;
+    }
+    if (cum.back() != 4096) { r.ok = false; return; }
+    size_t off = (size_t)size;
+    uint32_t x = buf[off - 1] >> 6, state;
+    if (x == 0) { off -= 1; state = buf[off] & 0x3F; }
+    else if (x == 1) { if (off < 2) { r.ok = false; return; } off -= 2; state = (buf[off] | (buf[off + 1] << 8)) & 0x3FFF; }
+    else if (x == 2) { if (off < 3) { r.ok = false; return; } off -= 3; state = (buf[off] | (buf[off + 1] << 8) | (buf[off + 2] << 16)) & 0x3FFFFF; }
+    else { if (off < 4) { r.ok = false; return; } off -= 4; state = (buf[off] | (buf[off + 1] << 8) | (buf[off + 2] << 16) | ((uint32_t)buf[off + 3] << 24)) & 0x3FFFFFFF; }
+    state += 16384;
+    uint64_t bits = 0;
+    for (uint64_t i = 0; i < num_values; i += nc) {
+      while (state < 16384 && off > 0) state = state * 256 + buf[--off];
+      const uint32_t rem = state & 4095u, sy = lut[rem];
+      state = (state >> 12) * prob[sy] + rem - cum[sy];
+      if (sy > 32) { r.ok = false; return; }
+      bits += (uint64_t)sy * nc;
+    }
+    r.skip((bits + 7) >> 3);
+  } else r.ok = false;
 }
 
 static uint32_t dt_len(uint32_t dt) {
@@ -81,7 +140,8 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m) {
     if (method == 0) return bad(ST_NOTIMPL);
     uint32_t traversal = r.u8();
     if (!r.ok || traversal > 2) return bad(ST_INVALID);
-    if (traversal != 0) return bad(ST_NOTIMPL);
+    if (traversal == 1) return bad(ST_NOTIMPL);                  // predictive traversal
+    if (traversal == 2) m.general = true;
     uint64_t nv = r.varint(), nf = r.varint();
     if (!r.ok || nf > 0x7FFFFFFFu / 3 || nv > nf * 3) return bad(ST_INVALID);
     uint32_t nad = r.u8();
@@ -94,13 +154,29 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m) {
     m.faces = (uint32_t)nf; m.enc_vertices = (uint32_t)nv; m.split_symbols = (uint32_t)nss; m.splits = (uint32_t)nsplits; m.num_att_data = nad;
     for (uint64_t i = 0; i < 2 * nsplits && r.ok; ++i) (void)r.varint();
     r.skip((nsplits + 7) >> 3);
-    uint64_t sz = r.varint(); r.skip(sz);                       // symbols
+    uint64_t sz;
+    if (traversal == 0) { sz = r.varint(); r.skip(sz); }        // symbols
     (void)r.u8(); sz = r.varint(); r.skip(sz);                  // start faces
     for (uint32_t i = 0; i < nad; ++i) { (void)r.u8(); sz = r.varint(); r.skip(sz); }
+    if (traversal == 2) {                                       // MeshEdgeBreakerTraversalValenceDecoder.cs:22-69
+      for (int c = 0; c < 6 && r.ok; ++c) {
+        const uint64_t num = r.varint();
+        if (!r.ok || num > nf) return bad(ST_INVALID);
+        host_skip_symbols(r, num, 1);
+      }
+    }
   }
   uint32_t ndec = r.u8();
   if (!r.ok || ndec > DSA_MAX_ATT) return bad(ST_INVALID);
-  if (!point_cloud) for (uint32_t i = 0; i < ndec; ++i) { (void)r.u8(); (void)r.u8(); (void)r.u8(); }
+  bool corner_dec[DSA_MAX_ATT + 1] = {};
+  if (!point_cloud) for (uint32_t i = 0; i < ndec; ++i) {
+    (void)r.u8();
+    corner_dec[i] = r.u8() != 0;                                // MeshAttributeElementType: corner attribute
+    (void)r.u8();
+    if (corner_dec[i]) m.general = true;
+  }
+  const bool force_general = getenv("DSA_FORCE_GENERAL") != nullptr;   // tests: every Edgebreaker mesh through k_general
+  if (force_general && !point_cloud) m.general = true;
   for (uint32_t i = 0; i < ndec; ++i) {
     uint64_t k = r.varint();
     if (!r.ok || m.atts.size() + k > DSA_MAX_ATT) return bad(ST_INVALID);
@@ -110,6 +186,7 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m) {
       a.att_type = (uint8_t)r.u8(); a.data_type = (uint8_t)r.u8(); a.nc = (uint8_t)r.u8(); (void)r.u8();
       (void)r.varint();
       a.seq_type = 0;
+      a.corner = corner_dec[i];
       m.atts.push_back(a);
     }
     for (uint64_t j = 0; j < k; ++j) m.atts[first + j].seq_type = (uint8_t)r.u8();
@@ -147,6 +224,7 @@ struct dsa_batch {
   BatchGlobals *d_globals = nullptr;
   BatchGlobals globals = {};
   uint32_t max_faces = 0, max_vertices = 0, max_atts = 0, max_att_data = 0;
+  bool any_general = false;
   bool decoded = false, collected = false;
   hipEvent_t ev[DSA_NUM_STAGES + 1] = {};
   hipEvent_t ev_sym[2] = {};
@@ -201,7 +279,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
     HostMesh &h = b->host[i];
     host_parse(streams[i], lengths[i], h);
     MeshLayout &L = b->layouts[i];
-    if (h.status != 0) { h.faces = 0; h.enc_vertices = 0; h.split_symbols = 0; h.splits = 0; h.atts.clear(); }
+    if (h.status != 0) { h.faces = 0; h.enc_vertices = 0; h.split_symbols = 0; h.splits = 0; h.atts.clear(); h.general = false; }
     const uint64_t F = h.faces, V = (uint64_t)h.enc_vertices + h.split_symbols;
     L.cap_faces = (uint32_t)F;
     L.cap_vertices = (uint32_t)V;
@@ -216,19 +294,29 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
     L.splits = take(16ull * h.splits);
     L.vrank = take(4 * V); L.para = take(12 * V);
     L.faces = take(12 * F);
+    // general path: corner attributes carry up to 3F entries, and seams up to 3F points
+    const uint64_t P = (h.general && h.num_att_data > 0) ? std::max<uint64_t>(3 * F, V) : V;
+    L.cap_points = (uint32_t)P;
+    if (h.general) {
+      const GenLayout g = gen_layout(F, V, h.splits, h.num_att_data, lengths[i]);
+      L.gen = take(g.total);
+      L.gen_bytes = g.total;
+    }
     for (size_t a = 0; a < h.atts.size(); ++a) {
       const HostAttr &A = h.atts[a];
       uint64_t ncp = A.seq_type == 3 ? 2 : A.nc;
-      uint64_t wcap = V * ncp, ocap = V * A.nc * dt_len(A.data_type);
+      const uint64_t E = A.corner ? std::max<uint64_t>(3 * F, V) : V;   // entry capacity
+      uint64_t wcap = E * ncp, ocap = E * A.nc * dt_len(A.data_type);
       if (ocap < V) ocap = V;                  // tag bytes of the tagged scheme are staged here
       L.work[a] = take(4 * wcap); L.work_cap[a] = (uint32_t)wcap;
       L.out[a] = take(ocap); L.out_cap[a] = (uint32_t)(ocap > 0xFFFFFFFFu ? 0xFFFFFFFFu : ocap);
-      L.map[a] = take(4 * V);
+      L.map[a] = take(4 * P);
     }
     b->max_faces = std::max<uint32_t>(b->max_faces, (uint32_t)F);
     b->max_vertices = std::max<uint32_t>(b->max_vertices, (uint32_t)V);
     b->max_atts = std::max<uint32_t>(b->max_atts, (uint32_t)h.atts.size());
     b->max_att_data = std::max<uint32_t>(b->max_att_data, h.num_att_data);
+    b->any_general = b->any_general || h.general;
   }
   // pool for the cumulative tables of large-alphabet streams (bump-allocated by k_locate)
   {
@@ -368,6 +456,10 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   hipStream_t st2 = serial ? st : ctx->stream2, st3 = serial ? st : ctx->stream3;
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_fork, 0));
+  if (b->any_general) {                 // whole-mesh serial decode of the general-path meshes, beside the fast kernels
+    HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_fork, 0));
+    hipLaunchKernelGGL(dsa::k_general, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+  }
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[0], st2));
   hipLaunchKernelGGL(dsa::k_symbols_reg, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
   hipLaunchKernelGGL(dsa::k_symbols<1>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
@@ -563,6 +655,11 @@ dsa_status dsa_batch_copy_debug(const dsa_batch *b, uint32_t mesh, int what, voi
     case 1: {   // de-interleave the 32-byte face records into the reference's opposite[] / corner_to_vertex[] arrays
       bytes = 12ull * D.num_faces;
       if (bytes > dst_bytes) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "destination too small");
+      if (D.general) {   // the general path keeps the two arrays as they are, back to back
+        dsa_status st = copy_out(b, dst, L.frec + (what == 0 ? 0 : bytes), bytes);
+        if (st == DSA_OK && written) *written = (size_t)bytes;
+        return st;
+      }
       std::vector<uint32_t> rec((size_t)D.num_faces * 8);
       dsa_status st = copy_out(b, rec.data(), L.frec, 32ull * D.num_faces);
       if (st != DSA_OK) return st;
@@ -578,7 +675,7 @@ dsa_status dsa_batch_copy_debug(const dsa_batch *b, uint32_t mesh, int what, voi
       dsa_status st = copy_out(b, dst, L.d2c, bytes);
       if (st != DSA_OK) return st;
       uint32_t *o = (uint32_t *)dst;
-      for (uint32_t i = 0; i < D.num_entries; ++i) o[i] = unquad(o[i]);
+      if (!D.general) for (uint32_t i = 0; i < D.num_entries; ++i) o[i] = unquad(o[i]);
       if (written) *written = (size_t)bytes;
       return DSA_OK;
     }

@@ -1,0 +1,906 @@
+// draco-sharp_amd/csrc/dsa_general.h
+//
+// k_general: the whole decode of one Edgebreaker mesh by a single lane, for the streams the fast kernels
+// of dsa_kernels.h do not take:
+//   * valence traversal            Mesh/MeshEdgeBreakerTraversalValenceDecoder.cs:22-154
+//   * attribute seams, attribute corner tables, corner attributes
+//                                  Mesh/MeshEdgeBreakerDecoder.cs:502-638, Mesh/MeshAttributeCornerTable.cs:19-215
+//   * TexCoordsPortable prediction PredictionSchemes/MeshPredictionSchemeTexCoordsPortable{Decoder,Predictor}.cs
+// It is the sequential algorithm of the reference, statement by statement, on arrays in the batch arena: one
+// wave per mesh with lane 0 active, meshes of a batch in parallel.  Correctness first: this is the parity path for
+// real-world files such as the reference's house_04 sample; the throughput path is dsa_kernels.h.
+// Everything after the header is parsed here (the host only sized the arena); results land where the fast path
+// puts them (faces, work[] = portable values, map[], AttrDesc), so k_finalize and the C-ABI do not care which
+// path produced them.
+#pragma once
+#include "dsa_kernels.h"
+
+namespace dsa {
+namespace gen {
+
+#define GFAIL(site) do { fail(D, ST_INVALID, (site)); return false; } while (0)
+#define GREQ(cond, site) do { if (!(cond)) GFAIL(site); } while (0)
+#define GNOTIMPL(site) do { fail(D, ST_NOTIMPL, (site)); return false; } while (0)
+
+__device__ __forceinline__ uint32_t cnx(uint32_t c) { return c == DSA_INVALID ? c : ((c % 3u == 2u) ? c - 2u : c + 1u); }
+__device__ __forceinline__ uint32_t cpv(uint32_t c) { return c == DSA_INVALID ? c : ((c % 3u == 0u) ? c + 2u : c - 1u); }
+
+// Mesh/CornerTable.cs:59-82,127-130,174-192,213-245,275-279
+struct Ct {
+  uint32_t *opp, *c2v, *vcorner;
+  uint32_t F, C, nv, vmax;
+  __device__ uint32_t opposite(uint32_t c) const { return c < C ? opp[c] : DSA_INVALID; }
+  __device__ uint32_t vertex(uint32_t c) const { return c < C ? c2v[c] : DSA_INVALID; }
+  __device__ uint32_t left_most(uint32_t v) const { return v < nv ? vcorner[v] : DSA_INVALID; }
+  __device__ uint32_t swing_right(uint32_t c) const { return cpv(opposite(cpv(c))); }
+  __device__ uint32_t swing_left(uint32_t c) const { return cnx(opposite(cnx(c))); }
+  __device__ uint32_t right_corner(uint32_t c) const { return opposite(cnx(c)); }
+  __device__ uint32_t left_corner(uint32_t c) const { return opposite(cpv(c)); }
+  __device__ bool is_on_boundary(uint32_t v) const { return swing_left(left_most(v)) == DSA_INVALID; }
+  __device__ uint32_t num_faces() const { return F; }
+  __device__ void set_opp(uint32_t a, uint32_t b) { if (a < C) opp[a] = b; if (b < C) opp[b] = a; }
+};
+
+// Mesh/MeshAttributeCornerTable.cs:19-30 (ctor), :80-93 (AddSeamEdge), :95-155 (RecomputeVertices), :157-215
+struct Act {
+  const Ct *ct;
+  uint8_t *edge_seam, *vert_seam;
+  uint32_t *c2v, *v2lm;
+  uint32_t nv;
+  __device__ uint32_t opposite(uint32_t c) const { return (c >= ct->C || edge_seam[c]) ? DSA_INVALID : ct->opp[c]; }
+  __device__ uint32_t vertex(uint32_t c) const { return c < ct->C ? c2v[c] : DSA_INVALID; }
+  __device__ uint32_t left_most(uint32_t v) const { return v < nv ? v2lm[v] : DSA_INVALID; }
+  __device__ uint32_t swing_right(uint32_t c) const { return cpv(opposite(cpv(c))); }
+  __device__ uint32_t swing_left(uint32_t c) const { return cnx(opposite(cnx(c))); }
+  __device__ uint32_t right_corner(uint32_t c) const { return opposite(cnx(c)); }
+  __device__ uint32_t left_corner(uint32_t c) const { return opposite(cpv(c)); }
+  __device__ bool is_on_boundary(uint32_t v) const { uint32_t c = left_most(v); return c == DSA_INVALID || swing_left(c) == DSA_INVALID; }
+  __device__ uint32_t num_faces() const { return ct->F; }
+  __device__ void add_seam_edge(uint32_t c) {
+    edge_seam[c] = 1;
+    uint32_t a = ct->vertex(cnx(c)), b = ct->vertex(cpv(c));
+    if (a < ct->vmax) vert_seam[a] = 1;
+    if (b < ct->vmax) vert_seam[b] = 1;
+    uint32_t o = ct->opposite(c);
+    if (o != DSA_INVALID && o < ct->C) {
+      edge_seam[o] = 1;
+      a = ct->vertex(cnx(o)); b = ct->vertex(cpv(o));
+      if (a < ct->vmax) vert_seam[a] = 1;
+      if (b < ct->vmax) vert_seam[b] = 1;
+    }
+  }
+};
+
+// Entropy/RAnsSymbolDecoder.cs:12-59 + RAnsDecoder.cs:20-99, serial; cum[0..ns] cumulative frequencies.
+struct Rans {
+  uint32_t pb, l_base, ns, state, off;
+  const uint8_t *buf;
+  const uint32_t *cum;
+  __device__ uint32_t read() {
+    while (state < l_base && off > 0) state = state * 256u + buf[--off];
+    const uint32_t rem = state & ((1u << pb) - 1u);
+    uint32_t lo = 0, hi = ns;          // largest s with cum[s] <= rem
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= rem) lo = mid; else hi = mid; }
+    state = (state >> pb) * (cum[lo + 1] - cum[lo]) + rem - cum[lo];
+    return lo;
+  }
+};
+
+__device__ bool rans_create(MeshDesc *D, Rd &r, uint32_t max_bit_length, uint32_t *cum, uint64_t cum_cap, Rans &x) {
+  x.pb = rans_precision_bits(max_bit_length);
+  x.l_base = 4u << x.pb;
+  const uint64_t ns = r.varint();
+  GREQ(r.ok && ns >= 1 && ns <= (1u << 20) && ns + 2 <= cum_cap, 600);
+  x.ns = (uint32_t)ns;
+  GREQ(read_prob_table(r, x.ns, cum + 1), 601);
+  cum[0] = 0;
+  for (uint32_t i = 0; i < x.ns; ++i) {
+    GREQ(cum[i + 1] <= (1u << x.pb), 602);
+    cum[i + 1] += cum[i];
+    GREQ(cum[i + 1] <= (1u << x.pb), 602);
+  }
+  GREQ(cum[x.ns] == (1u << x.pb), 603);
+  x.cum = cum;
+  // RAnsSymbolDecoder.cs:53-59, RAnsDecoder.cs:20-54
+  const uint64_t size = r.varint();
+  GREQ(r.ok && size >= 1 && size <= (uint64_t)(r.n - r.pos), 604);
+  x.buf = r.p + r.pos;
+  r.skip(size);
+  const uint32_t o = (uint32_t)size, t = x.buf[o - 1] >> 6;
+  if (t == 0) { x.off = o - 1; x.state = x.buf[o - 1] & 0x3Fu; }
+  else if (t == 1) { GREQ(o >= 2, 605); x.off = o - 2; x.state = ((uint32_t)x.buf[o - 2] | ((uint32_t)x.buf[o - 1] << 8)) & 0x3FFFu; }
+  else if (t == 2) { GREQ(o >= 3, 605); x.off = o - 3; x.state = ((uint32_t)x.buf[o - 3] | ((uint32_t)x.buf[o - 2] << 8) | ((uint32_t)x.buf[o - 1] << 16)) & 0x3FFFFFu; }
+  else { GREQ(o >= 4, 605); x.off = o - 4; x.state = ((uint32_t)x.buf[o - 4] | ((uint32_t)x.buf[o - 3] << 8) | ((uint32_t)x.buf[o - 2] << 16) | ((uint32_t)x.buf[o - 1] << 24)) & 0x3FFFFFFFu; }
+  x.state += x.l_base;
+  GREQ(x.state < x.l_base * 256u, 606);
+  return true;
+}
+
+// Entropy/SymbolDecoding.cs:7-67 (tagged path per the bitstream, D-1)
+__device__ bool decode_symbols(MeshDesc *D, Rd &r, uint32_t num_values, uint32_t nc, uint32_t *out, uint32_t *cum, uint64_t cum_cap) {
+  if (num_values == 0) return true;
+  const uint32_t scheme = r.u8();
+  GREQ(r.ok && scheme <= 1, 610);
+  Rans x;
+  if (scheme == 0) {
+    if (!rans_create(D, r, 5, cum, cum_cap, x)) return false;
+    const uint8_t *bits = r.p + r.pos;
+    const uint32_t nbytes = r.n - r.pos;
+    uint64_t bitpos = 0;
+    uint32_t vid = 0;
+    for (uint32_t i = 0; i < num_values; i += nc) {
+      const uint32_t len = x.read();
+      GREQ(len <= 32, 611);
+      for (uint32_t j = 0; j < nc; ++j) {
+        GREQ(vid < num_values, 612);
+        out[vid++] = len ? read_bits(bits, nbytes, bitpos, len) : 0u;
+        bitpos += len;
+      }
+    }
+    r.skip((bitpos + 7) >> 3);
+    GREQ(r.ok, 613);
+  } else {
+    const uint32_t mbl = r.u8();
+    GREQ(r.ok && mbl >= 1 && mbl <= 18, 614);
+    if (!rans_create(D, r, mbl, cum, cum_cap, x)) return false;
+    for (uint32_t i = 0; i < num_values; ++i) out[i] = x.read();
+  }
+  return true;
+}
+
+// Traverser/DepthFirstTraverser.cs:9-99 + MeshAttributeIndicesEncodingObserver.cs:14-21 +
+// MeshTraversalSequencer.cs:13-31 on either corner table.
+template <class T>
+__device__ bool traverse(MeshDesc *D, const T &t, uint32_t num_verts, const int32_t *c2p, uint8_t *fvis, uint8_t *vvis, uint32_t *stack,
+                         uint32_t stack_cap, uint32_t *d2c, int32_t *v2d, uint32_t *pids, uint32_t cap_entries, uint32_t *num_entries) {
+  const uint32_t F = t.num_faces();
+  for (uint32_t f = 0; f < F; ++f) fvis[f] = 0;
+  for (uint32_t v = 0; v < num_verts; ++v) { vvis[v] = 0; v2d[v] = -1; }
+  uint32_t count = 0;
+#define G_VISIT(v_, c_) { GREQ(count < cap_entries, 620); vvis[v_] = 1; pids[count] = (uint32_t)c2p[c_]; d2c[count] = (c_); v2d[v_] = (int32_t)count; ++count; }
+  for (uint32_t f0 = 0; f0 < F; ++f0) {
+    if (fvis[f0]) continue;
+    uint32_t corner = 3 * f0, sp = 0;
+    stack[sp++] = corner;
+    const uint32_t nv = t.vertex(cnx(corner)), pv = t.vertex(cpv(corner));
+    GREQ(nv < num_verts && pv < num_verts, 621);
+    if (!vvis[nv]) G_VISIT(nv, cnx(corner));
+    if (!vvis[pv]) G_VISIT(pv, cpv(corner));
+    while (sp > 0) {
+      corner = stack[sp - 1];
+      uint32_t face = corner == DSA_INVALID ? DSA_INVALID : corner / 3;
+      if (corner == DSA_INVALID || face >= F || fvis[face]) { --sp; continue; }
+      for (;;) {
+        fvis[face] = 1;
+        const uint32_t v = t.vertex(corner);
+        GREQ(v < num_verts, 622);
+        if (!vvis[v]) {
+          const bool on_boundary = t.is_on_boundary(v);
+          G_VISIT(v, corner);
+          if (!on_boundary) {
+            corner = t.right_corner(corner);
+            GREQ(corner != DSA_INVALID && corner / 3 < F, 623);
+            face = corner / 3;
+            continue;
+          }
+        }
+        const uint32_t rc = t.right_corner(corner), lc = t.left_corner(corner);
+        const uint32_t rf = rc == DSA_INVALID ? DSA_INVALID : rc / 3, lf = lc == DSA_INVALID ? DSA_INVALID : lc / 3;
+        const bool rdone = rf >= F || fvis[rf], ldone = lf >= F || fvis[lf];
+        if (rdone) {
+          if (ldone) { --sp; break; }
+          corner = lc; face = lf;
+        } else {
+          if (ldone) { corner = rc; face = rf; }
+          else { GREQ(sp < stack_cap, 624); stack[sp - 1] = lc; stack[sp++] = rc; break; }
+        }
+      }
+    }
+  }
+#undef G_VISIT
+  *num_entries = count;
+  return true;
+}
+
+// MeshPredictionSchemeParallelogramDecoder.cs:29-54,56-89 + wrap transform, in place on corr -> values
+template <class T>
+__device__ void parallelogram_wrap(const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t entries, uint32_t nc, int32_t *w,
+                                   int32_t mn, int32_t mx, int32_t max_dif) {
+  for (uint32_t c = 0; c < nc; ++c) w[c] = wrap_original(0, w[c], mn, mx, max_dif);
+  for (uint32_t p = 1; p < entries; ++p) {
+    const uint32_t oci = t.opposite(d2c[p]);
+    bool ok = false;
+    int32_t vo = -1, vn = -1, vp = -1;
+    if (oci != DSA_INVALID) {
+      const uint32_t a = t.vertex(oci), b = t.vertex(cnx(oci)), c = t.vertex(cpv(oci));
+      if (a != DSA_INVALID && b != DSA_INVALID && c != DSA_INVALID) { vo = v2d[a]; vn = v2d[b]; vp = v2d[c]; }
+      ok = vo >= 0 && vn >= 0 && vp >= 0 && vo < (int32_t)p && vn < (int32_t)p && vp < (int32_t)p;
+    }
+    for (uint32_t c = 0; c < nc; ++c) {
+      const int32_t pred = ok ? (int32_t)((uint32_t)w[vn * nc + c] + (uint32_t)w[vp * nc + c] - (uint32_t)w[vo * nc + c]) : w[(p - 1) * nc + c];
+      w[p * nc + c] = wrap_original(pred, w[p * nc + c], mn, mx, max_dif);
+    }
+  }
+}
+
+__device__ inline uint64_t int_sqrt(uint64_t number) {   // Core/MathUtilities.cs:5-25
+  if (number == 0) return 0;
+  uint64_t act = number, root = 1;
+  while (act >= 2) { root *= 2; act /= 4; }
+  do { root = (root + number / root) / 2; } while (root * root > number);
+  return root;
+}
+
+// MeshPredictionSchemeTexCoordsPortableDecoder.cs:50-85 + ...PortablePredictor.cs:46-150, in place
+template <class T>
+__device__ bool texcoords_portable_wrap(MeshDesc *D, const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t entries, int32_t *w,
+                                        const uint32_t *entry_to_point, const int32_t *pos, const uint32_t *pos_map, uint32_t num_points,
+                                        uint32_t pos_entries, const uint8_t *orient, uint32_t num_orient, int32_t mn, int32_t mx, int32_t max_dif) {
+  uint32_t left = num_orient;
+  for (uint32_t p = 0; p < entries; ++p) {
+    const int32_t data_id = (int32_t)p;
+    const uint32_t ci = d2c[p];
+    const uint32_t vnx = t.vertex(cnx(ci)), vpv = t.vertex(cpv(ci));
+    const int32_t next_id = vnx != DSA_INVALID ? v2d[vnx] : -1, prev_id = vpv != DSA_INVALID ? v2d[vpv] : -1;
+    int32_t pred[2] = {0, 0};
+    bool done = false;
+    if (prev_id >= 0 && next_id >= 0 && prev_id < data_id && next_id < data_id) {
+      const int64_t n_uv[2] = {w[next_id * 2], w[next_id * 2 + 1]}, p_uv[2] = {w[prev_id * 2], w[prev_id * 2 + 1]};
+      if (p_uv[0] == n_uv[0] && p_uv[1] == n_uv[1]) { pred[0] = (int32_t)p_uv[0]; pred[1] = (int32_t)p_uv[1]; done = true; }
+      else {
+        int64_t tip[3], np[3], pp[3];
+        const int32_t ids[3] = {data_id, next_id, prev_id};
+        int64_t *dst[3] = {tip, np, pp};
+        for (int q = 0; q < 3; ++q) {
+          const uint32_t point = entry_to_point[ids[q]];
+          GREQ(point < num_points, 630);
+          const uint32_t e = pos_map[point];
+          GREQ(e < pos_entries, 631);
+          for (int k = 0; k < 3; ++k) dst[q][k] = pos[(size_t)e * 3 + k];
+        }
+        const int64_t pn[3] = {pp[0] - np[0], pp[1] - np[1], pp[2] - np[2]};
+        const int64_t pn_norm2 = pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2];
+        if (pn_norm2 != 0) {
+          const int64_t cn[3] = {tip[0] - np[0], tip[1] - np[1], tip[2] - np[2]};
+          const int64_t cn_dot_pn = pn[0] * cn[0] + pn[1] * cn[1] + pn[2] * cn[2];
+          const int64_t pn_uv[2] = {p_uv[0] - n_uv[0], p_uv[1] - n_uv[1]};
+          const int64_t x_uv[2] = {n_uv[0] * pn_norm2 + cn_dot_pn * pn_uv[0], n_uv[1] * pn_norm2 + cn_dot_pn * pn_uv[1]};
+          int64_t x_pos[3];
+          for (int k = 0; k < 3; ++k) x_pos[k] = np[k] + (cn_dot_pn * pn[k]) / pn_norm2;
+          const int64_t cx[3] = {tip[0] - x_pos[0], tip[1] - x_pos[1], tip[2] - x_pos[2]};
+          const uint64_t cx_norm2 = (uint64_t)(cx[0] * cx[0] + cx[1] * cx[1] + cx[2] * cx[2]);
+          int64_t cx_uv[2] = {pn_uv[1], -pn_uv[0]};
+          const int64_t norm = (int64_t)int_sqrt(cx_norm2 * (uint64_t)pn_norm2);
+          cx_uv[0] *= norm; cx_uv[1] *= norm;
+          GREQ(left > 0, 632);
+          const bool orientation = orient[--left] != 0;
+          int64_t pu, pv;
+          if (orientation) { pu = (x_uv[0] + cx_uv[0]) / pn_norm2; pv = (x_uv[1] + cx_uv[1]) / pn_norm2; }
+          else { pu = (x_uv[0] - cx_uv[0]) / pn_norm2; pv = (x_uv[1] - cx_uv[1]) / pn_norm2; }
+          pred[0] = (int32_t)pu; pred[1] = (int32_t)pv;
+          done = true;
+        }
+      }
+    }
+    if (!done) {
+      int32_t data_offset = 0;
+      bool zero = false;
+      if (prev_id >= 0 && prev_id < data_id) data_offset = prev_id * 2;
+      if (next_id >= 0 && next_id < data_id) data_offset = next_id * 2;
+      else {
+        if (data_id > 0) data_offset = (data_id - 1) * 2;
+        else zero = true;
+      }
+      if (!zero) { pred[0] = w[data_offset]; pred[1] = w[data_offset + 1]; }
+    }
+    w[p * 2] = wrap_original(pred[0], w[p * 2], mn, mx, max_dif);
+    w[p * 2 + 1] = wrap_original(pred[1], w[p * 2 + 1], mn, mx, max_dif);
+  }
+  return true;
+}
+
+struct DecoderInfo { int att_data_id; uint32_t element_type, first_att, num_atts, num_entries; };
+
+// The whole mesh.  Returns false after latching the failure.
+__device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r) {
+  const uint8_t *s = arena + L.stream;
+  // ---------------------------------------------------------------- MeshEdgeBreakerDecoder.cs:25-134
+  D->traversal_type = (uint8_t)r.u8();
+  GREQ(r.ok && D->traversal_type <= 2, 109);
+  if (D->traversal_type == 1) GNOTIMPL(110);               // predictive traversal
+  const bool valence = D->traversal_type == 2;
+  const uint64_t nv64 = r.varint(), nf64 = r.varint();
+  GREQ(r.ok && nf64 <= 0x7FFFFFFFu / 3 && nv64 <= nf64 * 3, 111);
+  GREQ(nv64 * (nv64 - 1) / 2 >= 3 * nf64 / 2, 112);
+  const uint32_t nad = r.u8();
+  const uint64_t nsym64 = r.varint();
+  GREQ(r.ok && nf64 >= nsym64 && nf64 <= nsym64 + nsym64 / 3, 113);
+  const uint64_t nss64 = r.varint();
+  GREQ(r.ok && nss64 <= nsym64 && nad <= DSA_MAX_ATT_DATA, 114);
+  const uint32_t F = (uint32_t)nf64, C = 3 * F, num_symbols = (uint32_t)nsym64;
+  const uint32_t VMAX = (uint32_t)(nv64 + nss64);
+  GREQ(F == L.cap_faces && VMAX == L.cap_vertices, 116);
+  D->num_enc_vertices = (uint32_t)nv64; D->num_faces = F; D->num_att_data = (uint8_t)nad;
+  D->num_symbols = num_symbols; D->num_split_symbols = (uint32_t)nss64;
+  const uint64_t nsplits64 = r.varint();
+  GREQ(r.ok && nsplits64 <= F && nsplits64 <= L.cap_splits, 117);
+  const uint32_t S = (uint32_t)nsplits64;
+  D->num_splits = S;
+  const GenLayout g = gen_layout(F, VMAX, L.cap_splits, nad, L.stream_len);
+  GREQ(g.total <= L.gen_bytes, 640);
+  uint8_t *G = arena + L.gen;
+  // arrays (the fast path's regions are free for a general mesh)
+  Ct ct;
+  ct.opp = (uint32_t *)(arena + L.frec); ct.c2v = ct.opp + C; ct.vcorner = (uint32_t *)(arena + L.vrec);
+  ct.F = F; ct.C = C; ct.nv = 0; ct.vmax = VMAX;
+  uint8_t *is_hole = arena + L.vvis;
+  uint32_t *valences = (uint32_t *)(arena + L.vstamp);
+  uint32_t *ctx_syms = (uint32_t *)(arena + L.fstamp);
+  uint32_t *invalid_list = (uint32_t *)(arena + L.vrank);
+  uint32_t *stack = (uint32_t *)(G + g.stack);
+  uint32_t *splits = (uint32_t *)(G + g.splits), *active = (uint32_t *)(G + g.active);
+  uint32_t *cum = (uint32_t *)(G + g.cum);
+  int32_t *c2p = (int32_t *)(arena + L.faces);
+  for (uint32_t c = 0; c < C; ++c) { ct.opp[c] = DSA_INVALID; ct.c2v[c] = DSA_INVALID; }
+  for (uint32_t v = 0; v < VMAX; ++v) is_hole[v] = 1;
+  // topology splits, :136-230
+  {
+    uint32_t last = 0;
+    for (uint32_t i = 0; i < S; ++i) {
+      const uint32_t source = (uint32_t)r.varint() + last;
+      const uint32_t delta = (uint32_t)r.varint();
+      GREQ(r.ok && delta <= source, 200);
+      splits[3 * i] = source; splits[3 * i + 1] = source - delta; splits[3 * i + 2] = 0;
+      last = source;
+    }
+    if (S > 0) {
+      const uint8_t *bits = r.p + r.pos;
+      const uint32_t nbytes = r.n - r.pos;
+      for (uint32_t i = 0; i < S; ++i) splits[3 * i + 2] = read_bits(bits, nbytes, i, 1);
+      r.skip(((uint64_t)S + 7) >> 3);
+      GREQ(r.ok, 118);
+    }
+  }
+  // traversal decoder start, MeshEdgeBreakerTraversalDecoder.cs:27-61 / ...ValenceDecoder.cs:22-69
+  const uint8_t *sym_bits = nullptr;
+  uint32_t sym_nbytes = 0;
+  uint64_t sym_bitpos = 0;
+  if (!valence) {
+    const uint64_t size = r.varint();
+    GREQ(r.ok && size <= (uint64_t)(r.n - r.pos), 119);
+    sym_bits = r.p + r.pos; sym_nbytes = (uint32_t)size;
+    r.skip(size);
+  }
+  Rabs start_face, seams[DSA_MAX_ATT_DATA];
+  uint32_t endp;
+  start_face.start(s, L.stream_len, r.pos, &endp);
+  GREQ(start_face.ok, 201);
+  r.pos = endp;
+  for (uint32_t i = 0; i < nad; ++i) {
+    seams[i].start(s, L.stream_len, r.pos, &endp);
+    GREQ(seams[i].ok, 260);
+    r.pos = endp;
+  }
+  uint32_t ctx_off[6] = {0, 0, 0, 0, 0, 0};
+  int32_t ctx_cnt[6] = {0, 0, 0, 0, 0, 0};
+  if (valence) {
+    for (uint32_t v = 0; v < VMAX; ++v) valences[v] = 0;
+    uint32_t total = 0;
+    for (int i = 0; i < 6; ++i) {
+      const uint64_t num = r.varint();
+      GREQ(r.ok && num <= F && total + num <= F, 641);
+      ctx_off[i] = total;
+      if (num > 0) {
+        if (!decode_symbols(D, r, (uint32_t)num, 1, ctx_syms + total, cum, g.cum_entries)) return false;
+        ctx_cnt[i] = (int32_t)num;
+      }
+      total += (uint32_t)num;
+    }
+  }
+  // ---------------------------------------------------------------- symbols, :232-442
+  int last_symbol = -1, active_context = -1;
+  uint32_t sp = 0, num_faces = 0, num_invalid = 0, splits_left = S, active_n = 0;
+  const bool remove_invalid = nad == 0;
+  for (uint32_t sid = 0; sid < num_symbols; ++sid) {
+    const uint32_t face = num_faces++;
+    bool check_split = false;
+    uint32_t sym;
+    if (!valence) {                                        // MeshEdgeBreakerTraversalDecoder.cs:89-99
+      sym = read_bits(sym_bits, sym_nbytes, sym_bitpos, 1); sym_bitpos += 1;
+      if (sym) { sym |= read_bits(sym_bits, sym_nbytes, sym_bitpos, 2) << 1; sym_bitpos += 2; }
+      GREQ(sym_bitpos <= (uint64_t)sym_nbytes * 8, 246);
+    } else {                                               // ...ValenceDecoder.cs:77-98
+      if (active_context != -1) {
+        const int32_t cnt = --ctx_cnt[active_context];
+        GREQ(cnt >= 0, 642);
+        const uint32_t id = ctx_syms[ctx_off[active_context] + cnt];
+        GREQ(id <= 4, 643);
+        last_symbol = id == 0 ? 0 : (id == 1 ? 1 : (id == 2 ? 3 : (id == 3 ? 5 : 7)));
+      } else last_symbol = 7;
+      sym = (uint32_t)last_symbol;
+    }
+    const uint32_t corner = 3 * face;
+    if (sym == 0) {                    // C
+      GREQ(sp > 0, 210);
+      const uint32_t ca = stack[sp - 1];
+      const uint32_t vx = ct.vertex(cnx(ca));
+      GREQ(vx < ct.nv, 213);
+      const uint32_t lm = ct.left_most(vx);
+      GREQ(lm < C, 213);
+      const uint32_t cb = cnx(lm);
+      GREQ(ca != cb && ca < C, 213);
+      GREQ(ct.opp[ca] == DSA_INVALID && ct.opp[cb] == DSA_INVALID, 263);
+      ct.set_opp(ca, corner + 1);
+      ct.set_opp(cb, corner + 2);
+      const uint32_t va_prev = ct.vertex(cpv(ca)), vb_next = ct.vertex(cnx(cb));
+      GREQ(va_prev < ct.nv && vb_next < ct.nv && vx != va_prev && vx != vb_next, 213);
+      ct.c2v[corner] = vx; ct.c2v[corner + 1] = vb_next; ct.c2v[corner + 2] = va_prev;
+      ct.vcorner[va_prev] = corner + 2;
+      is_hole[vx] = 0;
+      stack[sp - 1] = corner;
+    } else if (sym == 5 || sym == 3) { // R / L
+      GREQ(sp > 0, 220);
+      const uint32_t ca = stack[sp - 1];
+      GREQ(ca < C && ct.opp[ca] == DSA_INVALID, 263);
+      uint32_t oc, cl, cr;
+      if (sym == 5) { oc = corner + 2; cl = corner + 1; cr = corner; }
+      else { oc = corner + 1; cl = corner; cr = corner + 2; }
+      ct.set_opp(oc, ca);
+      GREQ(ct.nv < VMAX, 220);
+      const uint32_t nv = ct.nv++;
+      ct.vcorner[nv] = oc;
+      ct.c2v[oc] = nv;
+      const uint32_t vr = ct.vertex(cpv(ca)), vl = ct.vertex(cnx(ca));
+      GREQ(vr < ct.nv && vl < ct.nv, 220);
+      ct.c2v[cr] = vr;
+      ct.vcorner[vr] = cr;
+      ct.c2v[cl] = vl;
+      stack[sp - 1] = corner;
+      check_split = true;
+    } else if (sym == 1) {             // S
+      GREQ(sp > 0, 230);
+      const uint32_t cb = stack[--sp];
+      for (uint32_t k = 0; k < active_n; ++k)
+        if (active[2 * k] == sid) { GREQ(sp < F, 232); stack[sp++] = active[2 * k + 1]; break; }
+      GREQ(sp > 0, 232);
+      const uint32_t ca = stack[sp - 1];
+      GREQ(ca != cb && ca < C && cb < C, 233);
+      GREQ(ct.opp[ca] == DSA_INVALID && ct.opp[cb] == DSA_INVALID, 263);
+      ct.set_opp(ca, corner + 2);
+      ct.set_opp(cb, corner + 1);
+      const uint32_t vp = ct.vertex(cpv(ca)), vq = ct.vertex(cnx(ca)), vb_prev = ct.vertex(cpv(cb));
+      GREQ(vp < ct.nv && vq < ct.nv && vb_prev < ct.nv, 234);
+      ct.c2v[corner] = vp; ct.c2v[corner + 1] = vq; ct.c2v[corner + 2] = vb_prev;
+      ct.vcorner[vb_prev] = corner + 2;
+      uint32_t cn = cnx(cb);
+      const uint32_t vn = ct.vertex(cn);
+      GREQ(vn < ct.nv, 234);
+      if (valence) valences[vp] += valences[vn];           // ...ValenceDecoder.cs:151-154
+      ct.vcorner[vp] = ct.left_most(vn);
+      const uint32_t first = cn;
+      uint32_t guard = 0;
+      while (cn != DSA_INVALID) {
+        ct.c2v[cn] = vp;
+        cn = ct.swing_left(cn);
+        GREQ(cn != first && ++guard <= C, 235);
+      }
+      ct.vcorner[vn] = DSA_INVALID;
+      if (remove_invalid) { GREQ(num_invalid < VMAX, 236); invalid_list[num_invalid++] = vn; }
+      stack[sp - 1] = corner;
+    } else if (sym == 7) {             // E
+      GREQ(ct.nv + 3 <= VMAX && sp < F, 240);
+      const uint32_t v0 = ct.nv;
+      ct.nv += 3;
+      ct.c2v[corner] = v0; ct.c2v[corner + 1] = v0 + 1; ct.c2v[corner + 2] = v0 + 2;
+      ct.vcorner[v0] = corner; ct.vcorner[v0 + 1] = corner + 1; ct.vcorner[v0 + 2] = corner + 2;
+      stack[sp++] = corner;
+      check_split = true;
+    } else GFAIL(241);
+    if (valence) {                     // NewActiveCornerReached, ...ValenceDecoder.cs:100-149
+      const uint32_t top = stack[sp - 1], nx = cnx(top), pv = cpv(top);
+      const uint32_t a = ct.vertex(top), b = ct.vertex(nx), c = ct.vertex(pv);
+      GREQ(a < VMAX && b < VMAX && c < VMAX, 644);
+      switch (last_symbol) {
+        case 0: case 1: valences[b] += 1; valences[c] += 1; break;
+        case 5: valences[a] += 1; valences[b] += 1; valences[c] += 2; break;
+        case 3: valences[a] += 1; valences[b] += 2; valences[c] += 1; break;
+        case 7: valences[a] += 2; valences[b] += 2; valences[c] += 2; break;
+        default: break;
+      }
+      const int32_t v = (int32_t)valences[b];
+      active_context = (v < 2 ? 2 : (v > 7 ? 7 : v)) - 2;
+    }
+    if (check_split) {                 // :363-375, IsTopologySplit :450-471
+      const int32_t enc_id = (int32_t)(num_symbols - sid - 1);
+      while (splits_left > 0) {
+        const uint32_t src = splits[3 * (splits_left - 1)];
+        GREQ((int64_t)src <= (int64_t)enc_id, 243);       // encoderSplitSymbolId < 0 in the reference
+        if ((int64_t)src != (int64_t)enc_id) break;
+        const uint32_t edge = splits[3 * (splits_left - 1) + 2], enc_split = splits[3 * (splits_left - 1) + 1];
+        --splits_left;
+        GREQ(enc_split < num_symbols, 244);
+        const uint32_t top = stack[sp - 1];
+        const uint32_t nc = edge == 1 ? cnx(top) : cpv(top);   // 1 = right face edge
+        const uint32_t key = num_symbols - enc_split - 1;
+        uint32_t k = 0;
+        for (; k < active_n; ++k) if (active[2 * k] == key) break;
+        GREQ(k < L.cap_splits, 244);
+        active[2 * k] = key; active[2 * k + 1] = nc;
+        if (k == active_n) ++active_n;
+      }
+    }
+  }
+  // start faces, :378-415
+  while (sp > 0) {
+    const uint32_t corner = stack[--sp];
+    const bool interior = start_face.next() != 0;
+    if (!interior) continue;
+    GREQ(num_faces < F && corner < C, 251);
+    const uint32_t ca = corner;
+    const uint32_t vn = ct.vertex(cnx(ca));
+    GREQ(vn < ct.nv && ct.left_most(vn) < C, 252);
+    const uint32_t cb = cnx(ct.left_most(vn));
+    const uint32_t vx = ct.vertex(cnx(cb));
+    GREQ(vx < ct.nv && ct.left_most(vx) < C, 253);
+    const uint32_t cc = cnx(ct.left_most(vx));
+    GREQ(ca != cb && ca != cc && cb != cc, 254);
+    GREQ(ct.opp[ca] == DSA_INVALID && ct.opp[cb] == DSA_INVALID && ct.opp[cc] == DSA_INVALID, 255);
+    const uint32_t vp = ct.vertex(cnx(cc));
+    GREQ(vp < ct.nv, 262);
+    const uint32_t face = num_faces++, nc = 3 * face;
+    ct.set_opp(nc, ca); ct.set_opp(nc + 1, cb); ct.set_opp(nc + 2, cc);
+    ct.c2v[nc] = vx; ct.c2v[nc + 1] = vp; ct.c2v[nc + 2] = vn;
+    is_hole[vx] = 0; is_hole[vp] = 0; is_hole[vn] = 0;
+  }
+  GREQ(num_faces == F, 256);
+  // isolated-vertex compaction, :417-441 (D-10)
+  uint32_t num_vertices = ct.nv;
+  for (uint32_t k = 0; k < num_invalid; ++k) {
+    const uint32_t inv = invalid_list[k];
+    GREQ(num_vertices > 0, 257);
+    uint32_t src = num_vertices - 1;
+    while (ct.left_most(src) == DSA_INVALID) { GREQ(num_vertices > 1, 258); src = --num_vertices - 1; }
+    if (src < inv) continue;
+    const uint32_t start = ct.left_most(src);
+    uint32_t c = start, guard = 0;
+    bool left = true;
+    while (c != DSA_INVALID) {
+      GREQ(c < C && ct.c2v[c] == src && ++guard <= C, 259);
+      ct.c2v[c] = inv;
+      if (left) {
+        c = ct.swing_left(c);
+        if (c == DSA_INVALID) { c = ct.swing_right(start); left = false; }
+        else if (c == start) c = DSA_INVALID;
+      } else c = ct.swing_right(c);
+    }
+    ct.vcorner[inv] = ct.left_most(src);
+    ct.vcorner[src] = DSA_INVALID;
+    is_hole[inv] = is_hole[src];
+    is_hole[src] = 0;
+    num_vertices--;
+  }
+  const uint32_t num_conn_vertices = num_vertices;
+  D->num_vertices = num_conn_vertices;
+  D->num_all_vertices = ct.nv;
+  // ---------------------------------------------------------------- attribute seams, :502-535
+  Act act[DSA_MAX_ATT_DATA];
+  for (uint32_t d = 0; d < nad; ++d) {
+    uint8_t *blk = G + g.data + (uint64_t)d * g.data_stride;
+    act[d].ct = &ct;
+    act[d].edge_seam = blk + g.edge_seam; act[d].vert_seam = blk + g.vert_seam;
+    act[d].c2v = (uint32_t *)(blk + g.c2v); act[d].v2lm = (uint32_t *)(blk + g.v2lm);
+    act[d].nv = 0;
+    for (uint32_t c = 0; c < C; ++c) { act[d].edge_seam[c] = 0; act[d].c2v[c] = DSA_INVALID; }
+    for (uint32_t v = 0; v < VMAX; ++v) act[d].vert_seam[v] = 0;
+  }
+  if (nad > 0) {
+    for (uint32_t c = 0; c < C; ++c) {
+      const uint32_t oc = ct.opp[c];
+      if (oc == DSA_INVALID) { for (uint32_t d = 0; d < nad; ++d) act[d].add_seam_edge(c); continue; }
+      if (oc / 3 < c / 3) continue;
+      for (uint32_t d = 0; d < nad; ++d) if (seams[d].next()) act[d].add_seam_edge(c);
+    }
+    // RecomputeVertices, MeshAttributeCornerTable.cs:95-155
+    for (uint32_t d = 0; d < nad; ++d) {
+      Act &A = act[d];
+      uint32_t num_new = 0;
+      for (uint32_t v = 0; v < ct.nv; ++v) {
+        const uint32_t c = ct.left_most(v);
+        if (c == DSA_INVALID) continue;
+        GREQ(c < C && num_new < C, 650);
+        uint32_t first_vert = num_new++, first_c = c;
+        if (A.vert_seam[v]) {
+          uint32_t a = A.swing_left(first_c), guard = 0;
+          while (a != DSA_INVALID) {
+            first_c = a;
+            a = A.swing_left(a);
+            GREQ(a != c && ++guard <= C, 651);
+          }
+        }
+        A.c2v[first_c] = first_vert;
+        A.v2lm[first_vert] = first_c;
+        uint32_t a = ct.swing_right(first_c), guard = 0;
+        while (a != DSA_INVALID && a != first_c) {
+          GREQ(++guard <= C, 652);
+          if (A.edge_seam[cnx(a)]) { GREQ(num_new < C, 650); first_vert = num_new++; A.v2lm[first_vert] = a; }
+          A.c2v[a] = first_vert;
+          a = ct.swing_right(a);
+        }
+      }
+      A.nv = num_new;
+    }
+  }
+  // ---------------------------------------------------------------- AssignPointsToCorners, :537-638
+  uint32_t num_points = 0;
+  if (nad == 0) {
+    for (uint32_t c = 0; c < C; ++c) c2p[c] = (int32_t)ct.c2v[c];
+    num_points = num_conn_vertices;
+  } else {
+    for (uint32_t c = 0; c < C; ++c) c2p[c] = 0;
+    for (uint32_t v = 0; v < ct.nv; ++v) {
+      uint32_t c = ct.left_most(v);
+      if (c == DSA_INVALID) continue;
+      GREQ(c < C, 660);
+      uint32_t dedup_first = c;
+      if (!is_hole[v]) {
+        for (uint32_t d = 0; d < nad; ++d) {
+          const uint32_t vv = ct.c2v[c];
+          if (vv >= VMAX || !act[d].vert_seam[vv]) continue;                 // IsCornerOnSeam
+          const uint32_t vid = act[d].vertex(c);
+          uint32_t a = ct.swing_right(c), guard = 0;
+          bool seam_found = false;
+          while (a != c) {
+            GREQ(a != DSA_INVALID && ++guard <= C, 661);
+            if (act[d].vertex(a) != vid) { dedup_first = a; seam_found = true; break; }
+            a = ct.swing_right(a);
+          }
+          if (seam_found) break;
+        }
+      }
+      c = dedup_first;
+      GREQ(num_points < L.cap_points, 662);
+      c2p[c] = (int32_t)num_points++;
+      uint32_t prev_c = c, guard = 0;
+      c = ct.swing_right(c);
+      while (c != DSA_INVALID && c != dedup_first) {
+        GREQ(c < C && ++guard <= C, 663);
+        bool seam = false;
+        for (uint32_t d = 0; d < nad; ++d) if (act[d].vertex(c) != act[d].vertex(prev_c)) { seam = true; break; }
+        if (seam) { GREQ(num_points < L.cap_points, 662); c2p[c] = (int32_t)num_points++; }
+        else c2p[c] = c2p[prev_c];
+        prev_c = c;
+        c = ct.swing_right(c);
+      }
+    }
+  }
+  D->num_points = num_points;
+  // ---------------------------------------------------------------- attribute section, ConnectivityDecoder.cs:16-44
+  D->off_attributes = r.pos;
+  const uint32_t ndec = r.u8();
+  GREQ(r.ok && ndec <= DSA_MAX_ATT, 122);
+  D->num_decoders = ndec;
+  DecoderInfo dec[DSA_MAX_ATT];
+  int data_decoder[DSA_MAX_ATT_DATA];
+  bool data_conn_used[DSA_MAX_ATT_DATA];
+  for (uint32_t d = 0; d < DSA_MAX_ATT_DATA; ++d) { data_decoder[d] = -1; data_conn_used[d] = true; }
+  bool pos_seen = false;
+  for (uint32_t i = 0; i < ndec; ++i) {                   // MeshEdgeBreakerDecoder.cs:640-708
+    dec[i].att_data_id = (int8_t)r.u8();
+    dec[i].element_type = r.u8();
+    const uint32_t traversal_method = r.u8();
+    GREQ(r.ok && traversal_method < 2 && dec[i].element_type < 2, 123);
+    if (dec[i].att_data_id >= 0) {
+      GREQ((uint32_t)dec[i].att_data_id < nad && data_decoder[dec[i].att_data_id] < 0, 124);
+      data_decoder[dec[i].att_data_id] = (int)i;
+    } else { GREQ(!pos_seen, 125); pos_seen = true; }
+    if (dec[i].element_type == 0) { if (dec[i].att_data_id >= 0) data_conn_used[dec[i].att_data_id] = false; }
+    else GREQ(traversal_method == 0 && dec[i].att_data_id >= 0, 126);
+    if (traversal_method != 0) GNOTIMPL(128);             // prediction-degree traversal
+  }
+  uint32_t natt = 0;
+  for (uint32_t i = 0; i < ndec; ++i) {                   // AttributesDecoder.cs:19-63 + controller :16-27
+    dec[i].first_att = natt;
+    const uint64_t k = r.varint();
+    GREQ(r.ok && natt + k <= DSA_MAX_ATT && natt + k <= L.cap_attributes, 129);
+    dec[i].num_atts = (uint32_t)k;
+    for (uint32_t j = 0; j < (uint32_t)k; ++j) {
+      AttrDesc &a = D->att[natt + j];
+      a.att_type = (uint8_t)r.u8(); a.data_type = (uint8_t)r.u8(); a.nc = (uint8_t)r.u8(); a.normalized = r.u8() != 0;
+      GREQ(r.ok && a.att_type < 5 && a.data_type != 0 && a.data_type < 12 && a.nc != 0, 130);
+      a.unique_id = (uint32_t)r.varint();
+      a.decoder_id = (int8_t)i;
+    }
+    for (uint32_t j = 0; j < (uint32_t)k; ++j) {
+      AttrDesc &a = D->att[natt + j];
+      a.seq_type = (uint8_t)r.u8();
+      GREQ(r.ok && a.seq_type <= 3, 131);
+      if (a.seq_type == 2) GREQ(a.data_type == 9 && a.nc <= 4, 132);
+      if (a.seq_type == 3) GREQ(a.data_type == 9 && a.nc == 3, 133);
+      if (a.seq_type == 1) { const uint32_t w = data_type_length(a.data_type); GREQ(w == 1 || w == 2 || w == 4, 134); }
+    }
+    natt += (uint32_t)k;
+  }
+  D->num_attributes = natt;
+  // ---------------------------------------------------------------- per decoder: sequence, values
+  uint8_t *fvis = G + g.fvis, *vvis = G + g.vvis;
+  uint32_t *dfs = (uint32_t *)(G + g.dfs);
+  const uint32_t NVMAX = C > VMAX ? C : VMAX;
+  for (uint32_t i = 0; i < ndec; ++i) {
+    // MeshTraversalSequencer + DepthFirstTraverser on the decoder's corner table
+    uint32_t *d2c, *pids;
+    int32_t *v2d;
+    uint32_t cap_entries, nverts;
+    const int dd = dec[i].att_data_id;
+    if (dd < 0) {
+      d2c = (uint32_t *)(arena + L.d2c); v2d = (int32_t *)(arena + L.v2d); pids = (uint32_t *)(arena + L.para);
+      cap_entries = VMAX; nverts = ct.nv;
+    } else {
+      uint8_t *blk = G + g.data + (uint64_t)dd * g.data_stride;
+      d2c = (uint32_t *)(blk + g.d2c); v2d = (int32_t *)(blk + g.v2d); pids = (uint32_t *)(blk + g.pids);
+      cap_entries = NVMAX; nverts = act[dd].nv > ct.nv ? act[dd].nv : ct.nv;
+    }
+    uint32_t entries = 0;
+    const bool corner_att = dec[i].element_type != 0;
+    if (!corner_att) { if (!traverse(D, ct, nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries)) return false; }
+    else { if (!traverse(D, act[dd], nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries)) return false; }
+    dec[i].num_entries = entries;
+    if (dd < 0) D->num_entries = entries;
+    // point -> entry map of every attribute of the decoder, MeshTraversalSequencer.cs:33-50
+    for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) {
+      uint32_t *map = (uint32_t *)(arena + L.map[ai]);
+      for (uint32_t p = 0; p < num_points; ++p) map[p] = 0;
+      for (uint32_t c = 0; c < C; ++c) {
+        const uint32_t point = (uint32_t)c2p[c];
+        const uint32_t v = corner_att ? act[dd].vertex(c) : ct.vertex(c);
+        GREQ(v < nverts && point < num_points, 670);
+        const int32_t e = v2d[v];
+        GREQ(e >= 0 && (uint32_t)e < num_points, 671);
+        map[point] = (uint32_t)e;
+      }
+    }
+    // values of every attribute, SequentialAttributeDecodersController.cs:29-38
+    for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) {
+      AttrDesc &a = D->att[ai];
+      a.num_entries = entries;
+      a.pred_method = -2; a.pred_transform = -1; a.have_scheme = 0; a.pred_kind = 0;
+      if (a.seq_type == 0) {                               // SequentialAttributeDecoder.cs:75-86
+        a.source = SRC_BYTES;
+        a.off_raw = r.pos;
+        const uint64_t bytes = (uint64_t)data_type_length(a.data_type) * a.nc * entries;
+        GREQ(bytes <= L.out_cap[ai], 140);
+        r.skip(bytes);
+        GREQ(r.ok, 141);
+        continue;
+      }
+      const uint32_t nc = a.seq_type == 3 ? 2u : a.nc;
+      a.nc_portable = (uint8_t)nc;
+      const uint64_t num_values = (uint64_t)entries * nc;
+      GREQ(num_values <= L.work_cap[ai], 142);
+      int32_t *w = (int32_t *)(arena + L.work[ai]);
+      const int method = (int8_t)r.u8();
+      GREQ(r.ok && method >= -2 && method < 7, 143);
+      a.pred_method = (int8_t)method;
+      int tt = -1;
+      if (method != -2) {
+        tt = (int8_t)r.u8();
+        GREQ(r.ok && tt >= -1 && tt < 4, 144);
+        a.pred_transform = (int8_t)tt;
+        a.have_scheme = a.seq_type == 3 ? (tt == 2 || tt == 3) : (tt == 1);
+      }
+      const uint32_t compressed = r.u8();
+      GREQ(r.ok, 145);
+      a.source = SRC_RAW;
+      if (compressed > 0) {
+        if (!decode_symbols(D, r, (uint32_t)num_values, nc, (uint32_t *)w, cum, g.cum_entries)) return false;
+      } else {                                             // SequentialIntegerAttributeDecoder.cs:68-84 (D-13)
+        const uint32_t nb = r.u8();
+        GREQ(r.ok && nb >= 1 && nb <= 4, 158);
+        for (uint64_t k = 0; k < num_values; ++k) { uint32_t v = 0; for (uint32_t q = 0; q < nb; ++q) v |= r.u8() << (8 * q); ((uint32_t *)w)[k] = v; }
+        GREQ(r.ok, 160);
+      }
+      const bool positive = a.have_scheme && (tt == 2 || tt == 3);      // D-4
+      if (num_values > 0 && !positive)
+        for (uint64_t k = 0; k < num_values; ++k) { const uint32_t sv = ((uint32_t *)w)[k]; w[k] = (sv & 1u) ? -(int32_t)(sv >> 1) - 1 : (int32_t)(sv >> 1); }
+      if (!a.have_scheme) continue;
+      // scheme selection, PredictionSchemeDecoderFactory.cs:9-76
+      int eff = method;
+      if (!(method == 1 || method == 5)) { if (method == 0) eff = 0; else GNOTIMPL(161); }
+      a.pred_kind = (int8_t)eff;
+      const bool use_act = dd >= 0 && data_conn_used[dd];
+      uint8_t *orient = nullptr;
+      uint32_t num_orient = 0;
+      if (eff == 5) {                                      // MeshPredictionSchemeTexCoordsPortableDecoder.cs:66-85
+        GREQ(dd >= 0, 680);                                // orientation scratch lives in the attribute data block
+        const int32_t num_or = (int32_t)r.u32();
+        GREQ(r.ok && num_or >= 0 && (uint32_t)num_or <= NVMAX, 681);
+        Rabs rd;
+        rd.start(s, L.stream_len, r.pos, &endp);
+        GREQ(rd.ok, 682);
+        r.pos = endp;
+        orient = G + g.data + (uint64_t)dd * g.data_stride + g.orient;
+        bool last = true;
+        for (int32_t k = 0; k < num_or; ++k) { if (rd.next() == 0) last = !last; orient[k] = last ? 1 : 0; }
+        num_orient = (uint32_t)num_or;
+      }
+      if (tt == 1) {                                       // PredictionSchemeWrapDecodingTransform.cs:69-75
+        a.wrap_min = (int32_t)r.u32(); a.wrap_max = (int32_t)r.u32();
+        GREQ(r.ok && a.wrap_min <= a.wrap_max, 162);
+        const int64_t dif = (int64_t)a.wrap_max - (int64_t)a.wrap_min;
+        GREQ(dif < 0x7FFFFFFF, 163);
+        const int32_t mn = a.wrap_min, mx = a.wrap_max, max_dif = (int32_t)(1 + dif);
+        if (num_values == 0) continue;
+        if (eff == 0) {                                    // PredictionSchemeDeltaDecoder.cs:23-37
+          for (uint32_t c = 0; c < nc; ++c) w[c] = wrap_original(0, w[c], mn, mx, max_dif);
+          for (uint64_t k = nc; k < num_values; ++k) w[k] = wrap_original(w[k - nc], w[k], mn, mx, max_dif);
+        } else if (eff == 1) {
+          if (use_act) parallelogram_wrap(act[dd], d2c, v2d, entries, nc, w, mn, mx, max_dif);
+          else parallelogram_wrap(ct, d2c, v2d, entries, nc, w, mn, mx, max_dif);
+        } else {
+          GREQ(nc == 2, 683);
+          // parent = portable positions, SequentialAttributeDecoder.cs:58-73
+          int pa = -1;
+          for (uint32_t q = 0; q < ai; ++q) if (D->att[q].att_type == 0 && D->att[q].seq_type != 0) { pa = (int)q; break; }
+          GREQ(pa >= 0 && D->att[pa].nc_portable == 3, 684);
+          const int32_t *pos = (const int32_t *)(arena + L.work[pa]);
+          const uint32_t *pos_map = (const uint32_t *)(arena + L.map[pa]);
+          bool ok;
+          if (use_act) ok = texcoords_portable_wrap(D, act[dd], d2c, v2d, entries, w, pids, pos, pos_map, num_points, D->att[pa].num_entries, orient, num_orient, mn, mx, max_dif);
+          else ok = texcoords_portable_wrap(D, ct, d2c, v2d, entries, w, pids, pos, pos_map, num_points, D->att[pa].num_entries, orient, num_orient, mn, mx, max_dif);
+          if (!ok) return false;
+        }
+      } else {                                             // normal octahedron transforms (D-19)
+        GREQ(eff == 0, 501);
+        const int32_t max_q = (int32_t)r.u32();
+        if (tt == 3) (void)r.u32();
+        GREQ(r.ok && max_q > 0 && (max_q & 1) == 1, 164);
+        a.oct_max_q = max_q;
+        if (num_values == 0) continue;
+        OctParams o;
+        const int q = 32 - __clz(max_q);
+        GREQ(q >= 2 && q <= 30, 165);
+        const int32_t max_value = (1 << q) - 2;
+        o.center = max_value / 2; o.max_q = (1 << q) - 1;
+        int32_t ps = 0, pt = 0;
+        for (uint32_t e = 0; e < entries; ++e) {
+          int32_t os, ot;
+          oct_original(o, tt == 3, ps, pt, w[2 * e], w[2 * e + 1], os, ot);
+          w[2 * e] = os; w[2 * e + 1] = ot;
+          ps = os; pt = ot;
+        }
+      }
+    }
+    // transform parameters follow the values of the decoder's attributes, AttributesDecoder.cs:65-70
+    for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) {
+      AttrDesc &a = D->att[ai];
+      if (a.seq_type == 2) {                               // AttributeQuantizationTransform.cs:110-121
+        for (uint32_t c = 0; c < a.nc; ++c) a.q_min[c] = r.f32();
+        a.q_range = r.f32();
+        a.q_bits = (uint8_t)r.u8();
+        GREQ(r.ok && a.q_bits >= 1 && a.q_bits <= 30, 135);
+      } else if (a.seq_type == 3) {                        // AttributeOctahedronTransform.cs:39-42 (D-5)
+        a.q_bits = (uint8_t)r.u8();
+        GREQ(r.ok && a.q_bits >= 2 && a.q_bits <= 30, 136);
+      }
+    }
+  }
+  D->end_pos = r.pos;
+  return true;
+}
+
+#undef GFAIL
+#undef GREQ
+#undef GNOTIMPL
+}  // namespace gen
+
+// One wave per mesh, lane 0 works.  Runs on the third stream beside the fast kernels (which skip general meshes).
+__global__ __launch_bounds__(WAVE) void k_general(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  const uint32_t mesh = blockIdx.x;
+  if (mesh >= n || threadIdx.x != 0) return;
+  MeshDesc *D = &descs[mesh];
+  if (!D->general || status_of(D) != ST_OK) return;
+  const MeshLayout &L = layouts[mesh];
+  Rd r(arena + L.stream, L.stream_len, D->end_pos);       // k_locate parked the reader behind the header
+  (void)gen::decode_mesh(arena, L, D, r);
+}
+
+}  // namespace dsa

@@ -426,6 +426,12 @@ __global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayou
     REQUIRE(r.ok, 104);
   }
   REQUIRE(D->encoder_type <= 1, 105);
+  if (L.gen_bytes != 0) {               // the host sized this mesh for the general path (dsa_general.h): k_general parses the rest
+    REQUIRE(D->encoder_type == 1 && D->encoder_method == 1, 107);
+    D->general = 1;
+    D->end_pos = r.pos;
+    return;
+  }
   const bool point_cloud = D->encoder_type == 0;
   uint32_t nad = 0;
   if (point_cloud) {
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
   if (mesh >= n) return;
   const MeshLayout &L = layouts[mesh];
   MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK || D->encoder_type == 0) return;   // point clouds have no connectivity
+  if (D->status != ST_OK || D->encoder_type == 0 || D->general) return;   // point clouds have no connectivity; general meshes: k_general
   const uint8_t *s = arena + L.stream;
   uint32_t *frec = (uint32_t *)(arena + L.frec);
   uint2 *vrec = (uint2 *)(arena + L.vrec);
@@ -1122,7 +1128,7 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
   if (mesh >= n) return;
   const MeshLayout &L = layouts[mesh];
   MeshDesc *D = &descs[mesh];
-  if (status_of(D) != ST_OK || D->encoder_type == 0 || d >= D->num_att_data) return;
+  if (status_of(D) != ST_OK || D->encoder_type == 0 || D->general || d >= D->num_att_data) return;
   const uint8_t *s = arena + L.stream;
   const uint32_t edges = D->interior_corners / 2;   // one seam bit per interior edge and attribute data
   Rabs rb;
@@ -1206,7 +1212,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   if (mesh >= n) return;
   const MeshLayout &L = layouts[mesh];
   MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK || D->encoder_type == 0) return;   // point clouds have no connectivity
+  if (D->status != ST_OK || D->encoder_type == 0 || D->general) return;   // point clouds have no connectivity; general meshes: k_general
   const uint32_t *frec = (const uint32_t *)(arena + L.frec);
   uint32_t *d2c = (uint32_t *)(arena + L.d2c);
   int32_t *v2d = (int32_t *)(arena + L.v2d);
@@ -1473,7 +1479,7 @@ __global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const Mes
   uint32_t mesh = blockIdx.y;
   if (mesh >= n) return;
   const MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK || D->encoder_type == 0) return;   // point clouds have no connectivity
+  if (D->status != ST_OK || D->encoder_type == 0 || D->general) return;   // point clouds have no connectivity; general meshes: k_general
   const MeshLayout &L = layouts[mesh];
   const uint32_t *frec = (const uint32_t *)(arena + L.frec);
   const uint32_t *d2c = (const uint32_t *)(arena + L.d2c);
@@ -1622,7 +1628,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
   uint32_t mesh = blockIdx.x, ai = blockIdx.y;
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK || ai >= D->num_attributes) return;
+  if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
   const MeshLayout &L = layouts[mesh];
   const AttrDesc &a = D->att[ai];
   if (a.source != SRC_RAW || a.precision_bits != 12 || a.num_symbols > REG_MAX_SYMS || a.num_symbols <= 64) return;
@@ -1780,7 +1786,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayo
   uint32_t mesh = blockIdx.x, ai = blockIdx.y;
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK || ai >= D->num_attributes) return;
+  if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
   const MeshLayout &L = layouts[mesh];
   const AttrDesc &a = D->att[ai];
   if (a.source == SRC_BYTES) return;
@@ -1906,7 +1912,7 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
   uint32_t mesh = blockIdx.x, ai = blockIdx.y;
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK || ai >= D->num_attributes) return;
+  if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
   const AttrDesc &a = D->att[ai];
   if (!a.have_scheme || a.source == SRC_BYTES) return;
   const MeshLayout &L = layouts[mesh];
@@ -2172,7 +2178,7 @@ __global__ __launch_bounds__(256) void k_point_maps(uint8_t *arena, const MeshLa
   uint32_t mesh = blockIdx.y;
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK) return;
+  if (D->status != ST_OK || D->general) return;   // k_general writes faces and maps of its meshes
   const MeshLayout &L = layouts[mesh];
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   const uint4 *frec = (const uint4 *)(arena + L.frec);

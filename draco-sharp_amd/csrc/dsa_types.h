@@ -70,11 +70,69 @@ struct MeshDesc {
   uint32_t num_all_vertices;   // corner-table vertices incl. isolated ones
   uint32_t num_points;
   uint32_t num_entries;    // traversal length
+  uint32_t general;        // decoded by k_general (dsa_general.h); the fast kernels skip the mesh
   uint32_t interior_corners;   // 2 x opposite links made by k_connectivity; one seam bit per link and attribute data
   uint32_t linked_corners;     // corners that hold an opposite, counted by k_point_maps (k_seal compares the two)
   uint32_t dbg[12];        // shader-clock deltas between phases of the per-mesh kernels (diagnostics)
   AttrDesc att[DSA_MAX_ATT];
 };
+
+// Scratch of the general path inside MeshLayout::gen (byte offsets from it).  The same function sizes the
+// region on the host and places the arrays in k_general.  F faces, V = cap_vertices, S split events, A attribute
+// data, len = stream bytes.  Arrays that the fast kernels own (frec, vrec, vvis, ...) are reused as well; see
+// dsa_general.h.
+struct GenLayout {
+  uint64_t stack;      // u32[F]      active corner stack of the Edgebreaker machine
+  uint64_t splits;     // u32[3S]     topology split events (source, split, edge)
+  uint64_t active;     // u32[2S]     active split corners (decoder symbol id, corner)
+  uint64_t fvis;       // u8[F]       traversal: face visited
+  uint64_t vvis;       // u8[NVmax]   traversal: vertex visited
+  uint64_t dfs;        // u32[F+1]    traversal stack
+  uint64_t cum;        // u32[cum_entries] cumulative frequencies of the stream being decoded
+  uint64_t cum_entries;
+  uint64_t data;       // first per-attribute-data block
+  uint64_t data_stride;
+  // inside a per-attribute-data block
+  uint64_t edge_seam;  // u8[3F]
+  uint64_t vert_seam;  // u8[V]
+  uint64_t c2v;        // u32[3F]     attribute vertex per corner
+  uint64_t v2lm;       // u32[3F]     left-most corner per attribute vertex
+  uint64_t d2c;        // u32[NVmax]  entry -> corner
+  uint64_t v2d;        // i32[NVmax]  attribute vertex -> entry
+  uint64_t pids;       // u32[NVmax]  entry -> point
+  uint64_t orient;     // u8[NVmax]   TexCoordsPortable orientations
+  uint64_t total;
+};
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline GenLayout gen_layout(uint64_t F, uint64_t V, uint64_t S, uint64_t A, uint64_t len) {
+  GenLayout g;
+  const uint64_t C = 3 * F, NV = C > V ? C : V;
+  uint64_t cur = 0;
+  auto take = [&](uint64_t bytes) { uint64_t at = cur; cur = (cur + bytes + 15) & ~15ull; return at; };
+  g.stack = take(4 * F);
+  g.splits = take(12 * S);
+  g.active = take(8 * S);
+  g.fvis = take(F);
+  g.vvis = take(NV);
+  g.dfs = take(4 * (F + 1));
+  g.cum_entries = (len * 64 < (1ull << 20) ? len * 64 : (1ull << 20)) + 2;
+  g.cum = take(4 * g.cum_entries);
+  g.data = cur;
+  cur = 0;
+  g.edge_seam = take(C);
+  g.vert_seam = take(V);
+  g.c2v = take(4 * C);
+  g.v2lm = take(4 * C);
+  g.d2c = take(4 * NV);
+  g.v2d = take(4 * NV);
+  g.pids = take(4 * NV);
+  g.orient = take(NV);
+  g.data_stride = cur;
+  g.total = g.data + A * g.data_stride;
+  return g;
+}
 
 // Batch-wide device state.
 struct BatchGlobals {
@@ -109,4 +167,10 @@ struct MeshLayout {
   uint64_t map[DSA_MAX_ATT];    // u32[cap_vertices] point -> entry
   uint32_t work_cap[DSA_MAX_ATT];  // capacity in int32 elements
   uint32_t out_cap[DSA_MAX_ATT];   // capacity in bytes
+  // General path (valence traversal, attribute seams, corner attributes; dsa_general.h): scratch region and the
+  // capacities that differ from the vertex-attribute case.  gen_bytes == 0: the mesh takes the fast kernels.
+  uint64_t gen;
+  uint64_t gen_bytes;
+  uint32_t cap_points;     // u32 entries of every map[] (3F when the mesh can have seams, else cap_vertices)
+  uint32_t pad2;
 };

@@ -165,10 +165,62 @@ def test_point_cloud_sequential(ctx):
     b.close()
 
 
-def test_reference_sample_reports_not_implemented(ctx, house04_bytes):
-    # house_04 uses valence traversal + UV seams + TexCoordsPortable: SURVEY.md section 8f "next" rows.
-    b = run_batch(ctx, [house04_bytes])
-    assert b.status(0) == 2
+def test_reference_sample_house04(ctx, house04_bytes):
+    """The reference's own sample (valence traversal, 59 topology splits, UV seams, TexCoordsPortable) through the
+    C-ABI: equal to the oracle, which tests/test_oracle_golden.py pins on house_04.obj."""
+    good = synth.encode_mesh(*_small_mesh())
+    b = run_batch(ctx, [house04_bytes, good, house04_bytes])
+    ref = oracle.decode(house04_bytes)
+    for i in (0, 2):
+        assert b.status(i) == 0, (b.status(i), b.mesh_info(i).detail)
+        assert_same(b.result(i), ref, b, i)
+    assert_same(b.result(1), oracle.decode(good), b, 1)      # a fast-path mesh in the same batch
+    # and directly against the fixture's ground truth (house_04.obj), without the oracle in between:
+    # every decoded face corner must carry the quantised (position, uv) of the matching .obj corner
+    import os
+    from meshutil import face_multiset, quantize
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "house_04_expected.npz"))
+    m = b.result(0).ConnectedData
+    pos, uv = m.Attributes[0], m.Attributes[1]
+    assert (m.FacesCount, pos.UniqueEntriesCount, pos.QuantizationBits, uv.QuantizationBits) == (2588, 1775, 11, 10)
+    qv = quantize(g["v"], pos.MinValues[:3], pos.Range, pos.QuantizationBits)
+    qvt = quantize(g["vt"], uv.MinValues[:2], uv.Range, uv.QuantizationBits)
+    exp_keys = np.concatenate([qv[g["fv"].ravel()], qvt[g["fvt"].ravel()]], axis=1)
+    exp = face_multiset(np.arange(exp_keys.shape[0]).reshape(-1, 3), exp_keys)
+    got_keys = np.concatenate([pos.PortableValues[pos.PointMap], uv.PortableValues[uv.PointMap]], axis=1)
+    assert face_multiset(m.Faces, got_keys) == exp
+    b.close()
+
+
+def _small_mesh():
+    pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 9, 7, 3)
+    return pos, faces, nrm, uv
+
+
+def test_general_path_on_every_synthetic_case(ctx, monkeypatch):
+    """DSA_FORCE_GENERAL routes every Edgebreaker mesh through k_general (dsa_general.h): the serial restatement
+    must agree with the oracle on all topologies, both symbol schemes, all predictions and bit depths."""
+    monkeypatch.setenv("DSA_FORCE_GENERAL", "1")
+    streams = []
+    for kind, nx, ny in KINDS:
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 11)
+        for single in (0, 1):
+            streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(single_connectivity=single)))
+    pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 12, 9, 5)
+    for scheme in (0, 1):
+        for pred in (0, 1):
+            streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(force_scheme=scheme, pos_prediction=pred, uv_prediction=pred)))
+    for bits in (4, 16, 20):
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_bits=bits, uv_bits=min(bits, 16), normal_bits=min(bits, 12))))
+    b = run_batch(ctx, streams)
+    for i, sbytes in enumerate(streams):
+        assert b.status(i) == 0, (i, b.status(i), b.mesh_info(i).detail)
+        assert_same(b.result(i), oracle.decode(sbytes), b, i)
+        assert b.debug_array(i, 4, np.uint32, 12)[6] == 0       # no k_traverse clock: the fast kernels skipped the mesh
+    b.close()
+    monkeypatch.delenv("DSA_FORCE_GENERAL")
+    b = run_batch(ctx, streams[:2])
+    assert b.debug_array(0, 4, np.uint32, 12)[6] != 0            # and without the switch they take it
     b.close()
 
 
