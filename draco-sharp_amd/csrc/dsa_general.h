@@ -13,7 +13,7 @@
 // puts them (faces, work[] = portable values, map[], AttrDesc), so k_finalize and the C-ABI do not care which
 // path produced them.
 #pragma once
-#include "dsa_kernels.h"
+#include "dsa_common.h"
 
 namespace dsa {
 namespace gen {
@@ -856,7 +856,7 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
         a.oct_max_q = max_q;
         if (num_values == 0) continue;
         OctParams o;
-        const int q = 32 - __clz(max_q);
+        const int q = 32 - __builtin_clz((uint32_t)max_q);
         GREQ(q >= 2 && q <= 30, 165);
         const int32_t max_value = (1 << q) - 2;
         o.center = max_value / 2; o.max_q = (1 << q) - 1;
@@ -892,6 +892,7 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
 #undef GNOTIMPL
 }  // namespace gen
 
+#if defined(__HIPCC__)
 // One wave per mesh, lane 0 works.  Runs on the third stream beside the fast kernels (which skip general meshes).
 __global__ __launch_bounds__(WAVE) void k_general(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   const uint32_t mesh = blockIdx.x;
@@ -902,5 +903,7 @@ __global__ __launch_bounds__(WAVE) void k_general(uint8_t *arena, const MeshLayo
   Rd r(arena + L.stream, L.stream_len, D->end_pos);       // k_locate parked the reader behind the header
   (void)gen::decode_mesh(arena, L, D, r);
 }
+
+#endif
 
 }  // namespace dsa

@@ -1,0 +1,235 @@
+// draco-sharp_amd/csrc/dsa_host_parse.h
+// Host side of batch construction that needs no HIP: the sizing parse of one stream (fixed header, section
+// lengths, attribute descriptors) and the placement of one mesh's regions in the batch arena.  Included by
+// dsa_api.hip; tests/hostcheck includes it too, to lay out a one-mesh arena for the sanitizer build of the
+// general path.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <utility>
+#include <vector>
+
+#include "dsa_types.h"
+
+namespace {
+
+// What the host learns from the fixed part of a stream; used only to size the arena.
+struct HostAttr { uint8_t att_type, data_type, nc, seq_type; bool corner = false; };
+struct HostMesh {
+  int status = 0;   // failure of the sizing parse (the device parse decides the reported status)
+  uint32_t faces = 0, enc_vertices = 0, split_symbols = 0, splits = 0, num_att_data = 0;
+  bool general = false;   // valence traversal or corner attributes: decoded by k_general
+  std::vector<HostAttr> atts;
+};
+
+struct HRd {
+  const uint8_t *p; size_t n, pos = 0; bool ok = true;
+  HRd(const uint8_t *d, size_t len) : p(d), n(len) {}
+  uint32_t u8() { if (pos < n) return p[pos++]; ok = false; return 0; }
+  uint64_t varint() {
+    uint64_t r = 0;
+    for (int shift = 0; shift < 64; shift += 7) { uint32_t b = u8(); r |= (uint64_t)(b & 0x7F) << shift; if (!(b & 0x80)) return r; }
+    ok = false; return r;
+  }
+  void skip(uint64_t k) { if (!ok || k > n - pos) { ok = false; pos = n; } else pos += (size_t)k; }
+};
+
+static void skip_metadata_element(HRd &r, int depth) {
+  if (depth > 16) { r.ok = false; return; }
+  uint32_t ne = (uint32_t)r.varint();
+  for (uint32_t i = 0; i < ne && r.ok; ++i) { uint32_t ks = r.u8(); r.skip(ks); uint64_t vs = r.varint(); r.skip(vs); }
+  uint32_t ns = (uint32_t)r.varint();
+  for (uint32_t i = 0; i < ns && r.ok; ++i) { uint32_t ks = r.u8(); r.skip(ks); skip_metadata_element(r, depth + 1); }
+}
+
+
+// Skips one SymbolDecoding.DecodeSymbols block (Entropy/SymbolDecoding.cs:7-67).  The bit section of the tagged
+// scheme has no length field, so its tags are decoded here (sizing only; the device decodes everything again).
+static void host_skip_symbols(HRd &r, uint64_t num_values, uint32_t nc) {
+  if (num_values == 0 || !r.ok) return;
+  const uint32_t scheme = r.u8();
+  auto read_table = [&](std::vector<uint32_t> &prob) {
+    const uint64_t ns = r.varint();
+    if (!r.ok || ns > (1u << 20)) { r.ok = false; return; }
+    prob.assign((size_t)ns, 0);
+    for (uint64_t i = 0; i < ns && r.ok; ++i) {
+      const uint32_t pd = r.u8(), token = pd & 3;
+      if (token == 3) { const uint64_t off = pd >> 2; if (i + off >= ns) { r.ok = false; return; } i += off; }
+      else { uint32_t p = pd >> 2; for (uint32_t k = 0; k < token; ++k) p |= r.u8() << (8 * (k + 1) - 2); prob[(size_t)i] = p; }
+    }
+  };
+  std::vector<uint32_t> prob;
+  if (scheme == 1) {
+    const uint32_t mbl = r.u8();
+    if (mbl < 1 || mbl > 18) { r.ok = false; return; }
+    read_table(prob);
+    const uint64_t size = r.varint();
+    r.skip(size);
+  } else if (scheme == 0) {
+    read_table(prob);
+    if (!r.ok || prob.empty()) { r.ok = false; return; }
+    const uint64_t size = r.varint();
+    if (!r.ok || size < 1 || size > r.n - r.pos) { r.ok = false; return; }
+    const uint8_t *buf = r.p + r.pos;
+    r.skip(size);
+    // rANS, precision 12 (RAnsSymbolCoding.cs:10-27 for 5-bit tags)
+    std::vector<uint32_t> cum(prob.size() + 1, 0), lut(4096, 0);
+    for (size_t i = 0; i < prob.size(); ++i) {
+      cum[i + 1] = cum[i] + prob[i];
+      if (cum[i + 1] > 4096) { r.ok = false; return; }
+      for (uint32_t j = cum[i]; j < cum[i + 1]; ++j) lut[j] = (uint32_t)i;
+    }
+    if (cum.back() != 4096) { r.ok = false; return; }
+    size_t off = (size_t)size;
+    uint32_t x = buf[off - 1] >> 6, state;
+    if (x == 0) { off -= 1; state = buf[off] & 0x3F; }
+    else if (x == 1) { if (off < 2) { r.ok = false; return; } off -= 2; state = (buf[off] | (buf[off + 1] << 8)) & 0x3FFF; }
+    else if (x == 2) { if (off < 3) { r.ok = false; return; } off -= 3; state = (buf[off] | (buf[off + 1] << 8) | (buf[off + 2] << 16)) & 0x3FFFFF; }
+    else { if (off < 4) { r.ok = false; return; } off -= 4; state = (buf[off] | (buf[off + 1] << 8) | (buf[off + 2] << 16) | ((uint32_t)buf[off + 3] << 24)) & 0x3FFFFFFF; }
+    state += 16384;
+    uint64_t bits = 0;
+    for (uint64_t i = 0; i < num_values; i += nc) {
+      while (state < 16384 && off > 0) state = state * 256 + buf[--off];
+      const uint32_t rem = state & 4095u, sy = lut[rem];
+      state = (state >> 12) * prob[sy] + rem - cum[sy];
+      if (sy > 32) { r.ok = false; return; }
+      bits += (uint64_t)sy * nc;
+    }
+    r.skip((bits + 7) >> 3);
+  } else r.ok = false;
+}
+
+static uint32_t dt_len(uint32_t dt) {
+  switch (dt) { case 1: case 2: case 11: return 1; case 3: case 4: return 2; case 5: case 6: case 9: return 4; case 7: case 8: case 10: return 8; default: return 0; }
+}
+
+// Mirrors the head of k_locate (same checks, same order) up to the attribute descriptors.
+static void host_parse(const uint8_t *s, size_t len, HostMesh &m) {
+  HRd r(s, len);
+  auto bad = [&](int code) { m.status = code; };
+  if (len < 11 || memcmp(s, "DRACO", 5) != 0) return bad(ST_INVALID);
+  r.pos = 5;
+  uint32_t major = r.u8(), minor = r.u8(), type = r.u8(), method = r.u8();
+  uint32_t flags = r.u8(); flags |= r.u8() << 8;
+  if (major != 2 || minor != 2) return bad(ST_INVALID);
+  if (flags & 0x8000) {
+    uint32_t natt = (uint32_t)r.varint();
+    for (uint32_t i = 0; i < natt && r.ok; ++i) { (void)r.varint(); skip_metadata_element(r, 0); }
+    skip_metadata_element(r, 0);
+    if (!r.ok) return bad(ST_INVALID);
+  }
+  if (type > 1) return bad(ST_INVALID);
+  const bool point_cloud = type == 0;
+  if (point_cloud) {
+    if (method > 1) return bad(ST_INVALID);
+    if (method != 0) return bad(ST_NOTIMPL);                  // kd-tree point clouds
+    uint32_t np = r.u8(); np |= r.u8() << 8; np |= r.u8() << 16; np |= r.u8() << 24;
+    // element counts far beyond what the stream's bytes can carry are rejected here, so that one corrupt header
+    // cannot claim the arena of the whole batch (a real stream spends at least a fraction of a bit per element)
+    if (!r.ok || np > 0x7FFFFFFFu || np > 1024ull * len) return bad(ST_INVALID);
+    m.faces = 0; m.enc_vertices = np; m.split_symbols = 0; m.splits = 0; m.num_att_data = 0;
+  } else {
+    if (method > 1) return bad(ST_INVALID);
+    if (method == 0) return bad(ST_NOTIMPL);
+    uint32_t traversal = r.u8();
+    if (!r.ok || traversal > 2) return bad(ST_INVALID);
+    if (traversal == 1) return bad(ST_NOTIMPL);                  // predictive traversal
+    if (traversal == 2) m.general = true;
+    uint64_t nv = r.varint(), nf = r.varint();
+    if (!r.ok || nf > 0x7FFFFFFFu / 3 || nv > nf * 3 || nf > 1024ull * len) return bad(ST_INVALID);
+    uint32_t nad = r.u8();
+    uint64_t nsym = r.varint();
+    if (!r.ok || nf < nsym || nf > nsym + nsym / 3) return bad(ST_INVALID);
+    uint64_t nss = r.varint();
+    if (!r.ok || nss > nsym || nad > DSA_MAX_ATT_DATA) return bad(ST_INVALID);
+    uint64_t nsplits = r.varint();
+    if (!r.ok || nsplits > nf) return bad(ST_INVALID);
+    m.faces = (uint32_t)nf; m.enc_vertices = (uint32_t)nv; m.split_symbols = (uint32_t)nss; m.splits = (uint32_t)nsplits; m.num_att_data = nad;
+    for (uint64_t i = 0; i < 2 * nsplits && r.ok; ++i) (void)r.varint();
+    r.skip((nsplits + 7) >> 3);
+    uint64_t sz;
+    if (traversal == 0) { sz = r.varint(); r.skip(sz); }        // symbols
+    (void)r.u8(); sz = r.varint(); r.skip(sz);                  // start faces
+    for (uint32_t i = 0; i < nad; ++i) { (void)r.u8(); sz = r.varint(); r.skip(sz); }
+    if (traversal == 2) {                                       // MeshEdgeBreakerTraversalValenceDecoder.cs:22-69
+      for (int c = 0; c < 6 && r.ok; ++c) {
+        const uint64_t num = r.varint();
+        if (!r.ok || num > nf) return bad(ST_INVALID);
+        host_skip_symbols(r, num, 1);
+      }
+    }
+  }
+  uint32_t ndec = r.u8();
+  if (!r.ok || ndec > DSA_MAX_ATT) return bad(ST_INVALID);
+  bool corner_dec[DSA_MAX_ATT + 1] = {};
+  if (!point_cloud) for (uint32_t i = 0; i < ndec; ++i) {
+    (void)r.u8();
+    corner_dec[i] = r.u8() != 0;                                // MeshAttributeElementType: corner attribute
+    (void)r.u8();
+    if (corner_dec[i]) m.general = true;
+  }
+  const bool force_general = getenv("DSA_FORCE_GENERAL") != nullptr;   // tests: every Edgebreaker mesh through k_general
+  if (force_general && !point_cloud) m.general = true;
+  for (uint32_t i = 0; i < ndec; ++i) {
+    uint64_t k = r.varint();
+    if (!r.ok || m.atts.size() + k > DSA_MAX_ATT) return bad(ST_INVALID);
+    size_t first = m.atts.size();
+    for (uint64_t j = 0; j < k; ++j) {
+      HostAttr a;
+      a.att_type = (uint8_t)r.u8(); a.data_type = (uint8_t)r.u8(); a.nc = (uint8_t)r.u8(); (void)r.u8();
+      (void)r.varint();
+      a.seq_type = 0;
+      a.corner = corner_dec[i];
+      m.atts.push_back(a);
+    }
+    for (uint64_t j = 0; j < k; ++j) m.atts[first + j].seq_type = (uint8_t)r.u8();
+  }
+  if (!r.ok) return bad(ST_INVALID);
+  for (auto &a : m.atts) if (a.nc == 0 || dt_len(a.data_type) == 0 || a.seq_type > 3) return bad(ST_INVALID);
+}
+
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+// Places the regions of one mesh behind `cur` (arena offset) and returns the new end.  `slack` bytes are left
+// after every region (the kernels over-read whole 16-byte words; the host check passes a larger red zone).
+static inline uint64_t layout_mesh(const HostMesh &h, uint64_t stream_len, MeshLayout &L, uint64_t cur, uint64_t slack,
+                                   std::vector<std::pair<uint64_t, uint64_t>> *regions = nullptr) {
+  const uint64_t F = h.faces, V = (uint64_t)h.enc_vertices + h.split_symbols;
+  L.cap_faces = (uint32_t)F;
+  L.cap_vertices = (uint32_t)V;
+  L.cap_attributes = (uint32_t)h.atts.size();
+  L.cap_splits = h.splits;
+  auto take = [&](uint64_t bytes) { uint64_t at = cur; cur = align_up(cur + bytes + slack, 256); if (regions) regions->push_back({at, bytes}); return at; };
+  L.frec = take(32 * F);
+  L.vrec = take(8 * V);
+  L.d2c = take(4 * V); L.v2d = take(4 * V);
+  L.fvis = take(F); L.vvis = take(V);
+  L.fstamp = take(4 * F); L.vstamp = take(4 * V);
+  L.splits = take(16ull * h.splits);
+  L.vrank = take(4 * V); L.para = take(12 * V);
+  L.faces = take(12 * F);
+  // general path: corner attributes carry up to 3F entries, and seams up to 3F points
+  const uint64_t P = (h.general && h.num_att_data > 0) ? std::max<uint64_t>(3 * F, V) : V;
+  L.cap_points = (uint32_t)P;
+  if (h.general) {
+    const GenLayout g = gen_layout(F, V, h.splits, h.num_att_data, stream_len);
+    L.gen = take(g.total);
+    L.gen_bytes = g.total;
+  }
+  for (size_t a = 0; a < h.atts.size(); ++a) {
+    const HostAttr &A = h.atts[a];
+    uint64_t ncp = A.seq_type == 3 ? 2 : A.nc;
+    const uint64_t E = A.corner ? std::max<uint64_t>(3 * F, V) : V;   // entry capacity
+    uint64_t wcap = E * ncp, ocap = E * A.nc * dt_len(A.data_type);
+    if (ocap < V) ocap = V;                  // tag bytes of the tagged scheme are staged here
+    L.work[a] = take(4 * wcap); L.work_cap[a] = (uint32_t)wcap;
+    L.out[a] = take(ocap); L.out_cap[a] = (uint32_t)(ocap > 0xFFFFFFFFu ? 0xFFFFFFFFu : ocap);
+    L.map[a] = take(4 * P);
+  }
+  return cur;
+}
+
+}  // namespace

@@ -26,32 +26,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "dsa_types.h"
+#include "dsa_common.h"
 
 namespace dsa {
-
-#define WAVE 64
-
-// ------------------------------------------------------------------ helpers
-__device__ __forceinline__ void fail(MeshDesc *d, int code, int site) {
-  if (atomicCAS(&d->status, ST_OK, code) == ST_OK) d->detail = site;
-}
-// REQUIRE/NOTIMPL latch the first failure of a mesh and leave the current function with RET.
-#define RET
-#define REQUIRE(cond, site)                  \
-  do {                                       \
-    if (!(cond)) {                           \
-      fail(D, ST_INVALID, (site));           \
-      return RET;                            \
-    }                                        \
-  } while (0)
-#define NOTIMPL(site)                        \
-  do {                                       \
-    fail(D, ST_NOTIMPL, (site));             \
-    return RET;                              \
-  } while (0)
-// status as seen through L2 (a plain load may hit a stale L1 line after an atomic by this CU)
-__device__ __forceinline__ int status_of(MeshDesc *d) { return __hip_atomic_load(&d->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ uint32_t cnext(uint32_t c) { return (c % 3u == 2u) ? c - 2u : c + 1u; }
 __device__ __forceinline__ uint32_t cprev(uint32_t c) { return (c % 3u == 0u) ? c + 2u : c - 1u; }
@@ -65,149 +42,6 @@ __device__ __forceinline__ uint32_t leading_lanes(bool pred) { uint64_t m = ~__b
 // load consumed at a loop merge point makes the compiler drain every outstanding store each iteration;
 // rare loads are therefore completed inside their own branch with this.
 #define WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
-
-// Bounds-checked little-endian byte reader over one compressed stream
-// (DecoderBuffer.cs:26-120).  A failed read latches ok=false and returns 0.
-struct Rd {
-  const uint8_t *p;
-  uint32_t n, pos;
-  bool ok;
-  __device__ Rd(const uint8_t *d, uint32_t len, uint32_t at) : p(d), n(len), pos(at), ok(at <= len) {}
-  __device__ uint32_t u8() {
-    if (pos < n) return p[pos++];
-    ok = false;
-    return 0;
-  }
-  __device__ uint32_t u16() { uint32_t a = u8(); return a | (u8() << 8); }
-  __device__ uint32_t u32() { uint32_t a = u8(); a |= u8() << 8; a |= u8() << 16; return a | (u8() << 24); }
-  __device__ float f32() { return __uint_as_float(u32()); }
-  __device__ uint64_t varint() {
-    uint64_t r = 0;
-    for (int shift = 0; shift < 64; shift += 7) {
-      uint32_t b = u8();
-      r |= (uint64_t)(b & 0x7F) << shift;
-      if (!(b & 0x80)) return r;
-    }
-    ok = false;
-    return r;
-  }
-  __device__ void skip(uint64_t k) {
-    if (!ok || k > (uint64_t)(n - pos)) { ok = false; pos = n; }
-    else pos += (uint32_t)k;
-  }
-};
-
-// Up to 32 bits at an arbitrary bit position of an LSB-first bit section
-// (DecoderBuffer.cs:138-154); bytes past `n` read as 0.
-__device__ __forceinline__ uint32_t read_bits(const uint8_t *p, uint32_t n, uint64_t bitpos, uint32_t count) {
-  uint32_t byte = (uint32_t)(bitpos >> 3), sh = (uint32_t)(bitpos & 7);
-  uint64_t w = 0;
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    uint32_t b = (byte + k < n) ? p[byte + k] : 0u;
-    w |= (uint64_t)b << (8 * k);
-  }
-  w >>= sh;
-  return count >= 32 ? (uint32_t)w : ((uint32_t)w & ((1u << count) - 1u));
-}
-
-// rABS binary decoder (Entropy/AnsDecoder.cs:12-56, BitCoders/RAnsBitDecoder.cs:12-24)
-struct Rabs {
-  const uint8_t *buf;
-  uint32_t off, state, p;   // p = 256 - prob_zero
-  bool ok;
-  __device__ void start(const uint8_t *s, uint32_t slen, uint32_t at, uint32_t *end_pos) {
-    Rd r(s, slen, at);
-    uint32_t prob_zero = r.u8();
-    uint64_t size = r.varint();
-    uint32_t begin = r.pos;
-    r.skip(size);
-    ok = r.ok && size >= 1;
-    *end_pos = r.pos;
-    p = 256u - prob_zero;
-    buf = s + begin;
-    off = 0; state = 4096;
-    if (!ok) return;
-    uint32_t o = (uint32_t)size;
-    uint32_t x = buf[o - 1] >> 6;
-    if (x == 0) { off = o - 1; state = buf[o - 1] & 0x3F; }
-    else if (x == 1) { if (o < 2) { ok = false; return; } off = o - 2; state = ((uint32_t)buf[o - 2] | ((uint32_t)buf[o - 1] << 8)) & 0x3FFF; }
-    else if (x == 2) { if (o < 3) { ok = false; return; } off = o - 3; state = ((uint32_t)buf[o - 3] | ((uint32_t)buf[o - 2] << 8) | ((uint32_t)buf[o - 1] << 16)) & 0x3FFFFF; }
-    else { ok = false; return; }
-    state += 4096;
-    if (state >= 4096u * 256u) ok = false;
-  }
-  __device__ uint32_t next() {
-    if (state < 4096 && off > 0) state = state * 256 + buf[--off];
-    uint32_t x = state, quot = x >> 8, rem = x & 255, xn = quot * p;
-    bool val = rem < p;
-    state = val ? xn + rem : x - xn - p;
-    return val ? 1u : 0u;
-  }
-};
-
-// rANS stream tail -> initial state (Entropy/RAnsDecoder.cs:20-54)
-__device__ __forceinline__ bool rans_init(const uint8_t *buf, uint32_t size, uint32_t l_base, uint32_t *state, uint32_t *off) {
-  if (size < 1) return false;
-  uint32_t x = buf[size - 1] >> 6, st, o;
-  if (x == 0) { o = size - 1; st = buf[size - 1] & 0x3F; }
-  else if (x == 1) { if (size < 2) return false; o = size - 2; st = ((uint32_t)buf[size - 2] | ((uint32_t)buf[size - 1] << 8)) & 0x3FFF; }
-  else if (x == 2) { if (size < 3) return false; o = size - 3; st = ((uint32_t)buf[size - 3] | ((uint32_t)buf[size - 2] << 8) | ((uint32_t)buf[size - 1] << 16)) & 0x3FFFFF; }
-  else { if (size < 4) return false; o = size - 4; st = ((uint32_t)buf[size - 4] | ((uint32_t)buf[size - 3] << 8) | ((uint32_t)buf[size - 2] << 16) | ((uint32_t)buf[size - 1] << 24)) & 0x3FFFFFFF; }
-  st += l_base;
-  if (st >= l_base * 256u) return false;
-  *state = st; *off = o;
-  return true;
-}
-
-// Reads the probability table of an rANS symbol stream into prob[0..n) (lane 0)
-// (Entropy/RAnsSymbolDecoder.cs:21-48).  Returns false on malformed input.
-__device__ bool read_prob_table(Rd &r, uint32_t n, uint32_t *prob) {
-  for (uint32_t i = 0; i < n; ++i) {
-    uint32_t pd = r.u8();
-    uint32_t token = pd & 3;
-    if (token == 3) {
-      uint32_t offset = pd >> 2;
-      if (i + offset >= n) return false;
-      for (uint32_t j = 0; j <= offset; ++j) prob[i + j] = 0;
-      i += offset;
-    } else {
-      uint32_t pr = pd >> 2;
-      for (uint32_t k = 0; k < token; ++k) pr |= r.u8() << (8 * (k + 1) - 2);
-      prob[i] = pr;
-    }
-  }
-  return r.ok;
-}
-// Same walk without storing (k_locate only needs to know where the table ends).
-__device__ bool skip_prob_table(Rd &r, uint32_t n) {
-  for (uint32_t i = 0; i < n; ++i) {
-    uint32_t pd = r.u8();
-    uint32_t token = pd & 3;
-    if (token == 3) {
-      uint32_t offset = pd >> 2;
-      if (i + offset >= n) return false;
-      i += offset;
-    } else {
-      r.skip(token);
-    }
-  }
-  return r.ok;
-}
-__device__ __forceinline__ uint32_t rans_precision_bits(uint32_t max_bit_length) {   // Entropy/RAnsSymbolCoding.cs:10-27
-  uint32_t p = (3 * max_bit_length) / 2;
-  return p < 12 ? 12 : (p > 20 ? 20 : p);
-}
-
-__device__ __forceinline__ uint32_t data_type_length(uint32_t dt) {   // Constants.cs:134-150
-  switch (dt) {
-    case 1: case 2: case 11: return 1;
-    case 3: case 4: return 2;
-    case 5: case 6: case 9: return 4;
-    case 7: case 8: case 10: return 8;
-    default: return 0;
-  }
-}
 
 // Wave-wide exclusive prefix sum of one value per lane; total in *total.
 // Cross-lane moves on the DPP path (no LDS crossbar round trip as with ds_bpermute / __shfl_up).
@@ -1844,56 +1678,6 @@ __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayo
 // =========================================================================
 // k_predict: inverse prediction, in place on the work buffer.
 // =========================================================================
-struct OctParams { int32_t max_q, center; };
-
-__device__ __forceinline__ void oct_invert_diamond(int32_t center, int32_t &s, int32_t &t) {   // OctahedronToolBox.cs:152-196
-  int32_t ss, st;
-  if (s >= 0 && t >= 0) { ss = 1; st = 1; }
-  else if (s <= 0 && t <= 0) { ss = -1; st = -1; }
-  else { ss = s > 0 ? 1 : -1; st = t > 0 ? 1 : -1; }
-  int32_t cs = ss * center, ct = st * center;
-  int32_t us = s + s - cs, ut = t + t - ct, tmp = us;
-  if (ss * st >= 0) { us = -ut; ut = -tmp; } else { us = ut; ut = tmp; }
-  us += cs; ut += ct;
-  s = us / 2; t = ut / 2;
-}
-__device__ __forceinline__ int32_t oct_mod_max(const OctParams &o, int32_t x) {   // OctahedronToolBox.cs:206-213
-  if (x > o.center) return x - o.max_q;
-  return x < -o.center ? x + o.max_q : x;
-}
-__device__ __forceinline__ void oct_rotate(int32_t &x, int32_t &y, int rot) {
-  int32_t a = x, b = y;
-  if (rot == 1) { x = b; y = -a; } else if (rot == 2) { x = -a; y = -b; } else if (rot == 3) { x = -b; y = a; }
-}
-// PredictionSchemeNormalOctahedron(Canonicalized)DecodingTransform.ComputeOriginalValue
-__device__ __forceinline__ void oct_original(const OctParams &o, bool canonical, int32_t ps, int32_t pt, int32_t c0, int32_t c1,
-                                             int32_t &os, int32_t &ot) {
-  ps -= o.center; pt -= o.center;
-  int32_t aps = ps < 0 ? -ps : ps, apt = pt < 0 ? -pt : pt;
-  bool in_d = (uint32_t)aps + (uint32_t)apt <= (uint32_t)o.center;
-  if (!in_d) oct_invert_diamond(o.center, ps, pt);
-  bool bottom_left = true;
-  int rot = 0;
-  if (canonical) {
-    bottom_left = (ps == 0 && pt == 0) || (ps < 0 && pt <= 0);
-    if (ps == 0) rot = pt == 0 ? 0 : (pt > 0 ? 3 : 1);
-    else if (ps > 0) rot = pt >= 0 ? 2 : 1;
-    else rot = pt <= 0 ? 0 : 3;
-    if (!bottom_left) oct_rotate(ps, pt, rot);
-  }
-  os = oct_mod_max(o, (int32_t)((uint32_t)ps + (uint32_t)c0));
-  ot = oct_mod_max(o, (int32_t)((uint32_t)pt + (uint32_t)c1));
-  if (canonical && !bottom_left) oct_rotate(os, ot, (4 - rot) % 4);
-  if (!in_d) oct_invert_diamond(o.center, os, ot);
-  os += o.center; ot += o.center;
-}
-__device__ __forceinline__ int32_t wrap_original(int32_t pred, int32_t corr, int32_t mn, int32_t mx, int32_t max_dif) {
-  int32_t p = pred > mx ? mx : (pred < mn ? mn : pred);       // PredictionSchemeWrapTransform.cs:67-86
-  int32_t o = (int32_t)((uint32_t)p + (uint32_t)corr);       // PredictionSchemeWrapDecodingTransform.cs:46-67
-  if (o > mx) o -= max_dif; else if (o < mn) o += max_dif;
-  return o;
-}
-
 // Wrap-transform schemes (Difference / Parallelogram + Wrap) are decoded 64 entries per step:
 //   * lane i owns entry p0+i.  Lane 0's prediction only uses finished entries and is computed with the
 //     reference's exact formula.  Lane i >= 1 joins the run if its prediction is "previous entry +

@@ -1,0 +1,89 @@
+"""The product's serial general path (draco-sharp_amd/csrc/dsa_general.h) compiled for the host under
+AddressSanitizer + UBSan (tests/hostcheck/general_host.cpp): the same source the GPU runs must reproduce the
+oracle on the reference's house_04 sample and on synthetic meshes, and must survive corrupt streams without a
+single out-of-bounds access.  This is a check of the product source on CPU, not a CPU decode path of the product."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+import draco_sharp_amd.synth as synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "hostcheck", "general_host.cpp")
+EXE = os.path.join(HERE, "hostcheck", "general_host")
+CSRC = os.path.join(HERE, "..", "draco-sharp_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("dsa_general.h", "dsa_common.h", "dsa_host_parse.h", "dsa_types.h")]
+    if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize=signed-integer-overflow",
+                        "-fno-sanitize-recover=undefined", "-o", EXE, SRC], check=True)
+    return EXE
+
+
+def host_decode(exe, data, tmp_path, force):
+    src, out = tmp_path / "in.drc", tmp_path / "out.bin"
+    src.write_bytes(data)
+    r = subprocess.run([exe, "decode", str(src), str(out)] + (["force"] if force else []), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = out.read_bytes()
+    status, detail = struct.unpack_from("<ii", raw, 0)
+    if status != 0:
+        return status, detail, None
+    nf, npnt, natt = struct.unpack_from("<III", raw, 8)
+    off = 20
+    faces = np.frombuffer(raw, np.int32, 3 * nf, off).reshape(nf, 3); off += 12 * nf
+    atts = []
+    for _ in range(natt):
+        entries, ncp = struct.unpack_from("<II", raw, off); off += 8
+        pmap = np.frombuffer(raw, np.uint32, npnt, off); off += 4 * npnt
+        portable = np.frombuffer(raw, np.int32, entries * ncp, off).reshape(entries, ncp) if ncp else None; off += 4 * entries * ncp
+        atts.append((entries, pmap, portable))
+    return 0, 0, (faces, npnt, atts)
+
+
+def assert_equals_oracle(got, ref):
+    faces, npnt, atts = got
+    assert np.array_equal(faces, ref.faces) and npnt == ref.num_points and len(atts) == len(ref.attributes)
+    for (entries, pmap, portable), r in zip(atts, ref.attributes):
+        assert entries == r.num_entries and np.array_equal(pmap, r.point_map)
+        if r.portable is not None:
+            assert np.array_equal(portable, r.portable)
+
+
+def test_house04_through_the_general_path_source(exe, house04_bytes, tmp_path):
+    status, detail, got = host_decode(exe, house04_bytes, tmp_path, force=False)
+    assert status == 0, detail
+    assert_equals_oracle(got, oracle.decode(house04_bytes))
+
+
+@pytest.mark.parametrize("kind,nx,ny,opts", [
+    (synth.TORUS, 10, 8, {}), (synth.HOLES, 14, 12, {"single_connectivity": 1}), (synth.SPHERE, 8, 7, {"force_scheme": 0}),
+    (synth.TWO_PARTS, 9, 6, {"pos_prediction": 0, "uv_prediction": 0}), (synth.GRID, 40, 33, {"force_scheme": 1})])
+def test_synthetic_meshes_through_the_general_path_source(exe, tmp_path, kind, nx, ny, opts):
+    pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 7)
+    data = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(**opts))
+    status, detail, got = host_decode(exe, data, tmp_path, force=True)
+    assert status == 0, detail
+    assert_equals_oracle(got, oracle.decode(data))
+
+
+def test_corrupt_streams_never_leave_their_regions(exe, house04_bytes, tmp_path):
+    """Bit flips, random bytes, truncations and bursts: every gap between arena regions is poisoned, so any
+    out-of-bounds access of the general path aborts the run."""
+    pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 10, 8, 3)
+    cases = [(house04_bytes, 3000, False), (synth.encode_mesh(pos, faces, nrm, uv), 1500, True),
+             (synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(force_scheme=0, single_connectivity=1)), 1500, True)]
+    for k, (data, iters, force) in enumerate(cases):
+        src = tmp_path / ("fuzz%d.drc" % k)
+        src.write_bytes(data)
+        r = subprocess.run([exe, "fuzz", str(src), str(iters), str(17 + k)] + (["force"] if force else []), capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        counts = dict(zip(r.stdout.split()[::2], map(int, r.stdout.split()[1::2])))
+        assert counts["ok"] + counts["invalid"] + counts["notimpl"] + counts["notgeneral"] == iters and counts["invalid"] > 0
