@@ -165,6 +165,57 @@ def test_point_cloud_sequential(ctx):
     b.close()
 
 
+def _corruptions(data, count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        m = bytearray(data)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 5))):
+                m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 9))):
+                m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+        elif kind == 2:
+            m = m[: int(rng.integers(11, len(m)))]
+        else:
+            at = int(rng.integers(11, len(m)))
+            for q in range(int(rng.integers(1, 17))):
+                if at + q < len(m):
+                    m[at + q] = int(rng.integers(0, 256))
+        out.append(bytes(m))
+    return out
+
+
+def test_corrupt_streams_agree_with_the_oracle(ctx, house04_bytes):
+    """Random corruptions of a fast-path mesh and of house_04 in one batch: where the oracle decodes, the GPU
+    must decode the same; where the oracle rejects, the GPU must not report success with different data.
+    (Both sides may legitimately accept a damaged payload: then they have to agree on the result.)"""
+    pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 10, 8, 3)
+    base = synth.encode_mesh(pos, faces, nrm, uv)
+    streams = _corruptions(base, 96, 5) + _corruptions(house04_bytes, 64, 6) + [base, house04_bytes]
+    b = run_batch(ctx, streams)
+    agree_ok = agree_bad = gpu_stricter = 0
+    for i, sbytes in enumerate(streams):
+        try:
+            ref = oracle.decode(sbytes)
+        except oracle.OracleError:
+            ref = None
+        st = b.status(i)
+        if ref is not None and st == 0:
+            assert_same(b.result(i), ref)
+            agree_ok += 1
+        elif ref is None:
+            assert st != 0, (i, "GPU accepted a stream the oracle rejects")
+            agree_bad += 1
+        else:
+            gpu_stricter += 1          # e.g. the link census or a sizing bound rejects what the oracle lets through
+    assert agree_ok >= 2 and agree_bad > 0
+    assert gpu_stricter <= len(streams) // 10, (agree_ok, agree_bad, gpu_stricter)
+    b.close()
+
+
 def test_reference_sample_house04(ctx, house04_bytes):
     """The reference's own sample (valence traversal, 59 topology splits, UV seams, TexCoordsPortable) through the
     C-ABI: equal to the oracle, which tests/test_oracle_golden.py pins on house_04.obj."""
