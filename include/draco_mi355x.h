@@ -37,7 +37,7 @@ extern "C" {
 typedef enum dsa_status {
   DSA_OK = 0,
   DSA_ERR_INVALID_DATA = 1,     /* -> System.IO.InvalidDataException */
-  DSA_ERR_NOT_IMPLEMENTED = 2,  /* -> System.NotImplementedException (stream feature outside the device path) */
+  DSA_ERR_NOT_IMPLEMENTED = 2,  /* -> System.NotImplementedException (stream feature outside the device path: see INTEGRATION.md section 5) */
   DSA_ERR_INVALID_ARGUMENT = 3, /* -> System.ArgumentException */
   DSA_ERR_DEVICE = 4,           /* HIP runtime failure; see dsa_last_error */
   DSA_ERR_OUT_OF_MEMORY = 5
