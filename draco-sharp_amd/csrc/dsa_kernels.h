@@ -1538,44 +1538,60 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
     uint32_t j = 0;
     while (j < cnt) {
       if (!exhausted) {
-        // r counts the remaining positions down (cnt-1 .. 0); position j = cnt-1-r is captured by the lane
-        // whose key is r.  The 64 rows v[16:79] are one indexed window: row = bits 11:6 of the state, lane =
-        // bits 5:0.  x' = f * (x >> 12) + (rem - cum) is evaluated on the whole row (v_mad_u32_u24: both
-        // factors < 2^12) and the state's lane is read back, which keeps the scalar pipe to 8 instructions.
-        uint32_t k6, q, va, vf;
-        uint32_t r = cnt - 1 - j;
-        const uint32_t key = cnt - 1 - lane;
-        asm volatile(
-            "Lrtop%=:\n"
-            " s_cmpk_lt_u32 s21, 0x4000\n"
-            " s_cbranch_scc1 Lrren%=\n"
-            " v_cmp_eq_u32_e32 vcc, %[r], %[key]\n"
-            " s_bfe_u32 %[k6], s21, 0x60006\n"
-            " v_mov_b32_e32 %[va], s21\n"
-            " s_lshr_b32 %[q], s21, 12\n"
-            " v_cndmask_b32_e32 %[mine], %[mine], %[va], vcc\n"
-            " s_set_gpr_idx_on %[k6], gpr_idx(SRC0)\n"
-            " v_mov_b32_e32 %[va], v16\n"
-            " s_set_gpr_idx_off\n"
-            " v_lshrrev_b32_e32 %[vf], 12, %[va]\n"
-            " v_and_b32_e32 %[va], 0xfff, %[va]\n"
-            " v_mad_u32_u24 %[va], %[vf], %[q], %[va]\n"
-            " s_sub_u32 %[r], %[r], 1\n"          // also the wait state between the VALU write and v_readlane
-            " v_readlane_b32 s21, %[va], s21\n"
-            " s_cbranch_scc0 Lrtop%=\n"
-            " s_branch Lrend%=\n"
-            "Lrren%=:\n"
-            " s_sub_u32 %[rc], %[rc], 1\n"
-            " s_cbranch_scc1 Lrempty%=\n"
-            " s_lshl_b64 s[20:21], s[20:21], 8\n"
-            " s_branch Lrtop%=\n"
-            "Lrempty%=:\n"
-            " s_mov_b32 %[rc], 0\n"
-            "Lrend%=:\n"
-            : "+{s[20:21]}"(P), [rc] "+s"(rc), [r] "+s"(r), [mine] "+v"(mine), [k6] "=&s"(k6), [q] "=&s"(q), [va] "=&v"(va), [vf] "=&v"(vf)
-            : [key] "v"(key), "{v[16:47]}"(tab_lo), "{v[48:79]}"(tab_hi)
-            : "vcc", "scc");
-        j = cnt - 1 - r;                       // r wrapped to 0xFFFFFFFF when the block completed: j == cnt
+        {
+          // The 64 steps of a block are unrolled, so position J is parked in lane J with v_writelane (inline
+          // lane number) and there is no loop counter: 6 scalar + 6 vector instructions per symbol.  A step is
+          // entered by a computed jump (all steps have the same size), which is how decoding resumes at
+          // position j after the reservoir was refilled.  The last block of a stream runs all 64 steps as well:
+          // positions past the end decode whatever the state yields and are not stored.  The row arithmetic runs under the index window
+          // (its src0 operands are constants / SGPRs, which the window does not touch); s_set_gpr_idx_off is
+          // also the wait state between the VALU write and v_readlane.
+          uint32_t k6, q, va, vf;
+          uint32_t js = uni(j);
+          asm volatile(
+              " s_getpc_b64 s[22:23]\n"
+              "Lupc%=:\n"
+              " s_mul_i32 %[k6], %[j], Lus1_%=-Lus0_%=\n"
+              " s_add_u32 s22, s22, Lus0_%=-Lupc%=\n"
+              " s_addc_u32 s23, s23, 0\n"
+              " s_add_u32 s22, s22, %[k6]\n"
+              " s_addc_u32 s23, s23, 0\n"
+              " s_setpc_b64 s[22:23]\n"
+              ".irp J,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63\n"
+              "Lus\\J\\()_%=:\n"
+              " s_cmpk_lt_u32 s21, 0x4000\n"
+              " s_cbranch_scc1 Lur\\J\\()_%=\n"
+              " v_writelane_b32 %[mine], s21, \\J\n"
+              " s_bfe_u32 %[k6], s21, 0x60006\n"
+              " s_lshr_b32 %[q], s21, 12\n"
+              " s_set_gpr_idx_on %[k6], gpr_idx(SRC0)\n"
+              " v_mov_b32_e32 %[va], v16\n"
+              " v_lshrrev_b32_e32 %[vf], 12, %[va]\n"
+              " v_and_b32_e32 %[va], 0xfff, %[va]\n"
+              " v_mad_u32_u24 %[va], %[q], %[vf], %[va]\n"
+              " s_set_gpr_idx_off\n"
+              " v_readlane_b32 s21, %[va], s21\n"
+              ".endr\n"
+              " s_movk_i32 %[j], 64\n"
+              " s_branch Luend%=\n"
+              ".irp J,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63\n"
+              "Lur\\J\\()_%=:\n"
+              " s_sub_u32 %[rc], %[rc], 1\n"
+              " s_cbranch_scc1 Lue\\J\\()_%=\n"
+              " s_lshl_b64 s[20:21], s[20:21], 8\n"
+              " s_branch Lus\\J\\()_%=\n"
+              "Lue\\J\\()_%=:\n"
+              " s_movk_i32 %[j], \\J\n"
+              " s_branch Luempty%=\n"
+              ".endr\n"
+              "Luempty%=:\n"
+              " s_mov_b32 %[rc], 0\n"
+              "Luend%=:\n"
+              : "+{s[20:21]}"(P), [rc] "+s"(rc), [j] "+s"(js), [mine] "+v"(mine), [k6] "=&s"(k6), [q] "=&s"(q), [va] "=&v"(va), [vf] "=&v"(vf)
+              : "{v[16:47]}"(tab_lo), "{v[48:79]}"(tab_hi)
+              : "vcc", "scc", "s22", "s23");
+          j = js;
+        }
         if (j < cnt) {                         // the state needs a byte and the reservoir is empty
           if (off == 0) exhausted = true;      // RAnsDecoder.cs:58-61: no bytes left, the state stays as it is
           else {
