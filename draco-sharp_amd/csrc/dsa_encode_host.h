@@ -186,12 +186,38 @@ struct RansEncoder {
   }
 };
 
-static int64_t shannon_bits(const uint32_t *syms, size_t n, uint32_t max_value, int *num_unique) {
-  std::vector<int> f((size_t)max_value + 1, 0);
-  for (size_t i = 0; i < n; ++i) ++f[syms[i]];
+// Statistics of one symbol stream: everything the scheme selection and the table construction need.  The CPU coder
+// fills it from the symbol list; the GPU encoder fills it with histograms computed on the device.
+struct SymbolStats {
+  size_t n = 0;                       // symbols (entries * nc)
+  int nc = 1;
+  uint32_t max_value = 0;
+  uint64_t total_bl = 0;              // sum of the per-entry bit lengths
+  std::vector<uint64_t> tag_freq;     // [33] histogram of per-entry bit lengths
+  std::vector<uint64_t> raw_freq;     // [max_value + 1] histogram of symbol values
+};
+static void symbol_stats(const std::vector<uint32_t> &v, int nc, SymbolStats &st, std::vector<uint32_t> *bit_lengths_out = nullptr) {
+  st.n = v.size(); st.nc = nc; st.max_value = 0; st.total_bl = 0;
+  st.tag_freq.assign(33, 0);
+  std::vector<uint32_t> bl;
+  bl.reserve(v.size() / nc);
+  for (size_t i = 0; i < v.size(); i += nc) {
+    uint32_t mc = v[i];
+    for (int j = 1; j < nc; ++j) mc = std::max(mc, v[i + j]);
+    const uint32_t b = (uint32_t)(mc > 0 ? msb(mc) : 0) + 1;
+    st.max_value = std::max(st.max_value, mc);
+    bl.push_back(b);
+    st.total_bl += b;
+    ++st.tag_freq[b];
+  }
+  st.raw_freq.assign((size_t)st.max_value + 1, 0);
+  for (uint32_t x : v) ++st.raw_freq[x];
+  if (bit_lengths_out) bit_lengths_out->swap(bl);
+}
+static int64_t shannon_bits(const std::vector<uint64_t> &f, size_t n, int *num_unique) {
   double bits = 0, nd = (double)n;
   int u = 0;
-  for (size_t i = 0; i < f.size(); ++i) if (f[i] > 0) { ++u; bits += f[i] * std::log2(f[i] / nd); }
+  for (size_t i = 0; i < f.size(); ++i) if (f[i] > 0) { ++u; bits += (double)f[i] * std::log2((double)f[i] / nd); }
   *num_unique = u;
   return (int64_t)(-bits);
 }
@@ -200,41 +226,25 @@ static int64_t approx_table_bits(int max_value, int num_unique) {   // RAnsSymbo
   return 8 * (int64_t)num_unique + zero_bits;
 }
 
-// SymbolEncoding.cs:8-40 (E-2 corrected), :92-137 tagged, :139-193 raw
-static void encode_symbols(ByteWriter &w, const std::vector<uint32_t> &v, int nc, int force_scheme, int compression_level) {
-  size_t n = v.size();
-  if (n == 0) return;
-  std::vector<uint32_t> bit_lengths;
-  bit_lengths.reserve(n / nc);
-  uint32_t max_value = 0;
-  for (size_t i = 0; i < n; i += nc) {
-    uint32_t mc = v[i];
-    for (int j = 1; j < nc; ++j) mc = std::max(mc, v[i + j]);
-    int pos = mc > 0 ? msb(mc) : 0;
-    max_value = std::max(max_value, mc);
-    bit_lengths.push_back((uint32_t)pos + 1);
-  }
-  uint64_t total_bl = 0;
-  for (uint32_t b : bit_lengths) total_bl += b;
+// SymbolEncoding.cs:8-40 (E-2 corrected): scheme choice, then the coder's tables.  `head` receives the bytes that
+// precede the rANS payload: scheme byte, (raw: unique-symbols bit length), probability table.
+struct SymbolPlan {
+  int method = 1;                     // 0 tagged, 1 raw
+  RansEncoder coder;                  // tagged: over bit lengths; raw: over symbol values
+  ByteWriter head;
+};
+static void plan_symbols(const SymbolStats &st, int force_scheme, int compression_level, SymbolPlan &pl) {
   int nu_tag = 0;
-  int64_t tag_bits = shannon_bits(bit_lengths.data(), bit_lengths.size(), 32, &nu_tag);
-  int64_t tagged_total = tag_bits + approx_table_bits(nu_tag, nu_tag) + (int64_t)total_bl * nc;
+  const int64_t tag_bits = shannon_bits(st.tag_freq, st.n / st.nc, &nu_tag);
+  const int64_t tagged_total = tag_bits + approx_table_bits(nu_tag, nu_tag) + (int64_t)st.total_bl * st.nc;
   int nu_raw = 0;
-  int64_t raw_total = shannon_bits(v.data(), n, max_value, &nu_raw) + approx_table_bits((int)max_value, nu_raw);
-  int max_value_bl = msb(std::max(1u, max_value)) + 1;
-  int method = force_scheme;
-  if (method < 0) method = (tagged_total < raw_total || max_value_bl > 18) ? 0 : 1;
-  w.u8((uint8_t)method);
-  if (method == 0) {
-    std::vector<uint64_t> freq(33, 0);
-    for (uint32_t b : bit_lengths) ++freq[b];
-    RansEncoder tag;
-    tag.create(w, 5, freq);
-    tag.encode(w, bit_lengths.data(), bit_lengths.size());
-    BitWriter bw;
-    for (size_t e = 0; e < bit_lengths.size(); ++e)
-      for (int c = 0; c < nc; ++c) bw.put((int)bit_lengths[e], v[e * nc + c]);
-    w.bytes(bw.d);
+  const int64_t raw_total = shannon_bits(st.raw_freq, st.n, &nu_raw) + approx_table_bits((int)st.max_value, nu_raw);
+  const int max_value_bl = msb(std::max(1u, st.max_value)) + 1;
+  pl.method = force_scheme;
+  if (pl.method < 0) pl.method = (tagged_total < raw_total || max_value_bl > 18) ? 0 : 1;
+  pl.head.u8((uint8_t)pl.method);
+  if (pl.method == 0) {
+    pl.coder.create(pl.head, 5, st.tag_freq);
   } else {
     int usbl = (nu_raw > 0 ? msb((uint32_t)nu_raw) : 0) + 1;
     check(usbl <= 18, "more than 2^18 unique symbols");
@@ -243,12 +253,28 @@ static void encode_symbols(ByteWriter &w, const std::vector<uint32_t> &v, int nc
     else if (compression_level > 9) usbl += 2;
     else if (compression_level > 7) usbl += 1;
     usbl = std::min(std::max(1, usbl), 18);
-    w.u8((uint8_t)usbl);
-    std::vector<uint64_t> freq((size_t)max_value + 1, 0);
-    for (size_t i = 0; i < n; ++i) ++freq[v[i]];
-    RansEncoder enc;
-    enc.create(w, usbl, freq);
-    enc.encode(w, v.data(), n);
+    pl.head.u8((uint8_t)usbl);
+    pl.coder.create(pl.head, usbl, st.raw_freq);
+  }
+}
+
+// SymbolEncoding.cs:92-137 tagged, :139-193 raw -- the CPU coder
+static void encode_symbols(ByteWriter &w, const std::vector<uint32_t> &v, int nc, int force_scheme, int compression_level) {
+  if (v.empty()) return;
+  SymbolStats st;
+  std::vector<uint32_t> bit_lengths;
+  symbol_stats(v, nc, st, &bit_lengths);
+  SymbolPlan pl;
+  plan_symbols(st, force_scheme, compression_level, pl);
+  w.bytes(pl.head.d);
+  if (pl.method == 0) {
+    pl.coder.encode(w, bit_lengths.data(), bit_lengths.size());
+    BitWriter bw;
+    for (size_t e = 0; e < bit_lengths.size(); ++e)
+      for (int c = 0; c < nc; ++c) bw.put((int)bit_lengths[e], v[e * nc + c]);
+    w.bytes(bw.d);
+  } else {
+    pl.coder.encode(w, v.data(), v.size());
   }
 }
 
