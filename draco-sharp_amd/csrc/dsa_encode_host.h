@@ -730,40 +730,43 @@ static void write_attribute_transform(ByteWriter &w, const PortableAttr &a) {
   else if (a.seq_type == 3) w.u8((uint8_t)a.bits);
 }
 
-static void encode_mesh(const MeshIn &in, const Options &opt, std::vector<uint8_t> &out) {
+// Everything about a mesh that does not depend on attribute values: connectivity, traversal order, attribute list.
+struct MeshPlan {
   CornerTable ct;
-  ct.build(in.faces, in.nf, in.nv);
-  for (uint32_t v = 0; v < in.nv; ++v) check(ct.vcorner[v] != kInvalid, "isolated vertex in input mesh");
   EbResult eb;
-  EbEncoder enc(ct, eb);
+  Sequence seq;
+  std::vector<PortableAttr> atts;    // descriptors; vals / quantisation parameters are filled by whoever codes the values
+  bool single = false;
+  uint32_t num_att_data = 0;
+};
+static void plan_mesh(const MeshIn &in, const Options &opt, MeshPlan &pl) {
+  pl.ct.build(in.faces, in.nf, in.nv);
+  for (uint32_t v = 0; v < in.nv; ++v) check(pl.ct.vcorner[v] != kInvalid, "isolated vertex in input mesh");
+  EbEncoder enc(pl.ct, pl.eb);
   enc.run();
+  dfs_sequence(pl.ct, pl.eb.processed_corners, pl.seq);
+  check(pl.seq.data_to_corner.size() == in.nv, "traversal did not reach every vertex");
+  pl.atts.clear();
+  { PortableAttr a; a.att_type = 0; a.nc = a.nc_out = 3; a.seq_type = 2; a.data_type = 9; a.prediction = opt.pos_prediction; a.bits = opt.pos_bits; pl.atts.push_back(a); }
+  if (in.normals) { PortableAttr a; a.att_type = 1; a.nc_out = 3; a.nc = 2; a.seq_type = 3; a.data_type = 9; a.bits = opt.normal_bits; a.prediction = 0; pl.atts.push_back(a); }
+  if (in.uvs) { PortableAttr a; a.att_type = 3; a.nc = a.nc_out = 2; a.seq_type = 2; a.data_type = 9; a.prediction = opt.uv_prediction; a.bits = opt.uv_bits; pl.atts.push_back(a); }
+  if (in.generic) { PortableAttr a; a.att_type = 4; a.nc = a.nc_out = 1; a.seq_type = 1; a.data_type = 2; a.prediction = 1; pl.atts.push_back(a); }
+  pl.single = opt.single_connectivity != 0;
+  pl.num_att_data = pl.single ? 0 : (uint32_t)pl.atts.size() - 1;
+}
 
-  std::vector<PortableAttr> atts;
-  { PortableAttr a; a.att_type = 0; a.nc = a.nc_out = 3; a.seq_type = 2; a.data_type = 9; a.prediction = opt.pos_prediction; quantize(in.pos, in.nv, 3, opt.pos_bits, a); atts.push_back(a); }
-  if (in.normals) {
-    PortableAttr a; a.att_type = 1; a.nc_out = 3; a.nc = 2; a.seq_type = 3; a.data_type = 9; a.bits = opt.normal_bits; a.prediction = 0;
-    Octa o(opt.normal_bits);
-    a.vals.resize((size_t)in.nv * 2);
-    for (uint32_t v = 0; v < in.nv; ++v) { int s, t; o.from_float_vector(in.normals + (size_t)v * 3, s, t); a.vals[(size_t)v * 2] = s; a.vals[(size_t)v * 2 + 1] = t; }
-    atts.push_back(a);
-  }
-  if (in.uvs) { PortableAttr a; a.att_type = 3; a.nc = a.nc_out = 2; a.seq_type = 2; a.data_type = 9; a.prediction = opt.uv_prediction; quantize(in.uvs, in.nv, 2, opt.uv_bits, a); atts.push_back(a); }
-  if (in.generic) {
-    PortableAttr a; a.att_type = 4; a.nc = a.nc_out = 1; a.seq_type = 1; a.data_type = 2; a.prediction = 1;
-    a.vals.resize(in.nv);
-    for (uint32_t v = 0; v < in.nv; ++v) a.vals[v] = in.generic[v];
-    atts.push_back(a);
-  }
-  bool single = opt.single_connectivity != 0;
-  uint32_t num_att_data = single ? 0 : (uint32_t)atts.size() - 1;
-
-  ByteWriter w;
+// Header, connectivity sections and the head of the attribute section; then values and transform parameters of
+// every attribute through the two callbacks, in the order the decoder expects (ConnectivityEncoder.cs:39-56).
+template <class ValuesWriter, class TransformWriter>
+static void write_stream(ByteWriter &w, const MeshIn &in, const MeshPlan &pl, ValuesWriter &&values, TransformWriter &&transform) {
+  const CornerTable &ct = pl.ct;
+  const EbResult &eb = pl.eb;
   w.d.insert(w.d.end(), {'D', 'R', 'A', 'C', 'O'});
   w.u8(2); w.u8(2); w.u8(1); w.u8(1); w.u16(0);
   w.u8(0);   // standard Edgebreaker traversal (DracoEncoder.cs:90)
   w.varint(in.nv);
   w.varint(in.nf);
-  w.u8((uint8_t)num_att_data);
+  w.u8((uint8_t)pl.num_att_data);
   w.varint(eb.symbols.size());
   w.varint(eb.num_split_symbols);
   // split events, MeshEdgeBreakerEncoder.cs:126-148
@@ -783,7 +786,7 @@ static void encode_mesh(const MeshIn &in, const Options &opt, std::vector<uint8_
     w.varint(bw.d.size());
     w.bytes(bw.d);
     write_rabs(w, eb.start_face_bits);
-    if (num_att_data) {
+    if (pl.num_att_data) {
       // per-vertex attributes: no interior seams, one 0 bit per interior edge in decoder face order
       std::vector<uint8_t> vis(ct.nf(), 0), bits;
       for (uint32_t c : eb.processed_corners) {
@@ -795,27 +798,44 @@ static void encode_mesh(const MeshIn &in, const Options &opt, std::vector<uint8_
           bits.push_back(0);
         }
       }
-      for (uint32_t i = 0; i < num_att_data; ++i) write_rabs(w, bits);
+      for (uint32_t i = 0; i < pl.num_att_data; ++i) write_rabs(w, bits);
     }
   }
   // attribute section (ConnectivityEncoder.cs:39-56)
-  Sequence seq;
-  dfs_sequence(ct, eb.processed_corners, seq);
-  check(seq.data_to_corner.size() == in.nv, "traversal did not reach every vertex");
-  uint32_t num_encoders = single ? 1 : (uint32_t)atts.size();
+  const std::vector<PortableAttr> &atts = pl.atts;
+  uint32_t num_encoders = pl.single ? 1 : (uint32_t)atts.size();
   w.u8((uint8_t)num_encoders);
   for (uint32_t i = 0; i < num_encoders; ++i) { w.i8(i == 0 ? -1 : (int8_t)(i - 1)); w.u8(0); w.u8(0); }
   auto write_desc = [&](const PortableAttr &a, uint32_t uid) { w.u8((uint8_t)a.att_type); w.u8((uint8_t)a.data_type); w.u8((uint8_t)a.nc_out); w.u8(0); w.varint(uid); };
-  if (single) {
+  if (pl.single) {
     w.varint(atts.size());
     for (size_t i = 0; i < atts.size(); ++i) write_desc(atts[i], (uint32_t)i);
     for (auto &a : atts) w.u8((uint8_t)a.seq_type);
-    for (auto &a : atts) write_attribute_values(w, a, ct, seq, opt);
-    for (auto &a : atts) write_attribute_transform(w, a);
+    for (size_t i = 0; i < atts.size(); ++i) values(w, i);
+    for (size_t i = 0; i < atts.size(); ++i) transform(w, i);
   } else {
     for (size_t i = 0; i < atts.size(); ++i) { w.varint(1); write_desc(atts[i], (uint32_t)i); w.u8((uint8_t)atts[i].seq_type); }
-    for (auto &a : atts) { write_attribute_values(w, a, ct, seq, opt); write_attribute_transform(w, a); }
+    for (size_t i = 0; i < atts.size(); ++i) { values(w, i); transform(w, i); }
   }
+}
+
+// The CPU coder: quantisation, prediction, entropy coding all on the host.
+static void encode_mesh(const MeshIn &in, const Options &opt, std::vector<uint8_t> &out) {
+  MeshPlan pl;
+  plan_mesh(in, opt, pl);
+  for (auto &a : pl.atts) {
+    if (a.att_type == 0) quantize(in.pos, in.nv, 3, opt.pos_bits, a);
+    else if (a.att_type == 1) {
+      Octa o(opt.normal_bits);
+      a.vals.resize((size_t)in.nv * 2);
+      for (uint32_t v = 0; v < in.nv; ++v) { int s, t; o.from_float_vector(in.normals + (size_t)v * 3, s, t); a.vals[(size_t)v * 2] = s; a.vals[(size_t)v * 2 + 1] = t; }
+    } else if (a.att_type == 3) quantize(in.uvs, in.nv, 2, opt.uv_bits, a);
+    else { a.vals.resize(in.nv); for (uint32_t v = 0; v < in.nv; ++v) a.vals[v] = in.generic[v]; }
+  }
+  ByteWriter w;
+  write_stream(w, in, pl,
+               [&](ByteWriter &bw, size_t i) { write_attribute_values(bw, pl.atts[i], pl.ct, pl.seq, opt); },
+               [&](ByteWriter &bw, size_t i) { write_attribute_transform(bw, pl.atts[i]); });
   out.swap(w.d);
 }
 
