@@ -6,3 +6,4 @@ __version__ = "0.1.0"
 
 from .decoder import (Batch, Context, DataBuffer, DeviceException, Draco, DracoDecoder, DracoHeader,  # noqa: E402,F401
                       InvalidDataException, Mesh, PointAttribute, PointCloud)
+from .encoder import Config, DracoEncoder, MeshData  # noqa: E402,F401

@@ -504,3 +504,5 @@ dsa_status dsa_batch_stage_times(const dsa_batch *b, float ms[DSA_NUM_STAGES], c
 }
 
 }  // extern "C"
+
+#include "dsa_encode.h"

@@ -1,0 +1,502 @@
+// draco-sharp_amd/csrc/dsa_encode.h  (included by dsa_api.hip)
+//
+// Encode direction of the C-ABI (include/draco_mi355x.h, dsa_encode_*): the drop-in for
+//     DracoEncoder.Encode(BinaryWriter, Config, PointCloud, ...)        src/Draco/IO/DracoEncoder.cs:22-41
+// for a batch of triangle meshes with per-vertex positions / normals / texture coordinates
+// (BASELINE.json configs[4]: "batch quantize + parallelogram predict + rANS encode as HIP kernels").
+//
+// Split of the work:
+//   host  (dsa_encode_host.h)  corner table, Edgebreaker connectivity, DFS sequencing, parallelogram operand
+//                              entries; after the statistics pass: symbol scheme choice + rANS tables
+//                              (O(alphabet) per stream); final stream layout
+//   GPU   (this file)          k_enc_bounds      quantisation range per attribute   AttributeQuantizationTransform.cs:66-108
+//                              k_enc_quantize    floats -> portable ints, normals -> octahedral (s,t)   :136-177, OctahedronToolBox.cs:28-119
+//                              k_enc_gather      vertex order -> traversal order, wrap bounds           PredictionSchemeWrapTransform.cs:88-100
+//                              k_enc_corr        prediction, correction, zig-zag, symbol statistics     MeshPredictionSchemeParallelogramEncoder.cs:35-56,
+//                                                                                                       PredictionSchemeWrapEncodingTransform.cs:45-90,
+//                                                                                                       ...NormalOctahedronCanonicalizedEncodingTransform.cs:47-83
+//                              k_enc_rans        rANS coding of every stream, one lane per stream        RAnsEncoder.cs:22-30, AnsEncoder.cs:34-64, SymbolEncoding.cs:92-193
+// The result is byte-identical to the CPU coder of dsa_encode_host.h (tests/test_gpu_encode.py), hence decodes
+// bit-exactly to the quantised input.
+#pragma once
+#include <thread>
+
+#include "dsa_encode_host.h"
+
+namespace dsa {
+
+struct EncStream {                 // one per (mesh, attribute); lives in device memory, mirrored on the host
+  uint64_t src;                    // f32 source values, vertex order, nc_out per vertex
+  uint64_t e2v, ops;               // per mesh: entry -> vertex; i32[3*entries] parallelogram operand entries (next, prev, opposite) or -1
+  uint64_t vals, d, syms, bl;      // i32[nv*nc] vertex order, i32[nv*nc] traversal order, u32[nv*nc] symbols, u8[nv] bit length per entry
+  uint64_t hist_raw;               // u32[hist_cap]
+  uint64_t out_rans, out_bits;     // coded bytes
+  uint64_t prob, cum;              // u32[num_symbols] (filled by the host between the two device phases)
+  uint32_t nv, nc_out, nc, kind;   // kind 0: quantised + wrap, 1: normals (octahedral, canonicalised delta)
+  uint32_t bits, prediction, hist_cap, out_cap;
+  float qmin[4], qrange;
+  int32_t wrap_mn, wrap_mx;
+  uint32_t max_value, overflow;
+  unsigned long long total_bl;
+  uint32_t hist_tag[33];
+  uint32_t method, precision_bits, num_symbols;
+  uint32_t rans_len, bits_len;
+};
+
+__device__ __forceinline__ uint32_t enc_msb(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+__device__ __forceinline__ uint32_t enc_zigzag(int32_t v) { return v >= 0 ? (uint32_t)v << 1 : (((uint32_t)(-(v + 1))) << 1) | 1u; }
+
+// Quantisation range: per-component min / max, range = largest extent (1 if degenerate).
+__global__ __launch_bounds__(256) void k_enc_bounds(uint8_t *arena, EncStream *streams, uint32_t ns) {
+  const uint32_t si = blockIdx.x;
+  if (si >= ns) return;
+  EncStream &S = streams[si];
+  if (S.kind != 0) return;
+  __shared__ float s_mn[4][256], s_mx[4][256];
+  const float *src = (const float *)(arena + S.src);
+  const uint32_t nc = S.nc_out, tid = threadIdx.x;
+  float mn[4], mx[4];
+  for (uint32_t c = 0; c < 4; ++c) { mn[c] = src[c < nc ? c : 0]; mx[c] = mn[c]; }
+  for (uint32_t v = tid; v < S.nv; v += 256)
+    for (uint32_t c = 0; c < nc; ++c) { const float x = src[(size_t)v * nc + c]; if (x < mn[c]) mn[c] = x; if (x > mx[c]) mx[c] = x; }
+  for (uint32_t c = 0; c < 4; ++c) { s_mn[c][tid] = mn[c]; s_mx[c][tid] = mx[c]; }
+  __syncthreads();
+  for (uint32_t h = 128; h >= 1; h >>= 1) {
+    if (tid < h) for (uint32_t c = 0; c < 4; ++c) {
+      if (s_mn[c][tid + h] < s_mn[c][tid]) s_mn[c][tid] = s_mn[c][tid + h];
+      if (s_mx[c][tid + h] > s_mx[c][tid]) s_mx[c][tid] = s_mx[c][tid + h];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float range = 0.0f;
+    for (uint32_t c = 0; c < nc; ++c) { S.qmin[c] = s_mn[c][0]; const float dlt = __fsub_rn(s_mx[c][0], s_mn[c][0]); if (dlt > range) range = dlt; }
+    if (range == 0.0f) range = 1.0f;
+    S.qrange = range;
+  }
+}
+
+// OctahedronToolBox.cs:28-119 (float vector -> canonical octahedral coordinates), in double as the host coder
+__device__ void enc_oct_from_float(const float *in, int32_t bits, int32_t &s, int32_t &t) {
+  const int32_t max_q = (1 << bits) - 1, max_value = max_q - 1, center = max_value / 2;
+  const double v0 = in[0], v1 = in[1], v2 = in[2];
+  const double abs_sum = __dadd_rn(__dadd_rn(fabs(v0), fabs(v1)), fabs(v2));
+  double s0, s1, s2;
+  if (abs_sum > 1e-6) { const double sc = __ddiv_rn(1.0, abs_sum); s0 = __dmul_rn(v0, sc); s1 = __dmul_rn(v1, sc); s2 = __dmul_rn(v2, sc); }
+  else { s0 = 1; s1 = 0; s2 = 0; }
+  int32_t i0 = (int32_t)floor(__dadd_rn(__dmul_rn(s0, (double)center), 0.5));
+  int32_t i1 = (int32_t)floor(__dadd_rn(__dmul_rn(s1, (double)center), 0.5));
+  int32_t i2 = center - abs(i0) - abs(i1);
+  if (i2 < 0) { if (i1 > 0) i1 += i2; else i1 -= i2; i2 = 0; }
+  if (s2 < 0) i2 = -i2;
+  if (i0 >= 0) { s = i1 + center; t = i2 + center; }
+  else {
+    s = i1 < 0 ? abs(i2) : max_value - abs(i2);
+    t = i2 < 0 ? abs(i1) : max_value - abs(i1);
+  }
+  // canonicalize
+  if ((s == 0 && t == 0) || (s == 0 && t == max_value) || (s == max_value && t == 0)) { s = max_value; t = max_value; }
+  else if (s == 0 && t > center) t = center - (t - center);
+  else if (s == max_value && t < center) t = center + (center - t);
+  else if (t == max_value && s < center) s = center + (center - s);
+  else if (t == 0 && s > center) s = center - (s - center);
+}
+
+__global__ __launch_bounds__(256) void k_enc_quantize(uint8_t *arena, EncStream *streams, uint32_t ns) {
+  const uint32_t si = blockIdx.y;
+  if (si >= ns) return;
+  const EncStream &S = streams[si];
+  const float *src = (const float *)(arena + S.src);
+  int32_t *vals = (int32_t *)(arena + S.vals);
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  if (S.kind == 0) {                // Quantizer: floor((v - min) * (max_q / range) + 0.5), every step rounded to f32
+    const float inv_delta = __fdiv_rn((float)(int32_t)((1u << S.bits) - 1u), S.qrange);
+    const uint32_t nc = S.nc_out, total = S.nv * nc;
+    for (uint32_t i = tid; i < total; i += stride) {
+      const float v = __fsub_rn(src[i], S.qmin[i % nc]);
+      vals[i] = (int32_t)floorf(__fadd_rn(__fmul_rn(v, inv_delta), 0.5f));
+    }
+  } else {
+    for (uint32_t v = tid; v < S.nv; v += stride) {
+      int32_t s, t;
+      enc_oct_from_float(src + (size_t)v * 3, (int32_t)S.bits, s, t);
+      vals[2 * v] = s; vals[2 * v + 1] = t;
+    }
+  }
+}
+
+// traversal order + bounds of the wrap transform over all values of the attribute
+__global__ __launch_bounds__(256) void k_enc_gather(uint8_t *arena, EncStream *streams, uint32_t ns) {
+  const uint32_t si = blockIdx.x;
+  if (si >= ns) return;
+  EncStream &S = streams[si];
+  __shared__ int32_t s_mn[256], s_mx[256];
+  const int32_t *vals = (const int32_t *)(arena + S.vals);
+  int32_t *d = (int32_t *)(arena + S.d);
+  const uint32_t *e2v = (const uint32_t *)(arena + S.e2v);
+  const uint32_t nc = S.nc, tid = threadIdx.x;
+  int32_t mn = 0x7FFFFFFF, mx = (int32_t)0x80000000;
+  for (uint32_t e = tid; e < S.nv; e += 256) {
+    const uint32_t v = e2v[e];
+    for (uint32_t c = 0; c < nc; ++c) { const int32_t x = vals[(size_t)v * nc + c]; d[(size_t)e * nc + c] = x; if (x < mn) mn = x; if (x > mx) mx = x; }
+  }
+  s_mn[tid] = mn; s_mx[tid] = mx;
+  __syncthreads();
+  for (uint32_t h = 128; h >= 1; h >>= 1) {
+    if (tid < h) { if (s_mn[tid + h] < s_mn[tid]) s_mn[tid] = s_mn[tid + h]; if (s_mx[tid + h] > s_mx[tid]) s_mx[tid] = s_mx[tid + h]; }
+    __syncthreads();
+  }
+  if (tid == 0) { S.wrap_mn = s_mn[0]; S.wrap_mx = s_mx[0]; }
+}
+
+// corrections -> symbols, per-entry bit lengths, statistics
+__global__ __launch_bounds__(256) void k_enc_corr(uint8_t *arena, EncStream *streams, uint32_t ns) {
+  const uint32_t si = blockIdx.y;
+  if (si >= ns) return;
+  EncStream &S = streams[si];
+  __shared__ uint32_t s_tag[33];
+  __shared__ uint32_t s_max;
+  __shared__ unsigned long long s_bl;
+  if (threadIdx.x < 33) s_tag[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { s_max = 0; s_bl = 0; }
+  __syncthreads();
+  const int32_t *d = (const int32_t *)(arena + S.d);
+  const int32_t *ops = (const int32_t *)(arena + S.ops);
+  uint32_t *syms = (uint32_t *)(arena + S.syms);
+  uint8_t *bl = arena + S.bl;
+  uint32_t *hist = (uint32_t *)(arena + S.hist_raw);
+  const uint32_t nc = S.nc;
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  // wrap transform, PredictionSchemeWrapEncodingTransform.cs:45-90 (E-5) + WrapTransform.cs:88-100
+  const int32_t mn = S.wrap_mn, mx = S.wrap_mx, max_dif = 1 + mx - mn;
+  int32_t max_corr = max_dif / 2;
+  const int32_t min_corr = -max_corr;
+  if ((max_dif & 1) == 0) max_corr -= 1;
+  // octahedron
+  const int32_t o_max_q = (1 << S.bits) - 1, o_center = (o_max_q - 1) / 2;
+  for (uint32_t p = tid; p < S.nv; p += stride) {
+    uint32_t mc = 0;
+    if (S.kind == 0) {
+      int32_t vn = -1, vp = -1, vo = -1;
+      if (S.prediction == 1 && p > 0) { vn = ops[3 * p]; vp = ops[3 * p + 1]; vo = ops[3 * p + 2]; }
+      for (uint32_t c = 0; c < nc; ++c) {
+        int32_t pred;
+        if (vn >= 0) pred = d[(size_t)vn * nc + c] + d[(size_t)vp * nc + c] - d[(size_t)vo * nc + c];
+        else pred = p > 0 ? d[(size_t)(p - 1) * nc + c] : 0;
+        const int32_t pc = pred > mx ? mx : (pred < mn ? mn : pred);
+        int32_t cr = d[(size_t)p * nc + c] - pc;
+        if (cr < min_corr) cr += max_dif; else if (cr > max_corr) cr -= max_dif;
+        const uint32_t sy = enc_zigzag(cr);
+        syms[(size_t)p * nc + c] = sy;
+        if (sy < S.hist_cap) atomicAdd(&hist[sy], 1u); else S.overflow = 1;
+        mc = sy > mc ? sy : mc;
+      }
+    } else {                        // PredictionSchemeNormalOctahedronCanonicalizedEncodingTransform.cs:47-83
+      int32_t os = d[2 * p] - o_center, ot = d[2 * p + 1] - o_center;
+      int32_t ps = (p > 0 ? d[2 * (p - 1)] : 0) - o_center, pt = (p > 0 ? d[2 * (p - 1) + 1] : 0) - o_center;
+      const int32_t aps = ps < 0 ? -ps : ps, apt = pt < 0 ? -pt : pt;
+      if (!((uint32_t)aps + (uint32_t)apt <= (uint32_t)o_center)) { oct_invert_diamond(o_center, os, ot); oct_invert_diamond(o_center, ps, pt); }
+      const bool bottom_left = (ps == 0 && pt == 0) || (ps < 0 && pt <= 0);
+      if (!bottom_left) {
+        int rot;
+        if (ps == 0) rot = pt == 0 ? 0 : (pt > 0 ? 3 : 1);
+        else if (ps > 0) rot = pt >= 0 ? 2 : 1;
+        else rot = pt <= 0 ? 0 : 3;
+        oct_rotate(os, ot, rot); oct_rotate(ps, pt, rot);
+      }
+      int32_t c0 = os - ps, c1 = ot - pt;
+      if (c0 < 0) c0 += o_max_q;
+      if (c1 < 0) c1 += o_max_q;
+      const uint32_t sy[2] = {(uint32_t)c0, (uint32_t)c1};     // positive: no zig-zag
+      for (uint32_t c = 0; c < 2; ++c) {
+        syms[2 * p + c] = sy[c];
+        if (sy[c] < S.hist_cap) atomicAdd(&hist[sy[c]], 1u); else S.overflow = 1;
+        mc = sy[c] > mc ? sy[c] : mc;
+      }
+    }
+    const uint32_t b = (mc > 0 ? enc_msb(mc) : 0u) + 1u;
+    bl[p] = (uint8_t)b;
+    atomicAdd(&s_tag[b], 1u);
+    atomicMax(&s_max, mc);
+    atomicAdd(&s_bl, (unsigned long long)b);
+  }
+  __syncthreads();
+  if (threadIdx.x < 33 && s_tag[threadIdx.x]) atomicAdd(&S.hist_tag[threadIdx.x], s_tag[threadIdx.x]);
+  if (threadIdx.x == 0) { atomicMax(&S.max_value, s_max); atomicAdd(&S.total_bl, s_bl); }
+}
+
+// rANS coding, one lane per stream (no cross-lane traffic; the wave shares the instruction stream).
+// Symbols are fed last -> first (SymbolEncoding.cs:177-183); bytes are written in coding order, the decoder reads
+// them from the end (RAnsEncoder.cs:22-30, AnsEncoder.cs:34-64).
+__global__ __launch_bounds__(WAVE) void k_enc_rans(uint8_t *arena, EncStream *streams, uint32_t ns) {
+  const uint32_t si = blockIdx.x * WAVE + threadIdx.x;
+  if (si >= ns) return;
+  EncStream &S = streams[si];
+  if (S.overflow) return;
+  const uint32_t *prob = (const uint32_t *)(arena + S.prob), *cum = (const uint32_t *)(arena + S.cum);
+  const uint32_t *syms = (const uint32_t *)(arena + S.syms);
+  const uint8_t *bl = arena + S.bl;
+  uint8_t *out = arena + S.out_rans;
+  const uint32_t pb = S.precision_bits, precision = 1u << pb, l_base = precision * 4u;
+  const bool tagged = S.method == 0;
+  const uint32_t n = tagged ? S.nv : S.nv * S.nc;
+  uint32_t state = l_base, len = 0;
+  const uint32_t cap = S.out_cap;
+  for (uint32_t k = n; k-- > 0;) {
+    const uint32_t s = tagged ? (uint32_t)bl[k] : syms[k];
+    const uint32_t p = prob[s];
+    const uint64_t lim = (uint64_t)(l_base / precision) * 256u * p;
+    while ((uint64_t)state >= lim) { if (len < cap) out[len] = (uint8_t)(state & 0xFF); ++len; state >>= 8; }
+    state = (state / p) * precision + state % p + cum[s];
+  }
+  const uint32_t fs = state - l_base;
+  uint32_t v, nb;
+  if (fs < (1u << 6)) { v = fs; nb = 1; }
+  else if (fs < (1u << 14)) { v = 0x4000u + fs; nb = 2; }
+  else if (fs < (1u << 22)) { v = 0x800000u + fs; nb = 3; }
+  else { v = 0xC0000000u + fs; nb = 4; }
+  for (uint32_t i = 0; i < nb; ++i) { if (len < cap) out[len] = (uint8_t)((v >> (8 * i)) & 0xFF); ++len; }
+  S.rans_len = len;
+  if (len > cap || fs >= (1u << 30)) S.overflow = 1;
+  // tagged scheme: the values follow as raw LSB-first bit fields of their entry's length (SymbolEncoding.cs:117-137)
+  uint32_t blen = 0;
+  if (tagged) {
+    uint8_t *bits = arena + S.out_bits;
+    uint64_t acc = 0;
+    uint32_t nacc = 0;
+    for (uint32_t e = 0; e < S.nv; ++e) {
+      const uint32_t b = bl[e];
+      for (uint32_t c = 0; c < S.nc; ++c) {
+        const uint64_t val = (uint64_t)syms[(size_t)e * S.nc + c] & (b >= 32 ? 0xFFFFFFFFull : ((1ull << b) - 1ull));
+        acc |= val << nacc;
+        nacc += b;
+        while (nacc >= 8) { if (blen < cap) bits[blen] = (uint8_t)(acc & 0xFF); ++blen; acc >>= 8; nacc -= 8; }
+      }
+    }
+    if (nacc > 0) { if (blen < cap) bits[blen] = (uint8_t)(acc & 0xFF); ++blen; }
+    if (blen > cap) S.overflow = 1;
+  }
+  S.bits_len = blen;
+}
+
+}  // namespace dsa
+
+// ------------------------------------------------------------------------------------------------ host side
+struct dsa_encoded {
+  dsa_context *ctx = nullptr;
+  std::vector<std::vector<uint8_t>> streams;
+  std::vector<int32_t> status;
+  std::vector<std::string> messages;
+};
+
+extern "C" {
+
+void dsa_encode_default_options(dsa_encode_options *o) {
+  if (!o) return;
+  synth::Options d;
+  o->position_bits = d.pos_bits; o->texcoord_bits = d.uv_bits; o->normal_bits = d.normal_bits;
+  o->single_connectivity = d.single_connectivity; o->symbol_scheme = d.force_scheme; o->compression_level = d.compression_level;
+  o->position_prediction = d.pos_prediction; o->texcoord_prediction = d.uv_prediction;
+}
+
+dsa_status dsa_encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out) {
+  if (!ctx || !out || (n && !meshes)) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  dsa_encode_options od;
+  dsa_encode_default_options(&od);
+  if (options) od = *options;
+  if (od.position_bits < 1 || od.position_bits > 20 || od.texcoord_bits < 1 || od.texcoord_bits > 20 || od.normal_bits < 2 || od.normal_bits > 20)
+    return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "quantisation bits out of range (positions/texcoords 1..20, normals 2..20)");
+  synth::Options opt;
+  opt.pos_bits = od.position_bits; opt.uv_bits = od.texcoord_bits; opt.normal_bits = od.normal_bits;
+  opt.single_connectivity = od.single_connectivity; opt.force_scheme = od.symbol_scheme; opt.compression_level = od.compression_level;
+  opt.pos_prediction = od.position_prediction; opt.uv_prediction = od.texcoord_prediction;
+  dsa_encoded *E = new (std::nothrow) dsa_encoded();
+  if (!E) return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "host allocation failed");
+  E->ctx = ctx;
+  E->streams.resize(n); E->status.assign(n, DSA_OK); E->messages.resize(n);
+  // ---- host phase 1: connectivity, traversal order, operand entries (threads over meshes)
+  std::vector<synth::MeshPlan> plans(n);
+  std::vector<synth::MeshIn> ins(n);
+  std::vector<std::vector<uint32_t>> e2v(n);
+  std::vector<std::vector<int32_t>> ops(n);
+  auto plan_one = [&](uint32_t i) {
+    const dsa_mesh_input &m = meshes[i];
+    synth::MeshIn &in = ins[i];
+    in.pos = m.positions; in.nv = m.num_vertices; in.faces = m.faces; in.nf = m.num_faces; in.normals = m.normals; in.uvs = m.texcoords; in.generic = nullptr;
+    try {
+      synth::check(m.positions && m.faces && m.num_vertices >= 3 && m.num_faces >= 1, "mesh needs positions and faces");
+      for (size_t k = 0; k < (size_t)m.num_faces * 3; ++k) synth::check(m.faces[k] < m.num_vertices, "face index out of range");
+      synth::plan_mesh(in, opt, plans[i]);
+      const synth::MeshPlan &pl = plans[i];
+      const uint32_t V = m.num_vertices;
+      e2v[i].resize(V);
+      ops[i].assign((size_t)3 * V, -1);
+      for (uint32_t p = 0; p < V; ++p) {
+        const uint32_t ci = pl.seq.data_to_corner[p];
+        e2v[i][p] = pl.ct.vertex(ci);
+        if (p == 0) continue;
+        const uint32_t oci = pl.ct.opposite(ci);
+        if (oci == synth::kInvalid) continue;
+        const int32_t vo = pl.seq.vertex_to_data[pl.ct.vertex(oci)];
+        const int32_t vn = pl.seq.vertex_to_data[pl.ct.vertex(synth::CornerTable::next(oci))];
+        const int32_t vp = pl.seq.vertex_to_data[pl.ct.vertex(synth::CornerTable::prev(oci))];
+        if (vo < (int32_t)p && vn < (int32_t)p && vp < (int32_t)p) { ops[i][3 * p] = vn; ops[i][3 * p + 1] = vp; ops[i][3 * p + 2] = vo; }
+      }
+    } catch (const std::exception &e) { E->status[i] = DSA_ERR_INVALID_DATA; E->messages[i] = e.what(); }
+  };
+  {
+    const uint32_t nt = std::max(1u, std::min<uint32_t>(n, std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 8));
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < nt; ++t) th.emplace_back([&, t]() { for (uint32_t i = t; i < n; i += nt) plan_one(i); });
+    for (auto &x : th) x.join();
+  }
+  // ---- device layout
+  std::vector<dsa::EncStream> hs;
+  std::vector<uint32_t> first_stream(n + 1, 0);
+  uint64_t cur = 0;
+  auto take = [&](uint64_t bytes) { uint64_t at = cur; cur = (cur + bytes + 255) & ~255ull; return at; };
+  struct Upload { uint64_t off; const void *src; size_t bytes; };
+  std::vector<Upload> uploads;
+  for (uint32_t i = 0; i < n; ++i) {
+    first_stream[i] = (uint32_t)hs.size();
+    if (E->status[i] != DSA_OK) continue;
+    const uint32_t V = meshes[i].num_vertices;
+    const uint64_t o_e2v = take(4ull * V), o_ops = take(12ull * V);
+    uploads.push_back({o_e2v, e2v[i].data(), 4ull * V});
+    uploads.push_back({o_ops, ops[i].data(), 12ull * V});
+    for (auto &a : plans[i].atts) {
+      dsa::EncStream S;
+      memset(&S, 0, sizeof(S));
+      const float *src = a.att_type == 0 ? meshes[i].positions : (a.att_type == 1 ? meshes[i].normals : meshes[i].texcoords);
+      S.nv = V; S.nc_out = (uint32_t)a.nc_out; S.nc = (uint32_t)a.nc; S.kind = a.seq_type == 3 ? 1u : 0u;
+      S.bits = (uint32_t)a.bits; S.prediction = (uint32_t)a.prediction;
+      S.src = take(4ull * V * S.nc_out);
+      uploads.push_back({S.src, src, 4ull * V * S.nc_out});
+      S.e2v = o_e2v; S.ops = o_ops;
+      S.vals = take(4ull * V * S.nc); S.d = take(4ull * V * S.nc); S.syms = take(4ull * V * S.nc); S.bl = take(V);
+      S.hist_cap = (1u << S.bits) + 2u;                      // zig-zag of a wrapped correction / a positive octahedral correction fits
+      S.hist_raw = take(4ull * S.hist_cap);
+      S.out_cap = 4u * V * S.nc + 16u;
+      S.out_rans = take(S.out_cap); S.out_bits = take(S.out_cap);
+      const uint64_t table_cap = std::max<uint64_t>(S.hist_cap, 64);   // the tagged scheme's alphabet is 33 bit lengths
+      S.prob = take(4ull * table_cap); S.cum = take(4ull * table_cap);
+      hs.push_back(S);
+    }
+  }
+  first_stream[n] = (uint32_t)hs.size();
+  const uint32_t ns = (uint32_t)hs.size();
+  uint8_t *arena = nullptr;
+  dsa::EncStream *d_streams = nullptr;
+  auto cleanup = [&]() { if (arena) (void)hipFree(arena); if (d_streams) (void)hipFree(d_streams); };
+#define ENC_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); delete E; return set_err(ctx, e_ == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
+  if (ns) {
+    hipStream_t st = ctx->stream;
+    ENC_TRY(hipMalloc((void **)&arena, cur ? cur : 256));
+    ENC_TRY(hipMalloc((void **)&d_streams, sizeof(dsa::EncStream) * ns));
+    ENC_TRY(hipMemsetAsync(arena, 0, cur, st));              // histograms start at zero
+    for (auto &u : uploads) ENC_TRY(hipMemcpyAsync(arena + u.off, u.src, u.bytes, hipMemcpyHostToDevice, st));
+    ENC_TRY(hipMemcpyAsync(d_streams, hs.data(), sizeof(dsa::EncStream) * ns, hipMemcpyHostToDevice, st));
+    uint32_t maxv = 0;
+    for (auto &S : hs) maxv = std::max(maxv, S.nv);
+    const uint32_t gx = std::max(1u, std::min(64u, (maxv + 2047) / 2048));
+    // ---- device phase 1: quantise, order, correct, count
+    hipLaunchKernelGGL(dsa::k_enc_bounds, dim3(ns), dim3(256), 0, st, arena, d_streams, ns);
+    hipLaunchKernelGGL(dsa::k_enc_quantize, dim3(gx, ns), dim3(256), 0, st, arena, d_streams, ns);
+    hipLaunchKernelGGL(dsa::k_enc_gather, dim3(ns), dim3(256), 0, st, arena, d_streams, ns);
+    hipLaunchKernelGGL(dsa::k_enc_corr, dim3(gx, ns), dim3(256), 0, st, arena, d_streams, ns);
+    ENC_TRY(hipMemcpyAsync(hs.data(), d_streams, sizeof(dsa::EncStream) * ns, hipMemcpyDeviceToHost, st));
+    ENC_TRY(hipStreamSynchronize(st));
+  }
+  // ---- host phase 2: scheme choice and rANS tables from the device statistics
+  std::vector<synth::SymbolPlan> splans(ns);
+  std::vector<std::vector<uint32_t>> hists(ns);
+  for (uint32_t s = 0; s < ns; ++s) {
+    if (hs[s].overflow || hs[s].max_value >= hs[s].hist_cap) { hs[s].overflow = 1; continue; }
+    hists[s].resize((size_t)hs[s].max_value + 1);
+    ENC_TRY(hipMemcpyAsync(hists[s].data(), arena + hs[s].hist_raw, 4ull * hists[s].size(), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (ns) ENC_TRY(hipStreamSynchronize(ctx->stream));
+  std::vector<int> stream_mesh(ns, 0);
+  for (uint32_t i = 0; i < n; ++i) for (uint32_t s = first_stream[i]; s < first_stream[i + 1]; ++s) stream_mesh[s] = (int)i;
+  for (uint32_t s = 0; s < ns; ++s) {
+    const uint32_t i = (uint32_t)stream_mesh[s];
+    if (E->status[i] != DSA_OK) continue;
+    try {
+      synth::check(!hs[s].overflow, "symbol outside the histogram range");
+      synth::SymbolStats stt;
+      stt.n = (size_t)hs[s].nv * hs[s].nc; stt.nc = (int)hs[s].nc; stt.max_value = hs[s].max_value; stt.total_bl = hs[s].total_bl;
+      stt.tag_freq.assign(hs[s].hist_tag, hs[s].hist_tag + 33);
+      stt.raw_freq.assign(hists[s].begin(), hists[s].end());
+      synth::plan_symbols(stt, opt.force_scheme, opt.compression_level, splans[s]);
+      hs[s].method = (uint32_t)splans[s].method;
+      hs[s].precision_bits = (uint32_t)splans[s].coder.precision_bits;
+      hs[s].num_symbols = splans[s].coder.num_symbols;
+      synth::check(splans[s].coder.num_symbols <= std::max<uint32_t>(hs[s].hist_cap, 64), "alphabet larger than the table region");
+      ENC_TRY(hipMemcpyAsync(arena + hs[s].prob, splans[s].coder.prob.data(), 4ull * splans[s].coder.num_symbols, hipMemcpyHostToDevice, ctx->stream));
+      ENC_TRY(hipMemcpyAsync(arena + hs[s].cum, splans[s].coder.cum.data(), 4ull * splans[s].coder.num_symbols, hipMemcpyHostToDevice, ctx->stream));
+    } catch (const std::exception &e) { E->status[i] = DSA_ERR_INVALID_DATA; E->messages[i] = e.what(); hs[s].overflow = 1; }
+  }
+  // ---- device phase 2: entropy coding
+  std::vector<std::vector<uint8_t>> rans(ns), bits(ns);
+  if (ns) {
+    hipStream_t st = ctx->stream;
+    ENC_TRY(hipMemcpyAsync(d_streams, hs.data(), sizeof(dsa::EncStream) * ns, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(dsa::k_enc_rans, dim3((ns + WAVE - 1) / WAVE), dim3(WAVE), 0, st, arena, d_streams, ns);
+    ENC_TRY(hipMemcpyAsync(hs.data(), d_streams, sizeof(dsa::EncStream) * ns, hipMemcpyDeviceToHost, st));
+    ENC_TRY(hipStreamSynchronize(st));
+    for (uint32_t s = 0; s < ns; ++s) {
+      if (hs[s].overflow) continue;
+      rans[s].resize(hs[s].rans_len); bits[s].resize(hs[s].bits_len);
+      if (hs[s].rans_len) ENC_TRY(hipMemcpyAsync(rans[s].data(), arena + hs[s].out_rans, hs[s].rans_len, hipMemcpyDeviceToHost, st));
+      if (hs[s].bits_len) ENC_TRY(hipMemcpyAsync(bits[s].data(), arena + hs[s].out_bits, hs[s].bits_len, hipMemcpyDeviceToHost, st));
+    }
+    ENC_TRY(hipStreamSynchronize(st));
+  }
+#undef ENC_TRY
+  cleanup();
+  // ---- host phase 3: stream layout
+  for (uint32_t i = 0; i < n; ++i) {
+    if (E->status[i] != DSA_OK) continue;
+    bool bad = false;
+    for (uint32_t s = first_stream[i]; s < first_stream[i + 1]; ++s) bad = bad || hs[s].overflow;
+    if (bad) { E->status[i] = DSA_ERR_INVALID_DATA; E->messages[i] = "entropy coding failed"; continue; }
+    synth::ByteWriter w;
+    const uint32_t s0 = first_stream[i];
+    synth::write_stream(w, ins[i], plans[i],
+      [&](synth::ByteWriter &bw, size_t k) {               // SequentialIntegerAttributeEncoder.cs:55-128
+        const dsa::EncStream &S = hs[s0 + k];
+        const synth::PortableAttr &a = plans[i].atts[k];
+        if (S.kind == 1) { bw.i8(0); bw.i8(3); } else { bw.i8((int8_t)a.prediction); bw.i8(1); }
+        bw.u8(1);
+        bw.bytes(splans[s0 + k].head.d);
+        bw.varint(rans[s0 + k].size());
+        bw.bytes(rans[s0 + k]);
+        if (S.method == 0) bw.bytes(bits[s0 + k]);
+        if (S.kind == 1) { const int32_t max_q = (1 << S.bits) - 1; bw.i32(max_q); bw.i32((max_q - 1) / 2); }
+        else { bw.i32(S.wrap_mn); bw.i32(S.wrap_mx); }
+      },
+      [&](synth::ByteWriter &bw, size_t k) {               // AttributeQuantizationTransform.cs:123-134 / AttributeOctahedronTransform.cs:44-47
+        const dsa::EncStream &S = hs[s0 + k];
+        if (S.kind == 0) { for (uint32_t c = 0; c < S.nc_out; ++c) bw.f32(S.qmin[c]); bw.f32(S.qrange); bw.u8((uint8_t)S.bits); }
+        else bw.u8((uint8_t)S.bits);
+      });
+    E->streams[i].swap(w.d);
+  }
+  *out = E;
+  return DSA_OK;
+}
+
+uint32_t dsa_encoded_size(const dsa_encoded *e) { return e ? (uint32_t)e->streams.size() : 0; }
+
+dsa_status dsa_encoded_stream(const dsa_encoded *e, uint32_t mesh, const uint8_t **bytes, size_t *length) {
+  if (!e || mesh >= e->streams.size() || !bytes || !length) return DSA_ERR_INVALID_ARGUMENT;
+  if (e->status[mesh] != DSA_OK) return set_err(e->ctx, (dsa_status)e->status[mesh], "mesh %u: %s", mesh, e->messages[mesh].c_str());
+  *bytes = e->streams[mesh].data();
+  *length = e->streams[mesh].size();
+  return DSA_OK;
+}
+
+void dsa_encoded_free(dsa_encoded *e) { delete e; }
+
+}  // extern "C"

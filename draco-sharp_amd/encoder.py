@@ -1,0 +1,81 @@
+"""Host-side mirror of the reference's encode surface for the GPU path:
+
+  DracoEncoder.Encode(BinaryWriter, Config, PointCloud, attributes)     src/Draco/IO/DracoEncoder.cs:22-41
+  Config (quantisation bits, speed, prediction overrides)              src/Draco/IO/Config.cs
+
+bound to the dsa_encode_* entry points of libdraco_mi355x.so.  Connectivity (Edgebreaker) is coded on the host side
+of the library, attribute quantisation / prediction / rANS coding by HIP kernels; there is no CPU fallback."""
+import ctypes as C
+
+import numpy as np
+
+from . import native
+from .decoder import DeviceException, _raise, default_context
+
+
+class Config:
+    """Subset of src/Draco/IO/Config.cs that the device path honours."""
+
+    def __init__(self, position_bits=11, texcoord_bits=10, normal_bits=8, speed=5, single_connectivity=False,
+                 symbol_scheme=-1, position_prediction=1, texcoord_prediction=1):
+        self.position_bits, self.texcoord_bits, self.normal_bits = position_bits, texcoord_bits, normal_bits
+        self.speed = speed                      # compression level = 10 - speed (DracoEncoder.cs:50-56)
+        self.single_connectivity = single_connectivity
+        self.symbol_scheme = symbol_scheme
+        self.position_prediction, self.texcoord_prediction = position_prediction, texcoord_prediction
+
+    def _native(self):
+        o = native.EncodeOptions()
+        native.lib().dsa_encode_default_options(C.byref(o))
+        o.position_bits, o.texcoord_bits, o.normal_bits = self.position_bits, self.texcoord_bits, self.normal_bits
+        o.single_connectivity = 1 if self.single_connectivity else 0
+        o.symbol_scheme = self.symbol_scheme
+        o.compression_level = 10 - self.speed
+        o.position_prediction, o.texcoord_prediction = self.position_prediction, self.texcoord_prediction
+        return o
+
+
+class MeshData:
+    """Triangle mesh with per-vertex attributes: positions (V,3) f32, faces (F,3) u32, optional normals (V,3), uvs (V,2)."""
+
+    def __init__(self, positions, faces, normals=None, texcoords=None):
+        self.positions = np.ascontiguousarray(positions, np.float32)
+        self.faces = np.ascontiguousarray(faces, np.uint32)
+        self.normals = None if normals is None else np.ascontiguousarray(normals, np.float32)
+        self.texcoords = None if texcoords is None else np.ascontiguousarray(texcoords, np.float32)
+
+
+class DracoEncoder:
+    def __init__(self, context=None):
+        self._ctx = context
+
+    def EncodeBatch(self, meshes, config=None):
+        """meshes: list of MeshData -> list of bytes (.drc streams).  A mesh that cannot be encoded raises."""
+        ctx = self._ctx or default_context()
+        L = native.lib()
+        n = len(meshes)
+        arr = (native.MeshInput * max(1, n))()
+        for i, m in enumerate(meshes):
+            arr[i].num_vertices, arr[i].num_faces = len(m.positions), len(m.faces)
+            arr[i].positions, arr[i].faces = m.positions.ctypes.data, m.faces.ctypes.data
+            arr[i].normals = m.normals.ctypes.data if m.normals is not None else None
+            arr[i].texcoords = m.texcoords.ctypes.data if m.texcoords is not None else None
+        opt = (config or Config())._native()
+        h = C.c_void_p()
+        st = L.dsa_encode_batch(ctx._h, n, arr, C.byref(opt), C.byref(h))
+        if st != 0:
+            _raise(st, ctx.error())
+        try:
+            out = []
+            for i in range(n):
+                p, ln = C.c_void_p(), C.c_size_t()
+                st = L.dsa_encoded_stream(h, i, C.byref(p), C.byref(ln))
+                if st != 0:
+                    _raise(st, ctx.error())
+                out.append(C.string_at(p, ln.value))
+            return out
+        finally:
+            L.dsa_encoded_free(h)
+
+    def Encode(self, mesh, config=None):
+        return self.EncodeBatch([mesh], config)[0]

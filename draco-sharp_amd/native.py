@@ -18,7 +18,19 @@ EXPORTS = [
     "dsa_batch_attribute_info", "dsa_batch_copy_faces", "dsa_batch_copy_attribute_values", "dsa_batch_copy_point_map",
     "dsa_batch_copy_portable_values", "dsa_batch_device_faces", "dsa_batch_device_attribute_values",
     "dsa_batch_device_point_map", "dsa_batch_copy_debug", "dsa_context_set_profiling", "dsa_batch_stage_times",
+    "dsa_encode_default_options", "dsa_encode_batch", "dsa_encoded_size", "dsa_encoded_stream", "dsa_encoded_free",
 ]
+
+
+class EncodeOptions(C.Structure):
+    _fields_ = [("position_bits", C.c_int32), ("texcoord_bits", C.c_int32), ("normal_bits", C.c_int32),
+                ("single_connectivity", C.c_int32), ("symbol_scheme", C.c_int32), ("compression_level", C.c_int32),
+                ("position_prediction", C.c_int32), ("texcoord_prediction", C.c_int32)]
+
+
+class MeshInput(C.Structure):
+    _fields_ = [("num_vertices", C.c_uint32), ("num_faces", C.c_uint32), ("positions", C.c_void_p), ("faces", C.c_void_p),
+                ("normals", C.c_void_p), ("texcoords", C.c_void_p)]
 
 
 class MeshInfo(C.Structure):
@@ -38,7 +50,8 @@ class AttributeInfo(C.Structure):
 
 def build(force=False):
     """Compiles the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_DIR, f) for f in ("dsa_api.hip", "dsa_kernels.h", "dsa_types.h")]
+    srcs = [os.path.join(_DIR, f) for f in ("dsa_api.hip", "dsa_kernels.h", "dsa_general.h", "dsa_common.h", "dsa_host_parse.h",
+                                            "dsa_encode.h", "dsa_encode_host.h", "dsa_types.h")]
     srcs.append(os.path.join(_DIR, "..", "..", "include", "draco_mi355x.h"))
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _DIR, "-s"])
@@ -87,5 +100,13 @@ def lib():
         L.dsa_batch_copy_debug.argtypes = [vp, u32, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.dsa_context_set_profiling.argtypes = [vp, C.c_int]
         L.dsa_batch_stage_times.argtypes = [vp, C.POINTER(C.c_float * DSA_NUM_STAGES), C.POINTER(C.c_char_p * DSA_NUM_STAGES)]
+        L.dsa_encode_default_options.argtypes = [C.POINTER(EncodeOptions)]
+        L.dsa_encode_default_options.restype = None
+        L.dsa_encode_batch.argtypes = [vp, u32, C.POINTER(MeshInput), C.POINTER(EncodeOptions), C.POINTER(vp)]
+        L.dsa_encoded_size.restype = u32
+        L.dsa_encoded_size.argtypes = [vp]
+        L.dsa_encoded_stream.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.dsa_encoded_free.argtypes = [vp]
+        L.dsa_encoded_free.restype = None
         _lib = L
     return _lib

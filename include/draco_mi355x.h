@@ -139,6 +139,43 @@ dsa_status dsa_batch_copy_debug(const dsa_batch *batch, uint32_t mesh, int what,
 dsa_status dsa_context_set_profiling(dsa_context *ctx, int enabled);
 dsa_status dsa_batch_stage_times(const dsa_batch *batch, float ms[DSA_NUM_STAGES], const char *names[DSA_NUM_STAGES]);
 
+/* ------------------------------------------------------------------ encode direction
+ * Drop-in for DracoEncoder.Encode(BinaryWriter, Config, PointCloud, attributes)   src/Draco/IO/DracoEncoder.cs:22-41
+ * on a batch of triangle meshes with per-vertex attributes: Edgebreaker (standard traversal) connectivity on the
+ * host, quantisation / prediction / symbol statistics / rANS coding as HIP kernels (BASELINE.json configs[4]).
+ * Options mirror the reference's Config (src/Draco/IO/Config.cs): quantisation bits per attribute type, speed
+ * (compression_level = 10 - speed), prediction scheme overrides. */
+typedef struct dsa_encode_options {
+  int32_t position_bits;       /* 1..20, default 11 */
+  int32_t texcoord_bits;       /* 1..20, default 10 */
+  int32_t normal_bits;         /* 2..20, default 8  */
+  int32_t single_connectivity; /* 0: one attributes decoder per attribute (Draco default at speed 5), 1: one for all */
+  int32_t symbol_scheme;       /* -1 choose per stream (SymbolEncoding.cs:8-40), 0 tagged, 1 raw */
+  int32_t compression_level;   /* 0..10, default 5 */
+  int32_t position_prediction; /* PredictionSchemeMethod: 1 parallelogram (default), 0 difference */
+  int32_t texcoord_prediction;
+} dsa_encode_options;
+
+typedef struct dsa_mesh_input {
+  uint32_t num_vertices, num_faces;
+  const float *positions;      /* num_vertices * 3 */
+  const uint32_t *faces;       /* num_faces * 3 vertex indices; manifold, no isolated vertices */
+  const float *normals;        /* num_vertices * 3 or NULL */
+  const float *texcoords;      /* num_vertices * 2 or NULL */
+} dsa_mesh_input;
+
+typedef struct dsa_encoded dsa_encoded;
+
+void dsa_encode_default_options(dsa_encode_options *options);
+/* Encodes n meshes (host-resident inputs, copied) into n .drc streams.  Synchronous.  A mesh that cannot be
+ * encoded (non-manifold, isolated vertex, index out of range) fails alone: see dsa_encoded_stream. */
+dsa_status dsa_encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options,
+                            dsa_encoded **out);
+uint32_t dsa_encoded_size(const dsa_encoded *encoded);
+/* Bytes of stream `mesh` (owned by `encoded`, valid until dsa_encoded_free) or that mesh's failure status. */
+dsa_status dsa_encoded_stream(const dsa_encoded *encoded, uint32_t mesh, const uint8_t **bytes, size_t *length);
+void dsa_encoded_free(dsa_encoded *encoded);
+
 #ifdef __cplusplus
 }
 #endif
