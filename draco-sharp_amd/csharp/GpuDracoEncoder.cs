@@ -1,0 +1,95 @@
+// GPU-backed twin of Draco.IO.DracoEncoder (src/Draco/IO/DracoEncoder.cs:8-41) for triangle meshes with per-vertex
+// positions / normals / texture coordinates.  Not compiled in the build image (no .NET SDK); the executable twin
+// is draco-sharp_amd/encoder.py.  Config options honoured: quantisation bits per attribute type and Speed
+// (src/Draco/IO/Config.cs); everything else keeps the reference's defaults (standard Edgebreaker, DFS traversal).
+using System;
+using System.Collections.Generic;
+using System.IO;
+using System.Runtime.InteropServices;
+using Draco.IO.Attributes;
+using Draco.IO.Enums;
+
+namespace Draco.IO.Gpu;
+
+public sealed unsafe class GpuDracoEncoder : IDisposable
+{
+    private IntPtr _ctx;
+
+    public GpuDracoEncoder(int device = 0)
+    {
+        NativeMethods.Check(NativeMethods.dsa_context_create(device, IntPtr.Zero, out _ctx), IntPtr.Zero, "dsa_context_create");
+    }
+
+    /// <summary>Same contract as DracoEncoder.Encode(BinaryWriter, Config, PointCloud, attributes): writes one .drc stream.</summary>
+    public void Encode(BinaryWriter writer, Config config, Mesh.Mesh mesh)
+    {
+        writer.Write(EncodeBatch(new[] { mesh }, config)[0]);
+    }
+
+    public byte[][] EncodeBatch(IReadOnlyList<Mesh.Mesh> meshes, Config config)
+    {
+        NativeMethods.dsa_encode_default_options(out var opt);
+        // per-attribute-type options are keyed by (int)GeometryAttributeType (Config.cs:55-62)
+        opt.PositionBits = config.GetAttributeOption((int)GeometryAttributeType.Position, ConfigOptionName.Attribute.QuantizationBits, opt.PositionBits);
+        opt.TexcoordBits = config.GetAttributeOption((int)GeometryAttributeType.TexCoord, ConfigOptionName.Attribute.QuantizationBits, opt.TexcoordBits);
+        opt.NormalBits = config.GetAttributeOption((int)GeometryAttributeType.Normal, ConfigOptionName.Attribute.QuantizationBits, opt.NormalBits);
+        opt.SymbolScheme = config.GetOption(ConfigOptionName.SymbolEncodingMethod, opt.SymbolScheme);
+        opt.CompressionLevel = 10 - config.Speed;
+        var inputs = new DsaMeshInput[meshes.Count];
+        var pins = new List<GCHandle>();
+        IntPtr encoded = IntPtr.Zero;
+        try
+        {
+            for (int i = 0; i < meshes.Count; ++i)
+            {
+                var m = meshes[i];
+                inputs[i].NumVertices = (uint)m.PointsCount;
+                inputs[i].NumFaces = (uint)m.FacesCount;
+                inputs[i].Positions = (float*)Pin(Floats(m, GeometryAttributeType.Position, 3), pins);
+                inputs[i].Normals = (float*)Pin(Floats(m, GeometryAttributeType.Normal, 3), pins);
+                inputs[i].Texcoords = (float*)Pin(Floats(m, GeometryAttributeType.TexCoord, 2), pins);
+                var faces = new uint[m.FacesCount * 3];
+                for (int f = 0; f < m.FacesCount; ++f) { var face = m.GetFace((uint)f); faces[3 * f] = (uint)face[0]; faces[3 * f + 1] = (uint)face[1]; faces[3 * f + 2] = (uint)face[2]; }
+                inputs[i].Faces = (uint*)Pin(faces, pins);
+            }
+            fixed (DsaMeshInput* p = inputs)
+                NativeMethods.Check(NativeMethods.dsa_encode_batch(_ctx, (uint)meshes.Count, p, in opt, out encoded), _ctx, "dsa_encode_batch");
+            var result = new byte[meshes.Count][];
+            for (uint i = 0; i < meshes.Count; ++i)
+            {
+                NativeMethods.Check(NativeMethods.dsa_encoded_stream(encoded, i, out var bytes, out var length), _ctx, $"mesh {i}");
+                result[i] = new ReadOnlySpan<byte>(bytes, (int)length).ToArray();
+            }
+            return result;
+        }
+        finally
+        {
+            if (encoded != IntPtr.Zero) NativeMethods.dsa_encoded_free(encoded);
+            foreach (var h in pins) if (h.IsAllocated) h.Free();
+        }
+    }
+
+    // values of a per-vertex float attribute in point order (null when the mesh has no such attribute)
+    private static float[]? Floats(Mesh.Mesh m, GeometryAttributeType type, int nc)
+    {
+        var a = m.GetNamedAttribute(type);
+        if (a == null) return null;
+        var v = new float[m.PointsCount * nc];
+        for (uint p = 0; p < m.PointsCount; ++p)
+            for (int c = 0; c < nc; ++c) v[p * nc + c] = a.Buffer!.Read<float>((int)(a.MappedIndex(p) * a.ByteStride + 4 * c));
+        return v;
+    }
+
+    private static IntPtr Pin(Array? a, List<GCHandle> pins)
+    {
+        if (a == null) return IntPtr.Zero;
+        var h = GCHandle.Alloc(a, GCHandleType.Pinned);
+        pins.Add(h);
+        return h.AddrOfPinnedObject();
+    }
+
+    public void Dispose()
+    {
+        if (_ctx != IntPtr.Zero) { NativeMethods.dsa_context_destroy(_ctx); _ctx = IntPtr.Zero; }
+    }
+}

@@ -49,6 +49,26 @@ internal unsafe struct DsaAttributeInfo
     public fixed float MinValues[4];
 }
 
+[StructLayout(LayoutKind.Sequential)]
+internal struct DsaEncodeOptions
+{
+    public int PositionBits, TexcoordBits, NormalBits;
+    public int SingleConnectivity;
+    public int SymbolScheme;        // -1 auto, 0 tagged, 1 raw
+    public int CompressionLevel;    // 10 - Config.Speed
+    public int PositionPrediction, TexcoordPrediction;
+}
+
+[StructLayout(LayoutKind.Sequential)]
+internal unsafe struct DsaMeshInput
+{
+    public uint NumVertices, NumFaces;
+    public float* Positions;
+    public uint* Faces;
+    public float* Normals;
+    public float* Texcoords;
+}
+
 internal static unsafe partial class NativeMethods
 {
     private const string Lib = "draco_mi355x";
@@ -78,6 +98,13 @@ internal static unsafe partial class NativeMethods
     [DllImport(Lib)] internal static extern DsaStatus dsa_batch_copy_debug(IntPtr batch, uint mesh, int what, void* dst, nuint dstBytes, out nuint written);
     [DllImport(Lib)] internal static extern DsaStatus dsa_context_set_profiling(IntPtr ctx, int enabled);
     [DllImport(Lib)] internal static extern DsaStatus dsa_batch_stage_times(IntPtr batch, float* ms, IntPtr* names);
+
+    // encode direction (DracoEncoder.Encode, src/Draco/IO/DracoEncoder.cs:22-41)
+    [DllImport(Lib)] internal static extern void dsa_encode_default_options(out DsaEncodeOptions options);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_encode_batch(IntPtr ctx, uint n, DsaMeshInput* meshes, in DsaEncodeOptions options, out IntPtr encoded);
+    [DllImport(Lib)] internal static extern uint dsa_encoded_size(IntPtr encoded);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_encoded_stream(IntPtr encoded, uint mesh, out byte* bytes, out nuint length);
+    [DllImport(Lib)] internal static extern void dsa_encoded_free(IntPtr encoded);
 
     internal static void Check(DsaStatus status, IntPtr ctx, string what)
     {
