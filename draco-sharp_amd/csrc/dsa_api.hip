@@ -276,12 +276,16 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_join3, st3));
   HIP_TRY(ctx, mark());
+  // parallelogram operands: by the traversal waves themselves when the batch keeps the machine busy anyway, by an
+  // element-parallel kernel behind the traversal when it does not
+  static const char *fuse_env = getenv("DSA_FUSE_OPERANDS");                              // diagnostics: 0 / 1 overrides the rule
+  const bool fuse_operands = fuse_env ? atoi(fuse_env) != 0 : n >= 2048;
   {
     static const int split = getenv("DSA_TRAV_SPLIT") ? atoi(getenv("DSA_TRAV_SPLIT")) : 1;   // diagnostics
     const uint32_t per = (n + split - 1) / split;
     for (uint32_t m0 = 0; m0 < n; m0 += per) {
       const uint32_t cnt = std::min(per, n - m0);
-      hipLaunchKernelGGL(dsa::k_traverse, dim3(cnt), dim3(WAVE), 0, st, b->arena, b->d_layouts + m0, b->d_descs + m0, cnt);
+      hipLaunchKernelGGL(dsa::k_traverse, dim3(cnt), dim3(WAVE), 0, st, b->arena, b->d_layouts + m0, b->d_descs + m0, cnt, fuse_operands ? 1u : 0u);
     }
   }
   HIP_TRY(ctx, mark());
@@ -293,7 +297,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_point_maps, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st3));
-  {
+  if (!fuse_operands) {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 8191) / 8192, 4));
     hipLaunchKernelGGL(dsa::k_para_operands, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   }

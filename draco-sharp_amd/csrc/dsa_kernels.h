@@ -1028,6 +1028,39 @@ __global__ __launch_bounds__(256) void k_init(uint8_t *arena, const MeshLayout *
   for (uint32_t v = tid; v < V; v += stride) { v2d[v] = -1; vstamp[v] = 0xFFFFFFFFu; }
 }
 
+// Parallelogram operands of entry p (MeshPredictionSchemeParallelogramDecoder.cs:56-89):
+// para[3p..3p+2] = entries (next, prev, opposite), or next = INVALID when the entry falls back to delta.
+__device__ __forceinline__ void para_operands_of(uint32_t p, const uint32_t *frec, const uint32_t *d2c, const int32_t *v2d, uint32_t F, uint32_t NV, uint32_t *para) {
+  uint32_t en = DSA_INVALID, ep = 0, eo = 0;
+  if (p > 0) {
+    const uint32_t c0 = d2c[p];
+    const uint32_t oci = (c0 < 4 * F && (c0 & 3u) != 3u) ? frec[fo_idx(c0)] : DSA_INVALID;
+    if (oci != DSA_INVALID && oci < 4 * F && (oci & 3u) != 3u) {
+      const uint4 fr = ((const uint4 *)frec)[(size_t)(oci >> 2) * 2];
+      const uint32_t k = oci & 3u;
+      const uint32_t a = k == 0 ? fr.x : (k == 1 ? fr.y : fr.z), b = k == 0 ? fr.y : (k == 1 ? fr.z : fr.x), c = k == 0 ? fr.z : (k == 1 ? fr.x : fr.y);
+      if (a < NV && b < NV && c < NV) {
+        const int32_t vo = v2d[a], vn = v2d[b], vp = v2d[c];
+        if (vo >= 0 && vn >= 0 && vp >= 0 && (uint32_t)vo < p && (uint32_t)vn < p && (uint32_t)vp < p) { en = (uint32_t)vn; ep = (uint32_t)vp; eo = (uint32_t)vo; }
+      }
+    }
+  }
+  para[3 * p] = en; para[3 * p + 1] = ep; para[3 * p + 2] = eo;
+}
+__global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n) {
+  uint32_t mesh = blockIdx.y;
+  if (mesh >= n) return;
+  const MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->encoder_type == 0 || D->general) return;   // point clouds have no connectivity; general meshes: k_general
+  const MeshLayout &L = layouts[mesh];
+  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
+  const uint32_t *d2c = (const uint32_t *)(arena + L.d2c);
+  const int32_t *v2d = (const int32_t *)(arena + L.v2d);
+  uint32_t *para = (uint32_t *)(arena + L.para);
+  const uint32_t entries = D->num_entries, F = D->num_faces, NV = D->num_vertices;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < entries; p += gridDim.x * blockDim.x) para_operands_of(p, frec, d2c, v2d, F, NV, para);
+}
+
 // k_traverse speculation: from a corner whose tip is new and interior the DFS usually repeats the pair
 // "tip new & interior -> right (N), then tip visited & right side done -> left (L)", i.e. it continues at
 //   succ(a) = Opposite(Previous(Opposite(Next(a)))).
@@ -1040,7 +1073,7 @@ __global__ __launch_bounds__(256) void k_init(uint8_t *arena, const MeshLayout *
 // retired at once.  Everything else is the scalar step = the reference's loop body.
 #define TR_PAIRS 64
 
-__global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+__global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t fuse_operands) {
   __builtin_amdgcn_s_setprio(3);   // critical path: issue ahead of the entropy-decode waves sharing the CU
   uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
@@ -1303,37 +1336,16 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
     // a valid stream carries exactly one entry per encoded vertex (k_locate sized the symbol streams on that)
     if (count != D->num_enc_vertices) fail(D, ST_INVALID, 305);
   }
+  // Large batches: the wave that just produced the order also derives the parallelogram operands of its mesh, while
+  // other meshes are still being traversed (small batches use the element-parallel k_para_operands instead).
+  if (fuse_operands && count == D->num_enc_vertices) {
+    uint32_t *para = (uint32_t *)(arena + L.para);
+    for (uint32_t p = lane; p < count; p += WAVE) para_operands_of(p, frec, d2c, v2d, F, NV, para);
+  }
 #undef TR_FAIL
 #undef VISIT_SCALAR
 }
 
-// Parallelogram operands per entry (MeshPredictionSchemeParallelogramDecoder.cs:56-89):
-// para[3p..3p+2] = entries (next, prev, opposite) or next = INVALID when the entry falls back to delta.
-__global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n) {
-  uint32_t mesh = blockIdx.y;
-  if (mesh >= n) return;
-  const MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK || D->encoder_type == 0 || D->general) return;   // point clouds have no connectivity; general meshes: k_general
-  const MeshLayout &L = layouts[mesh];
-  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
-  const uint32_t *d2c = (const uint32_t *)(arena + L.d2c);
-  const int32_t *v2d = (const int32_t *)(arena + L.v2d);
-  uint32_t *para = (uint32_t *)(arena + L.para);
-  uint32_t entries = D->num_entries;
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < entries; p += gridDim.x * blockDim.x) {
-    uint32_t en = DSA_INVALID, ep = 0, eo = 0;
-    if (p > 0) {
-      uint32_t oci = frec[fo_idx(d2c[p])];
-      if (oci != DSA_INVALID) {
-        const uint32_t *fr = frec + 8 * (oci >> 2);
-        const uint32_t k = oci & 3u;
-        int32_t vo = v2d[fr[k]], vn = v2d[fr[k == 2 ? 0 : k + 1]], vp = v2d[fr[k == 0 ? 2 : k - 1]];
-        if (vo >= 0 && vn >= 0 && vp >= 0 && (uint32_t)vo < p && (uint32_t)vn < p && (uint32_t)vp < p) { en = (uint32_t)vn; ep = (uint32_t)vp; eo = (uint32_t)vo; }
-      }
-    }
-    para[3 * p] = en; para[3 * p + 1] = ep; para[3 * p + 2] = eo;
-  }
-}
 
 // =========================================================================
 // k_symbols: one wave per (mesh, attribute) value stream -> int32 corrections.
