@@ -839,6 +839,61 @@ static void encode_mesh(const MeshIn &in, const Options &opt, std::vector<uint8_
   out.swap(w.d);
 }
 
+// Sequential mesh (Mesh/MeshSequentialEncoder.cs:9-121 with the bitstream's index widths): faces as point indices,
+// compressed (differences, sign in the LSB, through the symbol coder) or raw; one attributes encoder with a linear
+// sequencer, so values are in point order and predicted by Difference + Wrap / canonicalised octahedral delta.
+static void encode_mesh_sequential(const MeshIn &in, const Options &opt, bool compressed, std::vector<uint8_t> &out) {
+  ByteWriter w;
+  w.d.insert(w.d.end(), {'D', 'R', 'A', 'C', 'O'});
+  w.u8(2); w.u8(2); w.u8(1); w.u8(0); w.u16(0);
+  w.varint(in.nf);
+  w.varint(in.nv);
+  if (compressed) {
+    w.u8(0);
+    std::vector<uint32_t> sym((size_t)in.nf * 3);
+    int64_t last = 0;
+    for (size_t k = 0; k < sym.size(); ++k) {
+      const int64_t diff = (int64_t)in.faces[k] - last;
+      sym[k] = ((uint32_t)(diff < 0 ? -diff : diff) << 1) | (diff < 0 ? 1u : 0u);
+      last = in.faces[k];
+    }
+    encode_symbols(w, sym, 1, opt.force_scheme, opt.compression_level);
+  } else {
+    w.u8(1);
+    for (size_t k = 0; k < (size_t)in.nf * 3; ++k) {
+      const uint32_t v = in.faces[k];
+      if (in.nv < 256) w.u8((uint8_t)v);
+      else if (in.nv < (1u << 16)) w.u16((uint16_t)v);
+      else if (in.nv < (1u << 21)) w.varint(v);
+      else w.u32(v);
+    }
+  }
+  std::vector<PortableAttr> atts;
+  { PortableAttr a; a.att_type = 0; a.nc = a.nc_out = 3; a.seq_type = 2; a.data_type = 9; a.prediction = 0; quantize(in.pos, in.nv, 3, opt.pos_bits, a); atts.push_back(a); }
+  if (in.normals) {
+    PortableAttr a; a.att_type = 1; a.nc_out = 3; a.nc = 2; a.seq_type = 3; a.data_type = 9; a.bits = opt.normal_bits; a.prediction = 0;
+    Octa o(opt.normal_bits);
+    a.vals.resize((size_t)in.nv * 2);
+    for (uint32_t v = 0; v < in.nv; ++v) { int s, t; o.from_float_vector(in.normals + (size_t)v * 3, s, t); a.vals[(size_t)v * 2] = s; a.vals[(size_t)v * 2 + 1] = t; }
+    atts.push_back(a);
+  }
+  if (in.uvs) { PortableAttr a; a.att_type = 3; a.nc = a.nc_out = 2; a.seq_type = 2; a.data_type = 9; a.prediction = 0; quantize(in.uvs, in.nv, 2, opt.uv_bits, a); atts.push_back(a); }
+  // linear order: entry i = point i.  write_attribute_values wants a corner table and a sequence: an identity stand-in
+  CornerTable ct;
+  ct.c2v.resize(in.nv);
+  for (uint32_t v = 0; v < in.nv; ++v) ct.c2v[v] = v;
+  Sequence seq;
+  seq.data_to_corner.resize(in.nv);
+  for (uint32_t v = 0; v < in.nv; ++v) seq.data_to_corner[v] = v;
+  w.u8(1);
+  w.varint(atts.size());
+  for (size_t i = 0; i < atts.size(); ++i) { w.u8((uint8_t)atts[i].att_type); w.u8((uint8_t)atts[i].data_type); w.u8((uint8_t)atts[i].nc_out); w.u8(0); w.varint(i); }
+  for (auto &a : atts) w.u8((uint8_t)a.seq_type);
+  for (auto &a : atts) write_attribute_values(w, a, ct, seq, opt);
+  for (auto &a : atts) write_attribute_transform(w, a);
+  out.swap(w.d);
+}
+
 // Point cloud, sequential (BASELINE config 1): int32 num_points, one attributes
 // decoder, positions quantised, Difference + Wrap in linear order.
 static void encode_point_cloud(const float *pos, uint32_t n, const Options &opt, std::vector<uint8_t> &out) {

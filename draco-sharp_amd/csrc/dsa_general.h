@@ -299,6 +299,229 @@ __device__ bool texcoords_portable_wrap(MeshDesc *D, const T &t, const uint32_t 
   return true;
 }
 
+// What the prediction schemes of one attributes decoder see.  ct == nullptr: no corner table (linear sequencing of a
+// sequential mesh); act != nullptr: the attribute corner table of the decoder's attribute data.
+struct ValueCtx {
+  const Ct *ct;
+  const Act *act;
+  const uint32_t *d2c;
+  const int32_t *v2d;
+  const uint32_t *pids;
+  uint8_t *orient;
+  uint32_t orient_cap, num_points;
+};
+
+// Values of attribute ai (SequentialAttributeDecoder.cs:47-52,75-86 / SequentialIntegerAttributeDecoder.cs:23-101):
+// symbols -> corrections -> portable values in work[ai].
+__device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, uint32_t ai, uint32_t entries, uint32_t *cum, uint64_t cum_cap,
+                              const ValueCtx &vc) {
+  AttrDesc &a = D->att[ai];
+  a.num_entries = entries;
+  a.pred_method = -2; a.pred_transform = -1; a.have_scheme = 0; a.pred_kind = 0;
+  if (a.seq_type == 0) {                               // SequentialAttributeDecoder.cs:75-86
+    a.source = SRC_BYTES;
+    a.off_raw = r.pos;
+    const uint64_t bytes = (uint64_t)data_type_length(a.data_type) * a.nc * entries;
+    GREQ(bytes <= L.out_cap[ai], 140);
+    r.skip(bytes);
+    GREQ(r.ok, 141);
+    return true;
+  }
+  const uint32_t nc = a.seq_type == 3 ? 2u : a.nc;
+  a.nc_portable = (uint8_t)nc;
+  const uint64_t num_values = (uint64_t)entries * nc;
+  GREQ(num_values <= L.work_cap[ai], 142);
+  int32_t *w = (int32_t *)(arena + L.work[ai]);
+  const int method = (int8_t)r.u8();
+  GREQ(r.ok && method >= -2 && method < 7, 143);
+  a.pred_method = (int8_t)method;
+  int tt = -1;
+  if (method != -2) {
+    tt = (int8_t)r.u8();
+    GREQ(r.ok && tt >= -1 && tt < 4, 144);
+    a.pred_transform = (int8_t)tt;
+    a.have_scheme = a.seq_type == 3 ? (tt == 2 || tt == 3) : (tt == 1);
+  }
+  const uint32_t compressed = r.u8();
+  GREQ(r.ok, 145);
+  a.source = SRC_RAW;
+  if (compressed > 0) {
+    if (!decode_symbols(D, r, (uint32_t)num_values, nc, (uint32_t *)w, cum, cum_cap)) return false;
+  } else {                                             // SequentialIntegerAttributeDecoder.cs:68-84 (D-13)
+    const uint32_t nb = r.u8();
+    GREQ(r.ok && nb >= 1 && nb <= 4, 158);
+    for (uint64_t k = 0; k < num_values; ++k) { uint32_t v = 0; for (uint32_t q = 0; q < nb; ++q) v |= r.u8() << (8 * q); ((uint32_t *)w)[k] = v; }
+    GREQ(r.ok, 160);
+  }
+  const bool positive = a.have_scheme && (tt == 2 || tt == 3);      // D-4
+  if (num_values > 0 && !positive)
+    for (uint64_t k = 0; k < num_values; ++k) { const uint32_t sv = ((uint32_t *)w)[k]; w[k] = (sv & 1u) ? -(int32_t)(sv >> 1) - 1 : (int32_t)(sv >> 1); }
+  if (!a.have_scheme) return true;
+  // scheme selection, PredictionSchemeDecoderFactory.cs:9-76
+  int eff = method;
+  if (vc.ct == nullptr) eff = 0;                       // no corner table (linear sequencing): every scheme falls back to delta
+  else if (!(method == 1 || method == 5)) { if (method == 0) eff = 0; else GNOTIMPL(161); }
+  a.pred_kind = (int8_t)eff;
+  uint8_t *orient = nullptr;
+  uint32_t num_orient = 0;
+  if (eff == 5) {                                      // MeshPredictionSchemeTexCoordsPortableDecoder.cs:66-85
+    GREQ(vc.orient != nullptr, 680);                   // orientation scratch lives in the attribute data block
+    const int32_t num_or = (int32_t)r.u32();
+    GREQ(r.ok && num_or >= 0 && (uint32_t)num_or <= vc.orient_cap, 681);
+    Rabs rd;
+    uint32_t endp;
+    rd.start(arena + L.stream, L.stream_len, r.pos, &endp);
+    GREQ(rd.ok, 682);
+    r.pos = endp;
+    orient = vc.orient;
+    bool last = true;
+    for (int32_t k = 0; k < num_or; ++k) { if (rd.next() == 0) last = !last; orient[k] = last ? 1 : 0; }
+    num_orient = (uint32_t)num_or;
+  }
+  if (tt == 1) {                                       // PredictionSchemeWrapDecodingTransform.cs:69-75
+    a.wrap_min = (int32_t)r.u32(); a.wrap_max = (int32_t)r.u32();
+    GREQ(r.ok && a.wrap_min <= a.wrap_max, 162);
+    const int64_t dif = (int64_t)a.wrap_max - (int64_t)a.wrap_min;
+    GREQ(dif < 0x7FFFFFFF, 163);
+    const int32_t mn = a.wrap_min, mx = a.wrap_max, max_dif = (int32_t)(1 + dif);
+    if (num_values == 0) return true;
+    if (eff == 0) {                                    // PredictionSchemeDeltaDecoder.cs:23-37
+      for (uint32_t c = 0; c < nc; ++c) w[c] = wrap_original(0, w[c], mn, mx, max_dif);
+      for (uint64_t k = nc; k < num_values; ++k) w[k] = wrap_original(w[k - nc], w[k], mn, mx, max_dif);
+    } else if (eff == 1) {
+      if (vc.act) parallelogram_wrap(*vc.act, vc.d2c, vc.v2d, entries, nc, w, mn, mx, max_dif);
+      else parallelogram_wrap(*vc.ct, vc.d2c, vc.v2d, entries, nc, w, mn, mx, max_dif);
+    } else {
+      GREQ(nc == 2, 683);
+      // parent = portable positions, SequentialAttributeDecoder.cs:58-73
+      int pa = -1;
+      for (uint32_t q = 0; q < ai; ++q) if (D->att[q].att_type == 0 && D->att[q].seq_type != 0) { pa = (int)q; break; }
+      GREQ(pa >= 0 && D->att[pa].nc_portable == 3, 684);
+      const int32_t *pos = (const int32_t *)(arena + L.work[pa]);
+      const uint32_t *pos_map = (const uint32_t *)(arena + L.map[pa]);
+      bool ok;
+      if (vc.act) ok = texcoords_portable_wrap(D, *vc.act, vc.d2c, vc.v2d, entries, w, vc.pids, pos, pos_map, vc.num_points, D->att[pa].num_entries, orient, num_orient, mn, mx, max_dif);
+      else ok = texcoords_portable_wrap(D, *vc.ct, vc.d2c, vc.v2d, entries, w, vc.pids, pos, pos_map, vc.num_points, D->att[pa].num_entries, orient, num_orient, mn, mx, max_dif);
+      if (!ok) return false;
+    }
+  } else {                                             // normal octahedron transforms (D-19)
+    GREQ(eff == 0, 501);
+    const int32_t max_q = (int32_t)r.u32();
+    if (tt == 3) (void)r.u32();
+    GREQ(r.ok && max_q > 0 && (max_q & 1) == 1, 164);
+    a.oct_max_q = max_q;
+    if (num_values == 0) return true;
+    OctParams o;
+    const int q = 32 - __builtin_clz((uint32_t)max_q);
+    GREQ(q >= 2 && q <= 30, 165);
+    const int32_t max_value = (1 << q) - 2;
+    o.center = max_value / 2; o.max_q = (1 << q) - 1;
+    int32_t ps = 0, pt = 0;
+    for (uint32_t e = 0; e < entries; ++e) {
+      int32_t os, ot;
+      oct_original(o, tt == 3, ps, pt, w[2 * e], w[2 * e + 1], os, ot);
+      w[2 * e] = os; w[2 * e + 1] = ot;
+      ps = os; pt = ot;
+    }
+  }
+  return true;
+}
+
+// AttributeQuantizationTransform.cs:110-121 / AttributeOctahedronTransform.cs:39-42 (D-5)
+__device__ bool decode_transform_params(MeshDesc *D, Rd &r, uint32_t ai) {
+  AttrDesc &a = D->att[ai];
+  if (a.seq_type == 2) {
+    for (uint32_t c = 0; c < a.nc; ++c) a.q_min[c] = r.f32();
+    a.q_range = r.f32();
+    a.q_bits = (uint8_t)r.u8();
+    GREQ(r.ok && a.q_bits >= 1 && a.q_bits <= 30, 135);
+  } else if (a.seq_type == 3) {
+    a.q_bits = (uint8_t)r.u8();
+    GREQ(r.ok && a.q_bits >= 2 && a.q_bits <= 30, 136);
+  }
+  return true;
+}
+
+// Attribute descriptors of one decoder (AttributesDecoder.cs:19-63 + SequentialAttributeDecodersController.cs:16-27)
+__device__ bool decode_descriptors(const MeshLayout &L, MeshDesc *D, Rd &r, uint32_t decoder, uint32_t &natt, uint32_t *first_att, uint32_t *num_atts) {
+  *first_att = natt;
+  const uint64_t k = r.varint();
+  GREQ(r.ok && natt + k <= DSA_MAX_ATT && natt + k <= L.cap_attributes, 129);
+  *num_atts = (uint32_t)k;
+  for (uint32_t j = 0; j < (uint32_t)k; ++j) {
+    AttrDesc &a = D->att[natt + j];
+    a.att_type = (uint8_t)r.u8(); a.data_type = (uint8_t)r.u8(); a.nc = (uint8_t)r.u8(); a.normalized = r.u8() != 0;
+    GREQ(r.ok && a.att_type < 5 && a.data_type != 0 && a.data_type < 12 && a.nc != 0, 130);
+    a.unique_id = (uint32_t)r.varint();
+    a.decoder_id = (int8_t)decoder;
+  }
+  for (uint32_t j = 0; j < (uint32_t)k; ++j) {
+    AttrDesc &a = D->att[natt + j];
+    a.seq_type = (uint8_t)r.u8();
+    GREQ(r.ok && a.seq_type <= 3, 131);
+    if (a.seq_type == 2) GREQ(a.data_type == 9 && a.nc <= 4, 132);
+    if (a.seq_type == 3) GREQ(a.data_type == 9 && a.nc == 3, 133);
+    if (a.seq_type == 1) { const uint32_t w = data_type_length(a.data_type); GREQ(w == 1 || w == 2 || w == 4, 134); }
+  }
+  natt += (uint32_t)k;
+  return true;
+}
+
+// Mesh/MeshSequentialDecoder.cs:8-123: faces as point indices (compressed: differences with the sign in the LSB
+// through the symbol coder -- D-22: the C# tests that bit inverted; raw: u8 / u16 / varint / u32 by point count), one
+// attributes decoder, linear sequencing (entry i = point i).
+__device__ bool decode_sequential_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r) {
+  const uint64_t nf64 = r.varint(), np64 = r.varint();
+  GREQ(r.ok && nf64 <= 0x7FFFFFFFu / 3 && np64 <= 0x7FFFFFFFu, 111);
+  const uint32_t F = (uint32_t)nf64, NP = (uint32_t)np64;
+  GREQ(F == L.cap_faces && NP == L.cap_vertices, 116);
+  const GenLayout g = gen_layout(F, NP, 0, 0, L.stream_len);
+  GREQ(g.total <= L.gen_bytes, 640);
+  uint32_t *cum = (uint32_t *)(arena + L.gen + g.cum);
+  int32_t *faces = (int32_t *)(arena + L.faces);
+  const uint32_t method = r.u8();
+  GREQ(r.ok && method <= 1, 690);
+  if (method == 0) {
+    if (!decode_symbols(D, r, 3 * F, 1, (uint32_t *)faces, cum, g.cum_entries)) return false;
+    int32_t last = 0;
+    for (uint32_t k = 0; k < 3 * F; ++k) {
+      const uint32_t e = (uint32_t)faces[k];
+      int32_t diff = (int32_t)(e >> 1);
+      if (e & 1u) { GREQ(diff <= last, 691); diff = -diff; }
+      else GREQ(diff <= 0x7FFFFFFF - last, 692);
+      last += diff;
+      faces[k] = last;
+    }
+  } else {
+    for (uint32_t k = 0; k < 3 * F; ++k) {
+      if (NP < 256) faces[k] = (int32_t)r.u8();
+      else if (NP < (1u << 16)) faces[k] = (int32_t)r.u16();
+      else if (NP < (1u << 21)) faces[k] = (int32_t)(uint32_t)r.varint();
+      else faces[k] = (int32_t)r.u32();
+    }
+    GREQ(r.ok, 693);
+  }
+  D->num_faces = F; D->num_points = NP; D->num_vertices = NP; D->num_all_vertices = NP; D->num_enc_vertices = NP; D->num_entries = NP;
+  D->off_attributes = r.pos;
+  const uint32_t ndec = r.u8();
+  GREQ(r.ok && ndec <= DSA_MAX_ATT, 122);
+  D->num_decoders = ndec;
+  uint32_t natt = 0, first[DSA_MAX_ATT], count[DSA_MAX_ATT];
+  for (uint32_t i = 0; i < ndec; ++i) if (!decode_descriptors(L, D, r, i, natt, &first[i], &count[i])) return false;
+  D->num_attributes = natt;
+  ValueCtx vc = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, NP};
+  for (uint32_t i = 0; i < ndec; ++i) {
+    for (uint32_t ai = first[i]; ai < first[i] + count[i]; ++ai) {
+      uint32_t *map = (uint32_t *)(arena + L.map[ai]);
+      for (uint32_t p = 0; p < NP; ++p) map[p] = p;           // LinearSequencer.cs:3-19
+    }
+    for (uint32_t ai = first[i]; ai < first[i] + count[i]; ++ai) if (!decode_values(arena, L, D, r, ai, NP, cum, g.cum_entries, vc)) return false;
+    for (uint32_t ai = first[i]; ai < first[i] + count[i]; ++ai) if (!decode_transform_params(D, r, ai)) return false;
+  }
+  D->end_pos = r.pos;
+  return true;
+}
+
 struct DecoderInfo { int att_data_id; uint32_t element_type, first_att, num_atts, num_entries; };
 
 // The whole mesh.  Returns false after latching the failure.
@@ -698,28 +921,7 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
     if (traversal_method != 0) GNOTIMPL(128);             // prediction-degree traversal
   }
   uint32_t natt = 0;
-  for (uint32_t i = 0; i < ndec; ++i) {                   // AttributesDecoder.cs:19-63 + controller :16-27
-    dec[i].first_att = natt;
-    const uint64_t k = r.varint();
-    GREQ(r.ok && natt + k <= DSA_MAX_ATT && natt + k <= L.cap_attributes, 129);
-    dec[i].num_atts = (uint32_t)k;
-    for (uint32_t j = 0; j < (uint32_t)k; ++j) {
-      AttrDesc &a = D->att[natt + j];
-      a.att_type = (uint8_t)r.u8(); a.data_type = (uint8_t)r.u8(); a.nc = (uint8_t)r.u8(); a.normalized = r.u8() != 0;
-      GREQ(r.ok && a.att_type < 5 && a.data_type != 0 && a.data_type < 12 && a.nc != 0, 130);
-      a.unique_id = (uint32_t)r.varint();
-      a.decoder_id = (int8_t)i;
-    }
-    for (uint32_t j = 0; j < (uint32_t)k; ++j) {
-      AttrDesc &a = D->att[natt + j];
-      a.seq_type = (uint8_t)r.u8();
-      GREQ(r.ok && a.seq_type <= 3, 131);
-      if (a.seq_type == 2) GREQ(a.data_type == 9 && a.nc <= 4, 132);
-      if (a.seq_type == 3) GREQ(a.data_type == 9 && a.nc == 3, 133);
-      if (a.seq_type == 1) { const uint32_t w = data_type_length(a.data_type); GREQ(w == 1 || w == 2 || w == 4, 134); }
-    }
-    natt += (uint32_t)k;
-  }
+  for (uint32_t i = 0; i < ndec; ++i) if (!decode_descriptors(L, D, r, i, natt, &dec[i].first_att, &dec[i].num_atts)) return false;
   D->num_attributes = natt;
   // ---------------------------------------------------------------- per decoder: sequence, values
   uint8_t *fvis = G + g.fvis, *vvis = G + g.vvis;
@@ -758,130 +960,15 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
         map[point] = (uint32_t)e;
       }
     }
-    // values of every attribute, SequentialAttributeDecodersController.cs:29-38
-    for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) {
-      AttrDesc &a = D->att[ai];
-      a.num_entries = entries;
-      a.pred_method = -2; a.pred_transform = -1; a.have_scheme = 0; a.pred_kind = 0;
-      if (a.seq_type == 0) {                               // SequentialAttributeDecoder.cs:75-86
-        a.source = SRC_BYTES;
-        a.off_raw = r.pos;
-        const uint64_t bytes = (uint64_t)data_type_length(a.data_type) * a.nc * entries;
-        GREQ(bytes <= L.out_cap[ai], 140);
-        r.skip(bytes);
-        GREQ(r.ok, 141);
-        continue;
-      }
-      const uint32_t nc = a.seq_type == 3 ? 2u : a.nc;
-      a.nc_portable = (uint8_t)nc;
-      const uint64_t num_values = (uint64_t)entries * nc;
-      GREQ(num_values <= L.work_cap[ai], 142);
-      int32_t *w = (int32_t *)(arena + L.work[ai]);
-      const int method = (int8_t)r.u8();
-      GREQ(r.ok && method >= -2 && method < 7, 143);
-      a.pred_method = (int8_t)method;
-      int tt = -1;
-      if (method != -2) {
-        tt = (int8_t)r.u8();
-        GREQ(r.ok && tt >= -1 && tt < 4, 144);
-        a.pred_transform = (int8_t)tt;
-        a.have_scheme = a.seq_type == 3 ? (tt == 2 || tt == 3) : (tt == 1);
-      }
-      const uint32_t compressed = r.u8();
-      GREQ(r.ok, 145);
-      a.source = SRC_RAW;
-      if (compressed > 0) {
-        if (!decode_symbols(D, r, (uint32_t)num_values, nc, (uint32_t *)w, cum, g.cum_entries)) return false;
-      } else {                                             // SequentialIntegerAttributeDecoder.cs:68-84 (D-13)
-        const uint32_t nb = r.u8();
-        GREQ(r.ok && nb >= 1 && nb <= 4, 158);
-        for (uint64_t k = 0; k < num_values; ++k) { uint32_t v = 0; for (uint32_t q = 0; q < nb; ++q) v |= r.u8() << (8 * q); ((uint32_t *)w)[k] = v; }
-        GREQ(r.ok, 160);
-      }
-      const bool positive = a.have_scheme && (tt == 2 || tt == 3);      // D-4
-      if (num_values > 0 && !positive)
-        for (uint64_t k = 0; k < num_values; ++k) { const uint32_t sv = ((uint32_t *)w)[k]; w[k] = (sv & 1u) ? -(int32_t)(sv >> 1) - 1 : (int32_t)(sv >> 1); }
-      if (!a.have_scheme) continue;
-      // scheme selection, PredictionSchemeDecoderFactory.cs:9-76
-      int eff = method;
-      if (!(method == 1 || method == 5)) { if (method == 0) eff = 0; else GNOTIMPL(161); }
-      a.pred_kind = (int8_t)eff;
-      const bool use_act = dd >= 0 && data_conn_used[dd];
-      uint8_t *orient = nullptr;
-      uint32_t num_orient = 0;
-      if (eff == 5) {                                      // MeshPredictionSchemeTexCoordsPortableDecoder.cs:66-85
-        GREQ(dd >= 0, 680);                                // orientation scratch lives in the attribute data block
-        const int32_t num_or = (int32_t)r.u32();
-        GREQ(r.ok && num_or >= 0 && (uint32_t)num_or <= NVMAX, 681);
-        Rabs rd;
-        rd.start(s, L.stream_len, r.pos, &endp);
-        GREQ(rd.ok, 682);
-        r.pos = endp;
-        orient = G + g.data + (uint64_t)dd * g.data_stride + g.orient;
-        bool last = true;
-        for (int32_t k = 0; k < num_or; ++k) { if (rd.next() == 0) last = !last; orient[k] = last ? 1 : 0; }
-        num_orient = (uint32_t)num_or;
-      }
-      if (tt == 1) {                                       // PredictionSchemeWrapDecodingTransform.cs:69-75
-        a.wrap_min = (int32_t)r.u32(); a.wrap_max = (int32_t)r.u32();
-        GREQ(r.ok && a.wrap_min <= a.wrap_max, 162);
-        const int64_t dif = (int64_t)a.wrap_max - (int64_t)a.wrap_min;
-        GREQ(dif < 0x7FFFFFFF, 163);
-        const int32_t mn = a.wrap_min, mx = a.wrap_max, max_dif = (int32_t)(1 + dif);
-        if (num_values == 0) continue;
-        if (eff == 0) {                                    // PredictionSchemeDeltaDecoder.cs:23-37
-          for (uint32_t c = 0; c < nc; ++c) w[c] = wrap_original(0, w[c], mn, mx, max_dif);
-          for (uint64_t k = nc; k < num_values; ++k) w[k] = wrap_original(w[k - nc], w[k], mn, mx, max_dif);
-        } else if (eff == 1) {
-          if (use_act) parallelogram_wrap(act[dd], d2c, v2d, entries, nc, w, mn, mx, max_dif);
-          else parallelogram_wrap(ct, d2c, v2d, entries, nc, w, mn, mx, max_dif);
-        } else {
-          GREQ(nc == 2, 683);
-          // parent = portable positions, SequentialAttributeDecoder.cs:58-73
-          int pa = -1;
-          for (uint32_t q = 0; q < ai; ++q) if (D->att[q].att_type == 0 && D->att[q].seq_type != 0) { pa = (int)q; break; }
-          GREQ(pa >= 0 && D->att[pa].nc_portable == 3, 684);
-          const int32_t *pos = (const int32_t *)(arena + L.work[pa]);
-          const uint32_t *pos_map = (const uint32_t *)(arena + L.map[pa]);
-          bool ok;
-          if (use_act) ok = texcoords_portable_wrap(D, act[dd], d2c, v2d, entries, w, pids, pos, pos_map, num_points, D->att[pa].num_entries, orient, num_orient, mn, mx, max_dif);
-          else ok = texcoords_portable_wrap(D, ct, d2c, v2d, entries, w, pids, pos, pos_map, num_points, D->att[pa].num_entries, orient, num_orient, mn, mx, max_dif);
-          if (!ok) return false;
-        }
-      } else {                                             // normal octahedron transforms (D-19)
-        GREQ(eff == 0, 501);
-        const int32_t max_q = (int32_t)r.u32();
-        if (tt == 3) (void)r.u32();
-        GREQ(r.ok && max_q > 0 && (max_q & 1) == 1, 164);
-        a.oct_max_q = max_q;
-        if (num_values == 0) continue;
-        OctParams o;
-        const int q = 32 - __builtin_clz((uint32_t)max_q);
-        GREQ(q >= 2 && q <= 30, 165);
-        const int32_t max_value = (1 << q) - 2;
-        o.center = max_value / 2; o.max_q = (1 << q) - 1;
-        int32_t ps = 0, pt = 0;
-        for (uint32_t e = 0; e < entries; ++e) {
-          int32_t os, ot;
-          oct_original(o, tt == 3, ps, pt, w[2 * e], w[2 * e + 1], os, ot);
-          w[2 * e] = os; w[2 * e + 1] = ot;
-          ps = os; pt = ot;
-        }
-      }
-    }
-    // transform parameters follow the values of the decoder's attributes, AttributesDecoder.cs:65-70
-    for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) {
-      AttrDesc &a = D->att[ai];
-      if (a.seq_type == 2) {                               // AttributeQuantizationTransform.cs:110-121
-        for (uint32_t c = 0; c < a.nc; ++c) a.q_min[c] = r.f32();
-        a.q_range = r.f32();
-        a.q_bits = (uint8_t)r.u8();
-        GREQ(r.ok && a.q_bits >= 1 && a.q_bits <= 30, 135);
-      } else if (a.seq_type == 3) {                        // AttributeOctahedronTransform.cs:39-42 (D-5)
-        a.q_bits = (uint8_t)r.u8();
-        GREQ(r.ok && a.q_bits >= 2 && a.q_bits <= 30, 136);
-      }
-    }
+    // values, then transform parameters, of every attribute of the decoder (SequentialAttributeDecodersController.cs:29-38,
+    // AttributesDecoder.cs:65-70)
+    ValueCtx vc;
+    vc.ct = &ct; vc.act = (dd >= 0 && data_conn_used[dd]) ? &act[dd] : nullptr;
+    vc.d2c = d2c; vc.v2d = v2d; vc.pids = pids;
+    vc.orient = dd >= 0 ? G + g.data + (uint64_t)dd * g.data_stride + g.orient : nullptr;
+    vc.orient_cap = NVMAX; vc.num_points = num_points;
+    for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) if (!decode_values(arena, L, D, r, ai, entries, cum, g.cum_entries, vc)) return false;
+    for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) if (!decode_transform_params(D, r, ai)) return false;
   }
   D->end_pos = r.pos;
   return true;
@@ -901,7 +988,8 @@ __global__ __launch_bounds__(WAVE) void k_general(uint8_t *arena, const MeshLayo
   if (!D->general || status_of(D) != ST_OK) return;
   const MeshLayout &L = layouts[mesh];
   Rd r(arena + L.stream, L.stream_len, D->end_pos);       // k_locate parked the reader behind the header
-  (void)gen::decode_mesh(arena, L, D, r);
+  if (D->encoder_method == 0) (void)gen::decode_sequential_mesh(arena, L, D, r);
+  else (void)gen::decode_mesh(arena, L, D, r);
 }
 
 #endif

@@ -123,6 +123,7 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m) {
   }
   if (type > 1) return bad(ST_INVALID);
   const bool point_cloud = type == 0;
+  const bool linear = point_cloud || method == 0;          // no decoder triples: linear sequencing
   if (point_cloud) {
     if (method > 1) return bad(ST_INVALID);
     if (method != 0) return bad(ST_NOTIMPL);                  // kd-tree point clouds
@@ -131,9 +132,23 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m) {
     // cannot claim the arena of the whole batch (a real stream spends at least a fraction of a bit per element)
     if (!r.ok || np > 0x7FFFFFFFu || np > 1024ull * len) return bad(ST_INVALID);
     m.faces = 0; m.enc_vertices = np; m.split_symbols = 0; m.splits = 0; m.num_att_data = 0;
+  } else if (method == 0) {
+    // sequential mesh (Mesh/MeshSequentialDecoder.cs:8-123): decoded by the general path
+    const uint64_t nf = r.varint(), np = r.varint();
+    if (!r.ok || nf > 0x7FFFFFFFu / 3 || np > 0x7FFFFFFFu || nf > 1024ull * len || np > 1024ull * len) return bad(ST_INVALID);
+    const uint32_t cm = r.u8();
+    if (cm == 0) host_skip_symbols(r, 3 * nf, 1);
+    else if (cm == 1) {
+      if (np < 256) r.skip(3 * nf);
+      else if (np < (1u << 16)) r.skip(6 * nf);
+      else if (np < (1u << 21)) { for (uint64_t k = 0; k < 3 * nf && r.ok; ++k) (void)r.varint(); }
+      else r.skip(12 * nf);
+    } else return bad(ST_INVALID);
+    if (!r.ok) return bad(ST_INVALID);
+    m.faces = (uint32_t)nf; m.enc_vertices = (uint32_t)np; m.split_symbols = 0; m.splits = 0; m.num_att_data = 0;
+    m.general = true;
   } else {
     if (method > 1) return bad(ST_INVALID);
-    if (method == 0) return bad(ST_NOTIMPL);
     uint32_t traversal = r.u8();
     if (!r.ok || traversal > 2) return bad(ST_INVALID);
     if (traversal == 1) return bad(ST_NOTIMPL);                  // predictive traversal
@@ -165,7 +180,7 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m) {
   uint32_t ndec = r.u8();
   if (!r.ok || ndec > DSA_MAX_ATT) return bad(ST_INVALID);
   bool corner_dec[DSA_MAX_ATT + 1] = {};
-  if (!point_cloud) for (uint32_t i = 0; i < ndec; ++i) {
+  if (!linear) for (uint32_t i = 0; i < ndec; ++i) {
     (void)r.u8();
     corner_dec[i] = r.u8() != 0;                                // MeshAttributeElementType: corner attribute
     (void)r.u8();

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayou
   }
   REQUIRE(D->encoder_type <= 1, 105);
   if (L.gen_bytes != 0) {               // the host sized this mesh for the general path (dsa_general.h): k_general parses the rest
-    REQUIRE(D->encoder_type == 1 && D->encoder_method == 1, 107);
+    REQUIRE(D->encoder_type == 1 && D->encoder_method <= 1, 107);
     D->general = 1;
     D->end_pos = r.pos;
     return;

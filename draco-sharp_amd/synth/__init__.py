@@ -40,6 +40,8 @@ def lib():
                                         C.c_void_p, C.POINTER(Options), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.synth_encode_point_cloud.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Options), C.POINTER(C.c_void_p),
                                                C.POINTER(C.c_size_t)]
+        L.synth_encode_mesh_sequential.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,
+                                                   C.POINTER(Options), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.synth_free.argtypes = [C.c_void_p]
         L.synth_make_mesh.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -93,6 +95,25 @@ def encode_mesh(pos, faces, normals=None, uvs=None, generic=None, opt=None):
     rc = L.synth_encode_mesh(pos.ctypes.data, len(pos), faces.ctypes.data, len(faces),
                              None if nrm is None else nrm.ctypes.data, None if uv is None else uv.ctypes.data,
                              None if gen is None else gen.ctypes.data, C.byref(opt), C.byref(out), C.byref(n))
+    if rc:
+        raise RuntimeError(_err())
+    data = C.string_at(out, n.value)
+    L.synth_free(out)
+    return data
+
+
+def encode_mesh_sequential(pos, faces, normals=None, uvs=None, compressed=True, opt=None):
+    """Sequential mesh stream (MeshSequentialEncoder): faces as point indices, attributes in point order."""
+    L = lib()
+    pos = np.ascontiguousarray(pos, np.float32)
+    faces = np.ascontiguousarray(faces, np.uint32)
+    nrm = None if normals is None else np.ascontiguousarray(normals, np.float32)
+    uv = None if uvs is None else np.ascontiguousarray(uvs, np.float32)
+    out, n = C.c_void_p(), C.c_size_t()
+    opt = opt or options()
+    rc = L.synth_encode_mesh_sequential(pos.ctypes.data, len(pos), faces.ctypes.data, len(faces),
+                                        None if nrm is None else nrm.ctypes.data, None if uv is None else uv.ctypes.data,
+                                        1 if compressed else 0, C.byref(opt), C.byref(out), C.byref(n))
     if rc:
         raise RuntimeError(_err())
     data = C.string_at(out, n.value)

@@ -149,6 +149,18 @@ int synth_encode_mesh(const float *pos, uint32_t nv, const uint32_t *faces, uint
     return 0;
   } catch (const std::exception &e) { snprintf(g_err, sizeof(g_err), "%s", e.what()); return 1; }
 }
+int synth_encode_mesh_sequential(const float *pos, uint32_t nv, const uint32_t *faces, uint32_t nf, const float *normals,
+                                 const float *uvs, int compressed, const synth_options *opt, uint8_t **out, size_t *out_len) {
+  try {
+    synth::MeshIn in{pos, nv, faces, nf, normals, uvs, nullptr};
+    std::vector<uint8_t> buf;
+    synth::encode_mesh_sequential(in, to_opt(opt), compressed != 0, buf);
+    *out = (uint8_t *)malloc(buf.size() ? buf.size() : 1);
+    memcpy(*out, buf.data(), buf.size());
+    *out_len = buf.size();
+    return 0;
+  } catch (const std::exception &e) { snprintf(g_err, sizeof(g_err), "%s", e.what()); return 1; }
+}
 int synth_encode_point_cloud(const float *pos, uint32_t n, const synth_options *opt, uint8_t **out, size_t *out_len) {
   try {
     std::vector<uint8_t> buf;

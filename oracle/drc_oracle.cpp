@@ -712,6 +712,7 @@ struct Mesh {
   int major = 0, minor = 0, encoder_type = 0, encoder_method = 0, flags = 0;
   int traversal_type = -1;
   bool is_point_cloud = false;
+  bool is_sequential = false;        // sequential mesh: faces stored as point indices, linear attribute sequencing
   // connectivity
   CornerTable ct;
   std::vector<uint8_t> is_vert_hole;
@@ -1149,7 +1150,7 @@ struct AttributeSectionDecoder {
   void decode() {
     int num_decoders = b.u8();
     m.decoders.assign(num_decoders, AttDecoder());
-    if (!m.is_point_cloud) {
+    if (!m.is_point_cloud && !m.is_sequential) {
       int pos_decoder = -1;
       for (int i = 0; i < num_decoders; ++i) {      // MeshEdgeBreakerDecoder.cs:640-708
         AttDecoder &d = m.decoders[i];
@@ -1205,7 +1206,7 @@ struct AttributeSectionDecoder {
   void decode_attributes(int di) {
     AttDecoder &d = m.decoders[di];
     // sequence
-    if (m.is_point_cloud) {                         // LinearSequencer.cs:3-19
+    if (m.is_point_cloud || m.is_sequential) {      // LinearSequencer.cs:3-19
       d.point_ids.resize(m.num_points);
       for (uint32_t i = 0; i < m.num_points; ++i) d.point_ids[i] = i;
     } else {
@@ -1294,7 +1295,7 @@ struct AttributeSectionDecoder {
     int eff = method;
     const AttrCornerTable *act = nullptr;
     EncodingData *ed = nullptr;
-    if (m.is_point_cloud) eff = 0;
+    if (m.is_point_cloud || m.is_sequential) eff = 0;   // no corner table: PredictionSchemeDecoderFactory.cs:24-36,58-61
     else {
       ed = encoding_data_for(aid);
       act = att_corner_table_for(aid);
@@ -1421,7 +1422,40 @@ static void decode(const uint8_t *data, size_t len, Mesh &m) {
     AttributeSectionDecoder ad(b, m);
     ad.decode();
   } else if (m.encoder_type == 1) {
-    if (m.encoder_method == 0) throw Error(ERR_NOT_IMPLEMENTED, "sequential mesh decoding is not implemented");
+    if (m.encoder_method == 0) {
+      // Mesh/MeshSequentialDecoder.cs:8-123.  D-22: the C# tests the sign bit inverted (:100) relative to its own
+      // encoder (MeshSequentialEncoder.cs:79) and to the bitstream: LSB set = negative difference.
+      m.is_sequential = true;
+      uint32_t nf = (uint32_t)b.varint(), np = (uint32_t)b.varint();
+      require(nf <= 0x7FFFFFFFu / 3, "too many faces");
+      uint8_t method = b.u8();
+      m.faces.assign((size_t)nf * 3, 0);
+      if (method == 0) {
+        std::vector<uint32_t> sym;
+        decode_symbols(b, nf * 3, 1, sym);
+        int32_t last = 0;
+        for (size_t k = 0; k < (size_t)nf * 3; ++k) {
+          uint32_t e = sym[k];
+          int32_t diff = (int32_t)(e >> 1);
+          if (e & 1) { require(diff <= last, "negative point index"); diff = -diff; }
+          else require(diff <= 0x7FFFFFFF - last, "point index overflow");
+          last += diff;
+          m.faces[k] = last;
+        }
+      } else if (method == 1) {
+        for (size_t k = 0; k < (size_t)nf * 3; ++k) {
+          if (np < 256) m.faces[k] = b.u8();
+          else if (np < (1u << 16)) m.faces[k] = b.u16();
+          else if (np < (1u << 21)) m.faces[k] = (int32_t)b.varint();
+          else m.faces[k] = (int32_t)b.u32();
+        }
+      } else require(false, "unsupported sequential connectivity method");
+      m.num_points = np;
+      AttributeSectionDecoder ad(b, m);
+      ad.decode();
+      m.end_pos = b.pos;
+      return;
+    }
     require(m.encoder_method == 1, "unsupported encoder method");
     m.traversal_type = b.u8();
     if (m.traversal_type == 1) throw Error(ERR_NOT_IMPLEMENTED, "predictive Edgebreaker traversal is not implemented");
@@ -1478,14 +1512,14 @@ void orc_header(const orc_mesh *h, int32_t out[8]) {
   out[0] = m.major; out[1] = m.minor; out[2] = m.encoder_type; out[3] = m.encoder_method;
   out[4] = m.flags; out[5] = m.traversal_type; out[6] = (int32_t)m.att_data.size(); out[7] = (int32_t)m.end_pos;
 }
-uint32_t orc_num_faces(const orc_mesh *h) { return h->m.is_point_cloud ? 0 : h->m.ct.num_faces(); }
+uint32_t orc_num_faces(const orc_mesh *h) { return h->m.is_point_cloud ? 0 : (h->m.is_sequential ? (uint32_t)(h->m.faces.size() / 3) : h->m.ct.num_faces()); }
 uint32_t orc_num_points(const orc_mesh *h) { return h->m.num_points; }
 uint32_t orc_num_vertices(const orc_mesh *h) { return h->m.ct.num_vertices(); }
 uint32_t orc_num_attributes(const orc_mesh *h) { return (uint32_t)h->m.atts.size(); }
 uint32_t orc_num_decoders(const orc_mesh *h) { return (uint32_t)h->m.decoders.size(); }
 void orc_faces(const orc_mesh *h, int32_t *out) { memcpy(out, h->m.faces.data(), h->m.faces.size() * 4); }
 void orc_corner_table(const orc_mesh *h, uint32_t *opp, uint32_t *c2v, uint32_t *vcorner) {
-  const orc::CornerTable &ct = h->m.ct;
+  const orc::CornerTable &ct = h->m.ct;   // empty for sequential meshes (the caller's arrays stay as they are)
   if (opp) memcpy(opp, ct.opp.data(), ct.opp.size() * 4);
   if (c2v) memcpy(c2v, ct.c2v.data(), ct.c2v.size() * 4);
   if (vcorner) memcpy(vcorner, ct.vcorner.data(), ct.vcorner.size() * 4);
@@ -1504,7 +1538,7 @@ void orc_decoder_sequence(const orc_mesh *h, uint32_t d, uint32_t *point_ids, ui
   const orc::Mesh &m = h->m;
   const orc::AttDecoder &x = m.decoders[d];
   if (point_ids) memcpy(point_ids, x.point_ids.data(), x.point_ids.size() * 4);
-  if (data_to_corner && !m.is_point_cloud) {
+  if (data_to_corner && !m.is_point_cloud && !m.is_sequential) {
     const orc::EncodingData &ed = x.att_data_id < 0 ? m.pos_enc : m.att_data[x.att_data_id].enc;
     memcpy(data_to_corner, ed.data_to_corner.data(), ed.data_to_corner.size() * 4);
   }

@@ -61,7 +61,8 @@ static bool run(const uint8_t *data, size_t len, bool force, Result &R) {
   }
   R.D.general = 1;
   dsa::Rd r(R.arena.data(), (uint32_t)len, (uint32_t)hr.pos);
-  (void)dsa::gen::decode_mesh(R.arena.data(), R.L, &R.D, r);
+  if (R.D.encoder_method == 0) (void)dsa::gen::decode_sequential_mesh(R.arena.data(), R.L, &R.D, r);
+  else (void)dsa::gen::decode_mesh(R.arena.data(), R.L, &R.D, r);
   ASAN_UNPOISON_MEMORY_REGION(R.arena.data(), R.arena.size());
   return true;
 }

@@ -165,6 +165,27 @@ def test_point_cloud_sequential(ctx):
     b.close()
 
 
+def test_sequential_meshes(ctx):
+    """MeshSequentialDecoder streams (faces as point indices, linear attribute order): raw index widths u8 / u16 /
+    varint and the compressed form; both symbol schemes."""
+    streams = []
+    for kind, nx, ny in ((synth.GRID, 9, 7), (synth.TORUS, 20, 16), (synth.GRID, 300, 250)):
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 3)
+        for compressed in (True, False):
+            streams.append(synth.encode_mesh_sequential(pos, faces, nrm, uv, compressed=compressed))
+    pos, nrm, uv, faces = synth.make_mesh(synth.SPHERE, 8, 7, 3)
+    streams.append(synth.encode_mesh_sequential(pos, faces, None, uv, compressed=True, opt=synth.options(force_scheme=0)))
+    b = run_batch(ctx, streams)
+    for i, sbytes in enumerate(streams):
+        ref = oracle.decode(sbytes)
+        assert b.status(i) == 0, (i, b.status(i), b.mesh_info(i).detail)
+        got = b.result(i)
+        assert got.Header.EncoderMethod == 0 and np.array_equal(got.ConnectedData.Faces, ref.faces)
+        assert got.ConnectedData.PointsCount == ref.num_points
+        assert_same_attributes(got.ConnectedData, ref)
+    b.close()
+
+
 def _corruptions(data, count, seed):
     rng = np.random.default_rng(seed)
     out = []

@@ -74,12 +74,28 @@ def test_synthetic_meshes_through_the_general_path_source(exe, tmp_path, kind, n
     assert_equals_oracle(got, oracle.decode(data))
 
 
+@pytest.mark.parametrize("compressed", [True, False])
+def test_sequential_mesh_through_the_general_path_source(exe, tmp_path, compressed):
+    pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 20, 16, 7)
+    data = synth.encode_mesh_sequential(pos, faces, nrm, uv, compressed=compressed)
+    status, detail, got = host_decode(exe, data, tmp_path, force=False)
+    assert status == 0, detail
+    ref = oracle.decode(data)
+    faces_got, npnt, atts = got
+    assert np.array_equal(faces_got, ref.faces) and npnt == ref.num_points
+    for (entries, pmap, portable), r in zip(atts, ref.attributes):
+        assert entries == r.num_entries and np.array_equal(pmap, np.arange(npnt, dtype=np.uint32))
+        assert np.array_equal(portable, r.portable)
+
+
 def test_corrupt_streams_never_leave_their_regions(exe, house04_bytes, tmp_path):
     """Bit flips, random bytes, truncations and bursts: every gap between arena regions is poisoned, so any
     out-of-bounds access of the general path aborts the run."""
     pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 10, 8, 3)
     cases = [(house04_bytes, 3000, False), (synth.encode_mesh(pos, faces, nrm, uv), 1500, True),
-             (synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(force_scheme=0, single_connectivity=1)), 1500, True)]
+             (synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(force_scheme=0, single_connectivity=1)), 1500, True),
+             (synth.encode_mesh_sequential(pos, faces, nrm, uv, compressed=True), 1000, False),
+             (synth.encode_mesh_sequential(pos, faces, nrm, uv, compressed=False), 1000, False)]
     for k, (data, iters, force) in enumerate(cases):
         src = tmp_path / ("fuzz%d.drc" % k)
         src.write_bytes(data)
