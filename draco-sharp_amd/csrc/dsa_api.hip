@@ -285,7 +285,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     const uint32_t per = (n + split - 1) / split;
     for (uint32_t m0 = 0; m0 < n; m0 += per) {
       const uint32_t cnt = std::min(per, n - m0);
-      hipLaunchKernelGGL(dsa::k_traverse, dim3(cnt), dim3(WAVE), 0, st, b->arena, b->d_layouts + m0, b->d_descs + m0, cnt, fuse_operands ? 1u : 0u);
+      hipLaunchKernelGGL(dsa::k_traverse, dim3(cnt), dim3(WAVE), 0, st, b->arena, b->d_layouts + m0, b->d_descs + m0, cnt, (fuse_operands ? 1u : 0u) | (getenv("DSA_TRAV_NO_WINDOW") ? 0u : 2u));   // bit 1: adaptive run window (diagnostics switch)
     }
   }
   HIP_TRY(ctx, mark());

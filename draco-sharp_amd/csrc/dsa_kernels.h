@@ -1098,6 +1098,10 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   int64_t step = 0, dd = 0;
   uint32_t backoff = 0;       // scalar steps to take before speculating again
   uint32_t fail_streak = 0;   // attempts in a row that retired nothing
+  // Pairs the next attempt loads and checks (its memory traffic is proportional to it).  A run that ended on a turn
+  // of the spiral predicts the following sides: they grow by one pair per ring, and sides cut by the boundary
+  // alternate, so the window is the longer of the last two such runs plus a margin; anything else opens it fully.
+  uint32_t window = WAVE, side1 = WAVE, side2 = WAVE;
   uint32_t n_run = 0, n_run_faces = 0, n_scalar = 0, n_fail = 0;
   bool failed = false;
 #ifdef DSA_TRAV_HIST
@@ -1184,7 +1188,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           exact = corner_ok(a3) ? 4 : (corner_ok(a2) ? 3 : (corner_ok(a1) ? 2 : 1));
           step = d1; dd = ddh;               // provisional; replaced below from the verified chain
         }
-        a_ok = ai >= 0 && ai < (int64_t)4 * F && ((uint32_t)ai & 3u) != 3u && (lane < exact || have_step || exact == 4);
+        a_ok = lane < window && ai >= 0 && ai < (int64_t)4 * F && ((uint32_t)ai & 3u) != 3u && (lane < exact || have_step || exact == 4);
         const uint32_t a = a_ok ? (uint32_t)ai : 0u;
         // pair `lane`: N element at a (face A), L element at b = Opposite(Next(a)) (face B)
         const uint32_t fa = a >> 2, ka = a & 3u;
@@ -1287,6 +1291,8 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           // Pair K lies on the verified path but is not an (N L) pair (a turn of the spiral, a boundary
           // vertex, a split): re-attempting from it would reach the same verdict, so step over it first.
           if (K < WAVE && len > K) { backoff = 1; have_step = false; }
+          if ((fuse_operands & 2u) && K < window && len > K) { side2 = side1; side1 = K; const uint32_t m = (side1 > side2 ? side1 : side2) + 4; window = m < WAVE ? m : WAVE; }
+          else window = WAVE;
           continue;
         }
         ++n_fail;
@@ -1338,7 +1344,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   }
   // Large batches: the wave that just produced the order also derives the parallelogram operands of its mesh, while
   // other meshes are still being traversed (small batches use the element-parallel k_para_operands instead).
-  if (fuse_operands && count == D->num_enc_vertices) {
+  if ((fuse_operands & 1u) && count == D->num_enc_vertices) {
     uint32_t *para = (uint32_t *)(arena + L.para);
     for (uint32_t p = lane; p < count; p += WAVE) para_operands_of(p, frec, d2c, v2d, F, NV, para);
   }
