@@ -542,6 +542,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
 
 #ifdef DSA_LOOP_PROFILE
   uint64_t acc_c = 0, acc_rl = 0, acc_fetch = 0, tp = clk();
+  uint32_t prof_run_syms = 0, prof_runs = 0;
   uint32_t n_c = 0, n_rl = 0;
 #define PROF(acc, cnt) { uint64_t t_ = clk(); acc += t_ - tp; tp = t_; ++cnt; }
 #else
@@ -581,19 +582,24 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
       }
       if (cand >= 4) {
         flush_stage(sid);                  // the run writes face records straight to global memory
-        WAIT_VM0();
         const uint32_t f0 = sid, nv0 = num_verts;
         const uint32_t vx0 = T1, va0 = T2;
-        const uint2 r0 = vrec[vx0];
-        const int32_t delta = (int32_t)uni(r0.y) - (int32_t)vx0;
+        // vertex records of the candidate pairs in both directions at once (lane 0 holds vx0's own record in
+        // either); the direction is the step to the vertex behind vx0's left-most corner
+        const int64_t idp = (int64_t)vx0 + (int64_t)lane, idm = (int64_t)vx0 - (int64_t)lane;
+        const bool okp = lane < cand && idp < (int64_t)nv0, okm = lane < cand && idm >= 0 && idm < (int64_t)nv0;
+        uint2 rp = make_uint2(DSA_INVALID, DSA_INVALID), rm = rp;
+        if (okp) rp = vrec[(uint32_t)idp];
+        if (okm) rm = vrec[(uint32_t)idm];
+        const int32_t delta = (int32_t)rdlane(rp.y, 0) - (int32_t)vx0;
         uint32_t k = 0;
         uint2 rj = make_uint2(DSA_INVALID, DSA_INVALID);
         uint32_t vxj = 0;
         if (delta == 1 || delta == -1) {
-          const int64_t id = (int64_t)vx0 + (int64_t)delta * (int64_t)lane;
-          const bool idok = lane < cand && id >= 0 && id < (int64_t)nv0 && (uint32_t)id != va0;
+          const int64_t id = delta == 1 ? idp : idm;
+          const bool idok = (delta == 1 ? okp : okm) && (uint32_t)id != va0;
           vxj = (uint32_t)id;
-          if (idok) rj = vrec[vxj];
+          rj = delta == 1 ? rp : rm;
           const uint32_t prev_nv = lane_prev(rj.y);
           // own record must be sane, and the previous pair must hand over exactly this vertex
           bool ok = idok && rj.x < 4 * f0 && (rj.x & 3u) != 3u && rj.y < nv0 && rj.y != vxj && (lane == 0 || prev_nv == vxj);
@@ -630,6 +636,9 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
           num_verts = nv0 + k;
           sid += 2 * k;
           n_links += 3 * k;
+#ifdef DSA_LOOP_PROFILE
+          prof_run_syms += 2 * k; ++prof_runs;
+#endif
           stage_base = sid;
           bits_used += 4ull * k;
           {                                 // consume 4k bits: first from the buffer, the rest from the window
@@ -637,8 +646,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
             if (need <= bcnt) { bb = need >= 64 ? 0 : bb >> need; bcnt -= need; }
             else { need -= bcnt; bb = 0; bcnt = 0; widx += need >> 5; const uint32_t rem = need & 31u; if (rem) { const uint32_t wv = uni(sh_win[widx - wbase]); bb = (uint64_t)(wv >> rem); bcnt = 32 - rem; ++widx; } }
           }
-          WAIT_VM0();
-          __syncthreads();
+          __syncthreads();                   // the wave's own stores are seen by its later loads: no drain needed
           continue;
         }
       }
@@ -940,6 +948,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
 #ifdef DSA_LOOP_PROFILE
     D->dbg[5] = (uint32_t)(acc_c / (n_c ? n_c : 1)); D->dbg[6] = (uint32_t)(acc_rl / (n_rl ? n_rl : 1));
     D->dbg[7] = (uint32_t)(acc_fetch / (n_c + n_rl + 1)); D->dbg[8] = n_c; D->dbg[9] = n_rl;
+    D->dbg[10] = prof_run_syms | (prof_runs << 20); D->dbg[11] = n_c | (n_rl << 16);
 #endif
   }
 #undef CN_FAIL
