@@ -1753,69 +1753,61 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
     const uint32_t M = (uint32_t)max_dif;
     const bool para_mode = a.pred_kind == 1;
     const uint32_t *para = (const uint32_t *)(arena + L.para);
+    // Every lane's prediction has the form  base + (o[ga] - o[gb])  with finished entries ga, gb (or none):
+    //   lane 0:   base = o[p-1] (delta, or a parallelogram that contains entry p-1), o[next] for a parallelogram of
+    //             three older entries, 0 for the first entry -- read from memory;
+    //   lane i>0: base = the value of lane i-1 in this run -- only entries whose prediction contains p-1 (or falls
+    //             back to delta) and whose other operands are finished can join the run.
+    // Small ranges (M < 2^25) scan plain sums with one DPP add per step and reduce modulo M once.
+    const bool small_m = M < (1u << 25);
+    const float inv_m = 1.0f / (float)M;
     uint32_t p0 = 0;
     while (p0 < entries) {
       const uint32_t p = p0 + lane;
       const bool live = p < entries;
-      // operands: chain on p-1 plus (ga - gb), or a full prediction for lane 0
       uint32_t en = DSA_INVALID, ep = 0, eo = 0;
       if (live && para_mode && p > 0) { en = para[3 * p]; ep = para[3 * p + 1]; eo = para[3 * p + 2]; }
-      bool chain = false;       // lane can join the run
-      uint32_t ga = DSA_INVALID, gb = DSA_INVALID;   // finished entries: g = o[ga] - o[gb] (INVALID -> 0)
-      if (live && lane > 0) {
-        if (en == DSA_INVALID) chain = true;                                       // delta fallback: pred = o[p-1]
-        else if (en == p - 1 && ep < p0 && eo < p0) { chain = true; ga = ep; gb = eo; }
-        else if (ep == p - 1 && en < p0 && eo < p0) { chain = true; ga = en; gb = eo; }
+      uint32_t ga = DSA_INVALID, gb = DSA_INVALID, bidx = DSA_INVALID;
+      bool chain = false;
+      if (live) {
+        if (en == DSA_INVALID) { chain = true; }                                            // delta: pred = o[p-1]
+        else if (en == p - 1) { ga = ep; gb = eo; chain = ep < p0 && eo < p0; }
+        else if (ep == p - 1) { ga = en; gb = eo; chain = en < p0 && eo < p0; }
+        else { ga = ep; gb = eo; bidx = en; }                                               // three older entries
+        if (bidx == DSA_INVALID && p > 0) bidx = p - 1;
       }
       // run = lane 0 + leading chain lanes
-      uint64_t not_chain = __ballot(!chain) & ~1ull;
+      const uint64_t not_chain = __ballot(!chain) & ~1ull;
       uint32_t run = not_chain ? (uint32_t)__builtin_ctzll(not_chain) : WAVE;
       if (p0 + run > entries) run = entries - p0;
       const bool in_run = lane < run;
       int32_t corr[4], g[4], o[4];
-      uint32_t red[4];
-#pragma unroll
-      for (uint32_t c = 0; c < 4; ++c) { corr[c] = 0; g[c] = 0; o[c] = 0; red[c] = 0; }
-      if (in_run) {
-#pragma unroll
-        for (uint32_t c = 0; c < 4; ++c) if (c < nc) corr[c] = w[p * nc + c];
-        if (lane == 0) {
-          // exact reference step for the first entry of the run
-          int32_t pred[4] = {0, 0, 0, 0};
-          if (p > 0) {
-            if (en != DSA_INVALID) {
-#pragma unroll
-              for (uint32_t c = 0; c < 4; ++c) if (c < nc) pred[c] = (int32_t)((uint32_t)w[en * nc + c] + (uint32_t)w[ep * nc + c] - (uint32_t)w[eo * nc + c]);
-            } else {
-#pragma unroll
-              for (uint32_t c = 0; c < 4; ++c) if (c < nc) pred[c] = w[(p - 1) * nc + c];
-            }
-          }
-#pragma unroll
-          for (uint32_t c = 0; c < 4; ++c) if (c < nc) o[c] = wrap_original(pred[c], corr[c], mn, mx, max_dif);
-        } else if (ga != DSA_INVALID) {
-#pragma unroll
-          for (uint32_t c = 0; c < 4; ++c) if (c < nc) g[c] = (int32_t)((uint32_t)w[ga * nc + c] - (uint32_t)w[gb * nc + c]);
-        }
-      }
-      // modular prefix sum of (g + corr) over lanes 1..run-1, seeded with lane 0's value.  Residues are
-      // formed without division: real corrections keep |g + corr| < 2M; a lane outside that range (or a
-      // seed outside [mn, mx]) ends the run in front of it and is decoded by the exact step of the next run.
+      uint32_t xr[4];
       bool irregular = false;
-      uint32_t xr[4] = {0, 0, 0, 0};
 #pragma unroll
       for (uint32_t c = 0; c < 4; ++c) {
+        corr[c] = 0; g[c] = 0; o[c] = 0; xr[c] = 0;
         if (c >= nc) continue;
+        if (in_run) {
+          corr[c] = w[p * nc + c];
+          if (ga != DSA_INVALID) g[c] = (int32_t)((uint32_t)w[ga * nc + c] - (uint32_t)w[gb * nc + c]);
+        }
+        // lane 0: the reference's step from memory operands (exact whatever happens to the rest of the run)
+        const int32_t base0 = (lane == 0 && bidx != DSA_INVALID) ? w[bidx * nc + c] : 0;
+        const int32_t o0 = wrap_original((int32_t)((uint32_t)base0 + (uint32_t)g[c]), corr[c], mn, mx, max_dif);
         if (lane == 0) {
-          const int64_t e = (int64_t)o[c] - mn;
-          if (e < 0 || e >= (int64_t)M) irregular = true; else xr[c] = (uint32_t)e;
+          o[c] = o0;
+          const uint32_t e0 = (uint32_t)o0 - (uint32_t)mn;
+          if (o0 < mn || e0 >= M) irregular = true; else xr[c] = e0;
         } else if (in_run) {
-          int64_t e = (int64_t)g[c] + (int64_t)corr[c];
-          if (e <= -2 * (int64_t)M || e >= 2 * (int64_t)M) irregular = true;
+          // residue of g + corr without division: real corrections keep |g + corr| < 2M
+          const int64_t e64 = (int64_t)g[c] + (int64_t)corr[c];
+          int32_t e = (int32_t)e64;
+          if (e64 <= -2 * (int64_t)M || e64 >= 2 * (int64_t)M) irregular = true;
           else {
-            if (e < 0) e += M;
-            if (e < 0) e += M;
-            if (e >= (int64_t)M) e -= M;
+            if (e < 0) e += (int32_t)M;
+            if (e < 0) e += (int32_t)M;
+            if (e >= (int32_t)M) e -= (int32_t)M;
             xr[c] = (uint32_t)e;
           }
         }
@@ -1829,8 +1821,17 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
 #pragma unroll
       for (uint32_t c = 0; c < 4; ++c) {
         if (c >= nc) continue;
-        const uint32_t x = wave_incl_scan(in_scan ? xr[c] : 0u, [M](uint32_t a, uint32_t b) { return addmod(a, b, M); });
-        red[c] = x;
+        uint32_t x = in_scan ? xr[c] : 0u;
+        if (small_m) {
+          x = wave_incl_scan(x, [](uint32_t a, uint32_t b) { return a + b; });             // < 64 M < 2^31
+          uint32_t q = (uint32_t)((float)x * inv_m);
+          int32_t rres = (int32_t)(x - q * M);
+          if (rres < 0) rres += (int32_t)M;
+          if (rres >= (int32_t)M) rres -= (int32_t)M;
+          x = (uint32_t)rres;
+        } else {
+          x = wave_incl_scan(x, [M](uint32_t a, uint32_t b) { return addmod(a, b, M); });
+        }
         if (lane > 0) o[c] = (int32_t)((uint32_t)mn + x);
       }
       // verify against the sequential step: pred = o[p-1] + g (uint32 arithmetic), clamp must be a no-op
