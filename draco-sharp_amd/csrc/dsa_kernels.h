@@ -1900,8 +1900,20 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
         if (xs >= M || xt >= M) { short_runs = 2; continue; }     // out-of-range state: exact sequential chunk
         uint32_t ss = (live && (uint32_t)cv.x < M) ? (uint32_t)cv.x : 0u, st = (live && (uint32_t)cv.y < M) ? (uint32_t)cv.y : 0u;
         if (lane == 0) { ss = addmod(ss, xs, M); st = addmod(st, xt, M); }
-        ss = wave_incl_scan(ss, [M](uint32_t a, uint32_t b) { return addmod(a, b, M); });
-        st = wave_incl_scan(st, [M](uint32_t a, uint32_t b) { return addmod(a, b, M); });
+        if (M < (1u << 25)) {       // plain sums (< 64 M) with one DPP add per step, then a single modulo
+          const float inv_m = 1.0f / (float)M;
+          ss = wave_incl_scan(ss, [](uint32_t a, uint32_t b) { return a + b; });
+          st = wave_incl_scan(st, [](uint32_t a, uint32_t b) { return a + b; });
+          int32_t rs = (int32_t)(ss - (uint32_t)((float)ss * inv_m) * M), rt = (int32_t)(st - (uint32_t)((float)st * inv_m) * M);
+          if (rs < 0) rs += (int32_t)M;
+          if (rs >= (int32_t)M) rs -= (int32_t)M;
+          if (rt < 0) rt += (int32_t)M;
+          if (rt >= (int32_t)M) rt -= (int32_t)M;
+          ss = (uint32_t)rs; st = (uint32_t)rt;
+        } else {
+          ss = wave_incl_scan(ss, [M](uint32_t a, uint32_t b) { return addmod(a, b, M); });
+          st = wave_incl_scan(st, [M](uint32_t a, uint32_t b) { return addmod(a, b, M); });
+        }
         int32_t os = (int32_t)ss - o.center, ot = (int32_t)st - o.center;     // w in [-center, center]
         if (canonical && !bl) oct_rotate(os, ot, (4 - rot) % 4);
         if (!in_d) oct_invert_diamond(o.center, os, ot);
