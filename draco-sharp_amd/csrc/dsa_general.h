@@ -72,21 +72,40 @@ struct Act {
 };
 
 // Entropy/RAnsSymbolDecoder.cs:12-59 + RAnsDecoder.cs:20-99, serial; cum[0..ns] cumulative frequencies.
+// Scratch for the symbol coder of a general mesh: tables of the common case (12-bit precision, <= 2048 symbols)
+// live in LDS (host check: plain memory), where a lookup costs ~100 cycles instead of a dependent chain of global
+// loads; larger tables stay in the arena region `cum` and are searched.
+#define GEN_LUT_SLOTS 4096
+#define GEN_LUT_SYMS 2048
+struct RansScratch {
+  uint16_t *lut;          // [GEN_LUT_SLOTS] slot -> symbol
+  uint32_t *fast_cum;     // [GEN_LUT_SYMS + 1]
+  uint32_t *cum;          // arena, cum_cap entries
+  uint64_t cum_cap;
+};
 struct Rans {
   uint32_t pb, l_base, ns, state, off;
   const uint8_t *buf;
   const uint32_t *cum;
+  const uint16_t *lut;    // nullptr: binary search over cum
   __device__ uint32_t read() {
     while (state < l_base && off > 0) state = state * 256u + buf[--off];
     const uint32_t rem = state & ((1u << pb) - 1u);
-    uint32_t lo = 0, hi = ns;          // largest s with cum[s] <= rem
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= rem) lo = mid; else hi = mid; }
+    uint32_t lo;
+    if (lut) lo = lut[rem];
+    else {
+      lo = 0;
+      uint32_t hi = ns;                // largest s with cum[s] <= rem
+      while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= rem) lo = mid; else hi = mid; }
+    }
     state = (state >> pb) * (cum[lo + 1] - cum[lo]) + rem - cum[lo];
     return lo;
   }
 };
 
-__device__ bool rans_create(MeshDesc *D, Rd &r, uint32_t max_bit_length, uint32_t *cum, uint64_t cum_cap, Rans &x) {
+__device__ bool rans_create(MeshDesc *D, Rd &r, uint32_t max_bit_length, const RansScratch &rs, Rans &x) {
+  uint32_t *cum = rs.cum;
+  const uint64_t cum_cap = rs.cum_cap;
   x.pb = rans_precision_bits(max_bit_length);
   x.l_base = 4u << x.pb;
   const uint64_t ns = r.varint();
@@ -101,6 +120,12 @@ __device__ bool rans_create(MeshDesc *D, Rd &r, uint32_t max_bit_length, uint32_
   }
   GREQ(cum[x.ns] == (1u << x.pb), 603);
   x.cum = cum;
+  x.lut = nullptr;
+  if (x.pb == 12 && x.ns <= GEN_LUT_SYMS && rs.lut) {
+    for (uint32_t i = 0; i <= x.ns; ++i) rs.fast_cum[i] = cum[i];
+    for (uint32_t i = 0; i < x.ns; ++i) for (uint32_t j = cum[i]; j < cum[i + 1]; ++j) rs.lut[j] = (uint16_t)i;
+    x.cum = rs.fast_cum; x.lut = rs.lut;
+  }
   // RAnsSymbolDecoder.cs:53-59, RAnsDecoder.cs:20-54
   const uint64_t size = r.varint();
   GREQ(r.ok && size >= 1 && size <= (uint64_t)(r.n - r.pos), 604);
@@ -117,13 +142,13 @@ __device__ bool rans_create(MeshDesc *D, Rd &r, uint32_t max_bit_length, uint32_
 }
 
 // Entropy/SymbolDecoding.cs:7-67 (tagged path per the bitstream, D-1)
-__device__ bool decode_symbols(MeshDesc *D, Rd &r, uint32_t num_values, uint32_t nc, uint32_t *out, uint32_t *cum, uint64_t cum_cap) {
+__device__ bool decode_symbols(MeshDesc *D, Rd &r, uint32_t num_values, uint32_t nc, uint32_t *out, const RansScratch &rs) {
   if (num_values == 0) return true;
   const uint32_t scheme = r.u8();
   GREQ(r.ok && scheme <= 1, 610);
   Rans x;
   if (scheme == 0) {
-    if (!rans_create(D, r, 5, cum, cum_cap, x)) return false;
+    if (!rans_create(D, r, 5, rs, x)) return false;
     const uint8_t *bits = r.p + r.pos;
     const uint32_t nbytes = r.n - r.pos;
     uint64_t bitpos = 0;
@@ -142,7 +167,7 @@ __device__ bool decode_symbols(MeshDesc *D, Rd &r, uint32_t num_values, uint32_t
   } else {
     const uint32_t mbl = r.u8();
     GREQ(r.ok && mbl >= 1 && mbl <= 18, 614);
-    if (!rans_create(D, r, mbl, cum, cum_cap, x)) return false;
+    if (!rans_create(D, r, mbl, rs, x)) return false;
     for (uint32_t i = 0; i < num_values; ++i) out[i] = x.read();
   }
   return true;
@@ -313,7 +338,7 @@ struct ValueCtx {
 
 // Values of attribute ai (SequentialAttributeDecoder.cs:47-52,75-86 / SequentialIntegerAttributeDecoder.cs:23-101):
 // symbols -> corrections -> portable values in work[ai].
-__device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, uint32_t ai, uint32_t entries, uint32_t *cum, uint64_t cum_cap,
+__device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, uint32_t ai, uint32_t entries, const RansScratch &rs,
                               const ValueCtx &vc) {
   AttrDesc &a = D->att[ai];
   a.num_entries = entries;
@@ -346,7 +371,7 @@ __device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, 
   GREQ(r.ok, 145);
   a.source = SRC_RAW;
   if (compressed > 0) {
-    if (!decode_symbols(D, r, (uint32_t)num_values, nc, (uint32_t *)w, cum, cum_cap)) return false;
+    if (!decode_symbols(D, r, (uint32_t)num_values, nc, (uint32_t *)w, rs)) return false;
   } else {                                             // SequentialIntegerAttributeDecoder.cs:68-84 (D-13)
     const uint32_t nb = r.u8();
     GREQ(r.ok && nb >= 1 && nb <= 4, 158);
@@ -470,19 +495,19 @@ __device__ bool decode_descriptors(const MeshLayout &L, MeshDesc *D, Rd &r, uint
 // Mesh/MeshSequentialDecoder.cs:8-123: faces as point indices (compressed: differences with the sign in the LSB
 // through the symbol coder -- D-22: the C# tests that bit inverted; raw: u8 / u16 / varint / u32 by point count), one
 // attributes decoder, linear sequencing (entry i = point i).
-__device__ bool decode_sequential_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r) {
+__device__ bool decode_sequential_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, RansScratch rs) {
   const uint64_t nf64 = r.varint(), np64 = r.varint();
   GREQ(r.ok && nf64 <= 0x7FFFFFFFu / 3 && np64 <= 0x7FFFFFFFu, 111);
   const uint32_t F = (uint32_t)nf64, NP = (uint32_t)np64;
   GREQ(F == L.cap_faces && NP == L.cap_vertices, 116);
   const GenLayout g = gen_layout(F, NP, 0, 0, L.stream_len);
   GREQ(g.total <= L.gen_bytes, 640);
-  uint32_t *cum = (uint32_t *)(arena + L.gen + g.cum);
+  rs.cum = (uint32_t *)(arena + L.gen + g.cum); rs.cum_cap = g.cum_entries;
   int32_t *faces = (int32_t *)(arena + L.faces);
   const uint32_t method = r.u8();
   GREQ(r.ok && method <= 1, 690);
   if (method == 0) {
-    if (!decode_symbols(D, r, 3 * F, 1, (uint32_t *)faces, cum, g.cum_entries)) return false;
+    if (!decode_symbols(D, r, 3 * F, 1, (uint32_t *)faces, rs)) return false;
     int32_t last = 0;
     for (uint32_t k = 0; k < 3 * F; ++k) {
       const uint32_t e = (uint32_t)faces[k];
@@ -515,7 +540,7 @@ __device__ bool decode_sequential_mesh(uint8_t *arena, const MeshLayout &L, Mesh
       uint32_t *map = (uint32_t *)(arena + L.map[ai]);
       for (uint32_t p = 0; p < NP; ++p) map[p] = p;           // LinearSequencer.cs:3-19
     }
-    for (uint32_t ai = first[i]; ai < first[i] + count[i]; ++ai) if (!decode_values(arena, L, D, r, ai, NP, cum, g.cum_entries, vc)) return false;
+    for (uint32_t ai = first[i]; ai < first[i] + count[i]; ++ai) if (!decode_values(arena, L, D, r, ai, NP, rs, vc)) return false;
     for (uint32_t ai = first[i]; ai < first[i] + count[i]; ++ai) if (!decode_transform_params(D, r, ai)) return false;
   }
   D->end_pos = r.pos;
@@ -525,7 +550,7 @@ __device__ bool decode_sequential_mesh(uint8_t *arena, const MeshLayout &L, Mesh
 struct DecoderInfo { int att_data_id; uint32_t element_type, first_att, num_atts, num_entries; };
 
 // The whole mesh.  Returns false after latching the failure.
-__device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r) {
+__device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, RansScratch rs) {
   const uint8_t *s = arena + L.stream;
   // ---------------------------------------------------------------- MeshEdgeBreakerDecoder.cs:25-134
   D->traversal_type = (uint8_t)r.u8();
@@ -562,7 +587,7 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
   uint32_t *invalid_list = (uint32_t *)(arena + L.vrank);
   uint32_t *stack = (uint32_t *)(G + g.stack);
   uint32_t *splits = (uint32_t *)(G + g.splits), *active = (uint32_t *)(G + g.active);
-  uint32_t *cum = (uint32_t *)(G + g.cum);
+  rs.cum = (uint32_t *)(G + g.cum); rs.cum_cap = g.cum_entries;
   int32_t *c2p = (int32_t *)(arena + L.faces);
   for (uint32_t c = 0; c < C; ++c) { ct.opp[c] = DSA_INVALID; ct.c2v[c] = DSA_INVALID; }
   for (uint32_t v = 0; v < VMAX; ++v) is_hole[v] = 1;
@@ -614,7 +639,7 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
       GREQ(r.ok && num <= F && total + num <= F, 641);
       ctx_off[i] = total;
       if (num > 0) {
-        if (!decode_symbols(D, r, (uint32_t)num, 1, ctx_syms + total, cum, g.cum_entries)) return false;
+        if (!decode_symbols(D, r, (uint32_t)num, 1, ctx_syms + total, rs)) return false;
         ctx_cnt[i] = (int32_t)num;
       }
       total += (uint32_t)num;
@@ -967,7 +992,7 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
     vc.d2c = d2c; vc.v2d = v2d; vc.pids = pids;
     vc.orient = dd >= 0 ? G + g.data + (uint64_t)dd * g.data_stride + g.orient : nullptr;
     vc.orient_cap = NVMAX; vc.num_points = num_points;
-    for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) if (!decode_values(arena, L, D, r, ai, entries, cum, g.cum_entries, vc)) return false;
+    for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) if (!decode_values(arena, L, D, r, ai, entries, rs, vc)) return false;
     for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) if (!decode_transform_params(D, r, ai)) return false;
   }
   D->end_pos = r.pos;
@@ -982,14 +1007,17 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
 #if defined(__HIPCC__)
 // One wave per mesh, lane 0 works.  Runs on the third stream beside the fast kernels (which skip general meshes).
 __global__ __launch_bounds__(WAVE) void k_general(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  __shared__ uint16_t sh_lut[GEN_LUT_SLOTS];
+  __shared__ uint32_t sh_cum[GEN_LUT_SYMS + 1];
   const uint32_t mesh = blockIdx.x;
   if (mesh >= n || threadIdx.x != 0) return;
   MeshDesc *D = &descs[mesh];
   if (!D->general || status_of(D) != ST_OK) return;
   const MeshLayout &L = layouts[mesh];
   Rd r(arena + L.stream, L.stream_len, D->end_pos);       // k_locate parked the reader behind the header
-  if (D->encoder_method == 0) (void)gen::decode_sequential_mesh(arena, L, D, r);
-  else (void)gen::decode_mesh(arena, L, D, r);
+  gen::RansScratch rs = {sh_lut, sh_cum, nullptr, 0};
+  if (D->encoder_method == 0) (void)gen::decode_sequential_mesh(arena, L, D, r, rs);
+  else (void)gen::decode_mesh(arena, L, D, r, rs);
 }
 
 #endif
