@@ -1022,19 +1022,17 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
 // loop body verbatim.  Either way each step is the sequential algorithm's result.
 // =========================================================================
 // Scratch initialisation for the traversal (no dependence on the stream contents: runs first):
-// face-visited marks, run stamps, vertex_to_data = -1.
+// face-visited marks, vertex_to_data = -1.
 __global__ __launch_bounds__(256) void k_init(uint8_t *arena, const MeshLayout *layouts, uint32_t n) {
   uint32_t mesh = blockIdx.y;
   if (mesh >= n) return;
   const MeshLayout &L = layouts[mesh];
   int32_t *v2d = (int32_t *)(arena + L.v2d);
   uint32_t *fvis4 = (uint32_t *)(arena + L.fvis);
-  uint32_t *fstamp = (uint32_t *)(arena + L.fstamp), *vstamp = (uint32_t *)(arena + L.vstamp);
   const uint32_t F = L.cap_faces, V = L.cap_vertices;
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-  for (uint32_t f = tid; f < F; f += stride) fstamp[f] = 0xFFFFFFFFu;
   for (uint32_t w4 = tid; w4 < (F + 3) / 4; w4 += stride) fvis4[w4] = 0;     // regions are 256-byte padded
-  for (uint32_t v = tid; v < V; v += stride) { v2d[v] = -1; vstamp[v] = 0xFFFFFFFFu; }
+  for (uint32_t v = tid; v < V; v += stride) v2d[v] = -1;
 }
 
 // Parallelogram operands of entry p (MeshPredictionSchemeParallelogramDecoder.cs:56-89):
@@ -1082,7 +1080,12 @@ __global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const Mes
 // retired at once.  Everything else is the scalar step = the reference's loop body.
 #define TR_PAIRS 64
 
+#define TR_SLOT_BITS 8
+#define TR_SLOTS (1u << TR_SLOT_BITS)
 __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t fuse_operands) {
+  __shared__ unsigned long long sh_tf[TR_SLOTS], sh_tv[TR_SLOTS];   // in-run membership of faces / tips
+  for (uint32_t i = threadIdx.x; i < TR_SLOTS; i += WAVE) { sh_tf[i] = 0; sh_tv[i] = 0; }
+  __syncthreads();
   __builtin_amdgcn_s_setprio(3);   // critical path: issue ahead of the entropy-decode waves sharing the CU
   uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
@@ -1094,7 +1097,6 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   int32_t *v2d = (int32_t *)(arena + L.v2d);
   uint8_t *fvis = arena + L.fvis;
   uint8_t *vflag = arena + L.vvis;      // bit0 visited, bit1 on boundary
-  uint32_t *fstamp = (uint32_t *)(arena + L.fstamp), *vstamp = (uint32_t *)(arena + L.vstamp);
   const uint32_t F = uni(D->num_faces), NV = uni(D->num_vertices);
   uint32_t *stack = (uint32_t *)(arena + L.faces);   // DFS stack: the faces output is only written by k_finalize
   const uint32_t stack_cap = 3 * F;
@@ -1231,26 +1233,50 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           fL_before = fvis[lcB >> 2];
           flA = vflag[tipA]; flB = vflag[tipB];
         }
-        // stamps: first position of every face / tip in the candidate list
+        // First position of every face / tip in the candidate list: two small open-addressing tables in LDS,
+        // slot = run tag (24) | id (32) | position (8); a slot of an older run counts as empty, so nothing is
+        // cleared between runs.  Exact: the smallest position per id wins (ds_min_u64).
         const uint32_t keyN = base | (2 * lane), keyL = base | (2 * lane + 1);
+        const uint32_t run_tag = base >> 8;
+        auto tbl_insert = [&](unsigned long long *t, uint32_t id, uint32_t pos) {
+          const unsigned long long want = ((unsigned long long)run_tag << 40) | ((unsigned long long)id << 8) | pos;
+          uint32_t sl = (id * 2654435761u) >> (32 - TR_SLOT_BITS);
+          for (;;) {
+            const unsigned long long cur = __hip_atomic_load(&t[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((uint32_t)(cur >> 40) != run_tag) { if (atomicCAS(&t[sl], cur, want) == cur) break; continue; }
+            if ((uint32_t)(cur >> 8) == id) { atomicMin(&t[sl], want); break; }
+            sl = (sl + 1) & (TR_SLOTS - 1);
+          }
+        };
+        auto tbl_lookup = [&](unsigned long long *t, uint32_t id) -> uint32_t {
+          uint32_t sl = (id * 2654435761u) >> (32 - TR_SLOT_BITS);
+          for (uint32_t probes = 0; probes < TR_SLOTS; ++probes) {
+            const unsigned long long cur = __hip_atomic_load(&t[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((uint32_t)(cur >> 40) != run_tag) return 0xFFFFFFFFu;
+            if ((uint32_t)(cur >> 8) == id) return base | (uint32_t)(cur & 0xFFu);
+            sl = (sl + 1) & (TR_SLOTS - 1);
+          }
+          return 0xFFFFFFFFu;
+        };
+        // A tip that was visited before the run can never count as new, so only unvisited tips are entered; the
+        // neighbour faces are looked up only where their state before the run leaves the question open.
         if (pair_ok) {
-          atomicMin(&fstamp[fa], keyN); atomicMin(&fstamp[fb], keyL);
-          atomicMin(&vstamp[tipA], keyN); atomicMin(&vstamp[tipB], keyL);
+          tbl_insert(sh_tf, fa, 2 * lane); tbl_insert(sh_tf, fb, 2 * lane + 1);
+          if (!(flA & 1u)) tbl_insert(sh_tv, tipA, 2 * lane);
+          if (!(flB & 1u)) tbl_insert(sh_tv, tipB, 2 * lane + 1);
         }
-        WAIT_VM0();
+        __syncthreads();
 #ifdef DSA_TRAV_HIST
         uint32_t why = pair_ok ? 0u : (in_chain ? 6u : 7u);
 #endif
         bool good = false, newA = false, newB = false;
         if (pair_ok) {
-          const uint32_t sfa = __hip_atomic_load(&fstamp[fa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t sfb = __hip_atomic_load(&fstamp[fb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t sta = __hip_atomic_load(&vstamp[tipA], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t stb = __hip_atomic_load(&vstamp[tipB], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t srf = rcB != DSA_INVALID ? __hip_atomic_load(&fstamp[rcB >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
-          const uint32_t slf = __hip_atomic_load(&fstamp[lcB >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint32_t sla = lcA != DSA_INVALID ? __hip_atomic_load(&fstamp[lcA >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
-          const uint32_t run_tag = base >> 8;
+          const uint32_t sfa = tbl_lookup(sh_tf, fa), sfb = tbl_lookup(sh_tf, fb);
+          const uint32_t sta = !(flA & 1u) ? tbl_lookup(sh_tv, tipA) : 0xFFFFFFFFu;
+          const uint32_t stb = !(flB & 1u) ? tbl_lookup(sh_tv, tipB) : 0xFFFFFFFFu;
+          const uint32_t srf = (rcB != DSA_INVALID && fR_before == 0) ? tbl_lookup(sh_tf, rcB >> 2) : 0xFFFFFFFFu;
+          const uint32_t slf = fL_before == 0 ? tbl_lookup(sh_tf, lcB >> 2) : 0xFFFFFFFFu;
+          const uint32_t sla = (lcA != DSA_INVALID && fLA_before == 0 && flA != 0) ? tbl_lookup(sh_tf, lcA >> 2) : 0xFFFFFFFFu;
           // first element (at a, face A): the face is first seen here and the DFS moves right -- because the
           // tip is new and interior (DepthFirstTraverser.cs:53-64), or because the left side is done
           // (:66-87; that the right side is open is the second element's "face B first seen")
