@@ -1511,7 +1511,6 @@ typedef uint32_t v32u __attribute__((ext_vector_type(32)));   // largest vector 
 #define REG_MAX_SYMS 2048
 
 __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
-  __shared__ uint32_t lds[REG_MAX_SYMS];   // probabilities, then packed {freq << 12 | cum} per symbol
   uint32_t mesh = blockIdx.x, ai = blockIdx.y;
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
@@ -1519,11 +1518,14 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
   const MeshLayout &L = layouts[mesh];
   const AttrDesc &a = D->att[ai];
   if (a.source != SRC_RAW || a.precision_bits != 12 || a.num_symbols > REG_MAX_SYMS || a.num_symbols <= 64) return;
-  if (L.out_cap[ai] < 4096 * 6) return;      // scratch for the two slot tables (k_symbols<T> takes the stream instead)
+  if (L.out_cap[ai] < 4096 * 6 + REG_MAX_SYMS * 4) return;      // scratch for the tables (k_symbols<T> takes the stream instead)
   const uint8_t *stream = arena + L.stream;
   uint32_t *out = (uint32_t *)(arena + L.work[ai]);
   uint32_t *slot_tab = (uint32_t *)(arena + L.out[ai]);            // {freq << 12 | rem - cum} per slot
   uint16_t *slot_sym = (uint16_t *)(arena + L.out[ai] + 4096 * 4); // symbol per slot
+  // probabilities, then packed {freq << 12 | cum} per symbol: global scratch rather than LDS, which the
+  // connectivity and traversal waves sharing the CU need for their caches and tables
+  uint32_t *lds = (uint32_t *)(arena + L.out[ai] + 4096 * 6);
   const uint32_t lane = lane_id();
   const uint32_t nsym = uni(a.num_symbols);
   const uint32_t num_values = uni(a.num_entries) * a.nc_portable;
@@ -1695,7 +1697,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayo
   if (a.source == SRC_BYTES) return;
   {
     const uint32_t ns = a.source == SRC_RAW ? a.num_symbols : 0u;
-    if (a.source == SRC_RAW && a.precision_bits == 12 && ns > 64 && ns <= REG_MAX_SYMS && L.out_cap[ai] >= 4096 * 6) return;   // k_symbols_reg
+    if (a.source == SRC_RAW && a.precision_bits == 12 && ns > 64 && ns <= REG_MAX_SYMS && L.out_cap[ai] >= 4096 * 6 + REG_MAX_SYMS * 4) return;   // k_symbols_reg
     const int tier = ns <= 64 ? 0 : (ns <= 960 ? 1 : 2);
     if (tier != TIER) return;
   }
