@@ -422,7 +422,7 @@ __device__ __forceinline__ uint32_t fo_idx(uint32_t c) { return 2u * c - (c & 3u
 // Rare events (S, topology splits, start faces, vertex compaction) sync everything to global memory and
 // run there on lane 0.
 #define CN_REC_BLOCKS 16     // 16 blocks x 64 records x 8 B = 8 KB of LDS, write-back
-#define CN_STAGE 64          // faces per staging block
+#define CN_STAGE 32          // faces per staging block (LDS per wave stays under 10 KB: 16 waves per CU)
 #define CN_WIN 64            // dwords of symbol bits per window
 
 __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
