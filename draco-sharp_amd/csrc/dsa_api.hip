@@ -31,7 +31,7 @@ struct dsa_context {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;     // symbol decode runs here, concurrently with connectivity + traversal
   hipStream_t stream3 = nullptr;     // connectivity validation (link symmetry, seam streams)
-  hipEvent_t ev_join3 = nullptr, ev_trav = nullptr, ev_maps = nullptr;
+  hipEvent_t ev_join3 = nullptr, ev_trav = nullptr, ev_maps = nullptr, ev_early = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_conn = nullptr;
   bool own_stream = false;
   bool profiling = false;
@@ -174,6 +174,7 @@ dsa_status dsa_context_create(int device, void *stream, dsa_context **out) {
       hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_trav, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_maps, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_conn, hipEventDisableTiming) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
@@ -192,6 +193,7 @@ void dsa_context_destroy(dsa_context *ctx) {
   if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
   if (ctx->ev_trav) (void)hipEventDestroy(ctx->ev_trav);
   if (ctx->ev_maps) (void)hipEventDestroy(ctx->ev_maps);
+  if (ctx->ev_early) (void)hipEventDestroy(ctx->ev_early);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -263,7 +265,15 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   hipLaunchKernelGGL(dsa::k_symbols<0>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
   hipLaunchKernelGGL(dsa::k_symbols<2>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[1], st2));
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_join, st2));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_join, st2));           // corrections of every attribute are ready
+  // attributes whose prediction needs no traversal data (difference, octahedral delta) are finished on this stream,
+  // beside the traversal and the parallelogram attributes; joined before k_seal
+  hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u);
+  {
+    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
+    hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u);
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_early, st2));
   hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   // link symmetry + seam streams are checked on the second stream while the traversal runs here
   HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st));
@@ -305,13 +315,14 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));   // join: corrections are ready
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join3, 0));  // join: connectivity validated
   HIP_TRY(ctx, mark());
-  hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+  hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u);
   HIP_TRY(ctx, mark());
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
-    hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+    hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u);
   }
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_maps, 0));
+  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_early, 0));
   hipLaunchKernelGGL(dsa::k_seal, dim3((n + 255) / 256), dim3(256), 0, st, b->d_descs, n);
   HIP_TRY(ctx, mark());
   HIP_TRY(ctx, hipGetLastError());

@@ -1763,13 +1763,16 @@ __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayo
 // (readlane) and coalesced loads/stores; its step is a short scalar program.
 __device__ __forceinline__ uint32_t addmod(uint32_t a, uint32_t b, uint32_t m) { uint32_t r = a + b; return r >= m ? r - m : r; }
 
-__global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+// phase 0: schemes that need no traversal data (difference / octahedral delta) -- launched behind the symbol
+// kernels on their stream; phase 1: parallelogram schemes, after the traversal.
+__global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t phase) {
   uint32_t mesh = blockIdx.x, ai = blockIdx.y;
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
   const AttrDesc &a = D->att[ai];
   if (!a.have_scheme || a.source == SRC_BYTES) return;
+  if ((a.pred_kind == 1) != (phase == 1)) return;
   const MeshLayout &L = layouts[mesh];
   int32_t *w = (int32_t *)(arena + L.work[ai]);
   const uint32_t nc = a.nc_portable, entries = a.num_entries;
@@ -1982,13 +1985,17 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
 // =========================================================================
 // k_finalize: portable ints -> attribute values, point->entry maps.
 // =========================================================================
-__global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n) {
+// phase 0 (symbol stream): attributes whose values are complete once the symbols and a traversal-free scheme are
+// done; phase 1 (main stream, last): parallelogram attributes and everything of the general-path meshes.
+__global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n, uint32_t phase) {
   uint32_t mesh = blockIdx.y, ai = blockIdx.z;
   if (mesh >= n) return;
   const MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK || ai >= D->num_attributes) return;
   const MeshLayout &L = layouts[mesh];
   const AttrDesc &a = D->att[ai];
+  const bool late = D->general || (a.have_scheme && a.pred_kind == 1);
+  if (late != (phase == 1)) return;
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   const int32_t *w = (const int32_t *)(arena + L.work[ai]);
   const uint32_t entries = a.num_entries;
