@@ -1168,7 +1168,12 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
 
       // ------------------------------------------------------------------ speculative (right left)^k run
       if (moves_right && backoff == 0) {
-        ++run_id;
+        if (++run_id >= 0x00FFFFF0u) {        // 24-bit run tags: start over with empty tables (meshes with > 16 M runs)
+          __syncthreads();
+          for (uint32_t i = lane; i < TR_SLOTS; i += WAVE) { sh_tf[i] = 0; sh_tv[i] = 0; }
+          __syncthreads();
+          run_id = 1;
+        }
         const uint32_t base = (0x00FFFFFFu - run_id) << 8;
         // candidate path a_i = a_0 + i*step + dd*i*(i-1)/2.  (step, dd) carry over from the previous run
         // (its last step + dd); if the first link then fails, three exact hops re-seed them.
