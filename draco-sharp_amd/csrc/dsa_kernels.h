@@ -1195,16 +1195,17 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           const int64_t i = lane;
           ai = (int64_t)a0 + i * step + dd * i * (i - 1) / 2;
         } else {
-          const uint32_t a1 = succ(a0), a2 = succ(a1), a3 = succ(a2);
-          const int64_t d1 = (int64_t)a1 - a0, d2 = (int64_t)a2 - a1, d3 = (int64_t)a3 - a2;
-          int64_t ddh = d3 - d2;
-          if (d2 - d1 != ddh) ddh = 0;       // no regular step change: assume a constant step
+          // two exact hops (four dependent record loads) seed the step and its change; the links of the
+          // extrapolated path are verified from the loaded records anyway
+          const uint32_t a1 = succ(a0), a2 = succ(a1);
+          const int64_t d1 = (int64_t)a1 - a0, d2 = (int64_t)a2 - a1;
+          const int64_t ddh = d2 - d1;
           const int64_t i = lane;
-          ai = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : lane == 3 ? a3 : (int64_t)a3 + (i - 3) * d3 + ddh * (i - 3) * (i - 2) / 2;
-          exact = corner_ok(a3) ? 4 : (corner_ok(a2) ? 3 : (corner_ok(a1) ? 2 : 1));
+          ai = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : (int64_t)a2 + (i - 2) * (d2 + ddh) + ddh * (i - 2) * (i - 3) / 2;
+          exact = corner_ok(a2) ? 3 : (corner_ok(a1) ? 2 : 1);
           step = d1; dd = ddh;               // provisional; replaced below from the verified chain
         }
-        a_ok = lane < window && ai >= 0 && ai < (int64_t)4 * F && ((uint32_t)ai & 3u) != 3u && (lane < exact || have_step || exact == 4);
+        a_ok = lane < window && ai >= 0 && ai < (int64_t)4 * F && ((uint32_t)ai & 3u) != 3u && (lane < exact || have_step || exact == 3);
         const uint32_t a = a_ok ? (uint32_t)ai : 0u;
         // pair `lane`: N element at a (face A), L element at b = Opposite(Next(a)) (face B)
         const uint32_t fa = a >> 2, ka = a & 3u;
