@@ -50,7 +50,9 @@ typedef struct dsa_batch dsa_batch;
  * (src/Draco/IO/Mesh/Mesh.cs:15-69, src/Draco/IO/PointCloud/PointCloud.cs:11-133). */
 typedef struct dsa_mesh_info {
   int32_t status;            /* dsa_status of this stream */
-  int32_t detail;            /* internal site code of the first failing check (diagnostics) */
+  int32_t detail;            /* internal site code of the first failing check (diagnostics): 1xx header / section walk
+                              * (k_locate), 2xx Edgebreaker connectivity, 3xx traversal, 4xx entropy decode, 5xx prediction,
+                              * 6xx general path (valence, seams, corner attributes, sequential meshes) */
   uint8_t major_version, minor_version, encoder_type, encoder_method;
   uint16_t flags;
   uint16_t reserved;
