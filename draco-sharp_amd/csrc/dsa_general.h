@@ -591,6 +591,7 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
   int32_t *c2p = (int32_t *)(arena + L.faces);
   for (uint32_t c = 0; c < C; ++c) { ct.opp[c] = DSA_INVALID; ct.c2v[c] = DSA_INVALID; }
   for (uint32_t v = 0; v < VMAX; ++v) is_hole[v] = 1;
+  if (S > 0) for (uint32_t f = 0; f < F; ++f) active[f] = DSA_INVALID;   // topologySplitActiveCorners as a direct map
   // topology splits, :136-230
   {
     uint32_t last = 0;
@@ -647,7 +648,7 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
   }
   // ---------------------------------------------------------------- symbols, :232-442
   int last_symbol = -1, active_context = -1;
-  uint32_t sp = 0, num_faces = 0, num_invalid = 0, splits_left = S, active_n = 0;
+  uint32_t sp = 0, num_faces = 0, num_invalid = 0, splits_left = S;
   const bool remove_invalid = nad == 0;
   for (uint32_t sid = 0; sid < num_symbols; ++sid) {
     const uint32_t face = num_faces++;
@@ -708,8 +709,7 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
     } else if (sym == 1) {             // S
       GREQ(sp > 0, 230);
       const uint32_t cb = stack[--sp];
-      for (uint32_t k = 0; k < active_n; ++k)
-        if (active[2 * k] == sid) { GREQ(sp < F, 232); stack[sp++] = active[2 * k + 1]; break; }
+      if (S > 0 && active[sid] != DSA_INVALID) { GREQ(sp < F, 232); stack[sp++] = active[sid]; }
       GREQ(sp > 0, 232);
       const uint32_t ca = stack[sp - 1];
       GREQ(ca != cb && ca < C && cb < C, 233);
@@ -770,11 +770,7 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
         const uint32_t top = stack[sp - 1];
         const uint32_t nc = edge == 1 ? cnx(top) : cpv(top);   // 1 = right face edge
         const uint32_t key = num_symbols - enc_split - 1;
-        uint32_t k = 0;
-        for (; k < active_n; ++k) if (active[2 * k] == key) break;
-        GREQ(k < L.cap_splits, 244);
-        active[2 * k] = key; active[2 * k + 1] = nc;
-        if (k == active_n) ++active_n;
+        active[key] = nc;                                      // dictionary semantics: overwrite
       }
     }
   }

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
   uint32_t *stack_mem = (uint32_t *)(arena + L.para);     // active corners below the top (<= #E <= cap_vertices/3); para[] is written later
   uint32_t *invalid_list = (uint32_t *)(arena + L.vrank); // merged-away vertices (<= num_split_symbols); consumed before vrank[] is written
   uint32_t *events = (uint32_t *)(arena + L.splits);      // (source, split | edge<<31) per topology split event
-  uint32_t *pairs = events + 2 * (size_t)L.cap_splits;    // topologySplitActiveCorners: (decoder symbol id, corner)
+  uint32_t *split_map = (uint32_t *)(arena + L.fstamp);   // topologySplitActiveCorners: decoder symbol id -> corner (k_init: INVALID)
   const uint32_t F = uni(D->num_faces), VMAX = uni(L.cap_vertices);
   const uint32_t num_symbols = uni(D->num_symbols);
   const bool remove_invalid = uni(D->num_att_data) == 0;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
   bool have_top = false;
   uint32_t sp = 0;                      // entries of stack_mem below the top
   uint32_t num_verts = 0, num_invalid = 0;
-  uint32_t splits_left = nsplits, active_n = 0;
+  uint32_t splits_left = nsplits;
   uint32_t next_src = nsplits ? uni(events[2 * (nsplits - 1)]) : DSA_INVALID;
   uint32_t dirty = 0;                   // bit per record-cache slot
   uint64_t bb = 0;                      // bit buffer (LSB first)
@@ -704,8 +704,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
         do {
           uint32_t cb = ca, ca2 = DSA_INVALID, sp2 = sp;
           bool pushed = false;
-          for (uint32_t k = 0; k < active_n; ++k)     // topologySplitActiveCorners lookup (:305)
-            if (pairs[2 * k] == sid) { ca2 = pairs[2 * k + 1]; pushed = true; break; }
+          if (nsplits) { ca2 = split_map[sid]; pushed = ca2 != DSA_INVALID; }     // topologySplitActiveCorners lookup (:305)
           if (!pushed) { if (sp2 == 0) { fail(D, ST_INVALID, 232); break; } ca2 = stack_mem[--sp2]; }
           if (ca2 >= corner || (ca2 & 3u) == 3u) { fail(D, ST_INVALID, 237); break; }
           if (ca2 == cb || frec[fo_idx(ca2)] != DSA_INVALID || frec[fo_idx(cb)] != DSA_INVALID) { fail(D, ST_INVALID, 233); break; }
@@ -802,7 +801,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
       const uint32_t enc_id = num_symbols - sid;
       if (next_src > enc_id) CN_FAIL(243);   // encoderSplitSymbolId < 0 in the reference
       if (next_src == enc_id) {
-        uint32_t r_left = splits_left, r_act = active_n, r_next = DSA_INVALID, ok = 1;
+        uint32_t r_left = splits_left, r_next = DSA_INVALID, ok = 1;
         if (lane == 0) {
           while (r_left > 0) {
             uint32_t source = events[2 * (r_left - 1)];
@@ -813,17 +812,13 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
             if (enc_split >= num_symbols) { ok = 0; break; }
             uint32_t nc = edge == 1 ? corner + 1 : corner + 2;   // Next / Previous of the new top (1 = RightFaceEdge)
             uint32_t key = num_symbols - enc_split - 1;
-            uint32_t k = 0;
-            for (; k < r_act; ++k) if (pairs[2 * k] == key) break;   // dictionary semantics: overwrite
-            if (k >= L.cap_splits) { ok = 0; break; }
-            pairs[2 * k] = key; pairs[2 * k + 1] = nc;
-            if (k == r_act) ++r_act;
+            split_map[key] = nc;                                  // dictionary semantics: overwrite
           }
           r_next = r_left ? events[2 * (r_left - 1)] : DSA_INVALID;
           WAIT_VM0();
         }
         if (!uni(ok)) CN_FAIL(244);
-        splits_left = uni(r_left); active_n = uni(r_act); next_src = uni(r_next);
+        splits_left = uni(r_left); next_src = uni(r_next);
       }
     }
   }
@@ -1033,6 +1028,10 @@ __global__ __launch_bounds__(256) void k_init(uint8_t *arena, const MeshLayout *
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   for (uint32_t w4 = tid; w4 < (F + 3) / 4; w4 += stride) fvis4[w4] = 0;     // regions are 256-byte padded
   for (uint32_t v = tid; v < V; v += stride) v2d[v] = -1;
+  if (L.cap_splits) {                    // topologySplitActiveCorners as a direct map: decoder symbol id -> corner
+    uint32_t *split_map = (uint32_t *)(arena + L.fstamp);
+    for (uint32_t f = tid; f < F; f += stride) split_map[f] = DSA_INVALID;
+  }
 }
 
 // Parallelogram operands of entry p (MeshPredictionSchemeParallelogramDecoder.cs:56-89):

@@ -84,7 +84,7 @@ struct MeshDesc {
 struct GenLayout {
   uint64_t stack;      // u32[F]      active corner stack of the Edgebreaker machine
   uint64_t splits;     // u32[3S]     topology split events (source, split, edge)
-  uint64_t active;     // u32[2S]     active split corners (decoder symbol id, corner)
+  uint64_t active;     // u32[F]      active split corners: decoder symbol id -> corner (only when S > 0)
   uint64_t fvis;       // u8[F]       traversal: face visited
   uint64_t vvis;       // u8[NVmax]   traversal: vertex visited
   uint64_t dfs;        // u32[F+1]    traversal stack
@@ -113,7 +113,7 @@ inline GenLayout gen_layout(uint64_t F, uint64_t V, uint64_t S, uint64_t A, uint
   auto take = [&](uint64_t bytes) { uint64_t at = cur; cur = (cur + bytes + 15) & ~15ull; return at; };
   g.stack = take(4 * F);
   g.splits = take(12 * S);
-  g.active = take(8 * S);
+  g.active = take(S ? 4 * F : 0);
   g.fvis = take(F);
   g.vvis = take(NV);
   g.dfs = take(4 * (F + 1));

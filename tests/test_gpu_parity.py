@@ -123,6 +123,24 @@ def test_64k_triangle_meshes(ctx):
     b.close()
 
 
+def test_many_holes_and_components(ctx):
+    """Thousands of boundary loops (one topology-split event each) and of connected components: the split-corner
+    dictionary and the traversal restarts must stay linear (a linear search there once cost seconds per mesh)."""
+    import time
+    pos, nrm, uv, faces = synth.make_mesh(synth.HOLES, 300, 250, 5)
+    big = synth.encode_mesh(pos, faces, nrm, uv)
+    b = run_batch(ctx, [big])
+    t0 = time.perf_counter()
+    b.decode()
+    dt = time.perf_counter() - t0
+    assert b.status(0) == 0, b.mesh_info(0).detail
+    ref = oracle.decode(big)
+    assert ref.num_faces > 100000
+    assert_same(b.result(0), ref, b, 0)
+    assert dt < 2.0, dt
+    b.close()
+
+
 def test_bad_streams_do_not_poison_the_batch(ctx):
     pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 9, 7, 3)
     good = synth.encode_mesh(pos, faces, nrm, uv)

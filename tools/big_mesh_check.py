@@ -1,0 +1,17 @@
+"""One-off: parity + stage times on multi-million-triangle meshes (single wave per mesh: latency-bound)."""
+import sys; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import numpy as np, time, oracle, draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
+import test_gpu_parity as T
+ctx = dsa.Context(0); ctx.set_profiling(True)
+streams = []
+for kind, nx, ny in ((synth.GRID, 1000, 1000), (synth.TORUS, 700, 900), (synth.HOLES, 600, 500)):
+    pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 9)
+    streams.append(synth.encode_mesh(pos, faces, nrm, uv))
+    print(kind, nx, ny, len(faces), len(streams[-1]))
+b = dsa.Batch(ctx, streams)
+for _ in range(2):
+    t0 = time.time(); b.decode(); print("decode s", round(time.time() - t0, 3), {k: round(v, 1) for k, v in b.stage_times().items()})
+for i, s in enumerate(streams):
+    assert b.status(i) == 0, (i, b.status(i), b.mesh_info(i).detail)
+    if "--check" in sys.argv: T.assert_same(b.result(i), oracle.decode(s), b, i)
+d = np.array([b.debug_array(i, 4, np.uint32, 12) for i in range(3)]); print(d)
