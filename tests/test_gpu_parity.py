@@ -123,6 +123,26 @@ def test_64k_triangle_meshes(ctx):
     b.close()
 
 
+def test_two_batches_in_flight(ctx):
+    """dsa_batch_decode is asynchronous: two batches enqueued back to back on one context, waited afterwards."""
+    sets = []
+    for seed in (1, 2):
+        streams = []
+        for kind, nx, ny in KINDS[:4]:
+            pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, seed)
+            streams.append(synth.encode_mesh(pos, faces, nrm, uv))
+        sets.append(streams)
+    b1, b2 = dsa.Batch(ctx, sets[0]), dsa.Batch(ctx, sets[1])
+    b1.decode(wait=False)
+    b2.decode(wait=False)
+    b2.wait()
+    b1.wait()
+    for b, streams in ((b1, sets[0]), (b2, sets[1])):
+        for i, sbytes in enumerate(streams):
+            assert_same(b.result(i), oracle.decode(sbytes), b, i)
+        b.close()
+
+
 def test_many_holes_and_components(ctx):
     """Thousands of boundary loops (one topology-split event each) and of connected components: the split-corner
     dictionary and the traversal restarts must stay linear (a linear search there once cost seconds per mesh)."""
