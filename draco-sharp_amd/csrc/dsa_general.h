@@ -948,6 +948,9 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
   uint8_t *fvis = G + g.fvis, *vvis = G + g.vvis;
   uint32_t *dfs = (uint32_t *)(G + g.dfs);
   const uint32_t NVMAX = C > VMAX ? C : VMAX;
+  uint32_t *shared_d2c = nullptr, *shared_pids = nullptr, shared_entries = 0;
+  int32_t *shared_v2d = nullptr;
+  const uint32_t *shared_map = nullptr;
   for (uint32_t i = 0; i < ndec; ++i) {
     // MeshTraversalSequencer + DepthFirstTraverser on the decoder's corner table
     uint32_t *d2c, *pids;
@@ -964,13 +967,20 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
     }
     uint32_t entries = 0;
     const bool corner_att = dec[i].element_type != 0;
-    if (!corner_att) { if (!traverse(D, ct, nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries)) return false; }
-    else { if (!traverse(D, act[dd], nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries)) return false; }
+    // Every vertex-type decoder traverses the position corner table from the same start: the order, the maps and
+    // the entry -> point list are those of the first one, so they are computed once and shared.
+    const uint32_t *map_src = nullptr;
+    if (!corner_att && shared_d2c) { d2c = shared_d2c; v2d = shared_v2d; pids = shared_pids; entries = shared_entries; map_src = shared_map; }
+    else if (!corner_att) {
+      if (!traverse(D, ct, nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries)) return false;
+      shared_d2c = d2c; shared_v2d = v2d; shared_pids = pids; shared_entries = entries;
+    } else { if (!traverse(D, act[dd], nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries)) return false; }
     dec[i].num_entries = entries;
     if (dd < 0) D->num_entries = entries;
     // point -> entry map of every attribute of the decoder, MeshTraversalSequencer.cs:33-50
     for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) {
       uint32_t *map = (uint32_t *)(arena + L.map[ai]);
+      if (map_src) { for (uint32_t p = 0; p < num_points; ++p) map[p] = map_src[p]; continue; }
       for (uint32_t p = 0; p < num_points; ++p) map[p] = 0;
       for (uint32_t c = 0; c < C; ++c) {
         const uint32_t point = (uint32_t)c2p[c];
@@ -980,6 +990,8 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
         GREQ(e >= 0 && (uint32_t)e < num_points, 671);
         map[point] = (uint32_t)e;
       }
+      map_src = map;                      // further attributes of this decoder share the map
+      if (!corner_att && !shared_map) shared_map = map;
     }
     // values, then transform parameters, of every attribute of the decoder (SequentialAttributeDecodersController.cs:29-38,
     // AttributesDecoder.cs:65-70)
