@@ -549,8 +549,52 @@ __device__ bool decode_sequential_mesh(uint8_t *arena, const MeshLayout &L, Mesh
 
 struct DecoderInfo { int att_data_id; uint32_t element_type, first_att, num_atts, num_entries; };
 
-// The whole mesh.  Returns false after latching the failure.
-__device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, RansScratch rs) {
+// Pointers and sizes of one general mesh, rebuilt by every phase from the layout and the descriptor.
+struct MeshCtx {
+  uint32_t F, C, VMAX, NVMAX, nad;
+  GenLayout g;
+  uint8_t *G;
+  Ct ct;
+  Act act[DSA_MAX_ATT_DATA];
+  uint8_t *is_hole;
+  int32_t *c2p;
+};
+__device__ bool mesh_ctx(uint8_t *arena, const MeshLayout &L, MeshDesc *D, MeshCtx &m) {
+  m.F = D->num_faces; m.C = 3 * m.F; m.VMAX = L.cap_vertices; m.NVMAX = m.C > m.VMAX ? m.C : m.VMAX; m.nad = D->num_att_data;
+  m.g = gen_layout(m.F, m.VMAX, L.cap_splits, m.nad, L.stream_len);
+  GREQ(m.g.total <= L.gen_bytes, 640);
+  m.G = arena + L.gen;
+  // arrays (the fast path's regions are free for a general mesh)
+  m.ct.opp = (uint32_t *)(arena + L.frec); m.ct.c2v = m.ct.opp + m.C; m.ct.vcorner = (uint32_t *)(arena + L.vrec);
+  m.ct.F = m.F; m.ct.C = m.C; m.ct.nv = D->num_all_vertices; m.ct.vmax = m.VMAX;
+  m.is_hole = arena + L.vvis;
+  m.c2p = (int32_t *)(arena + L.faces);
+  for (uint32_t d = 0; d < m.nad; ++d) {
+    uint8_t *blk = m.G + m.g.data + (uint64_t)d * m.g.data_stride;
+    m.act[d].ct = &m.ct;
+    m.act[d].edge_seam = blk + m.g.edge_seam; m.act[d].vert_seam = blk + m.g.vert_seam;
+    m.act[d].c2v = (uint32_t *)(blk + m.g.c2v); m.act[d].v2lm = (uint32_t *)(blk + m.g.v2lm);
+    m.act[d].nv = D->gen_act_nv[d];
+  }
+  return true;
+}
+
+// Lane abstraction of the cooperative phase: a wave on the device, a single "lane" in the host check.
+#if defined(__HIPCC__)
+#define G_NL 64u
+__device__ __forceinline__ uint32_t g_lane() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t g_excl_scan(uint32_t x, uint32_t *total) { return wave_excl_scan(x, total); }
+__device__ __forceinline__ bool g_any(bool b) { return __ballot(b) != 0; }
+#else
+#define G_NL 1u
+inline uint32_t g_lane() { return 0; }
+inline uint32_t g_excl_scan(uint32_t x, uint32_t *total) { *total = x; return 0; }
+inline bool g_any(bool b) { return b; }
+#endif
+
+// Phase 1 (one lane): connectivity header, topology splits, Edgebreaker symbols (standard or valence), start faces,
+// vertex compaction, attribute seam bits.  Leaves the reader position in D->end_pos for phase 3.
+__device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, RansScratch rs) {
   const uint8_t *s = arena + L.stream;
   // ---------------------------------------------------------------- MeshEdgeBreakerDecoder.cs:25-134
   D->traversal_type = (uint8_t)r.u8();
@@ -574,21 +618,21 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
   GREQ(r.ok && nsplits64 <= F && nsplits64 <= L.cap_splits, 117);
   const uint32_t S = (uint32_t)nsplits64;
   D->num_splits = S;
-  const GenLayout g = gen_layout(F, VMAX, L.cap_splits, nad, L.stream_len);
-  GREQ(g.total <= L.gen_bytes, 640);
-  uint8_t *G = arena + L.gen;
-  // arrays (the fast path's regions are free for a general mesh)
-  Ct ct;
-  ct.opp = (uint32_t *)(arena + L.frec); ct.c2v = ct.opp + C; ct.vcorner = (uint32_t *)(arena + L.vrec);
-  ct.F = F; ct.C = C; ct.nv = 0; ct.vmax = VMAX;
-  uint8_t *is_hole = arena + L.vvis;
+  D->num_all_vertices = 0;
+  for (uint32_t d = 0; d < DSA_MAX_ATT_DATA; ++d) D->gen_act_nv[d] = 0;
+  MeshCtx m;
+  if (!mesh_ctx(arena, L, D, m)) return false;
+  const GenLayout &g = m.g;
+  uint8_t *G = m.G;
+  Ct &ct = m.ct;
+  Act *act = m.act;
+  uint8_t *is_hole = m.is_hole;
   uint32_t *valences = (uint32_t *)(arena + L.vstamp);
   uint32_t *ctx_syms = (uint32_t *)(arena + L.fstamp);
   uint32_t *invalid_list = (uint32_t *)(arena + L.vrank);
   uint32_t *stack = (uint32_t *)(G + g.stack);
   uint32_t *splits = (uint32_t *)(G + g.splits), *active = (uint32_t *)(G + g.active);
   rs.cum = (uint32_t *)(G + g.cum); rs.cum_cap = g.cum_entries;
-  int32_t *c2p = (int32_t *)(arena + L.faces);
   for (uint32_t c = 0; c < C; ++c) { ct.opp[c] = DSA_INVALID; ct.c2v[c] = DSA_INVALID; }
   for (uint32_t v = 0; v < VMAX; ++v) is_hole[v] = 1;
   if (S > 0) for (uint32_t f = 0; f < F; ++f) active[f] = DSA_INVALID;   // topologySplitActiveCorners as a direct map
@@ -827,13 +871,7 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
   D->num_vertices = num_conn_vertices;
   D->num_all_vertices = ct.nv;
   // ---------------------------------------------------------------- attribute seams, :502-535
-  Act act[DSA_MAX_ATT_DATA];
   for (uint32_t d = 0; d < nad; ++d) {
-    uint8_t *blk = G + g.data + (uint64_t)d * g.data_stride;
-    act[d].ct = &ct;
-    act[d].edge_seam = blk + g.edge_seam; act[d].vert_seam = blk + g.vert_seam;
-    act[d].c2v = (uint32_t *)(blk + g.c2v); act[d].v2lm = (uint32_t *)(blk + g.v2lm);
-    act[d].nv = 0;
     for (uint32_t c = 0; c < C; ++c) { act[d].edge_seam[c] = 0; act[d].c2v[c] = DSA_INVALID; }
     for (uint32_t v = 0; v < VMAX; ++v) act[d].vert_seam[v] = 0;
   }
@@ -844,80 +882,150 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
       if (oc / 3 < c / 3) continue;
       for (uint32_t d = 0; d < nad; ++d) if (seams[d].next()) act[d].add_seam_edge(c);
     }
-    // RecomputeVertices, MeshAttributeCornerTable.cs:95-155
-    for (uint32_t d = 0; d < nad; ++d) {
-      Act &A = act[d];
-      uint32_t num_new = 0;
-      for (uint32_t v = 0; v < ct.nv; ++v) {
+  }
+  D->end_pos = r.pos;
+  return true;
+}
+
+// Phase 2 (cooperative: every lane owns vertices): attribute vertices per corner (RecomputeVertices,
+// MeshAttributeCornerTable.cs:95-155) and points per corner (AssignPointsToCorners, MeshEdgeBreakerDecoder.cs:537-638).
+// Both number things vertex by vertex and, inside a vertex, in ring order; the counts of a chunk of vertices are
+// prefix-summed, so every lane can write the ids of its own vertex.
+__device__ bool mesh_tables(uint8_t *arena, const MeshLayout &L, MeshDesc *D) {
+  MeshCtx m;
+  if (!mesh_ctx(arena, L, D, m)) return false;
+  const Ct &ct = m.ct;
+  const uint32_t C = m.C, nad = m.nad, lane = g_lane();
+  for (uint32_t d = 0; d < nad; ++d) {
+    Act &A = m.act[d];
+    uint32_t base = 0;
+    for (uint32_t v0 = 0; v0 < ct.nv; v0 += G_NL) {
+      const uint32_t v = v0 + lane;
+      uint32_t cnt = 0, first_c = DSA_INVALID;
+      bool bad = false;
+      if (v < ct.nv) {
         const uint32_t c = ct.left_most(v);
-        if (c == DSA_INVALID) continue;
-        GREQ(c < C && num_new < C, 650);
-        uint32_t first_vert = num_new++, first_c = c;
-        if (A.vert_seam[v]) {
-          uint32_t a = A.swing_left(first_c), guard = 0;
-          while (a != DSA_INVALID) {
-            first_c = a;
-            a = A.swing_left(a);
-            GREQ(a != c && ++guard <= C, 651);
+        if (c != DSA_INVALID) {
+          if (c >= C) bad = true;
+          else {
+            first_c = c;
+            if (A.vert_seam[v]) {
+              uint32_t a = A.swing_left(first_c), guard = 0;
+              while (a != DSA_INVALID) {
+                first_c = a;
+                a = A.swing_left(a);
+                if (a == c || ++guard > C) { bad = true; break; }
+              }
+            }
+            cnt = 1;
+            uint32_t a = ct.swing_right(first_c), guard = 0;
+            while (!bad && a != DSA_INVALID && a != first_c) {
+              if (++guard > C) { bad = true; break; }
+              if (A.edge_seam[cnx(a)]) ++cnt;
+              a = ct.swing_right(a);
+            }
           }
         }
-        A.c2v[first_c] = first_vert;
-        A.v2lm[first_vert] = first_c;
-        uint32_t a = ct.swing_right(first_c), guard = 0;
+      }
+      if (g_any(bad)) { if (lane == 0) fail(D, ST_INVALID, 651); return false; }
+      uint32_t total;
+      uint32_t id = base + g_excl_scan(cnt, &total);
+      if (g_any(cnt && id + cnt > C)) { if (lane == 0) fail(D, ST_INVALID, 650); return false; }
+      if (cnt) {
+        A.c2v[first_c] = id;
+        A.v2lm[id] = first_c;
+        uint32_t a = ct.swing_right(first_c);
         while (a != DSA_INVALID && a != first_c) {
-          GREQ(++guard <= C, 652);
-          if (A.edge_seam[cnx(a)]) { GREQ(num_new < C, 650); first_vert = num_new++; A.v2lm[first_vert] = a; }
-          A.c2v[a] = first_vert;
+          if (A.edge_seam[cnx(a)]) { ++id; A.v2lm[id] = a; }
+          A.c2v[a] = id;
           a = ct.swing_right(a);
         }
       }
-      A.nv = num_new;
+      base += total;
     }
+    A.nv = base;
+    if (lane == 0) D->gen_act_nv[d] = base;
   }
   // ---------------------------------------------------------------- AssignPointsToCorners, :537-638
-  uint32_t num_points = 0;
+  int32_t *c2p = m.c2p;
+  const uint8_t *is_hole = m.is_hole;
   if (nad == 0) {
-    for (uint32_t c = 0; c < C; ++c) c2p[c] = (int32_t)ct.c2v[c];
-    num_points = num_conn_vertices;
-  } else {
-    for (uint32_t c = 0; c < C; ++c) c2p[c] = 0;
-    for (uint32_t v = 0; v < ct.nv; ++v) {
-      uint32_t c = ct.left_most(v);
-      if (c == DSA_INVALID) continue;
-      GREQ(c < C, 660);
-      uint32_t dedup_first = c;
-      if (!is_hole[v]) {
-        for (uint32_t d = 0; d < nad; ++d) {
-          const uint32_t vv = ct.c2v[c];
-          if (vv >= VMAX || !act[d].vert_seam[vv]) continue;                 // IsCornerOnSeam
-          const uint32_t vid = act[d].vertex(c);
-          uint32_t a = ct.swing_right(c), guard = 0;
-          bool seam_found = false;
-          while (a != c) {
-            GREQ(a != DSA_INVALID && ++guard <= C, 661);
-            if (act[d].vertex(a) != vid) { dedup_first = a; seam_found = true; break; }
+    for (uint32_t c = lane; c < C; c += G_NL) c2p[c] = (int32_t)ct.c2v[c];
+    if (lane == 0) D->num_points = D->num_vertices;
+    return true;
+  }
+  for (uint32_t c = lane; c < C; c += G_NL) c2p[c] = 0;
+  uint32_t base = 0;
+  for (uint32_t v0 = 0; v0 < ct.nv; v0 += G_NL) {
+    const uint32_t v = v0 + lane;
+    uint32_t cnt = 0, dedup_first = DSA_INVALID;
+    bool bad = false;
+    if (v < ct.nv) {
+      const uint32_t c = ct.left_most(v);
+      if (c != DSA_INVALID) {
+        if (c >= C) bad = true;
+        else {
+          dedup_first = c;
+          if (!is_hole[v]) {
+            for (uint32_t d = 0; d < nad && !bad; ++d) {
+              const uint32_t vv = ct.c2v[c];
+              if (vv >= m.VMAX || !m.act[d].vert_seam[vv]) continue;           // IsCornerOnSeam
+              const uint32_t vid = m.act[d].vertex(c);
+              uint32_t a = ct.swing_right(c), guard = 0;
+              bool seam_found = false;
+              while (a != c) {
+                if (a == DSA_INVALID || ++guard > C) { bad = true; break; }
+                if (m.act[d].vertex(a) != vid) { dedup_first = a; seam_found = true; break; }
+                a = ct.swing_right(a);
+              }
+              if (seam_found) break;
+            }
+          }
+          cnt = 1;
+          uint32_t prev_c = dedup_first, a = ct.swing_right(dedup_first), guard = 0;
+          while (!bad && a != DSA_INVALID && a != dedup_first) {
+            if (a >= C || ++guard > C) { bad = true; break; }
+            for (uint32_t d = 0; d < nad; ++d) if (m.act[d].vertex(a) != m.act[d].vertex(prev_c)) { ++cnt; break; }
+            prev_c = a;
             a = ct.swing_right(a);
           }
-          if (seam_found) break;
         }
       }
-      c = dedup_first;
-      GREQ(num_points < L.cap_points, 662);
-      c2p[c] = (int32_t)num_points++;
-      uint32_t prev_c = c, guard = 0;
-      c = ct.swing_right(c);
-      while (c != DSA_INVALID && c != dedup_first) {
-        GREQ(c < C && ++guard <= C, 663);
+    }
+    if (g_any(bad)) { if (lane == 0) fail(D, ST_INVALID, 661); return false; }
+    uint32_t total;
+    uint32_t id = base + g_excl_scan(cnt, &total);
+    if (g_any(cnt && id + cnt > L.cap_points)) { if (lane == 0) fail(D, ST_INVALID, 662); return false; }
+    if (cnt) {
+      c2p[dedup_first] = (int32_t)id;
+      uint32_t prev_c = dedup_first, a = ct.swing_right(dedup_first);
+      while (a != DSA_INVALID && a != dedup_first) {
         bool seam = false;
-        for (uint32_t d = 0; d < nad; ++d) if (act[d].vertex(c) != act[d].vertex(prev_c)) { seam = true; break; }
-        if (seam) { GREQ(num_points < L.cap_points, 662); c2p[c] = (int32_t)num_points++; }
-        else c2p[c] = c2p[prev_c];
-        prev_c = c;
-        c = ct.swing_right(c);
+        for (uint32_t d = 0; d < nad; ++d) if (m.act[d].vertex(a) != m.act[d].vertex(prev_c)) { seam = true; break; }
+        if (seam) ++id;
+        c2p[a] = (int32_t)id;
+        prev_c = a;
+        a = ct.swing_right(a);
       }
     }
+    base += total;
   }
-  D->num_points = num_points;
+  if (lane == 0) D->num_points = base;
+  return true;
+}
+
+// Phase 3 (one lane): the attribute section -- per decoder the traversal order, point maps, values.
+__device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D, RansScratch rs) {
+  MeshCtx m;
+  if (!mesh_ctx(arena, L, D, m)) return false;
+  Rd r(arena + L.stream, L.stream_len, D->end_pos);
+  const GenLayout &g = m.g;
+  uint8_t *G = m.G;
+  Ct &ct = m.ct;
+  Act *act = m.act;
+  int32_t *c2p = m.c2p;
+  const uint32_t F = m.F, C = m.C, VMAX = m.VMAX, nad = m.nad, num_points = D->num_points;
+  rs.cum = (uint32_t *)(G + g.cum); rs.cum_cap = g.cum_entries;
   // ---------------------------------------------------------------- attribute section, ConnectivityDecoder.cs:16-44
   D->off_attributes = r.pos;
   const uint32_t ndec = r.u8();
@@ -947,7 +1055,7 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
   // ---------------------------------------------------------------- per decoder: sequence, values
   uint8_t *fvis = G + g.fvis, *vvis = G + g.vvis;
   uint32_t *dfs = (uint32_t *)(G + g.dfs);
-  const uint32_t NVMAX = C > VMAX ? C : VMAX;
+  const uint32_t NVMAX = m.NVMAX;
   uint32_t *shared_d2c = nullptr, *shared_pids = nullptr, shared_entries = 0;
   int32_t *shared_v2d = nullptr;
   const uint32_t *shared_map = nullptr;
@@ -1007,13 +1115,23 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
   return true;
 }
 
+
+// The whole mesh in one go (host check; the device runs the three phases as separate kernels so that the second
+// one can use the whole wave).
+__device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, RansScratch rs) {
+  return mesh_connectivity(arena, L, D, r, rs) && mesh_tables(arena, L, D) && mesh_attributes(arena, L, D, rs);
+}
+
 #undef GFAIL
 #undef GREQ
 #undef GNOTIMPL
 }  // namespace gen
 
 #if defined(__HIPCC__)
-// One wave per mesh, lane 0 works.  Runs on the third stream beside the fast kernels (which skip general meshes).
+// The general path as three kernels on the third stream, beside the fast kernels (which skip general meshes):
+//   k_general             one lane per mesh: connectivity + seam bits (sequential meshes: the whole decode)
+//   k_general_tables      one wave per mesh, all lanes: attribute corner tables, points per corner
+//   k_general_attributes  one lane per mesh: traversal orders, point maps, attribute values
 __global__ __launch_bounds__(WAVE) void k_general(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   __shared__ uint16_t sh_lut[GEN_LUT_SLOTS];
   __shared__ uint32_t sh_cum[GEN_LUT_SYMS + 1];
@@ -1025,9 +1143,25 @@ __global__ __launch_bounds__(WAVE) void k_general(uint8_t *arena, const MeshLayo
   Rd r(arena + L.stream, L.stream_len, D->end_pos);       // k_locate parked the reader behind the header
   gen::RansScratch rs = {sh_lut, sh_cum, nullptr, 0};
   if (D->encoder_method == 0) (void)gen::decode_sequential_mesh(arena, L, D, r, rs);
-  else (void)gen::decode_mesh(arena, L, D, r, rs);
+  else (void)gen::mesh_connectivity(arena, L, D, r, rs);
 }
-
+__global__ __launch_bounds__(WAVE) void k_general_tables(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  const uint32_t mesh = blockIdx.x;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (!D->general || D->encoder_method == 0 || status_of(D) != ST_OK) return;
+  (void)gen::mesh_tables(arena, layouts[mesh], D);
+}
+__global__ __launch_bounds__(WAVE) void k_general_attributes(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  __shared__ uint16_t sh_lut[GEN_LUT_SLOTS];
+  __shared__ uint32_t sh_cum[GEN_LUT_SYMS + 1];
+  const uint32_t mesh = blockIdx.x;
+  if (mesh >= n || threadIdx.x != 0) return;
+  MeshDesc *D = &descs[mesh];
+  if (!D->general || D->encoder_method == 0 || status_of(D) != ST_OK) return;
+  gen::RansScratch rs = {sh_lut, sh_cum, nullptr, 0};
+  (void)gen::mesh_attributes(arena, layouts[mesh], D, rs);
+}
 #endif
 
 }  // namespace dsa
