@@ -84,3 +84,24 @@ def test_bad_mesh_fails_alone(ctx):
     for f in (bad_faces, nonmanifold):
         with pytest.raises(dsa.InvalidDataException):
             enc.EncodeBatch([dsa.MeshData(pos, faces), dsa.MeshData(pos, f)])
+
+
+def test_edge_case_inputs_match_cpu_coder(ctx):
+    """One triangle, degenerate ranges, zero normals, huge coordinates, extreme bit depths."""
+    enc = dsa.DracoEncoder(ctx)
+    tri = np.array([[0, 1, 2]], np.uint32)
+    p3 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    cases = [
+        (p3, tri, None, None, dsa.Config()),
+        (np.zeros((3, 3), np.float32) + 5.0, tri, np.zeros((3, 3), np.float32), np.zeros((3, 2), np.float32), dsa.Config()),     # range 0, zero normals
+        (p3 * 1e6 - 3e5, tri, np.array([[0, 0, -1], [1e-9, 0, 0], [-1, -1, -1]], np.float32), p3[:, :2], dsa.Config(position_bits=20, texcoord_bits=20, normal_bits=20)),
+        (p3, tri, np.array([[0, 0, 1], [0, 1, 0], [1, 0, 0]], np.float32), p3[:, :2], dsa.Config(position_bits=1, texcoord_bits=1, normal_bits=2)),
+    ]
+    pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 30, 20, 8)
+    cases.append((pos * np.float32(1e-6), faces, -nrm, uv * 1000, dsa.Config(speed=0)))
+    cases.append((pos, faces, nrm, uv, dsa.Config(speed=10, symbol_scheme=0)))
+    for p, f, n_, u_, cfg in cases:
+        got = enc.Encode(dsa.MeshData(p, f, n_, u_), cfg)
+        assert got == cpu_stream(p, f, n_, u_, cfg)
+        ref = oracle.decode(got)
+        assert ref.num_faces == len(f)
