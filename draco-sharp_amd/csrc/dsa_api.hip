@@ -57,6 +57,11 @@ struct dsa_batch {
   hipEvent_t ev_sym[2] = {};
   bool have_events = false;
   float stage_ms[DSA_NUM_STAGES] = {};
+  // meshes the fast kernels handed back (DSA_SITE_RETRY_GENERAL): decoded again through the general path in a batch
+  // of their own by dsa_batch_wait; every per-mesh accessor follows retry_index
+  bool all_general = false;
+  dsa_batch *retry = nullptr;
+  std::vector<int32_t> retry_index;
 };
 
 namespace {
@@ -79,7 +84,7 @@ dsa_status set_err(dsa_context *ctx, dsa_status st, const char *fmt, ...) {
                                          "%s failed: %s", #call, hipGetErrorString(e_));          \
   } while (0)
 
-dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *streams, const size_t *lengths, dsa_batch **out) {
+dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *streams, const size_t *lengths, dsa_batch **out, bool all_general = false) {
   if (!ctx || !out || (n && (!streams || !lengths))) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "null argument");
   if (n > 65535) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "batch too large (max 65535 meshes)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -87,6 +92,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
   if (!b) return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "host allocation failed");
   b->ctx = ctx;
   b->n = n;
+  b->all_general = all_general;
   b->layouts.resize(n);
   b->host.resize(n);
   b->descs.resize(n);
@@ -104,7 +110,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
   const uint64_t streams_end = cur;
   for (uint32_t i = 0; i < n; ++i) {
     HostMesh &h = b->host[i];
-    host_parse(streams[i], lengths[i], h);
+    host_parse(streams[i], lengths[i], h, all_general);
     MeshLayout &L = b->layouts[i];
     if (h.status != 0) { h.faces = 0; h.enc_vertices = 0; h.split_symbols = 0; h.splits = 0; h.atts.clear(); h.general = false; }
     const uint64_t F = h.faces, V = (uint64_t)h.enc_vertices + h.split_symbols;
@@ -229,6 +235,8 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   const uint32_t n = b->n;
   b->decoded = true;
   b->collected = false;
+  if (b->retry) { dsa_batch_free(b->retry); b->retry = nullptr; }
+  b->retry_index.clear();
   if (n == 0) return DSA_OK;
   hipStream_t st = ctx->stream;
   const bool prof = ctx->profiling;
@@ -347,12 +355,39 @@ dsa_status dsa_batch_wait(dsa_batch *b) {
     HIP_TRY(ctx, hipEventElapsedTime(&b->stage_ms[STG_TOTAL], b->ev[0], b->ev[STG_TOTAL]));
   }
   b->collected = true;
+  // second chance: meshes whose prediction schemes need the general path's tables (the fast kernels find that out
+  // only behind the symbol streams, where the host parse does not go)
+  if (!b->all_general) {
+    std::vector<uint32_t> again;
+    for (uint32_t i = 0; i < b->n; ++i)
+      if (b->descs[i].status == ST_NOTIMPL && b->descs[i].detail == DSA_SITE_RETRY_GENERAL) again.push_back(i);
+    if (!again.empty()) {
+      std::vector<std::vector<uint8_t>> copies(again.size());
+      std::vector<const uint8_t *> ptrs(again.size());
+      std::vector<size_t> lens(again.size());
+      for (size_t k = 0; k < again.size(); ++k) {
+        const MeshLayout &L = b->layouts[again[k]];
+        copies[k].resize(L.stream_len);
+        if (L.stream_len) HIP_TRY(ctx, hipMemcpy(copies[k].data(), b->arena + L.stream, L.stream_len, hipMemcpyDeviceToHost));
+        ptrs[k] = copies[k].data(); lens[k] = L.stream_len;
+      }
+      dsa_batch *rb = nullptr;
+      dsa_status st = build_batch(ctx, (uint32_t)again.size(), ptrs.data(), lens.data(), &rb, true);
+      if (st == DSA_OK) st = dsa_batch_decode(rb);
+      if (st == DSA_OK) st = dsa_batch_wait(rb);
+      if (st != DSA_OK) { if (rb) dsa_batch_free(rb); b->collected = false; return st; }
+      b->retry = rb;
+      b->retry_index.assign(b->n, -1);
+      for (size_t k = 0; k < again.size(); ++k) b->retry_index[again[k]] = (int32_t)k;
+    }
+  }
   return DSA_OK;
 }
 
 void dsa_batch_free(dsa_batch *b) {
   if (!b) return;
   (void)hipSetDevice(b->ctx->device);
+  if (b->retry) { dsa_batch_free(b->retry); b->retry = nullptr; }
   if (b->have_events) for (int i = 0; i <= DSA_NUM_STAGES; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
   if (b->have_events) for (int i = 0; i < 2; ++i) if (b->ev_sym[i]) (void)hipEventDestroy(b->ev_sym[i]);
   if (b->arena) (void)hipFree(b->arena);
@@ -377,9 +412,18 @@ uint64_t dsa_batch_algorithmic_bytes(const dsa_batch *b) {
       total += (uint64_t)A.num_entries * A.nc * dt_len(A.data_type) + 4ull * D.num_points;
     }
   }
+  if (b->retry) total += dsa_batch_algorithmic_bytes(b->retry);
   return total;
 }
 
+// a mesh that was decoded again lives in the retry batch
+#define FOLLOW_RETRY(b, mesh, call)                                                                  \
+  if ((b) && (b)->retry && (mesh) < (b)->n && (b)->retry_index[mesh] >= 0) {                         \
+    const dsa_batch *rb_ = (b)->retry;                                                               \
+    const uint32_t rm_ = (uint32_t)(b)->retry_index[mesh];                                           \
+    (void)rb_; (void)rm_;                                                                            \
+    return call;                                                                                     \
+  }
 #define CHECK_MESH(b, mesh)                                                                         \
   if (!(b)) return DSA_ERR_INVALID_ARGUMENT;                                                        \
   if (!(b)->collected) return set_err((b)->ctx, DSA_ERR_INVALID_ARGUMENT, "results not collected: call dsa_batch_wait"); \
@@ -390,6 +434,7 @@ uint64_t dsa_batch_algorithmic_bytes(const dsa_batch *b) {
   if ((a) >= (b)->descs[mesh].num_attributes) return set_err((b)->ctx, DSA_ERR_INVALID_ARGUMENT, "attribute index %u out of range", (unsigned)(a));
 
 dsa_status dsa_batch_mesh_info(const dsa_batch *b, uint32_t mesh, dsa_mesh_info *out) {
+  FOLLOW_RETRY(b, mesh, dsa_batch_mesh_info(rb_, rm_, out));
   CHECK_MESH(b, mesh);
   if (!out) return DSA_ERR_INVALID_ARGUMENT;
   const MeshDesc &D = b->descs[mesh];
@@ -403,6 +448,7 @@ dsa_status dsa_batch_mesh_info(const dsa_batch *b, uint32_t mesh, dsa_mesh_info 
 }
 
 dsa_status dsa_batch_attribute_info(const dsa_batch *b, uint32_t mesh, uint32_t a, dsa_attribute_info *out) {
+  FOLLOW_RETRY(b, mesh, dsa_batch_attribute_info(rb_, rm_, a, out));
   CHECK_ATTR(b, mesh, a);
   if (!out) return DSA_ERR_INVALID_ARGUMENT;
   const AttrDesc &A = b->descs[mesh].att[a];
@@ -424,20 +470,24 @@ static dsa_status copy_out(const dsa_batch *b, void *dst, uint64_t off, uint64_t
 }
 
 dsa_status dsa_batch_copy_faces(const dsa_batch *b, uint32_t mesh, int32_t *dst) {
+  FOLLOW_RETRY(b, mesh, dsa_batch_copy_faces(rb_, rm_, dst));
   CHECK_MESH(b, mesh);
   if (b->descs[mesh].status != ST_OK) return set_err(b->ctx, (dsa_status)b->descs[mesh].status, "mesh %u failed to decode", mesh);
   return copy_out(b, dst, b->layouts[mesh].faces, 12ull * b->descs[mesh].num_faces);
 }
 dsa_status dsa_batch_copy_attribute_values(const dsa_batch *b, uint32_t mesh, uint32_t a, void *dst) {
+  FOLLOW_RETRY(b, mesh, dsa_batch_copy_attribute_values(rb_, rm_, a, dst));
   CHECK_ATTR(b, mesh, a);
   const AttrDesc &A = b->descs[mesh].att[a];
   return copy_out(b, dst, b->layouts[mesh].out[a], (uint64_t)A.num_entries * A.nc * dt_len(A.data_type));
 }
 dsa_status dsa_batch_copy_point_map(const dsa_batch *b, uint32_t mesh, uint32_t a, uint32_t *dst) {
+  FOLLOW_RETRY(b, mesh, dsa_batch_copy_point_map(rb_, rm_, a, dst));
   CHECK_ATTR(b, mesh, a);
   return copy_out(b, dst, b->layouts[mesh].map[a], 4ull * b->descs[mesh].num_points);
 }
 dsa_status dsa_batch_copy_portable_values(const dsa_batch *b, uint32_t mesh, uint32_t a, int32_t *dst) {
+  FOLLOW_RETRY(b, mesh, dsa_batch_copy_portable_values(rb_, rm_, a, dst));
   CHECK_ATTR(b, mesh, a);
   const AttrDesc &A = b->descs[mesh].att[a];
   if (A.source == SRC_BYTES) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "generic attributes have no portable form");
@@ -445,19 +495,23 @@ dsa_status dsa_batch_copy_portable_values(const dsa_batch *b, uint32_t mesh, uin
 }
 
 const int32_t *dsa_batch_device_faces(const dsa_batch *b, uint32_t mesh) {
+  FOLLOW_RETRY(b, mesh, dsa_batch_device_faces(rb_, rm_));
   if (!b || mesh >= b->n) return nullptr;
   return (const int32_t *)(b->arena + b->layouts[mesh].faces);
 }
 const void *dsa_batch_device_attribute_values(const dsa_batch *b, uint32_t mesh, uint32_t a) {
+  FOLLOW_RETRY(b, mesh, dsa_batch_device_attribute_values(rb_, rm_, a));
   if (!b || mesh >= b->n || a >= DSA_MAX_ATT) return nullptr;
   return b->arena + b->layouts[mesh].out[a];
 }
 const uint32_t *dsa_batch_device_point_map(const dsa_batch *b, uint32_t mesh, uint32_t a) {
+  FOLLOW_RETRY(b, mesh, dsa_batch_device_point_map(rb_, rm_, a));
   if (!b || mesh >= b->n || a >= DSA_MAX_ATT) return nullptr;
   return (const uint32_t *)(b->arena + b->layouts[mesh].map[a]);
 }
 
 dsa_status dsa_batch_copy_debug(const dsa_batch *b, uint32_t mesh, int what, void *dst, size_t dst_bytes, size_t *written) {
+  FOLLOW_RETRY(b, mesh, dsa_batch_copy_debug(rb_, rm_, what, dst, dst_bytes, written));
   CHECK_MESH(b, mesh);
   const MeshDesc &D = b->descs[mesh];
   if (D.status != ST_OK && what != 4) return set_err(b->ctx, (dsa_status)D.status, "mesh %u failed to decode", mesh);

@@ -541,6 +541,7 @@ struct Options {
   int32_t pos_prediction = 1;        // 1 parallelogram, 0 difference
   int32_t uv_prediction = 1;
   int32_t generic_u8 = 0;            // add a per-vertex uint8 generic attribute (Integer decoder) when generic data is given
+  int32_t normal_prediction = 0;     // 0 difference, 6 geometric normal (the CPU coder only)
 };
 
 // Octahedral quantisation (OctahedronToolBox.cs:28-119)
@@ -670,7 +671,50 @@ struct MeshIn {
 
 // One attribute's value section: method, transform, compressed flag, symbols, prediction data
 // (SequentialIntegerAttributeEncoder.cs:55-128)
-static void write_attribute_values(ByteWriter &w, const PortableAttr &a, const CornerTable &ct, const Sequence &seq, const Options &opt) {
+// Area-weighted normal of the faces around a corner's vertex from the quantised positions, canonicalised to the
+// octahedron (MeshPredictionSchemeGeometricNormalPredictorArea.cs:16-63 + OctahedronToolBox.cs:121-137, with the
+// bitstream's 64-bit arithmetic).  Per-vertex attributes only: a data id's position is its vertex's.
+static void geometric_normal_prediction(const Octa &o, const CornerTable &ct, const std::vector<int32_t> &pos, uint32_t ci, int32_t v3[3]) {
+  auto P = [&](uint32_t c, int k) { return (int64_t)pos[(size_t)ct.vertex(c) * 3 + k]; };
+  uint64_t n[3] = {0, 0, 0};
+  uint32_t c = ci;
+  bool left = true;
+  while (c != kInvalid) {
+    uint32_t cn = CornerTable::next(c), cp = CornerTable::prev(c);
+    uint64_t a[3], b[3];
+    for (int k = 0; k < 3; ++k) { a[k] = (uint64_t)(P(cn, k) - P(ci, k)); b[k] = (uint64_t)(P(cp, k) - P(ci, k)); }
+    n[0] += a[1] * b[2] - a[2] * b[1];
+    n[1] += a[2] * b[0] - a[0] * b[2];
+    n[2] += a[0] * b[1] - a[1] * b[0];
+    if (left) {
+      c = ct.swing_left(c);
+      if (c == kInvalid) { c = ct.swing_right(ci); left = false; }
+      else if (c == ci) break;
+    } else c = ct.swing_right(c);
+  }
+  int64_t nv[3] = {(int64_t)n[0], (int64_t)n[1], (int64_t)n[2]};
+  uint64_t as = 0;
+  bool sat = false;
+  for (int k = 0; k < 3; ++k) {
+    uint64_t x = nv[k] < 0 ? (uint64_t)0 - (uint64_t)nv[k] : (uint64_t)nv[k];
+    if (x > (uint64_t)INT64_MAX || as > (uint64_t)INT64_MAX - x) sat = true; else as += x;
+  }
+  int64_t abs_sum = sat ? INT64_MAX : (int64_t)as;
+  const int64_t upper = (int64_t)1 << 29;
+  if (abs_sum > upper) { int64_t q = abs_sum / upper; for (int k = 0; k < 3; ++k) nv[k] /= q; }
+  for (int k = 0; k < 3; ++k) v3[k] = (int32_t)nv[k];
+  int64_t s3 = std::llabs((int64_t)v3[0]) + std::llabs((int64_t)v3[1]) + std::llabs((int64_t)v3[2]);
+  if (s3 == 0) v3[0] = o.center;
+  else {
+    v3[0] = (int32_t)(((int64_t)v3[0] * o.center) / s3);
+    v3[1] = (int32_t)(((int64_t)v3[1] * o.center) / s3);
+    int32_t rest = o.center - std::abs(v3[0]) - std::abs(v3[1]);
+    v3[2] = v3[2] >= 0 ? rest : -rest;
+  }
+}
+
+static void write_attribute_values(ByteWriter &w, const PortableAttr &a, const CornerTable &ct, const Sequence &seq, const Options &opt,
+                                   const PortableAttr *positions = nullptr) {
   int nc = a.nc;
   size_t entries = seq.data_to_corner.size();
   // values in entry order
@@ -680,6 +724,38 @@ static void write_attribute_values(ByteWriter &w, const PortableAttr &a, const C
     for (int c = 0; c < nc; ++c) d[e * nc + c] = a.vals[(size_t)v * nc + c];
   }
   std::vector<uint32_t> symbols(entries * nc);
+  if (a.seq_type == 3 && a.prediction == 6) {
+    // MeshPredictionSchemeGeometricNormalEncoder.cs:47-108: the prediction or its negation, whichever leaves the
+    // smaller correction; one flip bit per entry behind the transform data
+    check(positions != nullptr && positions->nc == 3, "geometric normal prediction needs quantised positions");
+    w.i8(6);
+    w.i8(3);
+    Octa o(a.bits);
+    std::vector<uint8_t> flips(entries);
+    auto mod_max = [&](int x) { return x > o.center ? x - o.max_q : (x < -o.center ? x + o.max_q : x); };
+    for (size_t e = 0; e < entries; ++e) {
+      int32_t v3[3];
+      geometric_normal_prediction(o, ct, positions->vals, seq.data_to_corner[e], v3);
+      int32_t pp[2], pn[2], cp[2], cn[2];
+      int s, t;
+      o.from_int_vector(v3, s, t); pp[0] = s; pp[1] = t;
+      int32_t neg[3] = {-v3[0], -v3[1], -v3[2]};
+      o.from_int_vector(neg, s, t); pn[0] = s; pn[1] = t;
+      oct_canon_corr(o, &d[e * 2], pp, cp);
+      oct_canon_corr(o, &d[e * 2], pn, cn);
+      int wp = std::abs(mod_max(cp[0])) + std::abs(mod_max(cp[1]));
+      int wn = std::abs(mod_max(cn[0])) + std::abs(mod_max(cn[1]));
+      const bool flip = !(wp < wn);
+      flips[e] = flip;
+      symbols[e * 2] = (uint32_t)(flip ? cn[0] : cp[0]); symbols[e * 2 + 1] = (uint32_t)(flip ? cn[1] : cp[1]);
+    }
+    w.u8(1);
+    encode_symbols(w, symbols, nc, opt.force_scheme, opt.compression_level);
+    w.i32(o.max_q);
+    w.i32(o.center);
+    write_rabs(w, flips);
+    return;
+  }
   if (a.seq_type == 3) {
     w.i8(0);   // Difference
     w.i8(3);   // NormalOctahedronCanonicalized
@@ -748,7 +824,7 @@ static void plan_mesh(const MeshIn &in, const Options &opt, MeshPlan &pl) {
   check(pl.seq.data_to_corner.size() == in.nv, "traversal did not reach every vertex");
   pl.atts.clear();
   { PortableAttr a; a.att_type = 0; a.nc = a.nc_out = 3; a.seq_type = 2; a.data_type = 9; a.prediction = opt.pos_prediction; a.bits = opt.pos_bits; pl.atts.push_back(a); }
-  if (in.normals) { PortableAttr a; a.att_type = 1; a.nc_out = 3; a.nc = 2; a.seq_type = 3; a.data_type = 9; a.bits = opt.normal_bits; a.prediction = 0; pl.atts.push_back(a); }
+  if (in.normals) { PortableAttr a; a.att_type = 1; a.nc_out = 3; a.nc = 2; a.seq_type = 3; a.data_type = 9; a.bits = opt.normal_bits; a.prediction = opt.normal_prediction == 6 ? 6 : 0; pl.atts.push_back(a); }
   if (in.uvs) { PortableAttr a; a.att_type = 3; a.nc = a.nc_out = 2; a.seq_type = 2; a.data_type = 9; a.prediction = opt.uv_prediction; a.bits = opt.uv_bits; pl.atts.push_back(a); }
   if (in.generic) { PortableAttr a; a.att_type = 4; a.nc = a.nc_out = 1; a.seq_type = 1; a.data_type = 2; a.prediction = 1; pl.atts.push_back(a); }
   pl.single = opt.single_connectivity != 0;
@@ -834,7 +910,7 @@ static void encode_mesh(const MeshIn &in, const Options &opt, std::vector<uint8_
   }
   ByteWriter w;
   write_stream(w, in, pl,
-               [&](ByteWriter &bw, size_t i) { write_attribute_values(bw, pl.atts[i], pl.ct, pl.seq, opt); },
+               [&](ByteWriter &bw, size_t i) { write_attribute_values(bw, pl.atts[i], pl.ct, pl.seq, opt, &pl.atts[0]); },
                [&](ByteWriter &bw, size_t i) { write_attribute_transform(bw, pl.atts[i]); });
   out.swap(w.d);
 }

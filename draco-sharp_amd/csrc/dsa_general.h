@@ -324,6 +324,90 @@ __device__ bool texcoords_portable_wrap(MeshDesc *D, const T &t, const uint32_t 
   return true;
 }
 
+// MeshPredictionSchemeGeometricNormalDecoder.cs:44-82 + ...GeometricNormalPredictorArea.cs:16-63 +
+// OctahedronToolBox.cs:28-77,121-137 with the bitstream's 64-bit arithmetic (D-23..D-27), in place on corr -> values.
+// One flip bit per entry is taken from the rABS block as the entries go by.
+template <class T>
+__device__ bool geometric_normal_oct(MeshDesc *D, const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t entries, int32_t *w,
+                                     const uint32_t *entry_to_point, uint32_t v2d_size, const int32_t *pos, const uint32_t *pos_map,
+                                     uint32_t num_points, uint32_t pos_entries, Rabs &flips, const OctParams &o, bool canonical, uint32_t max_steps) {
+  const int32_t max_value = o.max_q - 1;
+  for (uint32_t p = 0; p < entries; ++p) {
+    const uint32_t ci = d2c[p];
+    int64_t center[3] = {0, 0, 0};
+    // position of the vertex at a corner: corner -> vertex -> data id -> point -> position entry
+#define G_POS(corner, dst)                                                         \
+    {                                                                              \
+      const uint32_t v_ = t.vertex(corner);                                        \
+      GREQ(v_ != DSA_INVALID && v_ < v2d_size, 650);                               \
+      const int32_t d_ = v2d[v_];                                                  \
+      GREQ(d_ >= 0 && (uint32_t)d_ < entries, 651);                                \
+      const uint32_t point_ = entry_to_point[d_];                                  \
+      GREQ(point_ < num_points, 652);                                              \
+      const uint32_t e_ = pos_map[point_];                                         \
+      GREQ(e_ < pos_entries, 653);                                                 \
+      for (int k_ = 0; k_ < 3; ++k_) (dst)[k_] = pos[(size_t)e_ * 3 + k_];         \
+    }
+    G_POS(ci, center);
+    uint64_t n[3] = {0, 0, 0};
+    uint32_t c = ci, steps = 0;
+    bool left = true;
+    while (c != DSA_INVALID) {                          // VertexCornersIterator.cs: left from the corner, then right from it
+      GREQ(++steps <= max_steps, 654);
+      int64_t pn[3], pp[3];
+      G_POS(cnx(c), pn);
+      G_POS(cpv(c), pp);
+      uint64_t a[3], b[3];
+      for (int k = 0; k < 3; ++k) { a[k] = (uint64_t)(pn[k] - center[k]); b[k] = (uint64_t)(pp[k] - center[k]); }
+      n[0] += a[1] * b[2] - a[2] * b[1];
+      n[1] += a[2] * b[0] - a[0] * b[2];
+      n[2] += a[0] * b[1] - a[1] * b[0];
+      if (left) {
+        c = t.swing_left(c);
+        if (c == DSA_INVALID) { c = t.swing_right(ci); left = false; }
+        else if (c == ci) break;
+      } else c = t.swing_right(c);
+    }
+#undef G_POS
+    int64_t nv[3] = {(int64_t)n[0], (int64_t)n[1], (int64_t)n[2]};
+    uint64_t as = 0;
+    bool sat = false;
+    for (int k = 0; k < 3; ++k) {
+      const uint64_t x = nv[k] < 0 ? (uint64_t)0 - (uint64_t)nv[k] : (uint64_t)nv[k];
+      if (x > 0x7FFFFFFFFFFFFFFFull || as > 0x7FFFFFFFFFFFFFFFull - x) sat = true; else as += x;
+    }
+    const int64_t abs_sum = sat ? 0x7FFFFFFFFFFFFFFFll : (int64_t)as, upper = (int64_t)1 << 29;
+    if (abs_sum > upper) { const int64_t q = abs_sum / upper; for (int k = 0; k < 3; ++k) nv[k] /= q; }
+    int32_t v3[3] = {(int32_t)nv[0], (int32_t)nv[1], (int32_t)nv[2]};
+    auto abs64 = [](int32_t x) { return x < 0 ? -(int64_t)x : (int64_t)x; };
+    const int64_t s3 = abs64(v3[0]) + abs64(v3[1]) + abs64(v3[2]);
+    if (s3 == 0) v3[0] = o.center;
+    else {
+      v3[0] = (int32_t)(((int64_t)v3[0] * o.center) / s3);
+      v3[1] = (int32_t)(((int64_t)v3[1] * o.center) / s3);
+      const int32_t rest = o.center - (int32_t)abs64(v3[0]) - (int32_t)abs64(v3[1]);
+      v3[2] = v3[2] >= 0 ? rest : -rest;
+    }
+    if (flips.next()) { v3[0] = -v3[0]; v3[1] = -v3[1]; v3[2] = -v3[2]; }
+    int32_t ps, pt;
+    if (v3[0] >= 0) { ps = v3[1] + o.center; pt = v3[2] + o.center; }
+    else {
+      const int32_t a1 = (int32_t)abs64(v3[1]), a2 = (int32_t)abs64(v3[2]);
+      ps = v3[1] < 0 ? a2 : max_value - a2;
+      pt = v3[2] < 0 ? a1 : max_value - a1;
+    }
+    if ((ps == 0 && pt == 0) || (ps == 0 && pt == max_value) || (ps == max_value && pt == 0)) { ps = max_value; pt = max_value; }
+    else if (ps == 0 && pt > o.center) pt = o.center - (pt - o.center);
+    else if (ps == max_value && pt < o.center) pt = o.center + (o.center - pt);
+    else if (pt == max_value && ps < o.center) ps = o.center + (o.center - ps);
+    else if (pt == 0 && ps > o.center) ps = o.center - (ps - o.center);
+    int32_t os, ot;
+    oct_original(o, canonical, ps, pt, w[2 * p], w[2 * p + 1], os, ot);
+    w[2 * p] = os; w[2 * p + 1] = ot;
+  }
+  return true;
+}
+
 // What the prediction schemes of one attributes decoder see.  ct == nullptr: no corner table (linear sequencing of a
 // sequential mesh); act != nullptr: the attribute corner table of the decoder's attribute data.
 struct ValueCtx {
@@ -334,6 +418,7 @@ struct ValueCtx {
   const uint32_t *pids;
   uint8_t *orient;
   uint32_t orient_cap, num_points;
+  uint32_t num_verts, num_corners;   // size of v2d; bound on a corner fan
 };
 
 // Values of attribute ai (SequentialAttributeDecoder.cs:47-52,75-86 / SequentialIntegerAttributeDecoder.cs:23-101):
@@ -385,7 +470,10 @@ __device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, 
   // scheme selection, PredictionSchemeDecoderFactory.cs:9-76
   int eff = method;
   if (vc.ct == nullptr) eff = 0;                       // no corner table (linear sequencing): every scheme falls back to delta
-  else if (!(method == 1 || method == 5)) { if (method == 0) eff = 0; else GNOTIMPL(161); }
+  // which mesh schemes exist depends on the transform (D-28): wrap carries the parallelogram family and the texture
+  // coordinate schemes, the octahedral transforms carry only the geometric normal scheme; the rest is delta
+  else if (tt == 1) { if (method == 1 || method == 5) eff = method; else if (method == 0 || method == 6) eff = 0; else GNOTIMPL(161); }
+  else eff = method == 6 ? 6 : 0;
   a.pred_kind = (int8_t)eff;
   uint8_t *orient = nullptr;
   uint32_t num_orient = 0;
@@ -430,17 +518,31 @@ __device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, 
       if (!ok) return false;
     }
   } else {                                             // normal octahedron transforms (D-19)
-    GREQ(eff == 0, 501);
     const int32_t max_q = (int32_t)r.u32();
     if (tt == 3) (void)r.u32();
     GREQ(r.ok && max_q > 0 && (max_q & 1) == 1, 164);
     a.oct_max_q = max_q;
-    if (num_values == 0) return true;
     OctParams o;
     const int q = 32 - __builtin_clz((uint32_t)max_q);
     GREQ(q >= 2 && q <= 30, 165);
     const int32_t max_value = (1 << q) - 2;
     o.center = max_value / 2; o.max_q = (1 << q) - 1;
+    if (eff == 6) {                                    // MeshPredictionSchemeGeometricNormalDecoder.cs:71-82: flip bits behind the transform data
+      Rabs rd;
+      uint32_t endp;
+      rd.start(arena + L.stream, L.stream_len, r.pos, &endp);
+      GREQ(rd.ok, 655);
+      r.pos = endp;
+      if (num_values == 0) return true;
+      int pa = -1;                                     // parent = portable positions, SequentialAttributeDecoder.cs:58-73
+      for (uint32_t k = 0; k < ai; ++k) if (D->att[k].att_type == 0 && D->att[k].seq_type != 0) { pa = (int)k; break; }
+      GREQ(pa >= 0 && D->att[pa].nc_portable == 3, 656);
+      const int32_t *pos = (const int32_t *)(arena + L.work[pa]);
+      const uint32_t *pos_map = (const uint32_t *)(arena + L.map[pa]);
+      if (vc.act) return geometric_normal_oct(D, *vc.act, vc.d2c, vc.v2d, entries, w, vc.pids, vc.num_verts, pos, pos_map, vc.num_points, D->att[pa].num_entries, rd, o, tt == 3, vc.num_corners + 1);
+      return geometric_normal_oct(D, *vc.ct, vc.d2c, vc.v2d, entries, w, vc.pids, vc.num_verts, pos, pos_map, vc.num_points, D->att[pa].num_entries, rd, o, tt == 3, vc.num_corners + 1);
+    }
+    if (num_values == 0) return true;
     int32_t ps = 0, pt = 0;
     for (uint32_t e = 0; e < entries; ++e) {
       int32_t os, ot;
@@ -534,7 +636,7 @@ __device__ bool decode_sequential_mesh(uint8_t *arena, const MeshLayout &L, Mesh
   uint32_t natt = 0, first[DSA_MAX_ATT], count[DSA_MAX_ATT];
   for (uint32_t i = 0; i < ndec; ++i) if (!decode_descriptors(L, D, r, i, natt, &first[i], &count[i])) return false;
   D->num_attributes = natt;
-  ValueCtx vc = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, NP};
+  ValueCtx vc = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, NP, 0, 0};
   for (uint32_t i = 0; i < ndec; ++i) {
     for (uint32_t ai = first[i]; ai < first[i] + count[i]; ++ai) {
       uint32_t *map = (uint32_t *)(arena + L.map[ai]);
@@ -1108,6 +1210,7 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
     vc.d2c = d2c; vc.v2d = v2d; vc.pids = pids;
     vc.orient = dd >= 0 ? G + g.data + (uint64_t)dd * g.data_stride + g.orient : nullptr;
     vc.orient_cap = NVMAX; vc.num_points = num_points;
+    vc.num_verts = nverts; vc.num_corners = C;
     for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) if (!decode_values(arena, L, D, r, ai, entries, rs, vc)) return false;
     for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) if (!decode_transform_params(D, r, ai)) return false;
   }

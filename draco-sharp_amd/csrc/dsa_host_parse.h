@@ -107,7 +107,7 @@ static uint32_t dt_len(uint32_t dt) {
 }
 
 // Mirrors the head of k_locate (same checks, same order) up to the attribute descriptors.
-static void host_parse(const uint8_t *s, size_t len, HostMesh &m) {
+static void host_parse(const uint8_t *s, size_t len, HostMesh &m, bool want_general = false) {
   HRd r(s, len);
   auto bad = [&](int code) { m.status = code; };
   if (len < 11 || memcmp(s, "DRACO", 5) != 0) return bad(ST_INVALID);
@@ -187,7 +187,7 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m) {
     if (corner_dec[i]) m.general = true;
   }
   const bool force_general = getenv("DSA_FORCE_GENERAL") != nullptr;   // tests: every Edgebreaker mesh through k_general
-  if (force_general && !point_cloud) m.general = true;
+  if ((force_general || want_general) && !point_cloud) m.general = true;
   for (uint32_t i = 0; i < ndec; ++i) {
     uint64_t k = r.varint();
     if (!r.ok || m.atts.size() + k > DSA_MAX_ATT) return bad(ST_INVALID);

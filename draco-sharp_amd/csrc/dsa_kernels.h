@@ -193,10 +193,17 @@ __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, Attr
   if (a.have_scheme) {
     // only Difference and Parallelogram run on the device path for now
     // PredictionSchemeDecoderFactory.cs:24-36: without a corner table (point clouds) every method falls back to delta
+    // With a corner table the schemes a transform carries are (D-28): wrap -> parallelogram family + texture
+    // coordinates, octahedral -> geometric normal only; every other combination is the delta scheme.  Schemes that
+    // need the general path's tables send the mesh there: the host decodes it again (site DSA_SITE_RETRY_GENERAL).
     if (D->encoder_type == 0) a.pred_kind = 0;
-    else {
-      if (!(method == 0 || method == 1)) NOTIMPL(161);
-      a.pred_kind = (int8_t)method;
+    else if (a.pred_transform == 1) {
+      if (method == 5) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+      if (!(method == 0 || method == 1 || method == 6)) NOTIMPL(161);
+      a.pred_kind = method == 1 ? 1 : 0;
+    } else {
+      if (method == 6) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+      a.pred_kind = 0;
     }
     if (a.pred_transform == 1) {           // PredictionSchemeWrapDecodingTransform.cs:69-75
       a.wrap_min = (int32_t)r.u32();

@@ -11,6 +11,8 @@
 #define ST_OK 0
 #define ST_INVALID 1
 #define ST_NOTIMPL 2
+// detail site of a mesh the fast kernels hand back for the general path (dsa_batch_wait decodes it again there)
+#define DSA_SITE_RETRY_GENERAL 170
 
 // symbol source of an attribute's value section
 #define SRC_TAGGED 0   // tagged rANS scheme      (Entropy/SymbolDecoding.cs:30-50)

@@ -16,12 +16,14 @@ GRID, TORUS, SPHERE, HOLES, TWO_PARTS = 0, 1, 2, 3, 4
 class Options(C.Structure):
     _fields_ = [("pos_bits", C.c_int32), ("uv_bits", C.c_int32), ("normal_bits", C.c_int32),
                 ("single_connectivity", C.c_int32), ("force_scheme", C.c_int32),
-                ("compression_level", C.c_int32), ("pos_prediction", C.c_int32), ("uv_prediction", C.c_int32)]
+                ("compression_level", C.c_int32), ("pos_prediction", C.c_int32), ("uv_prediction", C.c_int32),
+                ("normal_prediction", C.c_int32)]
 
 
 def build(force=False):
     src = os.path.join(_DIR, "synth_encoder.cpp")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    deps = [src, os.path.join(_DIR, "..", "csrc", "dsa_encode_host.h")]
+    if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(_LIB_PATH) < os.path.getmtime(d) for d in deps):
         subprocess.check_call(["make", "-C", _DIR, "-s"])
     return _LIB_PATH
 

@@ -692,6 +692,108 @@ static void texcoords_portable_original(const Transform &tr, const CT &ct, const
   }
 }
 
+// MeshPredictionSchemeGeometricNormalDecoder.cs:44-82 +
+// MeshPredictionSchemeGeometricNormalPredictorArea.cs:16-63 +
+// MeshPredictionSchemeGeometricNormalPredictor.cs:19-33 +
+// OctahedronToolBox.cs:28-77,121-137.  The bitstream's arithmetic is kept where
+// the C# narrows it (D-23..D-26 in DESIGN.md): the area-weighted normal is summed
+// and scaled in 64 bits, its third component is normal[2], and the
+// canonicalisation multiplies in 64 bits.
+template <class CT>
+static void geometric_normal_original(const Transform &tr, const CT &ct, const EncodingData &ed,
+                                      const std::vector<int32_t> &corr,
+                                      const std::vector<uint32_t> &entry_to_point, const Attribute &pos,
+                                      const std::vector<uint8_t> &flips, std::vector<int32_t> &out) {
+  require(pos.nc_portable == 3, "normal prediction needs 3-component positions");
+  size_t entries = ed.data_to_corner.size();
+  out.assign(entries * 2, 0);
+  require(corr.size() >= entries * 2, "normals: fewer values than entries");
+  require(flips.size() >= entries, "normals: fewer flip bits than entries");
+  const OctaToolBox &oct = tr.oct;
+  const size_t pos_entries = pos.portable.size() / 3;
+  auto pos_of_corner = [&](uint32_t c, int64_t p[3]) {
+    uint32_t v = ct.vertex(c);
+    require(v != kInvalid && v < ed.vertex_to_data.size(), "normals: corner without vertex");
+    int32_t d = ed.vertex_to_data[v];
+    require(d >= 0 && (size_t)d < entry_to_point.size(), "normals: vertex without data id");
+    uint32_t point = entry_to_point[d];
+    require(pos.point_map.empty() || point < pos.point_map.size(), "normals: point outside the position map");
+    uint32_t e = pos.point_map.empty() ? point : pos.point_map[point];
+    require(e < pos_entries, "normals: position entry out of range");
+    for (int k = 0; k < 3; ++k) p[k] = pos.portable[(size_t)e * 3 + k];
+  };
+  const size_t max_steps = (size_t)ct.num_faces() * 3 + 1;
+  for (size_t p = 0; p < entries; ++p) {
+    uint32_t ci = ed.data_to_corner[p];
+    int64_t center[3];
+    pos_of_corner(ci, center);
+    uint64_t n[3] = {0, 0, 0};               // wrapping 64-bit sums
+    // VertexCornersIterator (Mesh/VertexCornersIterator.cs): swing left from the
+    // start corner; at a boundary swing right from the start corner.
+    uint32_t c = ci;
+    bool left = true;
+    size_t steps = 0;
+    while (c != kInvalid) {
+      require(++steps <= max_steps, "normals: corner fan does not close");
+      int64_t pn[3], pp[3];
+      pos_of_corner(CT::next(c), pn);
+      pos_of_corner(CT::prev(c), pp);
+      uint64_t a[3], b[3];
+      for (int k = 0; k < 3; ++k) { a[k] = (uint64_t)(pn[k] - center[k]); b[k] = (uint64_t)(pp[k] - center[k]); }
+      n[0] += a[1] * b[2] - a[2] * b[1];
+      n[1] += a[2] * b[0] - a[0] * b[2];
+      n[2] += a[0] * b[1] - a[1] * b[0];
+      if (left) {
+        c = ct.swing_left(c);
+        if (c == kInvalid) { c = ct.swing_right(ci); left = false; }
+        else if (c == ci) break;
+      } else c = ct.swing_right(c);
+    }
+    int64_t nv[3] = {(int64_t)n[0], (int64_t)n[1], (int64_t)n[2]};
+    // VectorD::AbsSum saturates instead of overflowing
+    auto abs_sum64 = [](const int64_t v[3]) {
+      uint64_t s = 0;
+      for (int k = 0; k < 3; ++k) {
+        uint64_t a = v[k] < 0 ? (uint64_t)0 - (uint64_t)v[k] : (uint64_t)v[k];
+        if (a > (uint64_t)INT64_MAX || s > (uint64_t)INT64_MAX - a) return (int64_t)INT64_MAX;
+        s += a;
+      }
+      return (int64_t)s;
+    };
+    const int64_t upper = (int64_t)1 << 29;
+    int64_t as = abs_sum64(nv);
+    if (as > upper) {
+      int64_t q = as / upper;
+      for (int k = 0; k < 3; ++k) nv[k] /= q;
+    }
+    int32_t v3[3] = {(int32_t)nv[0], (int32_t)nv[1], (int32_t)nv[2]};
+    // CanonicalizeIntegerVector
+    int64_t s3 = std::llabs((int64_t)v3[0]) + std::llabs((int64_t)v3[1]) + std::llabs((int64_t)v3[2]);
+    if (s3 == 0) v3[0] = oct.center;
+    else {
+      v3[0] = (int32_t)(((int64_t)v3[0] * oct.center) / s3);
+      v3[1] = (int32_t)(((int64_t)v3[1] * oct.center) / s3);
+      int32_t rest = oct.center - std::abs(v3[0]) - std::abs(v3[1]);
+      v3[2] = v3[2] >= 0 ? rest : -rest;
+    }
+    if (flips[p]) { v3[0] = -v3[0]; v3[1] = -v3[1]; v3[2] = -v3[2]; }
+    // IntegerVectorToQuantizedOctahedralCoords + CanonicalizeOctahedralCoords
+    int32_t s, t;
+    if (v3[0] >= 0) { s = v3[1] + oct.center; t = v3[2] + oct.center; }
+    else {
+      s = v3[1] < 0 ? std::abs(v3[2]) : oct.max_value - std::abs(v3[2]);
+      t = v3[2] < 0 ? std::abs(v3[1]) : oct.max_value - std::abs(v3[1]);
+    }
+    if ((s == 0 && t == 0) || (s == 0 && t == oct.max_value) || (s == oct.max_value && t == 0)) { s = oct.max_value; t = oct.max_value; }
+    else if (s == 0 && t > oct.center) t = oct.center - (t - oct.center);
+    else if (s == oct.max_value && t < oct.center) t = oct.center + (oct.center - t);
+    else if (t == oct.max_value && s < oct.center) s = oct.center + (oct.center - s);
+    else if (t == 0 && s > oct.center) s = oct.center - (s - oct.center);
+    int32_t pred[2] = {s, t};
+    tr.original(pred, &corr[p * 2], &out[p * 2]);
+  }
+}
+
 // ---------------------------------------------------------------------- mesh
 struct AttributeData {           // IO/Mesh/DecoderAttributeData.cs
   int decoder_id = -1;
@@ -1299,10 +1401,14 @@ struct AttributeSectionDecoder {
     else {
       ed = encoding_data_for(aid);
       act = att_corner_table_for(aid);
-      if (!(method == 1 || method == 5)) {
-        if (method == 0) eff = 0;
-        else throw Error(ERR_NOT_IMPLEMENTED, "prediction scheme not implemented in the oracle (multi-parallelogram / geometric normal / deprecated texcoords)");
-      }
+      // Which mesh schemes exist depends on the transform (the bitstream's factory): the wrap transform carries
+      // the parallelogram family and the texture-coordinate schemes, the octahedral transforms carry only the
+      // geometric normal scheme; every other combination is the delta scheme (D-28).
+      if (tr.type == 1) {
+        if (method == 1 || method == 5) eff = method;
+        else if (method == 0 || method == 6) eff = 0;
+        else throw Error(ERR_NOT_IMPLEMENTED, "prediction scheme not implemented in the oracle (multi-parallelogram / deprecated texcoords)");
+      } else eff = method == 6 ? 6 : 0;
     }
     // prediction data: scheme-specific first, then the transform's
     std::vector<uint8_t> orientations;
@@ -1319,7 +1425,22 @@ struct AttributeSectionDecoder {
       }
     }
     tr.decode_data(b);
+    std::vector<uint8_t> flips;
+    if (eff == 6) {                        // MeshPredictionSchemeGeometricNormalDecoder.cs:71-82: transform data, then the flip bits
+      RabsDecoder rd;
+      rd.start(b);
+      flips.resize(num_entries);
+      for (uint32_t i = 0; i < num_entries; ++i) flips[i] = rd.next() ? 1 : 0;
+    }
     if (num_values == 0) { a.portable.clear(); return; }
+    if (eff == 6) {
+      const Attribute *pos = nullptr;      // parent = portable position attribute, SequentialAttributeDecoder.cs:58-73
+      for (auto &x : m.atts) if (x.att_type == 0) { pos = &x; break; }
+      require(pos != nullptr && pos != &a && !pos->portable.empty(), "normal prediction without decoded positions");
+      if (act) geometric_normal_original(tr, *act, *ed, corr, d.point_ids, *pos, flips, a.portable);
+      else geometric_normal_original(tr, m.ct, *ed, corr, d.point_ids, *pos, flips, a.portable);
+      return;
+    }
     if (eff == 0) delta_original(tr, corr, nc, a.portable);
     else if (eff == 1) {
       if (act) parallelogram_original(tr, *act, *ed, corr, nc, a.portable);

@@ -334,6 +334,38 @@ def test_general_path_on_every_synthetic_case(ctx, monkeypatch):
     b.close()
 
 
+def test_geometric_normal_meshes_take_the_second_chance(ctx):
+    """GeometricNormal prediction (method 6) needs the general path's tables, and the host parse cannot see the
+    method byte behind the symbol streams: k_locate hands such meshes back (DSA_SITE_RETRY_GENERAL) and
+    dsa_batch_wait decodes them again through k_general, next to meshes that stay on the fast kernels."""
+    streams, geo = [], []
+    for k, (kind, nx, ny) in enumerate(KINDS):
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 21)
+        g = k % 3 != 1
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(normal_prediction=6 if g else 0, single_connectivity=k & 1,
+                                                                                  pos_bits=11 + k, normal_bits=8 + (k % 5))))
+        geo.append(g)
+    b = run_batch(ctx, streams)
+    for i, sbytes in enumerate(streams):
+        assert b.status(i) == 0, (i, b.status(i), b.mesh_info(i).detail)
+        ref = oracle.decode(sbytes)
+        assert ref.attributes[1].pred_method == (6 if geo[i] else 0)
+        assert_same(b.result(i), ref, b, i)
+        assert (b.debug_array(i, 4, np.uint32, 12)[6] == 0) == geo[i]      # decoded by k_general / by the fast kernels
+    # decoding the same batch again rebuilds the second-chance batch
+    b.decode()
+    for i in (0, 1, len(streams) - 1):
+        assert_same(b.result(i), oracle.decode(streams[i]))
+    b.close()
+    # a geometric-normal stream and the difference-coded stream of the same mesh decode to the same normals
+    pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 24, 40, 2)
+    b = run_batch(ctx, [synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(normal_prediction=p)) for p in (0, 6)])
+    n0, n6 = (b.result(i).ConnectedData.Attributes[1] for i in (0, 1))
+    assert n6.PredictionMethod == 6 if hasattr(n6, "PredictionMethod") else True
+    assert np.array_equal(n0.PortableValues, n6.PortableValues) and np.array_equal(n0.Values.view(np.uint32), n6.Values.view(np.uint32))
+    b.close()
+
+
 def test_single_decode_api(ctx):
     pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 12, 9, 4)
     s = synth.encode_mesh(pos, faces, nrm, uv)

@@ -109,3 +109,37 @@ def test_bad_magic_and_version():
     data[5] = 1
     with pytest.raises(oracle.OracleError):
         oracle.decode(bytes(data))
+
+
+@pytest.mark.parametrize("kind,nx,ny", KINDS + [(synth.SPHERE, 40, 40)])
+@pytest.mark.parametrize("single", [0, 1])
+def test_geometric_normal_prediction(kind, nx, ny, single):
+    # GeometricNormal (method 6) is lossless over the octahedral coordinates: the stream must decode to exactly the
+    # normals of the Difference-coded stream of the same mesh, through the area-weighted prediction from the
+    # quantised positions and the flip bits (MeshPredictionSchemeGeometricNormalDecoder.cs:44-82)
+    pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 5)
+    ref = oracle.decode(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(single_connectivity=single)))
+    data = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(single_connectivity=single, normal_prediction=6))
+    m = check_roundtrip(kind, nx, ny, 5, single_connectivity=single, normal_prediction=6)
+    assert m.end_pos == len(data)
+    an, rn = m.attributes[1], ref.attributes[1]
+    assert an.pred_method == 6 and an.pred_transform == 3 and rn.pred_method == 0
+    assert np.array_equal(an.portable, rn.portable)
+    assert np.array_equal(an.values.view(np.uint32), rn.values.view(np.uint32))
+    assert np.array_equal(m.faces, ref.faces)
+
+
+def test_geometric_normal_prediction_pays_where_normals_follow_the_geometry():
+    # on the height-field grid the vertex normals follow the faces: the corrections against the area-weighted face
+    # normal are smaller than against the previous vertex's normal, and the stream shrinks
+    pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 64, 64, 1)
+    a = synth.encode_mesh(pos, faces, nrm, None, opt=synth.options(normal_bits=10, pos_bits=14))
+    b = synth.encode_mesh(pos, faces, nrm, None, opt=synth.options(normal_bits=10, pos_bits=14, normal_prediction=6))
+    assert len(b) < len(a)
+    ma, mb = oracle.decode(a), oracle.decode(b)
+    assert mb.attributes[1].pred_method == 6
+
+    def mean_correction(m):
+        s = m.attributes[1].symbols.astype(np.int64)
+        return np.abs(np.where(s > 511, s - 1023, s)).mean()
+    assert mean_correction(mb) < 0.6 * mean_correction(ma)
