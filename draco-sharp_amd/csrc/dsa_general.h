@@ -325,7 +325,7 @@ __device__ bool texcoords_portable_wrap(MeshDesc *D, const T &t, const uint32_t 
 }
 
 // MeshPredictionSchemeGeometricNormalDecoder.cs:44-82 + ...GeometricNormalPredictorArea.cs:16-63 +
-// OctahedronToolBox.cs:28-77,121-137 with the bitstream's 64-bit arithmetic (D-23..D-27), in place on corr -> values.
+// OctahedronToolBox.cs:28-77,121-137 with the bitstream's 64-bit arithmetic (D-9, D-10, D-23..D-25), in place on corr -> values.
 // One flip bit per entry is taken from the rABS block as the entries go by.
 template <class T>
 __device__ bool geometric_normal_oct(MeshDesc *D, const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t entries, int32_t *w,
@@ -470,7 +470,7 @@ __device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, 
   // scheme selection, PredictionSchemeDecoderFactory.cs:9-76
   int eff = method;
   if (vc.ct == nullptr) eff = 0;                       // no corner table (linear sequencing): every scheme falls back to delta
-  // which mesh schemes exist depends on the transform (D-28): wrap carries the parallelogram family and the texture
+  // which mesh schemes exist depends on the transform (D-26): wrap carries the parallelogram family and the texture
   // coordinate schemes, the octahedral transforms carry only the geometric normal scheme; the rest is delta
   else if (tt == 1) { if (method == 1 || method == 5) eff = method; else if (method == 0 || method == 6) eff = 0; else GNOTIMPL(161); }
   else eff = method == 6 ? 6 : 0;

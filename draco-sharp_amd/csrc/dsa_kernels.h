@@ -193,7 +193,7 @@ __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, Attr
   if (a.have_scheme) {
     // only Difference and Parallelogram run on the device path for now
     // PredictionSchemeDecoderFactory.cs:24-36: without a corner table (point clouds) every method falls back to delta
-    // With a corner table the schemes a transform carries are (D-28): wrap -> parallelogram family + texture
+    // With a corner table the schemes a transform carries are (D-26): wrap -> parallelogram family + texture
     // coordinates, octahedral -> geometric normal only; every other combination is the delta scheme.  Schemes that
     // need the general path's tables send the mesh there: the host decodes it again (site DSA_SITE_RETRY_GENERAL).
     if (D->encoder_type == 0) a.pred_kind = 0;

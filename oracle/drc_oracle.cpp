@@ -696,7 +696,7 @@ static void texcoords_portable_original(const Transform &tr, const CT &ct, const
 // MeshPredictionSchemeGeometricNormalPredictorArea.cs:16-63 +
 // MeshPredictionSchemeGeometricNormalPredictor.cs:19-33 +
 // OctahedronToolBox.cs:28-77,121-137.  The bitstream's arithmetic is kept where
-// the C# narrows it (D-23..D-26 in DESIGN.md): the area-weighted normal is summed
+// the C# narrows it (D-9, D-10, D-23..D-25 in DESIGN.md): the area-weighted normal is summed
 // and scaled in 64 bits, its third component is normal[2], and the
 // canonicalisation multiplies in 64 bits.
 template <class CT>
@@ -1403,7 +1403,7 @@ struct AttributeSectionDecoder {
       act = att_corner_table_for(aid);
       // Which mesh schemes exist depends on the transform (the bitstream's factory): the wrap transform carries
       // the parallelogram family and the texture-coordinate schemes, the octahedral transforms carry only the
-      // geometric normal scheme; every other combination is the delta scheme (D-28).
+      // geometric normal scheme; every other combination is the delta scheme (D-26).
       if (tr.type == 1) {
         if (method == 1 || method == 5) eff = method;
         else if (method == 0 || method == 6) eff = 0;
