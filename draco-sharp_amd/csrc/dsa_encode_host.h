@@ -772,6 +772,79 @@ static void write_attribute_values(ByteWriter &w, const PortableAttr &a, const C
     w.i32(o.center);
     return;
   }
+  if (a.prediction == 5) {
+    // MeshPredictionSchemeTexCoordsPortableEncoder.cs + ...PortablePredictor.cs:46-150 (encoder side: both candidate
+    // predictions, the closer one wins and its orientation is recorded), last entry first
+    check(nc == 2 && positions != nullptr && positions->nc == 3, "texture coordinate prediction needs 2 components and quantised positions");
+    WrapEnc wr;
+    wr.init(d);
+    w.i8(5);
+    w.i8(1);
+    std::vector<uint8_t> orientations;
+    auto isqrt = [](uint64_t number) {   // Core/MathUtilities.cs:5-25
+      if (number == 0) return (uint64_t)0;
+      uint64_t act = number, root = 1;
+      while (act >= 2) { root *= 2; act /= 4; }
+      do { root = (root + number / root) / 2; } while (root * root > number);
+      return root;
+    };
+    auto P = [&](int32_t entry, int k) { return (int64_t)positions->vals[(size_t)ct.vertex(seq.data_to_corner[entry]) * 3 + k]; };
+    for (size_t p = entries; p-- > 0;) {
+      const int32_t data_id = (int32_t)p;
+      const uint32_t ci = seq.data_to_corner[p];
+      const int32_t next_id = seq.vertex_to_data[ct.vertex(CornerTable::next(ci))], prev_id = seq.vertex_to_data[ct.vertex(CornerTable::prev(ci))];
+      int32_t pred[2] = {0, 0};
+      bool done = false;
+      if (prev_id >= 0 && next_id >= 0 && prev_id < data_id && next_id < data_id) {
+        const int64_t n_uv[2] = {d[next_id * 2], d[next_id * 2 + 1]}, p_uv[2] = {d[prev_id * 2], d[prev_id * 2 + 1]};
+        if (p_uv[0] == n_uv[0] && p_uv[1] == n_uv[1]) { pred[0] = (int32_t)p_uv[0]; pred[1] = (int32_t)p_uv[1]; done = true; }
+        else {
+          int64_t pn[3], cn[3];
+          for (int k = 0; k < 3; ++k) { pn[k] = P(prev_id, k) - P(next_id, k); cn[k] = P(data_id, k) - P(next_id, k); }
+          const int64_t pn_norm2 = pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2];
+          if (pn_norm2 != 0) {
+            const int64_t cn_dot_pn = pn[0] * cn[0] + pn[1] * cn[1] + pn[2] * cn[2];
+            const int64_t pn_uv[2] = {p_uv[0] - n_uv[0], p_uv[1] - n_uv[1]};
+            const int64_t x_uv[2] = {n_uv[0] * pn_norm2 + cn_dot_pn * pn_uv[0], n_uv[1] * pn_norm2 + cn_dot_pn * pn_uv[1]};
+            int64_t cx[3];
+            for (int k = 0; k < 3; ++k) cx[k] = P(data_id, k) - (P(next_id, k) + (cn_dot_pn * pn[k]) / pn_norm2);
+            const uint64_t cx_norm2 = (uint64_t)(cx[0] * cx[0] + cx[1] * cx[1] + cx[2] * cx[2]);
+            const int64_t norm = (int64_t)isqrt(cx_norm2 * (uint64_t)pn_norm2);
+            const int64_t cx_uv[2] = {pn_uv[1] * norm, -pn_uv[0] * norm};
+            const int64_t c0[2] = {(x_uv[0] + cx_uv[0]) / pn_norm2, (x_uv[1] + cx_uv[1]) / pn_norm2};
+            const int64_t c1[2] = {(x_uv[0] - cx_uv[0]) / pn_norm2, (x_uv[1] - cx_uv[1]) / pn_norm2};
+            const int64_t u = d[p * 2], v = d[p * 2 + 1];
+            const uint64_t e0 = (uint64_t)((u - c0[0]) * (u - c0[0]) + (v - c0[1]) * (v - c0[1]));
+            const uint64_t e1 = (uint64_t)((u - c1[0]) * (u - c1[0]) + (v - c1[1]) * (v - c1[1]));
+            if (e0 < e1) { pred[0] = (int32_t)c0[0]; pred[1] = (int32_t)c0[1]; orientations.push_back(1); }
+            else { pred[0] = (int32_t)c1[0]; pred[1] = (int32_t)c1[1]; orientations.push_back(0); }
+            done = true;
+          }
+        }
+      }
+      if (!done) {
+        int32_t data_offset = 0;
+        bool zero = false;
+        if (prev_id >= 0 && prev_id < data_id) data_offset = prev_id * 2;
+        if (next_id >= 0 && next_id < data_id) data_offset = next_id * 2;
+        else { if (data_id > 0) data_offset = (data_id - 1) * 2; else zero = true; }
+        if (!zero) { pred[0] = d[data_offset]; pred[1] = d[data_offset + 1]; }
+      }
+      symbols[p * 2] = zigzag(wr.corr(d[p * 2], pred[0]));
+      symbols[p * 2 + 1] = zigzag(wr.corr(d[p * 2 + 1], pred[1]));
+    }
+    w.u8(1);
+    encode_symbols(w, symbols, nc, opt.force_scheme, opt.compression_level);
+    // orientations in the order they were found (last entry first), delta-coded against `true`
+    w.i32((int32_t)orientations.size());
+    std::vector<uint8_t> bits(orientations.size());
+    bool last = true;
+    for (size_t i = 0; i < orientations.size(); ++i) { const bool o = orientations[i] != 0; bits[i] = o == last; last = o; }
+    write_rabs(w, bits);
+    w.i32(wr.mn);
+    w.i32(wr.mx);
+    return;
+  }
   WrapEnc wr;
   wr.init(d);
   w.i8((int8_t)a.prediction);

@@ -1208,8 +1208,10 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
     ValueCtx vc;
     vc.ct = &ct; vc.act = (dd >= 0 && data_conn_used[dd]) ? &act[dd] : nullptr;
     vc.d2c = d2c; vc.v2d = v2d; vc.pids = pids;
-    vc.orient = dd >= 0 ? G + g.data + (uint64_t)dd * g.data_stride + g.orient : nullptr;
-    vc.orient_cap = NVMAX; vc.num_points = num_points;
+    // orientation scratch: the attribute data block's, or (attributes of the position decoder) the Edgebreaker
+    // machine's corner stack, which is free by now
+    vc.orient = dd >= 0 ? G + g.data + (uint64_t)dd * g.data_stride + g.orient : G + g.stack;
+    vc.orient_cap = dd >= 0 ? NVMAX : 4 * F; vc.num_points = num_points;
     vc.num_verts = nverts; vc.num_corners = C;
     for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) if (!decode_values(arena, L, D, r, ai, entries, rs, vc)) return false;
     for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) if (!decode_transform_params(D, r, ai)) return false;

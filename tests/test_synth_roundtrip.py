@@ -143,3 +143,17 @@ def test_geometric_normal_prediction_pays_where_normals_follow_the_geometry():
         s = m.attributes[1].symbols.astype(np.int64)
         return np.abs(np.where(s > 511, s - 1023, s)).mean()
     assert mean_correction(mb) < 0.6 * mean_correction(ma)
+
+
+@pytest.mark.parametrize("kind,nx,ny", KINDS)
+@pytest.mark.parametrize("single", [0, 1])
+def test_texcoords_portable_prediction(kind, nx, ny, single):
+    # TexCoordsPortable (method 5) is pinned on the reference's house_04 (tests/test_oracle_golden.py); here the CPU
+    # coder's side of it (MeshPredictionSchemeTexCoordsPortableEncoder.cs) against that decoder on every topology,
+    # with standard traversal: same UVs as the parallelogram stream of the same mesh
+    pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 6)
+    ref = oracle.decode(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(single_connectivity=single)))
+    m = check_roundtrip(kind, nx, ny, 6, single_connectivity=single, uv_prediction=5, normal_prediction=6)
+    assert m.attributes[2].pred_method == 5 and m.attributes[1].pred_method == 6
+    assert np.array_equal(m.attributes[2].portable, ref.attributes[2].portable)
+    assert np.array_equal(m.attributes[1].portable, ref.attributes[1].portable)
