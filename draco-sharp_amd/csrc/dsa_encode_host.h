@@ -850,6 +850,75 @@ static void write_attribute_values(ByteWriter &w, const PortableAttr &a, const C
   w.i8((int8_t)a.prediction);
   w.i8(1);     // Wrap
   std::vector<int32_t> pred(nc);
+  if (a.prediction == 2 || a.prediction == 4) {
+    // MeshPredictionSchemeMultiParallelogramEncoder.cs / ...ConstrainedMultiParallelogramEncoder.cs: averages of the
+    // parallelograms around the entry's vertex.  The constrained scheme may drop any of (up to four) parallelograms
+    // by a crease flag; this coder takes the subset with the smallest correction (the reference's entropy-driven
+    // choice is an encoder heuristic, the stream is valid for any choice).
+    auto para = [&](size_t p, uint32_t ci, int32_t *out) {
+      const uint32_t oci = ct.opposite(ci);
+      if (oci == kInvalid) return false;
+      const int32_t vo = seq.vertex_to_data[ct.vertex(oci)], vn = seq.vertex_to_data[ct.vertex(CornerTable::next(oci))], vp = seq.vertex_to_data[ct.vertex(CornerTable::prev(oci))];
+      if (!(vo < (int32_t)p && vn < (int32_t)p && vp < (int32_t)p)) return false;
+      for (int c = 0; c < nc; ++c) out[c] = (int32_t)((uint32_t)d[vn * nc + c] + (uint32_t)d[vp * nc + c] - (uint32_t)d[vo * nc + c]);
+      return true;
+    };
+    std::vector<uint8_t> crease[4];
+    std::vector<int32_t> cand(4 * nc), sum(nc);
+    for (int c = 0; c < nc; ++c) symbols[c] = zigzag(wr.corr(d[c], 0));
+    for (size_t p = 1; p < entries; ++p) {
+      const uint32_t start = seq.data_to_corner[p];
+      uint32_t c = start;
+      int found = 0;
+      bool have = false;
+      if (a.prediction == 2) {
+        std::fill(sum.begin(), sum.end(), 0);
+        while (c != kInvalid) {
+          if (para(p, c, cand.data())) { for (int k = 0; k < nc; ++k) sum[k] = (int32_t)((uint32_t)sum[k] + (uint32_t)cand[k]); ++found; }
+          c = ct.swing_right(c);
+          if (c == start) c = kInvalid;
+        }
+        if (found) { for (int k = 0; k < nc; ++k) pred[k] = sum[k] / found; have = true; }
+      } else {
+        bool first_pass = true;
+        while (c != kInvalid) {
+          if (para(p, c, &cand[(size_t)found * nc])) { if (++found == 4) break; }
+          c = first_pass ? ct.swing_left(c) : ct.swing_right(c);
+          if (c == start) break;
+          if (c == kInvalid && first_pass) { first_pass = false; c = ct.swing_right(start); }
+        }
+        if (found) {
+          int64_t best_cost = -1;
+          uint32_t best_mask = 0;
+          for (uint32_t mask = 0; mask < (1u << found); ++mask) {      // bit i set: parallelogram i is used
+            int used = 0;
+            std::fill(sum.begin(), sum.end(), 0);
+            for (int i = 0; i < found; ++i) if (mask >> i & 1) { ++used; for (int k = 0; k < nc; ++k) sum[k] = (int32_t)((uint32_t)sum[k] + (uint32_t)cand[(size_t)i * nc + k]); }
+            int64_t cost = 0;
+            for (int k = 0; k < nc; ++k) cost += std::abs((int64_t)wr.corr(d[p * nc + k], used ? sum[k] / used : d[(p - 1) * nc + k]));
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_mask = mask; }
+          }
+          int used = 0;
+          std::fill(sum.begin(), sum.end(), 0);
+          for (int i = 0; i < found; ++i) {
+            const bool use = best_mask >> i & 1;
+            crease[found - 1].push_back(use ? 0 : 1);
+            if (use) { ++used; for (int k = 0; k < nc; ++k) sum[k] = (int32_t)((uint32_t)sum[k] + (uint32_t)cand[(size_t)i * nc + k]); }
+          }
+          if (used) { for (int k = 0; k < nc; ++k) pred[k] = sum[k] / used; have = true; }
+        }
+      }
+      if (!have) for (int k = 0; k < nc; ++k) pred[k] = d[(p - 1) * nc + k];
+      for (int k = 0; k < nc; ++k) symbols[p * nc + k] = zigzag(wr.corr(d[p * nc + k], pred[k]));
+    }
+    w.u8(1);
+    encode_symbols(w, symbols, nc, opt.force_scheme, opt.compression_level);
+    if (a.prediction == 4)
+      for (int i = 0; i < 4; ++i) { w.varint(crease[i].size()); if (!crease[i].empty()) write_rabs(w, crease[i]); }
+    w.i32(wr.mn);
+    w.i32(wr.mx);
+    return;
+  }
   for (size_t p = entries; p-- > 0;) {
     bool have = false;
     if (a.prediction == 1 && p > 0) {   // MeshPredictionSchemeParallelogramEncoder.cs:35-56 (E-4 corrected)

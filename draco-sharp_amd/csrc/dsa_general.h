@@ -248,6 +248,65 @@ __device__ void parallelogram_wrap(const T &t, const uint32_t *d2c, const int32_
   }
 }
 
+// MeshPredictionSchemeParallelogramDecoder.cs:56-89 (TryComputeParallelogramPrediction)
+template <class T>
+__device__ inline bool parallelogram_prediction(const T &t, const int32_t *v2d, uint32_t p, uint32_t ci, const int32_t *w, uint32_t nc, int32_t *pred) {
+  const uint32_t oci = t.opposite(ci);
+  if (oci == DSA_INVALID) return false;
+  const uint32_t a = t.vertex(oci), b = t.vertex(cnx(oci)), c = t.vertex(cpv(oci));
+  if (a == DSA_INVALID || b == DSA_INVALID || c == DSA_INVALID) return false;
+  const int32_t vo = v2d[a], vn = v2d[b], vp = v2d[c];
+  if (!(vo >= 0 && vn >= 0 && vp >= 0 && vo < (int32_t)p && vn < (int32_t)p && vp < (int32_t)p)) return false;
+  for (uint32_t k = 0; k < nc; ++k) pred[k] = (int32_t)((uint32_t)w[vn * nc + k] + (uint32_t)w[vp * nc + k] - (uint32_t)w[vo * nc + k]);
+  return true;
+}
+
+// MeshPredictionSchemeMultiParallelogramDecoder.cs:24-73 (D-27: the sum is cleared per entry) and
+// MeshPredictionSchemeConstrainedMultiParallelogramDecoder.cs:28-108 (D-14 resolved to the bitstream), in place.
+// constrained: up to four parallelograms, left swing first, each kept or dropped by the next crease flag of the
+// context (= parallelograms found - 1); the four flag streams are read as the entries go by.
+template <class T>
+__device__ bool multi_parallelogram_wrap(MeshDesc *D, const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t entries, uint32_t nc, int32_t *w,
+                                         int32_t mn, int32_t mx, int32_t max_dif, bool constrained, Rabs *crease, uint32_t *crease_left, uint32_t max_steps) {
+  if (nc > 4) GNOTIMPL(660);                          // wider integer attributes: not on the device yet
+  int32_t cand[4][4], sum[4];
+  for (uint32_t c = 0; c < nc; ++c) w[c] = wrap_original(0, w[c], mn, mx, max_dif);
+  for (uint32_t p = 1; p < entries; ++p) {
+    const uint32_t start = d2c[p];
+    uint32_t c = start, found = 0, used = 0, steps = 0;
+    for (uint32_t k = 0; k < nc; ++k) sum[k] = 0;
+    if (!constrained) {
+      while (c != DSA_INVALID) {
+        GREQ(++steps <= max_steps, 661);
+        if (parallelogram_prediction(t, v2d, p, c, w, nc, cand[0])) { for (uint32_t k = 0; k < nc; ++k) sum[k] = (int32_t)((uint32_t)sum[k] + (uint32_t)cand[0][k]); ++found; }
+        c = t.swing_right(c);
+        if (c == start) c = DSA_INVALID;
+      }
+      used = found;
+    } else {
+      bool first_pass = true;
+      while (c != DSA_INVALID) {
+        GREQ(++steps <= max_steps, 661);
+        if (parallelogram_prediction(t, v2d, p, c, w, nc, cand[found])) { if (++found == 4) break; }
+        c = first_pass ? t.swing_left(c) : t.swing_right(c);
+        if (c == start) break;
+        if (c == DSA_INVALID && first_pass) { first_pass = false; c = t.swing_right(start); }
+      }
+      for (uint32_t i = 0; i < found; ++i) {
+        const uint32_t context = found - 1;
+        GREQ(crease_left[context] > 0, 662);
+        --crease_left[context];
+        if (!crease[context].next()) { ++used; for (uint32_t k = 0; k < nc; ++k) sum[k] = (int32_t)((uint32_t)sum[k] + (uint32_t)cand[i][k]); }
+      }
+    }
+    for (uint32_t k = 0; k < nc; ++k) {
+      const int32_t pred = used ? sum[k] / (int32_t)used : w[(p - 1) * nc + k];
+      w[p * nc + k] = wrap_original(pred, w[p * nc + k], mn, mx, max_dif);
+    }
+  }
+  return true;
+}
+
 __device__ inline uint64_t int_sqrt(uint64_t number) {   // Core/MathUtilities.cs:5-25
   if (number == 0) return 0;
   uint64_t act = number, root = 1;
@@ -472,7 +531,7 @@ __device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, 
   if (vc.ct == nullptr) eff = 0;                       // no corner table (linear sequencing): every scheme falls back to delta
   // which mesh schemes exist depends on the transform (D-26): wrap carries the parallelogram family and the texture
   // coordinate schemes, the octahedral transforms carry only the geometric normal scheme; the rest is delta
-  else if (tt == 1) { if (method == 1 || method == 5) eff = method; else if (method == 0 || method == 6) eff = 0; else GNOTIMPL(161); }
+  else if (tt == 1) { if (method == 1 || method == 2 || method == 4 || method == 5) eff = method; else if (method == 0 || method == 6) eff = 0; else GNOTIMPL(161); }
   else eff = method == 6 ? 6 : 0;
   a.pred_kind = (int8_t)eff;
   uint8_t *orient = nullptr;
@@ -491,6 +550,21 @@ __device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, 
     for (int32_t k = 0; k < num_or; ++k) { if (rd.next() == 0) last = !last; orient[k] = last ? 1 : 0; }
     num_orient = (uint32_t)num_or;
   }
+  Rabs crease[4];
+  uint32_t crease_left[4] = {0, 0, 0, 0};
+  if (eff == 4) {                                      // MeshPredictionSchemeConstrainedMultiParallelogramDecoder.cs:110-134 (v2.2: no mode byte)
+    for (int i = 0; i < 4; ++i) {
+      const uint64_t num_flags = r.varint();
+      GREQ(r.ok && num_flags <= vc.num_corners, 663);
+      crease_left[i] = (uint32_t)num_flags;
+      if (num_flags > 0) {
+        uint32_t endp;
+        crease[i].start(arena + L.stream, L.stream_len, r.pos, &endp);
+        GREQ(crease[i].ok, 664);
+        r.pos = endp;
+      }
+    }
+  }
   if (tt == 1) {                                       // PredictionSchemeWrapDecodingTransform.cs:69-75
     a.wrap_min = (int32_t)r.u32(); a.wrap_max = (int32_t)r.u32();
     GREQ(r.ok && a.wrap_min <= a.wrap_max, 162);
@@ -504,6 +578,9 @@ __device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, 
     } else if (eff == 1) {
       if (vc.act) parallelogram_wrap(*vc.act, vc.d2c, vc.v2d, entries, nc, w, mn, mx, max_dif);
       else parallelogram_wrap(*vc.ct, vc.d2c, vc.v2d, entries, nc, w, mn, mx, max_dif);
+    } else if (eff == 2 || eff == 4) {
+      if (vc.act) return multi_parallelogram_wrap(D, *vc.act, vc.d2c, vc.v2d, entries, nc, w, mn, mx, max_dif, eff == 4, crease, crease_left, vc.num_corners + 1);
+      return multi_parallelogram_wrap(D, *vc.ct, vc.d2c, vc.v2d, entries, nc, w, mn, mx, max_dif, eff == 4, crease, crease_left, vc.num_corners + 1);
     } else {
       GREQ(nc == 2, 683);
       // parent = portable positions, SequentialAttributeDecoder.cs:58-73

@@ -198,7 +198,7 @@ __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, Attr
     // need the general path's tables send the mesh there: the host decodes it again (site DSA_SITE_RETRY_GENERAL).
     if (D->encoder_type == 0) a.pred_kind = 0;
     else if (a.pred_transform == 1) {
-      if (method == 5) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+      if (method == 2 || method == 4 || method == 5) NOTIMPL(DSA_SITE_RETRY_GENERAL);
       if (!(method == 0 || method == 1 || method == 6)) NOTIMPL(161);
       a.pred_kind = method == 1 ? 1 : 0;
     } else {

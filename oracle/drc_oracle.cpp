@@ -618,6 +618,108 @@ static void parallelogram_original(const Transform &tr, const CT &ct, const Enco
   }
 }
 
+// MeshPredictionSchemeParallelogramDecoder.cs:56-89 (TryComputeParallelogramPrediction)
+template <class CT>
+static bool parallelogram_prediction(const CT &ct, const EncodingData &ed, size_t p, uint32_t ci,
+                                     const std::vector<int32_t> &out, int nc, int32_t *pred) {
+  uint32_t oci = ct.opposite(ci);
+  if (oci == kInvalid) return false;
+  uint32_t a = ct.vertex(oci), b = ct.vertex(CT::next(oci)), c = ct.vertex(CT::prev(oci));
+  if (a == kInvalid || b == kInvalid || c == kInvalid) return false;
+  int32_t vo = ed.vertex_to_data[a], vn = ed.vertex_to_data[b], vp = ed.vertex_to_data[c];
+  if (!(vo >= 0 && vn >= 0 && vp >= 0 && vo < (int32_t)p && vn < (int32_t)p && vp < (int32_t)p)) return false;
+  for (int k = 0; k < nc; ++k)
+    pred[k] = (int32_t)((uint32_t)out[vn * nc + k] + (uint32_t)out[vp * nc + k] - (uint32_t)out[vo * nc + k]);
+  return true;
+}
+
+// MeshPredictionSchemeMultiParallelogramDecoder.cs:24-73: the average of the parallelograms met while swinging
+// right from the entry's corner.  D-27: the C# never clears the running sum between entries; the bitstream does.
+template <class CT>
+static void multi_parallelogram_original(const Transform &tr, const CT &ct, const EncodingData &ed,
+                                         const std::vector<int32_t> &corr, int nc, std::vector<int32_t> &out) {
+  size_t n = corr.size();
+  out.assign(n, 0);
+  if (n == 0) return;
+  std::vector<int32_t> pred(nc, 0), one(nc, 0);
+  tr.original(pred.data(), corr.data(), out.data());
+  size_t entries = ed.data_to_corner.size();
+  require(entries * nc <= n, "multi-parallelogram: fewer values than entries");
+  const size_t max_steps = (size_t)ct.num_faces() * 3 + 1;
+  for (size_t p = 1; p < entries; ++p) {
+    uint32_t start = ed.data_to_corner[p], c = start;
+    int count = 0;
+    size_t steps = 0;
+    std::fill(pred.begin(), pred.end(), 0);
+    while (c != kInvalid) {
+      require(++steps <= max_steps, "multi-parallelogram: corner fan does not close");
+      if (parallelogram_prediction(ct, ed, p, c, out, nc, one.data())) {
+        for (int k = 0; k < nc; ++k) pred[k] = (int32_t)((uint32_t)pred[k] + (uint32_t)one[k]);
+        ++count;
+      }
+      c = ct.swing_right(c);
+      if (c == start) c = kInvalid;
+    }
+    if (count == 0) tr.original(&out[(p - 1) * nc], &corr[p * nc], &out[p * nc]);
+    else {
+      for (int k = 0; k < nc; ++k) pred[k] /= count;
+      tr.original(pred.data(), &corr[p * nc], &out[p * nc]);
+    }
+  }
+}
+
+// MeshPredictionSchemeConstrainedMultiParallelogramDecoder.cs:28-108 with D-14 resolved to the bitstream: up to four
+// parallelograms (left swing first, then right from the start), each kept or dropped by its crease flag; the flags
+// live in one list per context (= number of parallelograms found - 1).
+template <class CT>
+static void constrained_multi_parallelogram_original(const Transform &tr, const CT &ct, const EncodingData &ed,
+                                                     const std::vector<int32_t> &corr, int nc,
+                                                     const std::vector<uint8_t> crease[4], std::vector<int32_t> &out) {
+  size_t n = corr.size();
+  out.assign(n, 0);
+  if (n == 0) return;
+  std::vector<int32_t> preds[4], multi(nc, 0);
+  for (auto &v : preds) v.assign(nc, 0);
+  tr.original(preds[0].data(), corr.data(), out.data());
+  size_t entries = ed.data_to_corner.size();
+  require(entries * nc <= n, "constrained multi-parallelogram: fewer values than entries");
+  size_t crease_pos[4] = {0, 0, 0, 0};
+  const size_t max_steps = (size_t)ct.num_faces() * 3 + 1;
+  for (size_t p = 1; p < entries; ++p) {
+    uint32_t start = ed.data_to_corner[p], c = start;
+    int found = 0;
+    bool first_pass = true;
+    size_t steps = 0;
+    while (c != kInvalid) {
+      require(++steps <= max_steps, "constrained multi-parallelogram: corner fan does not close");
+      if (parallelogram_prediction(ct, ed, p, c, out, nc, preds[found].data())) {
+        if (++found == 4) break;
+      }
+      c = first_pass ? ct.swing_left(c) : ct.swing_right(c);
+      if (c == start) break;
+      if (c == kInvalid && first_pass) { first_pass = false; c = ct.swing_right(start); }
+    }
+    int used = 0;
+    if (found > 0) {
+      std::fill(multi.begin(), multi.end(), 0);
+      for (int i = 0; i < found; ++i) {
+        int context = found - 1;
+        size_t pos = crease_pos[context]++;
+        require(pos < crease[context].size(), "constrained multi-parallelogram: ran out of crease flags");
+        if (!crease[context][pos]) {
+          ++used;
+          for (int k = 0; k < nc; ++k) multi[k] = (int32_t)((uint32_t)multi[k] + (uint32_t)preds[i][k]);
+        }
+      }
+    }
+    if (used == 0) tr.original(&out[(p - 1) * nc], &corr[p * nc], &out[p * nc]);
+    else {
+      for (int k = 0; k < nc; ++k) multi[k] /= used;
+      tr.original(multi.data(), &corr[p * nc], &out[p * nc]);
+    }
+  }
+}
+
 // MeshPredictionSchemeTexCoordsPortableDecoder.cs:50-85 +
 // MeshPredictionSchemeTexCoordsPortablePredictor.cs:46-150 (fallback chain kept
 // exactly as written there, which is also what upstream Draco does).
@@ -1405,9 +1507,9 @@ struct AttributeSectionDecoder {
       // the parallelogram family and the texture-coordinate schemes, the octahedral transforms carry only the
       // geometric normal scheme; every other combination is the delta scheme (D-26).
       if (tr.type == 1) {
-        if (method == 1 || method == 5) eff = method;
+        if (method == 1 || method == 2 || method == 4 || method == 5) eff = method;
         else if (method == 0 || method == 6) eff = 0;
-        else throw Error(ERR_NOT_IMPLEMENTED, "prediction scheme not implemented in the oracle (multi-parallelogram / deprecated texcoords)");
+        else throw Error(ERR_NOT_IMPLEMENTED, "prediction scheme not implemented in the oracle (deprecated texcoords)");
       } else eff = method == 6 ? 6 : 0;
     }
     // prediction data: scheme-specific first, then the transform's
@@ -1422,6 +1524,19 @@ struct AttributeSectionDecoder {
       for (int i = 0; i < num_or; ++i) {
         if (rd.next() == 0) last = !last;
         orientations.push_back(last ? 1 : 0);
+      }
+    }
+    std::vector<uint8_t> crease[4];
+    if (eff == 4) {                        // MeshPredictionSchemeConstrainedMultiParallelogramDecoder.cs:110-134 (v2.2: no mode byte)
+      for (int i = 0; i < 4; ++i) {
+        uint64_t num_flags = b.varint();
+        require(num_flags <= (uint64_t)m.ct.num_corners(), "more crease flags than corners");
+        if (num_flags > 0) {
+          RabsDecoder rd;
+          rd.start(b);
+          crease[i].resize((size_t)num_flags);
+          for (uint64_t j = 0; j < num_flags; ++j) crease[i][j] = rd.next() ? 1 : 0;
+        }
       }
     }
     tr.decode_data(b);
@@ -1445,6 +1560,12 @@ struct AttributeSectionDecoder {
     else if (eff == 1) {
       if (act) parallelogram_original(tr, *act, *ed, corr, nc, a.portable);
       else parallelogram_original(tr, m.ct, *ed, corr, nc, a.portable);
+    } else if (eff == 2) {
+      if (act) multi_parallelogram_original(tr, *act, *ed, corr, nc, a.portable);
+      else multi_parallelogram_original(tr, m.ct, *ed, corr, nc, a.portable);
+    } else if (eff == 4) {
+      if (act) constrained_multi_parallelogram_original(tr, *act, *ed, corr, nc, crease, a.portable);
+      else constrained_multi_parallelogram_original(tr, m.ct, *ed, corr, nc, crease, a.portable);
     } else {
       // parent = portable position attribute, SequentialAttributeDecoder.cs:58-73
       const Attribute *pos = nullptr;

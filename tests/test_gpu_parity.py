@@ -350,11 +350,15 @@ def test_geometric_normal_meshes_take_the_second_chance(ctx):
     for npred in (0, 6):
         streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(uv_prediction=5, normal_prediction=npred)))
         geo.append(True)
+    # and so do the multi-parallelogram schemes
+    for ppred, upred in ((2, 1), (4, 4), (1, 2)):
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=ppred, uv_prediction=upred)))
+        geo.append(True)
     b = run_batch(ctx, streams)
     for i, sbytes in enumerate(streams):
         assert b.status(i) == 0, (i, b.status(i), b.mesh_info(i).detail)
         ref = oracle.decode(sbytes)
-        assert ref.attributes[1].pred_method == 6 or ref.attributes[2].pred_method == 5 or not geo[i]
+        assert any(x.pred_method in (2, 4, 5, 6) for x in ref.attributes) == geo[i]
         assert_same(b.result(i), ref, b, i)
         assert (b.debug_array(i, 4, np.uint32, 12)[6] == 0) == geo[i]      # decoded by k_general / by the fast kernels
     # decoding the same batch again rebuilds the second-chance batch

@@ -157,3 +157,17 @@ def test_texcoords_portable_prediction(kind, nx, ny, single):
     assert m.attributes[2].pred_method == 5 and m.attributes[1].pred_method == 6
     assert np.array_equal(m.attributes[2].portable, ref.attributes[2].portable)
     assert np.array_equal(m.attributes[1].portable, ref.attributes[1].portable)
+
+
+@pytest.mark.parametrize("kind,nx,ny", KINDS)
+@pytest.mark.parametrize("method", [2, 4])
+def test_multi_parallelogram_predictions(kind, nx, ny, method):
+    # MultiParallelogram (2) and ConstrainedMultiParallelogram (4, with its four crease-flag streams): lossless over
+    # the quantised values, so the stream must decode to the values of the Parallelogram stream of the same mesh
+    pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 9)
+    ref = oracle.decode(synth.encode_mesh(pos, faces, nrm, uv))
+    m = check_roundtrip(kind, nx, ny, 9, pos_prediction=method, uv_prediction=method)
+    for k in (0, 2):
+        assert m.attributes[k].pred_method == method
+        assert np.array_equal(m.attributes[k].portable, ref.attributes[k].portable)
+    assert np.array_equal(m.faces, ref.faces)
