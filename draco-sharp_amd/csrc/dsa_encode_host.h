@@ -382,6 +382,46 @@ static void dfs_sequence(const CornerTable &ct, const std::vector<uint32_t> &cor
   }
 }
 
+// MaxPredictionDegreeTraverser.cs:22-152 (with the degree list sized, as in the bitstream): faces whose tip vertex is
+// already coded first, then tips seen from two faces, then the rest.
+static void prediction_degree_sequence(const CornerTable &ct, const std::vector<uint32_t> &corner_order, Sequence &seq) {
+  std::vector<uint8_t> fvis(ct.nf(), 0), vvis(ct.nv(), 0);
+  std::vector<uint32_t> degree(ct.nv(), 0), stacks[3];
+  seq.vertex_to_data.assign(ct.nv(), -1);
+  seq.data_to_corner.clear();
+  int best = 0;
+  auto visit = [&](uint32_t v, uint32_t c) { vvis[v] = 1; seq.vertex_to_data[v] = (int32_t)seq.data_to_corner.size(); seq.data_to_corner.push_back(c); };
+  auto fdone = [&](uint32_t c) { return c == kInvalid || fvis[c / 3]; };
+  auto pop = [&]() {
+    for (int i = best; i < 3; ++i) if (!stacks[i].empty()) { uint32_t c = stacks[i].back(); stacks[i].pop_back(); best = i; return c; }
+    return kInvalid;
+  };
+  auto push = [&](uint32_t c, int pr) { stacks[pr].push_back(c); if (pr < best) best = pr; };
+  auto priority = [&](uint32_t c) { uint32_t v = ct.vertex(c); if (vvis[v]) return 0; return ++degree[v] > 1 ? 1 : 2; };
+  for (uint32_t start : corner_order) {
+    stacks[0].push_back(start);
+    best = 0;
+    uint32_t nv = ct.vertex(CornerTable::next(start)), pv = ct.vertex(CornerTable::prev(start)), tv = ct.vertex(start);
+    if (!vvis[nv]) visit(nv, CornerTable::next(start));
+    if (!vvis[pv]) visit(pv, CornerTable::prev(start));
+    if (!vvis[tv]) visit(tv, start);
+    uint32_t corner;
+    while ((corner = pop()) != kInvalid) {
+      if (fdone(corner)) continue;
+      for (;;) {
+        fvis[corner / 3] = 1;
+        uint32_t v = ct.vertex(corner);
+        if (!vvis[v]) visit(v, corner);
+        uint32_t rc = ct.right_corner(corner), lc = ct.left_corner(corner);
+        const bool rdone = fdone(rc), ldone = fdone(lc);
+        if (!ldone) { int pr = priority(lc); if (rdone && pr <= best) { corner = lc; continue; } push(lc, pr); }
+        if (!rdone) { int pr = priority(rc); if (pr <= best) { corner = rc; continue; } push(rc, pr); }
+        break;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------- Edgebreaker connectivity
 struct EbResult {
   std::vector<uint8_t> symbols;               // encoder order, bit patterns (0,1,3,5,7)
@@ -542,6 +582,8 @@ struct Options {
   int32_t uv_prediction = 1;
   int32_t generic_u8 = 0;            // add a per-vertex uint8 generic attribute (Integer decoder) when generic data is given
   int32_t normal_prediction = 0;     // 0 difference, 6 geometric normal (the CPU coder only)
+  int32_t traversal_method = 0;      // attribute sequencing: 0 depth first; 1 prediction degree for the decoder of the positions
+                                     // (what stock encoders do at their highest level); 2 prediction degree for every decoder (CPU coder only)
 };
 
 // Octahedral quantisation (OctahedronToolBox.cs:28-119)
@@ -952,7 +994,11 @@ static void write_attribute_transform(ByteWriter &w, const PortableAttr &a) {
 struct MeshPlan {
   CornerTable ct;
   EbResult eb;
-  Sequence seq;
+  Sequence seq;                      // depth-first order
+  Sequence seq_pd;                   // prediction-degree order (only when an attributes decoder asks for it)
+  int traversal_method = 0;
+  bool uses_pd(size_t att) const { return traversal_method == 2 || (traversal_method == 1 && (single || att == 0)); }
+  const Sequence &seq_of(size_t att) const { return uses_pd(att) ? seq_pd : seq; }
   std::vector<PortableAttr> atts;    // descriptors; vals / quantisation parameters are filled by whoever codes the values
   bool single = false;
   uint32_t num_att_data = 0;
@@ -971,6 +1017,11 @@ static void plan_mesh(const MeshIn &in, const Options &opt, MeshPlan &pl) {
   if (in.generic) { PortableAttr a; a.att_type = 4; a.nc = a.nc_out = 1; a.seq_type = 1; a.data_type = 2; a.prediction = 1; pl.atts.push_back(a); }
   pl.single = opt.single_connectivity != 0;
   pl.num_att_data = pl.single ? 0 : (uint32_t)pl.atts.size() - 1;
+  pl.traversal_method = opt.traversal_method;
+  if (pl.traversal_method != 0) {
+    prediction_degree_sequence(pl.ct, pl.eb.processed_corners, pl.seq_pd);
+    check(pl.seq_pd.data_to_corner.size() == in.nv, "traversal did not reach every vertex");
+  }
 }
 
 // Header, connectivity sections and the head of the attribute section; then values and transform parameters of
@@ -1023,7 +1074,7 @@ static void write_stream(ByteWriter &w, const MeshIn &in, const MeshPlan &pl, Va
   const std::vector<PortableAttr> &atts = pl.atts;
   uint32_t num_encoders = pl.single ? 1 : (uint32_t)atts.size();
   w.u8((uint8_t)num_encoders);
-  for (uint32_t i = 0; i < num_encoders; ++i) { w.i8(i == 0 ? -1 : (int8_t)(i - 1)); w.u8(0); w.u8(0); }
+  for (uint32_t i = 0; i < num_encoders; ++i) { w.i8(i == 0 ? -1 : (int8_t)(i - 1)); w.u8(0); w.u8(pl.uses_pd(i) ? 1 : 0); }   // MeshTraversalMethod
   auto write_desc = [&](const PortableAttr &a, uint32_t uid) { w.u8((uint8_t)a.att_type); w.u8((uint8_t)a.data_type); w.u8((uint8_t)a.nc_out); w.u8(0); w.varint(uid); };
   if (pl.single) {
     w.varint(atts.size());
@@ -1052,7 +1103,7 @@ static void encode_mesh(const MeshIn &in, const Options &opt, std::vector<uint8_
   }
   ByteWriter w;
   write_stream(w, in, pl,
-               [&](ByteWriter &bw, size_t i) { write_attribute_values(bw, pl.atts[i], pl.ct, pl.seq, opt, &pl.atts[0]); },
+               [&](ByteWriter &bw, size_t i) { write_attribute_values(bw, pl.atts[i], pl.ct, pl.seq_of(i), opt, &pl.atts[0]); },
                [&](ByteWriter &bw, size_t i) { write_attribute_transform(bw, pl.atts[i]); });
   out.swap(w.d);
 }

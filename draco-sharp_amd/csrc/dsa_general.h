@@ -227,6 +227,68 @@ __device__ bool traverse(MeshDesc *D, const T &t, uint32_t num_verts, const int3
   return true;
 }
 
+// Traverser/MaxPredictionDegreeTraverser.cs:22-152 (D-28: with the degree list sized) + the same observer and
+// sequencer.  The three priority stacks are linked lists threaded through one u32 per corner: an edge into a face is
+// pushed at most once in a consistent table (only the face on its other side pushes it), and a second push is refused.
+template <class T>
+__device__ bool traverse_prediction_degree(MeshDesc *D, const T &t, uint32_t num_verts, const int32_t *c2p, uint8_t *fvis, uint8_t *vvis,
+                                           uint32_t *next, uint32_t *degree, uint32_t *d2c, int32_t *v2d, uint32_t *pids,
+                                           uint32_t cap_entries, uint32_t *num_entries) {
+  const uint32_t F = t.num_faces(), NEVER = 0xFFFFFFFEu, END = 0xFFFFFFFDu, USED = 0xFFFFFFFCu;
+  for (uint32_t f = 0; f < F; ++f) fvis[f] = 0;
+  for (uint32_t c = 0; c < 3 * F; ++c) next[c] = NEVER;
+  for (uint32_t v = 0; v < num_verts; ++v) { vvis[v] = 0; v2d[v] = -1; degree[v] = 0; }
+  uint32_t count = 0, head[3] = {END, END, END};
+  int best = 0;
+#define G_VISIT(v_, c_) { GREQ(count < cap_entries, 620); vvis[v_] = 1; pids[count] = (uint32_t)c2p[c_]; d2c[count] = (c_); v2d[v_] = (int32_t)count; ++count; }
+#define G_PUSH(c_, pr_) { GREQ((c_) < 3 * F && next[c_] == NEVER, 625); next[c_] = head[pr_]; head[pr_] = (c_); if ((pr_) < best) best = (pr_); }
+#define G_PRIORITY(c_, out_) { const uint32_t tip_ = t.vertex(c_); GREQ(tip_ < num_verts, 622); out_ = vvis[tip_] ? 0 : (++degree[tip_] > 1 ? 1 : 2); }
+  for (uint32_t f0 = 0; f0 < F; ++f0) {
+    if (fvis[f0]) continue;                            // a visited start face would be pushed, popped and dropped
+    uint32_t corner = 3 * f0;
+    G_PUSH(corner, 0);
+    best = 0;
+    const uint32_t nv = t.vertex(cnx(corner)), pv = t.vertex(cpv(corner)), tv = t.vertex(corner);
+    GREQ(nv < num_verts && pv < num_verts && tv < num_verts, 621);
+    if (!vvis[nv]) G_VISIT(nv, cnx(corner));
+    if (!vvis[pv]) G_VISIT(pv, cpv(corner));
+    if (!vvis[tv]) G_VISIT(tv, corner);
+    for (;;) {
+      corner = DSA_INVALID;                            // PopNextCornerToTraverse
+      for (int i = best; i < 3; ++i)
+        if (head[i] != END) { corner = head[i]; head[i] = next[corner]; next[corner] = USED; best = i; break; }
+      if (corner == DSA_INVALID) break;
+      if (fvis[corner / 3]) continue;
+      for (;;) {
+        fvis[corner / 3] = 1;
+        const uint32_t v = t.vertex(corner);
+        GREQ(v < num_verts, 622);
+        if (!vvis[v]) G_VISIT(v, corner);
+        const uint32_t rc = t.right_corner(corner), lc = t.left_corner(corner);
+        const bool rdone = rc == DSA_INVALID || rc / 3 >= F || fvis[rc / 3], ldone = lc == DSA_INVALID || lc / 3 >= F || fvis[lc / 3];
+        if (!ldone) {
+          int pr;
+          G_PRIORITY(lc, pr);
+          if (rdone && pr <= best) { corner = lc; continue; }
+          G_PUSH(lc, pr);
+        }
+        if (!rdone) {
+          int pr;
+          G_PRIORITY(rc, pr);
+          if (pr <= best) { corner = rc; continue; }
+          G_PUSH(rc, pr);
+        }
+        break;
+      }
+    }
+  }
+#undef G_VISIT
+#undef G_PUSH
+#undef G_PRIORITY
+  *num_entries = count;
+  return true;
+}
+
 // MeshPredictionSchemeParallelogramDecoder.cs:29-54,56-89 + wrap transform, in place on corr -> values
 template <class T>
 __device__ void parallelogram_wrap(const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t entries, uint32_t nc, int32_t *w,
@@ -726,7 +788,7 @@ __device__ bool decode_sequential_mesh(uint8_t *arena, const MeshLayout &L, Mesh
   return true;
 }
 
-struct DecoderInfo { int att_data_id; uint32_t element_type, first_att, num_atts, num_entries; };
+struct DecoderInfo { int att_data_id; uint32_t element_type, traversal_method, first_att, num_atts, num_entries; };
 
 // Pointers and sizes of one general mesh, rebuilt by every phase from the layout and the descriptor.
 struct MeshCtx {
@@ -1226,7 +1288,7 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
     } else { GREQ(!pos_seen, 125); pos_seen = true; }
     if (dec[i].element_type == 0) { if (dec[i].att_data_id >= 0) data_conn_used[dec[i].att_data_id] = false; }
     else GREQ(traversal_method == 0 && dec[i].att_data_id >= 0, 126);
-    if (traversal_method != 0) GNOTIMPL(128);             // prediction-degree traversal
+    dec[i].traversal_method = traversal_method;           // 1: prediction degree (vertex attributes only, checked above)
   }
   uint32_t natt = 0;
   for (uint32_t i = 0; i < ndec; ++i) if (!decode_descriptors(L, D, r, i, natt, &dec[i].first_att, &dec[i].num_atts)) return false;
@@ -1235,9 +1297,7 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
   uint8_t *fvis = G + g.fvis, *vvis = G + g.vvis;
   uint32_t *dfs = (uint32_t *)(G + g.dfs);
   const uint32_t NVMAX = m.NVMAX;
-  uint32_t *shared_d2c = nullptr, *shared_pids = nullptr, shared_entries = 0;
-  int32_t *shared_v2d = nullptr;
-  const uint32_t *shared_map = nullptr;
+  struct Shared { uint32_t *d2c, *pids, entries; int32_t *v2d; const uint32_t *map; } shared[2] = {{nullptr, nullptr, 0, nullptr, nullptr}, {nullptr, nullptr, 0, nullptr, nullptr}};
   for (uint32_t i = 0; i < ndec; ++i) {
     // MeshTraversalSequencer + DepthFirstTraverser on the decoder's corner table
     uint32_t *d2c, *pids;
@@ -1257,10 +1317,13 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
     // Every vertex-type decoder traverses the position corner table from the same start: the order, the maps and
     // the entry -> point list are those of the first one, so they are computed once and shared.
     const uint32_t *map_src = nullptr;
-    if (!corner_att && shared_d2c) { d2c = shared_d2c; v2d = shared_v2d; pids = shared_pids; entries = shared_entries; map_src = shared_map; }
+    Shared &sh = shared[dec[i].traversal_method];       // one set per traversal method (MeshEdgeBreakerDecoder.cs:681-690)
+    if (!corner_att && sh.d2c) { d2c = sh.d2c; v2d = sh.v2d; pids = sh.pids; entries = sh.entries; map_src = sh.map; }
     else if (!corner_att) {
-      if (!traverse(D, ct, nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries)) return false;
-      shared_d2c = d2c; shared_v2d = v2d; shared_pids = pids; shared_entries = entries;
+      if (dec[i].traversal_method == 1) {
+        if (!traverse_prediction_degree(D, ct, nverts, c2p, fvis, vvis, (uint32_t *)(G + g.pd_next), (uint32_t *)(G + g.pd_degree), d2c, v2d, pids, cap_entries, &entries)) return false;
+      } else if (!traverse(D, ct, nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries)) return false;
+      sh.d2c = d2c; sh.v2d = v2d; sh.pids = pids; sh.entries = entries;
     } else { if (!traverse(D, act[dd], nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries)) return false; }
     dec[i].num_entries = entries;
     if (dd < 0) D->num_entries = entries;
@@ -1278,7 +1341,7 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
         map[point] = (uint32_t)e;
       }
       map_src = map;                      // further attributes of this decoder share the map
-      if (!corner_att && !shared_map) shared_map = map;
+      if (!corner_att && !sh.map) sh.map = map;
     }
     // values, then transform parameters, of every attribute of the decoder (SequentialAttributeDecodersController.cs:29-38,
     // AttributesDecoder.cs:65-70)

@@ -183,8 +183,8 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m, bool want_gene
   if (!linear) for (uint32_t i = 0; i < ndec; ++i) {
     (void)r.u8();
     corner_dec[i] = r.u8() != 0;                                // MeshAttributeElementType: corner attribute
-    (void)r.u8();
-    if (corner_dec[i]) m.general = true;
+    const bool prediction_degree = r.u8() != 0;                 // MeshTraversalMethod
+    if (corner_dec[i] || prediction_degree) m.general = true;
   }
   const bool force_general = getenv("DSA_FORCE_GENERAL") != nullptr;   // tests: every Edgebreaker mesh through k_general
   if ((force_general || want_general) && !point_cloud) m.general = true;

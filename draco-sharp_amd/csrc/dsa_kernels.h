@@ -350,7 +350,7 @@ __global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayou
       pos_seen = true;
     }
     if (element_type != 0) { REQUIRE(att_data_id >= 0 && traversal_method == 0, 126); NOTIMPL(127); }   // corner attributes (seams)
-    if (traversal_method != 0) NOTIMPL(128);                                                        // prediction-degree traversal
+    if (traversal_method != 0) NOTIMPL(DSA_SITE_RETRY_GENERAL);                                     // prediction-degree traversal: general path (the host parse routes it there)
     att_data_of[i] = att_data_id;
   }
   (void)att_data_of;

@@ -93,6 +93,8 @@ struct GenLayout {
   uint64_t dfs;        // u32[F+1]    traversal stack
   uint64_t cum;        // u32[cum_entries] cumulative frequencies of the stream being decoded
   uint64_t cum_entries;
+  uint64_t pd_next;    // u32[3F]     prediction-degree traversal: the three priority stacks as linked lists over corners
+  uint64_t pd_degree;  // u32[NVmax]  prediction-degree traversal: faces a vertex has been seen from
   uint64_t data;       // first per-attribute-data block
   uint64_t data_stride;
   // inside a per-attribute-data block
@@ -122,6 +124,8 @@ inline GenLayout gen_layout(uint64_t F, uint64_t V, uint64_t S, uint64_t A, uint
   g.dfs = take(4 * (F + 1));
   g.cum_entries = (len * 64 < (1ull << 20) ? len * 64 : (1ull << 20)) + 2;
   g.cum = take(4 * g.cum_entries);
+  g.pd_next = take(4 * C);
+  g.pd_degree = take(4 * NV);
   g.data = cur;
   cur = 0;
   g.edge_seam = take(C);

@@ -434,6 +434,85 @@ struct DepthFirst {
   }
 };
 
+// IO/Mesh/Traverser/MaxPredictionDegreeTraverser.cs:22-152 with the same observer.  Three stacks by priority: 0 = the
+// tip of the face behind the edge is already visited, 1 = it has been seen from two or more faces, 2 = first time
+// seen.  D-28: the C# never sizes its prediction-degree list, so its TraverseFromCorner returns at once (:24-27);
+// the bitstream sizes it to the vertex count when the traversal starts.
+template <class CT>
+struct PredictionDegree {
+  const CT &ct;
+  const std::vector<int32_t> &corner_to_point;
+  EncodingData &ed;
+  std::vector<uint32_t> &point_ids;
+  std::vector<uint8_t> face_visited, vert_visited;
+  std::vector<uint32_t> degree;
+  std::vector<uint32_t> stacks[3];
+  int best = 0;
+  PredictionDegree(const CT &t, uint32_t num_verts, const std::vector<int32_t> &c2p, EncodingData &e, std::vector<uint32_t> &pids)
+      : ct(t), corner_to_point(c2p), ed(e), point_ids(pids) {
+    face_visited.assign(t.num_faces(), 0);
+    vert_visited.assign(num_verts, 0);
+    degree.assign(num_verts, 0);
+  }
+  bool face_done(uint32_t f) const { return f == kInvalid || face_visited[f]; }
+  void visit_vertex(uint32_t v, uint32_t c) {
+    vert_visited[v] = 1;
+    point_ids.push_back((uint32_t)corner_to_point[c]);
+    ed.data_to_corner.push_back(c);
+    ed.vertex_to_data[v] = ed.num_values++;
+  }
+  uint32_t pop() {                                     // :114-127
+    for (int i = best; i < 3; ++i)
+      if (!stacks[i].empty()) { uint32_t c = stacks[i].back(); stacks[i].pop_back(); best = i; return c; }
+    return kInvalid;
+  }
+  void push(uint32_t c, int priority) {                // :129-137
+    stacks[priority].push_back(c);
+    if (priority < best) best = priority;
+  }
+  int priority_of(uint32_t c) {                        // :139-152
+    uint32_t v = ct.vertex(c);
+    require(v != kInvalid, "invalid vertex in traversal");
+    if (vert_visited[v]) return 0;
+    return ++degree[v] > 1 ? 1 : 2;
+  }
+  void traverse_from(uint32_t corner) {                // :22-112
+    if (degree.empty()) return;
+    stacks[0].push_back(corner);
+    best = 0;
+    uint32_t nv = ct.vertex(CT::next(corner)), pv = ct.vertex(CT::prev(corner)), tv = ct.vertex(corner);
+    require(nv != kInvalid && pv != kInvalid && tv != kInvalid, "invalid vertex in traversal");
+    if (!vert_visited[nv]) visit_vertex(nv, CT::next(corner));
+    if (!vert_visited[pv]) visit_vertex(pv, CT::prev(corner));
+    if (!vert_visited[tv]) visit_vertex(tv, corner);
+    while ((corner = pop()) != kInvalid) {
+      if (face_done(corner / 3)) continue;
+      for (;;) {
+        face_visited[corner / 3] = 1;
+        uint32_t v = ct.vertex(corner);
+        require(v != kInvalid, "invalid vertex in traversal");
+        if (!vert_visited[v]) visit_vertex(v, corner);
+        uint32_t rc = ct.right_corner(corner), lc = ct.left_corner(corner);
+        bool right_done = face_done(rc == kInvalid ? kInvalid : rc / 3), left_done = face_done(lc == kInvalid ? kInvalid : lc / 3);
+        if (!left_done) {
+          int pr = priority_of(lc);
+          if (right_done && pr <= best) { corner = lc; continue; }
+          push(lc, pr);
+        }
+        if (!right_done) {
+          int pr = priority_of(rc);
+          if (pr <= best) { corner = rc; continue; }
+          push(rc, pr);
+        }
+        break;
+      }
+    }
+  }
+  void run() {
+    for (uint32_t f = 0; f < ct.num_faces(); ++f) traverse_from(3 * f);
+  }
+};
+
 // ---------------------------------------------------------------- attributes
 // IO/Attributes/GeometryAttribute.cs:8-67 + PointAttribute.cs:5-63 (subset)
 struct Attribute {
@@ -1376,7 +1455,6 @@ struct AttributeSectionDecoder {
           require(d.traversal_method == 0, "unsupported traversal for corner attributes");
           require(d.att_data_id >= 0, "attribute data must be specified");
         }
-        if (d.traversal_method != 0) throw Error(ERR_NOT_IMPLEMENTED, "prediction-degree traversal is not implemented");
       }
     }
     for (int i = 0; i < num_decoders; ++i) {        // AttributesDecoder.cs:19-63
@@ -1415,7 +1493,10 @@ struct AttributeSectionDecoder {
       for (uint32_t i = 0; i < m.num_points; ++i) d.point_ids[i] = i;
     } else {
       EncodingData *ed = d.att_data_id < 0 ? &m.pos_enc : &m.att_data[d.att_data_id].enc;
-      if (d.element_type == 0) {
+      if (d.element_type == 0 && d.traversal_method == 1) {   // MeshEdgeBreakerDecoder.cs:681-684
+        PredictionDegree<CornerTable> t(m.ct, m.ct.num_vertices(), m.faces, *ed, d.point_ids);
+        t.run();
+      } else if (d.element_type == 0) {
         DepthFirst<CornerTable> t(m.ct, m.ct.num_vertices(), m.faces, *ed, d.point_ids);
         t.run();
       } else {

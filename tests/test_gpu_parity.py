@@ -375,6 +375,23 @@ def test_geometric_normal_meshes_take_the_second_chance(ctx):
     b.close()
 
 
+def test_prediction_degree_traversal(ctx):
+    """MeshTraversalMethod 1 (MaxPredictionDegreeTraverser) is visible to the host parse in the decoder triples: such
+    meshes get the general scratch up front and are decoded by k_general*, beside fast-path meshes."""
+    streams = []
+    for k, (kind, nx, ny) in enumerate(KINDS):
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 31)
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(traversal_method=k % 3, single_connectivity=(k >> 1) & 1,
+                                                                                  pos_prediction=(1, 4, 2)[k % 3], uv_prediction=(1, 5)[k & 1])))
+    b = run_batch(ctx, streams)
+    for i, sbytes in enumerate(streams):
+        assert b.status(i) == 0, (i, b.status(i), b.mesh_info(i).detail)
+        ref = oracle.decode(sbytes)
+        assert ref.decoders[0]["traversal_method"] == (1 if i % 3 else 0)
+        assert_same(b.result(i), ref, b, i)
+    b.close()
+
+
 def test_single_decode_api(ctx):
     pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 12, 9, 4)
     s = synth.encode_mesh(pos, faces, nrm, uv)

@@ -171,3 +171,18 @@ def test_multi_parallelogram_predictions(kind, nx, ny, method):
         assert m.attributes[k].pred_method == method
         assert np.array_equal(m.attributes[k].portable, ref.attributes[k].portable)
     assert np.array_equal(m.faces, ref.faces)
+
+
+@pytest.mark.parametrize("kind,nx,ny", KINDS + [(synth.TORUS, 24, 40)])
+@pytest.mark.parametrize("single,method", [(0, 1), (0, 2), (1, 1)])
+def test_prediction_degree_traversal(kind, nx, ny, single, method):
+    # MaxPredictionDegreeTraverser (MeshTraversalMethod 1): another attribute order over the same connectivity, so
+    # the decoded mesh must be the depth-first stream's mesh, vertex for vertex
+    pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 12)
+    ref = oracle.decode(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(single_connectivity=single)))
+    m = check_roundtrip(kind, nx, ny, 12, single_connectivity=single, traversal_method=method, uv_prediction=5)
+    want = [1] if single else ([1, 0, 0] if method == 1 else [1, 1, 1])
+    assert [d["traversal_method"] for d in m.decoders] == want
+    assert np.array_equal(m.faces, ref.faces)
+    for a, r in zip(m.attributes, ref.attributes):
+        assert np.array_equal(a.portable[a.point_map], r.portable[r.point_map])
