@@ -572,6 +572,45 @@ struct EbEncoder {
   }
 };
 
+// Predictive Edgebreaker traversal, encoder side (the reference has only the decoder,
+// MeshEdgeBreakerTraversalPredictiveDecoder.cs:19-93; this follows the format's encoder): valences of the not yet
+// coded part of the mesh are what the decoder will have built when it gets there.  Before a C or R symbol the
+// previous symbol (the decoder's next) is predicted from the valence of the pivot: a hit costs one bit, a miss one
+// bit and the symbol.  The tip of a split face is poisoned (two decoder vertices until the S merges them).
+static void predictive_symbols(const CornerTable &ct, const EbResult &eb, std::vector<uint8_t> &explicit_symbols, std::vector<uint8_t> &predictions) {
+  const size_t n = eb.symbols.size();
+  std::vector<int32_t> valence(ct.nv(), 0);
+  for (uint32_t c = 0; c < ct.nc(); ++c) {                 // edges around a vertex: faces, +1 on a boundary
+    valence[ct.vertex(c)] += 1;
+    if (ct.opposite(CornerTable::prev(c)) == kInvalid) valence[ct.vertex(c)] += 1;   // the boundary edge leaving the fan on this side
+  }
+  explicit_symbols.clear();
+  predictions.clear();
+  int prev_symbol = -1;
+  for (size_t i = 0; i < n; ++i) {
+    const uint8_t symbol = eb.symbols[i];
+    const uint32_t corner = eb.processed_corners[n - 1 - i], next = CornerTable::next(corner), prev = CornerTable::prev(corner);
+    const uint32_t a = ct.vertex(corner), b = ct.vertex(next), c = ct.vertex(prev);
+    auto predict = [&](uint32_t pivot) { const int32_t v = valence[pivot]; return v < 0 ? -2 : (v < 6 ? 5 : 0); };
+    int predicted = -1;
+    switch (symbol) {
+      case 0: predicted = predict(b); valence[b] -= 1; valence[c] -= 1; break;
+      case 1: valence[b] -= 1; valence[c] -= 1; valence[a] = -1; break;
+      case 5: predicted = predict(b); valence[a] -= 1; valence[b] -= 1; valence[c] -= 2; break;
+      case 3: valence[a] -= 1; valence[b] -= 2; valence[c] -= 1; break;
+      default: valence[a] -= 2; valence[b] -= 2; valence[c] -= 2; break;
+    }
+    bool store_prev = true;
+    if (predicted != -1) {
+      if (predicted == prev_symbol) { predictions.push_back(1); store_prev = false; }
+      else if (prev_symbol != -1) predictions.push_back(0);
+    }
+    if (store_prev && prev_symbol != -1) explicit_symbols.push_back((uint8_t)prev_symbol);
+    prev_symbol = symbol;
+  }
+  if (prev_symbol != -1) explicit_symbols.push_back((uint8_t)prev_symbol);
+}
+
 // ----------------------------------------------------------------- options
 struct Options {
   int32_t pos_bits = 11, uv_bits = 10, normal_bits = 8;
@@ -582,6 +621,7 @@ struct Options {
   int32_t uv_prediction = 1;
   int32_t generic_u8 = 0;            // add a per-vertex uint8 generic attribute (Integer decoder) when generic data is given
   int32_t normal_prediction = 0;     // 0 difference, 6 geometric normal (the CPU coder only)
+  int32_t predictive_connectivity = 0;   // 1: predictive Edgebreaker traversal (deprecated in the format; CPU coder only)
   int32_t traversal_method = 0;      // attribute sequencing: 0 depth first; 1 prediction degree for the decoder of the positions
                                      // (what stock encoders do at their highest level); 2 prediction degree for every decoder (CPU coder only)
 };
@@ -997,6 +1037,8 @@ struct MeshPlan {
   Sequence seq;                      // depth-first order
   Sequence seq_pd;                   // prediction-degree order (only when an attributes decoder asks for it)
   int traversal_method = 0;
+  bool predictive = false;           // predictive Edgebreaker traversal: explicit symbols + prediction bits below
+  std::vector<uint8_t> explicit_symbols, predictions;   // encoder order
   bool uses_pd(size_t att) const { return traversal_method == 2 || (traversal_method == 1 && (single || att == 0)); }
   const Sequence &seq_of(size_t att) const { return uses_pd(att) ? seq_pd : seq; }
   std::vector<PortableAttr> atts;    // descriptors; vals / quantisation parameters are filled by whoever codes the values
@@ -1017,6 +1059,8 @@ static void plan_mesh(const MeshIn &in, const Options &opt, MeshPlan &pl) {
   if (in.generic) { PortableAttr a; a.att_type = 4; a.nc = a.nc_out = 1; a.seq_type = 1; a.data_type = 2; a.prediction = 1; pl.atts.push_back(a); }
   pl.single = opt.single_connectivity != 0;
   pl.num_att_data = pl.single ? 0 : (uint32_t)pl.atts.size() - 1;
+  pl.predictive = opt.predictive_connectivity != 0;
+  if (pl.predictive) predictive_symbols(pl.ct, pl.eb, pl.explicit_symbols, pl.predictions);
   pl.traversal_method = opt.traversal_method;
   if (pl.traversal_method != 0) {
     prediction_degree_sequence(pl.ct, pl.eb.processed_corners, pl.seq_pd);
@@ -1032,7 +1076,7 @@ static void write_stream(ByteWriter &w, const MeshIn &in, const MeshPlan &pl, Va
   const EbResult &eb = pl.eb;
   w.d.insert(w.d.end(), {'D', 'R', 'A', 'C', 'O'});
   w.u8(2); w.u8(2); w.u8(1); w.u8(1); w.u16(0);
-  w.u8(0);   // standard Edgebreaker traversal (DracoEncoder.cs:90)
+  w.u8(pl.predictive ? 1 : 0);   // Edgebreaker traversal: standard (DracoEncoder.cs:90) or predictive
   w.varint(in.nv);
   w.varint(in.nf);
   w.u8((uint8_t)pl.num_att_data);
@@ -1051,7 +1095,8 @@ static void write_stream(ByteWriter &w, const MeshIn &in, const MeshPlan &pl, Va
   {
     BitWriter bw;
     static const int len[8] = {1, 3, 0, 3, 0, 3, 0, 3};
-    for (size_t i = eb.symbols.size(); i-- > 0;) bw.put(len[eb.symbols[i]], eb.symbols[i]);
+    const std::vector<uint8_t> &syms = pl.predictive ? pl.explicit_symbols : eb.symbols;
+    for (size_t i = syms.size(); i-- > 0;) bw.put(len[syms[i]], syms[i]);
     w.varint(bw.d.size());
     w.bytes(bw.d);
     write_rabs(w, eb.start_face_bits);
@@ -1068,6 +1113,11 @@ static void write_stream(ByteWriter &w, const MeshIn &in, const MeshPlan &pl, Va
         }
       }
       for (uint32_t i = 0; i < pl.num_att_data; ++i) write_rabs(w, bits);
+    }
+    if (pl.predictive) {   // MeshEdgeBreakerTraversalPredictiveDecoder.cs:19-27: split symbol count, then the prediction bits in decoder order
+      w.i32((int32_t)eb.num_split_symbols);
+      std::vector<uint8_t> bits(pl.predictions.rbegin(), pl.predictions.rend());
+      write_rabs(w, bits);
     }
   }
   // attribute section (ConnectivityEncoder.cs:39-56)

@@ -840,8 +840,7 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
   // ---------------------------------------------------------------- MeshEdgeBreakerDecoder.cs:25-134
   D->traversal_type = (uint8_t)r.u8();
   GREQ(r.ok && D->traversal_type <= 2, 109);
-  if (D->traversal_type == 1) GNOTIMPL(110);               // predictive traversal
-  const bool valence = D->traversal_type == 2;
+  const bool valence = D->traversal_type == 2, predictive = D->traversal_type == 1;
   const uint64_t nv64 = r.varint(), nf64 = r.varint();
   GREQ(r.ok && nf64 <= 0x7FFFFFFFu / 3 && nv64 <= nf64 * 3, 111);
   GREQ(nv64 * (nv64 - 1) / 2 >= 3 * nf64 / 2, 112);
@@ -899,7 +898,7 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
   const uint8_t *sym_bits = nullptr;
   uint32_t sym_nbytes = 0;
   uint64_t sym_bitpos = 0;
-  if (!valence) {
+  if (!valence) {                                          // standard and predictive: the explicit symbols
     const uint64_t size = r.varint();
     GREQ(r.ok && size <= (uint64_t)(r.n - r.pos), 119);
     sym_bits = r.p + r.pos; sym_nbytes = (uint32_t)size;
@@ -913,6 +912,16 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
   for (uint32_t i = 0; i < nad; ++i) {
     seams[i].start(s, L.stream_len, r.pos, &endp);
     GREQ(seams[i].ok, 260);
+    r.pos = endp;
+  }
+  Rabs prediction;
+  int predicted_symbol = -1;
+  if (predictive) {                                        // MeshEdgeBreakerTraversalPredictiveDecoder.cs:19-27
+    const int32_t nss = (int32_t)r.u32();
+    GREQ(r.ok && nss >= 0 && (uint32_t)nss < VMAX, 645);
+    for (uint32_t v = 0; v < VMAX; ++v) valences[v] = 0;
+    prediction.start(s, L.stream_len, r.pos, &endp);
+    GREQ(prediction.ok, 646);
     r.pos = endp;
   }
   uint32_t ctx_off[6] = {0, 0, 0, 0, 0, 0};
@@ -939,10 +948,14 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
     const uint32_t face = num_faces++;
     bool check_split = false;
     uint32_t sym;
-    if (!valence) {                                        // MeshEdgeBreakerTraversalDecoder.cs:89-99
+    if (predictive && predicted_symbol != -1 && prediction.next() != 0) {   // ...PredictiveDecoder.cs:34-46: predicted and confirmed
+      sym = (uint32_t)predicted_symbol;
+      last_symbol = predicted_symbol;
+    } else if (!valence) {                                 // MeshEdgeBreakerTraversalDecoder.cs:89-99
       sym = read_bits(sym_bits, sym_nbytes, sym_bitpos, 1); sym_bitpos += 1;
       if (sym) { sym |= read_bits(sym_bits, sym_nbytes, sym_bitpos, 2) << 1; sym_bitpos += 2; }
       GREQ(sym_bitpos <= (uint64_t)sym_nbytes * 8, 246);
+      last_symbol = (int)sym;
     } else {                                               // ...ValenceDecoder.cs:77-98
       if (active_context != -1) {
         const int32_t cnt = --ctx_cnt[active_context];
@@ -1008,7 +1021,7 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
       uint32_t cn = cnx(cb);
       const uint32_t vn = ct.vertex(cn);
       GREQ(vn < ct.nv, 234);
-      if (valence) valences[vp] += valences[vn];           // ...ValenceDecoder.cs:151-154
+      if (valence || predictive) valences[vp] += valences[vn];   // ...ValenceDecoder.cs:151-154 / ...PredictiveDecoder MergeVertices
       ct.vcorner[vp] = ct.left_most(vn);
       const uint32_t first = cn;
       uint32_t guard = 0;
@@ -1029,7 +1042,7 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
       stack[sp++] = corner;
       check_split = true;
     } else GFAIL(241);
-    if (valence) {                     // NewActiveCornerReached, ...ValenceDecoder.cs:100-149
+    if (valence || predictive) {       // NewActiveCornerReached, ...ValenceDecoder.cs:100-149 / ...PredictiveDecoder.cs:48-92
       const uint32_t top = stack[sp - 1], nx = cnx(top), pv = cpv(top);
       const uint32_t a = ct.vertex(top), b = ct.vertex(nx), c = ct.vertex(pv);
       GREQ(a < VMAX && b < VMAX && c < VMAX, 644);
@@ -1042,6 +1055,7 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
       }
       const int32_t v = (int32_t)valences[b];
       active_context = (v < 2 ? 2 : (v > 7 ? 7 : v)) - 2;
+      predicted_symbol = (last_symbol == 0 || last_symbol == 5) ? (v < 6 ? 5 : 0) : -1;
     }
     if (check_split) {                 // :363-375, IsTopologySplit :450-471
       const int32_t enc_id = (int32_t)(num_symbols - sid - 1);

@@ -151,8 +151,7 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m, bool want_gene
     if (method > 1) return bad(ST_INVALID);
     uint32_t traversal = r.u8();
     if (!r.ok || traversal > 2) return bad(ST_INVALID);
-    if (traversal == 1) return bad(ST_NOTIMPL);                  // predictive traversal
-    if (traversal == 2) m.general = true;
+    if (traversal != 0) m.general = true;                       // valence / predictive symbols: general path
     uint64_t nv = r.varint(), nf = r.varint();
     if (!r.ok || nf > 0x7FFFFFFFu / 3 || nv > nf * 3 || nf > 1024ull * len) return bad(ST_INVALID);
     uint32_t nad = r.u8();
@@ -166,9 +165,10 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m, bool want_gene
     for (uint64_t i = 0; i < 2 * nsplits && r.ok; ++i) (void)r.varint();
     r.skip((nsplits + 7) >> 3);
     uint64_t sz;
-    if (traversal == 0) { sz = r.varint(); r.skip(sz); }        // symbols
+    if (traversal != 2) { sz = r.varint(); r.skip(sz); }        // symbols
     (void)r.u8(); sz = r.varint(); r.skip(sz);                  // start faces
     for (uint32_t i = 0; i < nad; ++i) { (void)r.u8(); sz = r.varint(); r.skip(sz); }
+    if (traversal == 1) { r.skip(4); (void)r.u8(); sz = r.varint(); r.skip(sz); }   // MeshEdgeBreakerTraversalPredictiveDecoder.cs:19-27
     if (traversal == 2) {                                       // MeshEdgeBreakerTraversalValenceDecoder.cs:22-69
       for (int c = 0; c < 6 && r.ok; ++c) {
         const uint64_t num = r.varint();

@@ -115,7 +115,7 @@ static void make_mesh(int kind, int nx, int ny, uint64_t seed, MeshBuf &m) {
 extern "C" {
 
 struct synth_options {
-  int32_t pos_bits, uv_bits, normal_bits, single_connectivity, force_scheme, compression_level, pos_prediction, uv_prediction, normal_prediction, traversal_method;
+  int32_t pos_bits, uv_bits, normal_bits, single_connectivity, force_scheme, compression_level, pos_prediction, uv_prediction, normal_prediction, traversal_method, predictive_connectivity;
 };
 
 static thread_local char g_err[256];
@@ -128,6 +128,7 @@ static synth::Options to_opt(const synth_options *o) {
     r.single_connectivity = o->single_connectivity; r.force_scheme = o->force_scheme;
     r.compression_level = o->compression_level; r.pos_prediction = o->pos_prediction; r.uv_prediction = o->uv_prediction;
     r.normal_prediction = o->normal_prediction; r.traversal_method = o->traversal_method;
+    r.predictive_connectivity = o->predictive_connectivity;
   }
   return r;
 }
@@ -136,6 +137,7 @@ void synth_default_options(synth_options *o) {
   o->pos_bits = d.pos_bits; o->uv_bits = d.uv_bits; o->normal_bits = d.normal_bits; o->single_connectivity = d.single_connectivity;
   o->force_scheme = d.force_scheme; o->compression_level = d.compression_level; o->pos_prediction = d.pos_prediction; o->uv_prediction = d.uv_prediction;
   o->normal_prediction = d.normal_prediction; o->traversal_method = d.traversal_method;
+  o->predictive_connectivity = d.predictive_connectivity;
 }
 
 // Encodes one mesh.  normals/uvs/generic may be NULL.  *out is malloc'ed; free with synth_free.

@@ -1024,6 +1024,8 @@ struct EdgebreakerDecoder {
   std::vector<std::vector<uint32_t>> ctx_symbols;
   std::vector<int> ctx_counters;
   int last_symbol = -1, active_context = -1;
+  int predicted_symbol = -1;              // predictive traversal
+  RabsDecoder prediction;
   // topology splits
   struct Split { uint32_t source, split, edge; };
   std::vector<Split> splits;
@@ -1056,7 +1058,7 @@ struct EdgebreakerDecoder {
 
   // MeshEdgeBreakerTraversalDecoder.cs:27-61 / ...ValenceDecoder.cs:22-69
   void traversal_start(uint32_t num_encoded_vertices_total) {
-    if (traversal_type == 0) {
+    if (traversal_type == 0 || traversal_type == 1) {
       // D-3: the symbol section is a size-prefixed byte block read LSB-first.
       uint64_t size = b.varint();
       require(size <= b.n - b.pos, "traversal symbol section exceeds stream");
@@ -1067,6 +1069,12 @@ struct EdgebreakerDecoder {
     start_face.start(b);
     require(num_att_data <= 64, "too many attribute data");
     for (uint32_t i = 0; i < num_att_data; ++i) seams[i].start(b);
+    if (traversal_type == 1) {             // MeshEdgeBreakerTraversalPredictiveDecoder.cs:19-27
+      int32_t num_split_symbols = b.i32();
+      require(num_split_symbols >= 0 && (uint32_t)num_split_symbols < num_encoded_vertices_total, "invalid predictive split symbol count");
+      vertex_valences.assign(num_encoded_vertices_total, 0);
+      prediction.start(b);
+    }
     if (traversal_type == 2) {
       vertex_valences.assign(num_encoded_vertices_total, 0);
       ctx_symbols.assign(6, {});
@@ -1083,6 +1091,13 @@ struct EdgebreakerDecoder {
   }
   // MeshEdgeBreakerTraversalDecoder.cs:89-99 / ...ValenceDecoder.cs:77-98
   uint32_t decode_symbol() {
+    if (traversal_type == 1) {             // MeshEdgeBreakerTraversalPredictiveDecoder.cs:34-46
+      if (predicted_symbol != -1 && prediction.next() != 0) { last_symbol = predicted_symbol; return (uint32_t)last_symbol; }
+      uint32_t s = symbol_buf.bits(1);
+      if (s != 0) s |= symbol_buf.bits(2) << 1;
+      last_symbol = (int)s;
+      return s;
+    }
     if (traversal_type == 0) {
       uint32_t s = symbol_buf.bits(1);
       if (s == 0) return 0;
@@ -1102,7 +1117,7 @@ struct EdgebreakerDecoder {
   }
   // ...ValenceDecoder.cs:100-149
   void new_active_corner(uint32_t corner) {
-    if (traversal_type != 2) return;
+    if (traversal_type == 0) return;
     uint32_t nx = CornerTable::next(corner), pv = CornerTable::prev(corner);
     switch (last_symbol) {
       case 0: case 1:
@@ -1116,11 +1131,15 @@ struct EdgebreakerDecoder {
       default: break;
     }
     int v = (int)vertex_valences[m.ct.vertex(nx)];
+    if (traversal_type == 1) {             // ...PredictiveDecoder.cs:79-92: after C or R, R while the pivot has fewer than six edges
+      predicted_symbol = (last_symbol == 0 || last_symbol == 5) ? (v < 6 ? 5 : 0) : -1;
+      return;
+    }
     int clamped = v < 2 ? 2 : (v > 7 ? 7 : v);
     active_context = clamped - 2;
   }
   void merge_vertices(uint32_t dest, uint32_t src) {   // ...ValenceDecoder.cs:151-154
-    if (traversal_type == 2) vertex_valences[dest] += vertex_valences[src];
+    if (traversal_type != 0) vertex_valences[dest] += vertex_valences[src];
   }
   // MeshEdgeBreakerDecoder.cs:450-471
   bool is_topology_split(int encoder_symbol_id, int *edge, int *split_id) {
@@ -1781,8 +1800,7 @@ static void decode(const uint8_t *data, size_t len, Mesh &m) {
     }
     require(m.encoder_method == 1, "unsupported encoder method");
     m.traversal_type = b.u8();
-    if (m.traversal_type == 1) throw Error(ERR_NOT_IMPLEMENTED, "predictive Edgebreaker traversal is not implemented");
-    require(m.traversal_type == 0 || m.traversal_type == 2, "unsupported Edgebreaker traversal type");
+    require(m.traversal_type <= 2, "unsupported Edgebreaker traversal type");
     EdgebreakerDecoder eb(b, m, m.traversal_type);
     eb.decode_connectivity();
     AttributeSectionDecoder ad(b, m);
