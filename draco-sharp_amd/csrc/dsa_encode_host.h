@@ -430,6 +430,7 @@ struct EbResult {
   struct Split { uint32_t source, split, edge; };
   std::vector<Split> splits;
   uint32_t num_split_symbols = 0;
+  std::vector<uint32_t> face_time;            // face -> index of the first symbol coded with the face already visited
 };
 
 struct EbEncoder {
@@ -502,6 +503,7 @@ struct EbEncoder {
         ++last_symbol_id;
         uint32_t face = corner / 3;
         visited_faces[face] = 1;
+        r.face_time[face] = (uint32_t)last_symbol_id;
         r.processed_corners.push_back(corner);
         uint32_t v = ct.vertex(corner);
         bool on_boundary = vertex_hole_id[v] != -1;
@@ -544,6 +546,7 @@ struct EbEncoder {
   }
   void run() {   // MeshEdgeBreakerEncoder.cs:38-124
     visited_faces.assign(ct.nf(), 0);
+    r.face_time.assign(ct.nf(), kInvalid);
     visited_verts.assign(ct.nv(), 0);
     vertex_hole_id.assign(ct.nv(), -1);
     find_holes();
@@ -559,6 +562,7 @@ struct EbEncoder {
         visited_verts[ct.vertex(CornerTable::next(start))] = 1;
         visited_verts[ct.vertex(CornerTable::prev(start))] = 1;
         visited_faces[face] = 1;
+        r.face_time[face] = (uint32_t)(last_symbol_id + 1);
         init_corners.push_back(CornerTable::next(start));
         uint32_t o = ct.opposite(CornerTable::next(start));
         if (o != kInvalid && !visited_faces[o / 3]) encode_from_corner(o);
@@ -611,6 +615,54 @@ static void predictive_symbols(const CornerTable &ct, const EbResult &eb, std::v
   if (prev_symbol != -1) explicit_symbols.push_back((uint8_t)prev_symbol);
 }
 
+// Valence Edgebreaker traversal, encoder side (decoder: MeshEdgeBreakerTraversalValenceDecoder.cs:22-154): every
+// symbol but the last coded one goes into one of six lists chosen by the valence, in the not yet coded part of the
+// mesh, of the vertex the decoder will stand on when it reads it.  A split face's tip is two decoder vertices until
+// the S merges them: the encoder splits it the same way (faces left of the split keep the vertex, faces right of it
+// get a new one).  Symbol ids: C 0, S 1, L 2, R 3, E 4 (Constants.cs:88-95).
+static void valence_context_symbols(const CornerTable &ct, const EbResult &eb, std::vector<uint32_t> ctx[6]) {
+  const size_t n = eb.symbols.size();
+  std::vector<int32_t> valence(ct.nv(), 0);
+  for (uint32_t c = 0; c < ct.nc(); ++c) {
+    valence[ct.vertex(c)] += 1;
+    if (ct.opposite(CornerTable::prev(c)) == kInvalid) valence[ct.vertex(c)] += 1;
+  }
+  std::vector<uint32_t> c2v(ct.nc());
+  for (uint32_t c = 0; c < ct.nc(); ++c) c2v[c] = ct.vertex(c);
+  for (int i = 0; i < 6; ++i) ctx[i].clear();
+  int prev_symbol = -1;
+  for (size_t i = 0; i < n; ++i) {
+    const uint8_t symbol = eb.symbols[i];
+    const uint32_t corner = eb.processed_corners[n - 1 - i], next = CornerTable::next(corner), prev = CornerTable::prev(corner);
+    auto coded = [&](uint32_t c) { return eb.face_time[c / 3] <= i; };
+    const int32_t active_valence = valence[c2v[next]];
+    switch (symbol) {
+      case 0: valence[c2v[next]] -= 1; valence[c2v[prev]] -= 1; break;
+      case 1: {
+        valence[c2v[next]] -= 1; valence[c2v[prev]] -= 1;
+        int left = 0, right = 0;
+        uint32_t a = ct.opposite(prev);
+        while (a != kInvalid && !coded(a)) { ++left; a = ct.opposite(CornerTable::next(a)); }
+        valence[c2v[corner]] = left + 1;
+        const uint32_t nv = (uint32_t)valence.size();
+        a = ct.opposite(next);
+        while (a != kInvalid && !coded(a)) { ++right; c2v[CornerTable::next(a)] = nv; a = ct.opposite(CornerTable::prev(a)); }
+        valence.push_back(right + 1);
+        break;
+      }
+      case 5: valence[c2v[corner]] -= 1; valence[c2v[next]] -= 1; valence[c2v[prev]] -= 2; break;
+      case 3: valence[c2v[corner]] -= 1; valence[c2v[next]] -= 2; valence[c2v[prev]] -= 1; break;
+      default: valence[c2v[corner]] -= 2; valence[c2v[next]] -= 2; valence[c2v[prev]] -= 2; break;
+    }
+    if (prev_symbol != -1) {
+      const int clamped = active_valence < 2 ? 2 : (active_valence > 7 ? 7 : active_valence);
+      static const uint32_t id_of[8] = {0, 1, 0, 2, 0, 3, 0, 4};
+      ctx[clamped - 2].push_back(id_of[prev_symbol]);
+    }
+    prev_symbol = symbol;
+  }
+}
+
 // ----------------------------------------------------------------- options
 struct Options {
   int32_t pos_bits = 11, uv_bits = 10, normal_bits = 8;
@@ -621,7 +673,8 @@ struct Options {
   int32_t uv_prediction = 1;
   int32_t generic_u8 = 0;            // add a per-vertex uint8 generic attribute (Integer decoder) when generic data is given
   int32_t normal_prediction = 0;     // 0 difference, 6 geometric normal (the CPU coder only)
-  int32_t predictive_connectivity = 0;   // 1: predictive Edgebreaker traversal (deprecated in the format; CPU coder only)
+  int32_t predictive_connectivity = 0;   // 1: predictive Edgebreaker traversal (deprecated in the format); 2: valence traversal, what stock
+                                         // encoders write at their default level (CPU coder only)
   int32_t traversal_method = 0;      // attribute sequencing: 0 depth first; 1 prediction degree for the decoder of the positions
                                      // (what stock encoders do at their highest level); 2 prediction degree for every decoder (CPU coder only)
 };
@@ -1037,6 +1090,9 @@ struct MeshPlan {
   Sequence seq;                      // depth-first order
   Sequence seq_pd;                   // prediction-degree order (only when an attributes decoder asks for it)
   int traversal_method = 0;
+  int force_scheme = -1, compression_level = 5;
+  bool valence = false;              // valence Edgebreaker traversal: six context symbol lists
+  std::vector<uint32_t> ctx_symbols[6];
   bool predictive = false;           // predictive Edgebreaker traversal: explicit symbols + prediction bits below
   std::vector<uint8_t> explicit_symbols, predictions;   // encoder order
   bool uses_pd(size_t att) const { return traversal_method == 2 || (traversal_method == 1 && (single || att == 0)); }
@@ -1059,7 +1115,10 @@ static void plan_mesh(const MeshIn &in, const Options &opt, MeshPlan &pl) {
   if (in.generic) { PortableAttr a; a.att_type = 4; a.nc = a.nc_out = 1; a.seq_type = 1; a.data_type = 2; a.prediction = 1; pl.atts.push_back(a); }
   pl.single = opt.single_connectivity != 0;
   pl.num_att_data = pl.single ? 0 : (uint32_t)pl.atts.size() - 1;
-  pl.predictive = opt.predictive_connectivity != 0;
+  pl.force_scheme = opt.force_scheme; pl.compression_level = opt.compression_level;
+  pl.predictive = opt.predictive_connectivity == 1;
+  pl.valence = opt.predictive_connectivity == 2;
+  if (pl.valence) valence_context_symbols(pl.ct, pl.eb, pl.ctx_symbols);
   if (pl.predictive) predictive_symbols(pl.ct, pl.eb, pl.explicit_symbols, pl.predictions);
   pl.traversal_method = opt.traversal_method;
   if (pl.traversal_method != 0) {
@@ -1076,7 +1135,7 @@ static void write_stream(ByteWriter &w, const MeshIn &in, const MeshPlan &pl, Va
   const EbResult &eb = pl.eb;
   w.d.insert(w.d.end(), {'D', 'R', 'A', 'C', 'O'});
   w.u8(2); w.u8(2); w.u8(1); w.u8(1); w.u16(0);
-  w.u8(pl.predictive ? 1 : 0);   // Edgebreaker traversal: standard (DracoEncoder.cs:90) or predictive
+  w.u8(pl.valence ? 2 : (pl.predictive ? 1 : 0));   // Edgebreaker traversal: standard (DracoEncoder.cs:90), predictive or valence
   w.varint(in.nv);
   w.varint(in.nf);
   w.u8((uint8_t)pl.num_att_data);
@@ -1096,9 +1155,11 @@ static void write_stream(ByteWriter &w, const MeshIn &in, const MeshPlan &pl, Va
     BitWriter bw;
     static const int len[8] = {1, 3, 0, 3, 0, 3, 0, 3};
     const std::vector<uint8_t> &syms = pl.predictive ? pl.explicit_symbols : eb.symbols;
-    for (size_t i = syms.size(); i-- > 0;) bw.put(len[syms[i]], syms[i]);
-    w.varint(bw.d.size());
-    w.bytes(bw.d);
+    if (!pl.valence) {
+      for (size_t i = syms.size(); i-- > 0;) bw.put(len[syms[i]], syms[i]);
+      w.varint(bw.d.size());
+      w.bytes(bw.d);
+    }
     write_rabs(w, eb.start_face_bits);
     if (pl.num_att_data) {
       // per-vertex attributes: no interior seams, one 0 bit per interior edge in decoder face order
@@ -1114,6 +1175,11 @@ static void write_stream(ByteWriter &w, const MeshIn &in, const MeshPlan &pl, Va
       }
       for (uint32_t i = 0; i < pl.num_att_data; ++i) write_rabs(w, bits);
     }
+    if (pl.valence)        // MeshEdgeBreakerTraversalValenceDecoder.cs:43-68: the six context lists, each through the symbol coder
+      for (int i = 0; i < 6; ++i) {
+        w.varint(pl.ctx_symbols[i].size());
+        if (!pl.ctx_symbols[i].empty()) encode_symbols(w, pl.ctx_symbols[i], 1, pl.force_scheme, pl.compression_level);
+      }
     if (pl.predictive) {   // MeshEdgeBreakerTraversalPredictiveDecoder.cs:19-27: split symbol count, then the prediction bits in decoder order
       w.i32((int32_t)eb.num_split_symbols);
       std::vector<uint8_t> bits(pl.predictions.rbegin(), pl.predictions.rend());

@@ -383,13 +383,13 @@ def test_prediction_degree_traversal(ctx):
         pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 31)
         streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(traversal_method=k % 3, single_connectivity=(k >> 1) & 1,
                                                                                   pos_prediction=(1, 4, 2)[k % 3], uv_prediction=(1, 5)[k & 1],
-                                                                                  predictive_connectivity=int(k in (0, 4, 5)))))
+                                                                                  predictive_connectivity=(1, 0, 2, 2, 1, 1, 2)[k])))
     b = run_batch(ctx, streams)
     for i, sbytes in enumerate(streams):
         assert b.status(i) == 0, (i, b.status(i), b.mesh_info(i).detail)
         ref = oracle.decode(sbytes)
         assert ref.decoders[0]["traversal_method"] == (1 if i % 3 else 0)
-        assert ref.traversal_type == int(i in (0, 4, 5))         # predictive Edgebreaker symbols: general path as well
+        assert ref.traversal_type == (1, 0, 2, 2, 1, 1, 2)[i]    # predictive / valence Edgebreaker symbols: general path as well
         assert_same(b.result(i), ref, b, i)
     b.close()
 

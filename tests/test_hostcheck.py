@@ -75,7 +75,11 @@ def test_house04_through_the_general_path_source(exe, house04_bytes, tmp_path):
     (synth.HOLES, 14, 12, {"traversal_method": 1, "pos_prediction": 4}), (synth.TORUS, 12, 9, {"traversal_method": 2, "uv_prediction": 5}),
     (synth.TWO_PARTS, 9, 6, {"traversal_method": 1, "single_connectivity": 1, "normal_prediction": 6}),
     # predictive Edgebreaker traversal
-    (synth.HOLES, 20, 16, {"predictive_connectivity": 1}), (synth.TORUS, 12, 9, {"predictive_connectivity": 1, "single_connectivity": 1}), (synth.HOLES, 14, 12, {"uv_prediction": 5, "normal_prediction": 6, "single_connectivity": 1})])
+    (synth.HOLES, 20, 16, {"predictive_connectivity": 1}), (synth.TORUS, 12, 9, {"predictive_connectivity": 1, "single_connectivity": 1}),
+    # valence Edgebreaker traversal on holes, handles and two components, with the predictors stock encoders pair it with
+    (synth.HOLES, 20, 16, {"predictive_connectivity": 2, "uv_prediction": 5, "normal_prediction": 6}),
+    (synth.TORUS, 12, 9, {"predictive_connectivity": 2, "single_connectivity": 1, "force_scheme": 0}),
+    (synth.TWO_PARTS, 9, 6, {"predictive_connectivity": 2, "pos_prediction": 4, "traversal_method": 1}), (synth.HOLES, 14, 12, {"uv_prediction": 5, "normal_prediction": 6, "single_connectivity": 1})])
 def test_synthetic_meshes_through_the_general_path_source(exe, tmp_path, kind, nx, ny, opts):
     pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 7)
     data = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(**opts))
@@ -108,6 +112,7 @@ def test_corrupt_streams_never_leave_their_regions(exe, house04_bytes, tmp_path)
              (synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, uv_prediction=5)), 1500, True),
              (synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(traversal_method=2)), 1500, False),
              (synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(predictive_connectivity=1)), 1500, False),
+             (synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(predictive_connectivity=2)), 1500, False),
              (synth.encode_mesh_sequential(pos, faces, nrm, uv, compressed=True), 1000, False),
              (synth.encode_mesh_sequential(pos, faces, nrm, uv, compressed=False), 1000, False)]
     for k, (data, iters, force) in enumerate(cases):

