@@ -21,6 +21,11 @@ namespace gen {
 #define GFAIL(site) do { fail(D, ST_INVALID, (site)); return false; } while (0)
 #define GREQ(cond, site) do { if (!(cond)) GFAIL(site); } while (0)
 #define GNOTIMPL(site) do { fail(D, ST_NOTIMPL, (site)); return false; } while (0)
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint64_t gclk() { return __builtin_amdgcn_s_memtime(); }
+#else
+inline uint64_t gclk() { return 0; }
+#endif
 
 __device__ __forceinline__ uint32_t cnx(uint32_t c) { return c == DSA_INVALID ? c : ((c % 3u == 2u) ? c - 2u : c + 1u); }
 __device__ __forceinline__ uint32_t cpv(uint32_t c) { return c == DSA_INVALID ? c : ((c % 3u == 0u) ? c + 2u : c - 1u); }
@@ -837,6 +842,7 @@ inline bool g_any(bool b) { return b; }
 // vertex compaction, attribute seam bits.  Leaves the reader position in D->end_pos for phase 3.
 __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, RansScratch rs) {
   const uint8_t *s = arena + L.stream;
+  const uint64_t t0 = gclk();
   // ---------------------------------------------------------------- MeshEdgeBreakerDecoder.cs:25-134
   D->traversal_type = (uint8_t)r.u8();
   GREQ(r.ok && D->traversal_type <= 2, 109);
@@ -865,7 +871,6 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
   const GenLayout &g = m.g;
   uint8_t *G = m.G;
   Ct &ct = m.ct;
-  Act *act = m.act;
   uint8_t *is_hole = m.is_hole;
   uint32_t *valences = (uint32_t *)(arena + L.vstamp);
   uint32_t *ctx_syms = (uint32_t *)(arena + L.fstamp);
@@ -909,7 +914,8 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
   start_face.start(s, L.stream_len, r.pos, &endp);
   GREQ(start_face.ok, 201);
   r.pos = endp;
-  for (uint32_t i = 0; i < nad; ++i) {
+  for (uint32_t i = 0; i < nad; ++i) {                     // decoded by phase 2 (mesh_seams), which has the whole wave
+    D->gen_seam_pos[i] = r.pos;
     seams[i].start(s, L.stream_len, r.pos, &endp);
     GREQ(seams[i].ok, 260);
     r.pos = endp;
@@ -941,6 +947,7 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
     }
   }
   // ---------------------------------------------------------------- symbols, :232-442
+  const uint64_t t1 = gclk();
   int last_symbol = -1, active_context = -1;
   uint32_t sp = 0, num_faces = 0, num_invalid = 0, splits_left = S;
   const bool remove_invalid = nad == 0;
@@ -1074,6 +1081,7 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
     }
   }
   // start faces, :378-415
+  const uint64_t t2 = gclk();
   while (sp > 0) {
     const uint32_t corner = stack[--sp];
     const bool interior = start_face.next() != 0;
@@ -1125,20 +1133,64 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
   const uint32_t num_conn_vertices = num_vertices;
   D->num_vertices = num_conn_vertices;
   D->num_all_vertices = ct.nv;
-  // ---------------------------------------------------------------- attribute seams, :502-535
-  for (uint32_t d = 0; d < nad; ++d) {
-    for (uint32_t c = 0; c < C; ++c) { act[d].edge_seam[c] = 0; act[d].c2v[c] = DSA_INVALID; }
-    for (uint32_t v = 0; v < VMAX; ++v) act[d].vert_seam[v] = 0;
-  }
-  if (nad > 0) {
-    for (uint32_t c = 0; c < C; ++c) {
-      const uint32_t oc = ct.opp[c];
-      if (oc == DSA_INVALID) { for (uint32_t d = 0; d < nad; ++d) act[d].add_seam_edge(c); continue; }
-      if (oc / 3 < c / 3) continue;
-      for (uint32_t d = 0; d < nad; ++d) if (seams[d].next()) act[d].add_seam_edge(c);
-    }
-  }
+  const uint64_t t3 = gclk();
   D->end_pos = r.pos;
+  const uint64_t t4 = gclk();     // diagnostics (tools/dbg_phases.py): header + tables, symbols, start faces + compaction, seams
+  D->dbg[0] = (uint32_t)(t1 - t0); D->dbg[1] = (uint32_t)(t2 - t1); D->dbg[2] = (uint32_t)(t3 - t2); D->dbg[3] = (uint32_t)(t4 - t3);
+  return true;
+}
+
+// Phase 2a (cooperative): attribute seams, MeshEdgeBreakerDecoder.cs:502-535.  One bit per interior edge and attribute
+// data, in corner order (an edge belongs to the lower of its two faces); boundary edges are seams of every attribute
+// data.  Only the rABS recurrences are serial (lane d decodes stream d into a byte per edge); which corner owns the
+// k-th bit is a prefix sum, and marking is idempotent stores.  Scratch: the c2v / v2lm regions of the attribute data
+// blocks, which phase 2b fills afterwards.
+__device__ bool mesh_seams(uint8_t *arena, const MeshLayout &L, MeshDesc *D, MeshCtx &m) {
+  const Ct &ct = m.ct;
+  Act *act = m.act;
+  const uint32_t C = m.C, nad = m.nad, VMAX = m.VMAX, lane = g_lane();
+  if (nad == 0) return true;
+  for (uint32_t d = 0; d < nad; ++d) {
+    for (uint32_t c = lane; c < C; c += G_NL) act[d].edge_seam[c] = 0;
+    for (uint32_t v = lane; v < VMAX; v += G_NL) act[d].vert_seam[v] = 0;
+  }
+  uint32_t *kidx = act[0].v2lm;                            // corner -> index of its bit
+  uint32_t base = 0;
+  for (uint32_t c0 = 0; c0 < C; c0 += G_NL) {
+    const uint32_t c = c0 + lane;
+    bool owns = false;
+    if (c < C) { const uint32_t oc = ct.opp[c]; owns = oc != DSA_INVALID && oc / 3 >= c / 3; }
+    uint32_t total;
+    const uint32_t k = base + g_excl_scan(owns ? 1u : 0u, &total);
+    if (owns) kidx[c] = k;
+    base += total;
+  }
+  const uint32_t num_bits = base;
+  bool bad = false;
+  for (uint32_t d = lane; d < nad; d += G_NL) {
+    Rabs rd;
+    uint32_t endp;
+    rd.start(arena + L.stream, L.stream_len, D->gen_seam_pos[d], &endp);
+    if (!rd.ok) { bad = true; continue; }
+    uint8_t *bits = (uint8_t *)act[d].c2v;
+    for (uint32_t k = 0; k < num_bits; ++k) bits[k] = (uint8_t)rd.next();
+  }
+  if (g_any(bad)) { if (lane == 0) fail(D, ST_INVALID, 260); return false; }
+#if defined(__HIPCC__)
+  __threadfence_block();
+#endif
+  for (uint32_t c = lane; c < C; c += G_NL) {
+    const uint32_t oc = ct.opp[c];
+    if (oc == DSA_INVALID) { for (uint32_t d = 0; d < nad; ++d) act[d].add_seam_edge(c); continue; }
+    if (oc / 3 < c / 3) continue;
+    const uint32_t k = kidx[c];
+    for (uint32_t d = 0; d < nad; ++d) if (((const uint8_t *)act[d].c2v)[k]) act[d].add_seam_edge(c);
+  }
+#if defined(__HIPCC__)
+  __threadfence_block();
+#endif
+  for (uint32_t d = 0; d < nad; ++d)
+    for (uint32_t c = lane; c < C; c += G_NL) act[d].c2v[c] = DSA_INVALID;
   return true;
 }
 
@@ -1149,6 +1201,7 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
 __device__ bool mesh_tables(uint8_t *arena, const MeshLayout &L, MeshDesc *D) {
   MeshCtx m;
   if (!mesh_ctx(arena, L, D, m)) return false;
+  if (!mesh_seams(arena, L, D, m)) return false;
   const Ct &ct = m.ct;
   const uint32_t C = m.C, nad = m.nad, lane = g_lane();
   for (uint32_t d = 0; d < nad; ++d) {
@@ -1269,11 +1322,16 @@ __device__ bool mesh_tables(uint8_t *arena, const MeshLayout &L, MeshDesc *D) {
   return true;
 }
 
-// Phase 3 (one lane): the attribute section -- per decoder the traversal order, point maps, values.
-__device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D, RansScratch rs) {
+// Phase 3: the attribute section -- per decoder the traversal order, point maps, values -- in three stages, so that
+// the element-parallel one has the whole wave: 0 (one lane) traversal orders, 1 (cooperative) point maps, 2 (one lane)
+// values.  Every stage re-reads the few bytes of decoder triples and descriptors.
+enum { ATT_SEQUENCE = 0, ATT_MAPS = 1, ATT_VALUES = 2 };
+__device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D, RansScratch rs, int stage) {
   MeshCtx m;
   if (!mesh_ctx(arena, L, D, m)) return false;
-  Rd r(arena + L.stream, L.stream_len, D->end_pos);
+  if (stage == ATT_SEQUENCE) D->off_attributes = D->end_pos;
+  Rd r(arena + L.stream, L.stream_len, D->off_attributes);
+  const uint32_t lane = stage == ATT_MAPS ? g_lane() : 0, nl = stage == ATT_MAPS ? G_NL : 1;
   const GenLayout &g = m.g;
   uint8_t *G = m.G;
   Ct &ct = m.ct;
@@ -1282,7 +1340,6 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
   const uint32_t F = m.F, C = m.C, VMAX = m.VMAX, nad = m.nad, num_points = D->num_points;
   rs.cum = (uint32_t *)(G + g.cum); rs.cum_cap = g.cum_entries;
   // ---------------------------------------------------------------- attribute section, ConnectivityDecoder.cs:16-44
-  D->off_attributes = r.pos;
   const uint32_t ndec = r.u8();
   GREQ(r.ok && ndec <= DSA_MAX_ATT, 122);
   D->num_decoders = ndec;
@@ -1312,7 +1369,9 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
   uint32_t *dfs = (uint32_t *)(G + g.dfs);
   const uint32_t NVMAX = m.NVMAX;
   struct Shared { uint32_t *d2c, *pids, entries; int32_t *v2d; const uint32_t *map; } shared[2] = {{nullptr, nullptr, 0, nullptr, nullptr}, {nullptr, nullptr, 0, nullptr, nullptr}};
+  uint64_t acc_trav = 0, acc_map = 0, acc_val = 0;
   for (uint32_t i = 0; i < ndec; ++i) {
+    const uint64_t ta = gclk();
     // MeshTraversalSequencer + DepthFirstTraverser on the decoder's corner table
     uint32_t *d2c, *pids;
     int32_t *v2d;
@@ -1332,31 +1391,51 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
     // the entry -> point list are those of the first one, so they are computed once and shared.
     const uint32_t *map_src = nullptr;
     Shared &sh = shared[dec[i].traversal_method];       // one set per traversal method (MeshEdgeBreakerDecoder.cs:681-690)
-    if (!corner_att && sh.d2c) { d2c = sh.d2c; v2d = sh.v2d; pids = sh.pids; entries = sh.entries; map_src = sh.map; }
-    else if (!corner_att) {
-      if (dec[i].traversal_method == 1) {
+    const bool first_of_kind = corner_att || !sh.d2c;
+    if (!first_of_kind) { d2c = sh.d2c; v2d = sh.v2d; pids = sh.pids; entries = sh.entries; map_src = sh.map; }
+    else {
+      if (stage != ATT_SEQUENCE) entries = D->gen_dec_entries[i];
+      else if (corner_att) { if (!traverse(D, act[dd], nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries)) return false; }
+      else if (dec[i].traversal_method == 1) {
         if (!traverse_prediction_degree(D, ct, nverts, c2p, fvis, vvis, (uint32_t *)(G + g.pd_next), (uint32_t *)(G + g.pd_degree), d2c, v2d, pids, cap_entries, &entries)) return false;
       } else if (!traverse(D, ct, nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries)) return false;
-      sh.d2c = d2c; sh.v2d = v2d; sh.pids = pids; sh.entries = entries;
-    } else { if (!traverse(D, act[dd], nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries)) return false; }
+      if (!corner_att) { sh.d2c = d2c; sh.v2d = v2d; sh.pids = pids; sh.entries = entries; }
+    }
     dec[i].num_entries = entries;
-    if (dd < 0) D->num_entries = entries;
-    // point -> entry map of every attribute of the decoder, MeshTraversalSequencer.cs:33-50
+    if (stage == ATT_SEQUENCE) { D->gen_dec_entries[i] = entries; if (dd < 0) D->num_entries = entries; }
+    const uint64_t tb = gclk();
+    // point -> entry map of every attribute of the decoder, MeshTraversalSequencer.cs:33-50.  All corners of a point
+    // carry the same attribute vertex (that is how phase 2 numbered the points), so the stores of different lanes to
+    // one point agree.
     for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) {
       uint32_t *map = (uint32_t *)(arena + L.map[ai]);
-      if (map_src) { for (uint32_t p = 0; p < num_points; ++p) map[p] = map_src[p]; continue; }
-      for (uint32_t p = 0; p < num_points; ++p) map[p] = 0;
-      for (uint32_t c = 0; c < C; ++c) {
-        const uint32_t point = (uint32_t)c2p[c];
-        const uint32_t v = corner_att ? act[dd].vertex(c) : ct.vertex(c);
-        GREQ(v < nverts && point < num_points, 670);
-        const int32_t e = v2d[v];
-        GREQ(e >= 0 && (uint32_t)e < num_points, 671);
-        map[point] = (uint32_t)e;
+      if (stage == ATT_MAPS) {
+        if (map_src) { for (uint32_t p = lane; p < num_points; p += nl) map[p] = map_src[p]; }
+        else {
+          for (uint32_t p = lane; p < num_points; p += nl) map[p] = 0;
+#if defined(__HIPCC__)
+          __threadfence_block();
+#endif
+          for (uint32_t c = lane; c < C; c += nl) {
+            const uint32_t point = (uint32_t)c2p[c];
+            const uint32_t v = corner_att ? act[dd].vertex(c) : ct.vertex(c);
+            GREQ(v < nverts && point < num_points, 670);
+            const int32_t e = v2d[v];
+            GREQ(e >= 0 && (uint32_t)e < num_points, 671);
+            map[point] = (uint32_t)e;
+          }
+#if defined(__HIPCC__)
+          __threadfence_block();
+#endif
+        }
       }
-      map_src = map;                      // further attributes of this decoder share the map
-      if (!corner_att && !sh.map) sh.map = map;
+      if (!map_src) {
+        map_src = map;                    // further attributes of this decoder share the map
+        if (!corner_att && !sh.map) sh.map = map;
+      }
     }
+    const uint64_t tc = gclk();
+    if (stage != ATT_VALUES) { acc_trav += tb - ta; acc_map += tc - tb; continue; }
     // values, then transform parameters, of every attribute of the decoder (SequentialAttributeDecodersController.cs:29-38,
     // AttributesDecoder.cs:65-70)
     ValueCtx vc;
@@ -1369,8 +1448,12 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
     vc.num_verts = nverts; vc.num_corners = C;
     for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) if (!decode_values(arena, L, D, r, ai, entries, rs, vc)) return false;
     for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) if (!decode_transform_params(D, r, ai)) return false;
+    acc_trav += tb - ta; acc_map += tc - tb; acc_val += gclk() - tc;
   }
-  D->end_pos = r.pos;
+  // diagnostics: traversals, point maps, values
+  if (stage == ATT_SEQUENCE) D->dbg[7] = (uint32_t)acc_trav;
+  else if (stage == ATT_MAPS) { if (lane == 0) D->dbg[8] = (uint32_t)acc_map; }
+  else { D->end_pos = r.pos; D->dbg[9] = (uint32_t)acc_val; }
   return true;
 }
 
@@ -1378,7 +1461,8 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
 // The whole mesh in one go (host check; the device runs the three phases as separate kernels so that the second
 // one can use the whole wave).
 __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, RansScratch rs) {
-  return mesh_connectivity(arena, L, D, r, rs) && mesh_tables(arena, L, D) && mesh_attributes(arena, L, D, rs);
+  return mesh_connectivity(arena, L, D, r, rs) && mesh_tables(arena, L, D) && mesh_attributes(arena, L, D, rs, ATT_SEQUENCE) &&
+         mesh_attributes(arena, L, D, rs, ATT_MAPS) && mesh_attributes(arena, L, D, rs, ATT_VALUES);
 }
 
 #undef GFAIL
@@ -1390,7 +1474,7 @@ __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd
 // The general path as three kernels on the third stream, beside the fast kernels (which skip general meshes):
 //   k_general             one lane per mesh: connectivity + seam bits (sequential meshes: the whole decode)
 //   k_general_tables      one wave per mesh, all lanes: attribute corner tables, points per corner
-//   k_general_attributes  one lane per mesh: traversal orders, point maps, attribute values
+//   k_general_attributes  three launches: traversal orders (one lane per mesh), point maps (whole wave), attribute values (one lane)
 __global__ __launch_bounds__(WAVE) void k_general(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   __shared__ uint16_t sh_lut[GEN_LUT_SLOTS];
   __shared__ uint32_t sh_cum[GEN_LUT_SYMS + 1];
@@ -1411,15 +1495,15 @@ __global__ __launch_bounds__(WAVE) void k_general_tables(uint8_t *arena, const M
   if (!D->general || D->encoder_method == 0 || status_of(D) != ST_OK) return;
   (void)gen::mesh_tables(arena, layouts[mesh], D);
 }
-__global__ __launch_bounds__(WAVE) void k_general_attributes(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+__global__ __launch_bounds__(WAVE) void k_general_attributes(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, int stage) {
   __shared__ uint16_t sh_lut[GEN_LUT_SLOTS];
   __shared__ uint32_t sh_cum[GEN_LUT_SYMS + 1];
   const uint32_t mesh = blockIdx.x;
-  if (mesh >= n || threadIdx.x != 0) return;
+  if (mesh >= n || (stage != gen::ATT_MAPS && threadIdx.x != 0)) return;
   MeshDesc *D = &descs[mesh];
   if (!D->general || D->encoder_method == 0 || status_of(D) != ST_OK) return;
   gen::RansScratch rs = {sh_lut, sh_cum, nullptr, 0};
-  (void)gen::mesh_attributes(arena, layouts[mesh], D, rs);
+  (void)gen::mesh_attributes(arena, layouts[mesh], D, rs, stage);
 }
 #endif
 

@@ -74,6 +74,8 @@ struct MeshDesc {
   uint32_t num_entries;    // traversal length
   uint32_t general;        // decoded by k_general (dsa_general.h); the fast kernels skip the mesh
   uint32_t gen_act_nv[DSA_MAX_ATT_DATA];   // general path: vertices of every attribute corner table (phase 2 -> phase 3)
+  uint32_t gen_seam_pos[DSA_MAX_ATT_DATA]; // general path: stream offset of every attribute seam rABS block (phase 1 -> phase 2)
+  uint32_t gen_dec_entries[DSA_MAX_ATT];   // general path: entries of every attributes decoder (phase 3 sequence -> maps -> values)
   uint32_t interior_corners;   // 2 x opposite links made by k_connectivity; one seam bit per link and attribute data
   uint32_t linked_corners;     // corners that hold an opposite, counted by k_point_maps (k_seal compares the two)
   uint32_t dbg[12];        // shader-clock deltas between phases of the per-mesh kernels (diagnostics)
