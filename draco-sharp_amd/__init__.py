@@ -4,6 +4,6 @@ DracoDecoder / Mesh / PointCloud surface.  The decode product lives in csrc/
 host-side mirror used by the tests and bench harness."""
 __version__ = "0.1.0"
 
-from .decoder import (Batch, Context, DataBuffer, DeviceException, Draco, DracoDecoder, DracoHeader,  # noqa: E402,F401
-                      InvalidDataException, Mesh, PointAttribute, PointCloud)
+from .decoder import (Batch, Context, DataBuffer, DeviceException, Draco, DracoDecoder, DracoHeader, DracoMetadata,  # noqa: E402,F401
+                      InvalidDataException, Mesh, MetadataElement, PointAttribute, PointCloud, parse_metadata)
 from .encoder import Config, DracoEncoder, MeshData  # noqa: E402,F401

@@ -8,6 +8,7 @@ using System.Collections.Generic;
 using System.IO;
 using Draco.IO.Attributes;
 using Draco.IO.Enums;
+using Draco.IO.Metadata;
 
 namespace Draco.IO.Gpu;
 
@@ -110,10 +111,51 @@ public sealed unsafe class GpuDracoDecoder : IDisposable
         return new Draco
         {
             Header = new DracoHeader(info.MajorVersion, info.MinorVersion, info.EncoderType, info.EncoderMethod, info.Flags),
-            Metadata = null,   // metadata is parsed by the managed MetadataDecoder when the caller needs it
+            Metadata = (info.Flags & 0x8000) != 0 ? ReadMetadata(batch, mesh) : null,   // DracoDecoder.cs:23-28
             ConnectedData = result,
             Attributes = result.Attributes
         };
+    }
+
+    // The metadata block byte for byte from the native side (it only skips it), parsed into the reference's
+    // DracoMetadata / MetadataElement here.  Layout: Metadata/MetadataDecoder.cs:5-49, with value sizes as varints
+    // (what the bitstream writes; the managed decoder reads a single byte there).
+    private DracoMetadata ReadMetadata(IntPtr batch, uint mesh)
+    {
+        NativeMethods.Check(NativeMethods.dsa_batch_copy_metadata(batch, mesh, null, 0, out nuint length), _ctx, "dsa_batch_copy_metadata");
+        var block = new byte[(int)length];
+        fixed (byte* p = block) NativeMethods.Check(NativeMethods.dsa_batch_copy_metadata(batch, mesh, p, length, out _), _ctx, "dsa_batch_copy_metadata");
+        int pos = 0;
+        byte U8() => pos < block.Length ? block[pos++] : throw new InvalidDataException("metadata block truncated");
+        ulong Varint()
+        {
+            ulong r = 0;
+            for (int shift = 0; shift < 64; shift += 7) { byte b = U8(); r |= (ulong)(b & 0x7F) << shift; if ((b & 0x80) == 0) return r; }
+            throw new InvalidDataException("metadata varint too long");
+        }
+        sbyte[] Take(ulong k)
+        {
+            if (k > (ulong)(block.Length - pos)) throw new InvalidDataException("metadata block truncated");
+            var r = new sbyte[(int)k];
+            Buffer.BlockCopy(block, pos, r, 0, (int)k);
+            pos += (int)k;
+            return r;
+        }
+        MetadataElement Element(int depth)
+        {
+            if (depth > 15) throw new InvalidDataException("metadata nesting too deep");
+            ulong n = Varint();
+            var keys = new List<sbyte[]>(); var values = new List<sbyte[]>();
+            for (ulong i = 0; i < n; ++i) { keys.Add(Take(U8())); values.Add(Take(Varint())); }
+            ulong ns = Varint();
+            var subKeys = new List<sbyte[]>(); var subs = new List<MetadataElement>();
+            for (ulong i = 0; i < ns; ++i) { subKeys.Add(Take(U8())); subs.Add(Element(depth + 1)); }
+            return new MetadataElement { Keys = keys.ToArray(), Values = values.ToArray(), SubMetadataKeys = subKeys.ToArray(), SubMetadata = subs.ToArray() };
+        }
+        var attributes = new List<MetadataElement>();
+        ulong count = Varint();
+        for (ulong i = 0; i < count; ++i) { uint id = (uint)Varint(); var e = Element(0); e.Id = id; attributes.Add(e); }
+        return new DracoMetadata { Attributes = attributes, File = Element(0) };
     }
 
     public void Dispose()

@@ -95,6 +95,7 @@ internal static unsafe partial class NativeMethods
     [DllImport(Lib)] internal static extern IntPtr dsa_batch_device_faces(IntPtr batch, uint mesh);
     [DllImport(Lib)] internal static extern IntPtr dsa_batch_device_attribute_values(IntPtr batch, uint mesh, uint attribute);
     [DllImport(Lib)] internal static extern IntPtr dsa_batch_device_point_map(IntPtr batch, uint mesh, uint attribute);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_copy_metadata(IntPtr batch, uint mesh, byte* dst, nuint dstBytes, out nuint length);
     [DllImport(Lib)] internal static extern DsaStatus dsa_batch_copy_debug(IntPtr batch, uint mesh, int what, void* dst, nuint dstBytes, out nuint written);
     [DllImport(Lib)] internal static extern DsaStatus dsa_context_set_profiling(IntPtr ctx, int enabled);
     [DllImport(Lib)] internal static extern DsaStatus dsa_batch_stage_times(IntPtr batch, float* ms, IntPtr* names);

@@ -511,6 +511,16 @@ const uint32_t *dsa_batch_device_point_map(const dsa_batch *b, uint32_t mesh, ui
   return (const uint32_t *)(b->arena + b->layouts[mesh].map[a]);
 }
 
+dsa_status dsa_batch_copy_metadata(const dsa_batch *b, uint32_t mesh, uint8_t *dst, size_t dst_bytes, size_t *length) {
+  FOLLOW_RETRY(b, mesh, dsa_batch_copy_metadata(rb_, rm_, dst, dst_bytes, length));
+  if (!b || mesh >= b->n || !length) return DSA_ERR_INVALID_ARGUMENT;
+  const HostMesh &h = b->host[mesh];
+  *length = h.meta_len;
+  if (!dst || h.meta_len == 0) return DSA_OK;
+  if (dst_bytes < h.meta_len) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "destination too small");
+  return copy_out(b, dst, b->layouts[mesh].stream + h.meta_off, h.meta_len);
+}
+
 dsa_status dsa_batch_copy_debug(const dsa_batch *b, uint32_t mesh, int what, void *dst, size_t dst_bytes, size_t *written) {
   FOLLOW_RETRY(b, mesh, dsa_batch_copy_debug(rb_, rm_, what, dst, dst_bytes, written));
   CHECK_MESH(b, mesh);

@@ -22,6 +22,7 @@ struct HostMesh {
   int status = 0;   // failure of the sizing parse (the device parse decides the reported status)
   uint32_t faces = 0, enc_vertices = 0, split_symbols = 0, splits = 0, num_att_data = 0;
   bool general = false;   // valence traversal or corner attributes: decoded by k_general
+  uint32_t meta_off = 0, meta_len = 0;   // metadata block of the stream (flag 0x8000), for dsa_batch_copy_metadata
   std::vector<HostAttr> atts;
 };
 
@@ -38,7 +39,7 @@ struct HRd {
 };
 
 static void skip_metadata_element(HRd &r, int depth) {
-  if (depth > 16) { r.ok = false; return; }
+  if (depth > 15) { r.ok = false; return; }             // same nesting limit as k_locate's explicit stack
   uint32_t ne = (uint32_t)r.varint();
   for (uint32_t i = 0; i < ne && r.ok; ++i) { uint32_t ks = r.u8(); r.skip(ks); uint64_t vs = r.varint(); r.skip(vs); }
   uint32_t ns = (uint32_t)r.varint();
@@ -116,10 +117,12 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m, bool want_gene
   uint32_t flags = r.u8(); flags |= r.u8() << 8;
   if (major != 2 || minor != 2) return bad(ST_INVALID);
   if (flags & 0x8000) {
+    const size_t begin = r.pos;
     uint32_t natt = (uint32_t)r.varint();
     for (uint32_t i = 0; i < natt && r.ok; ++i) { (void)r.varint(); skip_metadata_element(r, 0); }
     skip_metadata_element(r, 0);
     if (!r.ok) return bad(ST_INVALID);
+    m.meta_off = (uint32_t)begin; m.meta_len = (uint32_t)(r.pos - begin);
   }
   if (type > 1) return bad(ST_INVALID);
   const bool point_cloud = type == 0;

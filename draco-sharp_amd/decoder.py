@@ -138,6 +138,85 @@ class Mesh(PointCloud):
         return int(self.Faces[corner // 3][corner % 3])
 
 
+class MetadataElement:
+    """src/Draco/IO/Metadata/MetadataElement.cs:3-10: keys and values as byte strings, nested elements by key."""
+    def __init__(self):
+        self.Id = None
+        self.Keys = []
+        self.Values = []
+        self.SubMetadataKeys = []
+        self.SubMetadata = []
+
+    def GetEntry(self, key):
+        key = key.encode() if isinstance(key, str) else bytes(key)
+        for k, v in zip(self.Keys, self.Values):
+            if k == key:
+                return v
+        return None
+
+
+class DracoMetadata:
+    """src/Draco/DracoMetadata.cs:5-9"""
+    def __init__(self, attributes, file):
+        self.Attributes = attributes
+        self.File = file
+
+
+def parse_metadata(block):
+    """The metadata block of a stream (Metadata/MetadataDecoder.cs:5-49; value sizes are varints as the bitstream
+    writes them, where the C# reads one byte) -> DracoMetadata.  Host-side: the decode path only skips the block."""
+    data = bytes(block)
+    pos = 0
+
+    def u8():
+        nonlocal pos
+        if pos >= len(data):
+            raise InvalidDataException("metadata block truncated")
+        pos += 1
+        return data[pos - 1]
+
+    def varint():
+        r, shift = 0, 0
+        while True:
+            b = u8()
+            r |= (b & 0x7F) << shift
+            if not b & 0x80:
+                return r
+            shift += 7
+            if shift > 63:
+                raise InvalidDataException("metadata varint too long")
+
+    def take(k):
+        nonlocal pos
+        if k > len(data) - pos:
+            raise InvalidDataException("metadata block truncated")
+        pos += k
+        return data[pos - k:pos]
+
+    def element(depth):
+        if depth > 15:
+            raise InvalidDataException("metadata nesting too deep")
+        e = MetadataElement()
+        for _ in range(varint()):
+            e.Keys.append(take(u8()))
+            e.Values.append(take(varint()))
+        for _ in range(varint()):
+            e.SubMetadataKeys.append(take(u8()))
+            e.SubMetadata.append(element(depth + 1))
+        return e
+
+    atts = []
+    for _ in range(varint()):
+        att_id = varint()
+        e = element(0)
+        e.Id = att_id
+        atts.append(e)
+    md = DracoMetadata(atts, element(0))
+    if pos != len(data):
+        raise InvalidDataException("metadata block has trailing bytes")
+    return md
+
+
 class Draco:
     def __init__(self, header, connected, metadata=None):
         self.Header = header
@@ -273,9 +352,18 @@ class Batch:
                 if ai.num_entries:
                     L.dsa_batch_copy_portable_values(self._h, i, a, portable.ctypes.data)
             atts.append(PointAttribute(ai, vals, pmap, portable))
+        metadata = None
+        if info.flags & 0x8000:         # DracoDecoder.cs:23-28
+            n = C.c_size_t(0)
+            L.dsa_batch_copy_metadata(self._h, i, None, 0, C.byref(n))
+            buf = (C.c_uint8 * max(1, n.value))()
+            st = L.dsa_batch_copy_metadata(self._h, i, buf, n.value, C.byref(n))
+            if st != 0:
+                _raise(st, self.ctx.error())
+            metadata = parse_metadata(bytes(buf)[:n.value])
         if info.encoder_type == 0:      # EncodedGeometryType.PointCloud (Constants.cs): no faces
-            return Draco(DracoHeader(info), PointCloud(atts, info.num_points))
-        return Draco(DracoHeader(info), Mesh(atts, info.num_points, faces))
+            return Draco(DracoHeader(info), PointCloud(atts, info.num_points), metadata)
+        return Draco(DracoHeader(info), Mesh(atts, info.num_points, faces), metadata)
 
     def close(self):
         if self._h:

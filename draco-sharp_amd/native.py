@@ -17,7 +17,7 @@ EXPORTS = [
     "dsa_batch_size", "dsa_batch_algorithmic_bytes", "dsa_batch_arena_bytes", "dsa_batch_mesh_info",
     "dsa_batch_attribute_info", "dsa_batch_copy_faces", "dsa_batch_copy_attribute_values", "dsa_batch_copy_point_map",
     "dsa_batch_copy_portable_values", "dsa_batch_device_faces", "dsa_batch_device_attribute_values",
-    "dsa_batch_device_point_map", "dsa_batch_copy_debug", "dsa_context_set_profiling", "dsa_batch_stage_times",
+    "dsa_batch_device_point_map", "dsa_batch_copy_metadata", "dsa_batch_copy_debug", "dsa_context_set_profiling", "dsa_batch_stage_times",
     "dsa_encode_default_options", "dsa_encode_batch", "dsa_encoded_size", "dsa_encoded_stream", "dsa_encoded_free",
 ]
 
@@ -97,6 +97,7 @@ def lib():
         for f in ("dsa_batch_device_attribute_values", "dsa_batch_device_point_map"):
             getattr(L, f).restype = vp
             getattr(L, f).argtypes = [vp, u32, u32]
+        L.dsa_batch_copy_metadata.argtypes = [vp, u32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.dsa_batch_copy_debug.argtypes = [vp, u32, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.dsa_context_set_profiling.argtypes = [vp, C.c_int]
         L.dsa_batch_stage_times.argtypes = [vp, C.POINTER(C.c_float * DSA_NUM_STAGES), C.POINTER(C.c_char_p * DSA_NUM_STAGES)]

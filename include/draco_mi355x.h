@@ -130,6 +130,11 @@ const int32_t *dsa_batch_device_faces(const dsa_batch *batch, uint32_t mesh);
 const void *dsa_batch_device_attribute_values(const dsa_batch *batch, uint32_t mesh, uint32_t attribute);
 const uint32_t *dsa_batch_device_point_map(const dsa_batch *batch, uint32_t mesh, uint32_t attribute);
 
+/* The metadata block of a stream (header flag 0x8000; what Metadata/MetadataDecoder.cs:5-49 reads: per-attribute
+ * elements, then the file element), byte for byte.  The decode path skips it structurally; the managed side parses
+ * these bytes into DracoMetadata when the caller asks.  dst may be NULL to query *length (0: no metadata). */
+dsa_status dsa_batch_copy_metadata(const dsa_batch *batch, uint32_t mesh, uint8_t *dst, size_t dst_bytes, size_t *length);
+
 /* Diagnostics for the parity tests: intermediate products of the path.
  * what: 0 opposite[3F], 1 corner_to_vertex[3F], 2 data_to_corner[entries], 3 vertex_to_data[vertices],
  *       4 uint32[12] shader-clock deltas between kernel phases. */

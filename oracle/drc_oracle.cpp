@@ -1731,7 +1731,7 @@ struct AttributeSectionDecoder {
 // Metadata is outside the hot path; skipped structurally.
 // IO/Metadata/MetadataDecoder.cs:5-49
 static void skip_metadata_element(Buffer &b, int depth) {
-  require(depth < 64, "metadata nesting too deep");
+  require(depth < 16, "metadata nesting too deep");   // the device parse keeps an explicit stack of 16 levels
   uint32_t n = (uint32_t)b.varint();
   for (uint32_t i = 0; i < n; ++i) {
     uint8_t ks = b.u8(); b.bytes(ks);

@@ -34,3 +34,37 @@ def decoded_point_keys(mesh, attr_ids=None):
             continue
         cols.append(a.portable[a.point_map] if len(a.point_map) else a.portable)
     return np.concatenate(cols, axis=1)
+
+
+def _varint(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def metadata_element(entries=(), subs=()):
+    """One metadata element as the bitstream writes it (Metadata/MetadataEncoder.cs; value sizes are varints):
+    entries = [(key, value)], subs = [(key, element_bytes)]."""
+    out = bytearray(_varint(len(entries)))
+    for k, v in entries:
+        out += bytes([len(k)]) + k + _varint(len(v)) + v
+    out += _varint(len(subs))
+    for k, e in subs:
+        out += bytes([len(k)]) + k + e
+    return bytes(out)
+
+
+def with_metadata(stream, attribute_elements, file_element):
+    """Inserts a metadata block behind the 11-byte header of a .drc stream and sets header flag 0x8000.
+    attribute_elements = [(attribute unique id, element_bytes)]."""
+    s = bytearray(stream)
+    assert s[:5] == b"DRACO" and not s[10] & 0x80
+    s[10] |= 0x80
+    block = bytearray(_varint(len(attribute_elements)))
+    for att_id, e in attribute_elements:
+        block += _varint(att_id) + e
+    block += file_element
+    return bytes(s[:11]) + bytes(block) + bytes(s[11:]), bytes(block)
