@@ -267,7 +267,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_fork, 0));
     hipLaunchKernelGGL(dsa::k_general, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_general_tables, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
-    for (int stage = 0; stage < 3; ++stage)
+    for (int stage = 0; stage < 4; ++stage)
       hipLaunchKernelGGL(dsa::k_general_attributes, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, stage);
   }
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[0], st2));

@@ -93,8 +93,18 @@ struct Rans {
   const uint8_t *buf;
   const uint32_t *cum;
   const uint16_t *lut;    // nullptr: binary search over cum
+  uint64_t win = 0;       // the eight stream bytes below `off + win_n`, so that a renormalisation byte costs a memory
+  uint32_t win_n = 0;     // round trip only once in eight
   __device__ uint32_t read() {
-    while (state < l_base && off > 0) state = state * 256u + buf[--off];
+    while (state < l_base && off > 0) {
+      if (win_n == 0) {
+        if (off < 8) { state = state * 256u + buf[--off]; continue; }
+        __builtin_memcpy(&win, buf + off - 8, 8);
+        win_n = 8;
+      }
+      --off; --win_n;
+      state = state * 256u + (uint32_t)((win >> (8 * win_n)) & 0xFFu);
+    }
     const uint32_t rem = state & ((1u << pb) - 1u);
     uint32_t lo;
     if (lut) lo = lut[rem];
@@ -147,7 +157,10 @@ __device__ bool rans_create(MeshDesc *D, Rd &r, uint32_t max_bit_length, const R
 }
 
 // Entropy/SymbolDecoding.cs:7-67 (tagged path per the bitstream, D-1)
-__device__ bool decode_symbols(MeshDesc *D, Rd &r, uint32_t num_values, uint32_t nc, uint32_t *out, const RansScratch &rs) {
+// zigzag: store ConvertSymbolToSignedInt(symbol) instead of the symbol (SequentialIntegerAttributeDecoder.cs:86-99),
+// saving the separate pass over the values.
+__device__ __forceinline__ uint32_t unzigzag(uint32_t sv) { return (sv & 1u) ? (uint32_t)(-(int32_t)(sv >> 1) - 1) : (sv >> 1); }
+__device__ bool decode_symbols(MeshDesc *D, Rd &r, uint32_t num_values, uint32_t nc, uint32_t *out, const RansScratch &rs, bool zigzag = false) {
   if (num_values == 0) return true;
   const uint32_t scheme = r.u8();
   GREQ(r.ok && scheme <= 1, 610);
@@ -163,7 +176,8 @@ __device__ bool decode_symbols(MeshDesc *D, Rd &r, uint32_t num_values, uint32_t
       GREQ(len <= 32, 611);
       for (uint32_t j = 0; j < nc; ++j) {
         GREQ(vid < num_values, 612);
-        out[vid++] = len ? read_bits(bits, nbytes, bitpos, len) : 0u;
+        const uint32_t sv = len ? read_bits(bits, nbytes, bitpos, len) : 0u;
+        out[vid++] = zigzag ? unzigzag(sv) : sv;
         bitpos += len;
       }
     }
@@ -173,7 +187,8 @@ __device__ bool decode_symbols(MeshDesc *D, Rd &r, uint32_t num_values, uint32_t
     const uint32_t mbl = r.u8();
     GREQ(r.ok && mbl >= 1 && mbl <= 18, 614);
     if (!rans_create(D, r, mbl, rs, x)) return false;
-    for (uint32_t i = 0; i < num_values; ++i) out[i] = x.read();
+    if (zigzag) for (uint32_t i = 0; i < num_values; ++i) out[i] = unzigzag(x.read());
+    else for (uint32_t i = 0; i < num_values; ++i) out[i] = x.read();
   }
   return true;
 }
@@ -294,20 +309,32 @@ __device__ bool traverse_prediction_degree(MeshDesc *D, const T &t, uint32_t num
   return true;
 }
 
-// MeshPredictionSchemeParallelogramDecoder.cs:29-54,56-89 + wrap transform, in place on corr -> values
+// Parallelogram operands of every entry of a sequence (MeshPredictionSchemeParallelogramDecoder.cs:56-89), element
+// parallel: para[3p..] = entries (next, prev, opposite) of the parallelogram across the entry's corner, next = INVALID
+// when the entry falls back to delta.  Takes the table chase out of the serial prediction chain.
 template <class T>
-__device__ void parallelogram_wrap(const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t entries, uint32_t nc, int32_t *w,
-                                   int32_t mn, int32_t mx, int32_t max_dif) {
-  for (uint32_t c = 0; c < nc; ++c) w[c] = wrap_original(0, w[c], mn, mx, max_dif);
-  for (uint32_t p = 1; p < entries; ++p) {
-    const uint32_t oci = t.opposite(d2c[p]);
-    bool ok = false;
-    int32_t vo = -1, vn = -1, vp = -1;
+__device__ void parallelogram_operands(const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t num_verts, uint32_t entries, uint32_t *para,
+                                       uint32_t lane, uint32_t nl) {
+  for (uint32_t p = lane; p < entries; p += nl) {
+    uint32_t en = DSA_INVALID, ep = 0, eo = 0;
+    const uint32_t oci = p > 0 ? t.opposite(d2c[p]) : DSA_INVALID;
     if (oci != DSA_INVALID) {
       const uint32_t a = t.vertex(oci), b = t.vertex(cnx(oci)), c = t.vertex(cpv(oci));
-      if (a != DSA_INVALID && b != DSA_INVALID && c != DSA_INVALID) { vo = v2d[a]; vn = v2d[b]; vp = v2d[c]; }
-      ok = vo >= 0 && vn >= 0 && vp >= 0 && vo < (int32_t)p && vn < (int32_t)p && vp < (int32_t)p;
+      if (a < num_verts && b < num_verts && c < num_verts) {
+        const int32_t vo = v2d[a], vn = v2d[b], vp = v2d[c];
+        if (vo >= 0 && vn >= 0 && vp >= 0 && vo < (int32_t)p && vn < (int32_t)p && vp < (int32_t)p) { en = (uint32_t)vn; ep = (uint32_t)vp; eo = (uint32_t)vo; }
+      }
     }
+    para[3 * p] = en; para[3 * p + 1] = ep; para[3 * p + 2] = eo;
+  }
+}
+
+// MeshPredictionSchemeParallelogramDecoder.cs:29-54 + wrap transform, in place on corr -> values, on the operands above
+__device__ inline void parallelogram_wrap(const uint32_t *para, uint32_t entries, uint32_t nc, int32_t *w, int32_t mn, int32_t mx, int32_t max_dif) {
+  for (uint32_t c = 0; c < nc; ++c) w[c] = wrap_original(0, w[c], mn, mx, max_dif);
+  for (uint32_t p = 1; p < entries; ++p) {
+    const uint32_t vn = para[3 * p], vp = para[3 * p + 1], vo = para[3 * p + 2];
+    const bool ok = vn != DSA_INVALID;
     for (uint32_t c = 0; c < nc; ++c) {
       const int32_t pred = ok ? (int32_t)((uint32_t)w[vn * nc + c] + (uint32_t)w[vp * nc + c] - (uint32_t)w[vo * nc + c]) : w[(p - 1) * nc + c];
       w[p * nc + c] = wrap_original(pred, w[p * nc + c], mn, mx, max_dif);
@@ -452,13 +479,15 @@ __device__ bool texcoords_portable_wrap(MeshDesc *D, const T &t, const uint32_t 
 
 // MeshPredictionSchemeGeometricNormalDecoder.cs:44-82 + ...GeometricNormalPredictorArea.cs:16-63 +
 // OctahedronToolBox.cs:28-77,121-137 with the bitstream's 64-bit arithmetic (D-9, D-10, D-23..D-25), in place on corr -> values.
-// One flip bit per entry is taken from the rABS block as the entries go by.
+// The flip bits (one per entry, a serial rABS stream) are decoded by the values stage into a byte array; the prediction
+// itself needs only the decoded positions, so it runs afterwards on the whole wave (ATT_NORMALS).
 template <class T>
 __device__ bool geometric_normal_oct(MeshDesc *D, const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t entries, int32_t *w,
                                      const uint32_t *entry_to_point, uint32_t v2d_size, const int32_t *pos, const uint32_t *pos_map,
-                                     uint32_t num_points, uint32_t pos_entries, Rabs &flips, const OctParams &o, bool canonical, uint32_t max_steps) {
+                                     uint32_t num_points, uint32_t pos_entries, const uint8_t *flips, const OctParams &o, bool canonical, uint32_t max_steps,
+                                     uint32_t lane, uint32_t nl) {
   const int32_t max_value = o.max_q - 1;
-  for (uint32_t p = 0; p < entries; ++p) {
+  for (uint32_t p = lane; p < entries; p += nl) {                // entries are independent of each other: element parallel
     const uint32_t ci = d2c[p];
     int64_t center[3] = {0, 0, 0};
     // position of the vertex at a corner: corner -> vertex -> data id -> point -> position entry
@@ -514,7 +543,7 @@ __device__ bool geometric_normal_oct(MeshDesc *D, const T &t, const uint32_t *d2
       const int32_t rest = o.center - (int32_t)abs64(v3[0]) - (int32_t)abs64(v3[1]);
       v3[2] = v3[2] >= 0 ? rest : -rest;
     }
-    if (flips.next()) { v3[0] = -v3[0]; v3[1] = -v3[1]; v3[2] = -v3[2]; }
+    if (flips[p]) { v3[0] = -v3[0]; v3[1] = -v3[1]; v3[2] = -v3[2]; }
     int32_t ps, pt;
     if (v3[0] >= 0) { ps = v3[1] + o.center; pt = v3[2] + o.center; }
     else {
@@ -545,6 +574,7 @@ struct ValueCtx {
   uint8_t *orient;
   uint32_t orient_cap, num_points;
   uint32_t num_verts, num_corners;   // size of v2d; bound on a corner fan
+  const uint32_t *para_ct, *para_act; // parallelogram operands of the sequence on the position / attribute corner table
 };
 
 // Values of attribute ai (SequentialAttributeDecoder.cs:47-52,75-86 / SequentialIntegerAttributeDecoder.cs:23-101):
@@ -581,17 +611,17 @@ __device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, 
   const uint32_t compressed = r.u8();
   GREQ(r.ok, 145);
   a.source = SRC_RAW;
+  const bool positive = a.have_scheme && (tt == 2 || tt == 3);      // D-4: zig-zag unless the transform's corrections are positive
+  const uint64_t t_sym = gclk();
   if (compressed > 0) {
-    if (!decode_symbols(D, r, (uint32_t)num_values, nc, (uint32_t *)w, rs)) return false;
+    if (!decode_symbols(D, r, (uint32_t)num_values, nc, (uint32_t *)w, rs, !positive)) return false;
   } else {                                             // SequentialIntegerAttributeDecoder.cs:68-84 (D-13)
     const uint32_t nb = r.u8();
     GREQ(r.ok && nb >= 1 && nb <= 4, 158);
-    for (uint64_t k = 0; k < num_values; ++k) { uint32_t v = 0; for (uint32_t q = 0; q < nb; ++q) v |= r.u8() << (8 * q); ((uint32_t *)w)[k] = v; }
+    for (uint64_t k = 0; k < num_values; ++k) { uint32_t v = 0; for (uint32_t q = 0; q < nb; ++q) v |= r.u8() << (8 * q); ((uint32_t *)w)[k] = positive ? v : unzigzag(v); }
     GREQ(r.ok, 160);
   }
-  const bool positive = a.have_scheme && (tt == 2 || tt == 3);      // D-4
-  if (num_values > 0 && !positive)
-    for (uint64_t k = 0; k < num_values; ++k) { const uint32_t sv = ((uint32_t *)w)[k]; w[k] = (sv & 1u) ? -(int32_t)(sv >> 1) - 1 : (int32_t)(sv >> 1); }
+  D->dbg[10] += (uint32_t)((gclk() - t_sym) >> 4);     // diagnostics: entropy decode of all attributes, in units of 16 clocks
   if (!a.have_scheme) return true;
   // scheme selection, PredictionSchemeDecoderFactory.cs:9-76
   int eff = method;
@@ -643,8 +673,7 @@ __device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, 
       for (uint32_t c = 0; c < nc; ++c) w[c] = wrap_original(0, w[c], mn, mx, max_dif);
       for (uint64_t k = nc; k < num_values; ++k) w[k] = wrap_original(w[k - nc], w[k], mn, mx, max_dif);
     } else if (eff == 1) {
-      if (vc.act) parallelogram_wrap(*vc.act, vc.d2c, vc.v2d, entries, nc, w, mn, mx, max_dif);
-      else parallelogram_wrap(*vc.ct, vc.d2c, vc.v2d, entries, nc, w, mn, mx, max_dif);
+      parallelogram_wrap(vc.act ? vc.para_act : vc.para_ct, entries, nc, w, mn, mx, max_dif);
     } else if (eff == 2 || eff == 4) {
       if (vc.act) return multi_parallelogram_wrap(D, *vc.act, vc.d2c, vc.v2d, entries, nc, w, mn, mx, max_dif, eff == 4, crease, crease_left, vc.num_corners + 1);
       return multi_parallelogram_wrap(D, *vc.ct, vc.d2c, vc.v2d, entries, nc, w, mn, mx, max_dif, eff == 4, crease, crease_left, vc.num_corners + 1);
@@ -681,10 +710,10 @@ __device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, 
       int pa = -1;                                     // parent = portable positions, SequentialAttributeDecoder.cs:58-73
       for (uint32_t k = 0; k < ai; ++k) if (D->att[k].att_type == 0 && D->att[k].seq_type != 0) { pa = (int)k; break; }
       GREQ(pa >= 0 && D->att[pa].nc_portable == 3, 656);
-      const int32_t *pos = (const int32_t *)(arena + L.work[pa]);
-      const uint32_t *pos_map = (const uint32_t *)(arena + L.map[pa]);
-      if (vc.act) return geometric_normal_oct(D, *vc.act, vc.d2c, vc.v2d, entries, w, vc.pids, vc.num_verts, pos, pos_map, vc.num_points, D->att[pa].num_entries, rd, o, tt == 3, vc.num_corners + 1);
-      return geometric_normal_oct(D, *vc.ct, vc.d2c, vc.v2d, entries, w, vc.pids, vc.num_verts, pos, pos_map, vc.num_points, D->att[pa].num_entries, rd, o, tt == 3, vc.num_corners + 1);
+      GREQ(entries <= L.out_cap[ai], 657);             // the flip bits wait in the attribute's output region (written last, by k_finalize)
+      uint8_t *flips = arena + L.out[ai];
+      for (uint32_t p = 0; p < entries; ++p) flips[p] = (uint8_t)rd.next();
+      return true;                                     // corrections stay in w; normals_stage() finishes the attribute
     }
     if (num_values == 0) return true;
     int32_t ps = 0, pt = 0;
@@ -694,6 +723,29 @@ __device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, 
       w[2 * e] = os; w[2 * e + 1] = ot;
       ps = os; pt = ot;
     }
+  }
+  return true;
+}
+
+// ATT_NORMALS: the GeometricNormal attributes of one decoder, on the whole wave.
+__device__ bool normals_stage(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t first_att, uint32_t num_atts, uint32_t entries,
+                              const ValueCtx &vc, uint32_t lane, uint32_t nl) {
+  for (uint32_t ai = first_att; ai < first_att + num_atts; ++ai) {
+    const AttrDesc &a = D->att[ai];
+    if (a.seq_type != 3 || !a.have_scheme || a.pred_kind != 6 || entries == 0) continue;
+    int pa = -1;
+    for (uint32_t k = 0; k < ai; ++k) if (D->att[k].att_type == 0 && D->att[k].seq_type != 0) { pa = (int)k; break; }
+    GREQ(pa >= 0 && D->att[pa].nc_portable == 3, 656);
+    OctParams o;
+    const int q = 32 - __builtin_clz((uint32_t)a.oct_max_q);
+    o.max_q = (1 << q) - 1; o.center = ((1 << q) - 2) / 2;
+    int32_t *w = (int32_t *)(arena + L.work[ai]);
+    const int32_t *pos = (const int32_t *)(arena + L.work[pa]);
+    const uint32_t *pos_map = (const uint32_t *)(arena + L.map[pa]);
+    const bool canonical = a.pred_transform == 3;
+    const bool ok = vc.act ? geometric_normal_oct(D, *vc.act, vc.d2c, vc.v2d, entries, w, vc.pids, vc.num_verts, pos, pos_map, vc.num_points, D->att[pa].num_entries, arena + L.out[ai], o, canonical, vc.num_corners + 1, lane, nl)
+                           : geometric_normal_oct(D, *vc.ct, vc.d2c, vc.v2d, entries, w, vc.pids, vc.num_verts, pos, pos_map, vc.num_points, D->att[pa].num_entries, arena + L.out[ai], o, canonical, vc.num_corners + 1, lane, nl);
+    if (!ok) return false;
   }
   return true;
 }
@@ -780,7 +832,7 @@ __device__ bool decode_sequential_mesh(uint8_t *arena, const MeshLayout &L, Mesh
   uint32_t natt = 0, first[DSA_MAX_ATT], count[DSA_MAX_ATT];
   for (uint32_t i = 0; i < ndec; ++i) if (!decode_descriptors(L, D, r, i, natt, &first[i], &count[i])) return false;
   D->num_attributes = natt;
-  ValueCtx vc = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, NP, 0, 0};
+  ValueCtx vc = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, NP, 0, 0, nullptr, nullptr};
   for (uint32_t i = 0; i < ndec; ++i) {
     for (uint32_t ai = first[i]; ai < first[i] + count[i]; ++ai) {
       uint32_t *map = (uint32_t *)(arena + L.map[ai]);
@@ -1325,13 +1377,14 @@ __device__ bool mesh_tables(uint8_t *arena, const MeshLayout &L, MeshDesc *D) {
 // Phase 3: the attribute section -- per decoder the traversal order, point maps, values -- in three stages, so that
 // the element-parallel one has the whole wave: 0 (one lane) traversal orders, 1 (cooperative) point maps, 2 (one lane)
 // values.  Every stage re-reads the few bytes of decoder triples and descriptors.
-enum { ATT_SEQUENCE = 0, ATT_MAPS = 1, ATT_VALUES = 2 };
+enum { ATT_SEQUENCE = 0, ATT_MAPS = 1, ATT_VALUES = 2, ATT_NORMALS = 3 };
 __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D, RansScratch rs, int stage) {
   MeshCtx m;
   if (!mesh_ctx(arena, L, D, m)) return false;
   if (stage == ATT_SEQUENCE) D->off_attributes = D->end_pos;
   Rd r(arena + L.stream, L.stream_len, D->off_attributes);
-  const uint32_t lane = stage == ATT_MAPS ? g_lane() : 0, nl = stage == ATT_MAPS ? G_NL : 1;
+  const bool cooperative = stage == ATT_MAPS || stage == ATT_NORMALS;
+  const uint32_t lane = cooperative ? g_lane() : 0, nl = cooperative ? G_NL : 1;
   const GenLayout &g = m.g;
   uint8_t *G = m.G;
   Ct &ct = m.ct;
@@ -1377,14 +1430,18 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
     int32_t *v2d;
     uint32_t cap_entries, nverts;
     const int dd = dec[i].att_data_id;
+    uint32_t *para;                                       // operands on the table the decoder's prediction schemes use
     if (dd < 0) {
-      d2c = (uint32_t *)(arena + L.d2c); v2d = (int32_t *)(arena + L.v2d); pids = (uint32_t *)(arena + L.para);
+      d2c = (uint32_t *)(arena + L.d2c); v2d = (int32_t *)(arena + L.v2d); pids = (uint32_t *)(arena + L.vrank);
+      para = (uint32_t *)(arena + L.para);
       cap_entries = VMAX; nverts = ct.nv;
     } else {
       uint8_t *blk = G + g.data + (uint64_t)dd * g.data_stride;
       d2c = (uint32_t *)(blk + g.d2c); v2d = (int32_t *)(blk + g.v2d); pids = (uint32_t *)(blk + g.pids);
+      para = (uint32_t *)(blk + g.para);
       cap_entries = NVMAX; nverts = act[dd].nv > ct.nv ? act[dd].nv : ct.nv;
     }
+    const bool use_act = dd >= 0 && data_conn_used[dd];
     uint32_t entries = 0;
     const bool corner_att = dec[i].element_type != 0;
     // Every vertex-type decoder traverses the position corner table from the same start: the order, the maps and
@@ -1434,18 +1491,24 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
         if (!corner_att && !sh.map) sh.map = map;
       }
     }
+    if (stage == ATT_MAPS) {
+      if (use_act) parallelogram_operands(act[dd], d2c, v2d, nverts, entries, para, lane, nl);
+      else parallelogram_operands(ct, d2c, v2d, nverts, entries, para, lane, nl);
+    }
     const uint64_t tc = gclk();
-    if (stage != ATT_VALUES) { acc_trav += tb - ta; acc_map += tc - tb; continue; }
+    if (stage == ATT_SEQUENCE || stage == ATT_MAPS) { acc_trav += tb - ta; acc_map += tc - tb; continue; }
     // values, then transform parameters, of every attribute of the decoder (SequentialAttributeDecodersController.cs:29-38,
     // AttributesDecoder.cs:65-70)
     ValueCtx vc;
-    vc.ct = &ct; vc.act = (dd >= 0 && data_conn_used[dd]) ? &act[dd] : nullptr;
+    vc.ct = &ct; vc.act = use_act ? &act[dd] : nullptr;
+    vc.para_ct = use_act ? nullptr : para; vc.para_act = use_act ? para : nullptr;
     vc.d2c = d2c; vc.v2d = v2d; vc.pids = pids;
     // orientation scratch: the attribute data block's, or (attributes of the position decoder) the Edgebreaker
     // machine's corner stack, which is free by now
     vc.orient = dd >= 0 ? G + g.data + (uint64_t)dd * g.data_stride + g.orient : G + g.stack;
     vc.orient_cap = dd >= 0 ? NVMAX : 4 * F; vc.num_points = num_points;
     vc.num_verts = nverts; vc.num_corners = C;
+    if (stage == ATT_NORMALS) { if (!normals_stage(arena, L, D, dec[i].first_att, dec[i].num_atts, entries, vc, lane, nl)) return false; continue; }
     for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) if (!decode_values(arena, L, D, r, ai, entries, rs, vc)) return false;
     for (uint32_t ai = dec[i].first_att; ai < dec[i].first_att + dec[i].num_atts; ++ai) if (!decode_transform_params(D, r, ai)) return false;
     acc_trav += tb - ta; acc_map += tc - tb; acc_val += gclk() - tc;
@@ -1453,7 +1516,7 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
   // diagnostics: traversals, point maps, values
   if (stage == ATT_SEQUENCE) D->dbg[7] = (uint32_t)acc_trav;
   else if (stage == ATT_MAPS) { if (lane == 0) D->dbg[8] = (uint32_t)acc_map; }
-  else { D->end_pos = r.pos; D->dbg[9] = (uint32_t)acc_val; }
+  else if (stage == ATT_VALUES) { D->end_pos = r.pos; D->dbg[9] = (uint32_t)acc_val; }
   return true;
 }
 
@@ -1462,7 +1525,7 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
 // one can use the whole wave).
 __device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, RansScratch rs) {
   return mesh_connectivity(arena, L, D, r, rs) && mesh_tables(arena, L, D) && mesh_attributes(arena, L, D, rs, ATT_SEQUENCE) &&
-         mesh_attributes(arena, L, D, rs, ATT_MAPS) && mesh_attributes(arena, L, D, rs, ATT_VALUES);
+         mesh_attributes(arena, L, D, rs, ATT_MAPS) && mesh_attributes(arena, L, D, rs, ATT_VALUES) && mesh_attributes(arena, L, D, rs, ATT_NORMALS);
 }
 
 #undef GFAIL
@@ -1499,7 +1562,7 @@ __global__ __launch_bounds__(WAVE) void k_general_attributes(uint8_t *arena, con
   __shared__ uint16_t sh_lut[GEN_LUT_SLOTS];
   __shared__ uint32_t sh_cum[GEN_LUT_SYMS + 1];
   const uint32_t mesh = blockIdx.x;
-  if (mesh >= n || (stage != gen::ATT_MAPS && threadIdx.x != 0)) return;
+  if (mesh >= n || (stage != gen::ATT_MAPS && stage != gen::ATT_NORMALS && threadIdx.x != 0)) return;
   MeshDesc *D = &descs[mesh];
   if (!D->general || D->encoder_method == 0 || status_of(D) != ST_OK) return;
   gen::RansScratch rs = {sh_lut, sh_cum, nullptr, 0};

@@ -107,7 +107,8 @@ struct GenLayout {
   uint64_t d2c;        // u32[NVmax]  entry -> corner
   uint64_t v2d;        // i32[NVmax]  attribute vertex -> entry
   uint64_t pids;       // u32[NVmax]  entry -> point
-  uint64_t orient;     // u8[NVmax]   TexCoordsPortable orientations
+  uint64_t orient;     // u8[NVmax]   TexCoordsPortable orientations / GeometricNormal flip bits
+  uint64_t para;       // u32[3 NVmax] parallelogram operands of every entry (next, prev, opposite entry; next = INVALID: delta)
   uint64_t total;
 };
 #if defined(__HIPCC__)
@@ -138,6 +139,7 @@ inline GenLayout gen_layout(uint64_t F, uint64_t V, uint64_t S, uint64_t A, uint
   g.v2d = take(4 * NV);
   g.pids = take(4 * NV);
   g.orient = take(NV);
+  g.para = take(12 * NV);
   g.data_stride = cur;
   g.total = g.data + A * g.data_stride;
   return g;
