@@ -57,16 +57,16 @@ struct Rd {
   const uint8_t *p;
   uint32_t n, pos;
   bool ok;
-  __device__ Rd(const uint8_t *d, uint32_t len, uint32_t at) : p(d), n(len), pos(at), ok(at <= len) {}
-  __device__ uint32_t u8() {
+  __device__ __forceinline__ Rd(const uint8_t *d, uint32_t len, uint32_t at) : p(d), n(len), pos(at), ok(at <= len) {}
+  __device__ __forceinline__ uint32_t u8() {
     if (pos < n) return p[pos++];
     ok = false;
     return 0;
   }
-  __device__ uint32_t u16() { uint32_t a = u8(); return a | (u8() << 8); }
-  __device__ uint32_t u32() { uint32_t a = u8(); a |= u8() << 8; a |= u8() << 16; return a | (u8() << 24); }
-  __device__ float f32() { return __uint_as_float(u32()); }
-  __device__ uint64_t varint() {
+  __device__ __forceinline__ uint32_t u16() { uint32_t a = u8(); return a | (u8() << 8); }
+  __device__ __forceinline__ uint32_t u32() { uint32_t a = u8(); a |= u8() << 8; a |= u8() << 16; return a | (u8() << 24); }
+  __device__ __forceinline__ float f32() { return __uint_as_float(u32()); }
+  __device__ __forceinline__ uint64_t varint() {
     uint64_t r = 0;
     for (int shift = 0; shift < 64; shift += 7) {
       uint32_t b = u8();
@@ -76,7 +76,7 @@ struct Rd {
     ok = false;
     return r;
   }
-  __device__ void skip(uint64_t k) {
+  __device__ __forceinline__ void skip(uint64_t k) {
     if (!ok || k > (uint64_t)(n - pos)) { ok = false; pos = n; }
     else pos += (uint32_t)k;
   }
@@ -101,7 +101,7 @@ struct Rabs {
   const uint8_t *buf;
   uint32_t off, state, p;   // p = 256 - prob_zero
   bool ok;
-  __device__ void start(const uint8_t *s, uint32_t slen, uint32_t at, uint32_t *end_pos) {
+  __device__ __forceinline__ void start(const uint8_t *s, uint32_t slen, uint32_t at, uint32_t *end_pos) {
     Rd r(s, slen, at);
     uint32_t prob_zero = r.u8();
     uint64_t size = r.varint();
@@ -122,7 +122,7 @@ struct Rabs {
     state += 4096;
     if (state >= 4096u * 256u) ok = false;
   }
-  __device__ uint32_t next() {
+  __device__ __forceinline__ uint32_t next() {
     if (state < 4096 && off > 0) state = state * 256 + buf[--off];
     uint32_t x = state, quot = x >> 8, rem = x & 255, xn = quot * p;
     bool val = rem < p;

@@ -34,16 +34,16 @@ __device__ __forceinline__ uint32_t cpv(uint32_t c) { return c == DSA_INVALID ? 
 struct Ct {
   uint32_t *opp, *c2v, *vcorner;
   uint32_t F, C, nv, vmax;
-  __device__ uint32_t opposite(uint32_t c) const { return c < C ? opp[c] : DSA_INVALID; }
-  __device__ uint32_t vertex(uint32_t c) const { return c < C ? c2v[c] : DSA_INVALID; }
-  __device__ uint32_t left_most(uint32_t v) const { return v < nv ? vcorner[v] : DSA_INVALID; }
-  __device__ uint32_t swing_right(uint32_t c) const { return cpv(opposite(cpv(c))); }
-  __device__ uint32_t swing_left(uint32_t c) const { return cnx(opposite(cnx(c))); }
-  __device__ uint32_t right_corner(uint32_t c) const { return opposite(cnx(c)); }
-  __device__ uint32_t left_corner(uint32_t c) const { return opposite(cpv(c)); }
-  __device__ bool is_on_boundary(uint32_t v) const { return swing_left(left_most(v)) == DSA_INVALID; }
-  __device__ uint32_t num_faces() const { return F; }
-  __device__ void set_opp(uint32_t a, uint32_t b) { if (a < C) opp[a] = b; if (b < C) opp[b] = a; }
+  __device__ __forceinline__ uint32_t opposite(uint32_t c) const { return c < C ? opp[c] : DSA_INVALID; }
+  __device__ __forceinline__ uint32_t vertex(uint32_t c) const { return c < C ? c2v[c] : DSA_INVALID; }
+  __device__ __forceinline__ uint32_t left_most(uint32_t v) const { return v < nv ? vcorner[v] : DSA_INVALID; }
+  __device__ __forceinline__ uint32_t swing_right(uint32_t c) const { return cpv(opposite(cpv(c))); }
+  __device__ __forceinline__ uint32_t swing_left(uint32_t c) const { return cnx(opposite(cnx(c))); }
+  __device__ __forceinline__ uint32_t right_corner(uint32_t c) const { return opposite(cnx(c)); }
+  __device__ __forceinline__ uint32_t left_corner(uint32_t c) const { return opposite(cpv(c)); }
+  __device__ __forceinline__ bool is_on_boundary(uint32_t v) const { return swing_left(left_most(v)) == DSA_INVALID; }
+  __device__ __forceinline__ uint32_t num_faces() const { return F; }
+  __device__ __forceinline__ void set_opp(uint32_t a, uint32_t b) { if (a < C) opp[a] = b; if (b < C) opp[b] = a; }
 };
 
 // Mesh/MeshAttributeCornerTable.cs:19-30 (ctor), :80-93 (AddSeamEdge), :95-155 (RecomputeVertices), :157-215
@@ -52,16 +52,16 @@ struct Act {
   uint8_t *edge_seam, *vert_seam;
   uint32_t *c2v, *v2lm;
   uint32_t nv;
-  __device__ uint32_t opposite(uint32_t c) const { return (c >= ct->C || edge_seam[c]) ? DSA_INVALID : ct->opp[c]; }
-  __device__ uint32_t vertex(uint32_t c) const { return c < ct->C ? c2v[c] : DSA_INVALID; }
-  __device__ uint32_t left_most(uint32_t v) const { return v < nv ? v2lm[v] : DSA_INVALID; }
-  __device__ uint32_t swing_right(uint32_t c) const { return cpv(opposite(cpv(c))); }
-  __device__ uint32_t swing_left(uint32_t c) const { return cnx(opposite(cnx(c))); }
-  __device__ uint32_t right_corner(uint32_t c) const { return opposite(cnx(c)); }
-  __device__ uint32_t left_corner(uint32_t c) const { return opposite(cpv(c)); }
-  __device__ bool is_on_boundary(uint32_t v) const { uint32_t c = left_most(v); return c == DSA_INVALID || swing_left(c) == DSA_INVALID; }
-  __device__ uint32_t num_faces() const { return ct->F; }
-  __device__ void add_seam_edge(uint32_t c) {
+  __device__ __forceinline__ uint32_t opposite(uint32_t c) const { return (c >= ct->C || edge_seam[c]) ? DSA_INVALID : ct->opp[c]; }
+  __device__ __forceinline__ uint32_t vertex(uint32_t c) const { return c < ct->C ? c2v[c] : DSA_INVALID; }
+  __device__ __forceinline__ uint32_t left_most(uint32_t v) const { return v < nv ? v2lm[v] : DSA_INVALID; }
+  __device__ __forceinline__ uint32_t swing_right(uint32_t c) const { return cpv(opposite(cpv(c))); }
+  __device__ __forceinline__ uint32_t swing_left(uint32_t c) const { return cnx(opposite(cnx(c))); }
+  __device__ __forceinline__ uint32_t right_corner(uint32_t c) const { return opposite(cnx(c)); }
+  __device__ __forceinline__ uint32_t left_corner(uint32_t c) const { return opposite(cpv(c)); }
+  __device__ __forceinline__ bool is_on_boundary(uint32_t v) const { uint32_t c = left_most(v); return c == DSA_INVALID || swing_left(c) == DSA_INVALID; }
+  __device__ __forceinline__ uint32_t num_faces() const { return ct->F; }
+  __device__ __forceinline__ void add_seam_edge(uint32_t c) {
     edge_seam[c] = 1;
     uint32_t a = ct->vertex(cnx(c)), b = ct->vertex(cpv(c));
     if (a < ct->vmax) vert_seam[a] = 1;
@@ -95,7 +95,7 @@ struct Rans {
   const uint16_t *lut;    // nullptr: binary search over cum
   uint64_t win = 0;       // the eight stream bytes below `off + win_n`, so that a renormalisation byte costs a memory
   uint32_t win_n = 0;     // round trip only once in eight
-  __device__ uint32_t read() {
+  __device__ __forceinline__ uint32_t read() {
     while (state < l_base && off > 0) {
       if (win_n == 0) {
         if (off < 8) { state = state * 256u + buf[--off]; continue; }
@@ -118,7 +118,7 @@ struct Rans {
   }
 };
 
-__device__ bool rans_create(MeshDesc *D, Rd &r, uint32_t max_bit_length, const RansScratch &rs, Rans &x) {
+__device__ __forceinline__ bool rans_create(MeshDesc *D, Rd &r, uint32_t max_bit_length, const RansScratch &rs, Rans &x) {
   uint32_t *cum = rs.cum;
   const uint64_t cum_cap = rs.cum_cap;
   x.pb = rans_precision_bits(max_bit_length);
@@ -160,7 +160,7 @@ __device__ bool rans_create(MeshDesc *D, Rd &r, uint32_t max_bit_length, const R
 // zigzag: store ConvertSymbolToSignedInt(symbol) instead of the symbol (SequentialIntegerAttributeDecoder.cs:86-99),
 // saving the separate pass over the values.
 __device__ __forceinline__ uint32_t unzigzag(uint32_t sv) { return (sv & 1u) ? (uint32_t)(-(int32_t)(sv >> 1) - 1) : (sv >> 1); }
-__device__ bool decode_symbols(MeshDesc *D, Rd &r, uint32_t num_values, uint32_t nc, uint32_t *out, const RansScratch &rs, bool zigzag = false) {
+__device__ __forceinline__ bool decode_symbols(MeshDesc *D, Rd &r, uint32_t num_values, uint32_t nc, uint32_t *out, const RansScratch &rs, bool zigzag = false) {
   if (num_values == 0) return true;
   const uint32_t scheme = r.u8();
   GREQ(r.ok && scheme <= 1, 610);
@@ -196,7 +196,7 @@ __device__ bool decode_symbols(MeshDesc *D, Rd &r, uint32_t num_values, uint32_t
 // Traverser/DepthFirstTraverser.cs:9-99 + MeshAttributeIndicesEncodingObserver.cs:14-21 +
 // MeshTraversalSequencer.cs:13-31 on either corner table.
 template <class T>
-__device__ bool traverse(MeshDesc *D, const T &t, uint32_t num_verts, const int32_t *c2p, uint8_t *fvis, uint8_t *vvis, uint32_t *stack,
+__device__ __forceinline__ bool traverse(MeshDesc *D, const T &t, uint32_t num_verts, const int32_t *c2p, uint8_t *fvis, uint8_t *vvis, uint32_t *stack,
                          uint32_t stack_cap, uint32_t *d2c, int32_t *v2d, uint32_t *pids, uint32_t cap_entries, uint32_t *num_entries) {
   const uint32_t F = t.num_faces();
   for (uint32_t f = 0; f < F; ++f) fvis[f] = 0;
@@ -251,7 +251,7 @@ __device__ bool traverse(MeshDesc *D, const T &t, uint32_t num_verts, const int3
 // sequencer.  The three priority stacks are linked lists threaded through one u32 per corner: an edge into a face is
 // pushed at most once in a consistent table (only the face on its other side pushes it), and a second push is refused.
 template <class T>
-__device__ bool traverse_prediction_degree(MeshDesc *D, const T &t, uint32_t num_verts, const int32_t *c2p, uint8_t *fvis, uint8_t *vvis,
+__device__ __forceinline__ bool traverse_prediction_degree(MeshDesc *D, const T &t, uint32_t num_verts, const int32_t *c2p, uint8_t *fvis, uint8_t *vvis,
                                            uint32_t *next, uint32_t *degree, uint32_t *d2c, int32_t *v2d, uint32_t *pids,
                                            uint32_t cap_entries, uint32_t *num_entries) {
   const uint32_t F = t.num_faces(), NEVER = 0xFFFFFFFEu, END = 0xFFFFFFFDu, USED = 0xFFFFFFFCu;
@@ -313,7 +313,7 @@ __device__ bool traverse_prediction_degree(MeshDesc *D, const T &t, uint32_t num
 // parallel: para[3p..] = entries (next, prev, opposite) of the parallelogram across the entry's corner, next = INVALID
 // when the entry falls back to delta.  Takes the table chase out of the serial prediction chain.
 template <class T>
-__device__ void parallelogram_operands(const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t num_verts, uint32_t entries, uint32_t *para,
+__device__ __forceinline__ void parallelogram_operands(const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t num_verts, uint32_t entries, uint32_t *para,
                                        uint32_t lane, uint32_t nl) {
   for (uint32_t p = lane; p < entries; p += nl) {
     uint32_t en = DSA_INVALID, ep = 0, eo = 0;
@@ -330,7 +330,7 @@ __device__ void parallelogram_operands(const T &t, const uint32_t *d2c, const in
 }
 
 // MeshPredictionSchemeParallelogramDecoder.cs:29-54 + wrap transform, in place on corr -> values, on the operands above
-__device__ inline void parallelogram_wrap(const uint32_t *para, uint32_t entries, uint32_t nc, int32_t *w, int32_t mn, int32_t mx, int32_t max_dif) {
+__device__ __forceinline__ void parallelogram_wrap(const uint32_t *para, uint32_t entries, uint32_t nc, int32_t *w, int32_t mn, int32_t mx, int32_t max_dif) {
   for (uint32_t c = 0; c < nc; ++c) w[c] = wrap_original(0, w[c], mn, mx, max_dif);
   for (uint32_t p = 1; p < entries; ++p) {
     const uint32_t vn = para[3 * p], vp = para[3 * p + 1], vo = para[3 * p + 2];
@@ -344,7 +344,7 @@ __device__ inline void parallelogram_wrap(const uint32_t *para, uint32_t entries
 
 // MeshPredictionSchemeParallelogramDecoder.cs:56-89 (TryComputeParallelogramPrediction)
 template <class T>
-__device__ inline bool parallelogram_prediction(const T &t, const int32_t *v2d, uint32_t p, uint32_t ci, const int32_t *w, uint32_t nc, int32_t *pred) {
+__device__ __forceinline__ bool parallelogram_prediction(const T &t, const int32_t *v2d, uint32_t p, uint32_t ci, const int32_t *w, uint32_t nc, int32_t *pred) {
   const uint32_t oci = t.opposite(ci);
   if (oci == DSA_INVALID) return false;
   const uint32_t a = t.vertex(oci), b = t.vertex(cnx(oci)), c = t.vertex(cpv(oci));
@@ -360,7 +360,7 @@ __device__ inline bool parallelogram_prediction(const T &t, const int32_t *v2d, 
 // constrained: up to four parallelograms, left swing first, each kept or dropped by the next crease flag of the
 // context (= parallelograms found - 1); the four flag streams are read as the entries go by.
 template <class T>
-__device__ bool multi_parallelogram_wrap(MeshDesc *D, const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t entries, uint32_t nc, int32_t *w,
+__device__ __forceinline__ bool multi_parallelogram_wrap(MeshDesc *D, const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t entries, uint32_t nc, int32_t *w,
                                          int32_t mn, int32_t mx, int32_t max_dif, bool constrained, Rabs *crease, uint32_t *crease_left, uint32_t max_steps) {
   if (nc > 4) GNOTIMPL(660);                          // wider integer attributes: not on the device yet
   int32_t cand[4][4], sum[4];
@@ -401,7 +401,7 @@ __device__ bool multi_parallelogram_wrap(MeshDesc *D, const T &t, const uint32_t
   return true;
 }
 
-__device__ inline uint64_t int_sqrt(uint64_t number) {   // Core/MathUtilities.cs:5-25
+__device__ __forceinline__ uint64_t int_sqrt(uint64_t number) {   // Core/MathUtilities.cs:5-25
   if (number == 0) return 0;
   uint64_t act = number, root = 1;
   while (act >= 2) { root *= 2; act /= 4; }
@@ -411,7 +411,7 @@ __device__ inline uint64_t int_sqrt(uint64_t number) {   // Core/MathUtilities.c
 
 // MeshPredictionSchemeTexCoordsPortableDecoder.cs:50-85 + ...PortablePredictor.cs:46-150, in place
 template <class T>
-__device__ bool texcoords_portable_wrap(MeshDesc *D, const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t entries, int32_t *w,
+__device__ __forceinline__ bool texcoords_portable_wrap(MeshDesc *D, const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t entries, int32_t *w,
                                         const uint32_t *entry_to_point, const int32_t *pos, const uint32_t *pos_map, uint32_t num_points,
                                         uint32_t pos_entries, const uint8_t *orient, uint32_t num_orient, int32_t mn, int32_t mx, int32_t max_dif) {
   uint32_t left = num_orient;
@@ -482,7 +482,7 @@ __device__ bool texcoords_portable_wrap(MeshDesc *D, const T &t, const uint32_t 
 // The flip bits (one per entry, a serial rABS stream) are decoded by the values stage into a byte array; the prediction
 // itself needs only the decoded positions, so it runs afterwards on the whole wave (ATT_NORMALS).
 template <class T>
-__device__ bool geometric_normal_oct(MeshDesc *D, const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t entries, int32_t *w,
+__device__ __forceinline__ bool geometric_normal_oct(MeshDesc *D, const T &t, const uint32_t *d2c, const int32_t *v2d, uint32_t entries, int32_t *w,
                                      const uint32_t *entry_to_point, uint32_t v2d_size, const int32_t *pos, const uint32_t *pos_map,
                                      uint32_t num_points, uint32_t pos_entries, const uint8_t *flips, const OctParams &o, bool canonical, uint32_t max_steps,
                                      uint32_t lane, uint32_t nl) {
@@ -579,7 +579,7 @@ struct ValueCtx {
 
 // Values of attribute ai (SequentialAttributeDecoder.cs:47-52,75-86 / SequentialIntegerAttributeDecoder.cs:23-101):
 // symbols -> corrections -> portable values in work[ai].
-__device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, uint32_t ai, uint32_t entries, const RansScratch &rs,
+__device__ __forceinline__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, uint32_t ai, uint32_t entries, const RansScratch &rs,
                               const ValueCtx &vc) {
   AttrDesc &a = D->att[ai];
   a.num_entries = entries;
@@ -728,7 +728,7 @@ __device__ bool decode_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, 
 }
 
 // ATT_NORMALS: the GeometricNormal attributes of one decoder, on the whole wave.
-__device__ bool normals_stage(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t first_att, uint32_t num_atts, uint32_t entries,
+__device__ __forceinline__ bool normals_stage(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t first_att, uint32_t num_atts, uint32_t entries,
                               const ValueCtx &vc, uint32_t lane, uint32_t nl) {
   for (uint32_t ai = first_att; ai < first_att + num_atts; ++ai) {
     const AttrDesc &a = D->att[ai];
@@ -751,7 +751,7 @@ __device__ bool normals_stage(uint8_t *arena, const MeshLayout &L, MeshDesc *D, 
 }
 
 // AttributeQuantizationTransform.cs:110-121 / AttributeOctahedronTransform.cs:39-42 (D-5)
-__device__ bool decode_transform_params(MeshDesc *D, Rd &r, uint32_t ai) {
+__device__ __forceinline__ bool decode_transform_params(MeshDesc *D, Rd &r, uint32_t ai) {
   AttrDesc &a = D->att[ai];
   if (a.seq_type == 2) {
     for (uint32_t c = 0; c < a.nc; ++c) a.q_min[c] = r.f32();
@@ -766,7 +766,7 @@ __device__ bool decode_transform_params(MeshDesc *D, Rd &r, uint32_t ai) {
 }
 
 // Attribute descriptors of one decoder (AttributesDecoder.cs:19-63 + SequentialAttributeDecodersController.cs:16-27)
-__device__ bool decode_descriptors(const MeshLayout &L, MeshDesc *D, Rd &r, uint32_t decoder, uint32_t &natt, uint32_t *first_att, uint32_t *num_atts) {
+__device__ __forceinline__ bool decode_descriptors(const MeshLayout &L, MeshDesc *D, Rd &r, uint32_t decoder, uint32_t &natt, uint32_t *first_att, uint32_t *num_atts) {
   *first_att = natt;
   const uint64_t k = r.varint();
   GREQ(r.ok && natt + k <= DSA_MAX_ATT && natt + k <= L.cap_attributes, 129);
@@ -793,7 +793,7 @@ __device__ bool decode_descriptors(const MeshLayout &L, MeshDesc *D, Rd &r, uint
 // Mesh/MeshSequentialDecoder.cs:8-123: faces as point indices (compressed: differences with the sign in the LSB
 // through the symbol coder -- D-22: the C# tests that bit inverted; raw: u8 / u16 / varint / u32 by point count), one
 // attributes decoder, linear sequencing (entry i = point i).
-__device__ bool decode_sequential_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, RansScratch rs) {
+__device__ __forceinline__ bool decode_sequential_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, RansScratch rs) {
   const uint64_t nf64 = r.varint(), np64 = r.varint();
   GREQ(r.ok && nf64 <= 0x7FFFFFFFu / 3 && np64 <= 0x7FFFFFFFu, 111);
   const uint32_t F = (uint32_t)nf64, NP = (uint32_t)np64;
@@ -857,7 +857,7 @@ struct MeshCtx {
   uint8_t *is_hole;
   int32_t *c2p;
 };
-__device__ bool mesh_ctx(uint8_t *arena, const MeshLayout &L, MeshDesc *D, MeshCtx &m) {
+__device__ __forceinline__ bool mesh_ctx(uint8_t *arena, const MeshLayout &L, MeshDesc *D, MeshCtx &m) {
   m.F = D->num_faces; m.C = 3 * m.F; m.VMAX = L.cap_vertices; m.NVMAX = m.C > m.VMAX ? m.C : m.VMAX; m.nad = D->num_att_data;
   m.g = gen_layout(m.F, m.VMAX, L.cap_splits, m.nad, L.stream_len);
   GREQ(m.g.total <= L.gen_bytes, 640);
@@ -892,7 +892,7 @@ inline bool g_any(bool b) { return b; }
 
 // Phase 1 (one lane): connectivity header, topology splits, Edgebreaker symbols (standard or valence), start faces,
 // vertex compaction, attribute seam bits.  Leaves the reader position in D->end_pos for phase 3.
-__device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, RansScratch rs) {
+__device__ __forceinline__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, RansScratch rs) {
   const uint8_t *s = arena + L.stream;
   const uint64_t t0 = gclk();
   // ---------------------------------------------------------------- MeshEdgeBreakerDecoder.cs:25-134
@@ -922,7 +922,7 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
   if (!mesh_ctx(arena, L, D, m)) return false;
   const GenLayout &g = m.g;
   uint8_t *G = m.G;
-  Ct &ct = m.ct;
+  Ct ct = m.ct;                 // by value: the hot loop below keeps the table pointers and the vertex count in registers
   uint8_t *is_hole = m.is_hole;
   uint32_t *valences = (uint32_t *)(arena + L.vstamp);
   uint32_t *ctx_syms = (uint32_t *)(arena + L.fstamp);
@@ -1003,6 +1003,19 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
   int last_symbol = -1, active_context = -1;
   uint32_t sp = 0, num_faces = 0, num_invalid = 0, splits_left = S;
   const bool remove_invalid = nad == 0;
+  // What the next symbol needs is almost always what the last one made: the active corner is the top of the stack
+  // (kept in `top`), and its face is the newest one, whose three vertices stay in `lv` (any other corner goes to
+  // memory).  With that a C symbol is two dependent round trips (left-most corner of its pivot, then the vertex
+  // behind it) and R / L / E none, instead of one per table the reference touches.  Valence traversal: the next
+  // symbol of each of the six context lists is fetched ahead (`nxt`), so choosing the list costs no round trip.
+  uint32_t top = DSA_INVALID, lf = DSA_INVALID, lv[3] = {DSA_INVALID, DSA_INVALID, DSA_INVALID};
+#define G_VTX(c_) (((c_) < C && (c_) / 3 == lf) ? lv[(c_) % 3] : ct.vertex(c_))
+#define G_FACE(f_, v0_, v1_, v2_) { ct.c2v[3 * (f_)] = (v0_); ct.c2v[3 * (f_) + 1] = (v1_); ct.c2v[3 * (f_) + 2] = (v2_); lf = (f_); lv[0] = (v0_); lv[1] = (v1_); lv[2] = (v2_); }
+  uint64_t win = 0, win_base = 0, win_end = 0;            // window over the explicit symbol bits
+  uint32_t n_links = 0;                                    // "corner already has an opposite" is not looked up per symbol: every link sets
+                                                           // two corners, so phase 2 counts the linked corners and compares (link census)
+  uint32_t nxt[6] = {0, 0, 0, 0, 0, 0};
+  if (valence) for (int i = 0; i < 6; ++i) if (ctx_cnt[i] > 0) nxt[i] = ctx_syms[ctx_off[i] + ctx_cnt[i] - 1];
   for (uint32_t sid = 0; sid < num_symbols; ++sid) {
     const uint32_t face = num_faces++;
     bool check_split = false;
@@ -1011,15 +1024,25 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
       sym = (uint32_t)predicted_symbol;
       last_symbol = predicted_symbol;
     } else if (!valence) {                                 // MeshEdgeBreakerTraversalDecoder.cs:89-99
-      sym = read_bits(sym_bits, sym_nbytes, sym_bitpos, 1); sym_bitpos += 1;
-      if (sym) { sym |= read_bits(sym_bits, sym_nbytes, sym_bitpos, 2) << 1; sym_bitpos += 2; }
+      // three bits at most, from a 64-bit window over the symbol bytes (refilled every twenty symbols or so)
+      if (sym_bitpos + 3 > win_end) {
+        const uint64_t byte = sym_bitpos >> 3;
+        win = 0;
+        if (byte + 8 <= sym_nbytes) __builtin_memcpy(&win, sym_bits + byte, 8);
+        else for (uint64_t k = byte; k < sym_nbytes; ++k) win |= (uint64_t)sym_bits[k] << (8 * (k - byte));
+        win_base = byte * 8; win_end = win_base + 64;
+      }
+      const uint32_t three = (uint32_t)(win >> (sym_bitpos - win_base)) & 7u;
+      sym = (three & 1u) ? three : 0u;
+      sym_bitpos += (three & 1u) ? 3 : 1;
       GREQ(sym_bitpos <= (uint64_t)sym_nbytes * 8, 246);
       last_symbol = (int)sym;
     } else {                                               // ...ValenceDecoder.cs:77-98
       if (active_context != -1) {
         const int32_t cnt = --ctx_cnt[active_context];
         GREQ(cnt >= 0, 642);
-        const uint32_t id = ctx_syms[ctx_off[active_context] + cnt];
+        const uint32_t id = nxt[active_context];
+        if (cnt > 0) nxt[active_context] = ctx_syms[ctx_off[active_context] + cnt - 1];   // not needed before this list's next turn
         GREQ(id <= 4, 643);
         last_symbol = id == 0 ? 0 : (id == 1 ? 1 : (id == 2 ? 3 : (id == 3 ? 5 : 7)));
       } else last_symbol = 7;
@@ -1028,54 +1051,54 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
     const uint32_t corner = 3 * face;
     if (sym == 0) {                    // C
       GREQ(sp > 0, 210);
-      const uint32_t ca = stack[sp - 1];
-      const uint32_t vx = ct.vertex(cnx(ca));
+      const uint32_t ca = top;
+      const uint32_t vx = G_VTX(cnx(ca));
       GREQ(vx < ct.nv, 213);
       const uint32_t lm = ct.left_most(vx);
       GREQ(lm < C, 213);
       const uint32_t cb = cnx(lm);
       GREQ(ca != cb && ca < C, 213);
-      GREQ(ct.opp[ca] == DSA_INVALID && ct.opp[cb] == DSA_INVALID, 263);
       ct.set_opp(ca, corner + 1);
       ct.set_opp(cb, corner + 2);
-      const uint32_t va_prev = ct.vertex(cpv(ca)), vb_next = ct.vertex(cnx(cb));
+      n_links += 2;
+      const uint32_t va_prev = G_VTX(cpv(ca)), vb_next = G_VTX(cnx(cb));
       GREQ(va_prev < ct.nv && vb_next < ct.nv && vx != va_prev && vx != vb_next, 213);
-      ct.c2v[corner] = vx; ct.c2v[corner + 1] = vb_next; ct.c2v[corner + 2] = va_prev;
+      G_FACE(face, vx, vb_next, va_prev);
       ct.vcorner[va_prev] = corner + 2;
       is_hole[vx] = 0;
-      stack[sp - 1] = corner;
+      top = corner;
     } else if (sym == 5 || sym == 3) { // R / L
       GREQ(sp > 0, 220);
-      const uint32_t ca = stack[sp - 1];
-      GREQ(ca < C && ct.opp[ca] == DSA_INVALID, 263);
-      uint32_t oc, cl, cr;
-      if (sym == 5) { oc = corner + 2; cl = corner + 1; cr = corner; }
-      else { oc = corner + 1; cl = corner; cr = corner + 2; }
+      const uint32_t ca = top;
+      GREQ(ca < C, 263);
+      ++n_links;
+      uint32_t oc, cr;
+      if (sym == 5) { oc = corner + 2; cr = corner; }
+      else { oc = corner + 1; cr = corner + 2; }
       ct.set_opp(oc, ca);
       GREQ(ct.nv < VMAX, 220);
       const uint32_t nv = ct.nv++;
       ct.vcorner[nv] = oc;
-      ct.c2v[oc] = nv;
-      const uint32_t vr = ct.vertex(cpv(ca)), vl = ct.vertex(cnx(ca));
+      const uint32_t vr = G_VTX(cpv(ca)), vl = G_VTX(cnx(ca));
       GREQ(vr < ct.nv && vl < ct.nv, 220);
-      ct.c2v[cr] = vr;
+      if (sym == 5) { G_FACE(face, vr, vl, nv); } else { G_FACE(face, vl, nv, vr); }
       ct.vcorner[vr] = cr;
-      ct.c2v[cl] = vl;
-      stack[sp - 1] = corner;
+      top = corner;
       check_split = true;
     } else if (sym == 1) {             // S
       GREQ(sp > 0, 230);
-      const uint32_t cb = stack[--sp];
+      const uint32_t cb = top;
+      --sp;
       if (S > 0 && active[sid] != DSA_INVALID) { GREQ(sp < F, 232); stack[sp++] = active[sid]; }
       GREQ(sp > 0, 232);
       const uint32_t ca = stack[sp - 1];
       GREQ(ca != cb && ca < C && cb < C, 233);
-      GREQ(ct.opp[ca] == DSA_INVALID && ct.opp[cb] == DSA_INVALID, 263);
       ct.set_opp(ca, corner + 2);
       ct.set_opp(cb, corner + 1);
+      n_links += 2;
       const uint32_t vp = ct.vertex(cpv(ca)), vq = ct.vertex(cnx(ca)), vb_prev = ct.vertex(cpv(cb));
       GREQ(vp < ct.nv && vq < ct.nv && vb_prev < ct.nv, 234);
-      ct.c2v[corner] = vp; ct.c2v[corner + 1] = vq; ct.c2v[corner + 2] = vb_prev;
+      G_FACE(face, vp, vq, vb_prev);
       ct.vcorner[vb_prev] = corner + 2;
       uint32_t cn = cnx(cb);
       const uint32_t vn = ct.vertex(cn);
@@ -1091,19 +1114,21 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
       }
       ct.vcorner[vn] = DSA_INVALID;
       if (remove_invalid) { GREQ(num_invalid < VMAX, 236); invalid_list[num_invalid++] = vn; }
-      stack[sp - 1] = corner;
+      for (int k = 0; k < 3; ++k) lv[k] = ct.c2v[corner + k];         // the ring walk above may have relabelled the new face's own corners
+      top = corner;
     } else if (sym == 7) {             // E
       GREQ(ct.nv + 3 <= VMAX && sp < F, 240);
       const uint32_t v0 = ct.nv;
       ct.nv += 3;
-      ct.c2v[corner] = v0; ct.c2v[corner + 1] = v0 + 1; ct.c2v[corner + 2] = v0 + 2;
+      G_FACE(face, v0, v0 + 1, v0 + 2);
       ct.vcorner[v0] = corner; ct.vcorner[v0 + 1] = corner + 1; ct.vcorner[v0 + 2] = corner + 2;
-      stack[sp++] = corner;
+      if (sp > 0) stack[sp - 1] = top;                      // the old top goes to memory only when something is pushed over it
+      ++sp;
+      top = corner;
       check_split = true;
     } else GFAIL(241);
     if (valence || predictive) {       // NewActiveCornerReached, ...ValenceDecoder.cs:100-149 / ...PredictiveDecoder.cs:48-92
-      const uint32_t top = stack[sp - 1], nx = cnx(top), pv = cpv(top);
-      const uint32_t a = ct.vertex(top), b = ct.vertex(nx), c = ct.vertex(pv);
+      const uint32_t a = lv[0], b = lv[1], c = lv[2];        // the active corner is corner 0 of the newest face
       GREQ(a < VMAX && b < VMAX && c < VMAX, 644);
       switch (last_symbol) {
         case 0: case 1: valences[b] += 1; valences[c] += 1; break;
@@ -1125,13 +1150,15 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
         const uint32_t edge = splits[3 * (splits_left - 1) + 2], enc_split = splits[3 * (splits_left - 1) + 1];
         --splits_left;
         GREQ(enc_split < num_symbols, 244);
-        const uint32_t top = stack[sp - 1];
         const uint32_t nc = edge == 1 ? cnx(top) : cpv(top);   // 1 = right face edge
         const uint32_t key = num_symbols - enc_split - 1;
         active[key] = nc;                                      // dictionary semantics: overwrite
       }
     }
   }
+#undef G_VTX
+#undef G_FACE
+  if (sp > 0) stack[sp - 1] = top;
   // start faces, :378-415
   const uint64_t t2 = gclk();
   while (sp > 0) {
@@ -1152,6 +1179,7 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
     GREQ(vp < ct.nv, 262);
     const uint32_t face = num_faces++, nc = 3 * face;
     ct.set_opp(nc, ca); ct.set_opp(nc + 1, cb); ct.set_opp(nc + 2, cc);
+    n_links += 3;
     ct.c2v[nc] = vx; ct.c2v[nc + 1] = vp; ct.c2v[nc + 2] = vn;
     is_hole[vx] = 0; is_hole[vp] = 0; is_hole[vn] = 0;
   }
@@ -1185,6 +1213,7 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
   const uint32_t num_conn_vertices = num_vertices;
   D->num_vertices = num_conn_vertices;
   D->num_all_vertices = ct.nv;
+  D->interior_corners = 2 * n_links;                       // checked against the corner table by phase 2
   const uint64_t t3 = gclk();
   D->end_pos = r.pos;
   const uint64_t t4 = gclk();     // diagnostics (tools/dbg_phases.py): header + tables, symbols, start faces + compaction, seams
@@ -1197,7 +1226,7 @@ __device__ bool mesh_connectivity(uint8_t *arena, const MeshLayout &L, MeshDesc 
 // data.  Only the rABS recurrences are serial (lane d decodes stream d into a byte per edge); which corner owns the
 // k-th bit is a prefix sum, and marking is idempotent stores.  Scratch: the c2v / v2lm regions of the attribute data
 // blocks, which phase 2b fills afterwards.
-__device__ bool mesh_seams(uint8_t *arena, const MeshLayout &L, MeshDesc *D, MeshCtx &m) {
+__device__ __forceinline__ bool mesh_seams(uint8_t *arena, const MeshLayout &L, MeshDesc *D, MeshCtx &m) {
   const Ct &ct = m.ct;
   Act *act = m.act;
   const uint32_t C = m.C, nad = m.nad, VMAX = m.VMAX, lane = g_lane();
@@ -1250,12 +1279,23 @@ __device__ bool mesh_seams(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Mes
 // MeshAttributeCornerTable.cs:95-155) and points per corner (AssignPointsToCorners, MeshEdgeBreakerDecoder.cs:537-638).
 // Both number things vertex by vertex and, inside a vertex, in ring order; the counts of a chunk of vertices are
 // prefix-summed, so every lane can write the ids of its own vertex.
-__device__ bool mesh_tables(uint8_t *arena, const MeshLayout &L, MeshDesc *D) {
+__device__ __forceinline__ bool mesh_tables(uint8_t *arena, const MeshLayout &L, MeshDesc *D) {
   MeshCtx m;
   if (!mesh_ctx(arena, L, D, m)) return false;
-  if (!mesh_seams(arena, L, D, m)) return false;
   const Ct &ct = m.ct;
   const uint32_t C = m.C, nad = m.nad, lane = g_lane();
+  {   // link census (MeshEdgeBreakerDecoder.cs "corner already has an opposite"): a corner linked twice leaves a stale
+      // link on its first partner, so fewer corners carry a link than phase 1 made
+    uint32_t linked = 0;
+    for (uint32_t c0 = 0; c0 < C; c0 += G_NL) {
+      const uint32_t c = c0 + lane;
+      uint32_t total;
+      (void)g_excl_scan((c < C && ct.opp[c] != DSA_INVALID) ? 1u : 0u, &total);
+      linked += total;
+    }
+    if (linked != D->interior_corners) { if (lane == 0) fail(D, ST_INVALID, 263); return false; }
+  }
+  if (!mesh_seams(arena, L, D, m)) return false;
   for (uint32_t d = 0; d < nad; ++d) {
     Act &A = m.act[d];
     uint32_t base = 0;
@@ -1378,7 +1418,7 @@ __device__ bool mesh_tables(uint8_t *arena, const MeshLayout &L, MeshDesc *D) {
 // the element-parallel one has the whole wave: 0 (one lane) traversal orders, 1 (cooperative) point maps, 2 (one lane)
 // values.  Every stage re-reads the few bytes of decoder triples and descriptors.
 enum { ATT_SEQUENCE = 0, ATT_MAPS = 1, ATT_VALUES = 2, ATT_NORMALS = 3 };
-__device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D, RansScratch rs, int stage) {
+__device__ __forceinline__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D, RansScratch rs, int stage) {
   MeshCtx m;
   if (!mesh_ctx(arena, L, D, m)) return false;
   if (stage == ATT_SEQUENCE) D->off_attributes = D->end_pos;
@@ -1523,7 +1563,7 @@ __device__ bool mesh_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D
 
 // The whole mesh in one go (host check; the device runs the three phases as separate kernels so that the second
 // one can use the whole wave).
-__device__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, RansScratch rs) {
+__device__ __forceinline__ bool decode_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, Rd &r, RansScratch rs) {
   return mesh_connectivity(arena, L, D, r, rs) && mesh_tables(arena, L, D) && mesh_attributes(arena, L, D, rs, ATT_SEQUENCE) &&
          mesh_attributes(arena, L, D, rs, ATT_MAPS) && mesh_attributes(arena, L, D, rs, ATT_VALUES) && mesh_attributes(arena, L, D, rs, ATT_NORMALS);
 }
