@@ -267,8 +267,11 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_fork, 0));
     hipLaunchKernelGGL(dsa::k_general, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_general_tables, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
-    for (int stage = 0; stage < 4; ++stage)
-      hipLaunchKernelGGL(dsa::k_general_attributes, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, stage);
+    hipLaunchKernelGGL(dsa::k_general_attributes<0>, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+    hipLaunchKernelGGL(dsa::k_general_attributes<1>, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+    if (n > 2048) hipLaunchKernelGGL(dsa::k_general_values_crowded, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+    else hipLaunchKernelGGL(dsa::k_general_attributes<2>, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+    hipLaunchKernelGGL(dsa::k_general_attributes<3>, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
   }
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[0], st2));
   hipLaunchKernelGGL(dsa::k_symbols_reg, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n);

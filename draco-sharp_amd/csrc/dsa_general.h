@@ -80,11 +80,13 @@ struct Act {
 // Scratch for the symbol coder of a general mesh: tables of the common case (12-bit precision, <= 2048 symbols)
 // live in LDS (host check: plain memory), where a lookup costs ~100 cycles instead of a dependent chain of global
 // loads; larger tables stay in the arena region `cum` and are searched.
-#define GEN_LUT_SLOTS 4096
-#define GEN_LUT_SYMS 2048
+#define GEN_LUT_SLOTS 4096    // full resolution: one slot per value of the 12-bit remainder; crowded launches use half (lut_shift 1)
+#define GEN_LUT_SYMS 2048    // alphabets up to 2^11 symbols at 12 precision bits keep their tables in LDS (u16 in crowded launches: 8 KB with the half-resolution LUT)
 struct RansScratch {
-  uint16_t *lut;          // [GEN_LUT_SLOTS] slot -> symbol
-  uint32_t *fast_cum;     // [GEN_LUT_SYMS + 1]
+  uint16_t *lut;          // [GEN_LUT_SLOTS >> lut_shift] slot -> symbol holding the slot's first value
+  uint32_t lut_shift;     // 0: exact; 1: one slot per two values (4 KB instead of 8), read() steps on when needed
+  uint16_t *fast_cum;     // [GEN_LUT_SYMS + 1], 12-bit precision only (lut_shift 1)
+  uint32_t *fast_cum32;   // the same as 32-bit words (lut_shift 0: two independent reads per symbol, no stepping)
   uint32_t *cum;          // arena, cum_cap entries
   uint64_t cum_cap;
 };
@@ -92,6 +94,8 @@ struct Rans {
   uint32_t pb, l_base, ns, state, off;
   const uint8_t *buf;
   const uint32_t *cum;
+  const uint16_t *cum16 = nullptr;
+  uint32_t lut_shift = 0;
   const uint16_t *lut;    // nullptr: binary search over cum
   uint64_t win = 0;       // the eight stream bytes below `off + win_n`, so that a renormalisation byte costs a memory
   uint32_t win_n = 0;     // round trip only once in eight
@@ -106,9 +110,20 @@ struct Rans {
       state = state * 256u + (uint32_t)((win >> (8 * win_n)) & 0xFFu);
     }
     const uint32_t rem = state & ((1u << pb) - 1u);
+    if (lut && lut_shift == 0) {       // 12-bit precision, exact LUT and table in LDS
+      const uint32_t s = lut[rem], c0 = cum[s];
+      state = (state >> 12) * (cum[s + 1] - c0) + rem - c0;
+      return s;
+    }
+    if (lut) {                         // 12-bit precision, half-resolution LUT (crowded launches: half the LDS)
+      uint32_t s = lut[rem >> 1], c1 = cum16[s + 1];
+      if (c1 <= rem) { ++s; c1 = cum16[s + 1]; while (c1 <= rem) { ++s; c1 = cum16[s + 1]; } }   // odd value in the next symbol (zero-frequency symbols are stepped over)
+      const uint32_t c0 = cum16[s];
+      state = (state >> 12) * (c1 - c0) + rem - c0;
+      return s;
+    }
     uint32_t lo;
-    if (lut) lo = lut[rem];
-    else {
+    {
       lo = 0;
       uint32_t hi = ns;                // largest s with cum[s] <= rem
       while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= rem) lo = mid; else hi = mid; }
@@ -137,9 +152,12 @@ __device__ __forceinline__ bool rans_create(MeshDesc *D, Rd &r, uint32_t max_bit
   x.cum = cum;
   x.lut = nullptr;
   if (x.pb == 12 && x.ns <= GEN_LUT_SYMS && rs.lut) {
-    for (uint32_t i = 0; i <= x.ns; ++i) rs.fast_cum[i] = cum[i];
-    for (uint32_t i = 0; i < x.ns; ++i) for (uint32_t j = cum[i]; j < cum[i + 1]; ++j) rs.lut[j] = (uint16_t)i;
-    x.cum = rs.fast_cum; x.lut = rs.lut;
+    if (rs.lut_shift == 0) { for (uint32_t i = 0; i <= x.ns; ++i) rs.fast_cum32[i] = cum[i]; x.cum = rs.fast_cum32; }
+    else for (uint32_t i = 0; i <= x.ns; ++i) rs.fast_cum[i] = (uint16_t)cum[i];
+    const uint32_t sh = rs.lut_shift, half = (1u << sh) - 1u;
+    for (uint32_t i = 0; i < x.ns; ++i) for (uint32_t j = (cum[i] + half) >> sh; (j << sh) < cum[i + 1]; ++j) rs.lut[j] = (uint16_t)i;   // slots whose first value lies in [cum[i], cum[i+1])
+    x.lut_shift = sh;
+    x.cum16 = rs.fast_cum; x.lut = rs.lut;
   }
   // RAnsSymbolDecoder.cs:53-59, RAnsDecoder.cs:20-54
   const uint64_t size = r.varint();
@@ -1579,15 +1597,15 @@ __device__ __forceinline__ bool decode_mesh(uint8_t *arena, const MeshLayout &L,
 //   k_general_tables      one wave per mesh, all lanes: attribute corner tables, points per corner
 //   k_general_attributes  three launches: traversal orders (one lane per mesh), point maps (whole wave), attribute values (one lane)
 __global__ __launch_bounds__(WAVE) void k_general(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
-  __shared__ uint16_t sh_lut[GEN_LUT_SLOTS];
-  __shared__ uint32_t sh_cum[GEN_LUT_SYMS + 1];
+  __shared__ uint16_t sh_lut[GEN_LUT_SLOTS / 2];          // half-resolution tables (8 KB): the entropy decode here is the small part
+  __shared__ uint16_t sh_cum[GEN_LUT_SYMS + 1];
   const uint32_t mesh = blockIdx.x;
   if (mesh >= n || threadIdx.x != 0) return;
   MeshDesc *D = &descs[mesh];
   if (!D->general || status_of(D) != ST_OK) return;
   const MeshLayout &L = layouts[mesh];
   Rd r(arena + L.stream, L.stream_len, D->end_pos);       // k_locate parked the reader behind the header
-  gen::RansScratch rs = {sh_lut, sh_cum, nullptr, 0};
+  gen::RansScratch rs = {sh_lut, 1, sh_cum, nullptr, nullptr, 0};
   if (D->encoder_method == 0) (void)gen::decode_sequential_mesh(arena, L, D, r, rs);
   else (void)gen::mesh_connectivity(arena, L, D, r, rs);
 }
@@ -1598,15 +1616,29 @@ __global__ __launch_bounds__(WAVE) void k_general_tables(uint8_t *arena, const M
   if (!D->general || D->encoder_method == 0 || status_of(D) != ST_OK) return;
   (void)gen::mesh_tables(arena, layouts[mesh], D);
 }
-__global__ __launch_bounds__(WAVE) void k_general_attributes(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, int stage) {
-  __shared__ uint16_t sh_lut[GEN_LUT_SLOTS];
-  __shared__ uint32_t sh_cum[GEN_LUT_SYMS + 1];
+// One instantiation per stage: each gets the registers its own code needs (the values stage carries every predictor
+// and wants ~180 VGPRs = 8 blocks per CU; its CROWDED variant is held to 128 so that 16 blocks per CU = a batch of 4096
+// meshes are resident at once, which is worth the spills only when the batch is that large).
+template <int STAGE, bool CROWDED>
+__device__ __forceinline__ void general_attributes_body(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n);
+template <int STAGE>
+__global__ __launch_bounds__(WAVE) void k_general_attributes(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  general_attributes_body<STAGE, false>(arena, layouts, descs, n);
+}
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_general_values_crowded(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  general_attributes_body<gen::ATT_VALUES, true>(arena, layouts, descs, n);
+}
+template <int STAGE, bool CROWDED>
+__device__ __forceinline__ void general_attributes_body(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  __shared__ uint16_t sh_lut[STAGE == gen::ATT_VALUES ? (CROWDED ? GEN_LUT_SLOTS / 2 : GEN_LUT_SLOTS) : 1];
+  __shared__ uint16_t sh_cum16[STAGE == gen::ATT_VALUES && CROWDED ? GEN_LUT_SYMS + 1 : 1];
+  __shared__ uint32_t sh_cum32[STAGE == gen::ATT_VALUES && !CROWDED ? GEN_LUT_SYMS + 1 : 1];
   const uint32_t mesh = blockIdx.x;
-  if (mesh >= n || (stage != gen::ATT_MAPS && stage != gen::ATT_NORMALS && threadIdx.x != 0)) return;
+  if (mesh >= n || (STAGE != gen::ATT_MAPS && STAGE != gen::ATT_NORMALS && threadIdx.x != 0)) return;
   MeshDesc *D = &descs[mesh];
   if (!D->general || D->encoder_method == 0 || status_of(D) != ST_OK) return;
-  gen::RansScratch rs = {sh_lut, sh_cum, nullptr, 0};
-  (void)gen::mesh_attributes(arena, layouts[mesh], D, rs, stage);
+  gen::RansScratch rs = {sh_lut, CROWDED ? 1u : 0u, sh_cum16, sh_cum32, nullptr, 0};
+  (void)gen::mesh_attributes(arena, layouts[mesh], D, rs, STAGE);
 }
 #endif
 

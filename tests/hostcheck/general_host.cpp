@@ -62,8 +62,9 @@ static bool run(const uint8_t *data, size_t len, bool force, Result &R) {
   R.D.general = 1;
   dsa::Rd r(R.arena.data(), (uint32_t)len, (uint32_t)hr.pos);
   std::vector<uint16_t> lut(GEN_LUT_SLOTS);
-  std::vector<uint32_t> fcum(GEN_LUT_SYMS + 1);
-  dsa::gen::RansScratch rs = {lut.data(), fcum.data(), nullptr, 0};
+  std::vector<uint16_t> fcum(GEN_LUT_SYMS + 1);
+  std::vector<uint32_t> fcum32(GEN_LUT_SYMS + 1);
+  dsa::gen::RansScratch rs = {lut.data(), getenv("DSA_HALF_LUT") ? 1u : 0u, fcum.data(), fcum32.data(), nullptr, 0};   // both LUT resolutions of the device launches
   if (R.D.encoder_method == 0) (void)dsa::gen::decode_sequential_mesh(R.arena.data(), R.L, &R.D, r, rs);
   else (void)dsa::gen::decode_mesh(R.arena.data(), R.L, &R.D, r, rs);
   ASAN_UNPOISON_MEMORY_REGION(R.arena.data(), R.arena.size());

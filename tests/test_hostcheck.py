@@ -27,10 +27,11 @@ def exe():
     return EXE
 
 
-def host_decode(exe, data, tmp_path, force):
+def host_decode(exe, data, tmp_path, force, half_lut=False):
     src, out = tmp_path / "in.drc", tmp_path / "out.bin"
     src.write_bytes(data)
-    r = subprocess.run([exe, "decode", str(src), str(out)] + (["force"] if force else []), capture_output=True, text=True)
+    env = dict(os.environ, DSA_HALF_LUT="1") if half_lut else None
+    r = subprocess.run([exe, "decode", str(src), str(out)] + (["force"] if force else []), capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     raw = out.read_bytes()
     status, detail = struct.unpack_from("<ii", raw, 0)
@@ -83,9 +84,11 @@ def test_house04_through_the_general_path_source(exe, house04_bytes, tmp_path):
 def test_synthetic_meshes_through_the_general_path_source(exe, tmp_path, kind, nx, ny, opts):
     pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 7)
     data = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(**opts))
-    status, detail, got = host_decode(exe, data, tmp_path, force=True)
-    assert status == 0, detail
-    assert_equals_oracle(got, oracle.decode(data))
+    ref = oracle.decode(data)
+    for half_lut in (False, True):                    # the two rANS look-up table resolutions of the device launches
+        status, detail, got = host_decode(exe, data, tmp_path, force=True, half_lut=half_lut)
+        assert status == 0, detail
+        assert_equals_oracle(got, ref)
 
 
 @pytest.mark.parametrize("compressed", [True, False])
