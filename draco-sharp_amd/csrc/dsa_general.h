@@ -215,7 +215,8 @@ __device__ __forceinline__ bool decode_symbols(MeshDesc *D, Rd &r, uint32_t num_
 // MeshTraversalSequencer.cs:13-31 on either corner table.
 template <class T>
 __device__ __forceinline__ bool traverse(MeshDesc *D, const T &t, uint32_t num_verts, const int32_t *c2p, uint8_t *fvis, uint8_t *vvis, uint32_t *stack,
-                         uint32_t stack_cap, uint32_t *d2c, int32_t *v2d, uint32_t *pids, uint32_t cap_entries, uint32_t *num_entries) {
+                         uint32_t stack_cap, uint32_t *d2c, int32_t *v2d, uint32_t *pids, uint32_t cap_entries, uint32_t *num_entries,
+                         const uint8_t *bnd, uint32_t bnd_size) {
   const uint32_t F = t.num_faces();
   for (uint32_t f = 0; f < F; ++f) fvis[f] = 0;
   for (uint32_t v = 0; v < num_verts; ++v) { vvis[v] = 0; v2d[v] = -1; }
@@ -235,19 +236,20 @@ __device__ __forceinline__ bool traverse(MeshDesc *D, const T &t, uint32_t num_v
       if (corner == DSA_INVALID || face >= F || fvis[face]) { --sp; continue; }
       for (;;) {
         fvis[face] = 1;
+        // the three reads a face needs start together: its tip and the corners behind its two other edges
         const uint32_t v = t.vertex(corner);
+        const uint32_t rc = t.right_corner(corner), lc = t.left_corner(corner);
         GREQ(v < num_verts, 622);
         if (!vvis[v]) {
-          const bool on_boundary = t.is_on_boundary(v);
+          const bool on_boundary = bnd ? (v < bnd_size ? bnd[v] != 0 : true) : t.is_on_boundary(v);
           G_VISIT(v, corner);
           if (!on_boundary) {
-            corner = t.right_corner(corner);
+            corner = rc;
             GREQ(corner != DSA_INVALID && corner / 3 < F, 623);
             face = corner / 3;
             continue;
           }
         }
-        const uint32_t rc = t.right_corner(corner), lc = t.left_corner(corner);
         const uint32_t rf = rc == DSA_INVALID ? DSA_INVALID : rc / 3, lf = lc == DSA_INVALID ? DSA_INVALID : lc / 3;
         const bool rdone = rf >= F || fvis[rf], ldone = lf >= F || fvis[lf];
         if (rdone) {
@@ -1429,6 +1431,20 @@ __device__ __forceinline__ bool mesh_tables(uint8_t *arena, const MeshLayout &L,
     base += total;
   }
   if (lane == 0) D->num_points = base;
+  // Boundary flag of every vertex of every table a depth-first traversal may walk (DepthFirstTraverser.cs:47 asks it for
+  // each new vertex: two dependent table reads there, one byte here).  Position table: in the is_hole region (done
+  // with); attribute tables: in the orientation scratch of their block (used only by the values stage).
+#if defined(__HIPCC__)
+  __threadfence_block();
+#endif
+  {
+    uint8_t *bnd = m.is_hole;
+    for (uint32_t v = lane; v < ct.nv; v += G_NL) bnd[v] = ct.is_on_boundary(v) ? 1 : 0;
+    for (uint32_t d = 0; d < nad; ++d) {
+      uint8_t *ba = m.G + m.g.data + (uint64_t)d * m.g.data_stride + m.g.orient;
+      for (uint32_t v = lane; v < m.act[d].nv; v += G_NL) ba[v] = m.act[d].is_on_boundary(v) ? 1 : 0;
+    }
+  }
   return true;
 }
 
@@ -1510,10 +1526,13 @@ __device__ __forceinline__ bool mesh_attributes(uint8_t *arena, const MeshLayout
     if (!first_of_kind) { d2c = sh.d2c; v2d = sh.v2d; pids = sh.pids; entries = sh.entries; map_src = sh.map; }
     else {
       if (stage != ATT_SEQUENCE) entries = D->gen_dec_entries[i];
-      else if (corner_att) { if (!traverse(D, act[dd], nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries)) return false; }
+      else if (corner_att) {
+        if (!traverse(D, act[dd], nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries,
+                      G + g.data + (uint64_t)dd * g.data_stride + g.orient, act[dd].nv)) return false;
+      }
       else if (dec[i].traversal_method == 1) {
         if (!traverse_prediction_degree(D, ct, nverts, c2p, fvis, vvis, (uint32_t *)(G + g.pd_next), (uint32_t *)(G + g.pd_degree), d2c, v2d, pids, cap_entries, &entries)) return false;
-      } else if (!traverse(D, ct, nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries)) return false;
+      } else if (!traverse(D, ct, nverts, c2p, fvis, vvis, dfs, F + 1, d2c, v2d, pids, cap_entries, &entries, m.is_hole, ct.nv)) return false;
       if (!corner_att) { sh.d2c = d2c; sh.v2d = v2d; sh.pids = pids; sh.entries = entries; }
     }
     dec[i].num_entries = entries;
