@@ -253,7 +253,12 @@ def test_corrupt_streams_agree_with_the_oracle(ctx, house04_bytes):
     (Both sides may legitimately accept a damaged payload: then they have to agree on the result.)"""
     pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 10, 8, 3)
     base = synth.encode_mesh(pos, faces, nrm, uv)
-    streams = _corruptions(base, 96, 5) + _corruptions(house04_bytes, 64, 6) + [base, house04_bytes]
+    # the stock-encoder mix (valence symbols, TexCoordsPortable, GeometricNormal, prediction-degree order) and the
+    # rarer one (predictive symbols, both multi-parallelogram schemes): all general-path code
+    stock = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(predictive_connectivity=2, uv_prediction=5, normal_prediction=6, traversal_method=1))
+    rare = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(predictive_connectivity=1, pos_prediction=4, uv_prediction=2, single_connectivity=1))
+    streams = (_corruptions(base, 96, 5) + _corruptions(house04_bytes, 64, 6) + _corruptions(stock, 64, 7) + _corruptions(rare, 64, 8) +
+               [base, house04_bytes, stock, rare])
     b = run_batch(ctx, streams)
     agree_ok = agree_bad = gpu_stricter = 0
     for i, sbytes in enumerate(streams):
@@ -270,7 +275,7 @@ def test_corrupt_streams_agree_with_the_oracle(ctx, house04_bytes):
             agree_bad += 1
         else:
             gpu_stricter += 1          # e.g. the link census or a sizing bound rejects what the oracle lets through
-    assert agree_ok >= 2 and agree_bad > 0
+    assert agree_ok >= 4 and agree_bad > 0
     assert gpu_stricter <= len(streams) // 10, (agree_ok, agree_bad, gpu_stricter)
     b.close()
 
