@@ -1607,12 +1607,13 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
       if (!exhausted) {
         {
           // The 64 steps of a block are unrolled, so position J is parked in lane J with v_writelane (inline
-          // lane number) and there is no loop counter: 6 scalar + 6 vector instructions per symbol.  A step is
+          // lane number) and there is no loop counter: 5 scalar + 6 vector instructions per symbol.  A step is
           // entered by a computed jump (all steps have the same size), which is how decoding resumes at
           // position j after the reservoir was refilled.  The last block of a stream runs all 64 steps as well:
-          // positions past the end decode whatever the state yields and are not stored.  The row arithmetic runs under the index window
-          // (its src0 operands are constants / SGPRs, which the window does not touch); s_set_gpr_idx_off is
-          // also the wait state between the VALU write and v_readlane.
+          // positions past the end decode whatever the state yields and are not stored.  The register-index window stays
+          // open over the whole block (one s_set_gpr_idx_idx per step instead of an on/off pair): it indexes src1 only,
+          // and every other vector instruction of a step has a constant or an SGPR there.  v_writelane sits between the
+          // VALU write of the new state and its v_readlane (the wait state that hazard needs).
           uint32_t k6, q, va, vf;
           uint32_t js = uni(j);
           asm volatile(
@@ -1623,20 +1624,20 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
               " s_addc_u32 s23, s23, 0\n"
               " s_add_u32 s22, s22, %[k6]\n"
               " s_addc_u32 s23, s23, 0\n"
+              " s_set_gpr_idx_on s22, gpr_idx(SRC1)\n"
               " s_setpc_b64 s[22:23]\n"
               ".irp J,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63\n"
               "Lus\\J\\()_%=:\n"
               " s_cmpk_lt_u32 s21, 0x4000\n"
               " s_cbranch_scc1 Lur\\J\\()_%=\n"
-              " v_writelane_b32 %[mine], s21, \\J\n"
               " s_bfe_u32 %[k6], s21, 0x60006\n"
               " s_lshr_b32 %[q], s21, 12\n"
-              " s_set_gpr_idx_on %[k6], gpr_idx(SRC0)\n"
-              " v_mov_b32_e32 %[va], v16\n"
-              " v_lshrrev_b32_e32 %[vf], 12, %[va]\n"
-              " v_and_b32_e32 %[va], 0xfff, %[va]\n"
-              " v_mad_u32_u24 %[va], %[q], %[vf], %[va]\n"
-              " s_set_gpr_idx_off\n"
+              " s_set_gpr_idx_idx %[k6]\n"
+              " v_or_b32_e32 %[va], 0, v16\n"
+              " v_bfe_u32 %[vf], %[va], 12, 20\n"
+              " v_and_b32_e64 %[va], %[va], %[m12]\n"
+              " v_mad_u32_u24 %[va], %[vf], %[q], %[va]\n"
+              " v_writelane_b32 %[mine], s21, \\J\n"
               " v_readlane_b32 s21, %[va], s21\n"
               ".endr\n"
               " s_movk_i32 %[j], 64\n"
@@ -1654,8 +1655,9 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
               "Luempty%=:\n"
               " s_mov_b32 %[rc], 0\n"
               "Luend%=:\n"
+              " s_set_gpr_idx_off\n"
               : "+{s[20:21]}"(P), [rc] "+s"(rc), [j] "+s"(js), [mine] "+v"(mine), [k6] "=&s"(k6), [q] "=&s"(q), [va] "=&v"(va), [vf] "=&v"(vf)
-              : "{v[16:47]}"(tab_lo), "{v[48:79]}"(tab_hi)
+              : "{v[16:47]}"(tab_lo), "{v[48:79]}"(tab_hi), [m12] "s"(0xfffu)
               : "vcc", "scc", "s22", "s23");
           j = js;
         }
