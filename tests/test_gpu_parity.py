@@ -435,3 +435,13 @@ def test_batch_properties_full_size(ctx):
         assert_same(d, oracle.decode(s), b, i)
     assert b.algorithmic_bytes > 16 * (65536 * 12 + 33153 * 32)
     b.close()
+
+
+def test_randomised_options_agree_with_the_oracle(ctx):
+    """tools/soak.py: random topology / size / bit depths / symbol scheme / prediction schemes / attribute order /
+    Edgebreaker symbol coding / connectivity mode per mesh, one batch, every result equal to the oracle's."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import soak
+    assert soak.run(120, 7, ctx) == []

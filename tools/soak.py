@@ -1,0 +1,58 @@
+"""Randomised differential run: N synthetic meshes with random encoder options (topology, size, bit depths, symbol
+scheme, prediction schemes, attribute order, Edgebreaker symbol coding, single / per-attribute connectivity) decoded
+in one batch and compared with the oracle.  usage: python tools/soak.py [count] [seed]"""
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+import oracle
+import draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
+
+
+def random_case(rng):
+    kind = int(rng.choice([synth.GRID, synth.TORUS, synth.SPHERE, synth.HOLES, synth.TWO_PARTS]))
+    nx, ny = int(rng.integers(4, 48)), int(rng.integers(4, 40))
+    if kind == synth.HOLES:
+        nx, ny = max(nx, 12), max(ny, 12)
+    opt = dict(pos_bits=int(rng.integers(4, 21)), uv_bits=int(rng.integers(4, 17)), normal_bits=int(rng.integers(3, 15)),
+               single_connectivity=int(rng.integers(0, 2)), force_scheme=int(rng.integers(-1, 2)),
+               compression_level=int(rng.integers(0, 11)), pos_prediction=int(rng.choice([0, 1, 2, 4])),
+               uv_prediction=int(rng.choice([0, 1, 2, 4, 5])), normal_prediction=int(rng.choice([0, 6])),
+               traversal_method=int(rng.integers(0, 3)), predictive_connectivity=int(rng.integers(0, 3)))
+    pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, int(rng.integers(0, 1 << 30)))
+    with_n, with_uv = bool(rng.integers(0, 4)), bool(rng.integers(0, 4))
+    return synth.encode_mesh(pos, faces, nrm if with_n else None, uv if with_uv else None, opt=synth.options(**opt)), (kind, nx, ny, opt, with_n, with_uv)
+
+
+def run(count, seed, ctx=None):
+    rng = np.random.default_rng(seed)
+    cases = [random_case(rng) for _ in range(count)]
+    own = ctx is None
+    ctx = ctx or dsa.Context(0)
+    b = dsa.Batch(ctx, [c[0] for c in cases])
+    b.decode()
+    bad = []
+    for i, (data, what) in enumerate(cases):
+        ref = oracle.decode(data)
+        if b.status(i) != 0:
+            bad.append((i, what, "status %d site %d" % (b.status(i), b.mesh_info(i).detail)))
+            continue
+        m = b.result(i).ConnectedData
+        ok = np.array_equal(m.Faces, ref.faces) and len(m.Attributes) == len(ref.attributes)
+        for a, r in zip(m.Attributes, ref.attributes):
+            ok = ok and np.array_equal(a.PortableValues, r.portable) and np.array_equal(a.PointMap, r.point_map) and a.Values.tobytes() == r.values.tobytes()
+        if not ok:
+            bad.append((i, what, "differs from the oracle"))
+    b.close()
+    if own:
+        ctx.close()
+    return bad
+
+
+if __name__ == "__main__":
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    bad = run(count, seed)
+    print("%d cases, %d bad" % (count, len(bad)))
+    for x in bad[:10]:
+        print(x)
+    sys.exit(1 if bad else 0)
