@@ -97,6 +97,8 @@ struct Rans {
   const uint16_t *cum16 = nullptr;
   uint32_t lut_shift = 0;
   const uint16_t *lut;    // nullptr: binary search over cum
+  const uint16_t *bucket_lut = nullptr;   // bucket of the remainder -> symbol holding the bucket's first value
+  uint32_t bucket_shift = 0, num_buckets = 0;
   uint64_t win = 0;       // the eight stream bytes below `off + win_n`, so that a renormalisation byte costs a memory
   uint32_t win_n = 0;     // round trip only once in eight
   __device__ __forceinline__ uint32_t read() {
@@ -122,13 +124,15 @@ struct Rans {
       state = (state >> 12) * (c1 - c0) + rem - c0;
       return s;
     }
-    uint32_t lo;
-    {
-      lo = 0;
-      uint32_t hi = ns;                // largest s with cum[s] <= rem
-      while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= rem) lo = mid; else hi = mid; }
+    uint32_t lo = 0, hi = ns;          // largest s with cum[s] <= rem
+    if (bucket_lut) {                  // other precisions: the LDS table narrows the search to the symbols that meet the
+      const uint32_t b = rem >> bucket_shift;                       // remainder's bucket (a few, where the full search takes 11-20 round trips)
+      lo = bucket_lut[b];
+      hi = (b + 1 < num_buckets ? bucket_lut[b + 1] : ns - 1) + 1;
     }
-    state = (state >> pb) * (cum[lo + 1] - cum[lo]) + rem - cum[lo];
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= rem) lo = mid; else hi = mid; }
+    const uint32_t c0 = cum[lo];
+    state = (state >> pb) * (cum[lo + 1] - c0) + rem - c0;
     return lo;
   }
 };
@@ -158,6 +162,16 @@ __device__ __forceinline__ bool rans_create(MeshDesc *D, Rd &r, uint32_t max_bit
     for (uint32_t i = 0; i < x.ns; ++i) for (uint32_t j = (cum[i] + half) >> sh; (j << sh) < cum[i + 1]; ++j) rs.lut[j] = (uint16_t)i;   // slots whose first value lies in [cum[i], cum[i+1])
     x.lut_shift = sh;
     x.cum16 = rs.fast_cum; x.lut = rs.lut;
+  } else if (rs.lut && x.ns <= 65536) {
+    const uint32_t nb = GEN_LUT_SLOTS >> rs.lut_shift, lg = rs.lut_shift ? 11u : 12u;
+    x.bucket_shift = x.pb - lg; x.num_buckets = nb;
+    uint32_t sym = 0;
+    for (uint32_t j = 0; j < nb; ++j) {
+      const uint32_t start = j << x.bucket_shift;
+      while (cum[sym + 1] <= start) ++sym;
+      rs.lut[j] = (uint16_t)sym;
+    }
+    x.bucket_lut = rs.lut;
   }
   // RAnsSymbolDecoder.cs:53-59, RAnsDecoder.cs:20-54
   const uint64_t size = r.varint();
