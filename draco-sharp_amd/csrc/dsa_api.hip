@@ -358,6 +358,10 @@ dsa_status dsa_batch_wait(dsa_batch *b) {
     HIP_TRY(ctx, hipEventElapsedTime(&b->stage_ms[STG_SYMBOLS], b->ev_sym[0], b->ev_sym[1]));
     HIP_TRY(ctx, hipEventElapsedTime(&b->stage_ms[STG_TOTAL], b->ev[0], b->ev[STG_TOTAL]));
   }
+  // a stream the sizing parse set aside as beyond the device path's limits (more than DSA_MAX_ATT attributes) got no
+  // regions, so the kernels stop at the first capacity check: the verdict is the host's
+  for (uint32_t i = 0; i < b->n; ++i)
+    if (b->host[i].status == ST_NOTIMPL && b->descs[i].status != ST_OK) { b->descs[i].status = ST_NOTIMPL; b->descs[i].detail = 129; }
   b->collected = true;
   // second chance: meshes whose prediction schemes need the general path's tables (the fast kernels find that out
   // only behind the symbol streams, where the host parse does not go)

@@ -803,7 +803,9 @@ __device__ __forceinline__ bool decode_transform_params(MeshDesc *D, Rd &r, uint
 __device__ __forceinline__ bool decode_descriptors(const MeshLayout &L, MeshDesc *D, Rd &r, uint32_t decoder, uint32_t &natt, uint32_t *first_att, uint32_t *num_atts) {
   *first_att = natt;
   const uint64_t k = r.varint();
-  GREQ(r.ok && natt + k <= DSA_MAX_ATT && natt + k <= L.cap_attributes, 129);
+  GREQ(r.ok, 129);
+  if (natt + k > DSA_MAX_ATT) GNOTIMPL(129);            // a valid stream with more attributes than the device path carries
+  GREQ(natt + k <= L.cap_attributes, 129);
   *num_atts = (uint32_t)k;
   for (uint32_t j = 0; j < (uint32_t)k; ++j) {
     AttrDesc &a = D->att[natt + j];
@@ -861,7 +863,8 @@ __device__ __forceinline__ bool decode_sequential_mesh(uint8_t *arena, const Mes
   D->num_faces = F; D->num_points = NP; D->num_vertices = NP; D->num_all_vertices = NP; D->num_enc_vertices = NP; D->num_entries = NP;
   D->off_attributes = r.pos;
   const uint32_t ndec = r.u8();
-  GREQ(r.ok && ndec <= DSA_MAX_ATT, 122);
+  GREQ(r.ok, 122);
+  if (ndec > DSA_MAX_ATT) GNOTIMPL(122);
   D->num_decoders = ndec;
   uint32_t natt = 0, first[DSA_MAX_ATT], count[DSA_MAX_ATT];
   for (uint32_t i = 0; i < ndec; ++i) if (!decode_descriptors(L, D, r, i, natt, &first[i], &count[i])) return false;
@@ -940,7 +943,8 @@ __device__ __forceinline__ bool mesh_connectivity(uint8_t *arena, const MeshLayo
   const uint64_t nsym64 = r.varint();
   GREQ(r.ok && nf64 >= nsym64 && nf64 <= nsym64 + nsym64 / 3, 113);
   const uint64_t nss64 = r.varint();
-  GREQ(r.ok && nss64 <= nsym64 && nad <= DSA_MAX_ATT_DATA, 114);
+  GREQ(r.ok && nss64 <= nsym64, 114);
+  if (nad > DSA_MAX_ATT_DATA) GNOTIMPL(115);
   const uint32_t F = (uint32_t)nf64, C = 3 * F, num_symbols = (uint32_t)nsym64;
   const uint32_t VMAX = (uint32_t)(nv64 + nss64);
   GREQ(F == L.cap_faces && VMAX == L.cap_vertices, 116);
@@ -1482,7 +1486,8 @@ __device__ __forceinline__ bool mesh_attributes(uint8_t *arena, const MeshLayout
   rs.cum = (uint32_t *)(G + g.cum); rs.cum_cap = g.cum_entries;
   // ---------------------------------------------------------------- attribute section, ConnectivityDecoder.cs:16-44
   const uint32_t ndec = r.u8();
-  GREQ(r.ok && ndec <= DSA_MAX_ATT, 122);
+  GREQ(r.ok, 122);
+  if (ndec > DSA_MAX_ATT) GNOTIMPL(122);
   D->num_decoders = ndec;
   DecoderInfo dec[DSA_MAX_ATT];
   int data_decoder[DSA_MAX_ATT_DATA];

@@ -161,7 +161,8 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m, bool want_gene
     uint64_t nsym = r.varint();
     if (!r.ok || nf < nsym || nf > nsym + nsym / 3) return bad(ST_INVALID);
     uint64_t nss = r.varint();
-    if (!r.ok || nss > nsym || nad > DSA_MAX_ATT_DATA) return bad(ST_INVALID);
+    if (!r.ok || nss > nsym) return bad(ST_INVALID);
+    if (nad > DSA_MAX_ATT_DATA) return bad(ST_NOTIMPL);
     uint64_t nsplits = r.varint();
     if (!r.ok || nsplits > nf) return bad(ST_INVALID);
     m.faces = (uint32_t)nf; m.enc_vertices = (uint32_t)nv; m.split_symbols = (uint32_t)nss; m.splits = (uint32_t)nsplits; m.num_att_data = nad;
@@ -181,7 +182,8 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m, bool want_gene
     }
   }
   uint32_t ndec = r.u8();
-  if (!r.ok || ndec > DSA_MAX_ATT) return bad(ST_INVALID);
+  if (!r.ok) return bad(ST_INVALID);
+  if (ndec > DSA_MAX_ATT) return bad(ST_NOTIMPL);               // a valid stream, more attribute decoders than the device path carries
   bool corner_dec[DSA_MAX_ATT + 1] = {};
   if (!linear) for (uint32_t i = 0; i < ndec; ++i) {
     (void)r.u8();
@@ -193,7 +195,8 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m, bool want_gene
   if ((force_general || want_general) && !point_cloud) m.general = true;
   for (uint32_t i = 0; i < ndec; ++i) {
     uint64_t k = r.varint();
-    if (!r.ok || m.atts.size() + k > DSA_MAX_ATT) return bad(ST_INVALID);
+    if (!r.ok) return bad(ST_INVALID);
+    if (m.atts.size() + k > DSA_MAX_ATT) return bad(ST_NOTIMPL);
     size_t first = m.atts.size();
     for (uint64_t j = 0; j < k; ++j) {
       HostAttr a;

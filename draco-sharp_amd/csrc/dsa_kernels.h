@@ -300,7 +300,7 @@ __global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayou
     REQUIRE(r.ok && nf >= nsym && nf <= nsym + nsym / 3, 113);
     uint64_t nsplit_sym = r.varint();
     REQUIRE(r.ok && nsplit_sym <= nsym, 114);
-    REQUIRE(nad <= DSA_MAX_ATT_DATA, 115);
+    if (nad > DSA_MAX_ATT_DATA) NOTIMPL(115);
     D->num_enc_vertices = (uint32_t)nv; D->num_faces = (uint32_t)nf; D->num_att_data = (uint8_t)nad;
     D->num_symbols = (uint32_t)nsym; D->num_split_symbols = (uint32_t)nsplit_sym;
     REQUIRE(nf == L.cap_faces && nv + nsplit_sym == L.cap_vertices, 116);   // host sizing must agree
@@ -332,7 +332,8 @@ __global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayou
   // attribute section, ConnectivityDecoder.cs:16-44
   D->off_attributes = r.pos;
   uint32_t ndec = r.u8();
-  REQUIRE(r.ok && ndec <= DSA_MAX_ATT, 122);
+  REQUIRE(r.ok, 122);
+  if (ndec > DSA_MAX_ATT) NOTIMPL(122);
   D->num_decoders = ndec;
   int att_data_of[DSA_MAX_ATT];
   bool pos_seen = false;
@@ -359,7 +360,9 @@ __global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayou
   for (uint32_t i = 0; i < ndec; ++i) {           // AttributesDecoder.cs:19-63 + controller :16-27
     first_att[i] = natt;
     uint64_t k = r.varint();
-    REQUIRE(r.ok && natt + k <= DSA_MAX_ATT && natt + k <= L.cap_attributes, 129);
+    REQUIRE(r.ok, 129);
+    if (natt + k > DSA_MAX_ATT) NOTIMPL(129);
+    REQUIRE(natt + k <= L.cap_attributes, 129);
     for (uint32_t j = 0; j < (uint32_t)k; ++j) {
       AttrDesc &a = D->att[natt + j];
       a.att_type = (uint8_t)r.u8(); a.data_type = (uint8_t)r.u8(); a.nc = (uint8_t)r.u8(); a.normalized = r.u8() != 0;

@@ -3,8 +3,8 @@
 #pragma once
 #include <stdint.h>
 
-#define DSA_MAX_ATT 8        // attributes per mesh on the device path
-#define DSA_MAX_ATT_DATA 7   // non-position connectivity data (num_attribute_data)
+#define DSA_MAX_ATT 16       // attributes per mesh on the device path
+#define DSA_MAX_ATT_DATA 15  // non-position connectivity data (num_attribute_data)
 #define DSA_INVALID 0xFFFFFFFFu
 
 // status codes written by kernels (== dsa_status for 0..2)

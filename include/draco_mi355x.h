@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define DSA_ABI_VERSION 1
-#define DSA_MAX_ATTRIBUTES 8   /* attributes per mesh handled by the device path */
+#define DSA_MAX_ATTRIBUTES 16  /* attributes per mesh handled by the device path; more: DSA_ERR_NOT_IMPLEMENTED */
 #define DSA_NUM_STAGES 8
 
 typedef enum dsa_status {

@@ -68,3 +68,25 @@ def with_metadata(stream, attribute_elements, file_element):
         block += _varint(att_id) + e
     block += file_element
     return bytes(s[:11]) + bytes(block) + bytes(s[11:]), bytes(block)
+
+
+def raw_point_cloud_stream(num_points, attributes, seed=0):
+    """A sequential point cloud written by hand (DracoDecoder.cs:44-64 header, PointCloud sequential decoder,
+    AttributesDecoder.cs:19-63 descriptors, SequentialAttributeDecoder.cs:75-86 raw values): one attributes decoder,
+    every attribute a generic one (decoder type 0) whose values are stored as they are.
+    attributes = [(attribute type, data type id, components)]; returns (stream, [value arrays])."""
+    import numpy as np
+    dtypes = {1: np.int8, 2: np.uint8, 3: np.int16, 4: np.uint16, 5: np.int32, 6: np.uint32, 9: np.float32}
+    rng = np.random.default_rng(seed)
+    out = bytearray(b"DRACO") + bytes([2, 2, 0, 0, 0, 0]) + int(num_points).to_bytes(4, "little") + bytes([1])
+    out += _varint(len(attributes))
+    for uid, (att_type, data_type, nc) in enumerate(attributes):
+        out += bytes([att_type, data_type, nc, 0]) + _varint(uid)
+    out += bytes([0] * len(attributes))
+    values = []
+    for att_type, data_type, nc in attributes:
+        dt = np.dtype(dtypes[data_type])
+        v = (rng.integers(0, 200, (num_points, nc)).astype(dt) if dt.kind != "f" else rng.uniform(-1, 1, (num_points, nc)).astype(dt))
+        values.append(v)
+        out += v.tobytes()
+    return bytes(out), values

@@ -445,3 +445,25 @@ def test_randomised_options_agree_with_the_oracle(ctx):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     import soak
     assert soak.run(120, 7, ctx) == []
+
+
+def test_many_attributes(ctx):
+    """Up to 16 attributes per stream decode on the device path; more is DSA_ERR_NOT_IMPLEMENTED, not invalid data."""
+    from meshutil import raw_point_cloud_stream
+    kinds = [(0, 9, 3), (1, 9, 3), (2, 2, 4), (3, 9, 2), (3, 9, 2), (4, 4, 4), (4, 9, 4), (4, 6, 1), (4, 1, 2), (4, 3, 3), (2, 2, 3), (4, 5, 1)]
+    ok12, vals12 = raw_point_cloud_stream(333, kinds, 1)
+    ok16, vals16 = raw_point_cloud_stream(100, (kinds * 2)[:16], 2)
+    too_many, _ = raw_point_cloud_stream(50, (kinds * 2)[:17], 3)
+    b = run_batch(ctx, [ok12, too_many, ok16])
+    assert b.status(1) == 2                                    # DSA_ERR_NOT_IMPLEMENTED
+    with pytest.raises(NotImplementedError):
+        b.result(1)
+    for i, (sbytes, vals) in ((0, (ok12, vals12)), (2, (ok16, vals16))):
+        assert b.status(i) == 0, (i, b.status(i), b.mesh_info(i).detail)
+        ref = oracle.decode(sbytes)
+        d = b.result(i)
+        assert isinstance(d.ConnectedData, dsa.PointCloud) and len(d.ConnectedData.Attributes) == len(vals)
+        assert_same_attributes(d.ConnectedData, ref)
+        for a, v in zip(d.ConnectedData.Attributes, vals):
+            assert a.Values.dtype == v.dtype and np.array_equal(a.Values, v)
+    b.close()

@@ -8,5 +8,5 @@ for _ in range(2): b.decode()
 print({k: round(v,2) for k,v in b.stage_times().items()})
 d = np.array([b.debug_array(i,4,np.uint32,12) for i in range(0,n,max(1,n//16))])
 print("dbg clocks (median over sampled meshes) x1e6:", np.round(np.median(d,axis=0)/1e6,2)); print("raw median:", np.median(d,axis=0).astype(int).tolist())
-a = np.array([b.debug_array(i,5,np.uint32,32)[:12].reshape(3,4) for i in range(0,n,max(1,n//8))])
+a = np.array([b.debug_array(i,5,np.uint32,64)[:12].reshape(3,4) for i in range(0,n,max(1,n//8))])
 print("attr (source, nsym, precision, rans bytes) mesh0:", a[0].tolist()); print("nsym range per attr:", a[:,:,1].min(0), a[:,:,1].max(0))
