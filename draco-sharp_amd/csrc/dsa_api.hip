@@ -108,29 +108,51 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
   }
   cur = align_up(cur + 1024, 256);   // window over-read slack behind the last stream
   const uint64_t streams_end = cur;
-  for (uint32_t i = 0; i < n; ++i) {
-    HostMesh &h = b->host[i];
-    host_parse(streams[i], lengths[i], h, all_general);
-    MeshLayout &L = b->layouts[i];
-    if (h.status != 0) { h.faces = 0; h.enc_vertices = 0; h.split_symbols = 0; h.splits = 0; h.atts.clear(); h.general = false; }
-    const uint64_t F = h.faces, V = (uint64_t)h.enc_vertices + h.split_symbols;
-    cur = layout_mesh(h, lengths[i], L, cur, 16);
-    b->max_faces = std::max<uint32_t>(b->max_faces, (uint32_t)F);
-    b->max_vertices = std::max<uint32_t>(b->max_vertices, (uint32_t)V);
-    b->max_atts = std::max<uint32_t>(b->max_atts, (uint32_t)h.atts.size());
-    b->max_att_data = std::max<uint32_t>(b->max_att_data, h.num_att_data);
-    b->any_general = b->any_general || h.general;
+  for (uint32_t i = 0; i < n; ++i) host_parse(streams[i], lengths[i], b->host[i], all_general);
+  // Regions of every mesh behind the streams.  When the arena does not fit the device, the mesh with the largest
+  // claim is set aside (per-mesh DSA_ERR_OUT_OF_MEMORY: a header may claim far more elements than its stream can
+  // carry) and the rest is laid out again, so that one stream cannot take the batch down.
+  hipError_t e = hipSuccess;
+  std::vector<uint64_t> claim(n, 0);
+  for (;;) {
+    cur = streams_end;
+    b->max_faces = b->max_vertices = b->max_atts = b->max_att_data = 0;
+    b->any_general = false;
+    for (uint32_t i = 0; i < n; ++i) {
+      HostMesh &h = b->host[i];
+      MeshLayout &L = b->layouts[i];
+      if (h.status != 0) { h.faces = 0; h.enc_vertices = 0; h.split_symbols = 0; h.splits = 0; h.atts.clear(); h.general = false; }
+      const uint64_t F = h.faces, V = (uint64_t)h.enc_vertices + h.split_symbols, before = cur;
+      const uint64_t stream_off = L.stream;
+      const uint32_t stream_len = L.stream_len;
+      memset(&L, 0, sizeof(L));
+      L.stream = stream_off; L.stream_len = stream_len;
+      cur = layout_mesh(h, lengths[i], L, cur, 16);
+      claim[i] = cur - before;
+      b->max_faces = std::max<uint32_t>(b->max_faces, (uint32_t)F);
+      b->max_vertices = std::max<uint32_t>(b->max_vertices, (uint32_t)V);
+      b->max_atts = std::max<uint32_t>(b->max_atts, (uint32_t)h.atts.size());
+      b->max_att_data = std::max<uint32_t>(b->max_att_data, h.num_att_data);
+      b->any_general = b->any_general || h.general;
+    }
+    // pool for the cumulative tables of large-alphabet streams (bump-allocated by k_locate)
+    {
+      uint64_t streams_total = 0;
+      for (uint32_t i = 0; i < n; ++i) streams_total += b->layouts[i].cap_attributes;
+      b->globals.pool = cur;
+      b->globals.pool_bytes = (64ull << 20) + 8192ull * streams_total;
+      cur = align_up(cur + b->globals.pool_bytes, 256);
+    }
+    b->arena_bytes = cur;
+    e = hipMalloc((void **)&b->arena, b->arena_bytes ? b->arena_bytes : 256);
+    if (e == hipSuccess) break;
+    (void)hipGetLastError();
+    b->arena = nullptr;
+    uint32_t worst = 0;
+    for (uint32_t i = 1; i < n; ++i) if (claim[i] > claim[worst]) worst = i;
+    if (n == 0 || b->host[worst].status != 0 || claim[worst] <= (64ull << 20)) break;   // nothing left to set aside: the batch itself is too large
+    b->host[worst].status = DSA_ERR_OUT_OF_MEMORY;
   }
-  // pool for the cumulative tables of large-alphabet streams (bump-allocated by k_locate)
-  {
-    uint64_t streams_total = 0;
-    for (uint32_t i = 0; i < n; ++i) streams_total += b->layouts[i].cap_attributes;
-    b->globals.pool = cur;
-    b->globals.pool_bytes = (64ull << 20) + 8192ull * streams_total;
-    cur = align_up(cur + b->globals.pool_bytes, 256);
-  }
-  b->arena_bytes = cur;
-  hipError_t e = hipMalloc((void **)&b->arena, b->arena_bytes ? b->arena_bytes : 256);
   if (e != hipSuccess) { uint64_t need = b->arena_bytes; delete b; return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "hipMalloc of %llu-byte arena failed: %s", (unsigned long long)need, hipGetErrorString(e)); }
   e = hipMalloc((void **)&b->d_layouts, sizeof(MeshLayout) * (n ? n : 1));
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_descs, sizeof(MeshDesc) * (n ? n : 1));
@@ -362,6 +384,7 @@ dsa_status dsa_batch_wait(dsa_batch *b) {
   // regions, so the kernels stop at the first capacity check: the verdict is the host's
   for (uint32_t i = 0; i < b->n; ++i)
     if (b->host[i].status == ST_NOTIMPL && b->descs[i].status != ST_OK) { b->descs[i].status = ST_NOTIMPL; b->descs[i].detail = 129; }
+    else if (b->host[i].status == DSA_ERR_OUT_OF_MEMORY) { b->descs[i].status = DSA_ERR_OUT_OF_MEMORY; b->descs[i].detail = 0; }   // set aside by build_batch
   b->collected = true;
   // second chance: meshes whose prediction schemes need the general path's tables (the fast kernels find that out
   // only behind the symbol streams, where the host parse does not go)

@@ -467,3 +467,27 @@ def test_many_attributes(ctx):
         for a, v in zip(d.ConnectedData.Attributes, vals):
             assert a.Values.dtype == v.dtype and np.array_equal(a.Values, v)
     b.close()
+
+
+def test_oversized_claims_are_set_aside_not_the_batch(ctx):
+    """Headers may claim far more elements than their bytes can carry (the sizing parse allows 1024 per byte, rANS can
+    go that low).  When the arena of a batch does not fit the device, the largest claimants get a per-mesh
+    DSA_ERR_OUT_OF_MEMORY and the rest of the batch decodes."""
+    from meshutil import _varint
+    nf, nv = 600_000_000, 300_000_000
+    head = (b"DRACO" + bytes([2, 2, 1, 1, 0, 0]) + bytes([0]) + _varint(nv) + _varint(nf) + bytes([0]) + _varint(nf) + _varint(0) + _varint(0) +
+            _varint(0) + bytes([128]) + _varint(0) +                      # no symbol bytes, empty start-face block
+            bytes([1, 0xFF, 0, 0]) + _varint(1) + bytes([0, 9, 3, 0]) + _varint(0) + bytes([2]))
+    hostile = head + bytes(1 << 20)                                        # 1 MiB of padding makes the claim admissible
+    pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 10, 8, 3)
+    good = synth.encode_mesh(pos, faces, nrm, uv)
+    streams = [good] + [hostile] * 8 + [good]
+    b = run_batch(ctx, streams)
+    st = [b.status(i) for i in range(len(streams))]
+    assert st[0] == 0 and st[-1] == 0
+    assert_same(b.result(0), oracle.decode(good))
+    assert set(st[1:-1]) <= {1, 5} and 5 in st[1:-1], st                   # set aside (5) or rejected by the device parse (1)
+    with pytest.raises(MemoryError):
+        b.result(1 + st[1:-1].index(5))
+    assert b.arena_bytes < 288 * (1 << 30)
+    b.close()
