@@ -1536,7 +1536,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
   if (L.out_cap[ai] < 4096 * 6 + REG_MAX_SYMS * 4) return;      // scratch for the tables (k_symbols<T> takes the stream instead)
   const uint8_t *stream = arena + L.stream;
   uint32_t *out = (uint32_t *)(arena + L.work[ai]);
-  uint32_t *slot_tab = (uint32_t *)(arena + L.out[ai]);            // {freq << 12 | rem - cum} per slot
+  uint32_t *slot_tab = (uint32_t *)(arena + L.out[ai]);            // {freq | (rem - cum) << 16} per slot
   uint16_t *slot_sym = (uint16_t *)(arena + L.out[ai] + 4096 * 4); // symbol per slot
   // probabilities, then packed {freq << 12 | cum} per symbol: global scratch rather than LDS, which the
   // connectivity and traversal waves sharing the CU need for their caches and tables
@@ -1570,7 +1570,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
   // 3. slot tables through the attribute's scratch: every symbol writes its own slots
   for (uint32_t sy = lane; sy < nsym; sy += WAVE) {
     const uint32_t e = lds[sy], f = e >> 12, c = e & 4095u;
-    for (uint32_t j = 0; j < f; ++j) { slot_tab[c + j] = (f << 12) | j; slot_sym[c + j] = (uint16_t)sy; }
+    for (uint32_t j = 0; j < f; ++j) { slot_tab[c + j] = f | (j << 16); slot_sym[c + j] = (uint16_t)sy; }   // {freq, rem - cum} as two 16-bit words (SDWA operands of the chain)
   }
   WAIT_VM0();
   __syncthreads();
@@ -1610,14 +1610,16 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
       if (!exhausted) {
         {
           // The 64 steps of a block are unrolled, so position J is parked in lane J with v_writelane (inline
-          // lane number) and there is no loop counter: 5 scalar + 6 vector instructions per symbol.  A step is
+          // lane number) and there is no loop counter: 4 scalar + 5 vector instructions per symbol.  A step is
           // entered by a computed jump (all steps have the same size), which is how decoding resumes at
           // position j after the reservoir was refilled.  The last block of a stream runs all 64 steps as well:
           // positions past the end decode whatever the state yields and are not stored.  The register-index window stays
           // open over the whole block (one s_set_gpr_idx_idx per step instead of an on/off pair): it indexes src1 only,
-          // and every other vector instruction of a step has a constant or an SGPR there.  v_writelane sits between the
-          // VALU write of the new state and its v_readlane (the wait state that hazard needs).
-          uint32_t k6, q, va, vf;
+          // and every other vector instruction of a step has a constant or an SGPR there.  The packed table word is
+          // consumed by two SDWA operations (freq = low word into the 24-bit multiply, rem - cum = high word into the add),
+          // both reading the indexed register directly.  v_writelane sits between the VALU write of the new state and
+          // its v_readlane (the wait state that hazard needs).
+          uint32_t k6, va, vf;
           uint32_t js = uni(j);
           asm volatile(
               " s_getpc_b64 s[22:23]\n"
@@ -1633,13 +1635,12 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
               "Lus\\J\\()_%=:\n"
               " s_cmpk_lt_u32 s21, 0x4000\n"
               " s_cbranch_scc1 Lur\\J\\()_%=\n"
+              "Lok\\J\\()_%=:\n"
               " s_bfe_u32 %[k6], s21, 0x60006\n"
-              " s_lshr_b32 %[q], s21, 12\n"
               " s_set_gpr_idx_idx %[k6]\n"
-              " v_or_b32_e32 %[va], 0, v16\n"
-              " v_bfe_u32 %[vf], %[va], 12, 20\n"
-              " v_and_b32_e64 %[va], %[va], %[m12]\n"
-              " v_mad_u32_u24 %[va], %[vf], %[q], %[va]\n"
+              " v_lshrrev_b32_e64 %[vf], 12, s21\n"
+              " v_mul_u32_u24_sdwa %[va], %[vf], v16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n"
+              " v_add_u32_sdwa %[va], %[va], v16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
               " v_writelane_b32 %[mine], s21, \\J\n"
               " v_readlane_b32 s21, %[va], s21\n"
               ".endr\n"
@@ -1650,7 +1651,9 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
               " s_sub_u32 %[rc], %[rc], 1\n"
               " s_cbranch_scc1 Lue\\J\\()_%=\n"
               " s_lshl_b64 s[20:21], s[20:21], 8\n"
-              " s_branch Lus\\J\\()_%=\n"
+              " s_cmpk_lt_u32 s21, 0x4000\n"
+              " s_cbranch_scc0 Lok\\J\\()_%=\n"
+              " s_branch Lur\\J\\()_%=\n"
               "Lue\\J\\()_%=:\n"
               " s_movk_i32 %[j], \\J\n"
               " s_branch Luempty%=\n"
@@ -1659,8 +1662,8 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
               " s_mov_b32 %[rc], 0\n"
               "Luend%=:\n"
               " s_set_gpr_idx_off\n"
-              : "+{s[20:21]}"(P), [rc] "+s"(rc), [j] "+s"(js), [mine] "+v"(mine), [k6] "=&s"(k6), [q] "=&s"(q), [va] "=&v"(va), [vf] "=&v"(vf)
-              : "{v[16:47]}"(tab_lo), "{v[48:79]}"(tab_hi), [m12] "s"(0xfffu)
+              : "+{s[20:21]}"(P), [rc] "+s"(rc), [j] "+s"(js), [mine] "+v"(mine), [k6] "=&s"(k6), [va] "=&v"(va), [vf] "=&v"(vf)
+              : "{v[16:47]}"(tab_lo), "{v[48:79]}"(tab_hi)
               : "vcc", "scc", "s22", "s23");
           j = js;
         }
@@ -1682,7 +1685,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
         const uint32_t k5 = (xs >> 6) & 31u, l6 = xs & 63u;
         const uint32_t e0 = rdlane(tab_lo[k5], l6), e1 = rdlane(tab_hi[k5], l6);
         const uint32_t e = (xs & 2048u) ? e1 : e0;
-        P = (uint64_t)((e >> 12) * (xs >> 12) + (e & 4095u)) << 32;
+        P = (uint64_t)((e & 0xFFFFu) * (xs >> 12) + (e >> 16)) << 32;
         ++j;
       }
     }
