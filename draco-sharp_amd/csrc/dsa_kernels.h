@@ -1598,10 +1598,13 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
   //     single s_lshl_b64 of the pair (the stream is consumed from its tail, so an aligned little-endian
   //     dword holds the next 4 bytes most-significant first);
   //   * both halves of the slot table are read under one s_set_gpr_idx_on and selected by bit 11;
-  //   * the block leaves to C only to refill the reservoir (once per 4 bytes) or when 64 positions are done.
+  //   * the block refills the reservoir itself (v_readlane from the 256-byte window in W) and leaves to C only for a new
+  //     window, the unaligned first / last bytes of the stream, or when 64 positions are done.
   // The tables are pinned to v[16:79] so that the indexed v_mov can name their first register.
   uint64_t P = (uint64_t)x << 32;
   uint32_t rc = 0;                             // valid bytes in the reservoir (top-aligned in P's low dword)
+  uint32_t dl = 0;                             // dword of the window the reservoir came from: the block refills itself from
+                                               // the dword below it (whole dwords, same 256-byte window) and leaves to C otherwise
   bool exhausted = false;
   for (uint32_t i0 = 0; i0 < num_values; i0 += WAVE) {
     const uint32_t cnt = uni(num_values - i0 < WAVE ? num_values - i0 : WAVE);
@@ -1655,6 +1658,18 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
               " s_cbranch_scc0 Lok\\J\\()_%=\n"
               " s_branch Lur\\J\\()_%=\n"
               "Lue\\J\\()_%=:\n"
+              " s_cmp_lt_u32 %[off], 4\n"
+              " s_cbranch_scc1 Lsl\\J\\()_%=\n"
+              " s_sub_u32 %[dl], %[dl], 1\n"
+              " s_cbranch_scc1 Lsl\\J\\()_%=\n"
+              " v_readlane_b32 s20, %[W], %[dl]\n"
+              " s_sub_u32 %[off], %[off], 4\n"
+              " s_mov_b32 %[rc], 3\n"
+              " s_lshl_b64 s[20:21], s[20:21], 8\n"
+              " s_cmpk_lt_u32 s21, 0x4000\n"
+              " s_cbranch_scc0 Lok\\J\\()_%=\n"
+              " s_branch Lur\\J\\()_%=\n"
+              "Lsl\\J\\()_%=:\n"
               " s_movk_i32 %[j], \\J\n"
               " s_branch Luempty%=\n"
               ".endr\n"
@@ -1662,8 +1677,9 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
               " s_mov_b32 %[rc], 0\n"
               "Luend%=:\n"
               " s_set_gpr_idx_off\n"
-              : "+{s[20:21]}"(P), [rc] "+s"(rc), [j] "+s"(js), [mine] "+v"(mine), [k6] "=&s"(k6), [va] "=&v"(va), [vf] "=&v"(vf)
-              : "{v[16:47]}"(tab_lo), "{v[48:79]}"(tab_hi)
+              : "+{s[20:21]}"(P), [rc] "+s"(rc), [j] "+s"(js), [mine] "+v"(mine), [k6] "=&s"(k6), [va] "=&v"(va), [vf] "=&v"(vf),
+                [off] "+s"(off), [dl] "+s"(dl)
+              : "{v[16:47]}"(tab_lo), "{v[48:79]}"(tab_hi), [W] "v"(W)
               : "vcc", "scc", "s22", "s23");
           j = js;
         }
@@ -1676,6 +1692,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
             const uint32_t res = rdlane(W, d & 63u) << (8 * (4 - r));
             rc = uni(r < off ? r : off);
             off -= rc;
+            dl = uni(d & 63u);
             P = (P & 0xFFFFFFFF00000000ull) | res;
           }
         }
