@@ -1830,6 +1830,8 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
     const bool small_m = M < (1u << 25);
     const float inv_m = 1.0f / (float)M;
     uint32_t p0 = 0;
+    int32_t last[4] = {0, 0, 0, 0};
+    bool have_last = false;
     while (p0 < entries) {
       const uint32_t p = p0 + lane;
       const bool live = p < entries;
@@ -1852,6 +1854,9 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
       int32_t corr[4], g[4], o[4];
       uint32_t xr[4];
       bool irregular = false;
+      // lane 0's base is usually the value the previous step ended on: it is carried in `last` instead of being
+      // read back from memory behind that step's store
+      const bool base_from_mem = lane == 0 && bidx != DSA_INVALID && !(have_last && bidx == p0 - 1);
 #pragma unroll
       for (uint32_t c = 0; c < 4; ++c) {
         corr[c] = 0; g[c] = 0; o[c] = 0; xr[c] = 0;
@@ -1861,7 +1866,8 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
           if (ga != DSA_INVALID) g[c] = (int32_t)((uint32_t)w[ga * nc + c] - (uint32_t)w[gb * nc + c]);
         }
         // lane 0: the reference's step from memory operands (exact whatever happens to the rest of the run)
-        const int32_t base0 = (lane == 0 && bidx != DSA_INVALID) ? w[bidx * nc + c] : 0;
+        int32_t base0 = base_from_mem ? w[bidx * nc + c] : 0;
+        if (lane == 0 && bidx != DSA_INVALID && !base_from_mem) base0 = last[c];
         const int32_t o0 = wrap_original((int32_t)((uint32_t)base0 + (uint32_t)g[c]), corr[c], mn, mx, max_dif);
         if (lane == 0) {
           o[c] = o0;
@@ -1919,6 +1925,9 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
 #pragma unroll
         for (uint32_t c = 0; c < 4; ++c) if (c < nc) w[p * nc + c] = o[c];
       }
+#pragma unroll
+      for (uint32_t c = 0; c < 4; ++c) last[c] = (int32_t)rdlane((uint32_t)o[c], run - 1);
+      have_last = true;
       p0 += run;
     }
     (void)para_mode;
