@@ -1124,6 +1124,8 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   uint32_t window = WAVE, side1 = WAVE, side2 = WAVE;
   uint32_t n_run = 0, n_run_faces = 0, n_scalar = 0, n_fail = 0;
   bool failed = false;
+  bool carry = false;         // (v, rc, lc) of the current corner handed over by the run that ended on it
+  uint32_t c_v = 0, c_rc = 0, c_lc = 0;
 #ifdef DSA_TRAV_HIST
   uint32_t hist[6] = {0, 0, 0, 0, 0, 0}, hist_len[6] = {0, 0, 0, 0, 0, 0}, why0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, whyK[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -1160,11 +1162,17 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
 
     for (;;) {   // DepthFirstTraverser.cs:39-97 inner loop
       const uint32_t face = corner >> 2;
-      const uint4 vv0 = ((const uint4 *)frec)[(size_t)face * 2], oo0 = ((const uint4 *)frec)[(size_t)face * 2 + 1];
-      const uint32_t kc0 = corner & 3u;
-      const uint32_t v = uni(kc0 == 0 ? vv0.x : (kc0 == 1 ? vv0.y : vv0.z));
-      const uint32_t rc = uni(kc0 == 0 ? oo0.y : (kc0 == 1 ? oo0.z : oo0.x));
-      const uint32_t lc = uni(kc0 == 0 ? oo0.z : (kc0 == 1 ? oo0.x : oo0.y));
+      uint32_t v, rc, lc;
+      if (carry) {             // the record of this corner was lane K's in the run that just ended: no read
+        v = c_v; rc = c_rc; lc = c_lc;
+        carry = false;
+      } else {
+        const uint4 vv0 = ((const uint4 *)frec)[(size_t)face * 2], oo0 = ((const uint4 *)frec)[(size_t)face * 2 + 1];
+        const uint32_t kc0 = corner & 3u;
+        v = uni(kc0 == 0 ? vv0.x : (kc0 == 1 ? vv0.y : vv0.z));
+        rc = uni(kc0 == 0 ? oo0.y : (kc0 == 1 ? oo0.z : oo0.x));
+        lc = uni(kc0 == 0 ? oo0.z : (kc0 == 1 ? oo0.x : oo0.y));
+      }
       if (v >= NV || (rc != DSA_INVALID && !corner_ok(rc)) || (lc != DSA_INVALID && !corner_ok(lc))) TR_FAIL(301);
       // tip flag and the state of both sides, issued together (the scalar step needs them as well)
       const uint32_t tip_flag = vflag[v];
@@ -1340,7 +1348,13 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
           fail_streak = 0;
           // Pair K lies on the verified path but is not an (N L) pair (a turn of the spiral, a boundary
           // vertex, a split): re-attempting from it would reach the same verdict, so step over it first.
-          if (K < WAVE && len > K) { backoff = 1; have_step = false; }
+          if (K < WAVE && len > K) {
+            backoff = 1; have_step = false;
+            // pair K was loaded and its link verified: its corner is where the DFS stands now, and its tip and the
+            // corners behind its two other edges are what the next iteration would read first
+            c_v = rdlane(tipA, K); c_rc = rdlane(b, K); c_lc = rdlane(lcA, K);
+            carry = true;
+          }
           if ((fuse_operands & 2u) && K < window && len > K) { side2 = side1; side1 = K; const uint32_t m = (side1 > side2 ? side1 : side2) + 4; window = m < WAVE ? m : WAVE; }
           else window = WAVE;
           continue;
