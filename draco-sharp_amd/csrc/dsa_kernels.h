@@ -1214,7 +1214,14 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
         } else {
           // two exact hops (four dependent record loads) seed the step and its change; the links of the
           // extrapolated path are verified from the loaded records anyway
-          const uint32_t a1 = succ(a0), a2 = succ(a1);
+          // Opposite(Next(a0)) is `rc`, read by the head of this iteration: the first hop needs one read, not two
+          auto succ_b = [&](uint32_t b1) -> uint32_t {
+            if (!corner_ok(b1)) return DSA_INVALID;
+            const uint4 o2 = ((const uint4 *)frec)[(size_t)(b1 >> 2) * 2 + 1];
+            const uint32_t k2 = b1 & 3u;
+            return uni(k2 == 0 ? o2.z : (k2 == 1 ? o2.x : o2.y));
+          };
+          const uint32_t a1 = succ_b(rc), a2 = succ(a1);
           const int64_t d1 = (int64_t)a1 - a0, d2 = (int64_t)a2 - a1;
           const int64_t ddh = d2 - d1;
           const int64_t i = lane;
