@@ -41,6 +41,33 @@ def cpu_baseline(blob, offsets, budget_s=12.0, max_meshes=1024):
             "host_cores_available": os.cpu_count()}
 
 
+def issue_roofline(meshes, triangles, shader_clocks, kernel_ms, step_ms):
+    """The roofline the step actually sits under: instruction issue.  Instruction counts per decode come from the
+    committed PMC pass (profiles/r01_final_sq_counters.txt, same workload); the shader clock is measured live (clocks
+    one traversal wave counted with s_memtime / that kernel's duration).  256 scalar units issue one instruction per
+    cycle; 1024 SIMD16 pipes take four cycles per wave64 vector instruction."""
+    import ast
+    path = os.path.join(ROOT, "profiles", "r01_final_sq_counters.txt")
+    if meshes != 4096 or triangles != 65536 or not shader_clocks or not kernel_ms:
+        return None
+    try:
+        salu = valu = 0.0
+        for line in open(path):
+            name, d = line.split(" {", 1)
+            if not (name.startswith("k_") or name.startswith("void k_")):
+                continue
+            d = ast.literal_eval("{" + d)
+            launches = 2 if name in ("k_predict", "k_finalize") else 1
+            salu += float(d["SQ_INSTS_SALU"]) * launches
+            valu += float(d["SQ_INSTS_VALU"]) * launches
+    except (OSError, KeyError, ValueError, SyntaxError):
+        return None
+    clock_hz = shader_clocks / (kernel_ms * 1e-3)
+    slots = 256 * clock_hz * step_ms * 1e-3
+    return {"bound": "instruction issue", "shader_clock_ghz": clock_hz / 1e9, "scalar_instructions": salu, "vector_instructions": valu,
+            "scalar_frac": salu / slots, "vector_frac": 4 * valu / (4 * slots), "source": "profiles/r01_final_sq_counters.txt"}
+
+
 def measured_traffic(kernel, meshes, triangles):
     """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on
     this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None if the committed
@@ -154,6 +181,11 @@ def main():
                          "kernel_ms": kernel_stages[dom], "algorithmic_bytes": alg_bytes},
             "setup_s": {"generate": t_gen, "upload_and_layout": t_upload},
         }
+        # shader clocks of the traversal kernel (debug array 4, slot 6), median over a sample of meshes
+        clocks = sorted(int(batch.debug_array(i, 4, np.uint32, 12)[6]) for i in range(0, args.meshes, max(1, args.meshes // 32)))
+        issue = issue_roofline(args.meshes, 2 * nx * ny, clocks[len(clocks) // 2], stages.get("traverse"), stages.get("total"))
+        if issue:
+            out["issue_roofline"] = issue
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(blob, offsets)
         print(json.dumps(out))
