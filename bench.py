@@ -93,6 +93,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if not all(os.path.exists(os.path.join(ROOT, *f)) for f in (("draco-sharp_amd", "csrc", "libdraco_mi355x.so"),
+                                                              ("draco-sharp_amd", "synth", "libdsa_synth.so"), ("oracle", "liboracle.so"))):
+        libs = [os.path.join(ROOT, *f) for f in (("draco-sharp_amd", "csrc", "libdraco_mi355x.so"), ("draco-sharp_amd", "synth", "libdsa_synth.so"),
+                                                 ("oracle", "liboracle.so"))]
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:      # a fresh checkout: build in-tree first (the harness, not the product, does this)
+            import __graft_entry__
+            __graft_entry__.build()
+        else:                                                # the other ranks of the node wait for rank 0's build
+            deadline = time.time() + 600
+            while not all(os.path.exists(f) for f in libs) and time.time() < deadline:
+                time.sleep(1.0)
+            time.sleep(2.0)
     import numpy as np
     import torch
     import draco_sharp_amd as dsa
