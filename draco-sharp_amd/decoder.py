@@ -365,6 +365,42 @@ class Batch:
             return Draco(DracoHeader(info), PointCloud(atts, info.num_points), metadata)
         return Draco(DracoHeader(info), Mesh(atts, info.num_points, faces), metadata)
 
+    def device_views(self, i):
+        """Zero-copy views of mesh i's results in the batch arena (dsa_batch_device_*), for consumers that stay on the
+        GPU: {"faces": int32[F, 3] point ids, "attributes": [{"values": [entries, components], "point_map": uint32 as
+        int32[points]}]} as torch tensors on the context's device.  Valid until the batch is closed or decoded again.
+        (torch.cuda must have been initialised before the first Context of the process: its bundled HIP runtime does
+        not come up behind the library's.)"""
+        import torch
+        L = self._L
+        info = self.mesh_info(i)
+        if info.status != 0:
+            _raise(info.status, "stream %d: decode failed (status %d, site %d)" % (i, info.status, info.detail))
+
+        class _Ptr:                                    # __cuda_array_interface__ v2 carrier
+            def __init__(self, ptr, shape, typestr):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+        def view(ptr, shape, typestr):
+            if ptr is None or 0 in shape:
+                return torch.empty(shape, dtype=torch.int32 if typestr == "<i4" else None, device="cuda:%d" % self.ctx.device)
+            return torch.as_tensor(_Ptr(ptr, shape, typestr), device="cuda:%d" % self.ctx.device)
+
+        typestr = {1: "|i1", 2: "|u1", 3: "<i2", 4: "<u2", 5: "<i4", 6: "<u4", 9: "<f4"}
+        out = {"faces": view(L.dsa_batch_device_faces(self._h, i), (info.num_faces, 3), "<i4"), "attributes": []}
+        for a in range(info.num_attributes):
+            ai = native.AttributeInfo()
+            st = L.dsa_batch_attribute_info(self._h, i, a, C.byref(ai))
+            if st != 0:
+                _raise(st, self.ctx.error())
+            ts = typestr.get(ai.data_type)
+            if ts in (None, "<u2", "<u4"):           # torch has no unsigned 16 / 32 bit tensors: same bits, signed view
+                ts = {"<u2": "<i2", "<u4": "<i4"}.get(ts)
+            values = view(L.dsa_batch_device_attribute_values(self._h, i, a), (ai.num_entries, ai.num_components), ts) if ts else None
+            pmap = view(L.dsa_batch_device_point_map(self._h, i, a), (info.num_points,), "<i4")
+            out["attributes"].append({"values": values, "point_map": pmap})
+        return out
+
     def close(self):
         if self._h:
             self._L.dsa_batch_free(self._h)

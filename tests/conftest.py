@@ -20,6 +20,14 @@ def pytest_configure(config):
     if not all(os.path.exists(f) for f in needed):
         import __graft_entry__
         __graft_entry__.build()
+    # torch's bundled HIP runtime has to come up before the library's (the other order leaves torch without a GPU):
+    # the device-view test wraps arena pointers as torch tensors
+    try:
+        import torch
+        if torch.cuda.device_count() > 0:
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -491,3 +491,27 @@ def test_oversized_claims_are_set_aside_not_the_batch(ctx):
         b.result(1 + st[1:-1].index(5))
     assert b.arena_bytes < 288 * (1 << 30)
     b.close()
+
+
+def test_device_views_are_the_results_without_a_copy(ctx):
+    """dsa_batch_device_faces / _attribute_values / _point_map: pointers into the batch arena for consumers that stay on
+    the GPU (a renderer, a torch pipeline).  Wrapped as torch tensors they must hold what the copy calls return."""
+    import torch
+    streams = []
+    for kind, nx, ny, opt in ((synth.TORUS, 12, 9, {}), (synth.HOLES, 20, 16, {"predictive_connectivity": 2, "normal_prediction": 6})):
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 17)
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(**opt)))
+    b = run_batch(ctx, streams)
+    for i in range(len(streams)):
+        m = b.result(i).ConnectedData
+        dv = b.device_views(i)
+        assert dv["faces"].is_cuda and dv["faces"].dtype == torch.int32
+        assert np.array_equal(dv["faces"].cpu().numpy(), m.Faces)
+        for a, d in zip(m.Attributes, dv["attributes"]):
+            assert np.array_equal(d["values"].cpu().numpy().view(a.Values.dtype), a.Values)
+            assert np.array_equal(d["point_map"].cpu().numpy().view(np.uint32), a.PointMap)
+        # positions per point, gathered on the device
+        p = dv["attributes"][0]
+        per_point = p["values"][p["point_map"].long()]
+        assert np.array_equal(per_point.cpu().numpy(), m.Attributes[0].Values[m.Attributes[0].PointMap])
+    b.close()
