@@ -164,8 +164,9 @@ __device__ bool read_prob_table(Rd &r, uint32_t n, uint32_t *prob) {
   }
   return r.ok;
 }
-// Same walk without storing (k_locate only needs to know where the table ends).
-__device__ bool skip_prob_table(Rd &r, uint32_t n) {
+// Same walk without storing (k_locate only needs to know where the table ends); counts the non-zero frequencies.
+__device__ bool skip_prob_table(Rd &r, uint32_t n, uint32_t *distinct) {
+  uint32_t nz = 0;
   for (uint32_t i = 0; i < n; ++i) {
     uint32_t pd = r.u8();
     uint32_t token = pd & 3;
@@ -174,9 +175,12 @@ __device__ bool skip_prob_table(Rd &r, uint32_t n) {
       if (i + offset >= n) return false;
       i += offset;
     } else {
-      r.skip(token);
+      uint32_t pr = pd >> 2;
+      for (uint32_t k = 0; k < token; ++k) pr |= r.u8() << (8 * (k + 1) - 2);
+      nz += pr != 0;
     }
   }
+  *distinct = nz;
   return r.ok;
 }
 __device__ __forceinline__ uint32_t rans_precision_bits(uint32_t max_bit_length) {   // Entropy/RAnsSymbolCoding.cs:10-27
@@ -192,6 +196,34 @@ __device__ __forceinline__ uint32_t data_type_length(uint32_t dt) {   // Constan
     case 7: case 8: case 10: return 8;
     default: return 0;
   }
+}
+
+// Internal corner ids are "quad coded": corner k of face f is 4*f + k (face = c >> 2, k = c & 3, no division), and a
+// face record is 32 bytes: {v0, v1, v2, flags, o0, o1, o2, 0} (vertices, opposite corners).
+__device__ __forceinline__ uint32_t qnext(uint32_t c) { return (c & 3u) == 2u ? c - 2u : c + 1u; }
+__device__ __forceinline__ uint32_t qprev(uint32_t c) { return (c & 3u) == 0u ? c + 2u : c - 1u; }
+__device__ __forceinline__ uint32_t fv_idx(uint32_t c) { return 2u * c - (c & 3u); }        // dword index of the vertex slot
+__device__ __forceinline__ uint32_t fo_idx(uint32_t c) { return 2u * c - (c & 3u) + 4u; }   // dword index of the opposite slot
+
+// Parallelogram operands of entry p (MeshPredictionSchemeParallelogramDecoder.cs:56-89):
+// para[3p..3p+2] = entries (next, prev, opposite), or next = INVALID when the entry falls back to delta.
+__device__ __forceinline__ void para_operands_of(uint32_t p, const uint32_t *frec, const uint32_t *d2c, const int32_t *v2d, uint32_t F, uint32_t NV, uint32_t *para) {
+  uint32_t en = DSA_INVALID, ep = 0, eo = 0;
+  if (p > 0) {
+    const uint32_t c0 = d2c[p];
+    const uint32_t oci = (c0 < 4 * F && (c0 & 3u) != 3u) ? frec[fo_idx(c0)] : DSA_INVALID;
+    if (oci != DSA_INVALID && oci < 4 * F && (oci & 3u) != 3u) {
+      const uint32_t *fr = frec + (size_t)(oci >> 2) * 8;
+      const uint32_t fx = fr[0], fy = fr[1], fz = fr[2];
+      const uint32_t k = oci & 3u;
+      const uint32_t a = k == 0 ? fx : (k == 1 ? fy : fz), b = k == 0 ? fy : (k == 1 ? fz : fx), c = k == 0 ? fz : (k == 1 ? fx : fy);
+      if (a < NV && b < NV && c < NV) {
+        const int32_t vo = v2d[a], vn = v2d[b], vp = v2d[c];
+        if (vo >= 0 && vn >= 0 && vp >= 0 && (uint32_t)vo < p && (uint32_t)vn < p && (uint32_t)vp < p) { en = (uint32_t)vn; ep = (uint32_t)vp; eo = (uint32_t)vo; }
+      }
+    }
+  }
+  para[3 * p] = en; para[3 * p + 1] = ep; para[3 * p + 2] = eo;
 }
 
 struct OctParams { int32_t max_q, center; };

@@ -1,0 +1,360 @@
+// draco-sharp_amd/csrc/dsa_lanes.h
+// Lane-per-chain kernels: the serial recurrences of the format that have no use for cross-lane help run with ONE
+// LANE PER CHAIN, 64 chains (of 64 different meshes) per wave.  The chip has 256 scalar units but 65 536 vector
+// lanes: a wave-per-mesh machine spends a scalar + a vector instruction stream on one chain, a lane-per-chain wave
+// spends one vector instruction stream on 64 of them, so these kernels take a few per cent of the issue slots
+// the wave-per-stream forms need and run at the latency of their dependent chain instead -- which is what bounds
+// a 4096-mesh batch either way.  What makes the chain short is kept on chip per lane:
+//   k_symbols_lanes   rANS (Entropy/RAnsDecoder.cs:20-99, RAnsSymbolDecoder.cs:21-59): per lane a 256-bucket
+//                     first-symbol LUT and the cumulative frequencies of the non-zero symbols in LDS (lane regions
+//                     at an odd dword stride: equal offsets of different lanes fall into different banks); one LUT
+//                     read + one batch of five cumulative reads per symbol, stream bytes through a per-lane dword
+//                     reservoir loaded one dword ahead, results stored four at a time.
+//   k_predict_lanes   PredictionSchemeDeltaDecoder.cs:23-37, MeshPredictionSchemeParallelogramDecoder.cs:29-54 with
+//                     PredictionSchemeWrapDecodingTransform.cs:46-75, and the octahedral delta
+//                     (PredictionSchemeNormalOctahedron(Canonicalized)DecodingTransform.cs): one lane per attribute,
+//                     operand indices and corrections loaded two entries ahead, the two latest results forwarded
+//                     in registers.
+// The per-lane bodies use no wave intrinsics, so tests/hostcheck compiles them for the host under ASan
+// (test infrastructure; the product has no host decode path).
+#pragma once
+#include <stdint.h>
+
+#include "dsa_common.h"
+#include "dsa_locate.h"
+
+namespace dsa {
+namespace lanes {
+
+// behaviour switches handed to the kernels (dsa_batch_decode reads them from the environment once; diagnostics)
+#define LN_FLAG_SYMBOLS 1u    // raw rANS streams that fit a tier are decoded by k_symbols_lanes
+#define LN_FLAG_PREDICT 2u    // prediction inverse by k_predict_lanes
+
+// ------------------------------------------------------------------------------------------------ rANS, lane per stream
+#define LN_MAX_PRECISION 15u          // cumulative frequencies are 16-bit in LDS (2^15 is the largest total)
+#define LN_T0_SYMS 120u               // tier 0: up to 120 non-zero symbols -> 772 B of LDS per lane (48 KB per wave)
+#define LN_T1_SYMS 440u               // tier 1: up to 440 non-zero symbols -> 1412 B per lane (88 KB per wave)
+#define LN_CUM_PAD 8u
+// bytes of one lane's LDS region: 256 x u16 LUT, (syms + pad) x u16 cumulative frequencies, + 4 so that the dword
+// stride between lanes is odd
+__host__ __device__ constexpr uint32_t ln_sym_stride(uint32_t syms) { return 512u + 2u * (syms + LN_CUM_PAD) + 4u; }
+
+__host__ __device__ __forceinline__ bool ln_sym_eligible(const AttrDesc &a, const MeshLayout &L, uint32_t ai, uint32_t flags) {
+  return (flags & LN_FLAG_SYMBOLS) && a.source == SRC_RAW && a.precision_bits <= LN_MAX_PRECISION && a.num_distinct >= 1 &&
+         a.num_distinct <= LN_T1_SYMS && a.num_entries != 0 && (uint64_t)L.out_cap[ai] >= 4ull * a.num_distinct;
+}
+
+// The stream is consumed from its tail (RAnsDecoder.cs:58-61: state = state * 256 + buf[--offset]).  Up to eight of
+// the next bytes wait top-aligned in a 64-bit reservoir (next byte = bits 63..56); every step loads the dword
+// below the reservoir's contents (address clamped to the start of the stream) and the step after merges it once four
+// bytes or fewer are left, so no load is ever waited for.  Pointers are arena + offset: the loads stay global_load.
+struct TailBytes {
+  const uint32_t *np;   // dword that `pend` was loaded from: the next one to enter the reservoir
+  const uint32_t *lo;   // lowest dword that may be read (start of the stream)
+  uint64_t res;
+  uint32_t have, pend;
+  __device__ __forceinline__ void init(const uint8_t *arena, uint64_t stream_off, uint32_t rans_off, uint32_t off) {
+    lo = (const uint32_t *)(arena + (stream_off & ~3ull));
+    res = 0; have = 0; np = lo; pend = 0;
+    if (off == 0) return;
+    const uint64_t last = stream_off + rans_off + off - 1;
+    const uint32_t *wp = (const uint32_t *)(arena + (last & ~3ull));
+    have = (uint32_t)(last & 3u) + 1u;
+    res = (uint64_t)(*wp << (8u * (4u - have))) << 32;
+    np = wp - 1;
+    pend = *(np < lo ? lo : np);
+  }
+  __device__ __forceinline__ void refill() {     // once per step, before bytes are taken
+    if (have <= 4) { res |= (uint64_t)pend << (32u - 8u * have); have += 4; --np; }
+    pend = *(np < lo ? lo : np);
+  }
+  __device__ __forceinline__ uint32_t take(uint32_t n) {   // n = 1..4 bytes, n <= have
+    const uint32_t b = (uint32_t)(res >> 32) >> (32u - 8u * n);
+    res <<= 8u * n; have -= n;
+    return b;
+  }
+};
+
+// Tables of one stream (RAnsSymbolDecoder.cs:21-59, RAnsDecoder.cs:69-88 restated as a search structure):
+//   symtab[k]  k-th symbol with a non-zero frequency (global scratch: read off the chain)
+//   cum[k]     its cumulative frequency; cum[distinct] = 2^P; LN_CUM_PAD entries of 0xFFFF behind it
+//   lut[b]     the k whose range holds slot b << (P - 8)
+// Returns 0, or the failure site.
+__device__ __forceinline__ int ln_sym_build(Rd &r, uint32_t nsym, uint32_t P, uint32_t cap, uint16_t *lut, uint16_t *cum, uint32_t *symtab) {
+  const uint32_t precision = 1u << P;
+  uint32_t k = 0, run = 0;
+  for (uint32_t i = 0; i < nsym; ++i) {
+    const uint32_t pd = r.u8(), token = pd & 3u;
+    if (token == 3u) {
+      const uint32_t offset = pd >> 2;
+      if (i + offset >= nsym) return 400;
+      i += offset;
+    } else {
+      uint32_t pr = pd >> 2;
+      for (uint32_t j = 0; j < token; ++j) pr |= r.u8() << (8 * (j + 1) - 2);
+      if (pr) {
+        if (k >= cap || pr > precision - run) return 401;
+        symtab[k] = i; cum[k] = (uint16_t)run;
+        run += pr; ++k;
+      }
+    }
+  }
+  if (!r.ok) return 400;
+  if (run != precision || k == 0) return 401;
+  cum[k] = (uint16_t)precision;
+  for (uint32_t j = 1; j < LN_CUM_PAD; ++j) cum[k + j] = 0xFFFFu;
+  const uint32_t sh = P - 8u;
+  uint32_t kk = 0;
+  for (uint32_t b = 0; b < 256u; ++b) {
+    const uint32_t slot = b << sh;
+    while (cum[kk + 1] <= slot) ++kk;
+    lut[b] = (uint16_t)kk;
+  }
+  return 0;
+}
+
+// RAnsDecoder.Read for every value of the stream (RAnsDecoder.cs:56-67) + zig-zag (BitUtilities.cs:94-103) unless the
+// transform's corrections are positive; out[] is 16-byte aligned.
+__device__ __forceinline__ void ln_sym_decode(const uint8_t *arena, uint64_t stream_off, uint32_t rans_off, uint32_t x, uint32_t off, uint32_t P,
+                                              const uint16_t *lut, const uint16_t *cum, const uint32_t *symtab, uint32_t num_values,
+                                              bool positive, int32_t *out) {
+  const uint32_t mask = (1u << P) - 1u, l_base = 4u << P, sh = P - 8u;
+  TailBytes tb;
+  tb.init(arena, stream_off, rans_off, off);
+  uint32_t pend0 = 0, pend1 = 0, pend2 = 0, sym_prev = 0;
+  auto emit = [&](uint32_t i, uint32_t v) {        // value i is complete
+    const uint32_t o = positive ? v : ((v & 1u) ? (uint32_t)(-(int32_t)(v >> 1) - 1) : (v >> 1));
+    const uint32_t q = i & 3u;
+    if (q == 0) pend0 = o;
+    else if (q == 1) pend1 = o;
+    else if (q == 2) pend2 = o;
+    else {
+#if defined(__HIPCC__)
+      *(uint4 *)(out + i - 3) = make_uint4(pend0, pend1, pend2, o);
+#else
+      out[i - 3] = (int32_t)pend0; out[i - 2] = (int32_t)pend1; out[i - 1] = (int32_t)pend2; out[i] = (int32_t)o;
+#endif
+    }
+  };
+  for (uint32_t i = 0; i < num_values; ++i) {
+    tb.refill();                                     // at least five bytes in the reservoir while the stream has them
+    {
+      // x >= 4 after a step (RAnsDecoder.cs:63-65 with x >= l_base before it), so two bytes reach l_base for P <= 15
+      uint32_t nb = (x < l_base ? 1u : 0u) + (x < (l_base >> 8) ? 1u : 0u);
+      nb = nb < off ? nb : off;
+      if (nb) { x = (x << (8u * nb)) | tb.take(nb); off -= nb; }
+      while (x < l_base && off > 0) {                // a state below 4: only behind an exhausted or malformed stream
+        if (tb.have == 0) tb.refill();
+        x = (x << 8) | tb.take(1); --off;
+      }
+    }
+    const uint32_t rem = x & mask;
+    uint32_t k = lut[rem >> sh];
+    const uint32_t c0 = cum[k], c1 = cum[k + 1], c2 = cum[k + 2], c3 = cum[k + 3], c4 = cum[k + 4];
+    uint32_t cs = c0, cn = c1;
+    if (rem >= c1) { ++k; cs = c1; cn = c2; }
+    if (rem >= c2) { ++k; cs = c2; cn = c3; }
+    if (rem >= c3) {
+      ++k; cs = c3; cn = c4;
+      while (rem >= cn) { ++k; cs = cn; cn = cum[k + 1]; }     // more than four range starts in one bucket: rare
+    }
+    x = (cn - cs) * (x >> P) + rem - cs;
+    // the symbol id is not on the chain: its load is consumed one value later
+    if (i > 0) emit(i - 1, sym_prev);
+    sym_prev = symtab[k];
+  }
+  emit(num_values - 1, sym_prev);
+  const uint32_t tail = num_values & 3u, base = num_values - tail;
+  if (tail >= 1) out[base] = (int32_t)pend0;
+  if (tail >= 2) out[base + 1] = (int32_t)pend1;
+  if (tail >= 3) out[base + 2] = (int32_t)pend2;
+}
+
+// One stream, start to finish (the body of a lane of k_symbols_lanes; tests/hostcheck calls it directly).
+__device__ __forceinline__ void ln_symbols_stream(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t cap, uint16_t *lds) {
+  const AttrDesc &a = D->att[ai];
+  const uint8_t *s = arena + L.stream;
+  uint16_t *lut = lds, *cum = lds + 256;
+  uint32_t *symtab = (uint32_t *)(arena + L.out[ai]);
+  Rd r(s, L.stream_len, a.off_table);
+  const int site = ln_sym_build(r, a.num_symbols, a.precision_bits, cap, lut, cum, symtab);
+  if (site) { fail(D, ST_INVALID, site); return; }
+  const uint8_t *buf = s + a.off_rans;
+  uint32_t x = 0, off = 0;
+  if (!rans_init(buf, a.size_rans, 4u << a.precision_bits, &x, &off)) { fail(D, ST_INVALID, 402); return; }
+  const bool positive = a.have_scheme && (a.pred_transform == 2 || a.pred_transform == 3);   // D-4
+  ln_sym_decode(arena, L.stream, a.off_rans, x, off, a.precision_bits, lut, cum, symtab, a.num_entries * a.nc_portable, positive, (int32_t *)(arena + L.work[ai]));
+}
+
+// ------------------------------------------------------------------------------------- prediction inverse, lane per attribute
+template <int NC>
+struct Vec { int32_t v[NC]; };
+
+// Difference / Parallelogram + wrap transform (PredictionSchemeDeltaDecoder.cs:23-37,
+// MeshPredictionSchemeParallelogramDecoder.cs:29-54, PredictionSchemeWrapDecodingTransform.cs:46-75), in place on
+// w[entries][NC]: corrections in, portable values out.  para[3p..3p+2] = entries (next, prev, opposite) of the
+// parallelogram of entry p, next = INVALID where the entry falls back to delta (para_operands_of); para == nullptr:
+// delta for every entry.  Software pipeline of depth one: while entry p is computed, the operands of entry p + 1
+// that are finished (index < p) and its correction are already on their way and the indices of entry p + 2 are
+// loaded; an operand that is entry p itself is forwarded in registers.  The loop is unrolled twice so that the two
+// slots swap roles instead of being copied.
+template <int NC>
+struct PredSlot { uint32_t en, ep, eo; Vec<NC> vn, vp, vo, corr; };
+
+// Every load of the pipeline is unconditional (indices clamped into the array): an operand that is not final yet is
+// loaded anyway and replaced by the forwarded register, which costs an address-unit slot instead of an exec-mask
+// region.  A delta entry is written as the parallelogram (p - 1, 0, 0): o[p-1] + o[0] - o[0].
+template <int NC, bool PARA>
+__device__ __forceinline__ void ln_predict_wrap(int32_t *w, const uint32_t *para, uint32_t entries, int32_t mn, int32_t mx) {
+  typedef Vec<NC> V;
+  const int32_t max_dif = 1 + mx - mn;
+  V *wv = (V *)w;
+  const uint32_t last = entries - 1;
+  auto load_idx = [&](uint32_t q, uint32_t &en, uint32_t &ep, uint32_t &eo) {
+    if (PARA) {
+      const Vec<3> t = *(const Vec<3> *)(para + 3 * (size_t)(q < last ? q : last));
+      en = (uint32_t)t.v[0]; ep = (uint32_t)t.v[1]; eo = (uint32_t)t.v[2];
+      if (en == DSA_INVALID) { en = q - 1; ep = 0; eo = 0; }      // delta fallback (entry 0: en = INVALID again, forwarded r1 = 0)
+    }
+  };
+  auto request = [&](PredSlot<NC> &s, uint32_t q) {
+    s.corr = wv[q < last ? q : last];
+    if (PARA) {
+      s.vn = wv[s.en < last ? s.en : last];
+      s.vp = wv[s.ep < last ? s.ep : last];
+      s.vo = wv[s.eo < last ? s.eo : last];
+    }
+  };
+  V r1;                                            // value of the previous entry
+#pragma unroll
+  for (int c = 0; c < NC; ++c) r1.v[c] = 0;
+  auto compute = [&](const PredSlot<NC> &s, uint32_t q) {
+    V o;
+    const bool fn = s.en + 1 == q, fp = s.ep + 1 == q, fo = s.eo + 1 == q;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      int32_t pred;
+      if (PARA) {
+        const int32_t a = fn ? r1.v[c] : s.vn.v[c], b = fp ? r1.v[c] : s.vp.v[c], d = fo ? r1.v[c] : s.vo.v[c];
+        pred = (int32_t)((uint32_t)a + (uint32_t)b - (uint32_t)d);
+      } else {
+        pred = r1.v[c];                            // delta; entry 0: r1 = 0
+      }
+      o.v[c] = wrap_original(pred, s.corr.v[c], mn, mx, max_dif);
+    }
+    wv[q] = o;
+    r1 = o;
+  };
+  PredSlot<NC> s0, s1;
+  s0.en = s0.ep = s0.eo = s1.en = s1.ep = s1.eo = 0;
+  load_idx(0, s0.en, s0.ep, s0.eo);
+  load_idx(1, s1.en, s1.ep, s1.eo);
+  request(s0, 0);
+  uint32_t p = 0;
+  while (p < entries) {
+    // even step: s0 = entry p, s1 = entry p + 1 (indices known); the indices of entry p + 2 go to s0 afterwards
+    uint32_t n2 = 0, p2 = 0, o2 = 0;
+    load_idx(p + 2, n2, p2, o2);
+    request(s1, p + 1);
+    compute(s0, p);
+    s0.en = n2; s0.ep = p2; s0.eo = o2;
+    if (++p >= entries) break;
+    // odd step: the roles of the slots are swapped
+    load_idx(p + 2, n2, p2, o2);
+    request(s0, p + 1);
+    compute(s1, p);
+    s1.en = n2; s1.ep = p2; s1.eo = o2;
+    ++p;
+  }
+}
+
+// Octahedral delta (PredictionSchemeDeltaDecoder.cs:23-37 with PredictionSchemeNormalOctahedron(Canonicalized)
+// DecodingTransform.ComputeOriginalValue), in place on w[entries][2].
+__device__ __forceinline__ void ln_predict_oct(int32_t *w, uint32_t entries, int32_t max_q, bool canonical) {
+  OctParams o;
+  const int q = 32 - __clz(max_q);
+  const int32_t max_value = (1 << q) - 2;
+  o.center = max_value / 2;
+  o.max_q = (1 << q) - 1;
+  Vec<2> *wv = (Vec<2> *)w;
+  int32_t ps = 0, pt = 0;
+  Vec<2> c = wv[0];
+  for (uint32_t p = 0; p < entries; ++p) {
+    const Vec<2> cn = wv[p + 1 < entries ? p + 1 : p];     // next correction, loaded while this entry is computed
+    int32_t os, ot;
+    oct_original(o, canonical, ps, pt, c.v[0], c.v[1], os, ot);
+    Vec<2> r; r.v[0] = os; r.v[1] = ot;
+    wv[p] = r;
+    ps = os; pt = ot;
+    c = cn;
+  }
+}
+
+// One attribute (the body of a lane of k_predict_lanes).  phase 0: schemes that need no traversal data (difference,
+// octahedral delta); phase 1: parallelogram.
+__device__ __forceinline__ void ln_predict_attribute(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t phase) {
+  const AttrDesc &a = D->att[ai];
+  if (!a.have_scheme || a.source == SRC_BYTES || a.num_entries == 0) return;
+  if ((a.pred_kind == 1) != (phase == 1)) return;
+  int32_t *w = (int32_t *)(arena + L.work[ai]);
+  if (a.pred_transform == 1) {
+    const uint32_t *para = (const uint32_t *)(arena + L.para);
+    const uint32_t nc = a.nc_portable, e = a.num_entries;
+    const int32_t mn = a.wrap_min, mx = a.wrap_max;
+    if (a.pred_kind == 1) {
+      if (nc == 1) ln_predict_wrap<1, true>(w, para, e, mn, mx);
+      else if (nc == 2) ln_predict_wrap<2, true>(w, para, e, mn, mx);
+      else if (nc == 3) ln_predict_wrap<3, true>(w, para, e, mn, mx);
+      else if (nc == 4) ln_predict_wrap<4, true>(w, para, e, mn, mx);
+      else fail(D, ST_NOTIMPL, 500);
+    } else {
+      if (nc == 1) ln_predict_wrap<1, false>(w, para, e, mn, mx);
+      else if (nc == 2) ln_predict_wrap<2, false>(w, para, e, mn, mx);
+      else if (nc == 3) ln_predict_wrap<3, false>(w, para, e, mn, mx);
+      else if (nc == 4) ln_predict_wrap<4, false>(w, para, e, mn, mx);
+      else fail(D, ST_NOTIMPL, 500);
+    }
+  } else {
+    if (a.pred_kind != 0) { fail(D, ST_NOTIMPL, 501); return; }
+    ln_predict_oct(w, a.num_entries, a.oct_max_q, a.pred_transform == 3);
+  }
+}
+
+#if defined(__HIPCC__)
+template <uint32_t SYMS>
+__global__ __launch_bounds__(WAVE) void k_symbols_lanes(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t flags) {
+  __shared__ uint32_t ln_lds[WAVE * ln_sym_stride(SYMS) / 4];
+  const uint32_t lane = threadIdx.x, mesh = blockIdx.x * WAVE + lane, ai = blockIdx.y;
+  bool mine = false;
+  uint32_t distinct = 0;
+  MeshDesc *D = nullptr;
+  if (mesh < n) {
+    D = &descs[mesh];
+    if (D->status == ST_OK && !D->general && ai < D->num_attributes) {
+      mine = ln_sym_eligible(D->att[ai], layouts[mesh], ai, flags);
+      distinct = mine ? D->att[ai].num_distinct : 0u;
+    }
+  }
+  // the wave's LDS is sized by the largest table among its 64 streams: one launch per tier, the others leave
+  uint32_t mx = distinct;
+  for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, WAVE); mx = o > mx ? o : mx; }
+  if (mx == 0 || (mx <= LN_T0_SYMS ? LN_T0_SYMS : LN_T1_SYMS) != SYMS || !mine) return;
+  ln_symbols_stream(arena, layouts[mesh], D, ai, SYMS, (uint16_t *)((uint8_t *)ln_lds + lane * ln_sym_stride(SYMS)));
+}
+#endif
+
+#if defined(__HIPCC__)
+// LPW meshes per wave (the other lanes stay idle): a fully divergent wave access costs the CU's address unit one
+// cycle per active lane, so the chains of a batch are spread over all CUs rather than packed 64 to a wave.
+template <uint32_t LPW>
+__global__ __launch_bounds__(WAVE) void k_predict_lanes(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t phase) {
+  const uint32_t lane = threadIdx.x, mesh = blockIdx.x * LPW + lane, ai = blockIdx.y;
+  if (lane >= LPW || mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
+  ln_predict_attribute(arena, layouts[mesh], D, ai, phase);
+}
+#endif
+
+}  // namespace lanes
+}  // namespace dsa

@@ -1,0 +1,344 @@
+// draco-sharp_amd/csrc/dsa_locate.h
+// The stream walk of k_locate (one lane per mesh): records where every section of a stream starts and what every
+// attribute is.  No wave intrinsics: tests/hostcheck compiles it for the host to drive the lane-per-chain kernels'
+// per-lane bodies under ASan (test infrastructure; the product library runs it only as the kernel k_locate).
+#pragma once
+#include "dsa_common.h"
+
+namespace dsa {
+
+#if !defined(__HIPCC__)
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
+#endif
+
+// locate_mesh: lane 0 of a wave walks the stream and records where every
+// section starts.  Tag streams of the tagged symbol scheme are decoded here
+// (their bit section has no length prefix), tags stored as bytes in the
+// attribute's output buffer for k_symbols.
+#define LOC_MAX_TAGS 64
+#define SYM_MAX_LDS 4032   // 63 blocks of 64 cumulative entries searched in LDS by k_symbols
+
+#undef RET
+#define RET false
+__device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, AttrDesc &a, const MeshLayout &L, int ai, uint8_t *arena,
+                                        uint32_t *s_cum, uint32_t num_entries, BatchGlobals *G) {
+  const uint8_t *s = r.p;
+  a.num_entries = num_entries;
+  if (a.seq_type == 0) {   // generic: raw bytes, SequentialAttributeDecoder.cs:75-86
+    a.source = SRC_BYTES;
+    a.nc_portable = a.nc;
+    a.off_raw = r.pos;
+    uint64_t bytes = (uint64_t)data_type_length(a.data_type) * a.nc * num_entries;
+    REQUIRE(bytes <= L.out_cap[ai], 140);
+    r.skip(bytes);
+    REQUIRE(r.ok, 141);
+    return true;
+  }
+  uint32_t nc = a.seq_type == 3 ? 2u : a.nc;   // normals are (s,t) in portable form
+  a.nc_portable = (uint8_t)nc;
+  uint64_t num_values = (uint64_t)num_entries * nc;
+  REQUIRE(num_values <= L.work_cap[ai], 142);
+  int method = (int8_t)r.u8();
+  REQUIRE(r.ok && method >= -2 && method < 7, 143);
+  a.pred_method = (int8_t)method;
+  a.have_scheme = 0;
+  a.pred_transform = -1;
+  if (method != -2) {
+    int tt = (int8_t)r.u8();
+    REQUIRE(r.ok && tt >= -1 && tt < 4, 144);
+    a.pred_transform = (int8_t)tt;
+    if (a.seq_type == 3) a.have_scheme = (tt == 2 || tt == 3);
+    else a.have_scheme = (tt == 1);
+  }
+  uint32_t compressed = r.u8();
+  REQUIRE(r.ok, 145);
+  if (compressed > 0) {
+    if (num_values > 0) {
+      uint32_t scheme = r.u8();
+      REQUIRE(r.ok && scheme <= 1, 146);
+      if (scheme == 1) {
+        a.source = SRC_RAW;
+        uint32_t mbl = r.u8();
+        REQUIRE(r.ok && mbl >= 1 && mbl <= 18, 147);
+        a.precision_bits = (uint8_t)rans_precision_bits(mbl);
+        uint64_t ns = r.varint();
+        REQUIRE(r.ok && ns >= 1 && ns <= (1u << 20), 148);
+        a.num_symbols = (uint32_t)ns;
+        a.off_table = r.pos;
+        REQUIRE(skip_prob_table(r, a.num_symbols, &a.num_distinct), 149);
+        if (a.num_symbols > SYM_MAX_LDS) {   // alphabet too large for the LDS search: cumulative table from the batch pool
+          unsigned long long bytes = ((unsigned long long)a.num_symbols + 2) * 4;
+          bytes = (bytes + 15) & ~15ull;
+          unsigned long long at = atomicAdd(&G->pool_cursor, bytes);
+          if (at + bytes > G->pool_bytes) NOTIMPL(166);
+          a.table = G->pool + at;
+        }
+        uint64_t size = r.varint();
+        a.off_rans = r.pos;
+        r.skip(size);
+        REQUIRE(r.ok && size >= 1, 150);
+        a.size_rans = (uint32_t)size;
+      } else {
+        a.source = SRC_TAGGED;
+        a.precision_bits = 12;   // SymbolDecoding.cs:34: tag alphabet is 5 bits wide
+        uint64_t ns = r.varint();
+        REQUIRE(r.ok && ns >= 1 && ns <= LOC_MAX_TAGS, 151);
+        a.num_symbols = (uint32_t)ns;
+        a.off_table = r.pos;
+        REQUIRE(read_prob_table(r, a.num_symbols, s_cum), 152);
+        uint32_t c = 0;
+        for (uint32_t i = 0; i < a.num_symbols; ++i) { uint32_t pr = s_cum[i]; s_cum[i] = c; c += pr; }
+        s_cum[a.num_symbols] = c;
+        REQUIRE(c == 4096, 153);
+        uint64_t size = r.varint();
+        a.off_rans = r.pos;
+        r.skip(size);
+        REQUIRE(r.ok && size >= 1, 154);
+        a.size_rans = (uint32_t)size;
+        a.off_bits = r.pos;
+        // decode the tag stream; tags -> out buffer (bytes)
+        REQUIRE(num_entries <= L.out_cap[ai], 155);
+        uint8_t *tags = arena + L.out[ai];
+        const uint8_t *buf = s + a.off_rans;
+        uint32_t state, off;
+        REQUIRE(rans_init(buf, a.size_rans, 16384, &state, &off), 156);
+        uint64_t total_bits = 0;
+        for (uint32_t e = 0; e < num_entries; ++e) {
+          while (state < 16384 && off > 0) state = state * 256 + buf[--off];
+          uint32_t rem = state & 4095, quo = state >> 12;
+          uint32_t lo = 0, hi = a.num_symbols;   // largest i with cum[i] <= rem
+          while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s_cum[mid] <= rem) lo = mid; else hi = mid; }
+          // skip zero-probability symbols that share the same cumulative value
+          uint32_t cs = s_cum[lo], f = s_cum[lo + 1] - cs;
+          state = quo * f + rem - cs;
+          REQUIRE(lo <= 32, 157);
+          tags[e] = (uint8_t)lo;
+          total_bits += (uint64_t)lo * nc;
+        }
+        r.skip((total_bits + 7) >> 3);
+        REQUIRE(r.ok, 158);
+      }
+    } else {
+      a.source = SRC_RAW;
+      a.num_symbols = 0;
+    }
+  } else {
+    a.source = SRC_FIXED;
+    uint32_t nb = r.u8();
+    REQUIRE(r.ok && nb >= 1 && nb <= 4, 159);
+    a.fixed_bytes = (uint8_t)nb;
+    a.off_raw = r.pos;
+    r.skip((uint64_t)nb * num_values);
+    REQUIRE(r.ok, 160);
+  }
+  if (a.have_scheme) {
+    // only Difference and Parallelogram run on the device path for now
+    // PredictionSchemeDecoderFactory.cs:24-36: without a corner table (point clouds) every method falls back to delta
+    // With a corner table the schemes a transform carries are (D-26): wrap -> parallelogram family + texture
+    // coordinates, octahedral -> geometric normal only; every other combination is the delta scheme.  Schemes that
+    // need the general path's tables send the mesh there: the host decodes it again (site DSA_SITE_RETRY_GENERAL).
+    if (D->encoder_type == 0) a.pred_kind = 0;
+    else if (a.pred_transform == 1) {
+      if (method == 2 || method == 4 || method == 5) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+      if (!(method == 0 || method == 1 || method == 6)) NOTIMPL(161);
+      a.pred_kind = method == 1 ? 1 : 0;
+    } else {
+      if (method == 6) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+      a.pred_kind = 0;
+    }
+    if (a.pred_transform == 1) {           // PredictionSchemeWrapDecodingTransform.cs:69-75
+      a.wrap_min = (int32_t)r.u32();
+      a.wrap_max = (int32_t)r.u32();
+      REQUIRE(r.ok && a.wrap_min <= a.wrap_max, 162);
+      int64_t dif = (int64_t)a.wrap_max - (int64_t)a.wrap_min;
+      REQUIRE(dif < 0x7FFFFFFF, 163);
+    } else {                               // NormalOctahedron(+Canonicalized)DecodingTransform
+      int32_t max_q = (int32_t)r.u32();
+      if (a.pred_transform == 3) (void)r.u32();
+      REQUIRE(r.ok && max_q > 0 && (max_q & 1) == 1, 164);
+      int q = 32 - __clz(max_q);
+      REQUIRE(q >= 2 && q <= 30, 165);
+      a.oct_max_q = max_q;
+    }
+  }
+  return true;
+}
+#undef RET
+#define RET
+
+__device__ inline void locate_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, BatchGlobals *G, uint32_t *s_cum) {
+  const uint8_t *s = arena + L.stream;
+  Rd r(s, L.stream_len, 0);
+  // header, DracoDecoder.cs:44-64
+  REQUIRE(L.stream_len >= 11, 100);
+  REQUIRE(s[0] == 'D' && s[1] == 'R' && s[2] == 'A' && s[3] == 'C' && s[4] == 'O', 101);
+  r.pos = 5;
+  D->major = (uint8_t)r.u8(); D->minor = (uint8_t)r.u8();
+  D->encoder_type = (uint8_t)r.u8(); D->encoder_method = (uint8_t)r.u8();
+  D->flags = (uint16_t)r.u16();
+  REQUIRE(D->major == 2 && D->minor == 2, 102);
+  if (D->flags & 0x8000) {   // metadata is skipped structurally (Metadata/MetadataDecoder.cs:5-49)
+    uint32_t natt = (uint32_t)r.varint();
+    uint32_t pending[16];
+    int depth = 0;
+    uint32_t elements_left = natt + 1;   // per-attribute elements (each preceded by an id) then the file element
+    bool first_level_ids = true;
+    (void)first_level_ids;
+    for (uint32_t e = 0; e < elements_left && r.ok; ++e) {
+      if (e < natt) (void)r.varint();
+      // one element, iteratively
+      depth = 0;
+      pending[0] = 1;
+      bool at_key = false;
+      while (depth >= 0 && r.ok) {
+        if (pending[depth] == 0) { --depth; continue; }
+        --pending[depth];
+        if (at_key || depth > 0) { uint32_t ks = r.u8(); r.skip(ks); }
+        uint32_t ne = (uint32_t)r.varint();
+        for (uint32_t i = 0; i < ne && r.ok; ++i) { uint32_t ks = r.u8(); r.skip(ks); uint64_t vs = r.varint(); r.skip(vs); }
+        uint32_t nsub = (uint32_t)r.varint();
+        if (nsub) { REQUIRE(depth < 15, 103); pending[++depth] = nsub; }
+      }
+    }
+    REQUIRE(r.ok, 104);
+  }
+  REQUIRE(D->encoder_type <= 1, 105);
+  if (L.gen_bytes != 0) {               // the host sized this mesh for the general path (dsa_general.h): k_general parses the rest
+    REQUIRE(D->encoder_type == 1 && D->encoder_method <= 1, 107);
+    D->general = 1;
+    D->end_pos = r.pos;
+    return;
+  }
+  const bool point_cloud = D->encoder_type == 0;
+  uint32_t nad = 0;
+  if (point_cloud) {
+    // Sequential point cloud (the reference stops at DracoDecoder.cs:70; layout of the upstream format):
+    // int32 point count, then the attribute section with a linear sequencer (entry i = point i).
+    REQUIRE(D->encoder_method <= 1, 107);
+    if (D->encoder_method != 0) NOTIMPL(106);               // kd-tree point clouds
+    const uint32_t np = r.u32();
+    REQUIRE(r.ok && np <= 0x7FFFFFFFu && np == L.cap_vertices, 116);
+    D->num_enc_vertices = np; D->num_faces = 0; D->num_att_data = 0;
+    D->num_vertices = np; D->num_all_vertices = np; D->num_points = np; D->num_entries = np;
+  } else {
+    REQUIRE(D->encoder_method <= 1, 107);
+    if (D->encoder_method == 0) NOTIMPL(108);                 // sequential mesh
+    D->traversal_type = (uint8_t)r.u8();
+    REQUIRE(r.ok && D->traversal_type <= 2, 109);
+    if (D->traversal_type != 0) NOTIMPL(110);                 // valence / predictive traversal
+    // MeshEdgeBreakerDecoder.cs:35-56
+    uint64_t nv = r.varint(), nf = r.varint();
+    REQUIRE(r.ok && nf <= 0x7FFFFFFFu / 3 && nv <= nf * 3, 111);
+    uint64_t min_face_edges = 3 * nf / 2, max_vertex_edges = nv * (nv - 1) / 2;
+    REQUIRE(max_vertex_edges >= min_face_edges, 112);
+    nad = r.u8();
+    uint64_t nsym = r.varint();
+    REQUIRE(r.ok && nf >= nsym && nf <= nsym + nsym / 3, 113);
+    uint64_t nsplit_sym = r.varint();
+    REQUIRE(r.ok && nsplit_sym <= nsym, 114);
+    if (nad > DSA_MAX_ATT_DATA) NOTIMPL(115);
+    D->num_enc_vertices = (uint32_t)nv; D->num_faces = (uint32_t)nf; D->num_att_data = (uint8_t)nad;
+    D->num_symbols = (uint32_t)nsym; D->num_split_symbols = (uint32_t)nsplit_sym;
+    REQUIRE(nf == L.cap_faces && nv + nsplit_sym == L.cap_vertices, 116);   // host sizing must agree
+    // topology splits, MeshEdgeBreakerDecoder.cs:136-193
+    uint64_t nsplits = r.varint();
+    REQUIRE(r.ok && nsplits <= nf && nsplits <= L.cap_splits, 117);
+    D->num_splits = (uint32_t)nsplits;
+    D->off_splits = r.pos;
+    for (uint64_t i = 0; i < 2 * nsplits; ++i) (void)r.varint();
+    D->off_split_bits = r.pos;
+    r.skip((nsplits + 7) >> 3);
+    REQUIRE(r.ok, 118);
+    // traversal sections, MeshEdgeBreakerTraversalDecoder.cs:27-61 (symbol section is `size` bytes, D-3)
+    uint64_t sym_size = r.varint();
+    D->off_symbols = r.pos;
+    r.skip(sym_size);
+    REQUIRE(r.ok, 119);
+    D->size_symbols = (uint32_t)sym_size;
+    D->off_start_faces = r.pos;
+    { (void)r.u8(); uint64_t sz = r.varint(); r.skip(sz); REQUIRE(r.ok && sz >= 1, 120); }
+    for (uint32_t i = 0; i < nad; ++i) {
+      D->off_seams[i] = r.pos;
+      (void)r.u8();
+      uint64_t sz = r.varint();
+      r.skip(sz);
+      REQUIRE(r.ok && sz >= 1, 121);
+    }
+  }
+  // attribute section, ConnectivityDecoder.cs:16-44
+  D->off_attributes = r.pos;
+  uint32_t ndec = r.u8();
+  REQUIRE(r.ok, 122);
+  if (ndec > DSA_MAX_ATT) NOTIMPL(122);
+  D->num_decoders = ndec;
+  int att_data_of[DSA_MAX_ATT];
+  bool pos_seen = false;
+  uint32_t data_seen = 0;
+  for (uint32_t i = 0; i < ndec && !point_cloud; ++i) {           // MeshEdgeBreakerDecoder.cs:640-708
+    int att_data_id = (int8_t)r.u8();
+    uint32_t element_type = r.u8();
+    uint32_t traversal_method = r.u8();
+    REQUIRE(r.ok && traversal_method < 2, 123);
+    if (att_data_id >= 0) {
+      REQUIRE((uint32_t)att_data_id < nad && !((data_seen >> att_data_id) & 1), 124);
+      data_seen |= 1u << att_data_id;
+    } else {
+      REQUIRE(!pos_seen, 125);
+      pos_seen = true;
+    }
+    if (element_type != 0) { REQUIRE(att_data_id >= 0 && traversal_method == 0, 126); NOTIMPL(127); }   // corner attributes (seams)
+    if (traversal_method != 0) NOTIMPL(DSA_SITE_RETRY_GENERAL);                                     // prediction-degree traversal: general path (the host parse routes it there)
+    att_data_of[i] = att_data_id;
+  }
+  (void)att_data_of;
+  uint32_t natt = 0;
+  uint32_t first_att[DSA_MAX_ATT + 1];
+  for (uint32_t i = 0; i < ndec; ++i) {           // AttributesDecoder.cs:19-63 + controller :16-27
+    first_att[i] = natt;
+    uint64_t k = r.varint();
+    REQUIRE(r.ok, 129);
+    if (natt + k > DSA_MAX_ATT) NOTIMPL(129);
+    REQUIRE(natt + k <= L.cap_attributes, 129);
+    for (uint32_t j = 0; j < (uint32_t)k; ++j) {
+      AttrDesc &a = D->att[natt + j];
+      a.att_type = (uint8_t)r.u8(); a.data_type = (uint8_t)r.u8(); a.nc = (uint8_t)r.u8(); a.normalized = r.u8() != 0;
+      REQUIRE(r.ok && a.att_type < 5 && a.data_type != 0 && a.data_type < 12 && a.nc != 0, 130);
+      a.unique_id = (uint32_t)r.varint();
+      a.decoder_id = (int8_t)i;
+    }
+    for (uint32_t j = 0; j < (uint32_t)k; ++j) {
+      AttrDesc &a = D->att[natt + j];
+      a.seq_type = (uint8_t)r.u8();
+      REQUIRE(r.ok && a.seq_type <= 3, 131);
+      if (a.seq_type == 2) REQUIRE(a.data_type == 9 && a.nc <= 4, 132);
+      if (a.seq_type == 3) REQUIRE(a.data_type == 9 && a.nc == 3, 133);
+      if (a.seq_type == 1) { uint32_t w = data_type_length(a.data_type); REQUIRE(w == 1 || w == 2 || w == 4, 134); }
+    }
+    natt += (uint32_t)k;
+  }
+  first_att[ndec] = natt;
+  D->num_attributes = natt;
+  // every vertex attribute of a valid stream carries one entry per encoded vertex
+  uint32_t num_entries = D->num_enc_vertices;
+  for (uint32_t i = 0; i < ndec; ++i) {           // AttributesDecoder.cs:65-70
+    for (uint32_t ai = first_att[i]; ai < first_att[i + 1]; ++ai) {
+      if (!locate_attribute_values(r, D, D->att[ai], L, (int)ai, arena, s_cum, num_entries, G)) return;
+    }
+    for (uint32_t ai = first_att[i]; ai < first_att[i + 1]; ++ai) {
+      AttrDesc &a = D->att[ai];
+      if (a.seq_type == 2) {                      // AttributeQuantizationTransform.cs:110-121
+        for (uint32_t c = 0; c < a.nc; ++c) a.q_min[c] = r.f32();
+        a.q_range = r.f32();
+        a.q_bits = (uint8_t)r.u8();
+        REQUIRE(r.ok && a.q_bits >= 1 && a.q_bits <= 30, 135);
+      } else if (a.seq_type == 3) {               // AttributeOctahedronTransform.cs:39-42 (D-5)
+        a.q_bits = (uint8_t)r.u8();
+        REQUIRE(r.ok && a.q_bits >= 2 && a.q_bits <= 30, 136);
+      }
+    }
+  }
+  D->end_pos = r.pos;
+}
+
+}  // namespace dsa

@@ -47,6 +47,7 @@ struct AttrDesc {
   float q_min[4];
   float q_range;
   uint32_t num_entries;
+  uint32_t num_distinct;   // raw scheme: symbols of the alphabet with a non-zero frequency (k_locate counts them while it skips the table)
   uint64_t table;          // arena offset of a cumulative table taken from the batch pool (large alphabets), else 0
 };
 

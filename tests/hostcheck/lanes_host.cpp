@@ -1,0 +1,123 @@
+// tests/hostcheck/lanes_host.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// The per-lane bodies of the lane-per-chain kernels (draco-sharp_amd/csrc/dsa_lanes.h: rANS symbol decode, prediction
+// inverse) and the stream walk of k_locate (dsa_locate.h), compiled for the host with AddressSanitizer: the same
+// source the GPU runs, one lane at a time, on an arena laid out by the library's own dsa_host_parse.h with every gap
+// between regions poisoned.  Nothing here is linked into libdraco_mi355x.so and the product has no host decode path.
+//
+//   lanes_host decode <in.drc> <out.bin> [conn.bin]
+//
+// conn.bin (optional, written by the test from the oracle's connectivity): u32 F, NV, E, then opposite[3F],
+// corner_to_vertex[3F] (reference corner numbering 3f+k), data_to_corner[E] -- what k_connectivity / k_traverse hand
+// to the prediction kernels; with it the parallelogram attributes are decoded too.
+#include <sanitizer/asan_interface.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../draco-sharp_amd/csrc/dsa_lanes.h"
+#include "../../draco-sharp_amd/csrc/dsa_host_parse.h"
+
+static std::vector<uint8_t> read_file(const char *path) {
+  std::vector<uint8_t> v;
+  FILE *f = fopen(path, "rb");
+  if (!f) { perror(path); exit(2); }
+  uint8_t buf[65536];
+  size_t k;
+  while ((k = fread(buf, 1, sizeof(buf), f)) > 0) v.insert(v.end(), buf, buf + k);
+  fclose(f);
+  return v;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 4 || strcmp(argv[1], "decode") != 0) { fprintf(stderr, "usage: lanes_host decode <in.drc> <out.bin> [conn.bin]\n"); return 2; }
+  const std::vector<uint8_t> data = read_file(argv[2]);
+  const size_t len = data.size();
+  FILE *out = fopen(argv[3], "wb");
+  if (!out) { perror(argv[3]); return 2; }
+  auto put32 = [&](uint32_t v) { fwrite(&v, 4, 1, out); };
+
+  HostMesh h;
+  unsetenv("DSA_FORCE_GENERAL");
+  host_parse(data.data(), len, h);
+  if (h.status != 0 || h.general) { put32(h.status ? (uint32_t)h.status : 1000u); put32(0); put32(0); fclose(out); return 0; }   // 1000: not a fast-path stream
+  MeshLayout L;
+  memset(&L, 0, sizeof(L));
+  L.stream = 0;
+  L.stream_len = (uint32_t)len;
+  uint64_t cur = align_up(len + 1024, 256);
+  std::vector<std::pair<uint64_t, uint64_t>> regions;
+  regions.push_back({0, align_up(len, 4)});          // the byte reservoir reads whole dwords
+  cur = layout_mesh(h, len, L, cur, 1024, &regions);
+  BatchGlobals G;
+  memset(&G, 0, sizeof(G));
+  G.pool = cur; G.pool_bytes = 1 << 20;
+  regions.push_back({cur, G.pool_bytes});
+  cur += G.pool_bytes;
+  std::vector<uint8_t> arena(cur, 0);
+  memcpy(arena.data(), data.data(), len);
+  ASAN_POISON_MEMORY_REGION(arena.data(), arena.size());
+  for (auto &rg : regions) ASAN_UNPOISON_MEMORY_REGION(arena.data() + rg.first, rg.second);
+
+  MeshDesc D;
+  memset(&D, 0, sizeof(D));
+  uint32_t s_cum[LOC_MAX_TAGS + 1];
+  dsa::locate_mesh(arena.data(), L, &D, &G, s_cum);
+  std::vector<int> decoded(DSA_MAX_ATT, 0);
+  if (D.status == ST_OK) {
+    // ---- k_symbols_lanes, one lane
+    for (uint32_t ai = 0; ai < D.num_attributes; ++ai) {
+      const AttrDesc &a = D.att[ai];
+      if (!dsa::lanes::ln_sym_eligible(a, L, ai, LN_FLAG_SYMBOLS)) continue;
+      const uint32_t cap = a.num_distinct <= LN_T0_SYMS ? LN_T0_SYMS : LN_T1_SYMS;
+      std::vector<uint16_t> lds(dsa::lanes::ln_sym_stride(cap) / 2);
+      dsa::lanes::ln_symbols_stream(arena.data(), L, &D, ai, cap, lds.data());
+      decoded[ai] = 1;
+    }
+    // ---- k_predict_lanes phase 0
+    for (uint32_t ai = 0; ai < D.num_attributes && D.status == ST_OK; ++ai)
+      if (decoded[ai]) dsa::lanes::ln_predict_attribute(arena.data(), L, &D, ai, 0);
+    // ---- parallelogram attributes: connectivity from the oracle, operands by the product's para_operands_of
+    bool have_conn = false;
+    if (argc >= 5 && D.status == ST_OK && D.encoder_type == 1) {
+      const std::vector<uint8_t> cb = read_file(argv[4]);
+      const uint32_t *c = (const uint32_t *)cb.data();
+      const uint32_t F = c[0], NV = c[1], E = c[2];
+      const uint32_t *opp = c + 3, *c2v = opp + 3 * (size_t)F, *d2c_ref = c2v + 3 * (size_t)F;
+      if (F == L.cap_faces && E <= L.cap_vertices && NV <= L.cap_vertices) {
+        uint32_t *frec = (uint32_t *)(arena.data() + L.frec), *d2c = (uint32_t *)(arena.data() + L.d2c), *para = (uint32_t *)(arena.data() + L.para);
+        int32_t *v2d = (int32_t *)(arena.data() + L.v2d);
+        auto quad = [](uint32_t cr) { return cr == DSA_INVALID ? cr : 4u * (cr / 3u) + cr % 3u; };
+        for (uint32_t f = 0; f < F; ++f) {
+          for (uint32_t k = 0; k < 3; ++k) { frec[8 * f + k] = c2v[3 * f + k]; frec[8 * f + 4 + k] = quad(opp[3 * f + k]); }
+          frec[8 * f + 3] = 0; frec[8 * f + 7] = 0;
+        }
+        for (uint32_t v = 0; v < L.cap_vertices; ++v) v2d[v] = -1;
+        for (uint32_t p = 0; p < E; ++p) { d2c[p] = quad(d2c_ref[p]); v2d[c2v[d2c_ref[p]]] = (int32_t)p; }
+        for (uint32_t p = 0; p < E; ++p) dsa::para_operands_of(p, frec, d2c, v2d, F, NV, para);
+        have_conn = true;
+      }
+    }
+    for (uint32_t ai = 0; ai < D.num_attributes && D.status == ST_OK; ++ai) {
+      if (!decoded[ai]) continue;
+      const AttrDesc &a = D.att[ai];
+      if (a.have_scheme && a.pred_kind == 1) {
+        if (have_conn) dsa::lanes::ln_predict_attribute(arena.data(), L, &D, ai, 1);
+        else decoded[ai] = 0;
+      }
+    }
+  }
+  ASAN_UNPOISON_MEMORY_REGION(arena.data(), arena.size());
+  put32((uint32_t)D.status); put32((uint32_t)D.detail);
+  if (D.status != ST_OK) { put32(0); fclose(out); return 0; }
+  put32(D.num_attributes);
+  for (uint32_t ai = 0; ai < D.num_attributes; ++ai) {
+    const AttrDesc &a = D.att[ai];
+    put32((uint32_t)decoded[ai]); put32(a.num_entries); put32(a.nc_portable);
+    if (decoded[ai]) fwrite(arena.data() + L.work[ai], 4, (size_t)a.num_entries * a.nc_portable, out);
+  }
+  fclose(out);
+  return 0;
+}
