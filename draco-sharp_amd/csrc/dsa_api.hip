@@ -296,10 +296,13 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_general_attributes<3>, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
   }
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[0], st2));
-  // DSA_LANES (diagnostics): bit 0 = rANS streams one lane per stream (k_symbols_lanes), bit 1 = prediction one lane per attribute
-  static const uint32_t lane_flags = getenv("DSA_LANES") ? (uint32_t)atoi(getenv("DSA_LANES")) : (LN_FLAG_SYMBOLS | LN_FLAG_PREDICT);
+  // DSA_LANES (diagnostics): bit 0 = raw rANS streams one lane per stream (k_symbols_lanes), bit 1 = prediction one lane per
+  // attribute (k_predict_lanes); both measured slower than the wave-per-stream kernels on this workload and off by
+  // default (profiles/README.md).  bit 2 = wrap prediction by k_predict_wrap (default on)
+  static const uint32_t lane_flags = getenv("DSA_LANES") ? (uint32_t)atoi(getenv("DSA_LANES")) : PW_FLAG;
   if (lane_flags & LN_FLAG_SYMBOLS) {
     const uint32_t groups = (n + WAVE - 1) / WAVE;
+    hipLaunchKernelGGL(dsa::lanes::k_symbols_lanes<LN_T2_SYMS>, dim3(groups, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
     hipLaunchKernelGGL(dsa::lanes::k_symbols_lanes<LN_T1_SYMS>, dim3(groups, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
     hipLaunchKernelGGL(dsa::lanes::k_symbols_lanes<LN_T0_SYMS>, dim3(groups, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
   }
@@ -312,7 +315,10 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // attributes whose prediction needs no traversal data (difference, octahedral delta) are finished on this stream,
   // beside the traversal and the parallelogram attributes; joined before k_seal
   if (lane_flags & LN_FLAG_PREDICT) hipLaunchKernelGGL(dsa::lanes::k_predict_lanes<16>, dim3((n + 15) / 16, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u);
-  else hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u);
+  else {
+    hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
+    if (lane_flags & PW_FLAG) hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
+  }
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
     hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u);
@@ -360,7 +366,10 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join3, 0));  // join: connectivity validated
   HIP_TRY(ctx, mark());
   if (lane_flags & LN_FLAG_PREDICT) hipLaunchKernelGGL(dsa::lanes::k_predict_lanes<32>, dim3((n + 31) / 32, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u);
-  else hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u);
+  else {
+    if (lane_flags & PW_FLAG) hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags);
+    hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags);
+  }
   HIP_TRY(ctx, mark());
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));

@@ -1477,13 +1477,15 @@ __device__ __forceinline__ uint32_t addmod(uint32_t a, uint32_t b, uint32_t m) {
 
 // phase 0: schemes that need no traversal data (difference / octahedral delta) -- launched behind the symbol
 // kernels on their stream; phase 1: parallelogram schemes, after the traversal.
-__global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t phase) {
+__device__ __forceinline__ bool wrap_fast_ok(const AttrDesc &a, uint32_t flags);
+__global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t phase, uint32_t flags) {
   uint32_t mesh = blockIdx.x, ai = blockIdx.y;
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
   const AttrDesc &a = D->att[ai];
   if (!a.have_scheme || a.source == SRC_BYTES) return;
+  if (wrap_fast_ok(a, flags)) return;                    // k_predict_wrap
   if ((a.pred_kind == 1) != (phase == 1)) return;
   const MeshLayout &L = layouts[mesh];
   int32_t *w = (int32_t *)(arena + L.work[ai]);
@@ -1700,6 +1702,150 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
       p0 += cnt;
       short_runs = 0;
     }
+  }
+}
+
+// =========================================================================
+// k_predict_wrap: the wrap-transform schemes (Difference / Parallelogram + Wrap) with few components and a range
+// below 2^25 -- every quantised attribute -- on a leaner form of k_predict's step: one instantiation per component
+// count, every load unconditional (indices clamped, a delta entry loads o[0] - o[0]), the scan as six DPP adds per
+// component, residues by one multiply with 1/M.  Same invariant: lane 0 is the reference's exact step from
+// finished entries, lanes 1.. join while their prediction is "previous entry + (finished - finished)", every lane
+// re-evaluates the sequential step from its neighbour's value and the run is cut at the first disagreement.
+// =========================================================================
+#define PW_FLAG 4u    // DSA_LANES bit 2: wrap schemes by k_predict_wrap (default on)
+__device__ __forceinline__ bool wrap_fast_ok(const AttrDesc &a, uint32_t flags) {
+  return (flags & PW_FLAG) && a.have_scheme && a.source != SRC_BYTES && a.pred_transform == 1 && a.nc_portable >= 1 && a.nc_portable <= 4 &&
+         (uint32_t)(1 + a.wrap_max - a.wrap_min) < (1u << 25) && a.num_entries != 0;
+}
+// inclusive wave64 prefix sum, one v_add with a DPP operand per step where the backend fuses them
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);    // row_shr:1 (lanes without a source add 0)
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+  return x;
+}
+template <int NC>
+struct PwVec { int32_t v[NC]; };
+
+template <int NC, bool PARA>
+__device__ __forceinline__ void predict_wrap_wave(int32_t *w, const uint32_t *para, uint32_t entries, int32_t mn, int32_t mx) {
+  typedef PwVec<NC> V;
+  const V *wv = (const V *)w;
+  const uint32_t lane = lane_id();
+  const uint32_t M = (uint32_t)(1 + mx - mn);
+  const int32_t max_dif = (int32_t)M;
+  const float inv_m = 1.0f / (float)M;
+  const uint32_t lastp = entries - 1;
+  uint32_t p0 = 0;
+  int32_t last[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) last[c] = 0;
+  while (p0 < entries) {
+    const uint32_t p = p0 + lane;
+    const bool live = p <= lastp;
+    const uint32_t pc = live ? p : lastp;
+    uint32_t en = DSA_INVALID, ep = 0, eo = 0;
+    if (PARA) { const PwVec<3> t = *(const PwVec<3> *)(para + 3 * (size_t)pc); en = (uint32_t)t.v[0]; ep = (uint32_t)t.v[1]; eo = (uint32_t)t.v[2]; }
+    const bool is_delta = en == DSA_INVALID;
+    const bool n_prev = en + 1 == pc, p_prev = ep + 1 == pc;                   // en = INVALID: en + 1 = 0, never pc (pc > 0 whenever para[pc] is a parallelogram)
+    // prediction = base + (o[ga] - o[gb]); a delta entry takes o[0] - o[0]
+    uint32_t ga = is_delta ? 0u : (n_prev ? ep : en), gb = is_delta ? 0u : eo;
+    const bool near_prev = is_delta || n_prev || p_prev;
+    bool chain = live && near_prev && (is_delta || (ga < p0 && gb < p0));
+    // lane 0 whose parallelogram is made of three older entries: base = o[next], g = o[prev] - o[opposite]
+    const bool far0 = lane == 0 && !near_prev;
+    if (far0) { ga = ep; gb = eo; }
+    const uint64_t not_chain = __ballot(!chain) & ~1ull;
+    uint32_t run = not_chain ? (uint32_t)__builtin_ctzll(not_chain) : WAVE;
+    run = run < entries - p0 ? run : entries - p0;
+    const V corr = wv[pc], va = wv[ga <= lastp ? ga : lastp], vb = wv[gb <= lastp ? gb : lastp];
+    int32_t base[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) base[c] = p0 ? last[c] : 0;
+    if (__ballot(far0)) {                          // rare (a handful per mesh): scalar branch
+      const V vf = wv[far0 && en <= lastp ? en : 0u];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) if (far0) base[c] = vf.v[c];
+    }
+    int32_t g[NC], o[NC];
+    bool irregular = false;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      g[c] = (int32_t)((uint32_t)va.v[c] - (uint32_t)vb.v[c]);
+      // lane 0: the reference's step from finished entries, exact whatever happens to the rest of the run
+      const int32_t o0 = wrap_original((int32_t)((uint32_t)base[c] + (uint32_t)g[c]), corr.v[c], mn, mx, max_dif);
+      const uint32_t x0 = (uint32_t)o0 - (uint32_t)mn;
+      // lanes 1..: residue of g + corr modulo M (both below M in magnitude for real data; anything else ends the run)
+      const bool wild = (uint32_t)(g[c] + max_dif - 1) > 2u * M - 2u || (uint32_t)(corr.v[c] + max_dif - 1) > 2u * M - 2u;
+      const uint32_t t = (uint32_t)(g[c] + corr.v[c] + 2 * max_dif);      // in (0, 4M) when not wild
+      uint32_t r = t - (uint32_t)((float)t * inv_m) * M;
+      r = (int32_t)r < 0 ? r + M : r;
+      r = r >= M ? r - M : r;
+      uint32_t x = lane == 0 ? x0 : r;
+      irregular = irregular || (lane == 0 ? x0 >= M : wild);
+      o[c] = o0;
+      g[c] = g[c];
+      // plain sums of up to 64 residues stay below 2^31
+      x = lane < run ? x : 0u;
+      x = wave_incl_sum(x);
+      uint32_t q = x - (uint32_t)((float)x * inv_m) * M;
+      q = (int32_t)q < 0 ? q + M : q;
+      q = q >= M ? q - M : q;
+      if (lane != 0) o[c] = (int32_t)((uint32_t)mn + q);
+    }
+    {
+      const uint64_t irr = __ballot(irregular && lane < run);
+      if (irr) run = (irr & 1ull) ? 1u : (uint32_t)__builtin_ctzll(irr);     // lane 0 keeps its exact value, nobody chains on it
+    }
+    // every lane re-evaluates the sequential step from its neighbour's value (the sums above included lanes that the
+    // irregular cut has just dropped: their successors fail here, as they must)
+    bool good = true;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int32_t prev = (int32_t)lane_prev((uint32_t)o[c]);
+      const int32_t pred = (int32_t)((uint32_t)prev + (uint32_t)g[c]);
+      good = good && pred >= mn && pred <= mx && wrap_original(pred, corr.v[c], mn, mx, max_dif) == o[c];
+    }
+    const uint64_t bad = __ballot(lane != 0 && lane < run && !good);
+    if (bad) run = (uint32_t)__builtin_ctzll(bad);       // >= 1: lane 0 is always exact
+    if (lane < run) {
+      V r;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) r.v[c] = o[c];
+      ((V *)w)[p] = r;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) last[c] = (int32_t)rdlane((uint32_t)o[c], run - 1);
+    p0 += run;
+  }
+}
+
+__global__ __launch_bounds__(WAVE) void k_predict_wrap(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t phase, uint32_t flags) {
+  uint32_t mesh = blockIdx.x, ai = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
+  const AttrDesc &a = D->att[ai];
+  if (!wrap_fast_ok(a, flags) || (a.pred_kind == 1) != (phase == 1)) return;
+  const MeshLayout &L = layouts[mesh];
+  int32_t *w = (int32_t *)(arena + L.work[ai]);
+  const uint32_t *para = (const uint32_t *)(arena + L.para);
+  const uint32_t e = a.num_entries, nc = a.nc_portable;
+  const int32_t mn = a.wrap_min, mx = a.wrap_max;
+  if (a.pred_kind == 1) {
+    if (nc == 1) predict_wrap_wave<1, true>(w, para, e, mn, mx);
+    else if (nc == 2) predict_wrap_wave<2, true>(w, para, e, mn, mx);
+    else if (nc == 3) predict_wrap_wave<3, true>(w, para, e, mn, mx);
+    else predict_wrap_wave<4, true>(w, para, e, mn, mx);
+  } else {
+    if (nc == 1) predict_wrap_wave<1, false>(w, para, e, mn, mx);
+    else if (nc == 2) predict_wrap_wave<2, false>(w, para, e, mn, mx);
+    else if (nc == 3) predict_wrap_wave<3, false>(w, para, e, mn, mx);
+    else predict_wrap_wave<4, false>(w, para, e, mn, mx);
   }
 }
 

@@ -32,55 +32,45 @@ namespace lanes {
 
 // ------------------------------------------------------------------------------------------------ rANS, lane per stream
 #define LN_MAX_PRECISION 15u          // cumulative frequencies are 16-bit in LDS (2^15 is the largest total)
-#define LN_T0_SYMS 120u               // tier 0: up to 120 non-zero symbols -> 772 B of LDS per lane (48 KB per wave)
-#define LN_T1_SYMS 440u               // tier 1: up to 440 non-zero symbols -> 1412 B per lane (88 KB per wave)
+#define LN_T0_SYMS 136u               // tiers by the number of non-zero symbols of the largest table among a wave's 64 streams:
+#define LN_T1_SYMS 312u               //   136 -> 1476 B of LDS per lane (92 KB per wave), 312 -> 1828 B (114 KB), 440 -> 2084 B (130 KB)
+#define LN_T2_SYMS 440u
 #define LN_CUM_PAD 8u
-// bytes of one lane's LDS region: 256 x u16 LUT, (syms + pad) x u16 cumulative frequencies, + 4 so that the dword
-// stride between lanes is odd
-__host__ __device__ constexpr uint32_t ln_sym_stride(uint32_t syms) { return 512u + 2u * (syms + LN_CUM_PAD) + 4u; }
+#define LN_LUT_BITS 10u               // first-symbol LUT: 1024 buckets (4 slots each at 12-bit precision: at most 4 range starts per bucket)
+// bytes of one lane's LDS region: 1024 x u8 LUT, (syms + pad) x u16 cumulative frequencies, 128-byte ring of stream
+// bytes, the 16 symbol indices of the current block; padded so that the dword stride between lanes is odd (equal
+// offsets of different lanes then fall into different banks)
+__host__ __device__ constexpr uint32_t ln_sym_stride(uint32_t syms) {
+  return ((1024u + 2u * (syms + LN_CUM_PAD) + 128u + 32u) / 4u) % 2u ? 1024u + 2u * (syms + LN_CUM_PAD) + 160u : 1024u + 2u * (syms + LN_CUM_PAD) + 164u;
+}
+__host__ __device__ constexpr uint32_t ln_sym_tier(uint32_t distinct) { return distinct <= LN_T0_SYMS ? LN_T0_SYMS : (distinct <= LN_T1_SYMS ? LN_T1_SYMS : LN_T2_SYMS); }
 
 __host__ __device__ __forceinline__ bool ln_sym_eligible(const AttrDesc &a, const MeshLayout &L, uint32_t ai, uint32_t flags) {
   return (flags & LN_FLAG_SYMBOLS) && a.source == SRC_RAW && a.precision_bits <= LN_MAX_PRECISION && a.num_distinct >= 1 &&
-         a.num_distinct <= LN_T1_SYMS && a.num_entries != 0 && (uint64_t)L.out_cap[ai] >= 4ull * a.num_distinct;
+         a.num_distinct <= LN_T2_SYMS && a.num_entries != 0 && (uint64_t)L.out_cap[ai] >= 4ull * a.num_distinct;
 }
 
-// The stream is consumed from its tail (RAnsDecoder.cs:58-61: state = state * 256 + buf[--offset]).  Up to eight of
-// the next bytes wait top-aligned in a 64-bit reservoir (next byte = bits 63..56); every step loads the dword
-// below the reservoir's contents (address clamped to the start of the stream) and the step after merges it once four
-// bytes or fewer are left, so no load is ever waited for.  Pointers are arena + offset: the loads stay global_load.
-struct TailBytes {
-  const uint32_t *np;   // dword that `pend` was loaded from: the next one to enter the reservoir
-  const uint32_t *lo;   // lowest dword that may be read (start of the stream)
-  uint64_t res;
-  uint32_t have, pend;
-  __device__ __forceinline__ void init(const uint8_t *arena, uint64_t stream_off, uint32_t rans_off, uint32_t off) {
-    lo = (const uint32_t *)(arena + (stream_off & ~3ull));
-    res = 0; have = 0; np = lo; pend = 0;
-    if (off == 0) return;
-    const uint64_t last = stream_off + rans_off + off - 1;
-    const uint32_t *wp = (const uint32_t *)(arena + (last & ~3ull));
-    have = (uint32_t)(last & 3u) + 1u;
-    res = (uint64_t)(*wp << (8u * (4u - have))) << 32;
-    np = wp - 1;
-    pend = *(np < lo ? lo : np);
-  }
-  __device__ __forceinline__ void refill() {     // once per step, before bytes are taken
-    if (have <= 4) { res |= (uint64_t)pend << (32u - 8u * have); have += 4; --np; }
-    pend = *(np < lo ? lo : np);
-  }
-  __device__ __forceinline__ uint32_t take(uint32_t n) {   // n = 1..4 bytes, n <= have
-    const uint32_t b = (uint32_t)(res >> 32) >> (32u - 8u * n);
-    res <<= 8u * n; have -= n;
-    return b;
-  }
-};
+// The stream is consumed from its tail (RAnsDecoder.cs:58-61: state = state * 256 + buf[--offset]).  Global memory
+// answers in 0.5-1 us when the chip is busy, so nothing inside the symbol loop waits for it: the stream is staged in
+// a per-lane LDS ring of eight 16-byte chunks (chunk c = bytes [base - 16(c+1), base - 16c) in memory order; base =
+// the 16-byte boundary behind the first byte to take), two chunks are requested at every 16-symbol block boundary and
+// written into the ring at the next one.  The q-th byte taken (counted from `base` down) sits at ring byte
+// (q ^ 15) & 127; every step reads the next two bytes while the table search runs and keeps 0, 1 or 2 of them.
+#define LN_RING_CHUNKS 8u
+#define LN_BLOCK 16u
+// diagnostic build only (-DLN_STAMPS): shader-clock shares of the segments of a symbol step, summed per wave
+#if defined(LN_STAMPS) && defined(__HIPCC__)
+#define LN_STAMP(i) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (i) ln_seg[i] += t_ - ln_t; ln_t = t_; }
+#else
+#define LN_STAMP(i)
+#endif
 
 // Tables of one stream (RAnsSymbolDecoder.cs:21-59, RAnsDecoder.cs:69-88 restated as a search structure):
 //   symtab[k]  k-th symbol with a non-zero frequency (global scratch: read off the chain)
 //   cum[k]     its cumulative frequency; cum[distinct] = 2^P; LN_CUM_PAD entries of 0xFFFF behind it
-//   lut[b]     the k whose range holds slot b << (P - 8)
+//   lut[b]     k >> 1 for the k whose range holds slot b << (P - 10): the search starts at an even entry
 // Returns 0, or the failure site.
-__device__ __forceinline__ int ln_sym_build(Rd &r, uint32_t nsym, uint32_t P, uint32_t cap, uint16_t *lut, uint16_t *cum, uint32_t *symtab) {
+__device__ __forceinline__ int ln_sym_build(Rd &r, uint32_t nsym, uint32_t P, uint32_t cap, uint8_t *lut, uint16_t *cum, uint32_t *symtab) {
   const uint32_t precision = 1u << P;
   uint32_t k = 0, run = 0;
   for (uint32_t i = 0; i < nsym; ++i) {
@@ -103,78 +93,151 @@ __device__ __forceinline__ int ln_sym_build(Rd &r, uint32_t nsym, uint32_t P, ui
   if (run != precision || k == 0) return 401;
   cum[k] = (uint16_t)precision;
   for (uint32_t j = 1; j < LN_CUM_PAD; ++j) cum[k + j] = 0xFFFFu;
-  const uint32_t sh = P - 8u;
+  const uint32_t sh = P - LN_LUT_BITS;
   uint32_t kk = 0;
-  for (uint32_t b = 0; b < 256u; ++b) {
+  for (uint32_t b = 0; b < (1u << LN_LUT_BITS); ++b) {
     const uint32_t slot = b << sh;
     while (cum[kk + 1] <= slot) ++kk;
-    lut[b] = (uint16_t)kk;
+    lut[b] = (uint8_t)(kk >> 1);
   }
   return 0;
 }
 
-// RAnsDecoder.Read for every value of the stream (RAnsDecoder.cs:56-67) + zig-zag (BitUtilities.cs:94-103) unless the
-// transform's corrections are positive; out[] is 16-byte aligned.
-__device__ __forceinline__ void ln_sym_decode(const uint8_t *arena, uint64_t stream_off, uint32_t rans_off, uint32_t x, uint32_t off, uint32_t P,
-                                              const uint16_t *lut, const uint16_t *cum, const uint32_t *symtab, uint32_t num_values,
-                                              bool positive, int32_t *out) {
-  const uint32_t mask = (1u << P) - 1u, l_base = 4u << P, sh = P - 8u;
-  TailBytes tb;
-  tb.init(arena, stream_off, rans_off, off);
-  uint32_t pend0 = 0, pend1 = 0, pend2 = 0, sym_prev = 0;
-  auto emit = [&](uint32_t i, uint32_t v) {        // value i is complete
-    const uint32_t o = positive ? v : ((v & 1u) ? (uint32_t)(-(int32_t)(v >> 1) - 1) : (v >> 1));
-    const uint32_t q = i & 3u;
-    if (q == 0) pend0 = o;
-    else if (q == 1) pend1 = o;
-    else if (q == 2) pend2 = o;
-    else {
+// 16 bytes of the arena as four dwords (global_load_dwordx4 on the device)
+struct Chunk { uint32_t d[4]; };
+__device__ __forceinline__ Chunk ln_load_chunk(const uint8_t *arena, uint64_t base, uint64_t lowest, uint32_t c) {
+  const uint64_t want = 16ull * (c + 1ull);
+  const uint64_t at = (base >= want && base - want >= lowest) ? base - want : lowest;     // below the stream: never consumed
 #if defined(__HIPCC__)
-      *(uint4 *)(out + i - 3) = make_uint4(pend0, pend1, pend2, o);
+  const uint4 v = *(const uint4 *)(arena + at);
+  Chunk r; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w;
+  return r;
 #else
-      out[i - 3] = (int32_t)pend0; out[i - 2] = (int32_t)pend1; out[i - 1] = (int32_t)pend2; out[i] = (int32_t)o;
+  Chunk r; memcpy(r.d, arena + at, 16);
+  return r;
 #endif
-    }
-  };
-  for (uint32_t i = 0; i < num_values; ++i) {
-    tb.refill();                                     // at least five bytes in the reservoir while the stream has them
-    {
+}
+
+// RAnsDecoder.Read for every value of the stream (RAnsDecoder.cs:56-67) + zig-zag (BitUtilities.cs:94-103) unless the
+// transform's corrections are positive; out[] is 16-byte aligned.  Blocks of 16 symbols: inside a block only LDS is
+// touched (tables, byte ring, the block's symbol indices); at a block boundary the symbol ids of the block are
+// gathered from symtab[] -- to be zig-zagged and stored, four at a time, one boundary later -- and the byte ring is
+// topped up the same way.
+__device__ __forceinline__ void ln_sym_decode(const uint8_t *arena, uint64_t stream_off, uint32_t rans_off, uint32_t x, uint32_t off, uint32_t P,
+                                              const uint8_t *lut, const uint16_t *cum, uint32_t *ring, uint16_t *kbuf, const uint32_t *symtab,
+                                              uint32_t num_values, bool positive, int32_t *out, uint32_t *dbg) {
+  const uint32_t mask = (1u << P) - 1u, l_base = 4u << P, sh = P - LN_LUT_BITS;
+#if defined(LN_STAMPS) && defined(__HIPCC__)
+  unsigned long long ln_t = 0, ln_seg[4] = {0, 0, 0, 0};
+#endif
+  const uint64_t lowest = stream_off & ~15ull;
+  const uint64_t last = stream_off + rans_off + (off ? off - 1u : 0u);
+  const uint64_t base = (last + 16ull) & ~15ull;
+  // the ring starts with six chunks (the only loads this lane waits for), two more are on their way
+  uint32_t loaded = 0;
+  for (; loaded < 6; ++loaded) {
+    const Chunk c = ln_load_chunk(arena, base, lowest, loaded);
+    for (int k = 0; k < 4; ++k) ring[((loaded & (LN_RING_CHUNKS - 1u)) << 2) + k] = c.d[k];
+  }
+  Chunk in0 = ln_load_chunk(arena, base, lowest, loaded), in1 = ln_load_chunk(arena, base, lowest, loaded + 1);
+  bool inflight = true;
+  const uint8_t *ring8 = (const uint8_t *)ring;
+  uint32_t q = (uint32_t)(base - 1 - last);        // index of the next byte, counted from `base` down
+  const uint32_t q_end = q + off;                  // bytes are left while q < q_end
+  uint32_t g[LN_BLOCK];
+#pragma unroll
+  for (uint32_t j = 0; j < LN_BLOCK; ++j) g[j] = 0;
+  auto zz = [&](uint32_t v) -> uint32_t { return positive ? v : ((v & 1u) ? (uint32_t)(-(int32_t)(v >> 1) - 1) : (v >> 1)); };
+  // the first step may need bytes as well (a stream whose initial state is below l_base cannot exist, but is cheap to allow)
+  while (x < l_base && q < q_end) { x = (x << 8) | ring8[(q ^ 15u) & 127u]; ++q; }
+  // one block: cnt symbols, LDS only.  x >= l_base (or the stream is exhausted) on entry to every step.
+  auto decode_block = [&](uint32_t cnt) {
+    for (uint32_t j = 0; j < cnt; ++j) {
+      // the next two stream bytes, read while the search runs
+      LN_STAMP(0);
+      const uint32_t b0 = ring8[(q ^ 15u) & 127u], b1 = ring8[((q + 1u) ^ 15u) & 127u];
+      const uint32_t rem = x & mask;
+      uint32_t k = 2u * (uint32_t)lut[rem >> sh];
+      LN_STAMP(1);
+      // entries k .. k + 7 in four aligned dwords; a bucket of four slots holds at most four range starts behind
+      // its first symbol (k or k + 1), so at 12-bit precision the symbol is one of k .. k + 5
+      const uint32_t *cw = (const uint32_t *)(cum + k);
+      const uint32_t w0 = cw[0], w1 = cw[1], w2 = cw[2], w3 = cw[3];
+      LN_STAMP(2);
+      uint32_t cs = w0 & 0xFFFFu, cn = w0 >> 16;
+      if (rem >= cn) { ++k; cs = cn; cn = w1 & 0xFFFFu; }
+      if (rem >= cn) { ++k; cs = cn; cn = w1 >> 16; }
+      if (rem >= cn) { ++k; cs = cn; cn = w2 & 0xFFFFu; }
+      if (rem >= cn) { ++k; cs = cn; cn = w2 >> 16; }
+      if (rem >= cn) { ++k; cs = cn; cn = w3 & 0xFFFFu; }
+      while (rem >= cn) { ++k; cs = cn; cn = cum[k + 1]; }       // only above 12-bit precision (wider buckets)
+      x = (cn - cs) * (x >> P) + rem - cs;
+      kbuf[j] = (uint16_t)k;
       // x >= 4 after a step (RAnsDecoder.cs:63-65 with x >= l_base before it), so two bytes reach l_base for P <= 15
       uint32_t nb = (x < l_base ? 1u : 0u) + (x < (l_base >> 8) ? 1u : 0u);
-      nb = nb < off ? nb : off;
-      if (nb) { x = (x << (8u * nb)) | tb.take(nb); off -= nb; }
-      while (x < l_base && off > 0) {                // a state below 4: only behind an exhausted or malformed stream
-        if (tb.have == 0) tb.refill();
-        x = (x << 8) | tb.take(1); --off;
+      const uint32_t left = q_end - q;
+      nb = nb < left ? nb : left;
+      x = (x << (8u * nb)) | (((b0 << 8) | b1) >> (16u - 8u * nb));
+      q += nb;
+      while (x < l_base && q < q_end) { x = (x << 8) | ring8[(q ^ 15u) & 127u]; ++q; }   // a state below 4: malformed streams only
+      LN_STAMP(3);
+    }
+  };
+  // Block boundary.  Order matters for the in-order memory counter: everything that was requested one boundary ago is
+  // consumed first (symbol ids, then the two chunks), only then are this boundary's stores and requests issued.  The
+  // first boundary has nothing to store; it is peeled so that no branch joins a path with stores in flight.
+  auto boundary = [&](uint32_t b0, uint32_t cnt, bool store_prev) {
+    uint32_t z[LN_BLOCK];
+#pragma unroll
+    for (uint32_t q = 0; q < LN_BLOCK; ++q) z[q] = zz(g[q]);
+    if (inflight) {
+      for (int k = 0; k < 4; ++k) { ring[((loaded & (LN_RING_CHUNKS - 1u)) << 2) + k] = in0.d[k]; ring[(((loaded + 1u) & (LN_RING_CHUNKS - 1u)) << 2) + k] = in1.d[k]; }
+      loaded += 2;
+    }
+    if (store_prev) {                                  // the previous block was a full one
+      int32_t *o = out + (b0 - LN_BLOCK);
+#pragma unroll
+      for (uint32_t q = 0; q < LN_BLOCK; q += 4) {
+#if defined(__HIPCC__)
+        *(uint4 *)(o + q) = make_uint4(z[q], z[q + 1], z[q + 2], z[q + 3]);
+#else
+        for (uint32_t t = 0; t < 4; ++t) o[q + t] = (int32_t)z[q + t];
+#endif
       }
     }
-    const uint32_t rem = x & mask;
-    uint32_t k = lut[rem >> sh];
-    const uint32_t c0 = cum[k], c1 = cum[k + 1], c2 = cum[k + 2], c3 = cum[k + 3], c4 = cum[k + 4];
-    uint32_t cs = c0, cn = c1;
-    if (rem >= c1) { ++k; cs = c1; cn = c2; }
-    if (rem >= c2) { ++k; cs = c2; cn = c3; }
-    if (rem >= c3) {
-      ++k; cs = c3; cn = c4;
-      while (rem >= cn) { ++k; cs = cn; cn = cum[k + 1]; }     // more than four range starts in one bucket: rare
-    }
-    x = (cn - cs) * (x >> P) + rem - cs;
-    // the symbol id is not on the chain: its load is consumed one value later
-    if (i > 0) emit(i - 1, sym_prev);
-    sym_prev = symtab[k];
+#pragma unroll
+    for (uint32_t j = 0; j < LN_BLOCK; ++j) g[j] = symtab[kbuf[j < cnt ? j : 0u]];
+    // two more chunks are requested while the ring has room for them
+    inflight = loaded + 2u - (q >> 4) <= LN_RING_CHUNKS;
+    if (inflight) { in0 = ln_load_chunk(arena, base, lowest, loaded); in1 = ln_load_chunk(arena, base, lowest, loaded + 1); }
+  };
+  {
+    const uint32_t cnt = num_values < LN_BLOCK ? num_values : LN_BLOCK;
+    decode_block(cnt);
+    boundary(0, cnt, false);
   }
-  emit(num_values - 1, sym_prev);
-  const uint32_t tail = num_values & 3u, base = num_values - tail;
-  if (tail >= 1) out[base] = (int32_t)pend0;
-  if (tail >= 2) out[base + 1] = (int32_t)pend1;
-  if (tail >= 3) out[base + 2] = (int32_t)pend2;
+  for (uint32_t b0 = LN_BLOCK; b0 < num_values; b0 += LN_BLOCK) {
+    const uint32_t cnt = num_values - b0 < LN_BLOCK ? num_values - b0 : LN_BLOCK;
+    decode_block(cnt);
+    boundary(b0, cnt, true);
+  }
+#if defined(LN_STAMPS) && defined(__HIPCC__)
+  if (dbg) { dbg[10] = (uint32_t)(ln_seg[1] >> 12) | ((uint32_t)(ln_seg[2] >> 12) << 16); dbg[11] = (uint32_t)(ln_seg[3] >> 12); }   // slots no other kernel writes
+#endif
+  // the last block (possibly partial)
+  const uint32_t tail = num_values % LN_BLOCK ? num_values % LN_BLOCK : LN_BLOCK, tbase = num_values - tail;
+#pragma unroll
+  for (uint32_t j = 0; j < LN_BLOCK; ++j) if (j < tail) out[tbase + j] = (int32_t)zz(g[j]);
 }
 
 // One stream, start to finish (the body of a lane of k_symbols_lanes; tests/hostcheck calls it directly).
 __device__ __forceinline__ void ln_symbols_stream(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t cap, uint16_t *lds) {
   const AttrDesc &a = D->att[ai];
   const uint8_t *s = arena + L.stream;
-  uint16_t *lut = lds, *cum = lds + 256;
+  uint8_t *lut = (uint8_t *)lds;
+  uint16_t *cum = lds + (1u << LN_LUT_BITS) / 2;
+  uint32_t *ring = (uint32_t *)(cum + cap + LN_CUM_PAD);          // cap is a multiple of 8: dword aligned
+  uint16_t *kbuf = (uint16_t *)(ring + 4 * LN_RING_CHUNKS);
   uint32_t *symtab = (uint32_t *)(arena + L.out[ai]);
   Rd r(s, L.stream_len, a.off_table);
   const int site = ln_sym_build(r, a.num_symbols, a.precision_bits, cap, lut, cum, symtab);
@@ -183,7 +246,7 @@ __device__ __forceinline__ void ln_symbols_stream(uint8_t *arena, const MeshLayo
   uint32_t x = 0, off = 0;
   if (!rans_init(buf, a.size_rans, 4u << a.precision_bits, &x, &off)) { fail(D, ST_INVALID, 402); return; }
   const bool positive = a.have_scheme && (a.pred_transform == 2 || a.pred_transform == 3);   // D-4
-  ln_sym_decode(arena, L.stream, a.off_rans, x, off, a.precision_bits, lut, cum, symtab, a.num_entries * a.nc_portable, positive, (int32_t *)(arena + L.work[ai]));
+  ln_sym_decode(arena, L.stream, a.off_rans, x, off, a.precision_bits, lut, cum, ring, kbuf, symtab, a.num_entries * a.nc_portable, positive, (int32_t *)(arena + L.work[ai]), ai == 0 ? D->dbg : nullptr);
 }
 
 // ------------------------------------------------------------------------------------- prediction inverse, lane per attribute
@@ -338,7 +401,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols_lanes(uint8_t *arena, const Me
   // the wave's LDS is sized by the largest table among its 64 streams: one launch per tier, the others leave
   uint32_t mx = distinct;
   for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, WAVE); mx = o > mx ? o : mx; }
-  if (mx == 0 || (mx <= LN_T0_SYMS ? LN_T0_SYMS : LN_T1_SYMS) != SYMS || !mine) return;
+  if (mx == 0 || ln_sym_tier(mx) != SYMS || !mine) return;
   ln_symbols_stream(arena, layouts[mesh], D, ai, SYMS, (uint16_t *)((uint8_t *)ln_lds + lane * ln_sym_stride(SYMS)));
 }
 #endif

@@ -49,7 +49,7 @@ int main(int argc, char **argv) {
   L.stream_len = (uint32_t)len;
   uint64_t cur = align_up(len + 1024, 256);
   std::vector<std::pair<uint64_t, uint64_t>> regions;
-  regions.push_back({0, align_up(len, 4)});          // the byte reservoir reads whole dwords
+  regions.push_back({0, align_up(len, 16)});         // the byte ring is filled in 16-byte chunks
   cur = layout_mesh(h, len, L, cur, 1024, &regions);
   BatchGlobals G;
   memset(&G, 0, sizeof(G));
@@ -71,7 +71,7 @@ int main(int argc, char **argv) {
     for (uint32_t ai = 0; ai < D.num_attributes; ++ai) {
       const AttrDesc &a = D.att[ai];
       if (!dsa::lanes::ln_sym_eligible(a, L, ai, LN_FLAG_SYMBOLS)) continue;
-      const uint32_t cap = a.num_distinct <= LN_T0_SYMS ? LN_T0_SYMS : LN_T1_SYMS;
+      const uint32_t cap = dsa::lanes::ln_sym_tier(a.num_distinct);
       std::vector<uint16_t> lds(dsa::lanes::ln_sym_stride(cap) / 2);
       dsa::lanes::ln_symbols_stream(arena.data(), L, &D, ai, cap, lds.data());
       decoded[ai] = 1;
