@@ -234,12 +234,17 @@ dsa_status dsa_context_set_profiling(dsa_context *ctx, int enabled) {
   return DSA_OK;
 }
 
+// No exception crosses the C boundary: a failed host allocation is DSA_ERR_OUT_OF_MEMORY, anything else DSA_ERR_DEVICE.
+#define DSA_GUARD(ctx, expr)                                                                              \
+  try { return (expr); }                                                                                   \
+  catch (const std::bad_alloc &) { return set_err((ctx), DSA_ERR_OUT_OF_MEMORY, "host allocation failed"); } \
+  catch (...) { return set_err((ctx), DSA_ERR_DEVICE, "unexpected failure inside the library"); }
+
 dsa_status dsa_batch_create(dsa_context *ctx, uint32_t n, const uint8_t *const *streams, const size_t *lengths, dsa_batch **out) {
-  return build_batch(ctx, n, streams, lengths, out);
+  DSA_GUARD(ctx, build_batch(ctx, n, streams, lengths, out));
 }
 
-dsa_status dsa_batch_create_packed(dsa_context *ctx, uint32_t n, const uint8_t *blob, const uint64_t *offsets, dsa_batch **out) {
-  if (!ctx || !out || (n && (!blob || !offsets))) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "null argument");
+static dsa_status create_packed(dsa_context *ctx, uint32_t n, const uint8_t *blob, const uint64_t *offsets, dsa_batch **out) {
   std::vector<const uint8_t *> ptrs(n);
   std::vector<size_t> lens(n);
   for (uint32_t i = 0; i < n; ++i) {
@@ -248,6 +253,10 @@ dsa_status dsa_batch_create_packed(dsa_context *ctx, uint32_t n, const uint8_t *
     lens[i] = (size_t)(offsets[i + 1] - offsets[i]);
   }
   return build_batch(ctx, n, ptrs.data(), lens.data(), out);
+}
+dsa_status dsa_batch_create_packed(dsa_context *ctx, uint32_t n, const uint8_t *blob, const uint64_t *offsets, dsa_batch **out) {
+  if (!ctx || !out || (n && (!blob || !offsets))) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "null argument");
+  DSA_GUARD(ctx, create_packed(ctx, n, blob, offsets, out));
 }
 
 dsa_status dsa_batch_decode(dsa_batch *b) {
@@ -328,6 +337,10 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // link symmetry + seam streams are checked on the second stream while the traversal runs here
   HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_conn, 0));
+  {                                                    // faces as point ids need the connectivity only: beside the traversal
+    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
+    hipLaunchKernelGGL(dsa::k_faces, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+  }
   {
     uint32_t lpm = 1;                                  // lanes per mesh >= attribute data per mesh (<= DSA_MAX_ATT_DATA = 7)
     while (lpm < b->max_att_data) lpm *= 2;
@@ -353,7 +366,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   HIP_TRY(ctx, hipEventRecord(ctx->ev_trav, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_trav, 0));
   {
-    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
+    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 16383) / 16384, 4));
     hipLaunchKernelGGL(dsa::k_point_maps, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st3));
@@ -383,8 +396,12 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   return DSA_OK;
 }
 
+static dsa_status batch_wait(dsa_batch *b);
 dsa_status dsa_batch_wait(dsa_batch *b) {
   if (!b) return DSA_ERR_INVALID_ARGUMENT;
+  DSA_GUARD(b->ctx, batch_wait(b));
+}
+static dsa_status batch_wait(dsa_batch *b) {
   dsa_context *ctx = b->ctx;
   if (!b->decoded) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "dsa_batch_decode was not called");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -545,17 +562,17 @@ dsa_status dsa_batch_copy_portable_values(const dsa_batch *b, uint32_t mesh, uin
 
 const int32_t *dsa_batch_device_faces(const dsa_batch *b, uint32_t mesh) {
   FOLLOW_RETRY(b, mesh, dsa_batch_device_faces(rb_, rm_));
-  if (!b || mesh >= b->n) return nullptr;
+  if (!b || mesh >= b->n || !b->collected || b->descs[mesh].status != ST_OK) return nullptr;
   return (const int32_t *)(b->arena + b->layouts[mesh].faces);
 }
 const void *dsa_batch_device_attribute_values(const dsa_batch *b, uint32_t mesh, uint32_t a) {
   FOLLOW_RETRY(b, mesh, dsa_batch_device_attribute_values(rb_, rm_, a));
-  if (!b || mesh >= b->n || a >= DSA_MAX_ATT) return nullptr;
+  if (!b || mesh >= b->n || !b->collected || b->descs[mesh].status != ST_OK || a >= b->descs[mesh].num_attributes) return nullptr;
   return b->arena + b->layouts[mesh].out[a];
 }
 const uint32_t *dsa_batch_device_point_map(const dsa_batch *b, uint32_t mesh, uint32_t a) {
   FOLLOW_RETRY(b, mesh, dsa_batch_device_point_map(rb_, rm_, a));
-  if (!b || mesh >= b->n || a >= DSA_MAX_ATT) return nullptr;
+  if (!b || mesh >= b->n || !b->collected || b->descs[mesh].status != ST_OK || a >= b->descs[mesh].num_attributes) return nullptr;
   return (const uint32_t *)(b->arena + b->layouts[mesh].map[a]);
 }
 

@@ -299,8 +299,12 @@ void dsa_encode_default_options(dsa_encode_options *o) {
   o->position_prediction = d.pos_prediction; o->texcoord_prediction = d.uv_prediction;
 }
 
+static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out);
 dsa_status dsa_encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out) {
   if (!ctx || !out || (n && !meshes)) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "null argument");
+  DSA_GUARD(ctx, encode_batch(ctx, n, meshes, options, out));     // host vectors and threads inside: nothing may unwind into the caller
+}
+static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   dsa_encode_options od;
   dsa_encode_default_options(&od);

@@ -759,8 +759,10 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   uint8_t *fvis = arena + L.fvis;
   uint8_t *vflag = arena + L.vvis;      // bit0 visited, bit1 on boundary
   const uint32_t F = uni(D->num_faces), NV = uni(D->num_vertices);
-  uint32_t *stack = (uint32_t *)(arena + L.faces);   // DFS stack: the faces output is only written by k_finalize
-  const uint32_t stack_cap = 3 * F;
+  // DFS stack: the topology-split map of k_connectivity is dead by now (the faces output is being written by k_faces
+  // meanwhile).  Only a face with two open sides pushes, and the last face cannot, so F entries always suffice.
+  uint32_t *stack = (uint32_t *)(arena + L.fstamp);
+  const uint32_t stack_cap = F;
   const uint32_t lane = lane_id();
   const uint64_t t_start = clk();
 
@@ -1206,7 +1208,8 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
   const MeshLayout &L = layouts[mesh];
   const AttrDesc &a = D->att[ai];
   if (lanes::ln_sym_eligible(a, L, ai, flags)) return;             // k_symbols_lanes
-  if (a.source != SRC_RAW || a.precision_bits != 12 || a.num_symbols > REG_MAX_SYMS || a.num_symbols <= 64) return;
+  // one non-zero symbol = a frequency of 4096, which the packed {freq, rem - cum} word cannot hold: k_symbols<T> takes it
+  if (a.source != SRC_RAW || a.precision_bits != 12 || a.num_symbols > REG_MAX_SYMS || a.num_symbols <= 64 || a.num_distinct <= 1) return;
   if (L.out_cap[ai] < 4096 * 6 + REG_MAX_SYMS * 4) return;      // scratch for the tables (k_symbols<T> takes the stream instead)
   const uint8_t *stream = arena + L.stream;
   uint32_t *out = (uint32_t *)(arena + L.work[ai]);
@@ -1409,7 +1412,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayo
   if (lanes::ln_sym_eligible(a, L, ai, flags)) return;             // k_symbols_lanes
   {
     const uint32_t ns = a.source == SRC_RAW ? a.num_symbols : 0u;
-    if (a.source == SRC_RAW && a.precision_bits == 12 && ns > 64 && ns <= REG_MAX_SYMS && L.out_cap[ai] >= 4096 * 6 + REG_MAX_SYMS * 4) return;   // k_symbols_reg
+    if (a.source == SRC_RAW && a.precision_bits == 12 && ns > 64 && ns <= REG_MAX_SYMS && a.num_distinct > 1 && L.out_cap[ai] >= 4096 * 6 + REG_MAX_SYMS * 4) return;   // k_symbols_reg
     const int tier = ns <= 64 ? 0 : (ns <= 960 ? 1 : 2);
     if (tier != TIER) return;
   }
@@ -1911,28 +1914,22 @@ __global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayo
 }
 
 // =========================================================================
-// k_point_maps: faces as point ids (Mesh.cs:15-69; MeshEdgeBreakerDecoder.cs:537-553,627-637) and the
+// k_faces / k_point_maps: faces as point ids (Mesh.cs:15-69; MeshEdgeBreakerDecoder.cs:537-553,627-637) and the
 // point -> entry map of every attribute (MeshTraversalSequencer.cs:33-50; vertex attributes on the
-// position corner table: one map value per vertex that has a corner).  Needs only the traversal, so it
-// runs beside the prediction kernels.
+// position corner table: one map value per vertex that has a corner).
 // =========================================================================
-__global__ __launch_bounds__(256) void k_point_maps(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+// k_faces: the face half (needs the connectivity only: launched behind k_connectivity, beside the traversal).
+__global__ __launch_bounds__(256) void k_faces(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   uint32_t mesh = blockIdx.y;
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK || D->general) return;   // k_general writes faces and maps of its meshes
+  if (D->status != ST_OK || D->general || D->encoder_type == 0) return;   // k_general writes the faces of its meshes
   const MeshLayout &L = layouts[mesh];
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   const uint4 *frec = (const uint4 *)(arena + L.frec);
   const uint32_t *vrank = (const uint32_t *)(arena + L.vrank);
-  const int32_t *v2d = (const int32_t *)(arena + L.v2d);
   int32_t *faces = (int32_t *)(arena + L.faces);
-  const uint32_t NV = D->num_vertices, na = D->num_attributes;
-  if (D->encoder_type == 0) {           // point cloud: linear sequencer, entry i = point i
-    for (uint32_t p = tid; p < D->num_points; p += stride)
-      for (uint32_t ai = 0; ai < na; ++ai) ((uint32_t *)(arena + L.map[ai]))[p] = p;
-    return;
-  }
+  const uint32_t NV = D->num_vertices;
   // Every link k_connectivity makes sets two corners; a corner linked twice ("corner already has an
   // opposite", MeshEdgeBreakerDecoder.cs:254,272,314,392) leaves fewer linked corners than 2 x links.
   uint32_t linked = 0, bad = 0;
@@ -1946,6 +1943,24 @@ __global__ __launch_bounds__(256) void k_point_maps(uint8_t *arena, const MeshLa
   for (int d = 32; d >= 1; d >>= 1) linked += __shfl_xor(linked, d, 64);
   if (lane_id() == 0 && linked) atomicAdd(&D->linked_corners, linked);
   if (__ballot(bad) && lane_id() == 0) fail(D, ST_INVALID, 263);
+}
+
+// k_point_maps: the point -> entry map of every attribute (needs the traversal).
+__global__ __launch_bounds__(256) void k_point_maps(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  uint32_t mesh = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->general) return;   // k_general writes the maps of its meshes
+  const MeshLayout &L = layouts[mesh];
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  const uint32_t *vrank = (const uint32_t *)(arena + L.vrank);
+  const int32_t *v2d = (const int32_t *)(arena + L.v2d);
+  const uint32_t NV = D->num_vertices, na = D->num_attributes;
+  if (D->encoder_type == 0) {           // point cloud: linear sequencer, entry i = point i
+    for (uint32_t p = tid; p < D->num_points; p += stride)
+      for (uint32_t ai = 0; ai < na; ++ai) ((uint32_t *)(arena + L.map[ai]))[p] = p;
+    return;
+  }
   for (uint32_t v = tid; v < NV; v += stride) {
     const int32_t e = v2d[v];
     if (e < 0) continue;                 // no corner: the map keeps its initial value

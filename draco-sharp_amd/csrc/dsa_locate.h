@@ -67,12 +67,18 @@ __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, Attr
         a.num_symbols = (uint32_t)ns;
         a.off_table = r.pos;
         REQUIRE(skip_prob_table(r, a.num_symbols, &a.num_distinct), 149);
-        if (a.num_symbols > SYM_MAX_LDS) {   // alphabet too large for the LDS search: cumulative table from the batch pool
+        if (a.num_symbols > SYM_MAX_LDS) {   // alphabet too large for the LDS search: cumulative table in global memory
           unsigned long long bytes = ((unsigned long long)a.num_symbols + 2) * 4;
           bytes = (bytes + 15) & ~15ull;
-          unsigned long long at = atomicAdd(&G->pool_cursor, bytes);
-          if (at + bytes > G->pool_bytes) NOTIMPL(166);
-          a.table = G->pool + at;
+          if (bytes <= L.out_cap[ai]) a.table = L.out[ai];       // the attribute's own output region: free until k_finalize
+          else {
+            // small mesh, large alphabet: the batch pool; when that is spent the mesh goes to the general path
+            // (a cumulative table per mesh), decoded again by dsa_batch_wait -- never a verdict that depends on the
+            // rest of the batch
+            unsigned long long at = atomicAdd(&G->pool_cursor, bytes);
+            if (at + bytes > G->pool_bytes) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+            a.table = G->pool + at;
+          }
         }
         uint64_t size = r.varint();
         a.off_rans = r.pos;

@@ -342,20 +342,28 @@ class Batch:
             vals = np.zeros((ai.num_entries, ai.num_components), _DT_NUMPY[ai.data_type])
             pmap = np.zeros(info.num_points, np.uint32)
             if ai.num_entries:
-                L.dsa_batch_copy_attribute_values(self._h, i, a, vals.ctypes.data)
+                st = L.dsa_batch_copy_attribute_values(self._h, i, a, vals.ctypes.data)
+                if st != 0:
+                    _raise(st, self.ctx.error())
             if info.num_points:
-                L.dsa_batch_copy_point_map(self._h, i, a, pmap.ctypes.data)
+                st = L.dsa_batch_copy_point_map(self._h, i, a, pmap.ctypes.data)
+                if st != 0:
+                    _raise(st, self.ctx.error())
             portable = None
             if ai.decoder_type != 0:
                 ncp = 2 if ai.decoder_type == 3 else ai.num_components
                 portable = np.zeros((ai.num_entries, ncp), np.int32)
                 if ai.num_entries:
-                    L.dsa_batch_copy_portable_values(self._h, i, a, portable.ctypes.data)
+                    st = L.dsa_batch_copy_portable_values(self._h, i, a, portable.ctypes.data)
+                    if st != 0:
+                        _raise(st, self.ctx.error())
             atts.append(PointAttribute(ai, vals, pmap, portable))
         metadata = None
         if info.flags & 0x8000:         # DracoDecoder.cs:23-28
             n = C.c_size_t(0)
-            L.dsa_batch_copy_metadata(self._h, i, None, 0, C.byref(n))
+            st = L.dsa_batch_copy_metadata(self._h, i, None, 0, C.byref(n))
+            if st != 0:
+                _raise(st, self.ctx.error())
             buf = (C.c_uint8 * max(1, n.value))()
             st = L.dsa_batch_copy_metadata(self._h, i, buf, n.value, C.byref(n))
             if st != 0:

@@ -91,13 +91,33 @@ def read_asset(source, base_dir=None, name=None):
         else:
             if base_dir is None:
                 raise InvalidDataException("%s: buffer %d is external (%s) and no base directory was given" % (name, i, uri))
-            from urllib.parse import unquote
-            with open(os.path.join(base_dir, unquote(uri)), "rb") as f:
-                raw = f.read()
+            raw = _read_external_buffer(name, i, base_dir, uri)
         if len(raw) < int(b.get("byteLength", 0)):
             raise InvalidDataException("%s: buffer %d is shorter than its byteLength" % (name, i))
         buffers.append(raw)
     return GltfAsset(doc, buffers, name)
+
+
+def _read_external_buffer(name, i, base_dir, uri):
+    """An external buffer is a file below the asset's own directory, nothing else: an asset is untrusted input, so
+    URIs with a scheme (file:, http:, ...), absolute paths and paths that climb out of base_dir (also percent-encoded
+    or through symbolic links) are rejected instead of opened."""
+    import re
+    from urllib.parse import unquote
+    if re.match(r"^[A-Za-z][A-Za-z0-9+.-]*:", uri):
+        raise InvalidDataException("%s: buffer %d: URI scheme not supported (%s)" % (name, i, uri.split(":", 1)[0]))
+    rel = unquote(uri)
+    if os.path.isabs(rel) or rel.startswith(("/", "\\")) or "\x00" in rel:
+        raise InvalidDataException("%s: buffer %d: absolute buffer path" % (name, i))
+    root = os.path.realpath(base_dir)
+    path = os.path.realpath(os.path.join(root, rel))
+    if os.path.commonpath([root, path]) != root or path == root:
+        raise InvalidDataException("%s: buffer %d: buffer path leaves the asset directory" % (name, i))
+    try:
+        with open(path, "rb") as f:
+            return f.read()
+    except OSError as e:
+        raise InvalidDataException("%s: buffer %d: cannot read external buffer (%s)" % (name, i, e.strerror))
 
 
 class DracoPrimitive:

@@ -103,6 +103,29 @@ def test_broken_containers_are_invalid_data(tmp_path):
         gltf.read_asset(json.dumps(doc).encode())
 
 
+def test_external_buffers_cannot_leave_the_asset_directory(tmp_path):
+    """An asset is untrusted input: buffer URIs with a scheme, absolute paths, and paths that climb out of the asset's
+    directory (plain, percent-encoded or through a symbolic link) are rejected, not opened."""
+    import os
+    streams, sources = _assets(tmp_path)
+    secret = tmp_path.parent / "secret.bin"
+    secret.write_bytes(b"x" * 4096)
+    sub = tmp_path / "sub"
+    sub.mkdir()
+    (sub / "inner.bin").write_bytes((tmp_path / "my scene.bin").read_bytes())
+    os.symlink(str(secret), str(tmp_path / "link.bin"))
+    doc = json.loads((tmp_path / "scene.gltf").read_text())
+    for uri in ("../secret.bin", "..%2Fsecret.bin", "%2e%2e/secret.bin", "sub/../../secret.bin", str(secret), "file://" + str(secret),
+                "file:secret.bin", "http://example.invalid/a.bin", "link.bin", "/etc/hostname", "."):
+        doc["buffers"][0]["uri"] = uri
+        (tmp_path / "evil.gltf").write_text(json.dumps(doc))
+        with pytest.raises(dsa.InvalidDataException):
+            gltf.read_asset(str(tmp_path / "evil.gltf"))
+    doc["buffers"][0]["uri"] = "sub/inner.bin"           # a path below the asset's directory is fine
+    (tmp_path / "nested.gltf").write_text(json.dumps(doc))
+    assert [p.stream for p in gltf.draco_primitives(gltf.read_asset(str(tmp_path / "nested.gltf")))] == [s for s, _, _ in streams]
+
+
 @pytest.mark.gpu
 def test_gpu_loader_decodes_all_primitives_in_one_batch(tmp_path):
     streams, sources = _assets(tmp_path)
