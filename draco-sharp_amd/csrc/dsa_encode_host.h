@@ -677,6 +677,11 @@ struct Options {
                                          // encoders write at their default level (CPU coder only)
   int32_t traversal_method = 0;      // attribute sequencing: 0 depth first; 1 prediction degree for the decoder of the positions
                                      // (what stock encoders do at their highest level); 2 prediction degree for every decoder (CPU coder only)
+  // Decoder branches no stock encoder setting reaches (CPU coder only; tests and tools/soak.py):
+  int32_t normal_transform = 3;      // 3 NormalOctahedronCanonicalized, 2 NormalOctahedron (difference prediction)
+  int32_t raw_integers = 0;          // 1 / 2 / 4: values of the difference / parallelogram attributes stored uncompressed at that many
+                                     // bytes (SequentialIntegerAttributeDecoder.cs:68-84)
+  int32_t no_prediction = 0;         // bit 0 positions, bit 1 texture coordinates, bit 2 normals: prediction method -2 (none)
 };
 
 // Octahedral quantisation (OctahedronToolBox.cs:28-119)
@@ -848,10 +853,31 @@ static void geometric_normal_prediction(const Octa &o, const CornerTable &ct, co
   }
 }
 
+// PredictionSchemeNormalOctahedronEncodingTransform.cs (the non-canonicalised transform: no rotation step)
+static void oct_plain_corr(const Octa &o, const int32_t orig_in[2], const int32_t pred_in[2], int32_t out[2]) {
+  int os = orig_in[0] - o.center, ot = orig_in[1] - o.center;
+  int ps = pred_in[0] - o.center, pt = pred_in[1] - o.center;
+  if (!o.in_diamond(ps, pt)) { o.invert_diamond(os, ot); o.invert_diamond(ps, pt); }
+  out[0] = o.make_positive(os - ps);
+  out[1] = o.make_positive(ot - pt);
+}
+
 static void write_attribute_values(ByteWriter &w, const PortableAttr &a, const CornerTable &ct, const Sequence &seq, const Options &opt,
                                    const PortableAttr *positions = nullptr) {
   int nc = a.nc;
   size_t entries = seq.data_to_corner.size();
+  // compressed flag + symbols: through the entropy coder, or as they are at 1 / 2 / 4 bytes each
+  auto put_symbols = [&](const std::vector<uint32_t> &sy) {
+    if (opt.raw_integers == 0) { w.u8(1); encode_symbols(w, sy, nc, opt.force_scheme, opt.compression_level); return; }
+    const int nb = opt.raw_integers;
+    check(nb == 1 || nb == 2 || nb == 4, "raw_integers must be 1, 2 or 4");
+    w.u8(0);
+    w.u8((uint8_t)nb);
+    for (uint32_t v : sy) {
+      check(nb == 4 || v < (1u << (8 * nb)), "value does not fit the raw integer width");
+      for (int k = 0; k < nb; ++k) w.u8((uint8_t)(v >> (8 * k)));
+    }
+  };
   // values in entry order
   std::vector<int32_t> d(entries * nc);
   for (size_t e = 0; e < entries; ++e) {
@@ -859,6 +885,15 @@ static void write_attribute_values(ByteWriter &w, const PortableAttr &a, const C
     for (int c = 0; c < nc; ++c) d[e * nc + c] = a.vals[(size_t)v * nc + c];
   }
   std::vector<uint32_t> symbols(entries * nc);
+  {
+    const int none_bit = a.seq_type == 3 ? 4 : (a.att_type == 0 ? 1 : (a.att_type == 3 ? 2 : 0));
+    if (opt.no_prediction & none_bit) {        // PredictionSchemeMethod.None (-2): no transform byte, the values themselves, signed
+      w.i8(-2);
+      for (size_t i = 0; i < symbols.size(); ++i) symbols[i] = zigzag(d[i]);
+      put_symbols(symbols);
+      return;
+    }
+  }
   if (a.seq_type == 3 && a.prediction == 6) {
     // MeshPredictionSchemeGeometricNormalEncoder.cs:47-108: the prediction or its negation, whichever leaves the
     // smaller correction; one flip bit per entry behind the transform data
@@ -892,19 +927,20 @@ static void write_attribute_values(ByteWriter &w, const PortableAttr &a, const C
     return;
   }
   if (a.seq_type == 3) {
+    const bool canonical = opt.normal_transform != 2;
     w.i8(0);   // Difference
-    w.i8(3);   // NormalOctahedronCanonicalized
+    w.i8(canonical ? 3 : 2);   // NormalOctahedronCanonicalized / NormalOctahedron
     Octa o(a.bits);
     int32_t zero[2] = {0, 0};
     for (size_t e = entries; e-- > 0;) {
       int32_t out[2];
-      oct_canon_corr(o, &d[e * 2], e ? &d[(e - 1) * 2] : zero, out);
+      if (canonical) oct_canon_corr(o, &d[e * 2], e ? &d[(e - 1) * 2] : zero, out);
+      else oct_plain_corr(o, &d[e * 2], e ? &d[(e - 1) * 2] : zero, out);
       symbols[e * 2] = (uint32_t)out[0]; symbols[e * 2 + 1] = (uint32_t)out[1];   // positive: no zig-zag
     }
-    w.u8(1);
-    encode_symbols(w, symbols, nc, opt.force_scheme, opt.compression_level);
+    put_symbols(symbols);
     w.i32(o.max_q);
-    w.i32(o.center);
+    if (canonical) w.i32(o.center);      // PredictionSchemeNormalOctahedronCanonicalizedDecodingTransform reads a centre it does not use
     return;
   }
   if (a.prediction == 5) {
@@ -1072,8 +1108,7 @@ static void write_attribute_values(ByteWriter &w, const PortableAttr &a, const C
     if (!have) for (int c = 0; c < nc; ++c) pred[c] = p > 0 ? d[(p - 1) * nc + c] : 0;
     for (int c = 0; c < nc; ++c) symbols[p * nc + c] = zigzag(wr.corr(d[p * nc + c], pred[c]));
   }
-  w.u8(1);
-  encode_symbols(w, symbols, nc, opt.force_scheme, opt.compression_level);
+  put_symbols(symbols);
   w.i32(wr.mn);
   w.i32(wr.mx);
 }

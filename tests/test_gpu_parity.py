@@ -339,6 +339,53 @@ def test_general_path_on_every_synthetic_case(ctx, monkeypatch):
     b.close()
 
 
+RARE = [dict(normal_transform=2), dict(raw_integers=4), dict(raw_integers=2, pos_bits=12, uv_bits=10, normal_bits=8),
+        dict(raw_integers=1, pos_bits=6, uv_bits=6, normal_bits=5), dict(no_prediction=1), dict(no_prediction=2), dict(no_prediction=4),
+        dict(no_prediction=7, raw_integers=2, pos_bits=10, uv_bits=10, normal_bits=7), dict(normal_transform=2, raw_integers=4, no_prediction=3),
+        dict(normal_transform=2, force_scheme=0), dict(no_prediction=7, force_scheme=0, single_connectivity=1)]
+
+
+@pytest.mark.parametrize("general", [False, True])
+def test_rare_decoder_branches(ctx, monkeypatch, general):
+    """The non-canonicalised octahedral transform (PredictionSchemeNormalOctahedronDecodingTransform.cs:47-76), integers
+    stored uncompressed at 1 / 2 / 4 bytes (SequentialIntegerAttributeDecoder.cs:68-84) and prediction method -2, on the
+    fast kernels and on the general path."""
+    if general:
+        monkeypatch.setenv("DSA_FORCE_GENERAL", "1")
+    streams = []
+    for kind, nx, ny in ((synth.GRID, 14, 11), (synth.TORUS, 10, 8), (synth.HOLES, 14, 12), (synth.GRID, 70, 50)):
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 21)
+        for opt in RARE:
+            streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(**opt)))
+    b = run_batch(ctx, streams)
+    for i, sbytes in enumerate(streams):
+        assert b.status(i) == 0, (i, b.status(i), b.mesh_info(i).detail)
+        assert_same(b.result(i), oracle.decode(sbytes), b, i)
+        assert (b.debug_array(i, 4, np.uint32, 12)[6] == 0) == general
+    b.close()
+
+
+def test_many_large_alphabets_in_one_batch(ctx):
+    """2048 small meshes whose streams carry alphabets beyond the LDS search (> 4032 symbols): the cumulative tables
+    live in the attributes' own regions, or in the batch pool, or -- when that is spent -- the mesh is decoded again by
+    the general path; the verdict of a stream never depends on the rest of the batch."""
+    rng = np.random.default_rng(3)
+    base = []
+    for k in range(8):
+        pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 40, 40, 50 + k)
+        pos = pos + rng.normal(0, 0.05, pos.shape).astype(np.float32)
+        base.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_bits=16, uv_bits=16, normal_bits=8, force_scheme=1)))
+    refs = [oracle.decode(s) for s in base]
+    streams = [base[i % 8] for i in range(2048)]
+    b = run_batch(ctx, streams)
+    assert all(int(r.attributes[0].symbols.max()) + 1 > 4032 for r in refs)      # the position alphabets are large ones
+    bad = [(i, b.status(i), b.mesh_info(i).detail) for i in range(len(streams)) if b.status(i) != 0]
+    assert not bad, bad[:5]
+    for i in list(range(0, 2048, 97)) + [2047]:
+        assert_same(b.result(i), refs[i % 8])
+    b.close()
+
+
 def test_geometric_normal_meshes_take_the_second_chance(ctx):
     """GeometricNormal prediction (method 6) needs the general path's tables, and the host parse cannot see the
     method byte behind the symbol streams: k_locate hands such meshes back (DSA_SITE_RETRY_GENERAL) and

@@ -80,7 +80,11 @@ def test_house04_through_the_general_path_source(exe, house04_bytes, tmp_path):
     # valence Edgebreaker traversal on holes, handles and two components, with the predictors stock encoders pair it with
     (synth.HOLES, 20, 16, {"predictive_connectivity": 2, "uv_prediction": 5, "normal_prediction": 6}),
     (synth.TORUS, 12, 9, {"predictive_connectivity": 2, "single_connectivity": 1, "force_scheme": 0}),
-    (synth.TWO_PARTS, 9, 6, {"predictive_connectivity": 2, "pos_prediction": 4, "traversal_method": 1}), (synth.HOLES, 14, 12, {"uv_prediction": 5, "normal_prediction": 6, "single_connectivity": 1})])
+    (synth.TWO_PARTS, 9, 6, {"predictive_connectivity": 2, "pos_prediction": 4, "traversal_method": 1}), (synth.HOLES, 14, 12, {"uv_prediction": 5, "normal_prediction": 6, "single_connectivity": 1}),
+    # decoder branches no stock setting reaches: non-canonicalised octahedral transform, uncompressed integers, prediction method -2
+    (synth.HOLES, 14, 12, {"normal_transform": 2}), (synth.TORUS, 10, 8, {"raw_integers": 4, "predictive_connectivity": 2}),
+    (synth.GRID, 14, 11, {"raw_integers": 1, "pos_bits": 6, "uv_bits": 6, "normal_bits": 5}), (synth.TWO_PARTS, 9, 6, {"raw_integers": 2, "pos_bits": 10, "normal_transform": 2, "force_scheme": 0}),
+    (synth.HOLES, 14, 12, {"no_prediction": 7}), (synth.TORUS, 10, 8, {"no_prediction": 5, "uv_prediction": 5, "single_connectivity": 1})])
 def test_synthetic_meshes_through_the_general_path_source(exe, tmp_path, kind, nx, ny, opts):
     pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 7)
     data = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(**opts))

@@ -57,6 +57,8 @@ CASES = [
     (synth.TORUS, 24, 20, {"pos_prediction": 0, "uv_prediction": 0}),                     # difference + wrap
     (synth.GRID, 30, 21, {"single_connectivity": 1}), (synth.GRID, 64, 64, {"pos_bits": 8, "uv_bits": 6, "normal_bits": 4}),
     (synth.GRID, 128, 64, {}),
+    # non-canonicalised octahedral transform; prediction method -2 (the symbols are the values)
+    (synth.HOLES, 20, 16, {"normal_transform": 2}), (synth.GRID, 40, 33, {"no_prediction": 7}), (synth.TORUS, 24, 20, {"no_prediction": 2, "normal_transform": 2}),
 ]
 
 

@@ -208,3 +208,31 @@ def test_predictive_and_valence_edgebreaker_traversal(kind, nx, ny, single, mode
     for a, r in zip(m.attributes, ref.attributes):
         assert np.array_equal(a.portable, r.portable) and np.array_equal(a.point_map, r.point_map)
     assert len(alt) < len(std) or nx * ny < 300          # six table headers outweigh the gain on tiny meshes
+
+
+# Decoder branches no stock encoder setting reaches: the non-canonicalised octahedral transform
+# (PredictionSchemeNormalOctahedronDecodingTransform.cs:47-76), integers stored uncompressed
+# (SequentialIntegerAttributeDecoder.cs:68-84) and prediction method -2 (none).
+RARE = [dict(normal_transform=2), dict(raw_integers=4), dict(raw_integers=2, pos_bits=12, uv_bits=10, normal_bits=8),
+        dict(raw_integers=1, pos_bits=6, uv_bits=6, normal_bits=5), dict(no_prediction=1), dict(no_prediction=2), dict(no_prediction=4),
+        dict(no_prediction=7, raw_integers=2, pos_bits=10, uv_bits=10, normal_bits=7), dict(normal_transform=2, raw_integers=4, no_prediction=3),
+        dict(normal_transform=2, force_scheme=0), dict(no_prediction=7, force_scheme=0, single_connectivity=1)]
+
+
+@pytest.mark.parametrize("opt", RARE)
+@pytest.mark.parametrize("kind,nx,ny", [(synth.GRID, 14, 11), (synth.TORUS, 10, 8), (synth.HOLES, 14, 12)])
+def test_rare_decoder_branches(kind, nx, ny, opt):
+    m = check_roundtrip(kind, nx, ny, 21, **opt)
+    ap, an, au = m.attributes
+    if opt.get("normal_transform") == 2 and not opt.get("no_prediction", 0) & 4:
+        assert (an.pred_method, an.pred_transform) == (0, 2)
+    for bit, a in ((1, ap), (4, an), (2, au)):
+        if opt.get("no_prediction", 0) & bit:
+            assert a.pred_method == -2
+    # the same mesh through the ordinary branches decodes to the same integers and floats
+    pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 21)
+    plain = {k: v for k, v in opt.items() if k not in ("normal_transform", "raw_integers", "no_prediction")}
+    ref = oracle.decode(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(**plain)))
+    assert np.array_equal(m.faces, ref.faces)
+    for a, r in zip(m.attributes, ref.attributes):
+        assert np.array_equal(a.portable, r.portable) and a.values.tobytes() == r.values.tobytes() and np.array_equal(a.point_map, r.point_map)

@@ -18,6 +18,17 @@ def random_case(rng):
                compression_level=int(rng.integers(0, 11)), pos_prediction=int(rng.choice([0, 1, 2, 4])),
                uv_prediction=int(rng.choice([0, 1, 2, 4, 5])), normal_prediction=int(rng.choice([0, 6])),
                traversal_method=int(rng.integers(0, 3)), predictive_connectivity=int(rng.integers(0, 3)))
+    # decoder branches no stock setting reaches (one case in three): the non-canonicalised octahedral transform, uncompressed
+    # integers (the width must hold the zig-zagged corrections), prediction method -2
+    if rng.integers(0, 3) == 0:
+        opt["normal_transform"] = int(rng.choice([2, 3]))
+        opt["no_prediction"] = int(rng.integers(0, 8))
+        raw = int(rng.choice([0, 1, 2, 4]))
+        if raw == 1:
+            opt.update(pos_bits=min(opt["pos_bits"], 6), uv_bits=min(opt["uv_bits"], 6), normal_bits=min(opt["normal_bits"], 6))
+        elif raw == 2:
+            opt.update(pos_bits=min(opt["pos_bits"], 14), uv_bits=min(opt["uv_bits"], 14))
+        opt["raw_integers"] = raw
     pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, int(rng.integers(0, 1 << 30)))
     with_n, with_uv = bool(rng.integers(0, 4)), bool(rng.integers(0, 4))
     return synth.encode_mesh(pos, faces, nrm if with_n else None, uv if with_uv else None, opt=synth.options(**opt)), (kind, nx, ny, opt, with_n, with_uv)
