@@ -59,8 +59,22 @@ WORKER = textwrap.dedent("""
     elapsed = time.perf_counter() - t0 + 0.01 * (comm.rank + 1)     # rank 1 is "slower"
     value, worst = aggregate_throughput(b - a, elapsed, 1, comm)
     total_faces = comm.sum(faces)
+    # strong split (BASELINE.json configs[3], bench.py --scaling strong): every rank derives the SAME job, the streams are
+    # assigned longest first, each rank decodes only its own
+    from draco_sharp_amd.sharding import balanced_assignment
+    streams = []
+    for i in range(n):
+        pos, nrm, uv, f = synth.make_mesh(synth.GRID, 6 + i, 5, 100 + i)
+        streams.append(synth.encode_mesh(pos, f, nrm, uv))
+    parts = balanced_assignment([len(s) for s in streams], comm.world)
+    strong_faces = sum(oracle.decode(streams[i]).num_faces for i in parts[comm.rank])
+    strong_total = comm.sum(strong_faces)
+    sizes = [int(comm.sum(len(parts[comm.rank]) if r == comm.rank else 0)) for r in range(comm.world)]
+    strong_bytes = [int(comm.sum(sum(len(streams[i]) for i in parts[comm.rank]) if r == comm.rank else 0)) for r in range(comm.world)]
     if comm.rank == 0:
-        print(json.dumps({"value": value, "worst": worst, "mine": elapsed, "total_faces": total_faces, "shard": [a, b]}))
+        print(json.dumps({"value": value, "worst": worst, "mine": elapsed, "total_faces": total_faces, "shard": [a, b],
+                          "strong_total_faces": strong_total, "strong_sizes": sizes, "strong_bytes": strong_bytes,
+                          "parts": parts, "max_stream": max(len(s) for s in streams)}))
     comm.close()
 """)
 
@@ -84,3 +98,7 @@ def test_two_gloo_ranks_shard_and_reduce(tmp_path):
     # MAX over ranks: rank 1 added more delay than rank 0
     assert res["worst"] >= res["mine"]
     assert abs(res["value"] - 6 / res["worst"]) < 1e-6
+    # the strong split: a partition of the same six streams, balanced by compressed bytes, every face counted once
+    assert sorted(i for p in res["parts"] for i in p) == list(range(6)) and res["strong_sizes"] == [len(p) for p in res["parts"]]
+    assert res["strong_total_faces"] == res["total_faces"]
+    assert abs(res["strong_bytes"][0] - res["strong_bytes"][1]) <= res["max_stream"]
