@@ -11,6 +11,84 @@ def quantize(vals, qmin, qrange, bits):
     return np.floor(((vals - mn).astype(np.float32) * inv).astype(np.float32) + np.float32(0.5)).astype(np.int64)
 
 
+def source_quantization(vals, bits):
+    """(min[c], range, quantised values) of a float32 source array, derived from the source alone by the rules of
+    AttributeQuantizationTransform.cs:66-108,136-177 + Core/Quantizer.cs:12-21 (SURVEY.md App. D "Quantise"): per-component
+    minimum, range = largest component extent (1 if 0), q = floor((v - min) * (max_q / range) + 0.5) in float32."""
+    vals = np.asarray(vals, np.float32)
+    mn = vals.min(axis=0).astype(np.float32)
+    rng = np.float32((vals.max(axis=0).astype(np.float32) - mn).max())
+    if rng == 0:
+        rng = np.float32(1.0)
+    return mn, rng, quantize(vals, mn, rng, bits)
+
+
+def oct_quantize(normals, bits):
+    """Octahedral quantisation of float normals, restated in numpy from OctahedronToolBox.cs:28-119 (SURVEY.md App. D
+    "Octahedral quantise"): scale to L1 norm 1 (double arithmetic), x and y rounded times the centre value, z by the
+    remainder with the two fix-ups, then (s, t) with the canonicalisation of the edge cases.  Independent of the stream
+    writer's C++ (draco-sharp_amd/csrc/dsa_encode_host.h)."""
+    v = np.asarray(normals, np.float64)
+    max_value = (1 << bits) - 2
+    center = max_value // 2
+    abs_sum = np.abs(v).sum(axis=1)
+    ok = abs_sum > 1e-6
+    sv = np.where(ok[:, None], v * (1.0 / np.where(ok, abs_sum, 1.0))[:, None], np.array([1.0, 0.0, 0.0]))
+    i0 = np.floor(sv[:, 0] * center + 0.5).astype(np.int64)
+    i1 = np.floor(sv[:, 1] * center + 0.5).astype(np.int64)
+    i2 = center - np.abs(i0) - np.abs(i1)
+    neg = i2 < 0
+    i1 = np.where(neg, np.where(i1 > 0, i1 + i2, i1 - i2), i1)
+    i2 = np.where(neg, 0, i2)
+    i2 = np.where(sv[:, 2] < 0, -i2, i2)
+    s = np.where(i0 >= 0, i1 + center, np.where(i1 < 0, np.abs(i2), max_value - np.abs(i2)))
+    t = np.where(i0 >= 0, i2 + center, np.where(i2 < 0, np.abs(i1), max_value - np.abs(i1)))
+    # CanonicalizeOctahedralCoords, first matching rule wins
+    out_s, out_t = s.copy(), t.copy()
+    done = np.zeros(len(s), bool)
+    r = ((s == 0) & (t == 0)) | ((s == 0) & (t == max_value)) | ((s == max_value) & (t == 0))
+    out_s[r], out_t[r] = max_value, max_value
+    done |= r
+    r = ~done & (s == 0) & (t > center)
+    out_t[r] = center - (t[r] - center)
+    done |= r
+    r = ~done & (s == max_value) & (t < center)
+    out_t[r] = center + (center - t[r])
+    done |= r
+    r = ~done & (t == max_value) & (s < center)
+    out_s[r] = center + (center - s[r])
+    done |= r
+    r = ~done & (t == 0) & (s > center)
+    out_s[r] = center - (s[r] - center)
+    return np.stack([out_s, out_t], axis=1)
+
+
+def source_corner_faces(pos, normals, uvs, faces, pos_bits=11, normal_bits=8, uv_bits=10):
+    """The quantised mesh a conformant codec must reproduce, from the INPUT alone: per vertex the key (quantised
+    position, octahedral normal, quantised texture coordinate), per face its three keys up to rotation, as a sorted
+    list.  Also returns the quantisation parameters the stream has to carry."""
+    pmin, prange, qp = source_quantization(pos, pos_bits)
+    umin, urange, qu = source_quantization(uvs, uv_bits)
+    keys = np.concatenate([qp, oct_quantize(normals, normal_bits), qu], axis=1)
+    return face_multiset_fast(faces, keys), (pmin, prange, umin, urange)
+
+
+def face_multiset_fast(faces, per_point_keys):
+    """Sorted rotation-canonical faces as an int64 array [F, 3 * K] (numpy throughout: 64k-triangle meshes)."""
+    k = np.asarray(per_point_keys, np.int64)[np.asarray(faces, np.int64)]            # [F, 3, K]
+    rots = np.stack([k.reshape(len(k), -1), np.roll(k, -1, axis=1).reshape(len(k), -1), np.roll(k, -2, axis=1).reshape(len(k), -1)], axis=1)   # [F, 3, 3K]
+    # lexicographically smallest rotation per face
+    best = rots[:, 0]
+    for j in (1, 2):
+        cand = rots[:, j]
+        diff = cand != best
+        first = np.where(diff.any(axis=1), diff.argmax(axis=1), 0)
+        less = diff.any(axis=1) & (cand[np.arange(len(cand)), first] < best[np.arange(len(best)), first])
+        best = np.where(less[:, None], cand, best)
+    order = np.lexsort(best.T[::-1])
+    return best[order]
+
+
 def canon_face(keys):
     r = [tuple(keys[i:] + keys[:i]) for i in range(3)]
     return min(r)

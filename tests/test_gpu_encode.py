@@ -7,7 +7,7 @@ import pytest
 import oracle
 import draco_sharp_amd as dsa
 import draco_sharp_amd.synth as synth
-from meshutil import quantize
+from meshutil import face_multiset_fast, source_corner_faces
 
 pytestmark = pytest.mark.gpu
 
@@ -51,17 +51,18 @@ def test_gpu_encoder_matches_cpu_coder_byte_for_byte(ctx):
             exp = cpu_stream(p, f, n, u, cfg)
             assert len(g) == len(exp)
             assert g == exp
-            meshes.append((p, cfg)); expected.append(g)
-    # round trip through the GPU decoder: portable positions == quantised input (in traversal order)
+            meshes.append((p, f, n, u, cfg)); expected.append(g)
+    # round trip through the GPU decoder: every face corner carries the quantised input -- position, octahedral normal
+    # and texture coordinate, derived from the INPUT with the numpy rules of meshutil (not with the coder under test)
     b = dsa.Batch(ctx, expected)
     b.decode()
-    for i, (p, cfg) in enumerate(meshes):
+    for i, (p, f, n, u, cfg) in enumerate(meshes):
         assert b.status(i) == 0
         m = b.result(i).ConnectedData
-        a = m.Attributes[0]
-        q = quantize(p, a.MinValues[:3], a.Range, a.QuantizationBits)
-        got = {tuple(int(x) for x in row) for row in a.PortableValues}
-        assert got == {tuple(int(x) for x in row) for row in q}
+        want, _ = source_corner_faces(p, n, u, f, cfg.position_bits, cfg.normal_bits, cfg.texcoord_bits)
+        keys = np.concatenate([np.asarray(a.PortableValues, np.int64)[np.asarray(a.PointMap, np.int64)] for a in m.Attributes], axis=1)
+        got = face_multiset_fast(m.Faces, keys)
+        assert got.shape == want.shape and np.array_equal(got, want)
     b.close()
 
 
