@@ -5,5 +5,5 @@ host-side mirror used by the tests and bench harness."""
 __version__ = "0.1.0"
 
 from .decoder import (Batch, Context, DataBuffer, DeviceException, Draco, DracoDecoder, DracoHeader, DracoMetadata,  # noqa: E402,F401
-                      InvalidDataException, Mesh, MetadataElement, PointAttribute, PointCloud, parse_metadata)
+                      InvalidDataException, Mesh, MetadataElement, PointAttribute, PointCloud, Pool, PoolJob, parse_metadata, pool_plan)
 from .encoder import Config, DracoEncoder, MeshData  # noqa: E402,F401

@@ -73,7 +73,9 @@ public sealed unsafe class GpuDracoDecoder : IDisposable
         }
     }
 
-    private Draco Materialize(IntPtr batch, uint mesh)
+    private Draco Materialize(IntPtr batch, uint mesh) => Materialize(_ctx, batch, mesh);
+
+    internal static Draco Materialize(IntPtr _ctx, IntPtr batch, uint mesh)
     {
         NativeMethods.Check(NativeMethods.dsa_batch_mesh_info(batch, mesh, out var info), _ctx, "dsa_batch_mesh_info");
         NativeMethods.Check((DsaStatus)info.Status, IntPtr.Zero, $"stream {mesh}: decode failed (site {info.Detail})");
@@ -111,7 +113,7 @@ public sealed unsafe class GpuDracoDecoder : IDisposable
         return new Draco
         {
             Header = new DracoHeader(info.MajorVersion, info.MinorVersion, info.EncoderType, info.EncoderMethod, info.Flags),
-            Metadata = (info.Flags & 0x8000) != 0 ? ReadMetadata(batch, mesh) : null,   // DracoDecoder.cs:23-28
+            Metadata = (info.Flags & 0x8000) != 0 ? ReadMetadata(_ctx, batch, mesh) : null,   // DracoDecoder.cs:23-28
             ConnectedData = result,
             Attributes = result.Attributes
         };
@@ -120,7 +122,7 @@ public sealed unsafe class GpuDracoDecoder : IDisposable
     // The metadata block byte for byte from the native side (it only skips it), parsed into the reference's
     // DracoMetadata / MetadataElement here.  Layout: Metadata/MetadataDecoder.cs:5-49, with value sizes as varints
     // (what the bitstream writes; the managed decoder reads a single byte there).
-    private DracoMetadata ReadMetadata(IntPtr batch, uint mesh)
+    private static DracoMetadata ReadMetadata(IntPtr _ctx, IntPtr batch, uint mesh)
     {
         NativeMethods.Check(NativeMethods.dsa_batch_copy_metadata(batch, mesh, null, 0, out nuint length), _ctx, "dsa_batch_copy_metadata");
         var block = new byte[(int)length];
@@ -161,5 +163,68 @@ public sealed unsafe class GpuDracoDecoder : IDisposable
     public void Dispose()
     {
         if (_ctx != IntPtr.Zero) { NativeMethods.dsa_context_destroy(_ctx); _ctx = IntPtr.Zero; }
+    }
+}
+
+/// <summary>All GPUs of the node behind one managed object: the library owns one context and one worker thread per
+/// listed device and hands the streams of a call out longest first through an atomic queue (dsa_pool_*; meshes are
+/// independent, DracoDecoder.cs:19-42, so there is no collective).  A device may be listed more than once.</summary>
+public sealed unsafe class GpuDracoDecoderPool : IDisposable
+{
+    private IntPtr _pool;
+
+    public GpuDracoDecoderPool(IReadOnlyList<int> devices, uint chunkMeshes = 256)
+    {
+        var d = new int[devices.Count];
+        for (int i = 0; i < d.Length; ++i) d[i] = devices[i];
+        fixed (int* p = d) NativeMethods.Check(NativeMethods.dsa_pool_create(p, (uint)d.Length, chunkMeshes, out _pool), IntPtr.Zero, "no usable GPU in the device list");
+    }
+
+    public int Workers => (int)NativeMethods.dsa_pool_size(_pool);
+
+    /// <summary>Decodes independent .drc streams on every GPU of the pool.  Element i of the result is stream i's Draco
+    /// object, or null with errors[i] set to what the reference would have thrown for that stream.</summary>
+    public Draco?[] DecodeBatch(IReadOnlyList<byte[]> streams, out Exception?[] errors)
+    {
+        var handles = new System.Runtime.InteropServices.GCHandle[streams.Count];
+        var ptrs = new byte*[streams.Count];
+        var lens = new nuint[streams.Count];
+        IntPtr job = IntPtr.Zero;
+        try
+        {
+            for (int i = 0; i < streams.Count; ++i)
+            {
+                handles[i] = System.Runtime.InteropServices.GCHandle.Alloc(streams[i], System.Runtime.InteropServices.GCHandleType.Pinned);
+                ptrs[i] = (byte*)handles[i].AddrOfPinnedObject();
+                lens[i] = (nuint)streams[i].Length;
+            }
+            DsaStatus st;
+            fixed (byte** p = ptrs)
+            fixed (nuint* l = lens)
+            {
+                st = NativeMethods.dsa_pool_decode(_pool, (uint)streams.Count, p, l, out job);
+            }
+            if (st != DsaStatus.Ok)
+                NativeMethods.Check(st, IntPtr.Zero, "dsa_pool_decode: " + System.Runtime.InteropServices.Marshal.PtrToStringAnsi(NativeMethods.dsa_pool_last_error(_pool)));
+            var results = new Draco?[streams.Count];
+            errors = new Exception?[streams.Count];
+            for (uint i = 0; i < streams.Count; ++i)
+            {
+                NativeMethods.Check(NativeMethods.dsa_pool_job_locate(job, i, out var batch, out var mesh, out _), IntPtr.Zero, "dsa_pool_job_locate");
+                try { results[i] = GpuDracoDecoder.Materialize(IntPtr.Zero, batch, mesh); }
+                catch (Exception e) when (e is InvalidDataException or NotImplementedException) { errors[i] = e; }
+            }
+            return results;
+        }
+        finally
+        {
+            if (job != IntPtr.Zero) NativeMethods.dsa_pool_job_free(job);
+            foreach (var h in handles) if (h.IsAllocated) h.Free();
+        }
+    }
+
+    public void Dispose()
+    {
+        if (_pool != IntPtr.Zero) { NativeMethods.dsa_pool_destroy(_pool); _pool = IntPtr.Zero; }
     }
 }

@@ -107,6 +107,17 @@ internal static unsafe partial class NativeMethods
     [DllImport(Lib)] internal static extern DsaStatus dsa_encoded_stream(IntPtr encoded, uint mesh, out byte* bytes, out nuint length);
     [DllImport(Lib)] internal static extern void dsa_encoded_free(IntPtr encoded);
 
+    // multi-GPU submit for a single-process host: one context + worker thread per listed device inside the library
+    [DllImport(Lib)] internal static extern DsaStatus dsa_pool_create(int* devices, uint numDevices, uint chunkMeshes, out IntPtr pool);
+    [DllImport(Lib)] internal static extern void dsa_pool_destroy(IntPtr pool);
+    [DllImport(Lib)] internal static extern uint dsa_pool_size(IntPtr pool);
+    [DllImport(Lib)] internal static extern IntPtr dsa_pool_last_error(IntPtr pool);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_pool_decode(IntPtr pool, uint n, byte** streams, nuint* lengths, out IntPtr job);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_pool_job_locate(IntPtr job, uint stream, out IntPtr batch, out uint mesh, out uint worker);
+    [DllImport(Lib)] internal static extern uint dsa_pool_job_chunks(IntPtr job);
+    [DllImport(Lib)] internal static extern void dsa_pool_job_free(IntPtr job);
+    [DllImport(Lib)] internal static extern uint dsa_pool_plan(uint n, nuint* lengths, uint chunkMeshes, uint* order, uint* chunkBegin);
+
     internal static void Check(DsaStatus status, IntPtr ctx, string what)
     {
         if (status == DsaStatus.Ok) return;

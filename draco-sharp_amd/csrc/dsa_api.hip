@@ -653,3 +653,4 @@ dsa_status dsa_batch_stage_times(const dsa_batch *b, float ms[DSA_NUM_STAGES], c
 }  // extern "C"
 
 #include "dsa_encode.h"
+#include "dsa_pool.h"

@@ -459,3 +459,122 @@ class DracoDecoder:
             return [b.result(i) for i in range(b.n)]
         finally:
             b.close()
+
+
+class _PoolErrors:
+    """What a Batch view of a pool job asks its `ctx` for."""
+
+    def __init__(self, pool):
+        self._pool = pool
+        self.device = None
+
+    def error(self):
+        return self._pool.error()
+
+
+class PoolJob:
+    """Results of Pool.decode: every stream was decoded in some chunk on some worker; result(i) / status(i) follow
+    dsa_pool_job_locate to the batch that holds stream i."""
+
+    def __init__(self, pool, handle, n):
+        self._pool, self._L, self._h, self.n = pool, pool._L, handle, n
+        self._views = {}
+
+    def locate(self, i):
+        b, m, w = C.c_void_p(), C.c_uint32(), C.c_uint32()
+        st = self._L.dsa_pool_job_locate(self._h, i, C.byref(b), C.byref(m), C.byref(w))
+        if st != 0:
+            _raise(st, "stream index %d out of range" % i)
+        return b.value, int(m.value), int(w.value)
+
+    def _view(self, handle, worker):
+        v = self._views.get(handle)
+        if v is None:
+            v = Batch.__new__(Batch)                     # a view: the job owns the batch
+            v.ctx = _PoolErrors(self._pool)
+            v.ctx.device = self._pool.devices[worker]
+            v._L, v._h, v.n = self._L, C.c_void_p(handle), int(self._L.dsa_batch_size(C.c_void_p(handle)))
+            v.close = lambda: None
+            self._views[handle] = v
+        return v
+
+    def status(self, i):
+        h, m, w = self.locate(i)
+        return self._view(h, w).status(m)
+
+    def worker(self, i):
+        return self.locate(i)[2]
+
+    def result(self, i):
+        h, m, w = self.locate(i)
+        return self._view(h, w).result(m)
+
+    @property
+    def chunks(self):
+        return int(self._L.dsa_pool_job_chunks(self._h))
+
+    def close(self):
+        if self._h:
+            for v in self._views.values():
+                v._h = None
+            self._views = {}
+            self._L.dsa_pool_job_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pool:
+    """One context + worker thread per listed GPU inside the library (dsa_pool_*): what a single-process host (the C#
+    one) uses instead of one process per GPU.  Streams are handed out longest first in chunks of `chunk_meshes`
+    through one atomic queue; there is no collective."""
+
+    def __init__(self, devices, chunk_meshes=256):
+        self._L = native.lib()
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        st = self._L.dsa_pool_create(arr, len(self.devices), chunk_meshes, C.byref(h))
+        if st != 0:
+            raise DeviceException("dsa_pool_create(devices=%s) failed with status %d (is a GPU visible?)" % (self.devices, st))
+        self._h = h
+
+    def error(self):
+        return self._L.dsa_pool_last_error(self._h).decode() if self._h else "pool closed"
+
+    def decode(self, streams):
+        n = len(streams)
+        bufs = [(C.c_uint8 * max(1, len(s))).from_buffer_copy(s if len(s) else b"\0") for s in streams]
+        ptrs = (C.c_void_p * max(1, n))(*[C.addressof(b) for b in bufs])
+        lens = (C.c_size_t * max(1, n))(*[len(s) for s in streams])
+        h = C.c_void_p()
+        st = self._L.dsa_pool_decode(self._h, n, ptrs, lens, C.byref(h))
+        if st != 0:
+            _raise(st, self.error())
+        return PoolJob(self, h, n)
+
+    def close(self):
+        if self._h:
+            self._L.dsa_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pool_plan(lengths, chunk_meshes):
+    """The queue order dsa_pool_decode uses (no GPU needed): (order, chunk_begin)."""
+    L = native.lib()
+    n = len(lengths)
+    lens = (C.c_size_t * max(1, n))(*[int(x) for x in lengths])
+    order = (C.c_uint32 * max(1, n))()
+    begin = (C.c_uint32 * (n + 1))()
+    chunks = L.dsa_pool_plan(n, lens, chunk_meshes, order, begin)
+    return list(order[:n]), list(begin[:chunks + 1])

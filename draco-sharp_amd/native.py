@@ -19,6 +19,8 @@ EXPORTS = [
     "dsa_batch_copy_portable_values", "dsa_batch_device_faces", "dsa_batch_device_attribute_values",
     "dsa_batch_device_point_map", "dsa_batch_copy_metadata", "dsa_batch_copy_debug", "dsa_context_set_profiling", "dsa_batch_stage_times",
     "dsa_encode_default_options", "dsa_encode_batch", "dsa_encoded_size", "dsa_encoded_stream", "dsa_encoded_free",
+    "dsa_pool_create", "dsa_pool_destroy", "dsa_pool_size", "dsa_pool_last_error", "dsa_pool_decode", "dsa_pool_job_locate",
+    "dsa_pool_job_chunks", "dsa_pool_job_free", "dsa_pool_plan",
 ]
 
 
@@ -51,7 +53,7 @@ class AttributeInfo(C.Structure):
 def build(force=False):
     """Compiles the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(_DIR, f) for f in ("dsa_api.hip", "dsa_kernels.h", "dsa_general.h", "dsa_common.h", "dsa_host_parse.h",
-                                            "dsa_encode.h", "dsa_encode_host.h", "dsa_types.h")]
+                                            "dsa_encode.h", "dsa_encode_host.h", "dsa_types.h", "dsa_lanes.h", "dsa_locate.h", "dsa_pool.h")]
     srcs.append(os.path.join(_DIR, "..", "..", "include", "draco_mi355x.h"))
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _DIR, "-s"])
@@ -109,5 +111,20 @@ def lib():
         L.dsa_encoded_stream.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.dsa_encoded_free.argtypes = [vp]
         L.dsa_encoded_free.restype = None
+        L.dsa_pool_create.argtypes = [C.POINTER(C.c_int), u32, u32, C.POINTER(vp)]
+        L.dsa_pool_destroy.argtypes = [vp]
+        L.dsa_pool_destroy.restype = None
+        L.dsa_pool_size.argtypes = [vp]
+        L.dsa_pool_size.restype = u32
+        L.dsa_pool_last_error.argtypes = [vp]
+        L.dsa_pool_last_error.restype = C.c_char_p
+        L.dsa_pool_decode.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
+        L.dsa_pool_job_locate.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]
+        L.dsa_pool_job_chunks.argtypes = [vp]
+        L.dsa_pool_job_chunks.restype = u32
+        L.dsa_pool_job_free.argtypes = [vp]
+        L.dsa_pool_job_free.restype = None
+        L.dsa_pool_plan.argtypes = [u32, C.POINTER(C.c_size_t), u32, C.POINTER(u32), C.POINTER(u32)]
+        L.dsa_pool_plan.restype = u32
         _lib = L
     return _lib

@@ -183,6 +183,32 @@ uint32_t dsa_encoded_size(const dsa_encoded *encoded);
 dsa_status dsa_encoded_stream(const dsa_encoded *encoded, uint32_t mesh, const uint8_t **bytes, size_t *length);
 void dsa_encoded_free(dsa_encoded *encoded);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Multi-GPU submit for a host that is one process (the C# host cannot use torch.distributed): a pool owns one
+ * context per listed device and decodes a list of independent streams with one worker thread per context.
+ * The reference creates everything per call (src/Draco/IO/DracoDecoder.cs:19-42): streams share nothing, so the
+ * partition is free -- streams are sorted by compressed length (longest first, the proxy for decode work), cut into
+ * chunks of `chunk_meshes`, and the workers pull chunk after chunk from one atomic queue; a chunk is one batch on the
+ * worker's context (no collective, no peer traffic).  A device may be listed more than once
+ * (several contexts on one GPU).  dsa_pool_decode blocks until every chunk is decoded; results stay on the device
+ * that decoded them and are read through the dsa_batch_* accessors of the batch dsa_pool_job_locate names. */
+typedef struct dsa_pool dsa_pool;
+typedef struct dsa_pool_job dsa_pool_job;
+
+dsa_status dsa_pool_create(const int *devices, uint32_t num_devices, uint32_t chunk_meshes, dsa_pool **out);
+void dsa_pool_destroy(dsa_pool *pool);
+uint32_t dsa_pool_size(const dsa_pool *pool);                 /* number of contexts / worker threads */
+const char *dsa_pool_last_error(const dsa_pool *pool);
+dsa_status dsa_pool_decode(dsa_pool *pool, uint32_t n, const uint8_t *const *streams, const size_t *lengths, dsa_pool_job **out);
+/* Where stream `stream` of the job was decoded: the batch, its index inside it, and the worker (index into the
+ * pool's device list) that took its chunk. */
+dsa_status dsa_pool_job_locate(const dsa_pool_job *job, uint32_t stream, const dsa_batch **batch, uint32_t *mesh, uint32_t *worker);
+uint32_t dsa_pool_job_chunks(const dsa_pool_job *job);
+void dsa_pool_job_free(dsa_pool_job *job);
+/* The queue order of a job (no GPU needed): order[0..n) = stream indices longest first (ties by index),
+ * chunk_begin[0..chunks] = chunk boundaries in `order` (chunk_begin needs n + 1 entries).  Returns the chunk count. */
+uint32_t dsa_pool_plan(uint32_t n, const size_t *lengths, uint32_t chunk_meshes, uint32_t *order, uint32_t *chunk_begin);
+
 #ifdef __cplusplus
 }
 #endif
