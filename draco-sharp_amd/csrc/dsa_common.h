@@ -226,6 +226,30 @@ __device__ __forceinline__ void para_operands_of(uint32_t p, const uint32_t *fre
   para[3 * p] = en; para[3 * p + 1] = ep; para[3 * p + 2] = eo;
 }
 
+// ---- staging of a stream that is consumed from its tail (rANS: state = state * 256 + buf[--offset], RAnsDecoder.cs:58-61)
+// Global memory answers in 0.5-1 us when the chip is busy, and the memory counter of a wave is in order (waiting for
+// a load waits for every older store as well), so the serial decoders touch global memory only at the boundaries of
+// 16-symbol blocks: the stream sits in an LDS ring of eight 16-byte chunks (chunk c = arena bytes
+// [base - 16(c+1), base - 16c), base = the 16-byte boundary behind the first byte to take), two chunks are requested
+// at a boundary and written into the ring at the next one.  The q-th byte taken, counted from `base` down, is ring
+// byte (q ^ 15) & 127.  A 12..15-bit rANS step takes at most two bytes, a block at most two chunks.
+#define LN_RING_CHUNKS 8u
+#define LN_BLOCK 16u
+// 16 bytes of the arena as four dwords (global_load_dwordx4 on the device)
+struct Chunk { uint32_t d[4]; };
+__device__ __forceinline__ Chunk ln_load_chunk(const uint8_t *arena, uint64_t base, uint64_t lowest, uint32_t c) {
+  const uint64_t want = 16ull * (c + 1ull);
+  const uint64_t at = (base >= want && base - want >= lowest) ? base - want : lowest;     // below the stream: never consumed
+#if defined(__HIPCC__)
+  const uint4 v = *(const uint4 *)(arena + at);
+  Chunk r; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w;
+  return r;
+#else
+  Chunk r; memcpy(r.d, arena + at, 16);
+  return r;
+#endif
+}
+
 struct OctParams { int32_t max_q, center; };
 
 __device__ __forceinline__ void oct_invert_diamond(int32_t center, int32_t &s, int32_t &t) {   // OctahedronToolBox.cs:152-196

@@ -73,11 +73,20 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total) 
 // =========================================================================
 // k_locate: one wave per mesh, lane 0 walks the stream (dsa_locate.h).
 // =========================================================================
-__global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, BatchGlobals *G) {
-  __shared__ uint32_t s_cum[LOC_MAX_TAGS + 1];
+__global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   uint32_t mesh = blockIdx.x;
   if (mesh >= n || threadIdx.x != 0) return;
-  locate_mesh(arena, layouts[mesh], &descs[mesh], G, s_cum);
+  locate_mesh(arena, layouts[mesh], &descs[mesh]);
+}
+// k_locate_attributes: the attribute section, on the symbol stream (beside k_connectivity).
+__global__ __launch_bounds__(WAVE) void k_locate_attributes(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, BatchGlobals *G) {
+  __shared__ uint32_t s_cum[LOC_MAX_TAGS + 1];
+  __shared__ __attribute__((aligned(16))) uint32_t s_lut[LOC_LDS_WORDS];
+  uint32_t mesh = blockIdx.x;
+  if (mesh >= n || threadIdx.x != 0) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->general) return;
+  locate_attributes(arena, layouts[mesh], D, G, s_cum, s_lut);
 }
 
 // =========================================================================
@@ -1086,16 +1095,33 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
 // stream offset are wave-uniform; the cumulative-frequency table is spread over the
 // lanes (first 64 boundaries in a register, the rest in LDS) and a symbol is found with
 // one or two ballot+popcount steps instead of the reference's 2^precision-entry LUT.
+// symtab != nullptr: the alphabet is sparse (more symbol ids than the LDS search holds, few of them used): the table is
+// compacted to the symbols with a non-zero frequency, the chain decodes compact indices and a lane-parallel pass
+// maps them back through symtab[] (global scratch).
 __device__ __forceinline__ void rans_decode_wave(MeshDesc *D, const uint8_t *stream, uint32_t stream_len, const AttrDesc &a, uint32_t num_values,
-                                 uint32_t *out, uint32_t *lds_cum) {
+                                 uint32_t *out, uint32_t *lds_cum, uint32_t *symtab) {
   const uint32_t lane = lane_id();
-  const uint32_t nsym = a.num_symbols;
+  const uint32_t nsym = symtab ? a.num_distinct : a.num_symbols;
   const uint32_t P = a.precision_bits, precision = 1u << P, l_base = precision * 4;
   // 1. probability table -> LDS (lane 0), then cumulative in place
   if (lane == 0) {
     Rd r(stream, stream_len, a.off_table);
-    if (!read_prob_table(r, nsym, lds_cum)) fail(D, ST_INVALID, 400);
+    if (symtab) {                       // RAnsSymbolDecoder.cs:21-48, keeping the non-zero entries only
+      uint32_t k = 0;
+      bool ok = true;
+      for (uint32_t i = 0; i < a.num_symbols && ok; ++i) {
+        const uint32_t pd = r.u8(), token = pd & 3u;
+        if (token == 3u) { const uint32_t offset = pd >> 2; if (i + offset >= a.num_symbols) ok = false; i += offset; }
+        else {
+          uint32_t pr = pd >> 2;
+          for (uint32_t j = 0; j < token; ++j) pr |= r.u8() << (8 * (j + 1) - 2);
+          if (pr) { if (k >= nsym) ok = false; else { lds_cum[k] = pr; symtab[k] = i; ++k; } }
+        }
+      }
+      if (!ok || !r.ok || k != nsym) fail(D, ST_INVALID, 400);
+    } else if (!read_prob_table(r, nsym, lds_cum)) fail(D, ST_INVALID, 400);
   }
+  WAIT_VM0();
   __syncthreads();
   if (status_of(D) != ST_OK) return;
   uint32_t carry = 0;
@@ -1160,6 +1186,11 @@ __device__ __forceinline__ void rans_decode_wave(MeshDesc *D, const uint8_t *str
   }
   uint32_t tail = num_values & 63u;
   if (tail && lane < tail) out[num_values - tail + lane] = mine;
+  if (symtab) {                         // compact index -> symbol id
+    WAIT_VM0();
+    __syncthreads();
+    for (uint32_t i = lane; i < num_values; i += WAVE) out[i] = symtab[out[i]];
+  }
 }
 
 // Generic (large alphabet) fallback: cumulative table in global scratch, lane 0, binary search.
@@ -1410,10 +1441,14 @@ __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayo
   const AttrDesc &a = D->att[ai];
   if (a.source == SRC_BYTES) return;
   if (lanes::ln_sym_eligible(a, L, ai, flags)) return;             // k_symbols_lanes
+  // a sparse large alphabet (14-bit positions: 16 384 ids, a few thousand of them used) is searched through its non-zero
+  // symbols; the table k_locate reserved for the serial fallback holds the compact -> symbol map instead
+  const bool compact = a.source == SRC_RAW && a.num_symbols > SYM_MAX_LDS && a.num_distinct <= SYM_MAX_LDS && a.num_distinct >= 1 && a.table != 0;
   {
     const uint32_t ns = a.source == SRC_RAW ? a.num_symbols : 0u;
     if (a.source == SRC_RAW && a.precision_bits == 12 && ns > 64 && ns <= REG_MAX_SYMS && a.num_distinct > 1 && L.out_cap[ai] >= 4096 * 6 + REG_MAX_SYMS * 4) return;   // k_symbols_reg
-    const int tier = ns <= 64 ? 0 : (ns <= 960 ? 1 : 2);
+    const uint32_t nse = compact ? a.num_distinct : ns;
+    const int tier = nse <= 64 ? 0 : (nse <= 960 ? 1 : 2);
     if (tier != TIER) return;
   }
   const uint8_t *s = arena + L.stream;
@@ -1423,7 +1458,8 @@ __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayo
   const uint32_t num_values = a.num_entries * nc;
   if (num_values == 0) return;
   if (a.source == SRC_RAW) {
-    if (a.num_symbols <= SYM_MAX_LDS) rans_decode_wave(D, s, L.stream_len, a, num_values, work, lds_cum);
+    if (a.num_symbols <= SYM_MAX_LDS) rans_decode_wave(D, s, L.stream_len, a, num_values, work, lds_cum, nullptr);
+    else if (compact) rans_decode_wave(D, s, L.stream_len, a, num_values, work, lds_cum, (uint32_t *)(arena + a.table));
     else rans_decode_serial(D, s, L.stream_len, a, num_values, work, (uint32_t *)(arena + a.table));
   } else if (a.source == SRC_TAGGED) {
     // SymbolDecoding.cs:38-47: entry e owns nc fields of tags[e] bits, packed LSB-first in entry order

@@ -56,8 +56,6 @@ __host__ __device__ __forceinline__ bool ln_sym_eligible(const AttrDesc &a, cons
 // the 16-byte boundary behind the first byte to take), two chunks are requested at every 16-symbol block boundary and
 // written into the ring at the next one.  The q-th byte taken (counted from `base` down) sits at ring byte
 // (q ^ 15) & 127; every step reads the next two bytes while the table search runs and keeps 0, 1 or 2 of them.
-#define LN_RING_CHUNKS 8u
-#define LN_BLOCK 16u
 // diagnostic build only (-DLN_STAMPS): shader-clock shares of the segments of a symbol step, summed per wave
 #if defined(LN_STAMPS) && defined(__HIPCC__)
 #define LN_STAMP(i) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (i) ln_seg[i] += t_ - ln_t; ln_t = t_; }
@@ -101,21 +99,6 @@ __device__ __forceinline__ int ln_sym_build(Rd &r, uint32_t nsym, uint32_t P, ui
     lut[b] = (uint8_t)(kk >> 1);
   }
   return 0;
-}
-
-// 16 bytes of the arena as four dwords (global_load_dwordx4 on the device)
-struct Chunk { uint32_t d[4]; };
-__device__ __forceinline__ Chunk ln_load_chunk(const uint8_t *arena, uint64_t base, uint64_t lowest, uint32_t c) {
-  const uint64_t want = 16ull * (c + 1ull);
-  const uint64_t at = (base >= want && base - want >= lowest) ? base - want : lowest;     // below the stream: never consumed
-#if defined(__HIPCC__)
-  const uint4 v = *(const uint4 *)(arena + at);
-  Chunk r; r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w;
-  return r;
-#else
-  Chunk r; memcpy(r.d, arena + at, 16);
-  return r;
-#endif
 }
 
 // RAnsDecoder.Read for every value of the stream (RAnsDecoder.cs:56-67) + zig-zag (BitUtilities.cs:94-103) unless the

@@ -18,11 +18,13 @@ static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long 
 // attribute's output buffer for k_symbols.
 #define LOC_MAX_TAGS 64
 #define SYM_MAX_LDS 4032   // 63 blocks of 64 cumulative entries searched in LDS by k_symbols
+#define LOC_LUT_SLOTS 4096   // slot table of a tag stream (12-bit precision)
+#define LOC_LDS_WORDS (LOC_LUT_SLOTS / 4 + 4 * LN_RING_CHUNKS + LN_BLOCK / 4)   // one byte per slot + byte ring + the tags of one block
 
 #undef RET
 #define RET false
 __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, AttrDesc &a, const MeshLayout &L, int ai, uint8_t *arena,
-                                        uint32_t *s_cum, uint32_t num_entries, BatchGlobals *G) {
+                                        uint32_t *s_cum, uint32_t *s_lut, uint32_t num_entries, BatchGlobals *G) {
   const uint8_t *s = r.p;
   a.num_entries = num_entries;
   if (a.seq_type == 0) {   // generic: raw bytes, SequentialAttributeDecoder.cs:75-86
@@ -94,7 +96,7 @@ __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, Attr
         a.off_table = r.pos;
         REQUIRE(read_prob_table(r, a.num_symbols, s_cum), 152);
         uint32_t c = 0;
-        for (uint32_t i = 0; i < a.num_symbols; ++i) { uint32_t pr = s_cum[i]; s_cum[i] = c; c += pr; }
+        for (uint32_t i = 0; i < a.num_symbols; ++i) { uint32_t pr = s_cum[i]; REQUIRE(pr <= 4096u - c, 153); s_cum[i] = c; c += pr; }
         s_cum[a.num_symbols] = c;
         REQUIRE(c == 4096, 153);
         uint64_t size = r.varint();
@@ -103,25 +105,71 @@ __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, Attr
         REQUIRE(r.ok && size >= 1, 154);
         a.size_rans = (uint32_t)size;
         a.off_bits = r.pos;
-        // decode the tag stream; tags -> out buffer (bytes)
+        // decode the tag stream; tags -> out buffer (bytes).  This chain sits in front of everything else of the mesh
+        // (the bit section behind it has no length field), so it is kept short: the tag from a byte-per-slot table of the
+        // 4096 slots (RAnsDecoder.cs:69-88), its range from the cumulative table, stream bytes from the LDS ring, the
+        // tags of a 16-entry block staged in LDS and stored with one 16-byte store at the block's boundary -- nothing
+        // inside a block waits for global memory.
         REQUIRE(num_entries <= L.out_cap[ai], 155);
         uint8_t *tags = arena + L.out[ai];
-        const uint8_t *buf = s + a.off_rans;
         uint32_t state, off;
-        REQUIRE(rans_init(buf, a.size_rans, 16384, &state, &off), 156);
-        uint64_t total_bits = 0;
-        for (uint32_t e = 0; e < num_entries; ++e) {
-          while (state < 16384 && off > 0) state = state * 256 + buf[--off];
-          uint32_t rem = state & 4095, quo = state >> 12;
-          uint32_t lo = 0, hi = a.num_symbols;   // largest i with cum[i] <= rem
-          while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s_cum[mid] <= rem) lo = mid; else hi = mid; }
-          // skip zero-probability symbols that share the same cumulative value
-          uint32_t cs = s_cum[lo], f = s_cum[lo + 1] - cs;
-          state = quo * f + rem - cs;
-          REQUIRE(lo <= 32, 157);
-          tags[e] = (uint8_t)lo;
-          total_bits += (uint64_t)lo * nc;
+        REQUIRE(rans_init(s + a.off_rans, a.size_rans, 16384, &state, &off), 156);
+        uint8_t *lut8 = (uint8_t *)s_lut;                   // slot -> tag: 4 KB, so that every mesh of a 4096-mesh batch is resident at once
+        for (uint32_t i = 0; i < a.num_symbols; ++i)
+          for (uint32_t j = s_cum[i]; j < s_cum[i + 1]; ++j) lut8[j] = (uint8_t)i;
+        uint32_t *ring = s_lut + LOC_LUT_SLOTS / 4, *tagbuf = ring + 4 * LN_RING_CHUNKS;
+        const uint8_t *ring8 = (const uint8_t *)ring;
+        uint8_t *tagbuf8 = (uint8_t *)tagbuf;
+        const uint64_t lowest = L.stream & ~15ull;
+        const uint64_t last = L.stream + a.off_rans + (off ? off - 1u : 0u);
+        const uint64_t base = (last + 16ull) & ~15ull;
+        uint32_t loaded = 0;
+        for (; loaded < 6; ++loaded) {
+          const Chunk c = ln_load_chunk(arena, base, lowest, loaded);
+          for (int k = 0; k < 4; ++k) ring[((loaded & (LN_RING_CHUNKS - 1u)) << 2) + k] = c.d[k];
         }
+        Chunk in0 = ln_load_chunk(arena, base, lowest, loaded), in1 = ln_load_chunk(arena, base, lowest, loaded + 1);
+        bool inflight = true;
+        uint32_t q = (uint32_t)(base - 1 - last);
+        const uint32_t q_end = q + off;
+        while (state < 16384 && q < q_end) { state = (state << 8) | ring8[(q ^ 15u) & 127u]; ++q; }
+        uint64_t total_bits = 0;
+        uint32_t worst = 0;
+        for (uint32_t b0 = 0; b0 < num_entries; b0 += LN_BLOCK) {
+          const uint32_t cnt = num_entries - b0 < LN_BLOCK ? num_entries - b0 : LN_BLOCK;
+          for (uint32_t j = 0; j < cnt; ++j) {
+            const uint32_t y0 = ring8[(q ^ 15u) & 127u], y1 = ring8[((q + 1u) ^ 15u) & 127u];
+            const uint32_t rem = state & 4095u, sym = lut8[rem];
+            const uint32_t cs = s_cum[sym], f = s_cum[sym + 1] - cs;
+            state = (state >> 12) * f + rem - cs;
+            tagbuf8[j] = (uint8_t)sym;
+            worst = sym > worst ? sym : worst;
+            total_bits += (uint64_t)sym * nc;
+            uint32_t nb = (state < 16384u ? 1u : 0u) + (state < 64u ? 1u : 0u);      // state >= 4 after a step: two bytes reach 2^14
+            const uint32_t left = q_end - q;
+            nb = nb < left ? nb : left;
+            state = (state << (8u * nb)) | (((y0 << 8) | y1) >> (16u - 8u * nb));
+            q += nb;
+            while (state < 16384 && q < q_end) { state = (state << 8) | ring8[(q ^ 15u) & 127u]; ++q; }
+          }
+          // block boundary: the chunks requested one boundary ago go into the ring, the block's tags leave, two more chunks are requested
+          if (inflight) {
+            for (int k = 0; k < 4; ++k) { ring[((loaded & (LN_RING_CHUNKS - 1u)) << 2) + k] = in0.d[k]; ring[(((loaded + 1u) & (LN_RING_CHUNKS - 1u)) << 2) + k] = in1.d[k]; }
+            loaded += 2;
+          }
+          if (cnt == LN_BLOCK) {
+#if defined(__HIPCC__)
+            *(uint4 *)(tags + b0) = make_uint4(tagbuf[0], tagbuf[1], tagbuf[2], tagbuf[3]);     // out regions are 256-byte aligned
+#else
+            memcpy(tags + b0, tagbuf8, LN_BLOCK);
+#endif
+          } else {
+            for (uint32_t j = 0; j < cnt; ++j) tags[b0 + j] = tagbuf8[j];
+          }
+          inflight = loaded + 2u - (q >> 4) <= LN_RING_CHUNKS;
+          if (inflight) { in0 = ln_load_chunk(arena, base, lowest, loaded); in1 = ln_load_chunk(arena, base, lowest, loaded + 1); }
+        }
+        REQUIRE(worst <= 32, 157);
         r.skip((total_bits + 7) >> 3);
         REQUIRE(r.ok, 158);
       }
@@ -173,7 +221,8 @@ __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, Attr
 #undef RET
 #define RET
 
-__device__ inline void locate_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D, BatchGlobals *G, uint32_t *s_cum) {
+// First half of the walk: header, metadata, connectivity sections (up to the attribute section).
+__device__ inline void locate_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D) {
   const uint8_t *s = arena + L.stream;
   Rd r(s, L.stream_len, 0);
   // header, DracoDecoder.cs:44-64
@@ -272,8 +321,17 @@ __device__ inline void locate_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc
       REQUIRE(r.ok && sz >= 1, 121);
     }
   }
-  // attribute section, ConnectivityDecoder.cs:16-44
   D->off_attributes = r.pos;
+}
+
+// Second half of the walk: the attribute section (ConnectivityDecoder.cs:16-44) from D->off_attributes on.  A kernel
+// of its own on the symbol stream: k_connectivity needs the first half only, and the tag streams of the tagged
+// scheme, which this half has to decode to find its way, then run beside the connectivity and the traversal.
+__device__ inline void locate_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D, BatchGlobals *G, uint32_t *s_cum, uint32_t *s_lut) {
+  const uint8_t *s = arena + L.stream;
+  Rd r(s, L.stream_len, D->off_attributes);
+  const bool point_cloud = D->encoder_type == 0;
+  const uint32_t nad = D->num_att_data;
   uint32_t ndec = r.u8();
   REQUIRE(r.ok, 122);
   if (ndec > DSA_MAX_ATT) NOTIMPL(122);
@@ -329,7 +387,7 @@ __device__ inline void locate_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc
   uint32_t num_entries = D->num_enc_vertices;
   for (uint32_t i = 0; i < ndec; ++i) {           // AttributesDecoder.cs:65-70
     for (uint32_t ai = first_att[i]; ai < first_att[i + 1]; ++ai) {
-      if (!locate_attribute_values(r, D, D->att[ai], L, (int)ai, arena, s_cum, num_entries, G)) return;
+      if (!locate_attribute_values(r, D, D->att[ai], L, (int)ai, arena, s_cum, s_lut, num_entries, G)) return;
     }
     for (uint32_t ai = first_att[i]; ai < first_att[i + 1]; ++ai) {
       AttrDesc &a = D->att[ai];

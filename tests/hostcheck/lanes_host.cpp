@@ -49,7 +49,7 @@ int main(int argc, char **argv) {
   L.stream_len = (uint32_t)len;
   uint64_t cur = align_up(len + 1024, 256);
   std::vector<std::pair<uint64_t, uint64_t>> regions;
-  regions.push_back({0, align_up(len, 16)});         // the byte ring is filled in 16-byte chunks
+  regions.push_back({0, align_up(len, 16)});         // the byte ring and the tag decoder read 16-byte chunks
   cur = layout_mesh(h, len, L, cur, 1024, &regions);
   BatchGlobals G;
   memset(&G, 0, sizeof(G));
@@ -64,7 +64,9 @@ int main(int argc, char **argv) {
   MeshDesc D;
   memset(&D, 0, sizeof(D));
   uint32_t s_cum[LOC_MAX_TAGS + 1];
-  dsa::locate_mesh(arena.data(), L, &D, &G, s_cum);
+  std::vector<uint32_t> s_lut(LOC_LDS_WORDS);
+  dsa::locate_mesh(arena.data(), L, &D);
+  if (D.status == ST_OK && !D.general) dsa::locate_attributes(arena.data(), L, &D, &G, s_cum, s_lut.data());
   std::vector<int> decoded(DSA_MAX_ATT, 0);
   if (D.status == ST_OK) {
     // ---- k_symbols_lanes, one lane

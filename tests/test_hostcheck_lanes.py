@@ -89,6 +89,22 @@ def test_point_cloud_delta_chain(exe, tmp_path):
     assert atts[0] is not None and np.array_equal(atts[0], ref.attributes[0].portable)
 
 
+def test_tagged_streams_walk_under_asan(exe, tmp_path):
+    """The tag streams of the tagged scheme are decoded by the stream walk itself (slot table + 16-byte chunks):
+    valid streams must come out of it with status 0, damaged ones with a verdict and no out-of-bounds access."""
+    rng = np.random.default_rng(4)
+    for kind, nx, ny in ((synth.GRID, 40, 33), (synth.TORUS, 24, 20), (synth.HOLES, 20, 16)):
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 13)
+        good = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(force_scheme=0))
+        status, detail, atts = lanes_decode(exe, good, tmp_path)
+        assert status == 0, detail
+        for it in range(40):
+            b = bytearray(good)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(len(b) // 3, len(b)))] = int(rng.integers(0, 256))
+            lanes_decode(exe, bytes(b), tmp_path)            # any verdict; ASan aborts on a bad access
+
+
 def test_corrupt_tables_and_payloads_stay_in_bounds(exe, tmp_path):
     """Random damage to a valid stream: whatever the verdict, no access may leave the regions (ASan aborts the run);
     streams that still decode must agree with the oracle."""
