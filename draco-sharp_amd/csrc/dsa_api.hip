@@ -32,7 +32,7 @@ struct dsa_context {
   hipStream_t stream2 = nullptr;     // symbol decode runs here, concurrently with connectivity + traversal
   hipStream_t stream3 = nullptr;     // connectivity validation (link symmetry, seam streams)
   hipEvent_t ev_join3 = nullptr, ev_trav = nullptr, ev_maps = nullptr, ev_early = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_conn = nullptr, ev_locatt = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_conn = nullptr;
   bool own_stream = false;
   bool profiling = false;
   std::string err;
@@ -205,8 +205,7 @@ dsa_status dsa_context_create(int device, void *stream, dsa_context **out) {
       hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_conn, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_locatt, hipEventDisableTiming) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
+      hipEventCreateWithFlags(&c->ev_conn, hipEventDisableTiming) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
   *out = c;
   return DSA_OK;
 }
@@ -217,7 +216,6 @@ void dsa_context_destroy(dsa_context *ctx) {
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_conn) (void)hipEventDestroy(ctx->ev_conn);
-  if (ctx->ev_locatt) (void)hipEventDestroy(ctx->ev_locatt);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
   if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
@@ -287,7 +285,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
     hipLaunchKernelGGL(dsa::k_init, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, n);
   }
-  hipLaunchKernelGGL(dsa::k_locate, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+  hipLaunchKernelGGL(dsa::k_locate, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, b->d_globals);
   HIP_TRY(ctx, mark());
   const uint32_t na = std::max<uint32_t>(1, b->max_atts);
   // fork: entropy decode of every attribute stream on the second stream (it only needs k_locate's offsets)
@@ -306,9 +304,6 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     else hipLaunchKernelGGL(dsa::k_general_attributes<2>, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_general_attributes<3>, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
   }
-  // the attribute half of the stream walk (with the tag streams of the tagged scheme) on the symbol stream
-  hipLaunchKernelGGL(dsa::k_locate_attributes, dim3(n), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, b->d_globals);
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_locatt, st2));
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[0], st2));
   // DSA_LANES (diagnostics): bit 0 = raw rANS streams one lane per stream (k_symbols_lanes), bit 1 = prediction one lane per
   // attribute (k_predict_lanes); both measured slower than the wave-per-stream kernels on this workload and off by
@@ -338,10 +333,6 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_early, st2));
-  {
-    static const bool conn_waits = getenv("DSA_CONN_WAITS_ATT") != nullptr;                 // diagnostics
-    if (conn_waits) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_locatt, 0));
-  }
   hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   // link symmetry + seam streams are checked on the second stream while the traversal runs here
   HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st));
@@ -374,7 +365,6 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // faces + point maps need only the traversal: third stream, beside the prediction kernels
   HIP_TRY(ctx, hipEventRecord(ctx->ev_trav, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_trav, 0));
-  HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_locatt, 0));      // the point maps are per attribute
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 16383) / 16384, 4));
     hipLaunchKernelGGL(dsa::k_point_maps, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);

@@ -73,20 +73,12 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total) 
 // =========================================================================
 // k_locate: one wave per mesh, lane 0 walks the stream (dsa_locate.h).
 // =========================================================================
-__global__ __launch_bounds__(WAVE) void k_locate(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
-  uint32_t mesh = blockIdx.x;
-  if (mesh >= n || threadIdx.x != 0) return;
-  locate_mesh(arena, layouts[mesh], &descs[mesh]);
-}
-// k_locate_attributes: the attribute section, on the symbol stream (beside k_connectivity).
-__global__ __launch_bounds__(WAVE) void k_locate_attributes(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, BatchGlobals *G) {
+__global__ __launch_bounds__(WAVE, 4) void k_locate(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, BatchGlobals *G) {
   __shared__ uint32_t s_cum[LOC_MAX_TAGS + 1];
-  __shared__ __attribute__((aligned(16))) uint32_t s_lut[LOC_LDS_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_lut[LOC_LDS_WORDS];     // tag streams of the tagged scheme: slot table, byte ring, tags of a block
   uint32_t mesh = blockIdx.x;
   if (mesh >= n || threadIdx.x != 0) return;
-  MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK || D->general) return;
-  locate_attributes(arena, layouts[mesh], D, G, s_cum, s_lut);
+  locate_all(arena, layouts[mesh], &descs[mesh], G, s_cum, s_lut);
 }
 
 // =========================================================================

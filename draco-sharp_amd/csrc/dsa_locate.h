@@ -323,10 +323,17 @@ __device__ inline void locate_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc
   }
   D->off_attributes = r.pos;
 }
+__device__ inline void locate_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D, BatchGlobals *G, uint32_t *s_cum, uint32_t *s_lut);
+// The whole walk of one stream (the body of k_locate's lane 0).
+__device__ inline void locate_all(uint8_t *arena, const MeshLayout &L, MeshDesc *D, BatchGlobals *G, uint32_t *s_cum, uint32_t *s_lut) {
+  locate_mesh(arena, L, D);
+  if (D->status != ST_OK || D->general) return;
+  locate_attributes(arena, L, D, G, s_cum, s_lut);
+}
 
-// Second half of the walk: the attribute section (ConnectivityDecoder.cs:16-44) from D->off_attributes on.  A kernel
-// of its own on the symbol stream: k_connectivity needs the first half only, and the tag streams of the tagged
-// scheme, which this half has to decode to find its way, then run beside the connectivity and the traversal.
+// Second half of the walk: the attribute section (ConnectivityDecoder.cs:16-44) from D->off_attributes on.  (Measured as
+// a kernel of its own beside k_connectivity: the connectivity waves hold nearly all LDS of a CU, so the tag decoders
+// trickle through one per CU and a tagged batch takes longer than with the walk in front: profiles/README.md.)
 __device__ inline void locate_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D, BatchGlobals *G, uint32_t *s_cum, uint32_t *s_lut) {
   const uint8_t *s = arena + L.stream;
   Rd r(s, L.stream_len, D->off_attributes);

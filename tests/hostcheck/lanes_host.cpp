@@ -65,8 +65,7 @@ int main(int argc, char **argv) {
   memset(&D, 0, sizeof(D));
   uint32_t s_cum[LOC_MAX_TAGS + 1];
   std::vector<uint32_t> s_lut(LOC_LDS_WORDS);
-  dsa::locate_mesh(arena.data(), L, &D);
-  if (D.status == ST_OK && !D.general) dsa::locate_attributes(arena.data(), L, &D, &G, s_cum, s_lut.data());
+  dsa::locate_all(arena.data(), L, &D, &G, s_cum, s_lut.data());
   std::vector<int> decoded(DSA_MAX_ATT, 0);
   if (D.status == ST_OK) {
     // ---- k_symbols_lanes, one lane

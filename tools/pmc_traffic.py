@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""profiles/r01_traffic.json from two rocprofv3 PMC passes of bench.py (FETCH_SIZE, WRITE_SIZE).
+"""profiles/rNN_traffic.json from two rocprofv3 PMC passes of bench.py (FETCH_SIZE, WRITE_SIZE).
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <meshes> <triangles> > profiles/r01_traffic.json
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <meshes> <triangles> <decodes in the run> > profiles/r02_traffic.json
 
 Per kernel: mean counter value per dispatch.  FETCH_SIZE / WRITE_SIZE are in KB (rocprofv3 derived
 metrics: TCC_EA0_RDREQ / WRREQ based); on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled
@@ -37,5 +37,8 @@ for k in sorted(fetch):
         continue
     fb, wb = 2.0 * fetch[k] * 1024.0, write.get(k, 0.0) * 1024.0
     out["kernels"][k] = {"fetch_bytes_x2": fb, "write_bytes": wb, "hbm_bytes": fb + wb, "dispatches": calls[k]}
-out["total_hbm_bytes_per_decode"] = sum(v["hbm_bytes"] for v in out["kernels"].values())
+decodes = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+for v in out["kernels"].values():
+    v["launches_per_decode"] = v["dispatches"] / decodes
+out["total_hbm_bytes"] = sum(v["hbm_bytes"] * v["launches_per_decode"] for v in out["kernels"].values())
 print(json.dumps(out, indent=1))
