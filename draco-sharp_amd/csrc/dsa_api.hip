@@ -307,7 +307,9 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[0], st2));
   // DSA_LANES (diagnostics): bit 0 = raw rANS streams one lane per stream (k_symbols_lanes), bit 1 = prediction one lane per
   // attribute (k_predict_lanes); both measured slower than the wave-per-stream kernels on this workload and off by
-  // default (profiles/README.md).  bit 2 = wrap prediction by k_predict_wrap (default on)
+  // default (profiles/README.md).  bit 2 = wrap prediction by k_predict_wrap (default on), bit 3 = octahedral delta
+  // one lane per stream (k_predict_oct_lanes: frees 2 G scalar + 2 G vector instructions per step, but its own chain is
+  // longer than the wave-per-stream kernel's and the traversal beside it does not speed up: measured 2 ms slower, off)
   static const uint32_t lane_flags = getenv("DSA_LANES") ? (uint32_t)atoi(getenv("DSA_LANES")) : PW_FLAG;
   if (lane_flags & LN_FLAG_SYMBOLS) {
     const uint32_t groups = (n + WAVE - 1) / WAVE;
@@ -327,6 +329,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   else {
     hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
     if (lane_flags & PW_FLAG) hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
+    if (lane_flags & LN_FLAG_OCT) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes, dim3((n + WAVE - 1) / WAVE, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
   }
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));

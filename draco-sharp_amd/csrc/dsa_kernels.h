@@ -1517,6 +1517,7 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
   const AttrDesc &a = D->att[ai];
   if (!a.have_scheme || a.source == SRC_BYTES) return;
   if (wrap_fast_ok(a, flags)) return;                    // k_predict_wrap
+  if (lanes::ln_oct_eligible(a, flags)) return;          // k_predict_oct_lanes
   if ((a.pred_kind == 1) != (phase == 1)) return;
   const MeshLayout &L = layouts[mesh];
   int32_t *w = (int32_t *)(arena + L.work[ai]);

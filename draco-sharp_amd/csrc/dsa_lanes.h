@@ -29,6 +29,7 @@ namespace lanes {
 // behaviour switches handed to the kernels (dsa_batch_decode reads them from the environment once; diagnostics)
 #define LN_FLAG_SYMBOLS 1u    // raw rANS streams that fit a tier are decoded by k_symbols_lanes
 #define LN_FLAG_PREDICT 2u    // prediction inverse by k_predict_lanes
+#define LN_FLAG_OCT 8u        // octahedral-delta attributes (normals) by k_predict_oct_lanes: one lane per stream (diagnostic option)
 
 // ------------------------------------------------------------------------------------------------ rANS, lane per stream
 #define LN_MAX_PRECISION 15u          // cumulative frequencies are 16-bit in LDS (2^15 is the largest total)
@@ -315,25 +316,68 @@ __device__ __forceinline__ void ln_predict_wrap(int32_t *w, const uint32_t *para
 }
 
 // Octahedral delta (PredictionSchemeDeltaDecoder.cs:23-37 with PredictionSchemeNormalOctahedron(Canonicalized)
-// DecodingTransform.ComputeOriginalValue), in place on w[entries][2].
+// DecodingTransform.ComputeOriginalValue), in place on w[entries][2].  The chain has no structure a wave could scan
+// when the values keep changing their class (which quadrant / which side of the diamond the previous value lies in:
+// the normals of a height field straddle x = 0 all the time), and a wave-uniform machine then spends ~60 scalar + ~60
+// vector instructions per entry of ONE stream.  One lane per stream: the same ~90 vector instructions serve 64 streams.
+// Blocks of 16 entries, fully unrolled: the corrections of the block are in registers, the next block's are loading,
+// the results leave with eight 16-byte stores at the block's end -- nothing inside a block waits for memory.
+#define LN_OCT_BLOCK 16u
 __device__ __forceinline__ void ln_predict_oct(int32_t *w, uint32_t entries, int32_t max_q, bool canonical) {
   OctParams o;
   const int q = 32 - __clz(max_q);
   const int32_t max_value = (1 << q) - 2;
   o.center = max_value / 2;
   o.max_q = (1 << q) - 1;
-  Vec<2> *wv = (Vec<2> *)w;
+  const uint32_t nchunks = (entries + 1u) / 2u;            // 16-byte chunks of two entries
+  auto load_chunk = [&](uint32_t c) -> Chunk {
+    Chunk r;
+    const uint32_t cc = c < nchunks ? c : nchunks - 1u;
+    if (2u * cc + 1u < entries) {
+#if defined(__HIPCC__)
+      const uint4 v = ((const uint4 *)w)[cc];
+      r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w;
+#else
+      memcpy(r.d, w + 4 * (size_t)cc, 16);
+#endif
+    } else {                                               // the last entry of an odd count: only its two values exist
+      r.d[0] = (uint32_t)w[4 * (size_t)cc]; r.d[1] = (uint32_t)w[4 * (size_t)cc + 1]; r.d[2] = 0; r.d[3] = 0;
+    }
+    return r;
+  };
+  Chunk cur[LN_OCT_BLOCK / 2], nxt[LN_OCT_BLOCK / 2], res[LN_OCT_BLOCK / 2];
+#pragma unroll
+  for (uint32_t k = 0; k < LN_OCT_BLOCK / 2; ++k) cur[k] = load_chunk(k);
   int32_t ps = 0, pt = 0;
-  Vec<2> c = wv[0];
-  for (uint32_t p = 0; p < entries; ++p) {
-    const Vec<2> cn = wv[p + 1 < entries ? p + 1 : p];     // next correction, loaded while this entry is computed
-    int32_t os, ot;
-    oct_original(o, canonical, ps, pt, c.v[0], c.v[1], os, ot);
-    Vec<2> r; r.v[0] = os; r.v[1] = ot;
-    wv[p] = r;
-    ps = os; pt = ot;
-    c = cn;
+  for (uint32_t b0 = 0; b0 < entries; b0 += LN_OCT_BLOCK) {
+    const uint32_t c0 = b0 / 2u;
+#pragma unroll
+    for (uint32_t k = 0; k < LN_OCT_BLOCK / 2; ++k) nxt[k] = load_chunk(c0 + LN_OCT_BLOCK / 2 + k);
+#pragma unroll
+    for (uint32_t j = 0; j < LN_OCT_BLOCK; ++j) {
+      int32_t os, ot;
+      oct_original(o, canonical, ps, pt, (int32_t)cur[j / 2].d[(j & 1u) * 2u], (int32_t)cur[j / 2].d[(j & 1u) * 2u + 1u], os, ot);
+      res[j / 2].d[(j & 1u) * 2u] = (uint32_t)os; res[j / 2].d[(j & 1u) * 2u + 1u] = (uint32_t)ot;
+      ps = os; pt = ot;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < LN_OCT_BLOCK / 2; ++k) {
+      const uint32_t c = c0 + k;
+      if (2u * c + 1u < entries) {
+#if defined(__HIPCC__)
+        ((uint4 *)w)[c] = make_uint4(res[k].d[0], res[k].d[1], res[k].d[2], res[k].d[3]);
+#else
+        memcpy(w + 4 * (size_t)c, res[k].d, 16);
+#endif
+      } else if (2u * c < entries) { w[4 * (size_t)c] = (int32_t)res[k].d[0]; w[4 * (size_t)c + 1] = (int32_t)res[k].d[1]; }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < LN_OCT_BLOCK / 2; ++k) cur[k] = nxt[k];
   }
+}
+
+__host__ __device__ __forceinline__ bool ln_oct_eligible(const AttrDesc &a, uint32_t flags) {
+  return (flags & LN_FLAG_OCT) && a.have_scheme && a.source != SRC_BYTES && (a.pred_transform == 2 || a.pred_transform == 3) && a.pred_kind == 0 && a.num_entries != 0;
 }
 
 // One attribute (the body of a lane of k_predict_lanes).  phase 0: schemes that need no traversal data (difference,
@@ -390,6 +434,17 @@ __global__ __launch_bounds__(WAVE) void k_symbols_lanes(uint8_t *arena, const Me
 #endif
 
 #if defined(__HIPCC__)
+// Octahedral-delta attributes of 64 meshes per wave.
+__global__ __launch_bounds__(WAVE) void k_predict_oct_lanes(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t flags) {
+  const uint32_t mesh = blockIdx.x * WAVE + threadIdx.x, ai = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
+  const AttrDesc &a = D->att[ai];
+  if (!ln_oct_eligible(a, flags)) return;
+  ln_predict_oct((int32_t *)(arena + layouts[mesh].work[ai]), a.num_entries, a.oct_max_q, a.pred_transform == 3);
+}
+
 // LPW meshes per wave (the other lanes stay idle): a fully divergent wave access costs the CU's address unit one
 // cycle per active lane, so the chains of a batch are spread over all CUs rather than packed 64 to a wave.
 template <uint32_t LPW>
