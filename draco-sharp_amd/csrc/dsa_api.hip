@@ -291,6 +291,8 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // fork: entropy decode of every attribute stream on the second stream (it only needs k_locate's offsets)
   // DSA_SERIAL=1 (diagnostics): everything on the main stream, so that stage times are stand-alone kernel times
   static const bool serial = getenv("DSA_SERIAL") != nullptr;
+  static const char *diag_env = getenv("DSA_DIAG");         // timing experiments only (results are wrong with bits 1 / 4 set): 1 no k_faces,
+  static const uint32_t diag = diag_env ? (uint32_t)atoi(diag_env) : 0u;   // 2 connectivity waits for the symbol kernels, 4 no early prediction
   hipStream_t st2 = serial ? st : ctx->stream2, st3 = serial ? st : ctx->stream3;
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_fork, 0));
@@ -327,7 +329,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // beside the traversal and the parallelogram attributes; joined before k_seal
   if (lane_flags & LN_FLAG_PREDICT) hipLaunchKernelGGL(dsa::lanes::k_predict_lanes<16>, dim3((n + 15) / 16, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u);
   else {
-    hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
+    if (!(diag & 4u)) hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
     if (lane_flags & PW_FLAG) hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
     if (lane_flags & LN_FLAG_OCT) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes, dim3((n + WAVE - 1) / WAVE, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
   }
@@ -336,13 +338,14 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_early, st2));
+  if (diag & 2u) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
   hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   // link symmetry + seam streams are checked on the second stream while the traversal runs here
   HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_conn, 0));
   {                                                    // faces as point ids need the connectivity only: beside the traversal
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
-    hipLaunchKernelGGL(dsa::k_faces, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+    if (!(diag & 1u)) hipLaunchKernelGGL(dsa::k_faces, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
   }
   {
     uint32_t lpm = 1;                                  // lanes per mesh >= attribute data per mesh (<= DSA_MAX_ATT_DATA = 7)
