@@ -252,10 +252,13 @@ def main():
                              "step_traffic": traffic_total},
                 "setup_s": {"generate": t_gen, "upload_and_layout": t_upload},
             }
-            # shader clock under this load: clocks one traversal wave counted with s_memtime / that kernel's duration
-            clocks = sorted(int(batch.debug_array(i, 4, np.uint32, 12)[6]) for i in range(0, args.meshes, max(1, args.meshes // 32)))
-            if stages.get("traverse"):
-                out["shader_clock_ghz"] = clocks[len(clocks) // 2] / (stages["traverse"] * 1e-3) / 1e9
+            # shader clock under this load, in-kernel: s_memtime ticks / s_memrealtime ticks (100 MHz) of the traversal and the
+            # connectivity wave of 32 meshes of the batch, median (MI355X_MICROARCH.md, "DVFS give-back", item 6)
+            dbg = [batch.debug_array(i, 4, np.uint32, 20) for i in range(0, args.meshes, max(1, args.meshes // 32))]
+            for name, a, b in (("traverse", 6, 17), ("connectivity", 13, 15)):
+                q = sorted(float(d[a]) / float(d[b]) * 0.1 for d in dbg if len(d) > b and d[b])
+                if q:
+                    out.setdefault("shader_clock_ghz", {})[name] = round(q[len(q) // 2], 3)
             if args.check > 0:
                 idx = sorted(set(int(i) for i in np.linspace(0, args.meshes - 1, min(args.check, args.meshes))))
                 bad = oracle_check(batch, blob, offsets, idx)

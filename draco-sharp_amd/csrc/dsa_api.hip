@@ -338,41 +338,45 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_early, st2));
-  if (diag & 2u) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
-  hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
-  // link symmetry + seam streams are checked on the second stream while the traversal runs here
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st));
-  HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_conn, 0));
-  {                                                    // faces as point ids need the connectivity only: beside the traversal
-    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
-    if (!(diag & 1u)) hipLaunchKernelGGL(dsa::k_faces, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
-  }
+  // the seam streams are checked on the third stream from the start: the check needs k_locate's offsets only (k_seal
+  // compares what it finds with the connectivity's edge count)
+  if (!b->any_general) HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_fork, 0));
   {
     uint32_t lpm = 1;                                  // lanes per mesh >= attribute data per mesh (<= DSA_MAX_ATT_DATA = 7)
     while (lpm < b->max_att_data) lpm *= 2;
     const uint32_t per_wave = WAVE / lpm;
     hipLaunchKernelGGL(dsa::k_conn_checks, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, lpm);
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_join3, st3));
-  HIP_TRY(ctx, mark());
+  if (diag & 2u) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
   // parallelogram operands: by the traversal waves themselves when the batch keeps the machine busy anyway, by an
   // element-parallel kernel behind the traversal when it does not
   static const char *fuse_env = getenv("DSA_FUSE_OPERANDS");                              // diagnostics: 0 / 1 overrides the rule
   const bool fuse_operands = fuse_env ? atoi(fuse_env) != 0 : n >= 2048;
-  {
+  const uint32_t trav_flags = (fuse_operands ? 1u : 0u) | (getenv("DSA_TRAV_NO_WINDOW") ? 0u : 2u);   // bit 1: adaptive run window (diagnostics switch)
+  // connectivity and traversal of a mesh by one wave (k_chain) unless DSA_CHAIN=0 asks for the two kernels: as two kernels,
+  // the slots the connectivity waves leave go to waiting entropy-decode waves and most traversal waves start late
+  static const bool chain = !(getenv("DSA_CHAIN") && atoi(getenv("DSA_CHAIN")) == 0);
+  if (chain) {
+    HIP_TRY(ctx, mark());                              // the connectivity stage has no time of its own
+    hipLaunchKernelGGL(dsa::k_chain, dim3(n), dim3(WAVE), CN_LDS_WORDS * 4, st, b->arena, b->d_layouts, b->d_descs, n, trav_flags);
+  } else {
+    hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+    HIP_TRY(ctx, mark());
     static const int split = getenv("DSA_TRAV_SPLIT") ? atoi(getenv("DSA_TRAV_SPLIT")) : 1;   // diagnostics
     const uint32_t per = (n + split - 1) / split;
     for (uint32_t m0 = 0; m0 < n; m0 += per) {
       const uint32_t cnt = std::min(per, n - m0);
-      hipLaunchKernelGGL(dsa::k_traverse, dim3(cnt), dim3(WAVE), 0, st, b->arena, b->d_layouts + m0, b->d_descs + m0, cnt, (fuse_operands ? 1u : 0u) | (getenv("DSA_TRAV_NO_WINDOW") ? 0u : 2u));   // bit 1: adaptive run window (diagnostics switch)
+      hipLaunchKernelGGL(dsa::k_traverse, dim3(cnt), dim3(WAVE), 0, st, b->arena, b->d_layouts + m0, b->d_descs + m0, cnt, trav_flags);
     }
   }
   HIP_TRY(ctx, mark());
-  // faces + point maps need only the traversal: third stream, beside the prediction kernels
+  // faces as point ids (they need the connectivity only) + point maps: third stream, beside the prediction kernels
   HIP_TRY(ctx, hipEventRecord(ctx->ev_trav, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_trav, 0));
   {
-    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 16383) / 16384, 4));
+    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
+    if (!(diag & 1u)) hipLaunchKernelGGL(dsa::k_faces, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+    gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 16383) / 16384, 4));
     hipLaunchKernelGGL(dsa::k_point_maps, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st3));
@@ -382,7 +386,6 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   }
   HIP_TRY(ctx, mark());
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));   // join: corrections are ready
-  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join3, 0));  // join: connectivity validated
   HIP_TRY(ctx, mark());
   if (lane_flags & LN_FLAG_PREDICT) hipLaunchKernelGGL(dsa::lanes::k_predict_lanes<32>, dim3((n + 31) / 32, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u);
   else {
@@ -639,9 +642,9 @@ dsa_status dsa_batch_copy_debug(const dsa_batch *b, uint32_t mesh, int what, voi
       return DSA_OK;
     }
     case 4:   // phase clocks recorded by the kernels (host copy)
-      if (dst_bytes < sizeof(D.dbg)) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "destination too small");
-      memcpy(dst, D.dbg, sizeof(D.dbg));
-      if (written) *written = sizeof(D.dbg);
+      if (dst_bytes < 48) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "destination too small");
+      memcpy(dst, D.dbg, dst_bytes < sizeof(D.dbg) ? dst_bytes : sizeof(D.dbg));
+      if (written) *written = dst_bytes < sizeof(D.dbg) ? dst_bytes : sizeof(D.dbg);
       return DSA_OK;
     default: return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "unknown debug array %d", what);
   }

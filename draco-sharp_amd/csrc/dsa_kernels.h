@@ -38,6 +38,7 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ uint64_t clk() { return __builtin_amdgcn_s_memtime(); }
+__device__ __forceinline__ uint64_t realclk() { return __builtin_amdgcn_s_memrealtime(); }   // constant 100 MHz
 // number of leading lanes (from lane 0) whose predicate is set
 __device__ __forceinline__ uint32_t leading_lanes(bool pred) { uint64_t m = ~__ballot(pred); return m ? (uint32_t)__builtin_ctzll(m) : 64u; }
 // s_waitcnt vmcnt(0) only (expcnt/lgkmcnt left at max).  On gfx950 loads and stores share vmcnt, so a
@@ -107,15 +108,10 @@ __global__ __launch_bounds__(WAVE, 4) void k_locate(uint8_t *arena, const MeshLa
 #define CN_STAGE 32          // faces per staging block (LDS per wave stays under 10 KB: 16 waves per CU)
 #define CN_WIN 64            // dwords of symbol bits per window
 
-__global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
-  __shared__ __attribute__((aligned(16))) uint32_t sh_stage[CN_STAGE * 8];
-  __shared__ __attribute__((aligned(16))) uint32_t sh_rec[CN_REC_BLOCKS * 64 * 2];
-  __shared__ uint32_t sh_win[CN_WIN];
-  __builtin_amdgcn_s_setprio(3);   // critical path: issue ahead of the entropy-decode waves sharing the CU
-  uint32_t mesh = blockIdx.x;
-  if (mesh >= n) return;
-  const MeshLayout &L = layouts[mesh];
-  MeshDesc *D = &descs[mesh];
+#define CN_LDS_WORDS (CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2 + CN_WIN)
+// The body of k_connectivity for one mesh on one wave; LDS: sh_stage[CN_STAGE * 8] and sh_rec[CN_REC_BLOCKS * 128] 16-byte
+// aligned, sh_win[CN_WIN].  Also the first half of k_chain.
+__device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t *sh_stage, uint32_t *sh_rec, uint32_t *sh_win) {
   if (D->status != ST_OK || D->encoder_type == 0 || D->general) return;   // point clouds have no connectivity; general meshes: k_general
   const uint8_t *s = arena + L.stream;
   uint32_t *frec = (uint32_t *)(arena + L.frec);
@@ -148,7 +144,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
 #define TAG(slot_) rdlane(tagv, (slot_))
   __syncthreads();
   if (status_of(D) != ST_OK) return;
-  const uint64_t t_start = clk();
+  const uint64_t t_start = clk(), r_start = realclk();
 
   // symbol section as 4-byte aligned words (the arena pads streams, so whole-window reads stay in bounds)
   const uint32_t sym_off = uni(D->off_symbols);
@@ -621,6 +617,7 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
   if (lane == 0) {
     D->dbg[0] = (uint32_t)(t_loop - t_start); D->dbg[1] = (uint32_t)(t_tail - t_loop); D->dbg[2] = (uint32_t)(t_sym - t_tail);
     D->dbg[3] = (uint32_t)(t_seam - t_sym); D->dbg[4] = (uint32_t)(clk() - t_seam);
+    D->dbg[13] = (uint32_t)(clk() - t_start); D->dbg[14] = (uint32_t)r_start; D->dbg[15] = (uint32_t)(realclk() - r_start);
     D->num_all_vertices = NVALL;
 #ifdef DSA_LOOP_PROFILE
     D->dbg[5] = (uint32_t)(acc_c / (n_c ? n_c : 1)); D->dbg[6] = (uint32_t)(acc_rl / (n_rl ? n_rl : 1));
@@ -636,9 +633,17 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
 #undef SET_OPP
 }
 
+__global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  __shared__ __attribute__((aligned(16))) uint32_t sh[CN_LDS_WORDS];
+  __builtin_amdgcn_s_setprio(3);   // critical path: issue ahead of the entropy-decode waves sharing the CU
+  const uint32_t mesh = blockIdx.x;
+  if (mesh >= n) return;
+  connectivity_wave(arena, layouts[mesh], &descs[mesh], sh, sh + CN_STAGE * 8, sh + CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2);
+}
+
 // =========================================================================
-// k_conn_checks: attribute seams (MeshEdgeBreakerDecoder.cs:502-535), on the third stream.  Only seam-free
-// attribute connectivity is handled on the device; a set bit is reported as not implemented.
+// k_conn_checks: attribute seams (MeshEdgeBreakerDecoder.cs:502-535), on the third stream.  The fast kernels decode seam-free
+// attribute connectivity only: the position of the first set seam bit goes to k_seal, which sends such a mesh to the general path.
 // =========================================================================
 __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t lanes_per_mesh) {
   // one lane per (mesh, attribute data): the bit-serial rABS decode has no cross-lane traffic, so a wave
@@ -650,37 +655,41 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
   MeshDesc *D = &descs[mesh];
   if (status_of(D) != ST_OK || D->encoder_type == 0 || D->general || d >= D->num_att_data) return;
   const uint8_t *s = arena + L.stream;
-  const uint32_t edges = D->interior_corners / 2;   // one seam bit per interior edge and attribute data
+  // One seam bit per interior edge and attribute data.  How many edges are interior is the connectivity's result, which this
+  // kernel does not wait for: it looks for the first set bit among as many bits as a mesh of F faces can have (3F / 2) and
+  // k_seal compares its position with the number of edges (decoding past the coded bits yields arbitrary bits: harmless).
+  const uint32_t edges = (uint32_t)(((uint64_t)D->num_faces * 3) / 2);
   Rabs rb;
   uint32_t endp;
   rb.start(s, L.stream_len, D->off_seams[d], &endp);
   if (!rb.ok) { fail(D, ST_INVALID, 260); return; }
   // AnsDecoder.cs:42-56, restructured so that the common case (no renormalisation) is a load-free loop
-  uint32_t state = rb.state, off = rb.off, any = 0;
+  uint32_t state = rb.state, off = rb.off, first = DSA_INVALID;
   const uint32_t p = rb.p;
   uint32_t i = 0;
-  while (i < edges && any == 0) {
+  while (i < edges) {
     if (state < 4096 && off > 0) state = state * 256 + rb.buf[--off];
     if (p <= 16 && state >= 8192 && i + 8 <= edges) {
-      // eight zero bits shrink the state by at most (15/16)^8 > 1/2, so none of them renormalises;
-      // a set bit ends the decode (seams are reported as not implemented), so only the zero-bit
-      // successor is computed
+      // eight zero bits shrink the state by at most (15/16)^8 > 1/2, so none of them renormalises; only the zero-bit
+      // successor is computed, and a group with a set bit is decoded again bit by bit
+      const uint32_t state0 = state;
+      uint32_t any = 0;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint32_t quot = state >> 8, rem = state & 255u;
         any |= rem < p ? 1u : 0u;
         state = state - quot * p - p;
       }
-      i += 8;
-      continue;
+      if (!any) { i += 8; continue; }
+      state = state0;
     }
     const uint32_t quot = state >> 8, rem = state & 255u, xn = quot * p;
     const bool val = rem < p;
-    any |= val ? 1u : 0u;
-    state = val ? xn + rem : state - xn - p;
+    if (val) { first = i; break; }
+    state = state - xn - p;
     ++i;
   }
-  if (any) fail(D, ST_NOTIMPL, 261);
+  D->seam_first[d] = first;
 }
 
 // =========================================================================
@@ -744,16 +753,10 @@ __global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const Mes
 
 #define TR_SLOT_BITS 8
 #define TR_SLOTS (1u << TR_SLOT_BITS)
-__global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t fuse_operands) {
-  __shared__ unsigned long long sh_tf[TR_SLOTS], sh_tv[TR_SLOTS];   // in-run membership of faces / tips
-  for (uint32_t i = threadIdx.x; i < TR_SLOTS; i += WAVE) { sh_tf[i] = 0; sh_tv[i] = 0; }
-  __syncthreads();
-  __builtin_amdgcn_s_setprio(3);   // critical path: issue ahead of the entropy-decode waves sharing the CU
-  uint32_t mesh = blockIdx.x;
-  if (mesh >= n) return;
-  const MeshLayout &L = layouts[mesh];
-  MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK || D->encoder_type == 0 || D->general) return;   // point clouds have no connectivity; general meshes: k_general
+// The body of k_traverse for one mesh on one wave; LDS: sh_tf[TR_SLOTS], sh_tv[TR_SLOTS] (in-run membership of faces / tips),
+// zeroed by the caller.  Also the second half of k_chain.
+__device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t fuse_operands, unsigned long long *sh_tf, unsigned long long *sh_tv) {
+  if (status_of(D) != ST_OK || D->encoder_type == 0 || D->general) return;   // point clouds have no connectivity; general meshes: k_general
   const uint32_t *frec = (const uint32_t *)(arena + L.frec);
   uint32_t *d2c = (uint32_t *)(arena + L.d2c);
   int32_t *v2d = (int32_t *)(arena + L.v2d);
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   uint32_t *stack = (uint32_t *)(arena + L.fstamp);
   const uint32_t stack_cap = F;
   const uint32_t lane = lane_id();
-  const uint64_t t_start = clk();
+  const uint64_t t_start = clk(), r_start = realclk();
 
   uint32_t count = 0, sp = 0, f_scan = 0;
   uint32_t run_id = 0;        // stamps of newer runs compare smaller, so atomicMin always replaces older ones
@@ -1060,6 +1063,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   if (lane == 0) {
     D->num_entries = count;
     D->dbg[5] = n_fail; D->dbg[6] = (uint32_t)(clk() - t_start);
+    D->dbg[16] = (uint32_t)r_start; D->dbg[17] = (uint32_t)(realclk() - r_start);
     D->dbg[7] = n_run; D->dbg[8] = n_run_faces; D->dbg[9] = n_scalar;
 #ifdef DSA_TRAV_HIST
     for (int i = 0; i < 8; ++i) D->dbg[i] = why0[i] | (whyK[i] << 16);
@@ -1076,6 +1080,41 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   }
 #undef TR_FAIL
 #undef VISIT_SCALAR
+}
+
+__global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t fuse_operands) {
+  __shared__ unsigned long long sh_tf[TR_SLOTS], sh_tv[TR_SLOTS];
+  for (uint32_t i = threadIdx.x; i < TR_SLOTS; i += WAVE) { sh_tf[i] = 0; sh_tv[i] = 0; }
+  __syncthreads();
+  __builtin_amdgcn_s_setprio(3);   // critical path: issue ahead of the entropy-decode waves sharing the CU
+  const uint32_t mesh = blockIdx.x;
+  if (mesh >= n) return;
+  traverse_wave(arena, layouts[mesh], &descs[mesh], fuse_operands, sh_tf, sh_tv);
+}
+
+// k_chain: connectivity and traversal of a mesh by the same wave, back to back.  As two kernels the traversal's waves
+// find their places taken: the connectivity waves of a large batch retire over 3 ms, every freed slot goes to a waiting
+// entropy-decode wave (that kernel is mid-dispatch, k_traverse is not launched yet), and most traversal waves then start up
+// to 11 ms late, when those decoders finish (tools/wave_times.py).  A wave that keeps its slot has no such gap.
+// LDS (CN_LDS_WORDS * 4 bytes) is passed at launch: with the size hidden from the compiler, the launch bound alone sets the
+// register budget (64 VGPRs: four of these waves and three entropy-decode waves of 80 share a SIMD's 512).
+extern __shared__ __attribute__((aligned(16))) uint32_t sh_chain[];
+__global__ __launch_bounds__(WAVE, 8) void k_chain(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t fuse_operands) {
+  uint32_t *sh = sh_chain;
+  static_assert(CN_LDS_WORDS * 4 >= 2 * TR_SLOTS * 8, "the traversal's tables reuse the connectivity's LDS");
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t mesh = blockIdx.x;
+  if (mesh >= n) return;
+  const MeshLayout &L = layouts[mesh];
+  MeshDesc *D = &descs[mesh];
+  connectivity_wave(arena, L, D, sh, sh + CN_STAGE * 8, sh + CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2);
+  // the traversal reads what this wave (all lanes) just wrote: records, ranks, flags
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  __syncthreads();
+  unsigned long long *sh_tf = (unsigned long long *)sh, *sh_tv = sh_tf + TR_SLOTS;
+  for (uint32_t i = threadIdx.x; i < TR_SLOTS; i += WAVE) { sh_tf[i] = 0; sh_tv[i] = 0; }
+  __syncthreads();
+  traverse_wave(arena, L, D, fuse_operands, sh_tf, sh_tv);
 }
 
 
@@ -1999,14 +2038,19 @@ __global__ __launch_bounds__(256) void k_point_maps(uint8_t *arena, const MeshLa
   }
 }
 
-// k_seal: last kernel of a decode, one thread per mesh: the link census of k_point_maps against k_connectivity's.
+// k_seal: last kernel of a decode, one thread per mesh: the link census of k_faces against k_connectivity's, and the seam
+// bits found by k_conn_checks against the number of interior edges.
 __global__ __launch_bounds__(256) void k_seal(MeshDesc *descs, uint32_t n) {
   const uint32_t mesh = blockIdx.x * blockDim.x + threadIdx.x;
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
   if (status_of(D) != ST_OK) return;
   if (D->general) return;                              // the general path's phase 2 has compared its own census
-  if (__hip_atomic_load(&D->linked_corners, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != D->interior_corners) fail(D, ST_INVALID, 263);
+  if (__hip_atomic_load(&D->linked_corners, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != D->interior_corners) { fail(D, ST_INVALID, 263); return; }
+  // a seam among the coded bits (k_conn_checks): the attribute has a corner table of its own, which the general path builds
+  if (D->encoder_type != 0)
+    for (uint32_t d = 0; d < D->num_att_data; ++d)
+      if (D->seam_first[d] < D->interior_corners / 2) { fail(D, ST_NOTIMPL, DSA_SITE_RETRY_GENERAL); return; }
 }
 
 }  // namespace dsa

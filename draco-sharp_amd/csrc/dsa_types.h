@@ -65,6 +65,7 @@ struct MeshDesc {
   uint32_t off_symbols, size_symbols;
   uint32_t off_start_faces;                 // rABS block (prob_zero byte first)
   uint32_t off_seams[DSA_MAX_ATT_DATA];     // rABS blocks
+  uint32_t seam_first[DSA_MAX_ATT_DATA];    // k_conn_checks: index of the first set seam bit (DSA_INVALID: none)
   uint32_t off_attributes;                  // num_attributes_decoders byte
   uint32_t num_decoders, num_attributes;
   uint32_t end_pos;
@@ -79,7 +80,9 @@ struct MeshDesc {
   uint32_t gen_dec_entries[DSA_MAX_ATT];   // general path: entries of every attributes decoder (phase 3 sequence -> maps -> values)
   uint32_t interior_corners;   // 2 x opposite links made by k_connectivity; one seam bit per link and attribute data
   uint32_t linked_corners;     // corners that hold an opposite, counted by k_point_maps (k_seal compares the two)
-  uint32_t dbg[12];        // shader-clock deltas between phases of the per-mesh kernels (diagnostics)
+  uint32_t dbg[20];        // diagnostics of the per-mesh kernels (tools/dbg_phases.py, bench.py): s_memtime deltas between phases;
+                           // k_connectivity: [13] its s_memtime ticks, [14] its start and [15] its duration in s_memrealtime ticks
+                           // (100 MHz); k_traverse: [6] ticks, [16] start, [17] duration: ticks / duration = the shader clock
   AttrDesc att[DSA_MAX_ATT];
 };
 

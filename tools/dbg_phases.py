@@ -6,7 +6,9 @@ ctx = dsa.Context(0); ctx.set_profiling(True)
 b = dsa.Batch(ctx, blob=blob, offsets=offs)
 for _ in range(2): b.decode()
 print({k: round(v,2) for k,v in b.stage_times().items()})
-d = np.array([b.debug_array(i,4,np.uint32,12) for i in range(0,n,max(1,n//16))])
+d = np.array([b.debug_array(i,4,np.uint32,20) for i in range(0,n,max(1,n//16))])
 print("dbg clocks (median over sampled meshes) x1e6:", np.round(np.median(d,axis=0)/1e6,2)); print("raw median:", np.median(d,axis=0).astype(int).tolist())
 a = np.array([b.debug_array(i,5,np.uint32,64)[:12].reshape(3,4) for i in range(0,n,max(1,n//8))])
 print("attr (source, nsym, precision, rans bytes) mesh0:", a[0].tolist()); print("nsym range per attr:", a[:,:,1].min(0), a[:,:,1].max(0))
+m = np.median(d, axis=0)
+print("shader clock GHz (s_memtime / s_memrealtime): traverse %.3f connectivity %.3f" % (m[6] / m[17] * 0.1, m[13] / m[15] * 0.1))
