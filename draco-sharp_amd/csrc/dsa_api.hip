@@ -31,6 +31,7 @@ struct dsa_context {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;     // symbol decode runs here, concurrently with connectivity + traversal
   hipStream_t stream3 = nullptr;     // connectivity validation (link symmetry, seam streams)
+  hipStream_t stream4 = nullptr;     // early attributes: symbols, prediction, dequantisation (dispatch priority)
   hipEvent_t ev_join3 = nullptr, ev_trav = nullptr, ev_maps = nullptr, ev_early = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_conn = nullptr;
   bool own_stream = false;
@@ -192,12 +193,17 @@ dsa_status dsa_context_create(int device, void *stream, dsa_context **out) {
   if (!c) return DSA_ERR_OUT_OF_MEMORY;
   c->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete c; return DSA_ERR_DEVICE; }
+  // Dispatch priorities (numerically lower = higher): the stream of the per-mesh chain above the stream of the early attributes
+  // above the late symbols, which fill whatever the others leave.
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
   if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
   else {
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return DSA_ERR_DEVICE; }
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest) != hipSuccess) { delete c; return DSA_ERR_DEVICE; }
     c->own_stream = true;
   }
-  if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+  if (hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, (least + greatest) / 2) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
+  if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_trav, hipEventDisableTiming) != hipSuccess ||
@@ -218,6 +224,7 @@ void dsa_context_destroy(dsa_context *ctx) {
   if (ctx->ev_conn) (void)hipEventDestroy(ctx->ev_conn);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+  if (ctx->stream4) (void)hipStreamDestroy(ctx->stream4);
   if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
   if (ctx->ev_trav) (void)hipEventDestroy(ctx->ev_trav);
   if (ctx->ev_maps) (void)hipEventDestroy(ctx->ev_maps);
@@ -291,8 +298,8 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // fork: entropy decode of every attribute stream on the second stream (it only needs k_locate's offsets)
   // DSA_SERIAL=1 (diagnostics): everything on the main stream, so that stage times are stand-alone kernel times
   static const bool serial = getenv("DSA_SERIAL") != nullptr;
-  static const char *diag_env = getenv("DSA_DIAG");         // timing experiments only (results are wrong with bits 1 / 4 set): 1 no k_faces,
-  static const uint32_t diag = diag_env ? (uint32_t)atoi(diag_env) : 0u;   // 2 connectivity waits for the symbol kernels, 4 no early prediction
+  static const char *diag_env = getenv("DSA_DIAG");         // timing experiments only (results are wrong with it): 4 = no early prediction
+  static const uint32_t diag = diag_env ? (uint32_t)atoi(diag_env) : 0u;
   hipStream_t st2 = serial ? st : ctx->stream2, st3 = serial ? st : ctx->stream3;
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_fork, 0));
@@ -305,39 +312,9 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     if (n > 2048) hipLaunchKernelGGL(dsa::k_general_values_crowded, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
     else hipLaunchKernelGGL(dsa::k_general_attributes<2>, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_general_attributes<3>, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_join3, st3));        // k_finalize(1) dequantises what these kernels decoded
   }
-  if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[0], st2));
-  // DSA_LANES (diagnostics): bit 0 = raw rANS streams one lane per stream (k_symbols_lanes), bit 1 = prediction one lane per
-  // attribute (k_predict_lanes); both measured slower than the wave-per-stream kernels on this workload and off by
-  // default (profiles/README.md).  bit 2 = wrap prediction by k_predict_wrap (default on), bit 3 = octahedral delta
-  // one lane per stream (k_predict_oct_lanes: frees 2 G scalar + 2 G vector instructions per step, but its own chain is
-  // longer than the wave-per-stream kernel's and the traversal beside it does not speed up: measured 2 ms slower, off)
-  static const uint32_t lane_flags = getenv("DSA_LANES") ? (uint32_t)atoi(getenv("DSA_LANES")) : PW_FLAG;
-  if (lane_flags & LN_FLAG_SYMBOLS) {
-    const uint32_t groups = (n + WAVE - 1) / WAVE;
-    hipLaunchKernelGGL(dsa::lanes::k_symbols_lanes<LN_T2_SYMS>, dim3(groups, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
-    hipLaunchKernelGGL(dsa::lanes::k_symbols_lanes<LN_T1_SYMS>, dim3(groups, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
-    hipLaunchKernelGGL(dsa::lanes::k_symbols_lanes<LN_T0_SYMS>, dim3(groups, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
-  }
-  hipLaunchKernelGGL(dsa::k_symbols_reg, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
-  hipLaunchKernelGGL(dsa::k_symbols<1>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
-  hipLaunchKernelGGL(dsa::k_symbols<0>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
-  hipLaunchKernelGGL(dsa::k_symbols<2>, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
-  if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[1], st2));
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_join, st2));           // corrections of every attribute are ready
-  // attributes whose prediction needs no traversal data (difference, octahedral delta) are finished on this stream,
-  // beside the traversal and the parallelogram attributes; joined before k_seal
-  if (lane_flags & LN_FLAG_PREDICT) hipLaunchKernelGGL(dsa::lanes::k_predict_lanes<16>, dim3((n + 15) / 16, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u);
-  else {
-    if (!(diag & 4u)) hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
-    if (lane_flags & PW_FLAG) hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
-    if (lane_flags & LN_FLAG_OCT) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes, dim3((n + WAVE - 1) / WAVE, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
-  }
-  {
-    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
-    hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st2, b->arena, b->d_layouts, b->d_descs, n, 0u);
-  }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_early, st2));
+  // ---- the chain of the mesh itself first: its waves must find their slots before the entropy decoders fill the machine
   // the seam streams are checked on the third stream from the start: the check needs k_locate's offsets only (k_seal
   // compares what it finds with the connectivity's edge count)
   if (!b->any_general) HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_fork, 0));
@@ -347,7 +324,6 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     const uint32_t per_wave = WAVE / lpm;
     hipLaunchKernelGGL(dsa::k_conn_checks, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, lpm);
   }
-  if (diag & 2u) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
   // parallelogram operands: by the traversal waves themselves when the batch keeps the machine busy anyway, by an
   // element-parallel kernel behind the traversal when it does not
   static const char *fuse_env = getenv("DSA_FUSE_OPERANDS");                              // diagnostics: 0 / 1 overrides the rule
@@ -370,22 +346,76 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     }
   }
   HIP_TRY(ctx, mark());
-  // faces as point ids (they need the connectivity only) + point maps: third stream, beside the prediction kernels
+  if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[0], st2));
+  // DSA_LANES (diagnostics): bit 0 = raw rANS streams one lane per stream (k_symbols_lanes), bit 1 = prediction one lane per
+  // attribute (k_predict_lanes); both measured slower than the wave-per-stream kernels on this workload and off by
+  // default (profiles/README.md).  bit 2 = wrap prediction by k_predict_wrap (default on), bit 3 = octahedral delta
+  // one lane per stream (k_predict_oct_lanes: frees 2 G scalar + 2 G vector instructions per step, but its own chain is
+  // longer than the wave-per-stream kernel's and the traversal beside it does not speed up: measured 2 ms slower, off)
+  static const uint32_t lane_flags = getenv("DSA_LANES") ? (uint32_t)atoi(getenv("DSA_LANES")) : PW_FLAG;
+  if (lane_flags & LN_FLAG_SYMBOLS) {
+    const uint32_t groups = (n + WAVE - 1) / WAVE;
+    hipLaunchKernelGGL(dsa::lanes::k_symbols_lanes<LN_T2_SYMS>, dim3(groups, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
+    hipLaunchKernelGGL(dsa::lanes::k_symbols_lanes<LN_T1_SYMS>, dim3(groups, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
+    hipLaunchKernelGGL(dsa::lanes::k_symbols_lanes<LN_T0_SYMS>, dim3(groups, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
+  }
+  // Attributes whose prediction does not wait for the traversal ("early": difference, octahedral delta) are decoded,
+  // predicted and dequantised on a stream of their own with dispatch priority, beside the traversal; the symbols of the
+  // parallelogram attributes ("late") follow on the second stream.  DSA_SYM_SPLIT=0, DSA_SERIAL and the lane-per-chain
+  // options keep the single symbol launch.
+  static const bool sym_split = !serial && !(lane_flags & (LN_FLAG_SYMBOLS | LN_FLAG_PREDICT | LN_FLAG_OCT)) &&
+                                !(getenv("DSA_SYM_SPLIT") && atoi(getenv("DSA_SYM_SPLIT")) == 0);
+  hipStream_t st4 = sym_split ? ctx->stream4 : st2;
+  auto launch_symbols = [&](hipStream_t s, uint32_t fl) {
+    hipLaunchKernelGGL(dsa::k_symbols_reg, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
+    hipLaunchKernelGGL(dsa::k_symbols<1>, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
+    hipLaunchKernelGGL(dsa::k_symbols<0>, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
+    hipLaunchKernelGGL(dsa::k_symbols<2>, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
+  };
+  {
+    // The identity maps of point clouds (nothing to do for meshes) go first on the symbol stream, and the symbol kernels of
+    // both streams behind them: those few microseconds let every wave of k_chain, which became ready at the same moment,
+    // take its slot (4 per SIMD) before the entropy decoders fill the rest; a chain wave that finds its SIMD full waits
+    // for a decoder to finish, 5 ms or more (tools/wave_times.py).
+    const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 16383) / 16384, 4));
+    hipLaunchKernelGGL(dsa::k_point_maps, dim3(gx, n), dim3(256), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st2));
+  }
+  if (sym_split) {
+    HIP_TRY(ctx, hipStreamWaitEvent(st4, ctx->ev_conn, 0));
+    launch_symbols(st4, lane_flags | SYM_EARLY_ONLY);
+    launch_symbols(st2, lane_flags | SYM_LATE_ONLY);
+  } else launch_symbols(st2, lane_flags);
+  if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[1], st2));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_join, st2));           // corrections of the late attributes (without the split: of every attribute) are ready
+  // attributes whose prediction needs no traversal data (difference, octahedral delta) are finished on this stream,
+  // beside the traversal and the parallelogram attributes; joined before k_seal
+  if (lane_flags & LN_FLAG_PREDICT) hipLaunchKernelGGL(dsa::lanes::k_predict_lanes<16>, dim3((n + 15) / 16, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u);
+  else {
+    if (!(diag & 4u)) hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
+    if (lane_flags & PW_FLAG) hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
+    if (lane_flags & LN_FLAG_OCT) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes, dim3((n + WAVE - 1) / WAVE, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
+  }
+  {
+    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
+    hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_early, st4));
+  // faces as point ids + link census need the connectivity: third stream, beside the parallelogram prediction
   HIP_TRY(ctx, hipEventRecord(ctx->ev_trav, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_trav, 0));
   {
-    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
-    if (!(diag & 1u)) hipLaunchKernelGGL(dsa::k_faces, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
-    gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 16383) / 16384, 4));
-    hipLaunchKernelGGL(dsa::k_point_maps, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+    const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
+    hipLaunchKernelGGL(dsa::k_faces, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st3));
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st3));
   if (!fuse_operands) {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 8191) / 8192, 4));
     hipLaunchKernelGGL(dsa::k_para_operands, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   }
   HIP_TRY(ctx, mark());
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));   // join: corrections are ready
+  if (b->any_general) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join3, 0));   // join: the general path's integers are ready
   HIP_TRY(ctx, mark());
   if (lane_flags & LN_FLAG_PREDICT) hipLaunchKernelGGL(dsa::lanes::k_predict_lanes<32>, dim3((n + 31) / 32, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u);
   else {
@@ -395,7 +425,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   HIP_TRY(ctx, mark());
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
-    hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u);
+    hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags);
   }
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_maps, 0));
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_early, 0));
@@ -417,6 +447,7 @@ static dsa_status batch_wait(dsa_batch *b) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream3));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream4));
   if (b->n) HIP_TRY(ctx, hipMemcpy(b->descs.data(), b->d_descs, sizeof(MeshDesc) * b->n, hipMemcpyDeviceToHost));
   if (ctx->profiling && b->have_events && b->n) {
     for (int i = 0; i < STG_TOTAL; ++i) HIP_TRY(ctx, hipEventElapsedTime(&b->stage_ms[i], b->ev[i], b->ev[i + 1]));

@@ -37,6 +37,15 @@ __device__ __forceinline__ uint32_t cprev(uint32_t c) { return (c % 3u == 0u) ? 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+// The symbol kernels are launched twice when the batch is decoded on four streams: once for the attributes whose prediction
+// waits for the traversal (parallelogram: "late") and once, on a stream of higher priority that goes on to predict and
+// dequantise them, for those whose prediction does not ("early": difference, octahedral delta, none).
+#define SYM_EARLY_ONLY 0x100u
+#define SYM_LATE_ONLY 0x200u
+__device__ __forceinline__ bool sym_filtered(const AttrDesc &a, uint32_t flags) {
+  const bool late = a.have_scheme && a.pred_kind == 1;
+  return ((flags & SYM_EARLY_ONLY) && late) || ((flags & SYM_LATE_ONLY) && !late);
+}
 __device__ __forceinline__ uint64_t clk() { return __builtin_amdgcn_s_memtime(); }
 __device__ __forceinline__ uint64_t realclk() { return __builtin_amdgcn_s_memrealtime(); }   // constant 100 MHz
 // number of leading lanes (from lane 0) whose predicate is set
@@ -1078,6 +1087,21 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
     uint32_t *para = (uint32_t *)(arena + L.para);
     for (uint32_t p = lane; p < count; p += WAVE) para_operands_of(p, frec, d2c, v2d, F, NV, para);
   }
+  // ---- point -> entry map of every attribute (MeshTraversalSequencer.cs:33-50), from the order just produced
+  if (count == D->num_enc_vertices) {
+    WAIT_VM0();
+    __threadfence_block();
+    const uint32_t *vrank = (const uint32_t *)(arena + L.vrank);
+    const uint32_t na = uni(D->num_attributes), npts = uni(D->num_points);
+#pragma unroll 2
+    for (uint32_t v = lane; v < NV; v += WAVE) {
+      const int32_t e = v2d[v];
+      if (e < 0) continue;                 // no corner: the map keeps its initial value
+      const uint32_t point = vrank[v];
+      if (point >= npts) continue;
+      for (uint32_t ai = 0; ai < na; ++ai) ((uint32_t *)(arena + L.map[ai]))[point] = (uint32_t)e;
+    }
+  }
 #undef TR_FAIL
 #undef VISIT_SCALAR
 }
@@ -1270,6 +1294,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
   const MeshLayout &L = layouts[mesh];
   const AttrDesc &a = D->att[ai];
   if (lanes::ln_sym_eligible(a, L, ai, flags)) return;             // k_symbols_lanes
+  if (sym_filtered(a, flags)) return;                              // the other launch of the early / late pair
   // one non-zero symbol = a frequency of 4096, which the packed {freq, rem - cum} word cannot hold: k_symbols<T> takes it
   if (a.source != SRC_RAW || a.precision_bits != 12 || a.num_symbols > REG_MAX_SYMS || a.num_symbols <= 64 || a.num_distinct <= 1) return;
   if (L.out_cap[ai] < 4096 * 6 + REG_MAX_SYMS * 4) return;      // scratch for the tables (k_symbols<T> takes the stream instead)
@@ -1472,6 +1497,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayo
   const AttrDesc &a = D->att[ai];
   if (a.source == SRC_BYTES) return;
   if (lanes::ln_sym_eligible(a, L, ai, flags)) return;             // k_symbols_lanes
+  if (sym_filtered(a, flags)) return;                              // the other launch of the early / late pair
   // a sparse large alphabet (14-bit positions: 16 384 ids, a few thousand of them used) is searched through its non-zero
   // symbols; the table k_locate reserved for the serial fallback holds the compact -> symbol map instead
   const bool compact = a.source == SRC_RAW && a.num_symbols > SYM_MAX_LDS && a.num_distinct <= SYM_MAX_LDS && a.num_distinct >= 1 && a.table != 0;
@@ -1548,6 +1574,7 @@ __device__ __forceinline__ uint32_t addmod(uint32_t a, uint32_t b, uint32_t m) {
 // phase 0: schemes that need no traversal data (difference / octahedral delta) -- launched behind the symbol
 // kernels on their stream; phase 1: parallelogram schemes, after the traversal.
 __device__ __forceinline__ bool wrap_fast_ok(const AttrDesc &a, uint32_t flags);
+__device__ __forceinline__ bool pw_dequant_fused(const AttrDesc &a, uint32_t flags);
 __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t phase, uint32_t flags) {
   uint32_t mesh = blockIdx.x, ai = blockIdx.y;
   if (mesh >= n) return;
@@ -1785,6 +1812,9 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
 // re-evaluates the sequential step from its neighbour's value and the run is cut at the first disagreement.
 // =========================================================================
 #define PW_FLAG 4u    // DSA_LANES bit 2: wrap schemes by k_predict_wrap (default on)
+__device__ __forceinline__ bool pw_dequant_fused(const AttrDesc &a, uint32_t flags) {
+  return wrap_fast_ok(a, flags) && a.seq_type == 2 && a.nc == a.nc_portable && a.q_bits >= 1 && a.q_bits <= 30;
+}
 __device__ __forceinline__ bool wrap_fast_ok(const AttrDesc &a, uint32_t flags) {
   return (flags & PW_FLAG) && a.have_scheme && a.source != SRC_BYTES && a.pred_transform == 1 && a.nc_portable >= 1 && a.nc_portable <= 4 &&
          (uint32_t)(1 + a.wrap_max - a.wrap_min) < (1u << 25) && a.num_entries != 0;
@@ -1803,7 +1833,7 @@ template <int NC>
 struct PwVec { int32_t v[NC]; };
 
 template <int NC, bool PARA>
-__device__ __forceinline__ void predict_wrap_wave(int32_t *w, const uint32_t *para, uint32_t entries, int32_t mn, int32_t mx) {
+__device__ __forceinline__ void predict_wrap_wave(int32_t *w, const uint32_t *para, uint32_t entries, int32_t mn, int32_t mx, float *out, float delta, const float *qmin) {
   typedef PwVec<NC> V;
   const V *wv = (const V *)w;
   const uint32_t lane = lane_id();
@@ -1888,6 +1918,12 @@ __device__ __forceinline__ void predict_wrap_wave(int32_t *w, const uint32_t *pa
 #pragma unroll
       for (int c = 0; c < NC; ++c) r.v[c] = o[c];
       ((V *)w)[p] = r;
+      if (out) {     // dequantised on the way out (what k_finalize would do from memory): two f32 roundings, Dequantizer.cs:15-23
+        PwVec<NC> f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) f.v[c] = __float_as_int(__fadd_rn(__fmul_rn((float)o[c], delta), qmin[c]));
+        ((PwVec<NC> *)out)[p] = f;
+      }
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) last[c] = (int32_t)rdlane((uint32_t)o[c], run - 1);
@@ -1907,16 +1943,22 @@ __global__ __launch_bounds__(WAVE) void k_predict_wrap(uint8_t *arena, const Mes
   const uint32_t *para = (const uint32_t *)(arena + L.para);
   const uint32_t e = a.num_entries, nc = a.nc_portable;
   const int32_t mn = a.wrap_min, mx = a.wrap_max;
+  // quantised floats leave this kernel dequantised (k_finalize skips them)
+  const bool fused = pw_dequant_fused(a, flags);
+  float *out = fused ? (float *)(arena + L.out[ai]) : nullptr;
+  const float delta = fused ? __fdiv_rn(a.q_range, (float)(int32_t)((1u << a.q_bits) - 1u)) : 0.0f;
+  float qmin[4];
+  for (int c = 0; c < 4; ++c) qmin[c] = fused && (uint32_t)c < nc ? a.q_min[c] : 0.0f;
   if (a.pred_kind == 1) {
-    if (nc == 1) predict_wrap_wave<1, true>(w, para, e, mn, mx);
-    else if (nc == 2) predict_wrap_wave<2, true>(w, para, e, mn, mx);
-    else if (nc == 3) predict_wrap_wave<3, true>(w, para, e, mn, mx);
-    else predict_wrap_wave<4, true>(w, para, e, mn, mx);
+    if (nc == 1) predict_wrap_wave<1, true>(w, para, e, mn, mx, out, delta, qmin);
+    else if (nc == 2) predict_wrap_wave<2, true>(w, para, e, mn, mx, out, delta, qmin);
+    else if (nc == 3) predict_wrap_wave<3, true>(w, para, e, mn, mx, out, delta, qmin);
+    else predict_wrap_wave<4, true>(w, para, e, mn, mx, out, delta, qmin);
   } else {
-    if (nc == 1) predict_wrap_wave<1, false>(w, para, e, mn, mx);
-    else if (nc == 2) predict_wrap_wave<2, false>(w, para, e, mn, mx);
-    else if (nc == 3) predict_wrap_wave<3, false>(w, para, e, mn, mx);
-    else predict_wrap_wave<4, false>(w, para, e, mn, mx);
+    if (nc == 1) predict_wrap_wave<1, false>(w, para, e, mn, mx, out, delta, qmin);
+    else if (nc == 2) predict_wrap_wave<2, false>(w, para, e, mn, mx, out, delta, qmin);
+    else if (nc == 3) predict_wrap_wave<3, false>(w, para, e, mn, mx, out, delta, qmin);
+    else predict_wrap_wave<4, false>(w, para, e, mn, mx, out, delta, qmin);
   }
 }
 
@@ -1925,7 +1967,7 @@ __global__ __launch_bounds__(WAVE) void k_predict_wrap(uint8_t *arena, const Mes
 // =========================================================================
 // phase 0 (symbol stream): attributes whose values are complete once the symbols and a traversal-free scheme are
 // done; phase 1 (main stream, last): parallelogram attributes and everything of the general-path meshes.
-__global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n, uint32_t phase) {
+__global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n, uint32_t phase, uint32_t flags) {
   uint32_t mesh = blockIdx.y, ai = blockIdx.z;
   if (mesh >= n) return;
   const MeshDesc *D = &descs[mesh];
@@ -1934,6 +1976,7 @@ __global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayo
   const AttrDesc &a = D->att[ai];
   const bool late = D->general || (a.have_scheme && a.pred_kind == 1);
   if (late != (phase == 1)) return;
+  if (!D->general && pw_dequant_fused(a, flags)) return;      // k_predict_wrap wrote the floats
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   const int32_t *w = (const int32_t *)(arena + L.work[ai]);
   const uint32_t entries = a.num_entries;
@@ -1981,12 +2024,9 @@ __global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayo
   }
 }
 
-// =========================================================================
-// k_faces / k_point_maps: faces as point ids (Mesh.cs:15-69; MeshEdgeBreakerDecoder.cs:537-553,627-637) and the
-// point -> entry map of every attribute (MeshTraversalSequencer.cs:33-50; vertex attributes on the
-// position corner table: one map value per vertex that has a corner).
-// =========================================================================
-// k_faces: the face half (needs the connectivity only: launched behind k_connectivity, beside the traversal).
+// k_faces: faces as point ids (Mesh.cs:15-69; MeshEdgeBreakerDecoder.cs:537-553,627-637) and the census of linked corners,
+// behind k_chain on the third stream, beside the parallelogram prediction.  (As a pass of the connectivity wave itself it
+// cost that wave 4 ms: 4096 waves reach it together and the 13 GB it moves are then on the critical path.)
 __global__ __launch_bounds__(256) void k_faces(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   uint32_t mesh = blockIdx.y;
   if (mesh >= n) return;
@@ -2013,7 +2053,7 @@ __global__ __launch_bounds__(256) void k_faces(uint8_t *arena, const MeshLayout 
   if (__ballot(bad) && lane_id() == 0) fail(D, ST_INVALID, 263);
 }
 
-// k_point_maps: the point -> entry map of every attribute (needs the traversal).
+// k_point_maps: the point -> entry map of point clouds (linear sequencer); meshes get theirs from the traversal wave.
 __global__ __launch_bounds__(256) void k_point_maps(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   uint32_t mesh = blockIdx.y;
   if (mesh >= n) return;
@@ -2021,24 +2061,13 @@ __global__ __launch_bounds__(256) void k_point_maps(uint8_t *arena, const MeshLa
   if (D->status != ST_OK || D->general) return;   // k_general writes the maps of its meshes
   const MeshLayout &L = layouts[mesh];
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-  const uint32_t *vrank = (const uint32_t *)(arena + L.vrank);
-  const int32_t *v2d = (const int32_t *)(arena + L.v2d);
-  const uint32_t NV = D->num_vertices, na = D->num_attributes;
-  if (D->encoder_type == 0) {           // point cloud: linear sequencer, entry i = point i
-    for (uint32_t p = tid; p < D->num_points; p += stride)
-      for (uint32_t ai = 0; ai < na; ++ai) ((uint32_t *)(arena + L.map[ai]))[p] = p;
-    return;
-  }
-  for (uint32_t v = tid; v < NV; v += stride) {
-    const int32_t e = v2d[v];
-    if (e < 0) continue;                 // no corner: the map keeps its initial value
-    const uint32_t point = vrank[v];
-    if (point >= D->num_points) continue;
-    for (uint32_t ai = 0; ai < na; ++ai) ((uint32_t *)(arena + L.map[ai]))[point] = (uint32_t)e;
-  }
+  const uint32_t na = D->num_attributes;
+  if (D->encoder_type != 0) return;
+  for (uint32_t p = tid; p < D->num_points; p += stride)
+    for (uint32_t ai = 0; ai < na; ++ai) ((uint32_t *)(arena + L.map[ai]))[p] = p;
 }
 
-// k_seal: last kernel of a decode, one thread per mesh: the link census of k_faces against k_connectivity's, and the seam
+// k_seal: last kernel of a decode, one thread per mesh: the census of linked corners against the links made, and the seam
 // bits found by k_conn_checks against the number of interior edges.
 __global__ __launch_bounds__(256) void k_seal(MeshDesc *descs, uint32_t n) {
   const uint32_t mesh = blockIdx.x * blockDim.x + threadIdx.x;

@@ -6,8 +6,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 blob, offs = synth.make_batch(synth.GRID, 128, 256, 1000, n)
 ctx = dsa.Context(0); ctx.set_profiling(True)
 b = dsa.Batch(ctx, blob=blob, offsets=offs)
-for _ in range(3): b.decode()
-print({k: round(v, 2) for k, v in b.stage_times().items()})
+for _ in range(6):
+    b.decode()
+    print({k: round(v, 2) for k, v in b.stage_times().items()})
 d = np.array([b.debug_array(i, 4, np.uint32, 20) for i in range(n)]).astype(np.int64)
 for name, ticks, start, dur in (("connectivity", 13, 14, 15), ("traverse", 6, 16, 17)):
     s0 = (d[:, start] - d[:, start].min()) / 1e5          # ms
