@@ -331,12 +331,24 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   const uint32_t trav_flags = (fuse_operands ? 1u : 0u) | (getenv("DSA_TRAV_NO_WINDOW") ? 0u : 2u);   // bit 1: adaptive run window (diagnostics switch)
   // connectivity and traversal of a mesh by one wave (k_chain) unless DSA_CHAIN=0 asks for the two kernels: as two kernels,
   // the slots the connectivity waves leave go to waiting entropy-decode waves and most traversal waves start late
-  static const bool chain = !(getenv("DSA_CHAIN") && atoi(getenv("DSA_CHAIN")) == 0);
+  // (a small batch leaves slots free anyway, and is quicker with the faces converted beside the traversal)
+  static const char *chain_env = getenv("DSA_CHAIN");
+  const bool chain = chain_env ? atoi(chain_env) != 0 : n > 2048;       // measured: equal at 2048, 1.3 ms slower at 1024, 4 ms faster at 4096
+  auto launch_faces = [&]() -> hipError_t {      // faces as point ids + link census need the connectivity: third stream
+    hipError_t e = hipEventRecord(ctx->ev_trav, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st3, ctx->ev_trav, 0);
+    const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
+    hipLaunchKernelGGL(dsa::k_faces, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_maps, st3);
+    return e;
+  };
+  const bool chain_launched = chain;
   if (chain) {
     HIP_TRY(ctx, mark());                              // the connectivity stage has no time of its own
     hipLaunchKernelGGL(dsa::k_chain, dim3(n), dim3(WAVE), CN_LDS_WORDS * 4, st, b->arena, b->d_layouts, b->d_descs, n, trav_flags);
   } else {
     hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+    HIP_TRY(ctx, launch_faces());                      // beside the traversal
     HIP_TRY(ctx, mark());
     static const int split = getenv("DSA_TRAV_SPLIT") ? atoi(getenv("DSA_TRAV_SPLIT")) : 1;   // diagnostics
     const uint32_t per = (n + split - 1) / split;
@@ -363,7 +375,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // predicted and dequantised on a stream of their own with dispatch priority, beside the traversal; the symbols of the
   // parallelogram attributes ("late") follow on the second stream.  DSA_SYM_SPLIT=0, DSA_SERIAL and the lane-per-chain
   // options keep the single symbol launch.
-  static const bool sym_split = !serial && !(lane_flags & (LN_FLAG_SYMBOLS | LN_FLAG_PREDICT | LN_FLAG_OCT)) &&
+  static const bool sym_split = !serial && !(lane_flags & (LN_FLAG_SYMBOLS | LN_FLAG_PREDICT)) &&
                                 !(getenv("DSA_SYM_SPLIT") && atoi(getenv("DSA_SYM_SPLIT")) == 0);
   hipStream_t st4 = sym_split ? ctx->stream4 : st2;
   auto launch_symbols = [&](hipStream_t s, uint32_t fl) {
@@ -381,7 +393,13 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_point_maps, dim3(gx, n), dim3(256), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st2));
   }
-  if (sym_split) {
+  static const int split_mode = getenv("DSA_SYM_SPLIT") ? atoi(getenv("DSA_SYM_SPLIT")) : 1;
+  if (sym_split && split_mode == 2) {          // early attributes first, then the late ones beside the early prediction
+    launch_symbols(st2, lane_flags | SYM_EARLY_ONLY);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st2));
+    HIP_TRY(ctx, hipStreamWaitEvent(st4, ctx->ev_conn, 0));
+    launch_symbols(st2, lane_flags | SYM_LATE_ONLY);
+  } else if (sym_split) {                      // both at once, the early ones on the stream with priority
     HIP_TRY(ctx, hipStreamWaitEvent(st4, ctx->ev_conn, 0));
     launch_symbols(st4, lane_flags | SYM_EARLY_ONLY);
     launch_symbols(st2, lane_flags | SYM_LATE_ONLY);
@@ -394,21 +412,20 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   else {
     if (!(diag & 4u)) hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
     if (lane_flags & PW_FLAG) hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
-    if (lane_flags & LN_FLAG_OCT) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes, dim3((n + WAVE - 1) / WAVE, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
+    if (lane_flags & LN_FLAG_OCT) {
+      static const uint32_t lpw = getenv("DSA_OCT_LPW") ? (uint32_t)atoi(getenv("DSA_OCT_LPW")) : 16u;   // meshes per wave (diagnostics: 8, 16, 32, 64)
+      if (lpw == 8) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes<8>, dim3((n + 7) / 8, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
+      else if (lpw == 32) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes<32>, dim3((n + 31) / 32, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
+      else if (lpw == 64) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes<64>, dim3((n + 63) / 64, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
+      else hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes<16>, dim3((n + 15) / 16, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
+    }
   }
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
     hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_early, st4));
-  // faces as point ids + link census need the connectivity: third stream, beside the parallelogram prediction
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_trav, st));
-  HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_trav, 0));
-  {
-    const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
-    hipLaunchKernelGGL(dsa::k_faces, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_maps, st3));
-  }
+  if (chain_launched) HIP_TRY(ctx, launch_faces());      // behind the chain, beside the parallelogram prediction
   if (!fuse_operands) {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 8191) / 8192, 4));
     hipLaunchKernelGGL(dsa::k_para_operands, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);

@@ -762,6 +762,23 @@ __global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const Mes
 
 #define TR_SLOT_BITS 8
 #define TR_SLOTS (1u << TR_SLOT_BITS)
+struct Triple { uint32_t a, b, c; };
+// para_operands_of (dsa_common.h) without branches: every load happens, at a clamped index when its guard is false.
+__device__ __forceinline__ void para_operands_flat(uint32_t p, const uint32_t *frec, const uint32_t *d2c, const int32_t *v2d, uint32_t F, uint32_t NV,
+                                                   uint32_t &en, uint32_t &ep, uint32_t &eo) {
+  const uint32_t c0 = d2c[p];
+  const bool ok0 = p > 0 && c0 < 4 * F && (c0 & 3u) != 3u;
+  const uint32_t oci = frec[ok0 ? fo_idx(c0) : 4u];
+  const bool ok1 = ok0 && oci != DSA_INVALID && oci < 4 * F && (oci & 3u) != 3u;
+  const uint4 fr = *(const uint4 *)(frec + (size_t)(ok1 ? (oci >> 2) : 0u) * 8);
+  const uint32_t k = oci & 3u;
+  const uint32_t a = k == 0 ? fr.x : (k == 1 ? fr.y : fr.z), b = k == 0 ? fr.y : (k == 1 ? fr.z : fr.x), c = k == 0 ? fr.z : (k == 1 ? fr.x : fr.y);
+  const bool ok2 = ok1 && a < NV && b < NV && c < NV;
+  const int32_t vo = v2d[ok2 ? a : 0u], vn = v2d[ok2 ? b : 0u], vp = v2d[ok2 ? c : 0u];
+  const bool ok3 = ok2 && vo >= 0 && vn >= 0 && vp >= 0 && (uint32_t)vo < p && (uint32_t)vn < p && (uint32_t)vp < p;
+  en = ok3 ? (uint32_t)vn : DSA_INVALID; ep = ok3 ? (uint32_t)vp : 0u; eo = ok3 ? (uint32_t)vo : 0u;
+}
+
 // The body of k_traverse for one mesh on one wave; LDS: sh_tf[TR_SLOTS], sh_tv[TR_SLOTS] (in-run membership of faces / tips),
 // zeroed by the caller.  Also the second half of k_chain.
 __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t fuse_operands, unsigned long long *sh_tf, unsigned long long *sh_tv) {
@@ -1083,23 +1100,45 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
   }
   // Large batches: the wave that just produced the order also derives the parallelogram operands of its mesh, while
   // other meshes are still being traversed (small batches use the element-parallel k_para_operands instead).
+  // Both passes below are chains of dependent gathers with independent iterations: written without branches (clamped
+  // indices, selects) and four iterations at a time, so that four chains are in flight per lane.
   if ((fuse_operands & 1u) && count == D->num_enc_vertices) {
+    WAIT_VM0();
+    __threadfence_block();
     uint32_t *para = (uint32_t *)(arena + L.para);
-    for (uint32_t p = lane; p < count; p += WAVE) para_operands_of(p, frec, d2c, v2d, F, NV, para);
+    for (uint32_t p0 = 0; p0 < count; p0 += 4 * WAVE) {
+      uint32_t en[4], ep[4], eo[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t p = p0 + u * WAVE + lane;
+        para_operands_flat(p < count ? p : 0u, frec, d2c, v2d, F, NV, en[u], ep[u], eo[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t p = p0 + u * WAVE + lane;
+        if (p < count) { Triple t; t.a = en[u]; t.b = ep[u]; t.c = eo[u]; *(Triple *)(para + 3 * (size_t)p) = t; }
+      }
+    }
   }
   // ---- point -> entry map of every attribute (MeshTraversalSequencer.cs:33-50), from the order just produced
-  if (count == D->num_enc_vertices) {
+  if (count == D->num_enc_vertices && NV) {
     WAIT_VM0();
     __threadfence_block();
     const uint32_t *vrank = (const uint32_t *)(arena + L.vrank);
     const uint32_t na = uni(D->num_attributes), npts = uni(D->num_points);
-#pragma unroll 2
-    for (uint32_t v = lane; v < NV; v += WAVE) {
-      const int32_t e = v2d[v];
-      if (e < 0) continue;                 // no corner: the map keeps its initial value
-      const uint32_t point = vrank[v];
-      if (point >= npts) continue;
-      for (uint32_t ai = 0; ai < na; ++ai) ((uint32_t *)(arena + L.map[ai]))[point] = (uint32_t)e;
+    for (uint32_t v0 = 0; v0 < NV; v0 += 4 * WAVE) {
+      int32_t e[4];
+      uint32_t point[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t v = v0 + u * WAVE + lane, vc = v < NV ? v : NV - 1;
+        e[u] = v < NV ? v2d[vc] : -1;          // no corner: the map keeps its initial value
+        point[u] = vrank[vc];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e[u] >= 0 && point[u] < npts)
+          for (uint32_t ai = 0; ai < na; ++ai) ((uint32_t *)(arena + L.map[ai]))[point[u]] = (uint32_t)e[u];
     }
   }
 #undef TR_FAIL

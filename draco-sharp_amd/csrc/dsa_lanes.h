@@ -318,62 +318,161 @@ __device__ __forceinline__ void ln_predict_wrap(int32_t *w, const uint32_t *para
 // Octahedral delta (PredictionSchemeDeltaDecoder.cs:23-37 with PredictionSchemeNormalOctahedron(Canonicalized)
 // DecodingTransform.ComputeOriginalValue), in place on w[entries][2].  The chain has no structure a wave could scan
 // when the values keep changing their class (which quadrant / which side of the diamond the previous value lies in:
-// the normals of a height field straddle x = 0 all the time), and a wave-uniform machine then spends ~60 scalar + ~60
-// vector instructions per entry of ONE stream.  One lane per stream: the same ~90 vector instructions serve 64 streams.
-// Blocks of 16 entries, fully unrolled: the corrections of the block are in registers, the next block's are loading,
-// the results leave with eight 16-byte stores at the block's end -- nothing inside a block waits for memory.
-#define LN_OCT_BLOCK 16u
+// the normals of a height field straddle x = 0 all the time), and a wave-uniform machine then spends ~15 scalar + ~15
+// vector instructions per entry of ONE stream (2 + 2 G per 4096-mesh batch, 10 ms as the last kernel of the decode).
+// One lane per stream: the same instructions serve up to 64 streams, and what counts is the length of the dependent chain
+// per entry (below).  Blocks of 8 entries, fully unrolled: the corrections of the block are in registers, those of the next
+// two blocks are loading, the results leave with four 16-byte stores at the block's end -- nothing inside a block waits
+// for memory, and the kernel fits the registers one entropy-decode wave leaves behind (it starts beside them).
+// The canonicalised transform as a recursion in the canonical frame.  ComputeOriginalValue maps the previous value p
+// (centred) through T = R_k . I^inv (I = InvertDiamond if p lies outside the diamond, R_k = the rotation that takes the result to
+// the bottom-left quadrant), adds the correction there (w = T p + corr), wraps (ModMax) and maps back: p' = I^inv R_-k w.
+// With q = R_-k w and w (after ModMax) within the square the next step's frame follows from w alone:
+//   |w|_1 <= center (w inside the diamond; strictly, when inv):  I(p') = q again (I undoes itself on the open diamond), the
+//       rotation counts add up (rotcount(R_-k w) = k + rotcount(w) mod 4: the four half-open quadrants are each other's
+//       images) and the next canonical point is w turned into the bottom-left quadrant: (-|w.x|, -|w.y|), swapped when
+//       rotcount(w) is odd; inv stays (it ends on the edge itself, which I leaves in place);
+//   |w|_1 > center (the normal crosses to the other half of the octahedron): with y = I(q), the next step starts from y
+//       whether p' = q (it will invert it) or p' = y (inside the diamond): canonical point and rotation count of y, inv flips.
+// (I and the rotations do not commute on the axes, so y is computed from q, as the reference does, not from w.)
+// The state (u, k, inv) advances in 10-30 dependent operations; the value, (inv ? I(q) : q) + center, hangs off the chain.
+// A correction that leaves the square, and out-of-range garbage, take the reference's own function and re-derive the state
+// from its result.
+struct OctLane { int32_t ux, uy, vs, vt; uint32_t k; bool inv, regular; };
+__device__ __forceinline__ uint32_t oct_rotcount(int32_t x, int32_t y) {
+  return (y < 0 && x >= 0) ? 1u : ((x > 0 && y >= 0) ? 2u : ((y > 0 && x <= 0) ? 3u : 0u));
+}
+__device__ __forceinline__ void oct_lane_state(const OctParams &o, OctLane &s) {       // from s.vs, s.vt, as ComputeOriginalValue starts
+  int32_t ps = (int32_t)((uint32_t)s.vs - (uint32_t)o.center), pt = (int32_t)((uint32_t)s.vt - (uint32_t)o.center);
+  const int32_t aps = ps < 0 ? -ps : ps, apt = pt < 0 ? -pt : pt;
+  const bool in_d = (uint32_t)aps + (uint32_t)apt <= (uint32_t)o.center;
+  // values far outside the square (only a damaged stream has them) stay on the reference's function
+  const bool tame = (uint32_t)aps <= 2u * (uint32_t)o.center + 2u && (uint32_t)apt <= 2u * (uint32_t)o.center + 2u;
+  if (!tame) { s.regular = false; s.ux = 0; s.uy = 0; s.k = 0; s.inv = false; return; }
+  if (!in_d) oct_invert_diamond(o.center, ps, pt);
+  const uint32_t rot = oct_rotcount(ps, pt);
+  oct_rotate(ps, pt, (int)rot);
+  s.ux = ps; s.uy = pt; s.k = rot; s.inv = !in_d;
+  s.regular = ps <= 0 && pt <= 0 && ps >= -o.center && pt >= -o.center;
+}
+// One entry on the fast path only: advances (u, k, inv) and returns the value; the result says whether the step was entitled
+// to (when it is not, state and value are garbage and the caller redoes the entry with oct_lane_exact).
+__device__ __forceinline__ bool oct_lane_fast(const OctParams &o, OctLane &s, int32_t cx, int32_t cy, int32_t &os, int32_t &ot) {
+  const int32_t C = o.center;
+  // ModMax once, as the reference does (corrections are stored modulo max_q: -2 arrives as max_q - 2); whatever is still
+  // outside the square afterwards is not this path's business
+  const int32_t wx = oct_mod_max(o, (int32_t)((uint32_t)s.ux + (uint32_t)cx)), wy = oct_mod_max(o, (int32_t)((uint32_t)s.uy + (uint32_t)cy));
+  const int32_t ax = wx < 0 ? -wx : wx, ay = wy < 0 ? -wy : wy;
+  const bool sane = (uint32_t)(cx + (1 << 30)) <= (1u << 31) && (uint32_t)(cy + (1 << 30)) <= (1u << 31);   // no overflow above (|u| <= center < 2^29)
+  const bool ok = s.regular && sane && (uint32_t)ax <= (uint32_t)C && (uint32_t)ay <= (uint32_t)C;
+  const int32_t l1 = ax + ay;                   // meaningful when ok
+  const bool out = l1 > C;
+  const uint32_t k = s.k;
+  int32_t qs = wx, qt = wy;
+  oct_rotate(qs, qt, (int)((4u - k) & 3u));
+  int32_t ys = qs, yt = qt;
+  if (s.inv || out) oct_invert_diamond(C, ys, yt);
+  os = (s.inv ? ys : qs) + C; ot = (s.inv ? yt : qt) + C;
+  // ---- the next frame
+  const int32_t bx = out ? ys : wx, by = out ? yt : wy;
+  const int32_t abx = bx < 0 ? -bx : bx, aby = by < 0 ? -by : by;
+  const uint32_t kk = oct_rotcount(bx, by);
+  const bool odd = (kk & 1u) != 0;
+  s.ux = -(odd ? aby : abx); s.uy = -(odd ? abx : aby);
+  s.k = out ? kk : ((abx | aby) == 0 ? 0u : ((k + kk) & 3u));
+  s.inv = out ? !s.inv : (s.inv && l1 < C);
+  return ok;
+}
+// One entry by the reference's function on the previous value (s.vs, s.vt), then the state from its result.
+__device__ __forceinline__ void oct_lane_exact(const OctParams &o, OctLane &s, int32_t cx, int32_t cy, int32_t &os, int32_t &ot) {
+  oct_original(o, true, s.vs, s.vt, cx, cy, os, ot);
+  s.vs = os; s.vt = ot;
+  oct_lane_state(o, s);
+}
+
+#define LN_OCT_BLOCK 8u
 __device__ __forceinline__ void ln_predict_oct(int32_t *w, uint32_t entries, int32_t max_q, bool canonical) {
   OctParams o;
   const int q = 32 - __clz(max_q);
   const int32_t max_value = (1 << q) - 2;
   o.center = max_value / 2;
   o.max_q = (1 << q) - 1;
-  const uint32_t nchunks = (entries + 1u) / 2u;            // 16-byte chunks of two entries
-  auto load_chunk = [&](uint32_t c) -> Chunk {
-    Chunk r;
-    const uint32_t cc = c < nchunks ? c : nchunks - 1u;
-    if (2u * cc + 1u < entries) {
-#if defined(__HIPCC__)
-      const uint4 v = ((const uint4 *)w)[cc];
-      r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w;
-#else
-      memcpy(r.d, w + 4 * (size_t)cc, 16);
-#endif
-    } else {                                               // the last entry of an odd count: only its two values exist
-      r.d[0] = (uint32_t)w[4 * (size_t)cc]; r.d[1] = (uint32_t)w[4 * (size_t)cc + 1]; r.d[2] = 0; r.d[3] = 0;
-    }
-    return r;
-  };
-  Chunk cur[LN_OCT_BLOCK / 2], nxt[LN_OCT_BLOCK / 2], res[LN_OCT_BLOCK / 2];
-#pragma unroll
-  for (uint32_t k = 0; k < LN_OCT_BLOCK / 2; ++k) cur[k] = load_chunk(k);
-  int32_t ps = 0, pt = 0;
-  for (uint32_t b0 = 0; b0 < entries; b0 += LN_OCT_BLOCK) {
-    const uint32_t c0 = b0 / 2u;
-#pragma unroll
-    for (uint32_t k = 0; k < LN_OCT_BLOCK / 2; ++k) nxt[k] = load_chunk(c0 + LN_OCT_BLOCK / 2 + k);
-#pragma unroll
-    for (uint32_t j = 0; j < LN_OCT_BLOCK; ++j) {
+  if (!canonical) {      // the plain transform (no stock encoder writes it): the reference's step, entry by entry from memory
+    int32_t ps = 0, pt = 0;
+    for (uint32_t e = 0; e < entries; ++e) {
       int32_t os, ot;
-      oct_original(o, canonical, ps, pt, (int32_t)cur[j / 2].d[(j & 1u) * 2u], (int32_t)cur[j / 2].d[(j & 1u) * 2u + 1u], os, ot);
-      res[j / 2].d[(j & 1u) * 2u] = (uint32_t)os; res[j / 2].d[(j & 1u) * 2u + 1u] = (uint32_t)ot;
+      oct_original(o, false, ps, pt, w[2 * (size_t)e], w[2 * (size_t)e + 1], os, ot);
+      w[2 * (size_t)e] = os; w[2 * (size_t)e + 1] = ot;
       ps = os; pt = ot;
     }
-#pragma unroll
-    for (uint32_t k = 0; k < LN_OCT_BLOCK / 2; ++k) {
-      const uint32_t c = c0 + k;
-      if (2u * c + 1u < entries) {
-#if defined(__HIPCC__)
-        ((uint4 *)w)[c] = make_uint4(res[k].d[0], res[k].d[1], res[k].d[2], res[k].d[3]);
-#else
-        memcpy(w + 4 * (size_t)c, res[k].d, 16);
-#endif
-      } else if (2u * c < entries) { w[4 * (size_t)c] = (int32_t)res[k].d[0]; w[4 * (size_t)c + 1] = (int32_t)res[k].d[1]; }
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < LN_OCT_BLOCK / 2; ++k) cur[k] = nxt[k];
+    return;
   }
+  OctLane st;
+  st.vs = 0; st.vt = 0;
+  oct_lane_state(o, st);
+  // entries [from, to) one by one from memory: the fast step where it is entitled to, else the reference's
+  auto rolled = [&](uint32_t from, uint32_t to) {
+    for (uint32_t e = from; e < to; ++e) {
+      const int32_t cx = w[2 * (size_t)e], cy = w[2 * (size_t)e + 1];
+      int32_t os, ot;
+      OctLane t = st;
+      if (oct_lane_fast(o, t, cx, cy, os, ot)) { st = t; st.vs = os; st.vt = ot; }
+      else oct_lane_exact(o, st, cx, cy, os, ot);
+      w[2 * (size_t)e] = os; w[2 * (size_t)e + 1] = ot;
+    }
+  };
+  // Whole blocks while the next block is a whole block too (every load of the loop is in range and a constant distance
+  // ahead); the last one or two blocks go through the rolled loop.
+  constexpr uint32_t CH = LN_OCT_BLOCK / 2;                // 16-byte chunks (two entries) per block
+  const uint32_t full = entries / LN_OCT_BLOCK;
+  const uint32_t nb = full >= 1u ? full - 1u : 0u;
+  if (nb) {
+    Chunk cur[CH], nxt[CH];          // an entry's value takes the place of its correction in cur
+    auto load = [&](uint32_t c) -> Chunk {
+      Chunk r;
+#if defined(__HIPCC__)
+      const uint4 v = ((const uint4 *)w)[c];
+      r.d[0] = v.x; r.d[1] = v.y; r.d[2] = v.z; r.d[3] = v.w;
+#else
+      memcpy(r.d, w + 4 * (size_t)c, 16);
+#endif
+      return r;
+    };
+#pragma unroll
+    for (uint32_t k = 0; k < CH; ++k) cur[k] = load(k);
+    for (uint32_t b = 0; b < nb; ++b) {
+      const uint32_t c0 = b * CH;
+#pragma unroll
+      for (uint32_t k = 0; k < CH; ++k) nxt[k] = load(c0 + CH + k);
+      // the block on the fast path alone (short straight-line code); a block in which some entry was not entitled to it is
+      // done again from its first entry by the rolled loop, from memory (its inputs are still there)
+      const OctLane st0 = st;
+      bool all_ok = true;
+#pragma unroll
+      for (uint32_t j = 0; j < LN_OCT_BLOCK; ++j) {
+        int32_t os, ot;
+        all_ok = oct_lane_fast(o, st, (int32_t)cur[j / 2].d[(j & 1u) * 2u], (int32_t)cur[j / 2].d[(j & 1u) * 2u + 1u], os, ot) && all_ok;
+        cur[j / 2].d[(j & 1u) * 2u] = (uint32_t)os; cur[j / 2].d[(j & 1u) * 2u + 1u] = (uint32_t)ot;
+        st.vs = os; st.vt = ot;
+      }
+      if (all_ok) {
+#pragma unroll
+        for (uint32_t k = 0; k < CH; ++k) {
+#if defined(__HIPCC__)
+          ((uint4 *)w)[c0 + k] = make_uint4(cur[k].d[0], cur[k].d[1], cur[k].d[2], cur[k].d[3]);
+#else
+          memcpy(w + 4 * (size_t)(c0 + k), cur[k].d, 16);
+#endif
+        }
+      } else {
+        st = st0;
+        rolled(b * LN_OCT_BLOCK, (b + 1) * LN_OCT_BLOCK);
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < CH; ++k) cur[k] = nxt[k];
+    }
+  }
+  rolled(nb * LN_OCT_BLOCK, entries);
 }
 
 __host__ __device__ __forceinline__ bool ln_oct_eligible(const AttrDesc &a, uint32_t flags) {
@@ -434,10 +533,12 @@ __global__ __launch_bounds__(WAVE) void k_symbols_lanes(uint8_t *arena, const Me
 #endif
 
 #if defined(__HIPCC__)
-// Octahedral-delta attributes of 64 meshes per wave.
+// Octahedral-delta attributes, LPW meshes per wave (see k_predict_lanes below for why not 64).
+template <uint32_t LPW>
 __global__ __launch_bounds__(WAVE) void k_predict_oct_lanes(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t flags) {
-  const uint32_t mesh = blockIdx.x * WAVE + threadIdx.x, ai = blockIdx.y;
-  if (mesh >= n) return;
+  __builtin_amdgcn_s_setprio(3);   // a handful of long chains that hundreds of short-lived waves wait for
+  const uint32_t lane = threadIdx.x, mesh = blockIdx.x * LPW + lane, ai = blockIdx.y;
+  if (lane >= LPW || mesh >= n) return;
   MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
   const AttrDesc &a = D->att[ai];

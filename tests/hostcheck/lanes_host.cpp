@@ -31,7 +31,49 @@ static std::vector<uint8_t> read_file(const char *path) {
   return v;
 }
 
+// lanes_host octcheck <seed> <sequences>: the canonical-frame recursion of ln_predict_oct against the reference's
+// ComputeOriginalValue applied entry by entry (oct_original), on random walks that keep crossing the axes, the diamond's
+// edge and the square's edge, with now and then a correction from the whole int32 range.
+static uint64_t rng_state = 1;
+static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 11); }
+static int octcheck(uint64_t seed, int sequences) {
+  rng_state = seed * 2654435761ull + 88172645463325252ull;
+  for (int it = 0; it < sequences; ++it) {
+    const int q = 2 + (int)(rnd() % 29);                        // 2..30 quantisation bits
+    const int32_t max_q = (int32_t)((1u << q) - 1u);
+    const uint32_t entries = 1 + rnd() % 400;
+    const int mode = (int)(rnd() % 5);
+    std::vector<int32_t> w(2 * entries + 8), ref(2 * entries);
+    const int64_t span = ((int64_t)1 << q);
+    for (uint32_t i = 0; i < 2 * entries; ++i) {
+      int64_t c;
+      const uint32_t r = rnd();
+      if (mode == 0) c = (int64_t)(r % 7) - 3;                              // noise around the current point
+      else if (mode == 1) c = (int64_t)(r % (uint32_t)(span / 4 + 1)) - span / 8;      // quarter-range jumps
+      else if (mode == 2) c = (int64_t)(r % (uint32_t)(2 * span)) - span;              // beyond the range: ModMax, edges
+      else if (mode == 3) c = (r % 50 == 0) ? (int64_t)(int32_t)(rnd() * 2654435761u) : (int64_t)(r % 5) - 2;   // garbage now and then
+      else c = (r % 9 == 0) ? ((int64_t)(r % (uint32_t)span) - span / 2) : (int64_t)(r % 3) - 1;
+      w[i] = (int32_t)c;
+    }
+    dsa::OctParams o;
+    const int32_t max_value = (1 << q) - 2;
+    o.center = max_value / 2; o.max_q = (1 << q) - 1;
+    int32_t ps = 0, pt = 0;
+    for (uint32_t e = 0; e < entries; ++e) {
+      int32_t os, ot;
+      dsa::oct_original(o, true, ps, pt, w[2 * e], w[2 * e + 1], os, ot);
+      ref[2 * e] = os; ref[2 * e + 1] = ot; ps = os; pt = ot;
+    }
+    dsa::lanes::ln_predict_oct(w.data(), entries, max_q, true);
+    for (uint32_t i = 0; i < 2 * entries; ++i)
+      if (w[i] != ref[i]) { fprintf(stderr, "octcheck: sequence %d (q %d, mode %d) differs at value %u: %d vs %d\n", it, q, mode, i, w[i], ref[i]); return 1; }
+  }
+  printf("octcheck: %d sequences equal\n", sequences);
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc >= 4 && strcmp(argv[1], "octcheck") == 0) return octcheck(strtoull(argv[2], nullptr, 10), atoi(argv[3]));
   if (argc < 4 || strcmp(argv[1], "decode") != 0) { fprintf(stderr, "usage: lanes_host decode <in.drc> <out.bin> [conn.bin]\n"); return 2; }
   const std::vector<uint8_t> data = read_file(argv[2]);
   const size_t len = data.size();

@@ -134,3 +134,11 @@ def test_corrupt_tables_and_payloads_stay_in_bounds(exe, tmp_path):
                 assert np.array_equal(got, r.portable)
         agreed += 1
     assert agreed > 0 and rejected > 0
+
+
+def test_canonical_octahedral_recursion_equals_the_reference_step(exe):
+    """ln_predict_oct advances the canonicalised octahedral transform in the canonical frame (dsa_lanes.h); here against
+    ComputeOriginalValue entry by entry on random walks across every edge case of the transform, under ASan / UBSan."""
+    for seed in (1, 2, 3):
+        r = subprocess.run([exe, "octcheck", str(seed), "4000"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr[-2000:]
