@@ -219,6 +219,8 @@ def main():
             kernel_stages = {k: v for k, v in stages.items() if k != "total"}
             dom = max(kernel_stages, key=kernel_stages.get)
             kernel_name = {"symbols": "k_symbols_reg"}.get(dom, "k_" + dom)
+            if dom == "traverse" and stages.get("connectivity", 1.0) < 0.2:
+                kernel_name = "k_chain"                   # batches above 2048 meshes: connectivity + traversal by one wave per mesh
             achieved = alg_bytes / (kernel_stages[dom] * 1e-3) / 1e9
             traffic, traffic_src, traffic_total = measured_traffic(kernel_name, args.meshes, 2 * nx * ny)
             out = {
