@@ -19,9 +19,11 @@
 // The result is byte-identical to the CPU coder of dsa_encode_host.h (tests/test_gpu_encode.py), hence decodes
 // bit-exactly to the quantised input.
 #pragma once
+#include <chrono>
 #include <thread>
 
 #include "dsa_encode_host.h"
+#include "dsa_encode_conn.h"
 
 namespace dsa {
 
@@ -324,6 +326,17 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
   std::vector<synth::MeshIn> ins(n);
   std::vector<std::vector<uint32_t>> e2v(n);
   std::vector<std::vector<int32_t>> ops(n);
+  // DSA_ENC_TIMING=1 (diagnostics): wall time of every phase on stderr
+  static const bool timing = getenv("DSA_ENC_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[dsa_encode_batch] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
+  // DSA_ENC_HOST_CONN=1 (diagnostics): connectivity by the host coder, as before k_enc_connectivity existed
+  const bool host_conn = getenv("DSA_ENC_HOST_CONN") != nullptr;           // read per call: the tests compare the two paths
   auto plan_one = [&](uint32_t i) {
     const dsa_mesh_input &m = meshes[i];
     synth::MeshIn &in = ins[i];
@@ -331,6 +344,7 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     try {
       synth::check(m.positions && m.faces && m.num_vertices >= 3 && m.num_faces >= 1, "mesh needs positions and faces");
       for (size_t k = 0; k < (size_t)m.num_faces * 3; ++k) synth::check(m.faces[k] < m.num_vertices, "face index out of range");
+      if (!host_conn) { synth::plan_attributes(in, opt, plans[i]); return; }      // the rest of the plan comes from the device
       synth::plan_mesh(in, opt, plans[i]);
       const synth::MeshPlan &pl = plans[i];
       const uint32_t V = m.num_vertices;
@@ -355,8 +369,10 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     for (uint32_t t = 0; t < nt; ++t) th.emplace_back([&, t]() { for (uint32_t i = t; i < n; i += nt) plan_one(i); });
     for (auto &x : th) x.join();
   }
+  lap("host checks / plan");
   // ---- device layout
   std::vector<dsa::EncStream> hs;
+  std::vector<dsa::EncConn> hc(host_conn ? 0 : n);
   std::vector<uint32_t> first_stream(n + 1, 0);
   uint64_t cur = 0;
   auto take = [&](uint64_t bytes) { uint64_t at = cur; cur = (cur + bytes + 255) & ~255ull; return at; };
@@ -367,8 +383,22 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     if (E->status[i] != DSA_OK) continue;
     const uint32_t V = meshes[i].num_vertices;
     const uint64_t o_e2v = take(4ull * V), o_ops = take(12ull * V);
-    uploads.push_back({o_e2v, e2v[i].data(), 4ull * V});
-    uploads.push_back({o_ops, ops[i].data(), 12ull * V});
+    if (host_conn) {
+      uploads.push_back({o_e2v, e2v[i].data(), 4ull * V});
+      uploads.push_back({o_ops, ops[i].data(), 12ull * V});
+    } else {
+      const uint32_t F = meshes[i].num_faces;
+      dsa::EncConn &C = hc[i];
+      memset(&C, 0, sizeof(C));
+      C.F = F; C.V = V; C.split_cap = F;
+      C.faces = take(12ull * F); uploads.push_back({C.faces, meshes[i].faces, 12ull * F});
+      C.opp = take(12ull * F); C.voff = take(4ull * (V + 1)); C.vcur = take(4ull * V); C.vlist = take(12ull * F); C.vcorner = take(4ull * V);
+      C.fvis = take(F); C.vvis = take(V); C.hole_id = take(4ull * V); C.hole_vis = take(V); C.split_sym = take(4ull * F);
+      C.stack = take(4ull * F); C.processed = take(4ull * F); C.init_corners = take(4ull * F);
+      C.symbols = take(F); C.start_bits = take(F); C.splits = take(12ull * C.split_cap);
+      C.d2c = take(4ull * V); C.v2d = take(4ull * V);
+      C.e2v = o_e2v; C.ops = o_ops;
+    }
     for (auto &a : plans[i].atts) {
       dsa::EncStream S;
       memset(&S, 0, sizeof(S));
@@ -392,7 +422,8 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
   const uint32_t ns = (uint32_t)hs.size();
   uint8_t *arena = nullptr;
   dsa::EncStream *d_streams = nullptr;
-  auto cleanup = [&]() { if (arena) (void)hipFree(arena); if (d_streams) (void)hipFree(d_streams); };
+  dsa::EncConn *d_conns = nullptr;
+  auto cleanup = [&]() { if (arena) (void)hipFree(arena); if (d_streams) (void)hipFree(d_streams); if (d_conns) (void)hipFree(d_conns); };
 #define ENC_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); delete E; return set_err(ctx, e_ == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
   if (ns) {
     hipStream_t st = ctx->stream;
@@ -404,14 +435,52 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     uint32_t maxv = 0;
     for (auto &S : hs) maxv = std::max(maxv, S.nv);
     const uint32_t gx = std::max(1u, std::min(64u, (maxv + 2047) / 2048));
+    lap("layout + uploads queued");
+    // ---- device phase 0: corner table, Edgebreaker symbols, attribute order, operand entries (one wave per mesh); meshes that
+    // failed the host's checks have F = 0 and no arrays
+    if (!host_conn) {
+      ENC_TRY(hipMalloc((void **)&d_conns, sizeof(dsa::EncConn) * n));
+      for (uint32_t i = 0; i < n; ++i) if (E->status[i] != DSA_OK) { memset(&hc[i], 0, sizeof(hc[i])); hc[i].status = dsa::ENC_ISOLATED; }
+      ENC_TRY(hipMemcpyAsync(d_conns, hc.data(), sizeof(dsa::EncConn) * n, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(dsa::k_enc_connectivity, dim3(n), dim3(WAVE), 0, st, arena, d_conns, n);
+    }
     // ---- device phase 1: quantise, order, correct, count
     hipLaunchKernelGGL(dsa::k_enc_bounds, dim3(ns), dim3(256), 0, st, arena, d_streams, ns);
     hipLaunchKernelGGL(dsa::k_enc_quantize, dim3(gx, ns), dim3(256), 0, st, arena, d_streams, ns);
     hipLaunchKernelGGL(dsa::k_enc_gather, dim3(ns), dim3(256), 0, st, arena, d_streams, ns);
     hipLaunchKernelGGL(dsa::k_enc_corr, dim3(gx, ns), dim3(256), 0, st, arena, d_streams, ns);
     ENC_TRY(hipMemcpyAsync(hs.data(), d_streams, sizeof(dsa::EncStream) * ns, hipMemcpyDeviceToHost, st));
+    if (!host_conn) ENC_TRY(hipMemcpyAsync(hc.data(), d_conns, sizeof(dsa::EncConn) * n, hipMemcpyDeviceToHost, st));
     ENC_TRY(hipStreamSynchronize(st));
+    lap("device phases 0 + 1");
+    if (!host_conn) {
+      // what the stream layout needs of the connectivity: symbols, start-face bits, split events, two counts
+      for (uint32_t i = 0; i < n; ++i) {
+        if (E->status[i] != DSA_OK) continue;
+        const dsa::EncConn &C = hc[i];
+        if (C.status != dsa::ENC_OK) {
+          E->status[i] = DSA_ERR_INVALID_DATA; E->messages[i] = dsa::enc_conn_message(C.status);
+          for (uint32_t sk = first_stream[i]; sk < first_stream[i + 1]; ++sk) hs[sk].overflow = 1;       // its attribute streams are not coded
+          continue;
+        }
+        synth::EbResult &eb = plans[i].eb;
+        eb.symbols.resize(C.num_symbols); eb.start_face_bits.resize(C.num_start_bits); eb.num_split_symbols = C.num_split_symbols;
+        e2v[i].resize((size_t)3 * C.num_splits);                                // staging for the split triples
+        if (C.num_symbols) ENC_TRY(hipMemcpyAsync(eb.symbols.data(), arena + C.symbols, C.num_symbols, hipMemcpyDeviceToHost, st));
+        if (C.num_start_bits) ENC_TRY(hipMemcpyAsync(eb.start_face_bits.data(), arena + C.start_bits, C.num_start_bits, hipMemcpyDeviceToHost, st));
+        if (C.num_splits) ENC_TRY(hipMemcpyAsync(e2v[i].data(), arena + C.splits, 12ull * C.num_splits, hipMemcpyDeviceToHost, st));
+        plans[i].interior_edges = (int64_t)C.interior_edges;
+      }
+      ENC_TRY(hipStreamSynchronize(st));
+      for (uint32_t i = 0; i < n; ++i) {
+        if (E->status[i] != DSA_OK) continue;
+        synth::EbResult &eb = plans[i].eb;
+        eb.splits.resize(hc[i].num_splits);
+        for (uint32_t k = 0; k < hc[i].num_splits; ++k) eb.splits[k] = {e2v[i][3 * k], e2v[i][3 * k + 1], e2v[i][3 * k + 2]};
+      }
+    }
   }
+  lap("connectivity results");
   // ---- host phase 2: scheme choice and rANS tables from the device statistics
   std::vector<synth::SymbolPlan> splans(ns);
   std::vector<std::vector<uint32_t>> hists(ns);
@@ -423,9 +492,10 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
   if (ns) ENC_TRY(hipStreamSynchronize(ctx->stream));
   std::vector<int> stream_mesh(ns, 0);
   for (uint32_t i = 0; i < n; ++i) for (uint32_t s = first_stream[i]; s < first_stream[i + 1]; ++s) stream_mesh[s] = (int)i;
-  for (uint32_t s = 0; s < ns; ++s) {
+  std::vector<std::string> plan_error(ns);
+  auto plan_stream = [&](uint32_t s) {
     const uint32_t i = (uint32_t)stream_mesh[s];
-    if (E->status[i] != DSA_OK) continue;
+    if (E->status[i] != DSA_OK) return;
     try {
       synth::check(!hs[s].overflow, "symbol outside the histogram range");
       synth::SymbolStats stt;
@@ -437,10 +507,22 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
       hs[s].precision_bits = (uint32_t)splans[s].coder.precision_bits;
       hs[s].num_symbols = splans[s].coder.num_symbols;
       synth::check(splans[s].coder.num_symbols <= std::max<uint32_t>(hs[s].hist_cap, 64), "alphabet larger than the table region");
-      ENC_TRY(hipMemcpyAsync(arena + hs[s].prob, splans[s].coder.prob.data(), 4ull * splans[s].coder.num_symbols, hipMemcpyHostToDevice, ctx->stream));
-      ENC_TRY(hipMemcpyAsync(arena + hs[s].cum, splans[s].coder.cum.data(), 4ull * splans[s].coder.num_symbols, hipMemcpyHostToDevice, ctx->stream));
-    } catch (const std::exception &e) { E->status[i] = DSA_ERR_INVALID_DATA; E->messages[i] = e.what(); hs[s].overflow = 1; }
+    } catch (const std::exception &e) { plan_error[s] = e.what(); if (plan_error[s].empty()) plan_error[s] = "symbol plan failed"; hs[s].overflow = 1; }
+  };
+  {
+    const uint32_t nt = std::max(1u, std::min<uint32_t>(ns, std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 8));
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < nt; ++t) th.emplace_back([&, t]() { for (uint32_t s = t; s < ns; s += nt) plan_stream(s); });
+    for (auto &x : th) x.join();
   }
+  for (uint32_t s = 0; s < ns; ++s) {
+    const uint32_t i = (uint32_t)stream_mesh[s];
+    if (E->status[i] != DSA_OK) continue;
+    if (!plan_error[s].empty()) { E->status[i] = DSA_ERR_INVALID_DATA; E->messages[i] = plan_error[s]; continue; }
+    ENC_TRY(hipMemcpyAsync(arena + hs[s].prob, splans[s].coder.prob.data(), 4ull * splans[s].coder.num_symbols, hipMemcpyHostToDevice, ctx->stream));
+    ENC_TRY(hipMemcpyAsync(arena + hs[s].cum, splans[s].coder.cum.data(), 4ull * splans[s].coder.num_symbols, hipMemcpyHostToDevice, ctx->stream));
+  }
+  lap("histograms + symbol plans");
   // ---- device phase 2: entropy coding
   std::vector<std::vector<uint8_t>> rans(ns), bits(ns);
   if (ns) {
@@ -458,15 +540,17 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     ENC_TRY(hipStreamSynchronize(st));
   }
 #undef ENC_TRY
+  lap("device phase 2 + downloads");
   cleanup();
-  // ---- host phase 3: stream layout
-  for (uint32_t i = 0; i < n; ++i) {
-    if (E->status[i] != DSA_OK) continue;
+  // ---- host phase 3: stream layout (threads over meshes; write_stream may throw like any part of the host coder)
+  auto layout_one = [&](uint32_t i) {
+    if (E->status[i] != DSA_OK) return;
     bool bad = false;
     for (uint32_t s = first_stream[i]; s < first_stream[i + 1]; ++s) bad = bad || hs[s].overflow;
-    if (bad) { E->status[i] = DSA_ERR_INVALID_DATA; E->messages[i] = "entropy coding failed"; continue; }
+    if (bad) { E->status[i] = DSA_ERR_INVALID_DATA; E->messages[i] = "entropy coding failed"; return; }
     synth::ByteWriter w;
     const uint32_t s0 = first_stream[i];
+    try {
     synth::write_stream(w, ins[i], plans[i],
       [&](synth::ByteWriter &bw, size_t k) {               // SequentialIntegerAttributeEncoder.cs:55-128
         const dsa::EncStream &S = hs[s0 + k];
@@ -485,8 +569,16 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
         if (S.kind == 0) { for (uint32_t c = 0; c < S.nc_out; ++c) bw.f32(S.qmin[c]); bw.f32(S.qrange); bw.u8((uint8_t)S.bits); }
         else bw.u8((uint8_t)S.bits);
       });
+    } catch (const std::exception &e) { E->status[i] = DSA_ERR_INVALID_DATA; E->messages[i] = e.what(); return; }
     E->streams[i].swap(w.d);
+  };
+  {
+    const uint32_t nt = std::max(1u, std::min<uint32_t>(n, std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 8));
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < nt; ++t) th.emplace_back([&, t]() { for (uint32_t i = t; i < n; i += nt) layout_one(i); });
+    for (auto &x : th) x.join();
   }
+  lap("stream layout");
   *out = E;
   return DSA_OK;
 }

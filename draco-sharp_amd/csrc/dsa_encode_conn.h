@@ -1,0 +1,339 @@
+// draco-sharp_amd/csrc/dsa_encode_conn.h  (included by dsa_encode.h)
+//
+// Encode direction, connectivity on the device: corner table, Edgebreaker symbols,
+// depth-first attribute order and parallelogram operand entries of a batch of triangle meshes, one wave per mesh.
+//   corner table            CornerTable.cs:15-172 (opposites from shared edges, left-most corners, manifold checks)
+//   Edgebreaker traversal   MeshEdgeBreakerEncoder.cs:38-124 (start faces), :158-183 (init face), :185-274 (symbols),
+//                           :276-303 (holes), :331-361 (hole ids), :373-390 (topology splits)
+//   attribute order         Traverser/DepthFirstTraverser.cs:9-99, MeshTraversalSequencer.cs:13-31
+// It is the host coder of dsa_encode_host.h (CornerTable::build, EbEncoder, dfs_sequence) statement by statement on
+// arrays in device memory: the table construction and the operand entries on the whole wave, the two traversals --
+// sequential by nature, every step decides the next from what is visited -- on lane 0, meshes of a batch in parallel.
+// The byte stream that results is the CPU coder's (tests/test_gpu_encode.py compares them).
+#pragma once
+
+namespace dsa {
+
+struct EncConn {                   // one per mesh; device memory, mirrored on the host
+  uint64_t faces;                  // u32[3F] input: vertex of every corner
+  uint64_t opp;                    // u32[3F] opposite corner or INVALID
+  uint64_t voff, vcur, vlist;      // u32[V+1], u32[V], u32[3F]: corners by vertex
+  uint64_t vcorner;                // u32[V] left-most corner
+  uint64_t fvis, vvis;             // u8[F], u8[V]
+  uint64_t hole_id, hole_vis;      // i32[V], u8[V]
+  uint64_t split_sym;              // i32[F]: symbol id of the S coded at the face, or -1
+  uint64_t stack;                  // u32[F]
+  uint64_t processed, init_corners;// u32[F] each
+  uint64_t symbols;                // u8[F] OUTPUT encoder order, bit patterns 0 1 3 5 7
+  uint64_t start_bits;             // u8[F] OUTPUT
+  uint64_t splits;                 // u32[3 * split_cap] OUTPUT (source, split, edge)
+  uint64_t d2c, v2d;               // u32[V], i32[V]
+  uint64_t e2v, ops;               // u32[V], i32[3V] OUTPUT for the attribute kernels
+  uint32_t F, V, split_cap, pad0;
+  uint32_t num_symbols, num_start_bits, num_splits, num_split_symbols, num_processed, num_init, num_entries, interior_edges;   // OUTPUT
+  uint32_t status, detail;         // 0 ok; else the host coder's complaint (see enc_conn_message)
+};
+
+enum { ENC_OK = 0, ENC_DEGENERATE = 1, ENC_NONMANIFOLD_EDGE = 2, ENC_RING = 3, ENC_NONMANIFOLD_VERTEX = 4, ENC_ISOLATED = 5, ENC_UNREACHED = 6, ENC_SPLITS = 7 };
+static inline const char *enc_conn_message(uint32_t status) {
+  switch (status) {
+    case ENC_DEGENERATE: return "degenerate face in input mesh";
+    case ENC_NONMANIFOLD_EDGE: return "non-manifold edge (duplicate half-edge)";
+    case ENC_RING: return "vertex ring does not close";
+    case ENC_NONMANIFOLD_VERTEX: return "non-manifold vertex in input mesh";
+    case ENC_ISOLATED: return "isolated vertex in input mesh";
+    case ENC_UNREACHED: return "traversal did not reach every vertex";
+    case ENC_SPLITS: return "too many topology splits";
+    default: return "connectivity coding failed";
+  }
+}
+
+__device__ __forceinline__ uint32_t ec_next(uint32_t c) { return c == DSA_INVALID ? c : ((c + 1) % 3 ? c + 1 : c - 2); }
+__device__ __forceinline__ uint32_t ec_prev(uint32_t c) { return c == DSA_INVALID ? c : (c % 3 ? c - 1 : c + 2); }
+
+struct EcTable {                   // the corner table as the traversals see it
+  const uint32_t *c2v, *opp, *vcorner;
+  __device__ __forceinline__ uint32_t opposite(uint32_t c) const { return c == DSA_INVALID ? c : opp[c]; }
+  __device__ __forceinline__ uint32_t vertex(uint32_t c) const { return c == DSA_INVALID ? DSA_INVALID : c2v[c]; }
+  __device__ __forceinline__ uint32_t swing_right(uint32_t c) const { return ec_prev(opposite(ec_prev(c))); }
+  __device__ __forceinline__ uint32_t swing_left(uint32_t c) const { return ec_next(opposite(ec_next(c))); }
+  __device__ __forceinline__ uint32_t right_corner(uint32_t c) const { return opposite(ec_next(c)); }
+  __device__ __forceinline__ uint32_t left_corner(uint32_t c) const { return opposite(ec_prev(c)); }
+};
+
+__device__ __forceinline__ void ec_fail(EncConn *E, uint32_t status, uint32_t detail) { if (atomicCAS(&E->status, 0u, status) == 0u) E->detail = detail; }
+__device__ __forceinline__ void ec_sync() { __threadfence_block(); __syncthreads(); }
+
+__global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncConn *conns, uint32_t n) {
+  const uint32_t mesh = blockIdx.x, lane = threadIdx.x;
+  if (mesh >= n) return;
+  EncConn *E = &conns[mesh];
+  const uint32_t F = E->F, V = E->V, NC = 3u * F;
+  const uint32_t *c2v = (const uint32_t *)(arena + E->faces);
+  uint32_t *opp = (uint32_t *)(arena + E->opp), *voff = (uint32_t *)(arena + E->voff), *vcur = (uint32_t *)(arena + E->vcur);
+  uint32_t *vlist = (uint32_t *)(arena + E->vlist), *vcorner = (uint32_t *)(arena + E->vcorner);
+  if (E->status != ENC_OK) return;
+
+  // ---- corners by vertex (counting sort: counts -> offsets -> lists), CornerTable.cs:41-67 needs them implicitly
+  for (uint32_t v = lane; v <= V; v += WAVE) voff[v] = 0;
+  ec_sync();
+  for (uint32_t c = lane; c < NC; c += WAVE) {
+    const uint32_t a = c2v[ec_next(c)], b = c2v[ec_prev(c)];
+    if (a == b || a == c2v[c] || b == c2v[c]) ec_fail(E, ENC_DEGENERATE, c / 3);
+    atomicAdd(&voff[c2v[c] + 1], 1u);
+  }
+  ec_sync();
+  if (E->status != ENC_OK) return;
+  {                                                  // exclusive prefix sum: voff[v + 1] held count(v)
+    uint32_t base = 0;
+    for (uint32_t v0 = 0; v0 < V; v0 += WAVE) {
+      const uint32_t v = v0 + lane;
+      uint32_t x = v < V ? voff[v + 1] : 0u, incl = x;
+      for (int d = 1; d < WAVE; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, WAVE); if ((int)lane >= d) incl += y; }
+      if (v < V) { voff[v + 1] = base + incl; vcur[v] = base + incl - x; }
+      base += (uint32_t)__shfl((int)incl, WAVE - 1, WAVE);
+    }
+  }
+  ec_sync();
+  for (uint32_t c = lane; c < NC; c += WAVE) vlist[atomicAdd(&vcur[c2v[c]], 1u)] = c;
+  ec_sync();
+  // ---- opposites: corner c faces the edge next(c) -> prev(c) = a -> b; its opposite is the corner facing b -> a, i.e.
+  // prev(k) of the corner k at b whose next is a.  The same directed edge twice is a non-manifold edge.
+  for (uint32_t c = lane; c < NC; c += WAVE) {
+    const uint32_t a = c2v[ec_next(c)], b = c2v[ec_prev(c)];
+    uint32_t found = DSA_INVALID, same = 0;
+    for (uint32_t i = voff[b]; i < voff[b + 1]; ++i) { const uint32_t k = vlist[i]; if (c2v[ec_next(k)] == a) found = ec_prev(k); }
+    for (uint32_t i = voff[a]; i < voff[a + 1]; ++i) { const uint32_t k = vlist[i]; if (c2v[ec_next(k)] == b) ++same; }
+    if (same != 1) ec_fail(E, ENC_NONMANIFOLD_EDGE, c);
+    opp[c] = found;
+  }
+  ec_sync();
+  if (E->status != ENC_OK) return;
+  EcTable ct;
+  ct.c2v = c2v; ct.opp = opp; ct.vcorner = vcorner;
+  // ---- left-most corner per vertex (first corner in index order, moved left to the boundary if there is one) and the
+  // manifold check: every corner of the vertex is reached by swinging right from there
+  uint32_t interior = 0;
+  for (uint32_t c = lane; c < NC; c += WAVE) interior += opp[c] != DSA_INVALID ? 1u : 0u;
+  for (int d = 32; d >= 1; d >>= 1) interior += (uint32_t)__shfl_xor((int)interior, d, WAVE);
+  for (uint32_t v = lane; v < V; v += WAVE) {
+    const uint32_t cnt = voff[v + 1] - voff[v];
+    if (cnt == 0) { ec_fail(E, ENC_ISOLATED, v); vcorner[v] = DSA_INVALID; continue; }
+    uint32_t first = DSA_INVALID;
+    for (uint32_t i = voff[v]; i < voff[v + 1]; ++i) first = vlist[i] < first ? vlist[i] : first;
+    uint32_t act = ct.swing_left(first), c = first, guard = 0, lm = first;
+    while (act != DSA_INVALID && act != first) { c = act; act = ct.swing_left(act); if (++guard >= NC) { ec_fail(E, ENC_RING, v); break; } }
+    if (act != first) lm = c;
+    vcorner[v] = lm;
+    uint32_t reach = 0, k = lm;
+    do { ++reach; k = ct.swing_right(k); } while (k != DSA_INVALID && k != lm && reach <= cnt);
+    if (reach != cnt) ec_fail(E, ENC_NONMANIFOLD_VERTEX, v);
+  }
+  ec_sync();
+  if (E->status != ENC_OK) return;
+
+  uint8_t *fvis = arena + E->fvis, *vvis = arena + E->vvis, *hole_vis = arena + E->hole_vis;
+  int32_t *hole_id = (int32_t *)(arena + E->hole_id), *split_sym = (int32_t *)(arena + E->split_sym);
+  uint32_t *stack = (uint32_t *)(arena + E->stack), *processed = (uint32_t *)(arena + E->processed), *init_corners = (uint32_t *)(arena + E->init_corners);
+  uint8_t *symbols = arena + E->symbols, *start_bits = arena + E->start_bits;
+  uint32_t *splits = (uint32_t *)(arena + E->splits);
+  uint32_t *d2c = (uint32_t *)(arena + E->d2c);
+  int32_t *v2d = (int32_t *)(arena + E->v2d);
+  for (uint32_t f = lane; f < F; f += WAVE) { fvis[f] = 0; split_sym[f] = -1; }
+  for (uint32_t v = lane; v < V; v += WAVE) { vvis[v] = 0; hole_id[v] = -1; hole_vis[v] = 0; v2d[v] = -1; }
+  ec_sync();
+
+  if (lane == 0) {
+    // ---- hole ids, MeshEdgeBreakerEncoder.cs:331-361
+    uint32_t num_holes = 0;
+    for (uint32_t i = 0; i < NC; ++i) {
+      if (opp[i] != DSA_INVALID) continue;
+      uint32_t bv = c2v[ec_next(i)];
+      if (hole_id[bv] != -1) continue;
+      const int32_t id = (int32_t)num_holes++;
+      uint32_t c = i;
+      while (hole_id[bv] == -1) {
+        hole_id[bv] = id;
+        c = ec_next(c);
+        while (opp[c] != DSA_INVALID) c = ec_next(opp[c]);
+        bv = c2v[ec_next(c)];
+      }
+    }
+    // ---- Edgebreaker symbols
+    uint32_t nsym = 0, nproc = 0, ninit = 0, nstart = 0, nsplit = 0, nsplit_sym = 0;
+    int32_t last_symbol_id = -1;
+    bool failed = false;
+    auto encode_hole = [&](uint32_t start_corner, bool encode_first) {          // :276-303
+      uint32_t c = ec_prev(start_corner);
+      while (opp[c] != DSA_INVALID) c = ec_next(opp[c]);
+      const uint32_t start_v = c2v[start_corner];
+      if (encode_first) vvis[start_v] = 1;
+      hole_vis[hole_id[start_v]] = 1;
+      uint32_t act = c2v[ec_prev(c)];
+      while (act != start_v) {
+        vvis[act] = 1;
+        c = ec_next(c);
+        while (opp[c] != DSA_INVALID) c = ec_next(opp[c]);
+        act = c2v[ec_prev(c)];
+      }
+    };
+    auto check_split = [&](int32_t src_symbol, uint32_t edge, uint32_t neighbor_face) {   // :373-390
+      const int32_t s = split_sym[neighbor_face];
+      if (s < 0) return;
+      if (nsplit >= E->split_cap) { failed = true; return; }
+      splits[3 * nsplit] = (uint32_t)src_symbol; splits[3 * nsplit + 1] = (uint32_t)s; splits[3 * nsplit + 2] = edge;
+      ++nsplit;
+    };
+    auto face_done = [&](uint32_t o) { return o == DSA_INVALID || fvis[o / 3] != 0; };
+    auto encode_from_corner = [&](uint32_t corner0) {                             // :185-274
+      uint32_t sp = 0;
+      stack[sp++] = corner0;
+      while (sp) {
+        uint32_t corner = stack[sp - 1];
+        if (corner == DSA_INVALID || fvis[corner / 3]) { --sp; continue; }
+        for (;;) {
+          ++last_symbol_id;
+          const uint32_t face = corner / 3;
+          fvis[face] = 1;
+          processed[nproc++] = corner;
+          const uint32_t v = c2v[corner];
+          const bool on_boundary = hole_id[v] != -1;
+          if (!vvis[v]) {
+            vvis[v] = 1;
+            if (!on_boundary) { symbols[nsym++] = 0; corner = ct.right_corner(corner); continue; }
+          }
+          const uint32_t rc = ct.right_corner(corner), lc = ct.left_corner(corner);
+          const uint32_t rf = rc == DSA_INVALID ? DSA_INVALID : rc / 3, lf = lc == DSA_INVALID ? DSA_INVALID : lc / 3;
+          if (face_done(rc)) {
+            if (rf != DSA_INVALID) check_split(last_symbol_id, 1, rf);
+            if (face_done(lc)) {
+              if (lf != DSA_INVALID) check_split(last_symbol_id, 0, lf);
+              symbols[nsym++] = 7;
+              --sp;
+              break;
+            }
+            symbols[nsym++] = 5;
+            corner = lc;
+          } else {
+            if (face_done(lc)) {
+              if (lf != DSA_INVALID) check_split(last_symbol_id, 0, lf);
+              symbols[nsym++] = 3;
+              corner = rc;
+            } else {
+              symbols[nsym++] = 1;
+              ++nsplit_sym;
+              if (on_boundary) { const int32_t hid = hole_id[v]; if (!hole_vis[hid]) encode_hole(corner, false); }
+              split_sym[face] = last_symbol_id;
+              stack[sp - 1] = lc;
+              stack[sp++] = rc;                       // sp <= F: every push marks a face first
+              break;
+            }
+          }
+        }
+      }
+    };
+    for (uint32_t c = 0; c < NC && !failed; ++c) {                                 // :38-124
+      const uint32_t face = c / 3;
+      if (fvis[face]) continue;
+      // find_init_face, :158-183
+      uint32_t corner = 3 * face, start = DSA_INVALID;
+      bool interior_face = true;
+      for (int i = 0; i < 3; ++i) {
+        if (opp[corner] == DSA_INVALID) { start = corner; interior_face = false; break; }
+        if (hole_id[c2v[corner]] != -1) {
+          uint32_t rc = corner;
+          while (rc != DSA_INVALID) { corner = rc; rc = ct.swing_right(rc); }
+          start = ec_prev(corner);
+          interior_face = false;
+          break;
+        }
+        corner = ec_next(corner);
+      }
+      if (interior_face) start = corner;
+      start_bits[nstart++] = interior_face ? 1 : 0;
+      if (interior_face) {
+        vvis[c2v[start]] = 1; vvis[c2v[ec_next(start)]] = 1; vvis[c2v[ec_prev(start)]] = 1;
+        fvis[face] = 1;
+        init_corners[ninit++] = ec_next(start);
+        const uint32_t o = opp[ec_next(start)];
+        if (o != DSA_INVALID && !fvis[o / 3]) encode_from_corner(o);
+      } else {
+        encode_hole(ec_next(start), true);
+        encode_from_corner(start);
+      }
+    }
+    if (failed) ec_fail(E, ENC_SPLITS, nsplit);
+    E->num_symbols = nsym; E->num_start_bits = nstart; E->num_splits = nsplit; E->num_split_symbols = nsplit_sym;
+    E->num_processed = nproc; E->num_init = ninit; E->interior_edges = interior / 2;
+    __threadfence_block();
+  }
+  __syncthreads();
+  if (E->status != ENC_OK) return;
+  // the traversal marks start over for the attribute order
+  for (uint32_t f = lane; f < F; f += WAVE) fvis[f] = 0;
+  for (uint32_t v = lane; v < V; v += WAVE) vvis[v] = 0;
+  ec_sync();
+  if (lane == 0) {
+    // ---- depth-first attribute order over the decoder's face order (processed corners last to first, then the init
+    // corners), DepthFirstTraverser.cs:9-99
+    const uint32_t nproc = E->num_processed, ninit = E->num_init;
+    uint32_t count = 0;
+    auto visit = [&](uint32_t v, uint32_t c) { vvis[v] = 1; v2d[v] = (int32_t)count; d2c[count++] = c; };
+    auto fdone = [&](uint32_t f) { return f == DSA_INVALID || fvis[f] != 0; };
+    for (uint32_t i = 0; i < nproc + ninit; ++i) {
+      const uint32_t start = i < nproc ? processed[nproc - 1 - i] : init_corners[i - nproc];
+      if (fdone(start / 3)) continue;
+      uint32_t sp = 0;
+      stack[sp++] = start;
+      const uint32_t nvx = c2v[ec_next(start)], pvx = c2v[ec_prev(start)];
+      if (!vvis[nvx]) visit(nvx, ec_next(start));
+      if (!vvis[pvx]) visit(pvx, ec_prev(start));
+      while (sp) {
+        uint32_t corner = stack[sp - 1];
+        uint32_t face = corner == DSA_INVALID ? DSA_INVALID : corner / 3;
+        if (corner == DSA_INVALID || fdone(face)) { --sp; continue; }
+        for (;;) {
+          fvis[face] = 1;
+          const uint32_t v = c2v[corner];
+          if (!vvis[v]) {
+            const bool ob = ct.swing_left(vcorner[v]) == DSA_INVALID;
+            visit(v, corner);
+            if (!ob) { corner = ct.right_corner(corner); face = corner / 3; continue; }
+          }
+          const uint32_t rc = ct.right_corner(corner), lc = ct.left_corner(corner);
+          const uint32_t rf = rc == DSA_INVALID ? DSA_INVALID : rc / 3, lf = lc == DSA_INVALID ? DSA_INVALID : lc / 3;
+          if (fdone(rf)) {
+            if (fdone(lf)) { --sp; break; }
+            corner = lc; face = lf;
+          } else {
+            if (fdone(lf)) { corner = rc; face = rf; }
+            else { stack[sp - 1] = lc; stack[sp++] = rc; break; }
+          }
+        }
+      }
+    }
+    E->num_entries = count;
+    if (count != V) ec_fail(E, ENC_UNREACHED, count);
+    __threadfence_block();
+  }
+  __syncthreads();
+  if (E->status != ENC_OK) return;
+  // ---- entry -> vertex and the parallelogram operand entries of every entry (MeshPredictionSchemeParallelogramEncoder.cs:35-56)
+  uint32_t *e2v = (uint32_t *)(arena + E->e2v);
+  int32_t *ops = (int32_t *)(arena + E->ops);
+  for (uint32_t p = lane; p < V; p += WAVE) {
+    const uint32_t ci = d2c[p];
+    e2v[p] = c2v[ci];
+    int32_t on = -1, op = -1, oo = -1;
+    if (p > 0) {
+      const uint32_t oci = opp[ci];
+      if (oci != DSA_INVALID) {
+        const int32_t vo = v2d[c2v[oci]], vn = v2d[c2v[ec_next(oci)]], vp = v2d[c2v[ec_prev(oci)]];
+        if (vo < (int32_t)p && vn < (int32_t)p && vp < (int32_t)p) { on = vn; op = vp; oo = vo; }
+      }
+    }
+    ops[3 * p] = on; ops[3 * p + 1] = op; ops[3 * p + 2] = oo;
+  }
+}
+
+}  // namespace dsa

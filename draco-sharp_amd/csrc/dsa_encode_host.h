@@ -1135,14 +1135,10 @@ struct MeshPlan {
   std::vector<PortableAttr> atts;    // descriptors; vals / quantisation parameters are filled by whoever codes the values
   bool single = false;
   uint32_t num_att_data = 0;
+  int64_t interior_edges = -1;       // >= 0: given (connectivity coded on the device, no corner table here); else counted from ct
 };
-static void plan_mesh(const MeshIn &in, const Options &opt, MeshPlan &pl) {
-  pl.ct.build(in.faces, in.nf, in.nv);
-  for (uint32_t v = 0; v < in.nv; ++v) check(pl.ct.vcorner[v] != kInvalid, "isolated vertex in input mesh");
-  EbEncoder enc(pl.ct, pl.eb);
-  enc.run();
-  dfs_sequence(pl.ct, pl.eb.processed_corners, pl.seq);
-  check(pl.seq.data_to_corner.size() == in.nv, "traversal did not reach every vertex");
+// What of a plan does not depend on the connectivity: attribute descriptors and the options that shape the stream.
+static void plan_attributes(const MeshIn &in, const Options &opt, MeshPlan &pl) {
   pl.atts.clear();
   { PortableAttr a; a.att_type = 0; a.nc = a.nc_out = 3; a.seq_type = 2; a.data_type = 9; a.prediction = opt.pos_prediction; a.bits = opt.pos_bits; pl.atts.push_back(a); }
   if (in.normals) { PortableAttr a; a.att_type = 1; a.nc_out = 3; a.nc = 2; a.seq_type = 3; a.data_type = 9; a.bits = opt.normal_bits; a.prediction = opt.normal_prediction == 6 ? 6 : 0; pl.atts.push_back(a); }
@@ -1153,9 +1149,18 @@ static void plan_mesh(const MeshIn &in, const Options &opt, MeshPlan &pl) {
   pl.force_scheme = opt.force_scheme; pl.compression_level = opt.compression_level;
   pl.predictive = opt.predictive_connectivity == 1;
   pl.valence = opt.predictive_connectivity == 2;
+  pl.traversal_method = opt.traversal_method;
+}
+static void plan_mesh(const MeshIn &in, const Options &opt, MeshPlan &pl) {
+  pl.ct.build(in.faces, in.nf, in.nv);
+  for (uint32_t v = 0; v < in.nv; ++v) check(pl.ct.vcorner[v] != kInvalid, "isolated vertex in input mesh");
+  EbEncoder enc(pl.ct, pl.eb);
+  enc.run();
+  dfs_sequence(pl.ct, pl.eb.processed_corners, pl.seq);
+  check(pl.seq.data_to_corner.size() == in.nv, "traversal did not reach every vertex");
+  plan_attributes(in, opt, pl);
   if (pl.valence) valence_context_symbols(pl.ct, pl.eb, pl.ctx_symbols);
   if (pl.predictive) predictive_symbols(pl.ct, pl.eb, pl.explicit_symbols, pl.predictions);
-  pl.traversal_method = opt.traversal_method;
   if (pl.traversal_method != 0) {
     prediction_degree_sequence(pl.ct, pl.eb.processed_corners, pl.seq_pd);
     check(pl.seq_pd.data_to_corner.size() == in.nv, "traversal did not reach every vertex");
@@ -1198,8 +1203,9 @@ static void write_stream(ByteWriter &w, const MeshIn &in, const MeshPlan &pl, Va
     write_rabs(w, eb.start_face_bits);
     if (pl.num_att_data) {
       // per-vertex attributes: no interior seams, one 0 bit per interior edge in decoder face order
-      std::vector<uint8_t> vis(ct.nf(), 0), bits;
-      for (uint32_t c : eb.processed_corners) {
+      std::vector<uint8_t> vis(pl.interior_edges >= 0 ? 0 : ct.nf(), 0), bits;
+      if (pl.interior_edges >= 0) bits.assign((size_t)pl.interior_edges, 0);
+      else for (uint32_t c : eb.processed_corners) {
         uint32_t corners[3] = {c, CornerTable::next(c), CornerTable::prev(c)};
         vis[c / 3] = 1;
         for (int k = 0; k < 3; ++k) {
