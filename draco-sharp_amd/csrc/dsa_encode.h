@@ -6,9 +6,8 @@
 // (BASELINE.json configs[4]: "batch quantize + parallelogram predict + rANS encode as HIP kernels").
 //
 // Split of the work:
-//   host  (dsa_encode_host.h)  corner table, Edgebreaker connectivity, DFS sequencing, parallelogram operand
-//                              entries; after the statistics pass: symbol scheme choice + rANS tables
-//                              (O(alphabet) per stream); final stream layout
+//   GPU   (dsa_encode_conn.h)  k_enc_connectivity corner table, Edgebreaker symbols, depth-first attribute order, parallelogram
+//                                                 operand entries, one wave per mesh (DSA_ENC_HOST_CONN=1: by the host coder)
 //   GPU   (this file)          k_enc_bounds      quantisation range per attribute   AttributeQuantizationTransform.cs:66-108
 //                              k_enc_quantize    floats -> portable ints, normals -> octahedral (s,t)   :136-177, OctahedronToolBox.cs:28-119
 //                              k_enc_gather      vertex order -> traversal order, wrap bounds           PredictionSchemeWrapTransform.cs:88-100
@@ -16,6 +15,8 @@
 //                                                                                                       PredictionSchemeWrapEncodingTransform.cs:45-90,
 //                                                                                                       ...NormalOctahedronCanonicalizedEncodingTransform.cs:47-83
 //                              k_enc_rans        rANS coding of every stream, one lane per stream        RAnsEncoder.cs:22-30, AnsEncoder.cs:34-64, SymbolEncoding.cs:92-193
+//   host  (dsa_encode_host.h)  input checks; after the statistics pass: symbol scheme choice + rANS tables (O(alphabet) per
+//                              stream, threads over streams); final stream layout (threads over meshes)
 // The result is byte-identical to the CPU coder of dsa_encode_host.h (tests/test_gpu_encode.py), hence decodes
 // bit-exactly to the quantised input.
 #pragma once
