@@ -3,8 +3,9 @@
   DracoEncoder.Encode(BinaryWriter, Config, PointCloud, attributes)     src/Draco/IO/DracoEncoder.cs:22-41
   Config (quantisation bits, speed, prediction overrides)              src/Draco/IO/Config.cs
 
-bound to the dsa_encode_* entry points of libdraco_mi355x.so.  Connectivity (Edgebreaker) is coded on the host side
-of the library, attribute quantisation / prediction / rANS coding by HIP kernels; there is no CPU fallback."""
+bound to the dsa_encode_* entry points of libdraco_mi355x.so.  Connectivity (corner table, Edgebreaker symbols, attribute
+order), attribute quantisation / prediction / rANS coding are HIP kernels; the library's host side chooses the symbol schemes
+and lays the bytes out; there is no CPU fallback."""
 import ctypes as C
 
 import numpy as np
