@@ -43,7 +43,12 @@ def run(count, seed, ctx=None):
     b.decode()
     bad = []
     for i, (data, what) in enumerate(cases):
-        ref = oracle.decode(data)
+        try:
+            ref = oracle.decode(data)
+        except oracle.OracleError as e:          # a stream the reference refuses (its own limits): the device must refuse it too
+            if b.status(i) == 0:
+                bad.append((i, what, "oracle refuses (%s), device decodes" % e))
+            continue
         if b.status(i) != 0:
             bad.append((i, what, "status %d site %d" % (b.status(i), b.mesh_info(i).detail)))
             continue
