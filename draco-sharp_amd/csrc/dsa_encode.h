@@ -284,6 +284,24 @@ __global__ __launch_bounds__(WAVE) void k_enc_rans(uint8_t *arena, EncStream *st
 
 }  // namespace dsa
 
+namespace dsa {
+// Many small pieces in one transfer: k_enc_pack gathers pieces of the arena into one buffer (then one copy to the host),
+// k_enc_unpack scatters one uploaded buffer into the arena.  A batch has thousands of such pieces (symbols and split events per
+// mesh, histograms, tables and coded bytes per stream); as copies of their own they cost more than the kernels between them.
+struct PackItem { uint64_t arena_off, packed_off; uint32_t len, pad; };
+__global__ __launch_bounds__(256) void k_enc_pack(const uint8_t *arena, uint8_t *packed, const PackItem *items, uint32_t n) {
+  if (blockIdx.x >= n) return;
+  const PackItem it = items[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < it.len; i += 256) packed[it.packed_off + i] = arena[it.arena_off + i];
+}
+__global__ __launch_bounds__(256) void k_enc_unpack(uint8_t *arena, const uint8_t *packed, const PackItem *items, uint32_t n) {
+  if (blockIdx.x >= n) return;
+  const PackItem it = items[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < it.len; i += 256) arena[it.arena_off + i] = packed[it.packed_off + i];
+}
+
+}  // namespace dsa
+
 // ------------------------------------------------------------------------------------------------ host side
 struct dsa_encoded {
   dsa_context *ctx = nullptr;
@@ -426,6 +444,37 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
   dsa::EncConn *d_conns = nullptr;
   auto cleanup = [&]() { if (arena) (void)hipFree(arena); if (d_streams) (void)hipFree(d_streams); if (d_conns) (void)hipFree(d_conns); };
 #define ENC_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); delete E; return set_err(ctx, e_ == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
+  // pieces of the arena -> one host buffer (items[k].packed_off filled in); host buffer -> pieces of the arena
+  auto gather = [&](std::vector<dsa::PackItem> &items, std::vector<uint8_t> &host) -> dsa_status {
+    uint64_t total = 0;
+    for (auto &it : items) { it.packed_off = total; total += ((uint64_t)it.len + 15) & ~15ull; }
+    host.resize(total);
+    if (items.empty() || total == 0) return DSA_OK;
+    uint8_t *d_packed = nullptr; dsa::PackItem *d_items = nullptr;
+    hipError_t e = hipMalloc((void **)&d_packed, total);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_items, sizeof(dsa::PackItem) * items.size());
+    if (e == hipSuccess) e = hipMemcpyAsync(d_items, items.data(), sizeof(dsa::PackItem) * items.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) { hipLaunchKernelGGL(dsa::k_enc_pack, dim3((uint32_t)items.size()), dim3(256), 0, ctx->stream, arena, d_packed, d_items, (uint32_t)items.size()); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d_packed, total, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (d_packed) (void)hipFree(d_packed);
+    if (d_items) (void)hipFree(d_items);
+    return e == hipSuccess ? DSA_OK : (e == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE);
+  };
+  auto scatter = [&](std::vector<dsa::PackItem> &items, const std::vector<uint8_t> &host) -> dsa_status {
+    if (items.empty() || host.empty()) return DSA_OK;
+    uint8_t *d_packed = nullptr; dsa::PackItem *d_items = nullptr;
+    hipError_t e = hipMalloc((void **)&d_packed, host.size());
+    if (e == hipSuccess) e = hipMalloc((void **)&d_items, sizeof(dsa::PackItem) * items.size());
+    if (e == hipSuccess) e = hipMemcpyAsync(d_items, items.data(), sizeof(dsa::PackItem) * items.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_packed, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) { hipLaunchKernelGGL(dsa::k_enc_unpack, dim3((uint32_t)items.size()), dim3(256), 0, ctx->stream, arena, d_packed, d_items, (uint32_t)items.size()); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (d_packed) (void)hipFree(d_packed);
+    if (d_items) (void)hipFree(d_items);
+    return e == hipSuccess ? DSA_OK : (e == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE);
+  };
+#define ENC_ST(call) do { dsa_status s_ = (call); if (s_ != DSA_OK) { cleanup(); delete E; return set_err(ctx, s_, "%s failed", #call); } } while (0)
   if (ns) {
     hipStream_t st = ctx->stream;
     ENC_TRY(hipMalloc((void **)&arena, cur ? cur : 256));
@@ -456,6 +505,7 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     lap("device phases 0 + 1");
     if (!host_conn) {
       // what the stream layout needs of the connectivity: symbols, start-face bits, split events, two counts
+      std::vector<dsa::PackItem> conn_items;
       for (uint32_t i = 0; i < n; ++i) {
         if (E->status[i] != DSA_OK) continue;
         const dsa::EncConn &C = hc[i];
@@ -466,18 +516,20 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
         }
         synth::EbResult &eb = plans[i].eb;
         eb.symbols.resize(C.num_symbols); eb.start_face_bits.resize(C.num_start_bits); eb.num_split_symbols = C.num_split_symbols;
-        e2v[i].resize((size_t)3 * C.num_splits);                                // staging for the split triples
-        if (C.num_symbols) ENC_TRY(hipMemcpyAsync(eb.symbols.data(), arena + C.symbols, C.num_symbols, hipMemcpyDeviceToHost, st));
-        if (C.num_start_bits) ENC_TRY(hipMemcpyAsync(eb.start_face_bits.data(), arena + C.start_bits, C.num_start_bits, hipMemcpyDeviceToHost, st));
-        if (C.num_splits) ENC_TRY(hipMemcpyAsync(e2v[i].data(), arena + C.splits, 12ull * C.num_splits, hipMemcpyDeviceToHost, st));
+        eb.splits.resize(C.num_splits);
+        conn_items.push_back({C.symbols, 0, C.num_symbols, i});
+        conn_items.push_back({C.start_bits, 0, C.num_start_bits, i});
+        conn_items.push_back({C.splits, 0, 12u * C.num_splits, i});
         plans[i].interior_edges = (int64_t)C.interior_edges;
       }
-      ENC_TRY(hipStreamSynchronize(st));
-      for (uint32_t i = 0; i < n; ++i) {
-        if (E->status[i] != DSA_OK) continue;
-        synth::EbResult &eb = plans[i].eb;
-        eb.splits.resize(hc[i].num_splits);
-        for (uint32_t k = 0; k < hc[i].num_splits; ++k) eb.splits[k] = {e2v[i][3 * k], e2v[i][3 * k + 1], e2v[i][3 * k + 2]};
+      std::vector<uint8_t> conn_host;
+      ENC_ST(gather(conn_items, conn_host));
+      for (size_t k = 0; k + 2 < conn_items.size(); k += 3) {
+        synth::EbResult &eb = plans[conn_items[k].pad].eb;
+        if (conn_items[k].len) memcpy(eb.symbols.data(), conn_host.data() + conn_items[k].packed_off, conn_items[k].len);
+        if (conn_items[k + 1].len) memcpy(eb.start_face_bits.data(), conn_host.data() + conn_items[k + 1].packed_off, conn_items[k + 1].len);
+        const uint32_t *sp = (const uint32_t *)(conn_host.data() + conn_items[k + 2].packed_off);
+        for (size_t q = 0; q < eb.splits.size(); ++q) eb.splits[q] = {sp[3 * q], sp[3 * q + 1], sp[3 * q + 2]};
       }
     }
   }
@@ -485,12 +537,19 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
   // ---- host phase 2: scheme choice and rANS tables from the device statistics
   std::vector<synth::SymbolPlan> splans(ns);
   std::vector<std::vector<uint32_t>> hists(ns);
-  for (uint32_t s = 0; s < ns; ++s) {
-    if (hs[s].overflow || hs[s].max_value >= hs[s].hist_cap) { hs[s].overflow = 1; continue; }
-    hists[s].resize((size_t)hs[s].max_value + 1);
-    ENC_TRY(hipMemcpyAsync(hists[s].data(), arena + hs[s].hist_raw, 4ull * hists[s].size(), hipMemcpyDeviceToHost, ctx->stream));
+  {
+    std::vector<dsa::PackItem> items;
+    for (uint32_t s = 0; s < ns; ++s) {
+      if (hs[s].overflow || hs[s].max_value >= hs[s].hist_cap) { hs[s].overflow = 1; continue; }
+      items.push_back({hs[s].hist_raw, 0, 4u * (hs[s].max_value + 1u), s});
+    }
+    std::vector<uint8_t> host;
+    ENC_ST(gather(items, host));
+    for (auto &it : items) {
+      hists[it.pad].resize(it.len / 4);
+      memcpy(hists[it.pad].data(), host.data() + it.packed_off, it.len);
+    }
   }
-  if (ns) ENC_TRY(hipStreamSynchronize(ctx->stream));
   std::vector<int> stream_mesh(ns, 0);
   for (uint32_t i = 0; i < n; ++i) for (uint32_t s = first_stream[i]; s < first_stream[i + 1]; ++s) stream_mesh[s] = (int)i;
   std::vector<std::string> plan_error(ns);
@@ -516,12 +575,22 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     for (uint32_t t = 0; t < nt; ++t) th.emplace_back([&, t]() { for (uint32_t s = t; s < ns; s += nt) plan_stream(s); });
     for (auto &x : th) x.join();
   }
-  for (uint32_t s = 0; s < ns; ++s) {
-    const uint32_t i = (uint32_t)stream_mesh[s];
-    if (E->status[i] != DSA_OK) continue;
-    if (!plan_error[s].empty()) { E->status[i] = DSA_ERR_INVALID_DATA; E->messages[i] = plan_error[s]; continue; }
-    ENC_TRY(hipMemcpyAsync(arena + hs[s].prob, splans[s].coder.prob.data(), 4ull * splans[s].coder.num_symbols, hipMemcpyHostToDevice, ctx->stream));
-    ENC_TRY(hipMemcpyAsync(arena + hs[s].cum, splans[s].coder.cum.data(), 4ull * splans[s].coder.num_symbols, hipMemcpyHostToDevice, ctx->stream));
+  {
+    std::vector<dsa::PackItem> items;
+    std::vector<uint8_t> host;
+    for (uint32_t s = 0; s < ns; ++s) {
+      const uint32_t i = (uint32_t)stream_mesh[s];
+      if (E->status[i] != DSA_OK) continue;
+      if (!plan_error[s].empty()) { E->status[i] = DSA_ERR_INVALID_DATA; E->messages[i] = plan_error[s]; continue; }
+      const uint32_t bytes = 4u * splans[s].coder.num_symbols;
+      for (int t = 0; t < 2; ++t) {
+        const std::vector<uint32_t> &src = t == 0 ? splans[s].coder.prob : splans[s].coder.cum;
+        items.push_back({t == 0 ? hs[s].prob : hs[s].cum, (uint64_t)host.size(), bytes, s});
+        host.insert(host.end(), (const uint8_t *)src.data(), (const uint8_t *)src.data() + bytes);
+        host.resize((host.size() + 15) & ~(size_t)15);
+      }
+    }
+    ENC_ST(scatter(items, host));
   }
   lap("histograms + symbol plans");
   // ---- device phase 2: entropy coding
@@ -532,15 +601,22 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     hipLaunchKernelGGL(dsa::k_enc_rans, dim3((ns + WAVE - 1) / WAVE), dim3(WAVE), 0, st, arena, d_streams, ns);
     ENC_TRY(hipMemcpyAsync(hs.data(), d_streams, sizeof(dsa::EncStream) * ns, hipMemcpyDeviceToHost, st));
     ENC_TRY(hipStreamSynchronize(st));
+    std::vector<dsa::PackItem> items;
     for (uint32_t s = 0; s < ns; ++s) {
       if (hs[s].overflow) continue;
-      rans[s].resize(hs[s].rans_len); bits[s].resize(hs[s].bits_len);
-      if (hs[s].rans_len) ENC_TRY(hipMemcpyAsync(rans[s].data(), arena + hs[s].out_rans, hs[s].rans_len, hipMemcpyDeviceToHost, st));
-      if (hs[s].bits_len) ENC_TRY(hipMemcpyAsync(bits[s].data(), arena + hs[s].out_bits, hs[s].bits_len, hipMemcpyDeviceToHost, st));
+      items.push_back({hs[s].out_rans, 0, hs[s].rans_len, s});
+      items.push_back({hs[s].out_bits, 0, hs[s].bits_len, s});
     }
-    ENC_TRY(hipStreamSynchronize(st));
+    std::vector<uint8_t> host;
+    ENC_ST(gather(items, host));
+    for (size_t k = 0; k + 1 < items.size(); k += 2) {
+      const uint32_t s = items[k].pad;
+      rans[s].assign(host.begin() + (ptrdiff_t)items[k].packed_off, host.begin() + (ptrdiff_t)(items[k].packed_off + items[k].len));
+      bits[s].assign(host.begin() + (ptrdiff_t)items[k + 1].packed_off, host.begin() + (ptrdiff_t)(items[k + 1].packed_off + items[k + 1].len));
+    }
   }
 #undef ENC_TRY
+#undef ENC_ST
   lap("device phase 2 + downloads");
   cleanup();
   // ---- host phase 3: stream layout (threads over meshes; write_stream may throw like any part of the host coder)
