@@ -394,16 +394,20 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st2));
   }
   static const int split_mode = getenv("DSA_SYM_SPLIT") ? atoi(getenv("DSA_SYM_SPLIT")) : 1;
+  // DSA_EARLY_FUSE=1 (measured 1.7 ms slower, off): the wave that decoded an early attribute's symbols also predicts and
+  // dequantises it -- the octahedral prediction leaves the tail (7.5 -> 4.7 ms) but its waves keep 80-register slots twice as
+  // long and the late symbols end 4.7 ms later
+  static const uint32_t early_fuse = (getenv("DSA_EARLY_FUSE") && atoi(getenv("DSA_EARLY_FUSE")) != 0) && !(lane_flags & (LN_FLAG_PREDICT | LN_FLAG_OCT)) ? SYM_EARLY_FUSE : 0u;
   if (sym_split && split_mode == 2) {          // early attributes first, then the late ones beside the early prediction
-    launch_symbols(st2, lane_flags | SYM_EARLY_ONLY);
+    launch_symbols(st2, lane_flags | SYM_EARLY_ONLY | early_fuse);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st2));
     HIP_TRY(ctx, hipStreamWaitEvent(st4, ctx->ev_conn, 0));
     launch_symbols(st2, lane_flags | SYM_LATE_ONLY);
   } else if (sym_split) {                      // both at once, the early ones on the stream with priority
     HIP_TRY(ctx, hipStreamWaitEvent(st4, ctx->ev_conn, 0));
-    launch_symbols(st4, lane_flags | SYM_EARLY_ONLY);
+    launch_symbols(st4, lane_flags | SYM_EARLY_ONLY | early_fuse);
     launch_symbols(st2, lane_flags | SYM_LATE_ONLY);
-  } else launch_symbols(st2, lane_flags);
+  } else launch_symbols(st2, lane_flags | early_fuse);
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[1], st2));
   HIP_TRY(ctx, hipEventRecord(ctx->ev_join, st2));           // corrections of the late attributes (without the split: of every attribute) are ready
   // attributes whose prediction needs no traversal data (difference, octahedral delta) are finished on this stream,

@@ -1325,7 +1325,33 @@ __device__ __forceinline__ void rans_decode_serial(MeshDesc *D, const uint8_t *s
 typedef uint32_t v32u __attribute__((ext_vector_type(32)));   // largest vector the backend indexes through M0
 #define REG_MAX_SYMS 2048
 
-__global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t flags) {
+// SYM_EARLY_FUSE (option, off by default): the wave that decoded the symbols of an "early" attribute (its prediction needs no
+// traversal data) goes on to predict and dequantise it -- what k_predict / k_predict_wrap / k_finalize of phase 0 do behind the
+// whole symbol launch, which ends 28 ms into a 4096-mesh decode and leaves the octahedral prediction (11 ms) in the tail.  The
+// wave keeps its 80-register slot for that, and measured, the late symbols then end 4.7 ms later for a tail 2.9 ms shorter.
+#define SYM_EARLY_FUSE 0x400u
+__device__ __forceinline__ void predict_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t phase, uint32_t flags);
+__device__ __forceinline__ void predict_wrap_attribute(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t phase, uint32_t flags);
+__device__ __forceinline__ void finalize_attribute(uint8_t *arena, const MeshLayout &L, const MeshDesc *D, uint32_t ai, uint32_t phase, uint32_t flags, uint32_t tid, uint32_t stride);
+__device__ __forceinline__ void early_tail(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t flags) {
+  if (!(flags & SYM_EARLY_FUSE) || D->general) return;
+  const AttrDesc &a = D->att[ai];
+  if (a.have_scheme && a.pred_kind == 1) return;                 // late: waits for the traversal
+  WAIT_VM0();
+  __threadfence_block();
+  __syncthreads();
+  if (status_of(D) != ST_OK) return;
+  predict_wrap_attribute(arena, L, D, ai, 0u, flags);
+  predict_wave(arena, L, D, ai, 0u, flags);
+  WAIT_VM0();
+  __threadfence_block();
+  __syncthreads();
+  if (status_of(D) != ST_OK) return;
+  finalize_attribute(arena, L, D, ai, 0u, flags, lane_id(), WAVE);
+  if (lane_id() == 0) D->att[ai].early_done = 1;
+}
+
+__global__ __launch_bounds__(WAVE, 6) void k_symbols_reg(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t flags) {
   uint32_t mesh = blockIdx.x, ai = blockIdx.y;
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
@@ -1519,6 +1545,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols_reg(uint8_t *arena, const Mesh
     uint32_t v = slot_sym[out[i] & 4095u];
     out[i] = positive ? v : ((v & 1u) ? (uint32_t)(-(int32_t)(v >> 1) - 1) : (v >> 1));
   }
+  early_tail(arena, L, D, ai, flags);
 }
 
 // Launched once per tier so that the LDS footprint of the cumulative table does not cap occupancy:
@@ -1614,17 +1641,13 @@ __device__ __forceinline__ uint32_t addmod(uint32_t a, uint32_t b, uint32_t m) {
 // kernels on their stream; phase 1: parallelogram schemes, after the traversal.
 __device__ __forceinline__ bool wrap_fast_ok(const AttrDesc &a, uint32_t flags);
 __device__ __forceinline__ bool pw_dequant_fused(const AttrDesc &a, uint32_t flags);
-__global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t phase, uint32_t flags) {
-  uint32_t mesh = blockIdx.x, ai = blockIdx.y;
-  if (mesh >= n) return;
-  MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
+// The body of k_predict for one attribute on one wave (also the tail of an entropy-decode wave, see early_tail).
+__device__ __forceinline__ void predict_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t phase, uint32_t flags) {
   const AttrDesc &a = D->att[ai];
   if (!a.have_scheme || a.source == SRC_BYTES) return;
   if (wrap_fast_ok(a, flags)) return;                    // k_predict_wrap
   if (lanes::ln_oct_eligible(a, flags)) return;          // k_predict_oct_lanes
   if ((a.pred_kind == 1) != (phase == 1)) return;
-  const MeshLayout &L = layouts[mesh];
   int32_t *w = (int32_t *)(arena + L.work[ai]);
   const uint32_t nc = a.nc_portable, entries = a.num_entries;
   const uint32_t lane = lane_id();
@@ -1842,6 +1865,15 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
   }
 }
 
+__global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t phase, uint32_t flags) {
+  const uint32_t mesh = blockIdx.x, ai = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
+  if (phase == 0 && D->att[ai].early_done) return;
+  predict_wave(arena, layouts[mesh], D, ai, phase, flags);
+}
+
 // =========================================================================
 // k_predict_wrap: the wrap-transform schemes (Difference / Parallelogram + Wrap) with few components and a range
 // below 2^25 -- every quantised attribute -- on a leaner form of k_predict's step: one instantiation per component
@@ -1970,14 +2002,9 @@ __device__ __forceinline__ void predict_wrap_wave(int32_t *w, const uint32_t *pa
   }
 }
 
-__global__ __launch_bounds__(WAVE) void k_predict_wrap(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t phase, uint32_t flags) {
-  uint32_t mesh = blockIdx.x, ai = blockIdx.y;
-  if (mesh >= n) return;
-  MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
+__device__ __forceinline__ void predict_wrap_attribute(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t phase, uint32_t flags) {
   const AttrDesc &a = D->att[ai];
   if (!wrap_fast_ok(a, flags) || (a.pred_kind == 1) != (phase == 1)) return;
-  const MeshLayout &L = layouts[mesh];
   int32_t *w = (int32_t *)(arena + L.work[ai]);
   const uint32_t *para = (const uint32_t *)(arena + L.para);
   const uint32_t e = a.num_entries, nc = a.nc_portable;
@@ -2000,23 +2027,26 @@ __global__ __launch_bounds__(WAVE) void k_predict_wrap(uint8_t *arena, const Mes
     else predict_wrap_wave<4, false>(w, para, e, mn, mx, out, delta, qmin);
   }
 }
+__global__ __launch_bounds__(WAVE) void k_predict_wrap(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t phase, uint32_t flags) {
+  const uint32_t mesh = blockIdx.x, ai = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
+  if (phase == 0 && D->att[ai].early_done) return;
+  predict_wrap_attribute(arena, layouts[mesh], D, ai, phase, flags);
+}
 
 // =========================================================================
 // k_finalize: portable ints -> attribute values, point->entry maps.
 // =========================================================================
 // phase 0 (symbol stream): attributes whose values are complete once the symbols and a traversal-free scheme are
 // done; phase 1 (main stream, last): parallelogram attributes and everything of the general-path meshes.
-__global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n, uint32_t phase, uint32_t flags) {
-  uint32_t mesh = blockIdx.y, ai = blockIdx.z;
-  if (mesh >= n) return;
-  const MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK || ai >= D->num_attributes) return;
-  const MeshLayout &L = layouts[mesh];
+// One attribute's share of k_finalize for the threads (tid, tid + stride, ...): a 256-thread grid slice, or one wave.
+__device__ __forceinline__ void finalize_attribute(uint8_t *arena, const MeshLayout &L, const MeshDesc *D, uint32_t ai, uint32_t phase, uint32_t flags, uint32_t tid, uint32_t stride) {
   const AttrDesc &a = D->att[ai];
   const bool late = D->general || (a.have_scheme && a.pred_kind == 1);
   if (late != (phase == 1)) return;
   if (!D->general && pw_dequant_fused(a, flags)) return;      // k_predict_wrap wrote the floats
-  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   const int32_t *w = (const int32_t *)(arena + L.work[ai]);
   const uint32_t entries = a.num_entries;
   if (a.seq_type == 2) {            // AttributeQuantizationTransform.cs:179-199, Dequantizer.cs:15-23: two f32 roundings
@@ -2061,6 +2091,14 @@ __global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayo
     const uint32_t total = entries * a.nc * data_type_length(a.data_type);
     for (uint32_t i = tid; i < total; i += stride) out[i] = src[i];
   }
+}
+__global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n, uint32_t phase, uint32_t flags) {
+  const uint32_t mesh = blockIdx.y, ai = blockIdx.z;
+  if (mesh >= n) return;
+  const MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || ai >= D->num_attributes) return;
+  if (phase == 0 && D->att[ai].early_done) return;
+  finalize_attribute(arena, layouts[mesh], D, ai, phase, flags, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 // k_faces: faces as point ids (Mesh.cs:15-69; MeshEdgeBreakerDecoder.cs:537-553,627-637) and the census of linked corners,

@@ -34,7 +34,8 @@ struct AttrDesc {
   uint8_t have_scheme;     // prediction scheme instantiated
   uint8_t precision_bits;  // rANS precision of the symbol (raw) or tag (tagged) stream
   uint8_t q_bits;          // quantisation bits / octahedron bits
-  uint8_t pad0, pad1;
+  uint8_t early_done;      // the symbol wave itself predicted and dequantised the attribute (k_predict / k_finalize of phase 0 skip it)
+  uint8_t pad1;
   uint32_t unique_id;
   uint32_t num_symbols;    // alphabet size
   uint32_t off_table;      // stream offset of the first probability-table byte
