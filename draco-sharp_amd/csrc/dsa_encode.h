@@ -15,8 +15,10 @@
 //                                                                                                       PredictionSchemeWrapEncodingTransform.cs:45-90,
 //                                                                                                       ...NormalOctahedronCanonicalizedEncodingTransform.cs:47-83
 //                              k_enc_rans        rANS coding of every stream, one lane per stream        RAnsEncoder.cs:22-30, AnsEncoder.cs:34-64, SymbolEncoding.cs:92-193
-//   host  (dsa_encode_host.h)  input checks; after the statistics pass: symbol scheme choice + rANS tables (O(alphabet) per
-//                              stream, threads over streams); final stream layout (threads over meshes)
+//                              k_enc_plan        symbol-scheme choice + frequency-table normalisation from the histograms, one lane per
+//                                                stream (dsa_symbol_plan.h, the code the host coder runs)   SymbolEncoding.cs:8-40, RAnsSymbolEncoder.cs:15-123
+//   host  (dsa_encode_host.h)  input checks; at the end the stream layout: bit-packing of the Edgebreaker symbols, table bytes, section order
+//                              (threads over meshes).  DSA_ENC_HOST_PLAN=1: the symbol plans by the host between the two device phases.
 // The result is byte-identical to the CPU coder of dsa_encode_host.h (tests/test_gpu_encode.py), hence decodes
 // bit-exactly to the quantised input.
 #pragma once
@@ -44,6 +46,8 @@ struct EncStream {                 // one per (mesh, attribute); lives in device
   uint32_t hist_tag[33];
   uint32_t method, precision_bits, num_symbols;
   uint32_t rans_len, bits_len;
+  uint64_t plan_order, plan_tmp;   // u32[table_cap] each: scratch of k_enc_plan
+  uint32_t usbl, plan_status;      // raw scheme: unique-symbols bit length; dsa::plan::PLAN_* of k_enc_plan
 };
 
 __device__ __forceinline__ uint32_t enc_msb(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
@@ -228,6 +232,30 @@ __global__ __launch_bounds__(256) void k_enc_corr(uint8_t *arena, EncStream *str
   if (threadIdx.x == 0) { atomicMax(&S.max_value, s_max); atomicAdd(&S.total_bl, s_bl); }
 }
 
+// Symbol-scheme choice and frequency-table normalisation, one lane per stream: dsa_symbol_plan.h, the code the host coder
+// runs, on the histograms k_enc_corr left in device memory.  Sequential per stream (a stable sort and a fix-up loop over the
+// alphabet), thousands of streams side by side; its tables go straight to k_enc_rans, no host in between.
+__global__ __launch_bounds__(WAVE) void k_enc_plan(uint8_t *arena, EncStream *streams, uint32_t ns, int force_scheme, int compression_level) {
+  const uint32_t si = blockIdx.x * WAVE + threadIdx.x;
+  if (si >= ns) return;
+  EncStream &S = streams[si];
+  if (S.overflow) return;
+  if (S.max_value >= S.hist_cap) { S.overflow = 1; return; }
+  const uint32_t *raw = (const uint32_t *)(arena + S.hist_raw);
+  uint32_t *prob = (uint32_t *)(arena + S.prob), *cum = (uint32_t *)(arena + S.cum);
+  uint32_t *order = (uint32_t *)(arena + S.plan_order), *tmp = (uint32_t *)(arena + S.plan_tmp);
+  int method = 1, usbl = 0;
+  int rc = plan::choose_scheme((const uint32_t *)S.hist_tag, raw, S.max_value, (uint64_t)S.nv * S.nc, S.nc, (uint64_t)S.total_bl, force_scheme, compression_level, &method, &usbl);
+  int pb = 12;
+  uint32_t nsym = 0;
+  if (rc == plan::PLAN_OK)
+    rc = method == 0 ? plan::rans_tables(5, (const uint32_t *)S.hist_tag, (size_t)33, prob, cum, order, tmp, &pb, &nsym)
+                     : plan::rans_tables(usbl, raw, (size_t)S.max_value + 1, prob, cum, order, tmp, &pb, &nsym);
+  S.plan_status = (uint32_t)rc;
+  if (rc != plan::PLAN_OK) { S.overflow = 1; return; }
+  S.method = (uint32_t)method; S.usbl = (uint32_t)usbl; S.precision_bits = (uint32_t)pb; S.num_symbols = nsym;
+}
+
 // rANS coding, one lane per stream (no cross-lane traffic; the wave shares the instruction stream).
 // Symbols are fed last -> first (SymbolEncoding.cs:177-183); bytes are written in coding order, the decoder reads
 // them from the end (RAnsEncoder.cs:22-30, AnsEncoder.cs:34-64).
@@ -355,7 +383,9 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     t_last = now;
   };
   // DSA_ENC_HOST_CONN=1 (diagnostics): connectivity by the host coder, as before k_enc_connectivity existed
-  const bool host_conn = getenv("DSA_ENC_HOST_CONN") != nullptr;           // read per call: the tests compare the two paths
+  const bool host_conn = getenv("DSA_ENC_HOST_CONN") != nullptr;
+  // DSA_ENC_HOST_PLAN=1 (diagnostics): symbol-scheme choice and table normalisation by the host between the two device phases
+  const bool host_plan = getenv("DSA_ENC_HOST_PLAN") != nullptr;           // read per call: the tests compare the two paths
   auto plan_one = [&](uint32_t i) {
     const dsa_mesh_input &m = meshes[i];
     synth::MeshIn &in = ins[i];
@@ -434,6 +464,7 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
       S.out_rans = take(S.out_cap); S.out_bits = take(S.out_cap);
       const uint64_t table_cap = std::max<uint64_t>(S.hist_cap, 64);   // the tagged scheme's alphabet is 33 bit lengths
       S.prob = take(4ull * table_cap); S.cum = take(4ull * table_cap);
+      S.plan_order = take(4ull * table_cap); S.plan_tmp = take(4ull * table_cap);
       hs.push_back(S);
     }
   }
@@ -499,6 +530,10 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     hipLaunchKernelGGL(dsa::k_enc_quantize, dim3(gx, ns), dim3(256), 0, st, arena, d_streams, ns);
     hipLaunchKernelGGL(dsa::k_enc_gather, dim3(ns), dim3(256), 0, st, arena, d_streams, ns);
     hipLaunchKernelGGL(dsa::k_enc_corr, dim3(gx, ns), dim3(256), 0, st, arena, d_streams, ns);
+    if (!host_plan) {       // device phase 2 follows at once: tables by k_enc_plan, no host round trip
+      hipLaunchKernelGGL(dsa::k_enc_plan, dim3((ns + WAVE - 1) / WAVE), dim3(WAVE), 0, st, arena, d_streams, ns, (int)opt.force_scheme, (int)opt.compression_level);
+      hipLaunchKernelGGL(dsa::k_enc_rans, dim3((ns + WAVE - 1) / WAVE), dim3(WAVE), 0, st, arena, d_streams, ns);
+    }
     ENC_TRY(hipMemcpyAsync(hs.data(), d_streams, sizeof(dsa::EncStream) * ns, hipMemcpyDeviceToHost, st));
     if (!host_conn) ENC_TRY(hipMemcpyAsync(hc.data(), d_conns, sizeof(dsa::EncConn) * n, hipMemcpyDeviceToHost, st));
     ENC_TRY(hipStreamSynchronize(st));
@@ -537,6 +572,9 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
   // ---- host phase 2: scheme choice and rANS tables from the device statistics
   std::vector<synth::SymbolPlan> splans(ns);
   std::vector<std::vector<uint32_t>> hists(ns);
+  std::vector<int> stream_mesh(ns, 0);
+  for (uint32_t i = 0; i < n; ++i) for (uint32_t s = first_stream[i]; s < first_stream[i + 1]; ++s) stream_mesh[s] = (int)i;
+  if (host_plan) {
   {
     std::vector<dsa::PackItem> items;
     for (uint32_t s = 0; s < ns; ++s) {
@@ -550,8 +588,6 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
       memcpy(hists[it.pad].data(), host.data() + it.packed_off, it.len);
     }
   }
-  std::vector<int> stream_mesh(ns, 0);
-  for (uint32_t i = 0; i < n; ++i) for (uint32_t s = first_stream[i]; s < first_stream[i + 1]; ++s) stream_mesh[s] = (int)i;
   std::vector<std::string> plan_error(ns);
   auto plan_stream = [&](uint32_t s) {
     const uint32_t i = (uint32_t)stream_mesh[s];
@@ -592,27 +628,48 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     }
     ENC_ST(scatter(items, host));
   }
+  } else {
+    for (uint32_t s = 0; s < ns; ++s) {
+      const uint32_t i = (uint32_t)stream_mesh[s];
+      if (E->status[i] != DSA_OK || !hs[s].overflow) continue;
+      E->status[i] = DSA_ERR_INVALID_DATA;
+      E->messages[i] = hs[s].plan_status ? dsa::plan::plan_message((int)hs[s].plan_status) : "symbol outside the histogram range";
+    }
+  }
   lap("histograms + symbol plans");
   // ---- device phase 2: entropy coding
   std::vector<std::vector<uint8_t>> rans(ns), bits(ns);
   if (ns) {
     hipStream_t st = ctx->stream;
-    ENC_TRY(hipMemcpyAsync(d_streams, hs.data(), sizeof(dsa::EncStream) * ns, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(dsa::k_enc_rans, dim3((ns + WAVE - 1) / WAVE), dim3(WAVE), 0, st, arena, d_streams, ns);
-    ENC_TRY(hipMemcpyAsync(hs.data(), d_streams, sizeof(dsa::EncStream) * ns, hipMemcpyDeviceToHost, st));
-    ENC_TRY(hipStreamSynchronize(st));
+    if (host_plan) {
+      ENC_TRY(hipMemcpyAsync(d_streams, hs.data(), sizeof(dsa::EncStream) * ns, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(dsa::k_enc_rans, dim3((ns + WAVE - 1) / WAVE), dim3(WAVE), 0, st, arena, d_streams, ns);
+      ENC_TRY(hipMemcpyAsync(hs.data(), d_streams, sizeof(dsa::EncStream) * ns, hipMemcpyDeviceToHost, st));
+      ENC_TRY(hipStreamSynchronize(st));
+    }
+    // coded bytes of every stream (and, when k_enc_plan made them, the probability tables: the stream carries them)
     std::vector<dsa::PackItem> items;
     for (uint32_t s = 0; s < ns; ++s) {
-      if (hs[s].overflow) continue;
+      if (hs[s].overflow || E->status[stream_mesh[s]] != DSA_OK) continue;
       items.push_back({hs[s].out_rans, 0, hs[s].rans_len, s});
       items.push_back({hs[s].out_bits, 0, hs[s].bits_len, s});
+      items.push_back({hs[s].prob, 0, host_plan ? 0u : 4u * hs[s].num_symbols, s});
     }
     std::vector<uint8_t> host;
     ENC_ST(gather(items, host));
-    for (size_t k = 0; k + 1 < items.size(); k += 2) {
+    for (size_t k = 0; k + 2 < items.size(); k += 3) {
       const uint32_t s = items[k].pad;
       rans[s].assign(host.begin() + (ptrdiff_t)items[k].packed_off, host.begin() + (ptrdiff_t)(items[k].packed_off + items[k].len));
       bits[s].assign(host.begin() + (ptrdiff_t)items[k + 1].packed_off, host.begin() + (ptrdiff_t)(items[k + 1].packed_off + items[k + 1].len));
+      if (!host_plan) {                      // the bytes in front of the payload: scheme, (raw: unique-symbols bit length), table
+        synth::SymbolPlan &pl = splans[s];
+        pl.method = (int)hs[s].method;
+        pl.coder.num_symbols = hs[s].num_symbols;
+        pl.coder.prob.assign((const uint32_t *)(host.data() + items[k + 2].packed_off), (const uint32_t *)(host.data() + items[k + 2].packed_off) + hs[s].num_symbols);
+        pl.head.u8((uint8_t)pl.method);
+        if (pl.method != 0) pl.head.u8((uint8_t)hs[s].usbl);
+        pl.coder.write_table(pl.head);
+      }
     }
   }
 #undef ENC_TRY

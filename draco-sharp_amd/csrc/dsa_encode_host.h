@@ -30,6 +30,8 @@
 #include <thread>
 #include <vector>
 
+#include "dsa_symbol_plan.h"
+
 namespace synth {
 
 static const uint32_t kInvalid = 0xFFFFFFFFu;
@@ -101,52 +103,18 @@ struct RansEncoder {
   uint32_t num_symbols = 0;
   // RAnsSymbolEncoder.cs:15-123 (normalisation) + :125-164 (table bytes, E-3 corrected)
   void create(ByteWriter &w, int max_bit_length, const std::vector<uint64_t> &freq) {
-    int p = (3 * max_bit_length) / 2;
-    precision_bits = p < 12 ? 12 : (p > 20 ? 20 : p);
+    prob.assign(freq.size() ? freq.size() : 1, 0);
+    cum.assign(prob.size(), 0);
+    std::vector<uint32_t> order(prob.size()), tmp(prob.size());
+    const int rc = dsa::plan::rans_tables(max_bit_length, freq.data(), freq.size(), prob.data(), cum.data(), order.data(), tmp.data(), &precision_bits, &num_symbols);
+    check(rc == dsa::plan::PLAN_OK, dsa::plan::plan_message(rc));
+    prob.resize(num_symbols); cum.resize(num_symbols);
     precision = 1u << precision_bits;
     l_base = precision * 4;
-    uint64_t total = 0;
-    int max_valid = 0;
-    for (size_t i = 0; i < freq.size(); ++i) { total += freq[i]; if (freq[i]) max_valid = (int)i; }
-    num_symbols = (uint32_t)max_valid + 1;
-    prob.assign(num_symbols, 0);
-    double total_d = (double)total, prec_d = (double)precision;
-    int64_t total_prob = 0;
-    for (uint32_t i = 0; i < num_symbols; ++i) {
-      double pr = (double)freq[i] / total_d;
-      uint32_t rp = (uint32_t)(pr * prec_d + 0.5);
-      if (rp == 0 && freq[i] > 0) rp = 1;
-      prob[i] = rp;
-      total_prob += rp;
-    }
-    if (total_prob != (int64_t)precision) {
-      std::vector<int> order(num_symbols);
-      for (uint32_t i = 0; i < num_symbols; ++i) order[i] = (int)i;
-      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return prob[a] < prob[b]; });
-      if (total_prob < (int64_t)precision) {
-        prob[order.back()] += (uint32_t)(precision - total_prob);
-      } else {
-        int64_t error = total_prob - precision;
-        while (error > 0) {
-          double rel = prec_d / (double)total_prob;
-          for (int j = (int)num_symbols - 1; j >= 0; --j) {
-            int sid = order[j];
-            if (prob[sid] <= 1) { check(j != (int)num_symbols - 1, "most frequent symbol would be empty"); break; }
-            int32_t np = (int32_t)std::floor(rel * (double)prob[sid]);
-            int32_t fix = (int32_t)prob[sid] - np;
-            if (fix == 0) fix = 1;
-            if (fix >= (int32_t)prob[sid]) fix = (int32_t)prob[sid] - 1;
-            if (fix > error) fix = (int32_t)error;
-            prob[sid] -= fix; total_prob -= fix; error -= fix;
-            if (total_prob == (int64_t)precision) break;
-          }
-        }
-      }
-    }
-    cum.assign(num_symbols, 0);
-    uint32_t c = 0;
-    for (uint32_t i = 0; i < num_symbols; ++i) { cum[i] = c; c += prob[i]; }
-    check(c == precision, "probabilities do not sum to the precision");
+    write_table(w);
+  }
+  // RAnsSymbolEncoder.cs:125-164 (E-3 corrected): the probability table as the stream carries it
+  void write_table(ByteWriter &w) const {
     w.varint(num_symbols);
     for (uint32_t i = 0; i < num_symbols; ++i) {
       uint32_t pr = prob[i];
@@ -214,18 +182,6 @@ static void symbol_stats(const std::vector<uint32_t> &v, int nc, SymbolStats &st
   for (uint32_t x : v) ++st.raw_freq[x];
   if (bit_lengths_out) bit_lengths_out->swap(bl);
 }
-static int64_t shannon_bits(const std::vector<uint64_t> &f, size_t n, int *num_unique) {
-  double bits = 0, nd = (double)n;
-  int u = 0;
-  for (size_t i = 0; i < f.size(); ++i) if (f[i] > 0) { ++u; bits += (double)f[i] * std::log2((double)f[i] / nd); }
-  *num_unique = u;
-  return (int64_t)(-bits);
-}
-static int64_t approx_table_bits(int max_value, int num_unique) {   // RAnsSymbolCoding.cs:29-41
-  int64_t zero_bits = 8 * ((int64_t)num_unique + (max_value - num_unique) / 64);
-  return 8 * (int64_t)num_unique + zero_bits;
-}
-
 // SymbolEncoding.cs:8-40 (E-2 corrected): scheme choice, then the coder's tables.  `head` receives the bytes that
 // precede the rANS payload: scheme byte, (raw: unique-symbols bit length), probability table.
 struct SymbolPlan {
@@ -234,25 +190,14 @@ struct SymbolPlan {
   ByteWriter head;
 };
 static void plan_symbols(const SymbolStats &st, int force_scheme, int compression_level, SymbolPlan &pl) {
-  int nu_tag = 0;
-  const int64_t tag_bits = shannon_bits(st.tag_freq, st.n / st.nc, &nu_tag);
-  const int64_t tagged_total = tag_bits + approx_table_bits(nu_tag, nu_tag) + (int64_t)st.total_bl * st.nc;
-  int nu_raw = 0;
-  const int64_t raw_total = shannon_bits(st.raw_freq, st.n, &nu_raw) + approx_table_bits((int)st.max_value, nu_raw);
-  const int max_value_bl = msb(std::max(1u, st.max_value)) + 1;
-  pl.method = force_scheme;
-  if (pl.method < 0) pl.method = (tagged_total < raw_total || max_value_bl > 18) ? 0 : 1;
+  int usbl = 0;
+  const int rc = dsa::plan::choose_scheme(st.tag_freq.data(), st.raw_freq.data(), st.max_value, (uint64_t)st.n, (uint32_t)st.nc, st.total_bl,
+                                          force_scheme, compression_level, &pl.method, &usbl);
+  check(rc == dsa::plan::PLAN_OK, dsa::plan::plan_message(rc));
   pl.head.u8((uint8_t)pl.method);
   if (pl.method == 0) {
     pl.coder.create(pl.head, 5, st.tag_freq);
   } else {
-    int usbl = (nu_raw > 0 ? msb((uint32_t)nu_raw) : 0) + 1;
-    check(usbl <= 18, "more than 2^18 unique symbols");
-    if (compression_level < 4) usbl -= 2;
-    else if (compression_level < 6) usbl -= 1;
-    else if (compression_level > 9) usbl += 2;
-    else if (compression_level > 7) usbl += 1;
-    usbl = std::min(std::max(1, usbl), 18);
     pl.head.u8((uint8_t)usbl);
     pl.coder.create(pl.head, usbl, st.raw_freq);
   }

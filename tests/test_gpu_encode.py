@@ -136,6 +136,7 @@ def test_device_connectivity_equals_host_connectivity(ctx, monkeypatch):
         return ok, verdicts
 
     monkeypatch.delenv("DSA_ENC_HOST_CONN", raising=False)
+    monkeypatch.delenv("DSA_ENC_HOST_PLAN", raising=False)
     dev, dev_verdicts = run()
     monkeypatch.setenv("DSA_ENC_HOST_CONN", "1")
     host, host_verdicts = run()
@@ -143,3 +144,24 @@ def test_device_connectivity_equals_host_connectivity(ctx, monkeypatch):
     for d, h in zip(dev, host):
         assert d == h
     assert dev_verdicts == host_verdicts and "coded" not in dev_verdicts
+
+
+def test_device_symbol_plan_equals_host_symbol_plan(ctx, monkeypatch):
+    """k_enc_plan (scheme choice + table normalisation on the device, dsa_symbol_plan.h one lane per stream) against the
+    same code run by the host between the two device phases (DSA_ENC_HOST_PLAN=1), and both against the CPU coder:
+    forced and chosen schemes, every compression level's precision rule, coarse and fine quantisation."""
+    enc = dsa.DracoEncoder(ctx)
+    cfgs = [dsa.Config(), dsa.Config(symbol_scheme=0), dsa.Config(symbol_scheme=1), dsa.Config(speed=0), dsa.Config(speed=2), dsa.Config(speed=7),
+            dsa.Config(speed=10), dsa.Config(position_bits=3, texcoord_bits=2, normal_bits=3), dsa.Config(position_bits=18, texcoord_bits=16, normal_bits=12)]
+    group = []
+    for k, (kind, nx, ny) in enumerate(((synth.GRID, 24, 20), (synth.TORUS, 16, 12), (synth.HOLES, 20, 16), (synth.GRID, 128, 256))):
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 9 + k)
+        group.append((pos, faces, nrm, uv))
+    for cfg in cfgs:
+        monkeypatch.delenv("DSA_ENC_HOST_PLAN", raising=False)
+        dev = enc.EncodeBatch([dsa.MeshData(*m) for m in group], cfg)
+        monkeypatch.setenv("DSA_ENC_HOST_PLAN", "1")
+        host = enc.EncodeBatch([dsa.MeshData(*m) for m in group], cfg)
+        for (p, f, n, u), d, h in zip(group, dev, host):
+            assert d == h
+            assert d == cpu_stream(p, f, n, u, cfg)
