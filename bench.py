@@ -76,7 +76,7 @@ def measured_traffic(kernel, meshes, triangles):
     return None, None, None
 
 
-def encode_leg(dsa, synth, ctx, nx, ny, count):
+def encode_leg(dsa, synth, ctx, nx, ny, count, comm=None, barrier=None, world=1):
     """BASELINE.json configs[4] in the same line: `count` raw 64k-triangle meshes -> .drc through dsa_encode_batch
     (corner table, Edgebreaker symbols and traversal order by k_enc_connectivity, quantise + predict + rANS code by the
     attribute kernels, symbol-scheme choice and stream layout on the host cores), decoded again and compared.  The batch
@@ -88,16 +88,21 @@ def encode_leg(dsa, synth, ctx, nx, ny, count):
         meshes.append(dsa.MeshData(pos, faces, nrm, uv))
     enc = dsa.DracoEncoder(ctx)
     enc.EncodeBatch(meshes[:2])
+    if barrier is not None:
+        barrier()
     t0 = time.perf_counter()
     out = enc.EncodeBatch(meshes)
     dt = time.perf_counter() - t0
+    if comm is not None:                     # every rank codes `count` meshes of its own (weak): the job's time is the slowest rank's
+        dt = comm.max(dt)
     checks = [synth.encode_mesh(*(lambda m: (m[0], m[3], m[1], m[2]))(distinct[k])) for k in range(min(4, len(distinct)))]
     identical = all(out[k] == checks[k] for k in range(len(checks)))
     b = dsa.Batch(ctx, out)
     b.decode()
     ok = identical and all(b.status(i) == 0 for i in range(count))
     b.close()
-    return {"meshes_per_s": count / dt, "ms": dt * 1e3, "meshes": count, "bytes_per_mesh": sum(map(len, out)) // count,
+    ok = ok if comm is None else comm.sum(0 if ok else 1) == 0
+    return {"meshes_per_s": world * count / dt, "ms": dt * 1e3, "meshes": world * count, "meshes_per_gpu": count, "n_gpus": world, "bytes_per_mesh": sum(map(len, out)) // count,
             "config": "%d x %d-triangle meshes, positions 11b + normals 8b + UVs 10b, end to end (device Edgebreaker + HIP attribute kernels, host stream layout)" % (count, 2 * nx * ny),
             "round_trip_ok": bool(ok), "byte_identical_to_cpu_coder": bool(identical)}
 
@@ -294,6 +299,9 @@ def main():
                       "meshes_per_gpu": shard_sizes, "assignment": "sharding.balanced_assignment (longest compressed stream first)",
                       "gb_per_s": alg_bytes_all / step_s / 1e9, "stage_ms_rank0": stages, "generate_s": t_gen_s}
         batch.close()
+    encode = None
+    if not args.no_encode:                                           # every rank: the leg's clock is the slowest rank's
+        encode = encode_leg(dsa, synth, ctx, nx, ny, 1024, comm if world > 1 else None, barrier if world > 1 else None, world)
     if rank == 0:
         if out is None:                                              # --scaling strong: the strong leg is the line
             out = {"metric": "decoded_meshes_per_sec", "value": strong["value"], "unit": "meshes/s", "n_gpus": world, "steps": args.steps,
@@ -308,8 +316,8 @@ def main():
         elif world == 1:
             out["strong_scaling"] = {"value": out["value"], "unit": "meshes/s", "ms_per_step": out["ms_per_step"], "meshes_in_job": args.meshes,
                                      "meshes_per_gpu": [args.meshes], "note": "one GPU: the strong and the weak partition are the same batch"}
-        if world == 1 and not args.no_encode:
-            out["encode"] = encode_leg(dsa, synth, ctx, nx, ny, 1024)
+        if encode is not None:
+            out["encode"] = encode
         if world == 1 and not args.no_cpu_baseline and weak_blob is not None:
             out["cpu_baseline"] = cpu_baseline(weak_blob, weak_offsets, 1, 10.0, 1024)
             out["cpu_baseline_all_cores"] = cpu_baseline(weak_blob, weak_offsets, min(host_cores, 32), 10.0, 4096)
