@@ -97,13 +97,27 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
   ec_sync();
   for (uint32_t c = lane; c < NC; c += WAVE) vlist[atomicAdd(&vcur[c2v[c]], 1u)] = c;
   ec_sync();
-  // ---- opposites: corner c faces the edge next(c) -> prev(c) = a -> b; its opposite is the corner facing b -> a, i.e.
-  // prev(k) of the corner k at b whose next is a.  The same directed edge twice is a non-manifold edge.
+  // ---- opposites: corner c faces the edge next(c) -> prev(c) = a -> b; its opposite is the corner facing b -> a.  That face has a
+  // corner k at b whose next is a (opposite: prev(k)) and a corner k' at a whose previous is b (opposite: next(k')): the shorter of
+  // the two vertex lists is searched, so that a vertex of huge valence (the apex of a cone) costs its neighbours nothing.  The same
+  // directed edge twice is a non-manifold edge.
   for (uint32_t c = lane; c < NC; c += WAVE) {
     const uint32_t a = c2v[ec_next(c)], b = c2v[ec_prev(c)];
+    const uint32_t na = voff[a + 1] - voff[a], nb = voff[b + 1] - voff[b];
     uint32_t found = DSA_INVALID, same = 0;
-    for (uint32_t i = voff[b]; i < voff[b + 1]; ++i) { const uint32_t k = vlist[i]; if (c2v[ec_next(k)] == a) found = ec_prev(k); }
-    for (uint32_t i = voff[a]; i < voff[a + 1]; ++i) { const uint32_t k = vlist[i]; if (c2v[ec_next(k)] == b) ++same; }
+    if (nb <= na) {
+      for (uint32_t i = voff[b]; i < voff[b + 1]; ++i) {
+        const uint32_t k = vlist[i];
+        if (c2v[ec_next(k)] == a) found = ec_prev(k);          // face (b, a, .): reverse edge
+        if (c2v[ec_prev(k)] == a) ++same;                      // face (a, b, .) seen from its corner at b: the edge itself
+      }
+    } else {
+      for (uint32_t i = voff[a]; i < voff[a + 1]; ++i) {
+        const uint32_t k = vlist[i];
+        if (c2v[ec_prev(k)] == b) found = ec_next(k);          // face (b, a, .) seen from its corner at a
+        if (c2v[ec_next(k)] == b) ++same;                      // face (a, b, .): the edge itself
+      }
+    }
     if (same != 1) ec_fail(E, ENC_NONMANIFOLD_EDGE, c);
     opp[c] = found;
   }

@@ -165,3 +165,17 @@ def test_device_symbol_plan_equals_host_symbol_plan(ctx, monkeypatch):
         for (p, f, n, u), d, h in zip(group, dev, host):
             assert d == h
             assert d == cpu_stream(p, f, n, u, cfg)
+
+
+def test_vertex_of_huge_valence(ctx):
+    """A cone: 20 000 faces around one apex.  The device corner table searches the shorter of an edge's two vertex lists, so the
+    apex costs its neighbours nothing; the stream equals the CPU coder's."""
+    n = 20000
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    pos = np.concatenate([[[0, 0, 1]], np.stack([np.cos(ang), np.sin(ang), np.zeros(n)], 1)]).astype(np.float32)
+    faces = np.stack([np.zeros(n, np.uint32), 1 + np.arange(n, dtype=np.uint32), 1 + (np.arange(n, dtype=np.uint32) + 1) % n], 1)
+    enc = dsa.DracoEncoder(ctx)
+    got = enc.EncodeBatch([dsa.MeshData(pos, faces)])[0]
+    assert got == synth.encode_mesh(pos, faces, None, None)
+    ref = oracle.decode(got)
+    assert ref.num_faces == n
