@@ -382,10 +382,12 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     fprintf(stderr, "[dsa_encode_batch] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now;
   };
-  // DSA_ENC_HOST_CONN=1 (diagnostics): connectivity by the host coder, as before k_enc_connectivity existed
-  const bool host_conn = getenv("DSA_ENC_HOST_CONN") != nullptr;
-  // DSA_ENC_HOST_PLAN=1 (diagnostics): symbol-scheme choice and table normalisation by the host between the two device phases
-  const bool host_plan = getenv("DSA_ENC_HOST_PLAN") != nullptr;           // read per call: the tests compare the two paths
+  // Both device stages are the serial algorithms on one lane per mesh / per stream: a batch takes 150 - 250 ms (connectivity) and
+  // about 40 ms (plans) whatever its size, which the host threads beat on a small batch (measured: 64 meshes 84 ms on the host, 128 meshes 252 ms on the device).  Below 256 meshes the host does both
+  // (DSA_ENC_HOST_CONN / DSA_ENC_HOST_PLAN = 1 or 0 force one or the other; read per call: the tests compare the paths).
+  auto choice = [&](const char *name) { const char *e = getenv(name); return e ? atoi(e) != 0 : n < 256; };
+  const bool host_conn = choice("DSA_ENC_HOST_CONN");
+  const bool host_plan = choice("DSA_ENC_HOST_PLAN");
   auto plan_one = [&](uint32_t i) {
     const dsa_mesh_input &m = meshes[i];
     synth::MeshIn &in = ins[i];

@@ -135,8 +135,8 @@ def test_device_connectivity_equals_host_connectivity(ctx, monkeypatch):
                 verdicts.append(type(e).__name__)
         return ok, verdicts
 
-    monkeypatch.delenv("DSA_ENC_HOST_CONN", raising=False)
-    monkeypatch.delenv("DSA_ENC_HOST_PLAN", raising=False)
+    monkeypatch.setenv("DSA_ENC_HOST_CONN", "0")            # unset, a batch this small would take the host path
+    monkeypatch.setenv("DSA_ENC_HOST_PLAN", "0")
     dev, dev_verdicts = run()
     monkeypatch.setenv("DSA_ENC_HOST_CONN", "1")
     host, host_verdicts = run()
@@ -158,7 +158,8 @@ def test_device_symbol_plan_equals_host_symbol_plan(ctx, monkeypatch):
         pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 9 + k)
         group.append((pos, faces, nrm, uv))
     for cfg in cfgs:
-        monkeypatch.delenv("DSA_ENC_HOST_PLAN", raising=False)
+        monkeypatch.setenv("DSA_ENC_HOST_PLAN", "0")
+        monkeypatch.setenv("DSA_ENC_HOST_CONN", "0")
         dev = enc.EncodeBatch([dsa.MeshData(*m) for m in group], cfg)
         monkeypatch.setenv("DSA_ENC_HOST_PLAN", "1")
         host = enc.EncodeBatch([dsa.MeshData(*m) for m in group], cfg)
@@ -167,7 +168,7 @@ def test_device_symbol_plan_equals_host_symbol_plan(ctx, monkeypatch):
             assert d == cpu_stream(p, f, n, u, cfg)
 
 
-def test_vertex_of_huge_valence(ctx):
+def test_vertex_of_huge_valence(ctx, monkeypatch):
     """A cone: 20 000 faces around one apex.  The device corner table searches the shorter of an edge's two vertex lists, so the
     apex costs its neighbours nothing; the stream equals the CPU coder's."""
     n = 20000
@@ -175,6 +176,8 @@ def test_vertex_of_huge_valence(ctx):
     pos = np.concatenate([[[0, 0, 1]], np.stack([np.cos(ang), np.sin(ang), np.zeros(n)], 1)]).astype(np.float32)
     faces = np.stack([np.zeros(n, np.uint32), 1 + np.arange(n, dtype=np.uint32), 1 + (np.arange(n, dtype=np.uint32) + 1) % n], 1)
     enc = dsa.DracoEncoder(ctx)
+    monkeypatch.setenv("DSA_ENC_HOST_CONN", "0")
+    monkeypatch.setenv("DSA_ENC_HOST_PLAN", "0")
     got = enc.EncodeBatch([dsa.MeshData(pos, faces)])[0]
     assert got == synth.encode_mesh(pos, faces, None, None)
     ref = oracle.decode(got)
