@@ -113,8 +113,8 @@ __global__ __launch_bounds__(WAVE, 4) void k_locate(uint8_t *arena, const MeshLa
 // "corner already has an opposite" is checked after the loop by a lane-parallel symmetry pass.
 // Rare events (S, topology splits, start faces, vertex compaction) sync everything to global memory and
 // run there on lane 0.
-#define CN_REC_BLOCKS 16     // 16 blocks x 64 records x 8 B = 8 KB of LDS, write-back
-#define CN_STAGE 32          // faces per staging block (LDS per wave stays under 10 KB: 16 waves per CU)
+#define CN_REC_BLOCKS 8      // 8 blocks x 64 records x 8 B = 4 KB of LDS, write-back (16 blocks measured no faster; the LDS is worth more to the symbol tiers beside)
+#define CN_STAGE 32          // faces per staging block (LDS per wave: 1 KB stage + 4 KB records + 256 B window = 5.4 KB)
 #define CN_WIN 64            // dwords of symbol bits per window
 
 #define CN_LDS_WORDS (CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2 + CN_WIN)
