@@ -378,8 +378,12 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   static const bool sym_split = !serial && !(lane_flags & (LN_FLAG_SYMBOLS | LN_FLAG_PREDICT)) &&
                                 !(getenv("DSA_SYM_SPLIT") && atoi(getenv("DSA_SYM_SPLIT")) == 0);
   hipStream_t st4 = sym_split ? ctx->stream4 : st2;
+  // k_symbols_wide (raw streams of any precision with a search table of <= 2048 entries, in registers) unless DSA_SYM_WIDE=0
+  static const uint32_t wide_flag = (getenv("DSA_SYM_WIDE") && atoi(getenv("DSA_SYM_WIDE")) == 0) ? 0u : SYM_WIDE;
   auto launch_symbols = [&](hipStream_t s, uint32_t fl) {
+    fl |= wide_flag;
     hipLaunchKernelGGL(dsa::k_symbols_reg, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
+    if (wide_flag) hipLaunchKernelGGL(dsa::k_symbols_wide, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
     hipLaunchKernelGGL(dsa::k_symbols<1>, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
     hipLaunchKernelGGL(dsa::k_symbols<0>, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
     hipLaunchKernelGGL(dsa::k_symbols<2>, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);

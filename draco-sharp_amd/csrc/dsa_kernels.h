@@ -40,6 +40,7 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uin
 // The symbol kernels are launched twice when the batch is decoded on four streams: once for the attributes whose prediction
 // waits for the traversal (parallelogram: "late") and once, on a stream of higher priority that goes on to predict and
 // dequantise them, for those whose prediction does not ("early": difference, octahedral delta, none).
+#define SYM_WIDE 0x800u        // k_symbols_wide is part of the launch set (DSA_SYM_WIDE=0: its streams stay with the LDS tiers)
 #define SYM_EARLY_ONLY 0x100u
 #define SYM_LATE_ONLY 0x200u
 __device__ __forceinline__ bool sym_filtered(const AttrDesc &a, uint32_t flags) {
@@ -1551,6 +1552,141 @@ __global__ __launch_bounds__(WAVE, 6) void k_symbols_reg(uint8_t *arena, const M
 // Launched once per tier so that the LDS footprint of the cumulative table does not cap occupancy:
 //   TIER 0: alphabets <= 64 (table in one register per lane) + tagged / fixed-width sources
 //   TIER 1: alphabets <= 960      TIER 2: alphabets <= SYM_MAX_LDS and the large-alphabet fallback
+// Which raw streams k_symbols_reg takes (12-bit precision, 64 < alphabet <= 2048, table scratch in the attribute's output region).
+__device__ __forceinline__ bool sym_reg_eligible(const AttrDesc &a, const MeshLayout &L, uint32_t ai) {
+  return a.source == SRC_RAW && a.precision_bits == 12 && a.num_symbols > 64 && a.num_symbols <= REG_MAX_SYMS && a.num_distinct > 1 &&
+         L.out_cap[ai] >= 4096 * 6 + REG_MAX_SYMS * 4;
+}
+// Which raw streams k_symbols_wide takes: any precision, at most 2048 symbols to search -- those of the alphabet, or, for a sparse
+// large alphabet (14-bit positions: 16 384 ids, about 2 000 used), its non-zero ones -- and room for the tables in global memory.
+__device__ __forceinline__ bool sym_wide_eligible(const AttrDesc &a, const MeshLayout &L, uint32_t ai) {
+  if (a.source != SRC_RAW || a.num_distinct <= 1 || sym_reg_eligible(a, L, ai)) return false;
+  const bool compact = a.num_symbols > SYM_MAX_LDS;
+  const uint32_t nse = compact ? a.num_distinct : a.num_symbols;
+  if (nse <= 64 || nse > REG_MAX_SYMS) return false;
+  return compact ? (a.table != 0 && 2ull * nse + 1 <= (unsigned long long)a.num_symbols + 2) : (L.out_cap[ai] >= 4ull * (nse + 1));
+}
+
+// =========================================================================
+// k_symbols_wide: rANS decode of raw streams of any precision whose search table (<= 2048 cumulative frequencies) fits the
+// register file: 32 VGPRs hold it, block b of 64 entries in register b, fetched by a uniform index (v_movrels) where k_symbols<2>
+// reads LDS.  No LDS at all -- beside the chain waves a CU has little -- and no LDS round trip in the chain of a symbol.  The
+// 15-bit-precision streams of 14-bit positions go here (compacted to their non-zero symbols), RAnsDecoder.cs:56-99.
+// =========================================================================
+__global__ __launch_bounds__(WAVE) void k_symbols_wide(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t flags) {
+  const uint32_t mesh = blockIdx.x, ai = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
+  const MeshLayout &L = layouts[mesh];
+  const AttrDesc &a = D->att[ai];
+  if (a.source == SRC_BYTES) return;
+  if (lanes::ln_sym_eligible(a, L, ai, flags)) return;
+  if (sym_filtered(a, flags)) return;
+  if (!sym_wide_eligible(a, L, ai)) return;
+  const uint32_t lane = lane_id();
+  const uint32_t num_values = a.num_entries * a.nc_portable;
+  if (num_values == 0) return;
+  const uint8_t *stream = arena + L.stream;
+  const uint32_t stream_len = L.stream_len;
+  uint32_t *out = (uint32_t *)(arena + L.work[ai]);
+  const bool compact = a.num_symbols > SYM_MAX_LDS;
+  const uint32_t nsym = compact ? a.num_distinct : a.num_symbols;
+  uint32_t *symtab = compact ? (uint32_t *)(arena + a.table) : nullptr;
+  uint32_t *gtab = compact ? symtab + nsym : (uint32_t *)(arena + L.out[ai]);          // nsym + 1 entries
+  const uint32_t P = a.precision_bits, precision = 1u << P, l_base = precision * 4;
+  // 1. probability table -> global scratch (lane 0), keeping the non-zero entries of a sparse alphabet (RAnsSymbolDecoder.cs:21-48)
+  if (lane == 0) {
+    Rd r(stream, stream_len, a.off_table);
+    uint32_t k = 0;
+    bool ok = true;
+    for (uint32_t i = 0; i < a.num_symbols && ok; ++i) {
+      const uint32_t pd = r.u8(), token = pd & 3u;
+      if (token == 3u) {
+        const uint32_t offset = pd >> 2;
+        if (i + offset >= a.num_symbols) ok = false;
+        if (!compact) for (uint32_t j = 0; j <= offset && i + j < a.num_symbols; ++j) gtab[i + j] = 0;
+        i += offset;
+      } else {
+        uint32_t pr = pd >> 2;
+        for (uint32_t j = 0; j < token; ++j) pr |= r.u8() << (8 * (j + 1) - 2);
+        if (compact) { if (pr) { if (k >= nsym) ok = false; else { gtab[k] = pr; symtab[k] = i; ++k; } } }
+        else gtab[i] = pr;
+      }
+    }
+    if (!ok || !r.ok || (compact && k != nsym)) fail(D, ST_INVALID, 400);
+    WAIT_VM0();
+    __threadfence_block();
+  }
+  __syncthreads();
+  if (status_of(D) != ST_OK) return;
+  // 2. cumulative frequencies, in place; entry nsym = precision
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 < nsym; b0 += WAVE) {
+    const uint32_t i = b0 + lane;
+    const uint32_t pr = i < nsym ? gtab[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = wave_excl_scan(pr, &tot);
+    if (i < nsym) gtab[i] = carry + ex;
+    carry += tot;
+  }
+  if (carry != precision) { if (lane == 0) fail(D, ST_INVALID, 401); return; }
+  WAIT_VM0();
+  __threadfence_block();
+  __syncthreads();
+  // 3. the table into registers: register r, lane l = cum[64 r + l] (precision beyond the alphabet: compares false)
+  const uint32_t nblocks = (nsym + WAVE - 1) / WAVE;
+  v32u tab;
+#pragma unroll
+  for (int r = 0; r < 32; ++r) { const uint32_t i = (uint32_t)r * WAVE + lane; tab[r] = i < nsym ? gtab[i] : precision; }
+  const uint32_t coarse = lane < nblocks ? gtab[lane * WAVE] : precision;       // lane l: first entry of block l
+  // 4. initial state from the stream tail
+  const uint8_t *buf = stream + a.off_rans;
+  uint32_t x, off;
+  {
+    uint32_t st = 0, o = 0;
+    const bool ok = rans_init(buf, a.size_rans, l_base, &st, &o);
+    if (!ok) { if (lane == 0) fail(D, ST_INVALID, 402); return; }
+    x = uni(st); off = uni(o);
+  }
+  const uintptr_t base_addr = (uintptr_t)buf;
+  const uint32_t mis = (uint32_t)(base_addr & 3u);
+  const uint32_t *abuf = (const uint32_t *)(base_addr - mis);
+  uint32_t chunk = 0xFFFFFFFFu, W = 0;
+  const uint32_t mask = precision - 1;
+  uint32_t mine = 0;
+  for (uint32_t i = 0; i < num_values; ++i) {
+    while (x < l_base && off > 0) {
+      --off;
+      const uint32_t q = off + mis, ch = q >> 8;
+      if (ch != chunk) { chunk = ch; W = abuf[(size_t)ch * 64 + lane]; }   // arena padding makes the over-read safe
+      const uint32_t byte = (rdlane(W, (q & 255u) >> 2) >> ((q & 3u) * 8)) & 0xFFu;
+      x = (x << 8) | byte;
+    }
+    const uint32_t rem = x & mask;
+    const uint32_t b = uni((uint32_t)__popcll(__ballot(coarse <= rem)) - 1u);
+    const uint32_t v = tab[b];
+    const uint32_t j = (uint32_t)__popcll(__ballot(v <= rem)) - 1u;
+    const uint32_t cs = rdlane(v, j);
+    const uint32_t nx = (j < 63) ? rdlane(v, j + 1) : rdlane(coarse, b + 1);
+    x = (nx - cs) * (x >> P) + rem - cs;
+    if ((i & 63u) == lane) mine = b * WAVE + j;
+    if ((i & 63u) == 63u) out[i - 63u + lane] = mine;
+  }
+  const uint32_t tail = num_values & 63u;
+  if (tail && lane < tail) out[num_values - tail + lane] = mine;
+  WAIT_VM0();
+  __threadfence_block();
+  __syncthreads();
+  // 5. compact index -> symbol id, then zig-zag unless the transform's corrections are positive (D-4)
+  const bool positive = a.have_scheme && (a.pred_transform == 2 || a.pred_transform == 3);
+  for (uint32_t i = lane; i < num_values; i += WAVE) {
+    uint32_t v = out[i];
+    if (compact) v = symtab[v];
+    out[i] = positive ? v : ((v & 1u) ? (uint32_t)(-(int32_t)(v >> 1) - 1) : (v >> 1));
+  }
+}
+
 template <int TIER>
 __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t flags) {
   constexpr uint32_t LDS_SYMS = TIER == 0 ? 64 : (TIER == 1 ? 960 : SYM_MAX_LDS);
@@ -1569,7 +1705,8 @@ __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayo
   const bool compact = a.source == SRC_RAW && a.num_symbols > SYM_MAX_LDS && a.num_distinct <= SYM_MAX_LDS && a.num_distinct >= 1 && a.table != 0;
   {
     const uint32_t ns = a.source == SRC_RAW ? a.num_symbols : 0u;
-    if (a.source == SRC_RAW && a.precision_bits == 12 && ns > 64 && ns <= REG_MAX_SYMS && a.num_distinct > 1 && L.out_cap[ai] >= 4096 * 6 + REG_MAX_SYMS * 4) return;   // k_symbols_reg
+    if (sym_reg_eligible(a, L, ai)) return;    // k_symbols_reg
+    if ((flags & SYM_WIDE) && sym_wide_eligible(a, L, ai)) return;   // k_symbols_wide
     const uint32_t nse = compact ? a.num_distinct : ns;
     const int tier = nse <= 64 ? 0 : (nse <= 960 ? 1 : 2);
     if (tier != TIER) return;
