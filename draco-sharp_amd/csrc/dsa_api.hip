@@ -380,13 +380,14 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   hipStream_t st4 = sym_split ? ctx->stream4 : st2;
   // k_symbols_wide (raw streams of any precision with a search table of <= 2048 entries, in registers) unless DSA_SYM_WIDE=0
   static const uint32_t wide_flag = (getenv("DSA_SYM_WIDE") && atoi(getenv("DSA_SYM_WIDE")) == 0) ? 0u : SYM_WIDE;
+  const uint32_t tier_blocks = (uint32_t)std::min<uint64_t>((uint64_t)n * na, SYM_TIER_BLOCKS);
   auto launch_symbols = [&](hipStream_t s, uint32_t fl) {
     fl |= wide_flag;
     hipLaunchKernelGGL(dsa::k_symbols_reg, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
     if (wide_flag) hipLaunchKernelGGL(dsa::k_symbols_wide, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
-    hipLaunchKernelGGL(dsa::k_symbols<1>, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
-    hipLaunchKernelGGL(dsa::k_symbols<0>, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
-    hipLaunchKernelGGL(dsa::k_symbols<2>, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
+    hipLaunchKernelGGL(dsa::k_symbols<1>, dim3(tier_blocks), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, na, fl);
+    hipLaunchKernelGGL(dsa::k_symbols<0>, dim3(tier_blocks), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, na, fl);
+    hipLaunchKernelGGL(dsa::k_symbols<2>, dim3(tier_blocks), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, na, fl);
   };
   {
     // The identity maps of point clouds (nothing to do for meshes) go first on the symbol stream, and the symbol kernels of

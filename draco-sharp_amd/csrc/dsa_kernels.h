@@ -1687,12 +1687,9 @@ __global__ __launch_bounds__(WAVE) void k_symbols_wide(uint8_t *arena, const Mes
   }
 }
 
+// One (mesh, attribute) item of k_symbols<TIER>.
 template <int TIER>
-__global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t flags) {
-  constexpr uint32_t LDS_SYMS = TIER == 0 ? 64 : (TIER == 1 ? 960 : SYM_MAX_LDS);
-  __shared__ uint32_t lds_cum[LDS_SYMS + WAVE + 1];
-  uint32_t mesh = blockIdx.x, ai = blockIdx.y;
-  if (mesh >= n) return;
+__device__ __forceinline__ void symbols_tier_item(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t mesh, uint32_t ai, uint32_t flags, uint32_t *lds_cum) {
   MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
   const MeshLayout &L = layouts[mesh];
@@ -1755,6 +1752,20 @@ __global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayo
       uint32_t v = work[i];
       work[i] = (v & 1u) ? (uint32_t)(-(int32_t)(v >> 1) - 1) : (v >> 1);
     }
+}
+// The tiers are launched for every batch, and almost always find nothing to do; a wave needs its registers and LDS (136 VGPRs,
+// 17 KB for tier 2) even to find that out, which beside the chain and decoder waves it gets one at a time.  So a launch is a
+// fixed number of waves that walk the (mesh, attribute) items with a stride, instead of one wave per item.
+#define SYM_TIER_BLOCKS 2048u
+template <int TIER>
+__global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t na, uint32_t flags) {
+  constexpr uint32_t LDS_SYMS = TIER == 0 ? 64 : (TIER == 1 ? 960 : SYM_MAX_LDS);
+  __shared__ uint32_t lds_cum[LDS_SYMS + WAVE + 1];
+  const uint64_t items = (uint64_t)n * na;
+  for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
+    symbols_tier_item<TIER>(arena, layouts, descs, (uint32_t)(it % n), (uint32_t)(it / n), flags, lds_cum);
+    __syncthreads();                                     // the next item reuses the LDS table
+  }
 }
 
 // =========================================================================
