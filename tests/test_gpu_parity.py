@@ -562,3 +562,25 @@ def test_device_views_are_the_results_without_a_copy(ctx):
         per_point = p["values"][p["point_map"].long()]
         assert np.array_equal(per_point.cpu().numpy(), m.Attributes[0].Values[m.Attributes[0].PointMap])
     b.close()
+
+
+def test_high_precision_symbol_streams(ctx):
+    """rANS precisions above 12 bits: alphabets of up to 2048 symbols (k_symbols_wide, table in registers), sparse large
+    alphabets searched through their non-zero symbols (14-bit positions), and what is left to the LDS tiers -- every
+    compression level's precision rule, one batch, against the oracle."""
+    cases = []
+    for k, opts in enumerate(({"pos_bits": 12, "uv_bits": 12, "normal_bits": 10}, {"pos_bits": 13, "compression_level": 0}, {"pos_bits": 14, "compression_level": 10},
+                              {"pos_bits": 14, "uv_bits": 13, "normal_bits": 12}, {"pos_bits": 16, "uv_bits": 15}, {"pos_bits": 12, "compression_level": 7},
+                              {"pos_bits": 20, "uv_bits": 16, "normal_bits": 14})):
+        pos, nrm, uv, faces = synth.make_mesh(synth.GRID if k % 2 == 0 else synth.TORUS, 96, 80, 40 + k)
+        cases.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(force_scheme=1, **opts)))
+    b = dsa.Batch(ctx, cases)
+    b.decode()
+    seen = set()
+    for i, data in enumerate(cases):
+        assert b.status(i) == 0, b.mesh_info(i).detail
+        assert_same(b.result(i), oracle.decode(data), b, i)
+        info = b.debug_array(i, 5, np.uint32, 64).reshape(16, 4)[:3]
+        seen.update(int(p) for src, _, p, _ in info if src == 1)
+    assert max(seen) >= 15 and len(seen) >= 3          # several precisions were really met
+    b.close()
