@@ -1563,7 +1563,7 @@ __device__ __forceinline__ bool sym_wide_eligible(const AttrDesc &a, const MeshL
   if (a.source != SRC_RAW || a.num_distinct <= 1 || sym_reg_eligible(a, L, ai)) return false;
   const bool compact = a.num_symbols > SYM_MAX_LDS;
   const uint32_t nse = compact ? a.num_distinct : a.num_symbols;
-  if (nse <= 64 || nse > REG_MAX_SYMS) return false;
+  if (nse <= 64 || nse > REG_MAX_SYMS || a.precision_bits > 16) return false;     // {cum, freq} packed in 16 + 16 bits
   return compact ? (a.table != 0 && 2ull * nse + 1 <= (unsigned long long)a.num_symbols + 2) : (L.out_cap[ai] >= 4ull * (nse + 1));
 }
 
@@ -1631,15 +1631,21 @@ __global__ __launch_bounds__(WAVE) void k_symbols_wide(uint8_t *arena, const Mes
     carry += tot;
   }
   if (carry != precision) { if (lane == 0) fail(D, ST_INVALID, 401); return; }
+  if (lane == 0) gtab[nsym] = precision;
   WAIT_VM0();
   __threadfence_block();
   __syncthreads();
-  // 3. the table into registers: register r, lane l = cum[64 r + l] (precision beyond the alphabet: compares false)
+  // 3. the table into registers: register r, lane l = {cum, freq} of entry 64 r + l in 16 + 16 bits (precision <= 16; a frequency of
+  // 2^16 would be a one-symbol alphabet, which never comes here); beyond the alphabet cum = 0xFFFF.. compares false
   const uint32_t nblocks = (nsym + WAVE - 1) / WAVE;
   v32u tab;
 #pragma unroll
-  for (int r = 0; r < 32; ++r) { const uint32_t i = (uint32_t)r * WAVE + lane; tab[r] = i < nsym ? gtab[i] : precision; }
-  const uint32_t coarse = lane < nblocks ? gtab[lane * WAVE] : precision;       // lane l: first entry of block l
+  for (int r = 0; r < 32; ++r) {
+    const uint32_t i = (uint32_t)r * WAVE + lane;
+    const uint32_t c0 = i < nsym ? gtab[i] : 0x1FFFFu, c1 = i < nsym ? gtab[i + 1] : 0x1FFFFu;      // gtab[nsym] = precision (set below)
+    tab[r] = i < nsym ? (c0 | ((c1 - c0) << 16)) : 0xFFFFFFFFu;
+  }
+  const uint32_t coarse = lane < nblocks ? gtab[lane * WAVE] : 0xFFFFFFFFu;     // lane l: first cumulative frequency of block l
   // 4. initial state from the stream tail
   const uint8_t *buf = stream + a.off_rans;
   uint32_t x, off;
@@ -1655,22 +1661,29 @@ __global__ __launch_bounds__(WAVE) void k_symbols_wide(uint8_t *arena, const Mes
   uint32_t chunk = 0xFFFFFFFFu, W = 0;
   const uint32_t mask = precision - 1;
   uint32_t mine = 0;
+  uint32_t res = 0, rc = 0;               // up to four bytes of the stream, the next one in the top bits (RAnsDecoder.cs:56-67 reads them one by one)
   for (uint32_t i = 0; i < num_values; ++i) {
-    while (x < l_base && off > 0) {
-      --off;
-      const uint32_t q = off + mis, ch = q >> 8;
-      if (ch != chunk) { chunk = ch; W = abuf[(size_t)ch * 64 + lane]; }   // arena padding makes the over-read safe
-      const uint32_t byte = (rdlane(W, (q & 255u) >> 2) >> ((q & 3u) * 8)) & 0xFFu;
-      x = (x << 8) | byte;
+    while (x < l_base) {
+      if (rc == 0) {
+        if (off == 0) break;              // no bytes left: the state stays as it is
+        const uint32_t end = off + mis;   // one past the next byte, in abuf coordinates
+        const uint32_t d = (end - 1) >> 2, r = end - 4 * d, ch = d >> 6;
+        if (ch != chunk) { chunk = ch; W = abuf[(size_t)ch * 64 + lane]; }   // arena padding makes the over-read safe
+        res = rdlane(W, d & 63u) << (8 * (4 - r));
+        rc = uni(r < off ? r : off);
+        off -= rc;
+      }
+      x = (x << 8) | (res >> 24);
+      res <<= 8;
+      --rc;
     }
     const uint32_t rem = x & mask;
     const uint32_t b = uni((uint32_t)__popcll(__ballot(coarse <= rem)) - 1u);
     const uint32_t v = tab[b];
-    const uint32_t j = (uint32_t)__popcll(__ballot(v <= rem)) - 1u;
-    const uint32_t cs = rdlane(v, j);
-    const uint32_t nx = (j < 63) ? rdlane(v, j + 1) : rdlane(coarse, b + 1);
-    x = (nx - cs) * (x >> P) + rem - cs;
-    if ((i & 63u) == lane) mine = b * WAVE + j;
+    const uint32_t j = (uint32_t)__popcll(__ballot((v & 0xFFFFu) <= rem)) - 1u;
+    const uint32_t e = rdlane(v, j);
+    x = (e >> 16) * (x >> P) + rem - (e & 0xFFFFu);
+    mine = (i & 63u) == lane ? b * WAVE + j : mine;
     if ((i & 63u) == 63u) out[i - 63u + lane] = mine;
   }
   const uint32_t tail = num_values & 63u;
