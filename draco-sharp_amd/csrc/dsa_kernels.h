@@ -1680,7 +1680,8 @@ __global__ __launch_bounds__(WAVE) void k_symbols_wide(uint8_t *arena, const Mes
     const uint32_t rem = x & mask;
     const uint32_t b = uni((uint32_t)__popcll(__ballot(coarse <= rem)) - 1u);
     const uint32_t v = tab[b];
-    const uint32_t j = (uint32_t)__popcll(__ballot((v & 0xFFFFu) <= rem)) - 1u;
+    // (the padding beyond the alphabet, 0xFFFFFFFF, must not count: at 16-bit precision its low half, 65535, is a value rem takes)
+    const uint32_t j = (uint32_t)__popcll(__ballot((v & 0xFFFFu) <= rem && v != 0xFFFFFFFFu)) - 1u;
     const uint32_t e = rdlane(v, j);
     x = (e >> 16) * (x >> P) + rem - (e & 0xFFFFu);
     mine = (i & 63u) == lane ? b * WAVE + j : mine;
