@@ -158,6 +158,12 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
   ec_sync();
 
   if (lane == 0) {
+    // Every walk below ends by itself on a mesh that passed the checks above (the host coder, which has no such counter, was fuzzed
+    // with 20 000 damaged meshes); the counter only makes sure that a kernel can never spin: a GPU does not take Ctrl-C.
+    uint32_t steps = 0;
+    bool failed = false;
+    const uint32_t step_limit = 64u * NC + 4096u;
+    auto runaway = [&]() { if (++steps > step_limit) failed = true; return failed; };
     // ---- hole ids, MeshEdgeBreakerEncoder.cs:331-361
     uint32_t num_holes = 0;
     for (uint32_t i = 0; i < NC; ++i) {
@@ -166,28 +172,27 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
       if (hole_id[bv] != -1) continue;
       const int32_t id = (int32_t)num_holes++;
       uint32_t c = i;
-      while (hole_id[bv] == -1) {
+      while (hole_id[bv] == -1 && !runaway()) {
         hole_id[bv] = id;
         c = ec_next(c);
-        while (opp[c] != DSA_INVALID) c = ec_next(opp[c]);
+        while (opp[c] != DSA_INVALID && !runaway()) c = ec_next(opp[c]);
         bv = c2v[ec_next(c)];
       }
     }
     // ---- Edgebreaker symbols
     uint32_t nsym = 0, nproc = 0, ninit = 0, nstart = 0, nsplit = 0, nsplit_sym = 0;
     int32_t last_symbol_id = -1;
-    bool failed = false;
     auto encode_hole = [&](uint32_t start_corner, bool encode_first) {          // :276-303
       uint32_t c = ec_prev(start_corner);
-      while (opp[c] != DSA_INVALID) c = ec_next(opp[c]);
+      while (opp[c] != DSA_INVALID && !runaway()) c = ec_next(opp[c]);
       const uint32_t start_v = c2v[start_corner];
       if (encode_first) vvis[start_v] = 1;
-      hole_vis[hole_id[start_v]] = 1;
+      if (hole_id[start_v] >= 0) hole_vis[hole_id[start_v]] = 1;
       uint32_t act = c2v[ec_prev(c)];
-      while (act != start_v) {
+      while (act != start_v && !runaway()) {
         vvis[act] = 1;
         c = ec_next(c);
-        while (opp[c] != DSA_INVALID) c = ec_next(opp[c]);
+        while (opp[c] != DSA_INVALID && !runaway()) c = ec_next(opp[c]);
         act = c2v[ec_prev(c)];
       }
     };
@@ -202,10 +207,11 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
     auto encode_from_corner = [&](uint32_t corner0) {                             // :185-274
       uint32_t sp = 0;
       stack[sp++] = corner0;
-      while (sp) {
+      while (sp && !failed) {
         uint32_t corner = stack[sp - 1];
         if (corner == DSA_INVALID || fvis[corner / 3]) { --sp; continue; }
         for (;;) {
+          if (runaway() || nsym >= F || nproc >= F || sp >= F) { failed = true; break; }
           ++last_symbol_id;
           const uint32_t face = corner / 3;
           fvis[face] = 1;
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
         if (opp[corner] == DSA_INVALID) { start = corner; interior_face = false; break; }
         if (hole_id[c2v[corner]] != -1) {
           uint32_t rc = corner;
-          while (rc != DSA_INVALID) { corner = rc; rc = ct.swing_right(rc); }
+          while (rc != DSA_INVALID && !runaway()) { corner = rc; rc = ct.swing_right(rc); }
           start = ec_prev(corner);
           interior_face = false;
           break;
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
         encode_from_corner(start);
       }
     }
-    if (failed) ec_fail(E, ENC_SPLITS, nsplit);
+    if (failed) ec_fail(E, steps > step_limit ? ENC_RING : ENC_SPLITS, nsplit);
     E->num_symbols = nsym; E->num_start_bits = nstart; E->num_splits = nsplit; E->num_split_symbols = nsplit_sym;
     E->num_processed = nproc; E->num_init = ninit; E->interior_edges = interior / 2;
     __threadfence_block();
@@ -291,8 +297,9 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
     // ---- depth-first attribute order over the decoder's face order (processed corners last to first, then the init
     // corners), DepthFirstTraverser.cs:9-99
     const uint32_t nproc = E->num_processed, ninit = E->num_init;
-    uint32_t count = 0;
-    auto visit = [&](uint32_t v, uint32_t c) { vvis[v] = 1; v2d[v] = (int32_t)count; d2c[count++] = c; };
+    uint32_t count = 0, dfs_steps = 0;
+    bool stuck = false;
+    auto visit = [&](uint32_t v, uint32_t c) { vvis[v] = 1; v2d[v] = (int32_t)count; if (count < V) d2c[count] = c; ++count; };
     auto fdone = [&](uint32_t f) { return f == DSA_INVALID || fvis[f] != 0; };
     for (uint32_t i = 0; i < nproc + ninit; ++i) {
       const uint32_t start = i < nproc ? processed[nproc - 1 - i] : init_corners[i - nproc];
@@ -302,11 +309,12 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
       const uint32_t nvx = c2v[ec_next(start)], pvx = c2v[ec_prev(start)];
       if (!vvis[nvx]) visit(nvx, ec_next(start));
       if (!vvis[pvx]) visit(pvx, ec_prev(start));
-      while (sp) {
+      while (sp && !stuck) {
         uint32_t corner = stack[sp - 1];
         uint32_t face = corner == DSA_INVALID ? DSA_INVALID : corner / 3;
         if (corner == DSA_INVALID || fdone(face)) { --sp; continue; }
         for (;;) {
+          if (++dfs_steps > 64u * NC + 4096u || sp >= F || count > V) { stuck = true; break; }
           fvis[face] = 1;
           const uint32_t v = c2v[corner];
           if (!vvis[v]) {
@@ -327,7 +335,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
       }
     }
     E->num_entries = count;
-    if (count != V) ec_fail(E, ENC_UNREACHED, count);
+    if (stuck) ec_fail(E, ENC_RING, count);
+    else if (count != V) ec_fail(E, ENC_UNREACHED, count);
     __threadfence_block();
   }
   __syncthreads();
