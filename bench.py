@@ -31,7 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 
 
 def cpu_baseline(blob, offsets, threads, budget_s, max_meshes):
@@ -107,6 +107,85 @@ def encode_leg(dsa, synth, ctx, nx, ny, count, comm=None, barrier=None, world=1)
             "round_trip_ok": bool(ok), "byte_identical_to_cpu_coder": bool(identical)}
 
 
+def end_to_end_leg(dsa, ctx, blob, offsets, batches, in_flight, comm, barrier, world):
+    """What a draco-sharp caller sees (DracoDecoder.cs:19-42 takes host bytes and returns host objects): `batches` batches of
+    this rank's streams, each host bytes -> dsa_batch_create (pinned staging, upload on the copy stream) -> dsa_batch_decode ->
+    dsa_batch_download (ONE transfer of faces + values + point maps into a pinned mirror) -> dsa_batch_wait, `in_flight` batches
+    queued at a time so that upload(k+1), the kernels of k and the download of k-1 overlap.  The clock runs from the first byte
+    handed over to the last array readable on the host.  h2d_s / d2h_s: one upload / one download alone, for the link rates."""
+    import numpy as np
+    n = len(offsets) - 1
+
+    def submit():
+        b = dsa.Batch(ctx, blob=blob, offsets=offsets)
+        b.decode(wait=False)
+        b.download(wait=False)
+        return b
+
+    def finish(b):
+        b.wait()
+        v0, v1 = b.host_views(0), b.host_views(n - 1)        # views into the mirror: the arrays are on the host
+        tag = int(v0["faces"][0, 0]) + int(v1["faces"][-1, -1]) + int(v1["attributes"][0]["point_map"][-1])
+        b.close()
+        return tag
+
+    # warm-up: the context's caches (arenas, pinned mirrors, staging) fill; also the stand-alone link times
+    t0 = time.perf_counter(); b = dsa.Batch(ctx, blob=blob, offsets=offsets); b.decode(wait=True); t_up_decode = time.perf_counter() - t0
+    out_bytes = b.output_bytes
+    b.download(wait=True)                                    # first use pins the mirror
+    t0 = time.perf_counter(); b.decode(wait=True); t_dec = time.perf_counter() - t0
+    t0 = time.perf_counter(); b.download(wait=True); t_d2h = time.perf_counter() - t0
+    b.close()
+    live = [submit() for _ in range(in_flight)]
+    for b in live:
+        finish(b)
+    t0 = time.perf_counter(); b = dsa.Batch(ctx, blob=blob, offsets=offsets); b.decode(wait=True); t_h2d = max(1e-6, time.perf_counter() - t0 - t_dec)
+    b.close()
+    if barrier is not None:
+        barrier()
+    t0 = time.perf_counter()
+    live, tags = [], 0
+    for k in range(batches):
+        live.append(submit())
+        if len(live) == in_flight:
+            tags += finish(live.pop(0))
+    while live:
+        tags += finish(live.pop(0))
+    dt = time.perf_counter() - t0
+    if comm is not None:
+        dt = comm.max(dt)
+    return {"value": world * batches * n / dt, "unit": "meshes/s", "seconds": dt, "batches_per_gpu": batches, "meshes_per_batch": n, "in_flight": in_flight,
+            "n_gpus": world, "host_bytes_in_per_batch": int(offsets[-1]), "host_bytes_out_per_batch": out_bytes,
+            "gb_per_s_out": world * batches * out_bytes / dt / 1e9,
+            "h2d_s": t_h2d, "h2d_gb_per_s": int(offsets[-1]) / t_h2d / 1e9, "d2h_s": t_d2h, "d2h_gb_per_s": out_bytes / t_d2h / 1e9,
+            "decode_s": t_dec, "first_batch_s_cold": t_up_decode,
+            "what": "host .drc bytes -> host arrays (faces, attribute values, point maps of every mesh), pinned staging + one download per batch, %d batches in flight" % in_flight}
+
+
+def pool_leg(dsa, devices, blob, offsets, chunk, repeats):
+    """The north star's per-GPU work queues inside one process (dsa_pool_*): the job's streams, longest first, in chunks of `chunk`
+    pulled by one worker thread per device from one atomic counter; device-resident results (no download)."""
+    pool = dsa.Pool(devices, chunk_meshes=chunk)
+    n = len(offsets) - 1
+    job = pool.decode(blob=blob, offsets=offsets)            # warm: arenas, staging
+    bad = sum(1 for i in range(0, n, max(1, n // 64)) if job.status(i) != 0)
+    per_worker = [0] * len(devices)
+    for i in range(n):
+        per_worker[job.worker(i)] += 1
+    job.close()
+    best = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        job = pool.decode(blob=blob, offsets=offsets)
+        dt = time.perf_counter() - t0
+        job.close()
+        best = dt if best is None else min(best, dt)
+    pool.close()
+    return {"value": n / best, "unit": "meshes/s", "seconds": best, "meshes_in_job": n, "devices": list(devices), "chunk_meshes": chunk,
+            "meshes_per_worker_first_run": per_worker, "failed_sampled": bad,
+            "what": "dsa_pool_decode from host bytes (parse + pinned staging + upload + decode per chunk, two chunks in flight per device), results device-resident"}
+
+
 def oracle_check(batch, blob, offsets, indices):
     """Outside the timed region: the decoded results of `indices` equal the CPU oracle's (faces, portable integers,
     point maps, floats bit for bit)."""
@@ -131,8 +210,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--meshes", type=int, default=4096, help="meshes per GPU (weak) / in the job (strong); BASELINE.json configs[2]: 4096")
     ap.add_argument("--grid", type=int, nargs=2, default=[128, 256], help="grid cells (128x256 -> 65 536 triangles)")
-    ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="both",
-                    help="which partition of the work is timed (both: weak is the line's value, strong is reported beside it)")
+    ap.add_argument("--scaling", choices=["auto", "weak", "strong", "both"], default="auto",
+                    help="auto: both partitions are timed; with one GPU they are the same batch, with several the STRONG one (BASELINE.json "
+                         "configs[3]: the same 4096 streams sharded over the GPUs) is the line's value and the weak one is reported beside it; "
+                         "both: like auto but weak stays the line; weak / strong: only that leg")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-pool", action="store_true")
+    ap.add_argument("--e2e-batches", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true")
     ap.add_argument("--check", type=int, default=64, help="meshes of the rank-0 batch compared with the oracle after the timed region")
@@ -204,8 +288,8 @@ def main():
                              (rank, len(bad), bad[0], batch.status(bad[0]), batch.mesh_info(bad[0]).detail))
         return comm.max(elapsed), {k: v / args.steps for k, v in stage_sum.items()}
 
-    do_weak = args.scaling in ("weak", "both")
-    do_strong = args.scaling == "strong" or (args.scaling == "both" and world > 1)
+    do_weak = args.scaling in ("weak", "both", "auto")
+    do_strong = args.scaling == "strong" or (args.scaling in ("both", "auto") and world > 1)
     out, strong = None, None
     t_gen = t_upload = 0.0
     weak_blob = weak_offsets = None
@@ -302,6 +386,24 @@ def main():
     encode = None
     if not args.no_encode:                                           # every rank: the leg's clock is the slowest rank's
         encode = encode_leg(dsa, synth, ctx, nx, ny, 1024, comm if world > 1 else None, barrier if world > 1 else None, world)
+    e2e = None
+    if not args.no_end_to_end and weak_blob is not None:             # every rank its own batches: the clock is the slowest rank's
+        e2e = end_to_end_leg(dsa, ctx, weak_blob, weak_offsets, args.e2e_batches, 2, comm if world > 1 else None, barrier if world > 1 else None, world)
+    pool = None
+    if not args.no_pool:
+        # the in-library work queue over all GPUs of the job, from rank 0 alone (the other ranks have released their contexts'
+        # caches and wait at the barrier): BASELINE.json configs[3] as a single-process host (the C# one) runs it
+        ctx.close()
+        ctx = None
+        barrier()
+        if rank == 0:
+            if weak_blob is not None:
+                pblob, poffs = weak_blob, weak_offsets
+            else:
+                pblob, poffs = synth.make_batch(synth.GRID, nx, ny, 1000, args.meshes, normals=True, uvs=True, threads=threads)
+            devices = [0] * world if rehearse else list(range(world))
+            pool = pool_leg(dsa, devices, pblob, poffs, 256, 3)
+        barrier()
     if rank == 0:
         if out is None:                                              # --scaling strong: the strong leg is the line
             out = {"metric": "decoded_meshes_per_sec", "value": strong["value"], "unit": "meshes/s", "n_gpus": world, "steps": args.steps,
@@ -316,13 +418,29 @@ def main():
         elif world == 1:
             out["strong_scaling"] = {"value": out["value"], "unit": "meshes/s", "ms_per_step": out["ms_per_step"], "meshes_in_job": args.meshes,
                                      "meshes_per_gpu": [args.meshes], "note": "one GPU: the strong and the weak partition are the same batch"}
+        if world > 1 and args.scaling == "auto" and strong is not None and out.get("scaling") == "weak":
+            # several GPUs: the line is BASELINE.json configs[3] (the same streams sharded), the per-GPU batches are beside it
+            out["weak_scaling"] = {"value": out["value"], "unit": "meshes/s", "ms_per_step": out["ms_per_step"], "gb_per_s": out["gb_per_s"],
+                                   "meshes_per_gpu": args.meshes, "meshes_in_job": args.meshes * world}
+            out["value"], out["ms_per_step"], out["gb_per_s"], out["scaling"] = strong["value"], strong["ms_per_step"], strong["gb_per_s"], "strong"
+            out["config"]["workload"] = ("one batch of %d x %d-triangle Edgebreaker .drc (positions 11b + octahedral normals 8b + UVs 10b) sharded over %d GPUs "
+                                         "by compressed length, device-resident decode" % (args.meshes, 2 * nx * ny, world))
+            out["config"]["meshes_in_job"] = args.meshes
+            out["roofline"]["leg"] = "weak (a full %d-mesh batch per GPU): the kernels' roofline does not depend on the partition" % args.meshes
         if encode is not None:
             out["encode"] = encode
+        if e2e is not None:
+            out["end_to_end"] = e2e
+        if pool is not None:
+            out["pool"] = pool
+        out["notes"] = ("value / gb_per_s: compressed bytes resident in HBM -> results in HBM (no PCIe in the timed region); end_to_end: host bytes -> host "
+                        "arrays; cpu_baseline: the oracle incl. its numpy export on the host")
         if world == 1 and not args.no_cpu_baseline and weak_blob is not None:
             out["cpu_baseline"] = cpu_baseline(weak_blob, weak_offsets, 1, 10.0, 1024)
             out["cpu_baseline_all_cores"] = cpu_baseline(weak_blob, weak_offsets, min(host_cores, 32), 10.0, 4096)
         print(json.dumps(out))
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     comm.close()
 
 

@@ -16,6 +16,7 @@
 #include "dsa_kernels.h"
 #include "dsa_general.h"
 #include "dsa_host_parse.h"
+#include "dsa_host_util.h"
 
 namespace {
 
@@ -32,11 +33,25 @@ struct dsa_context {
   hipStream_t stream2 = nullptr;     // symbol decode runs here, concurrently with connectivity + traversal
   hipStream_t stream3 = nullptr;     // connectivity validation (link symmetry, seam streams)
   hipStream_t stream4 = nullptr;     // early attributes: symbols, prediction, dequantisation (dispatch priority)
+  hipStream_t up = nullptr;          // host -> device: compressed streams of the next batch, beside the kernels of this one
+  hipStream_t down = nullptr;        // device -> host: the output block and the mesh descriptors of the previous one
   hipEvent_t ev_join3 = nullptr, ev_trav = nullptr, ev_maps = nullptr, ev_early = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_conn = nullptr;
   bool own_stream = false;
   bool profiling = false;
   std::string err;
+  // Uploads go through pinned staging (two buffers, used in turn: the DMA of one batch reads its buffer while the next batch is
+  // staged into the other).
+  hostutil::Staging stage[2];
+  int stage_next = 0;
+  // Arenas and pinned mirrors of freed batches are kept for the next batch of the context: hipMalloc / hipFree of tens of GB and
+  // pinning GBs of host memory cost as much as the decode itself.  Three of each: two batches in flight + one being built.
+  struct Spare { uint8_t *p; uint64_t bytes; };
+  std::vector<Spare> spare_arenas, spare_mirrors;
+  static constexpr size_t kSpares = 3;
+  // batches point at their context: a context destroyed first lives on until its last batch is freed
+  int live_batches = 0;
+  bool doomed = false;
 };
 
 struct dsa_batch {
@@ -45,12 +60,13 @@ struct dsa_batch {
   std::vector<MeshLayout> layouts;
   std::vector<HostMesh> host;
   std::vector<MeshDesc> descs;       // copied back by dsa_batch_wait
-  uint8_t *arena = nullptr;
-  uint64_t arena_bytes = 0;
-  MeshLayout *d_layouts = nullptr;
+  uint8_t *arena = nullptr;          // [layouts | globals | streams + slack | descs | per-mesh scratch | table pool | output block]
+  uint64_t arena_bytes = 0, arena_cap = 0;
+  MeshLayout *d_layouts = nullptr;   // inside the arena
   MeshDesc *d_descs = nullptr;
   BatchGlobals *d_globals = nullptr;
   BatchGlobals globals = {};
+  uint64_t out_base = 0, out_bytes = 0;   // the output block: faces, attribute values and point maps of every mesh
   uint32_t max_faces = 0, max_vertices = 0, max_atts = 0, max_att_data = 0;
   bool any_general = false;
   bool decoded = false, collected = false;
@@ -58,6 +74,14 @@ struct dsa_batch {
   hipEvent_t ev_sym[2] = {};
   bool have_events = false;
   float stage_ms[DSA_NUM_STAGES] = {};
+  // per-batch ordering between the copy streams and the kernels (a second batch may be queued on the same context meanwhile,
+  // so nothing here waits for a whole stream)
+  hipEvent_t ev_uploaded = nullptr, ev_done = nullptr, ev_descs = nullptr, ev_down = nullptr;
+  MeshDesc *descs_pin = nullptr;     // pinned landing zone of the descriptors
+  // host copy of the output block: a library-owned pinned mirror or the caller's buffer
+  uint8_t *mirror = nullptr;
+  uint64_t mirror_bytes = 0;
+  bool mirror_owned = false, download_queued = false, downloaded = false;
   // meshes the fast kernels handed back (DSA_SITE_RETRY_GENERAL): decoded again through the general path in a batch
   // of their own by dsa_batch_wait; every per-mesh accessor follows retry_index
   bool all_general = false;
@@ -85,22 +109,63 @@ dsa_status set_err(dsa_context *ctx, dsa_status st, const char *fmt, ...) {
                                          "%s failed: %s", #call, hipGetErrorString(e_));          \
   } while (0)
 
+// Arena / mirror caches of a context (see dsa_context).
+uint8_t *take_spare(std::vector<dsa_context::Spare> &spares, uint64_t need, uint64_t *got) {
+  int best = -1;
+  for (size_t k = 0; k < spares.size(); ++k)
+    if (spares[k].bytes >= need && (best < 0 || spares[k].bytes < spares[(size_t)best].bytes)) best = (int)k;
+  if (best < 0) return nullptr;
+  uint8_t *p = spares[(size_t)best].p;
+  *got = spares[(size_t)best].bytes;
+  spares.erase(spares.begin() + best);
+  return p;
+}
+template <class FreeFn>
+void give_spare(std::vector<dsa_context::Spare> &spares, uint8_t *p, uint64_t bytes, FreeFn release) {
+  if (!p) return;
+  try { spares.push_back({p, bytes}); } catch (...) { release(p); return; }
+  while (spares.size() > dsa_context::kSpares) {       // drop the smallest
+    size_t s = 0;
+    for (size_t k = 1; k < spares.size(); ++k) if (spares[k].bytes < spares[s].bytes) s = k;
+    release(spares[s].p);
+    spares.erase(spares.begin() + (ptrdiff_t)s);
+  }
+}
+void drop_spares(std::vector<dsa_context::Spare> &spares, bool pinned) {
+  for (auto &sp : spares) { if (pinned) (void)hipHostFree(sp.p); else (void)hipFree(sp.p); }
+  spares.clear();
+}
+hipError_t arena_alloc(dsa_context *ctx, uint64_t need, uint8_t **out, uint64_t *cap) {
+  if (uint8_t *p = take_spare(ctx->spare_arenas, need, cap)) { *out = p; return hipSuccess; }
+  hipError_t e = hipMalloc((void **)out, need);
+  if (e != hipSuccess && !ctx->spare_arenas.empty()) {     // the cache may be what is in the way
+    (void)hipGetLastError();
+    drop_spares(ctx->spare_arenas, false);
+    e = hipMalloc((void **)out, need);
+  }
+  *cap = need;
+  return e;
+}
+
 dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *streams, const size_t *lengths, dsa_batch **out, bool all_general = false) {
   if (!ctx || !out || (n && (!streams || !lengths))) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "null argument");
   if (n > 65535) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "batch too large (max 65535 meshes)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   dsa_batch *b = new (std::nothrow) dsa_batch();
   if (!b) return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "host allocation failed");
+  struct Guard { dsa_batch *b; ~Guard() { if (b) dsa_batch_free(b); } } guard{b};     // freed on every failing path (exceptions included)
   b->ctx = ctx;
+  ++ctx->live_batches;
   b->n = n;
   b->all_general = all_general;
   b->layouts.resize(n);
   b->host.resize(n);
   b->descs.resize(n);
-  // ---- arena layout: [streams | padding | per-mesh regions]
-  uint64_t cur = 0;
+  // ---- arena layout: [layouts | globals | streams | slack | descs | per-mesh scratch | table pool | output block]
+  const uint64_t off_layouts = 0, off_globals = align_up(sizeof(MeshLayout) * (uint64_t)n, 256);
+  uint64_t cur = align_up(off_globals + sizeof(BatchGlobals), 256);
   for (uint32_t i = 0; i < n; ++i) {
-    if (lengths[i] > 0xFFFFFF00u) { delete b; return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "stream %u longer than 4 GiB", i); }
+    if (lengths[i] > 0xFFFFFF00u) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "stream %u longer than 4 GiB", i);
     MeshLayout &L = b->layouts[i];
     memset(&L, 0, sizeof(L));
     L.stream = cur;
@@ -108,28 +173,32 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
     cur = align_up(cur + lengths[i], 16);
   }
   cur = align_up(cur + 1024, 256);   // window over-read slack behind the last stream
-  const uint64_t streams_end = cur;
-  for (uint32_t i = 0; i < n; ++i) host_parse(streams[i], lengths[i], b->host[i], all_general);
+  const uint64_t upload_bytes = cur;  // everything the host provides, one transfer
+  const uint64_t off_descs = cur;
+  cur = align_up(cur + sizeof(MeshDesc) * (uint64_t)(n ? n : 1), 256);
+  const uint64_t scratch_begin = cur;
+  hostutil::parallel_for(n, [&](uint32_t i) { host_parse(streams[i], lengths[i], b->host[i], all_general); }, 16);
   // Regions of every mesh behind the streams.  When the arena does not fit the device, the mesh with the largest
   // claim is set aside (per-mesh DSA_ERR_OUT_OF_MEMORY: a header may claim far more elements than its stream can
   // carry) and the rest is laid out again, so that one stream cannot take the batch down.
   hipError_t e = hipSuccess;
   std::vector<uint64_t> claim(n, 0);
   for (;;) {
-    cur = streams_end;
+    cur = scratch_begin;
+    uint64_t ocur = 0;
     b->max_faces = b->max_vertices = b->max_atts = b->max_att_data = 0;
     b->any_general = false;
     for (uint32_t i = 0; i < n; ++i) {
       HostMesh &h = b->host[i];
       MeshLayout &L = b->layouts[i];
       if (h.status != 0) { h.faces = 0; h.enc_vertices = 0; h.split_symbols = 0; h.splits = 0; h.atts.clear(); h.general = false; }
-      const uint64_t F = h.faces, V = (uint64_t)h.enc_vertices + h.split_symbols, before = cur;
+      const uint64_t F = h.faces, V = (uint64_t)h.enc_vertices + h.split_symbols, before = cur, obefore = ocur;
       const uint64_t stream_off = L.stream;
       const uint32_t stream_len = L.stream_len;
       memset(&L, 0, sizeof(L));
       L.stream = stream_off; L.stream_len = stream_len;
-      cur = layout_mesh(h, lengths[i], L, cur, 16);
-      claim[i] = cur - before;
+      cur = layout_mesh(h, lengths[i], L, cur, 16, nullptr, &ocur);
+      claim[i] = (cur - before) + (ocur - obefore);
       b->max_faces = std::max<uint32_t>(b->max_faces, (uint32_t)F);
       b->max_vertices = std::max<uint32_t>(b->max_vertices, (uint32_t)V);
       b->max_atts = std::max<uint32_t>(b->max_atts, (uint32_t)h.atts.size());
@@ -144,8 +213,16 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
       b->globals.pool_bytes = (64ull << 20) + 8192ull * streams_total;
       cur = align_up(cur + b->globals.pool_bytes, 256);
     }
-    b->arena_bytes = cur;
-    e = hipMalloc((void **)&b->arena, b->arena_bytes ? b->arena_bytes : 256);
+    // the output block behind everything else; the offsets layout_mesh handed out were relative to it
+    b->out_base = align_up(cur, 4096);
+    b->out_bytes = ocur;
+    for (uint32_t i = 0; i < n; ++i) {
+      MeshLayout &L = b->layouts[i];
+      L.faces += b->out_base;
+      for (uint32_t a = 0; a < L.cap_attributes; ++a) { L.out[a] += b->out_base; L.map[a] += b->out_base; }
+    }
+    b->arena_bytes = b->out_base + align_up(ocur, 256) + 256;
+    e = arena_alloc(ctx, b->arena_bytes, &b->arena, &b->arena_cap);
     if (e == hipSuccess) break;
     (void)hipGetLastError();
     b->arena = nullptr;
@@ -154,20 +231,37 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
     if (n == 0 || b->host[worst].status != 0 || claim[worst] <= (64ull << 20)) break;   // nothing left to set aside: the batch itself is too large
     b->host[worst].status = DSA_ERR_OUT_OF_MEMORY;
   }
-  if (e != hipSuccess) { uint64_t need = b->arena_bytes; delete b; return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "hipMalloc of %llu-byte arena failed: %s", (unsigned long long)need, hipGetErrorString(e)); }
-  e = hipMalloc((void **)&b->d_layouts, sizeof(MeshLayout) * (n ? n : 1));
-  if (e == hipSuccess) e = hipMalloc((void **)&b->d_descs, sizeof(MeshDesc) * (n ? n : 1));
-  if (e == hipSuccess) e = hipMalloc((void **)&b->d_globals, sizeof(BatchGlobals));
-  if (e != hipSuccess) { dsa_batch_free(b); return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "hipMalloc failed: %s", hipGetErrorString(e)); }
-  // ---- upload: one staging copy of all streams, one of the layouts
+  if (e != hipSuccess) return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "hipMalloc of %llu-byte arena failed: %s", (unsigned long long)b->arena_bytes, hipGetErrorString(e));
+  b->d_layouts = (MeshLayout *)(b->arena + off_layouts);
+  b->d_globals = (BatchGlobals *)(b->arena + off_globals);
+  b->d_descs = (MeshDesc *)(b->arena + off_descs);
+  HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_uploaded, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_descs, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_down, hipEventDisableTiming));
+  HIP_TRY(ctx, hipHostMalloc((void **)&b->descs_pin, sizeof(MeshDesc) * (size_t)(n ? n : 1), hipHostMallocDefault));
+  // ---- upload: layouts, globals and all streams staged in pinned memory (host threads), one DMA on the upload stream.  The
+  // caller's buffers are not referenced once this function returns; the kernels wait for ev_uploaded, the host does not.
   {
-    std::vector<uint8_t> staging(streams_end, 0);
-    for (uint32_t i = 0; i < n; ++i) if (lengths[i]) memcpy(staging.data() + b->layouts[i].stream, streams[i], lengths[i]);
-    e = hipMemcpyAsync(b->arena, staging.data(), streams_end, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && n) e = hipMemcpyAsync(b->d_layouts, b->layouts.data(), sizeof(MeshLayout) * n, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { dsa_batch_free(b); return set_err(ctx, DSA_ERR_DEVICE, "upload failed: %s", hipGetErrorString(e)); }
+    hostutil::Staging &stg = ctx->stage[ctx->stage_next];
+    ctx->stage_next ^= 1;
+    HIP_TRY(ctx, stg.acquire(upload_bytes));
+    uint8_t *h = stg.buf.p;
+    if (n) memcpy(h + off_layouts, b->layouts.data(), sizeof(MeshLayout) * (size_t)n);
+    memset(h + sizeof(MeshLayout) * (size_t)n, 0, (size_t)(off_globals - sizeof(MeshLayout) * (uint64_t)n));
+    memcpy(h + off_globals, &b->globals, sizeof(BatchGlobals));
+    const uint64_t first = n ? b->layouts[0].stream : upload_bytes;
+    memset(h + off_globals + sizeof(BatchGlobals), 0, (size_t)(first - off_globals - sizeof(BatchGlobals)));
+    hostutil::parallel_for(n, [&](uint32_t i) {       // stream i and the zero gap up to the next one
+      const uint64_t at = b->layouts[i].stream, end = at + lengths[i], next = i + 1 < n ? b->layouts[i + 1].stream : upload_bytes;
+      if (lengths[i]) memcpy(h + at, streams[i], lengths[i]);
+      memset(h + end, 0, (size_t)(next - end));
+    }, 8);
+    HIP_TRY(ctx, hipMemcpyAsync(b->arena, h, upload_bytes, hipMemcpyHostToDevice, ctx->up));
+    HIP_TRY(ctx, stg.submitted(ctx->up));
+    HIP_TRY(ctx, hipEventRecord(b->ev_uploaded, ctx->up));
   }
+  guard.b = nullptr;
   *out = b;
   return DSA_OK;
 }
@@ -205,6 +299,8 @@ dsa_status dsa_context_create(int device, void *stream, dsa_context **out) {
   if (hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, (least + greatest) / 2) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
   if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least) != hipSuccess ||
       hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_trav, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_maps, hipEventDisableTiming) != hipSuccess ||
@@ -218,6 +314,7 @@ dsa_status dsa_context_create(int device, void *stream, dsa_context **out) {
 
 void dsa_context_destroy(dsa_context *ctx) {
   if (!ctx) return;
+  if (ctx->live_batches > 0) { ctx->doomed = true; return; }     // dsa_batch_free of the last batch comes back here
   (void)hipSetDevice(ctx->device);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -225,6 +322,10 @@ void dsa_context_destroy(dsa_context *ctx) {
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
   if (ctx->stream4) (void)hipStreamDestroy(ctx->stream4);
+  if (ctx->up) { (void)hipStreamSynchronize(ctx->up); (void)hipStreamDestroy(ctx->up); }
+  if (ctx->down) { (void)hipStreamSynchronize(ctx->down); (void)hipStreamDestroy(ctx->down); }
+  drop_spares(ctx->spare_arenas, false);
+  drop_spares(ctx->spare_mirrors, true);
   if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
   if (ctx->ev_trav) (void)hipEventDestroy(ctx->ev_trav);
   if (ctx->ev_maps) (void)hipEventDestroy(ctx->ev_maps);
@@ -275,8 +376,12 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   b->collected = false;
   if (b->retry) { dsa_batch_free(b->retry); b->retry = nullptr; }
   b->retry_index.clear();
-  if (n == 0) return DSA_OK;
   hipStream_t st = ctx->stream;
+  if (n == 0) {
+    HIP_TRY(ctx, hipEventRecord(b->ev_done, st));
+    HIP_TRY(ctx, hipEventRecord(b->ev_descs, st));
+    return DSA_OK;
+  }
   const bool prof = ctx->profiling;
   if (prof && !b->have_events) {
     for (int i = 0; i <= DSA_NUM_STAGES; ++i) HIP_TRY(ctx, hipEventCreate(&b->ev[i]));
@@ -285,8 +390,11 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   }
   int evi = 0;
   auto mark = [&]() -> hipError_t { return prof ? hipEventRecord(b->ev[evi++], st) : hipSuccess; };
+  if (b->download_queued && !b->downloaded) HIP_TRY(ctx, hipStreamWaitEvent(st, b->ev_down, 0));   // a download of the previous decode still reads the arena
+  b->download_queued = false; b->downloaded = false;
+  HIP_TRY(ctx, hipStreamWaitEvent(st, b->ev_uploaded, 0));           // the streams and layouts are in the arena
   HIP_TRY(ctx, hipMemsetAsync(b->d_descs, 0, sizeof(MeshDesc) * n, st));
-  HIP_TRY(ctx, hipMemcpyAsync(b->d_globals, &b->globals, sizeof(BatchGlobals), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemsetAsync(&b->d_globals->pool_cursor, 0, sizeof(unsigned long long) * 2, st));   // the table pool starts empty
   HIP_TRY(ctx, mark());
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
@@ -458,6 +566,11 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   hipLaunchKernelGGL(dsa::k_seal, dim3((n + 255) / 256), dim3(256), 0, st, b->d_descs, n);
   HIP_TRY(ctx, mark());
   HIP_TRY(ctx, hipGetLastError());
+  // every other stream has joined `st` by now: this event is the whole decode.  The descriptors follow on the download stream.
+  HIP_TRY(ctx, hipEventRecord(b->ev_done, st));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->down, b->ev_done, 0));
+  HIP_TRY(ctx, hipMemcpyAsync(b->descs_pin, b->d_descs, sizeof(MeshDesc) * n, hipMemcpyDeviceToHost, ctx->down));
+  HIP_TRY(ctx, hipEventRecord(b->ev_descs, ctx->down));
   return DSA_OK;
 }
 
@@ -470,11 +583,15 @@ static dsa_status batch_wait(dsa_batch *b) {
   dsa_context *ctx = b->ctx;
   if (!b->decoded) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "dsa_batch_decode was not called");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream3));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream4));
-  if (b->n) HIP_TRY(ctx, hipMemcpy(b->descs.data(), b->d_descs, sizeof(MeshDesc) * b->n, hipMemcpyDeviceToHost));
+  if (b->collected) {                  // results are in; what can still be outstanding is a download queued since
+    if (b->download_queued && !b->downloaded) { HIP_TRY(ctx, hipEventSynchronize(b->ev_down)); b->downloaded = true; }
+    if (b->retry) return dsa_batch_wait(b->retry);
+    return DSA_OK;
+  }
+  // this batch's own events, not the streams: another batch of the context may be queued behind it
+  HIP_TRY(ctx, hipEventSynchronize(b->ev_descs));
+  if (b->download_queued) { HIP_TRY(ctx, hipEventSynchronize(b->ev_down)); b->downloaded = true; }
+  if (b->n) memcpy(b->descs.data(), b->descs_pin, sizeof(MeshDesc) * (size_t)b->n);
   if (ctx->profiling && b->have_events && b->n) {
     for (int i = 0; i < STG_TOTAL; ++i) HIP_TRY(ctx, hipEventElapsedTime(&b->stage_ms[i], b->ev[i], b->ev[i + 1]));
     // the symbol stage runs on the second stream: its own event pair (the slot on the main stream is the join wait)
@@ -506,6 +623,7 @@ static dsa_status batch_wait(dsa_batch *b) {
       dsa_batch *rb = nullptr;
       dsa_status st = build_batch(ctx, (uint32_t)again.size(), ptrs.data(), lens.data(), &rb, true);
       if (st == DSA_OK) st = dsa_batch_decode(rb);
+      if (st == DSA_OK && b->download_queued) st = dsa_batch_download(rb, nullptr, 0);      // block 1 of the download
       if (st == DSA_OK) st = dsa_batch_wait(rb);
       if (st != DSA_OK) { if (rb) dsa_batch_free(rb); b->collected = false; return st; }
       b->retry = rb;
@@ -522,11 +640,17 @@ void dsa_batch_free(dsa_batch *b) {
   if (b->retry) { dsa_batch_free(b->retry); b->retry = nullptr; }
   if (b->have_events) for (int i = 0; i <= DSA_NUM_STAGES; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
   if (b->have_events) for (int i = 0; i < 2; ++i) if (b->ev_sym[i]) (void)hipEventDestroy(b->ev_sym[i]);
-  if (b->arena) (void)hipFree(b->arena);
-  if (b->d_layouts) (void)hipFree(b->d_layouts);
-  if (b->d_descs) (void)hipFree(b->d_descs);
-  if (b->d_globals) (void)hipFree(b->d_globals);
+  // nothing of this batch may still be in flight when its arena goes back to the cache (a caller may free without waiting)
+  if (b->ev_uploaded) { (void)hipEventSynchronize(b->ev_uploaded); (void)hipEventDestroy(b->ev_uploaded); }
+  if (b->ev_done) { if (b->decoded) (void)hipEventSynchronize(b->ev_done); (void)hipEventDestroy(b->ev_done); }
+  if (b->ev_descs) { if (b->decoded) (void)hipEventSynchronize(b->ev_descs); (void)hipEventDestroy(b->ev_descs); }
+  if (b->ev_down) { if (b->download_queued) (void)hipEventSynchronize(b->ev_down); (void)hipEventDestroy(b->ev_down); }
+  if (b->descs_pin) (void)hipHostFree(b->descs_pin);
+  if (b->mirror && b->mirror_owned) give_spare(b->ctx->spare_mirrors, b->mirror, b->mirror_bytes, [](uint8_t *p) { (void)hipHostFree(p); });
+  give_spare(b->ctx->spare_arenas, b->arena, b->arena_cap, [](uint8_t *p) { (void)hipFree(p); });
+  dsa_context *ctx = b->ctx;
   delete b;
+  if (--ctx->live_batches == 0 && ctx->doomed) dsa_context_destroy(ctx);
 }
 
 uint32_t dsa_batch_size(const dsa_batch *b) { return b ? b->n : 0; }
@@ -596,6 +720,10 @@ dsa_status dsa_batch_attribute_info(const dsa_batch *b, uint32_t mesh, uint32_t 
 static dsa_status copy_out(const dsa_batch *b, void *dst, uint64_t off, uint64_t bytes) {
   if (!dst) return DSA_ERR_INVALID_ARGUMENT;
   if (bytes == 0) return DSA_OK;
+  if (b->downloaded && off >= b->out_base && off + bytes <= b->out_base + b->out_bytes) {     // already on the host
+    memcpy(dst, b->mirror + (off - b->out_base), (size_t)bytes);
+    return DSA_OK;
+  }
   HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
   HIP_TRY(b->ctx, hipMemcpy(dst, b->arena + off, bytes, hipMemcpyDeviceToHost));
   return DSA_OK;
@@ -640,6 +768,80 @@ const uint32_t *dsa_batch_device_point_map(const dsa_batch *b, uint32_t mesh, ui
   FOLLOW_RETRY(b, mesh, dsa_batch_device_point_map(rb_, rm_, a));
   if (!b || mesh >= b->n || !b->collected || b->descs[mesh].status != ST_OK || a >= b->descs[mesh].num_attributes) return nullptr;
   return (const uint32_t *)(b->arena + b->layouts[mesh].map[a]);
+}
+
+// ---- whole-batch results on the host: one transfer of the output block
+uint64_t dsa_batch_output_bytes(const dsa_batch *b) { return b ? b->out_bytes : 0; }
+
+dsa_status dsa_batch_download(dsa_batch *b, void *dst, size_t dst_bytes) {
+  if (!b) return DSA_ERR_INVALID_ARGUMENT;
+  dsa_context *ctx = b->ctx;
+  if (!b->decoded) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "dsa_batch_decode was not called");
+  if (b->download_queued) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "the batch is already being downloaded");
+  if (dst && dst_bytes < b->out_bytes) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "destination smaller than dsa_batch_output_bytes");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (b->mirror && b->mirror_owned && dst) { give_spare(ctx->spare_mirrors, b->mirror, b->mirror_bytes, [](uint8_t *p) { (void)hipHostFree(p); }); b->mirror = nullptr; }
+  if (dst) { b->mirror = (uint8_t *)dst; b->mirror_bytes = dst_bytes; b->mirror_owned = false; }
+  else if (!b->mirror || !b->mirror_owned) {
+    const uint64_t need = b->out_bytes ? b->out_bytes : 256;
+    uint64_t got = 0;
+    uint8_t *p = take_spare(ctx->spare_mirrors, need, &got);
+    if (!p) {
+      hipError_t e = hipHostMalloc((void **)&p, need, hipHostMallocDefault);
+      if (e != hipSuccess && !ctx->spare_mirrors.empty()) { (void)hipGetLastError(); drop_spares(ctx->spare_mirrors, true); e = hipHostMalloc((void **)&p, need, hipHostMallocDefault); }
+      if (e != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "pinned host mirror of %llu bytes: %s", (unsigned long long)need, hipGetErrorString(e)); }
+      got = need;
+    }
+    b->mirror = p; b->mirror_bytes = got; b->mirror_owned = true;
+  }
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->down, b->ev_done, 0));
+  // in pieces, so that a transfer of gigabytes does not hold the engine against the descriptors of the batch behind it
+  const uint64_t piece = 256ull << 20;
+  for (uint64_t at = 0; at < b->out_bytes; at += piece)
+    HIP_TRY(ctx, hipMemcpyAsync(b->mirror + at, b->arena + b->out_base + at, (size_t)std::min(piece, b->out_bytes - at), hipMemcpyDeviceToHost, ctx->down));
+  HIP_TRY(ctx, hipEventRecord(b->ev_down, ctx->down));
+  b->download_queued = true;
+  b->downloaded = false;
+  if (b->retry && !b->retry->download_queued) return dsa_batch_download(b->retry, nullptr, 0);   // block 1: the meshes decoded a second time
+  return DSA_OK;
+}
+
+const void *dsa_batch_host_output(const dsa_batch *b, uint32_t block) {
+  if (!b || !b->downloaded) return nullptr;
+  if (block == 0) return b->mirror;
+  if (block == 1 && b->retry && b->retry->downloaded) return b->retry->mirror;
+  return nullptr;
+}
+
+dsa_status dsa_batch_output_layout(const dsa_batch *b, uint32_t mesh, dsa_mesh_output *out) {
+  CHECK_MESH(b, mesh);
+  if (!out) return DSA_ERR_INVALID_ARGUMENT;
+  memset(out, 0, sizeof(*out));
+  const dsa_batch *src = b;
+  uint32_t m = mesh;
+  if (b->retry && b->retry_index[mesh] >= 0) { src = b->retry; m = (uint32_t)b->retry_index[mesh]; out->block = 1; }
+  const MeshLayout &L = src->layouts[m];
+  out->faces = L.faces - src->out_base;
+  for (uint32_t a = 0; a < L.cap_attributes && a < DSA_MAX_ATTRIBUTES; ++a) { out->values[a] = L.out[a] - src->out_base; out->point_map[a] = L.map[a] - src->out_base; }
+  return DSA_OK;
+}
+
+void *dsa_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void dsa_host_free(void *p) { if (p) (void)hipHostFree(p); }
+dsa_status dsa_host_register(void *p, size_t bytes) {
+  if (!p || !bytes) return DSA_ERR_INVALID_ARGUMENT;
+  const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE; }
+  return DSA_OK;
+}
+dsa_status dsa_host_unregister(void *p) {
+  if (!p) return DSA_ERR_INVALID_ARGUMENT;
+  if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return DSA_ERR_DEVICE; }
+  return DSA_OK;
 }
 
 dsa_status dsa_batch_copy_metadata(const dsa_batch *b, uint32_t mesh, uint8_t *dst, size_t dst_bytes, size_t *length) {

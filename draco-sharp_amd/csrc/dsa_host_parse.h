@@ -216,14 +216,17 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 
 // Places the regions of one mesh behind `cur` (arena offset) and returns the new end.  `slack` bytes are left
 // after every region (the kernels over-read whole 16-byte words; the host check passes a larger red zone).
+// `out_cur` (optional): the arrays a caller receives -- faces, attribute values, point maps -- are placed behind *out_cur instead
+// (offsets relative to the batch's output block, which dsa_api.hip puts behind all scratch so that one transfer downloads it).
 static inline uint64_t layout_mesh(const HostMesh &h, uint64_t stream_len, MeshLayout &L, uint64_t cur, uint64_t slack,
-                                   std::vector<std::pair<uint64_t, uint64_t>> *regions = nullptr) {
+                                   std::vector<std::pair<uint64_t, uint64_t>> *regions = nullptr, uint64_t *out_cur = nullptr) {
   const uint64_t F = h.faces, V = (uint64_t)h.enc_vertices + h.split_symbols;
   L.cap_faces = (uint32_t)F;
   L.cap_vertices = (uint32_t)V;
   L.cap_attributes = (uint32_t)h.atts.size();
   L.cap_splits = h.splits;
   auto take = [&](uint64_t bytes) { uint64_t at = cur; cur = align_up(cur + bytes + slack, 256); if (regions) regions->push_back({at, bytes}); return at; };
+  auto take_out = [&](uint64_t bytes) { if (!out_cur) return take(bytes); uint64_t at = *out_cur; *out_cur = align_up(*out_cur + bytes + slack, 256); return at; };
   L.frec = take(32 * F);
   L.vrec = take(8 * V);
   L.d2c = take(4 * V); L.v2d = take(4 * V);
@@ -231,7 +234,7 @@ static inline uint64_t layout_mesh(const HostMesh &h, uint64_t stream_len, MeshL
   L.fstamp = take(4 * F); L.vstamp = take(4 * V);
   L.splits = take(16ull * h.splits);
   L.vrank = take(4 * V); L.para = take(12 * V);
-  L.faces = take(12 * F);
+  L.faces = take_out(12 * F);
   // general path: corner attributes carry up to 3F entries, and seams up to 3F points
   const uint64_t P = (h.general && h.num_att_data > 0) ? std::max<uint64_t>(3 * F, V) : V;
   L.cap_points = (uint32_t)P;
@@ -247,8 +250,8 @@ static inline uint64_t layout_mesh(const HostMesh &h, uint64_t stream_len, MeshL
     uint64_t wcap = E * ncp, ocap = E * A.nc * dt_len(A.data_type);
     if (ocap < V) ocap = V;                  // tag bytes of the tagged scheme are staged here
     L.work[a] = take(4 * wcap); L.work_cap[a] = (uint32_t)wcap;
-    L.out[a] = take(ocap); L.out_cap[a] = (uint32_t)(ocap > 0xFFFFFFFFu ? 0xFFFFFFFFu : ocap);
-    L.map[a] = take(4 * P);
+    L.out[a] = take_out(ocap); L.out_cap[a] = (uint32_t)(ocap > 0xFFFFFFFFu ? 0xFFFFFFFFu : ocap);
+    L.map[a] = take_out(4 * P);
   }
   return cur;
 }

@@ -630,9 +630,10 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
     D->dbg[13] = (uint32_t)(clk() - t_start); D->dbg[14] = (uint32_t)r_start; D->dbg[15] = (uint32_t)(realclk() - r_start);
     D->num_all_vertices = NVALL;
 #ifdef DSA_LOOP_PROFILE
-    D->dbg[5] = (uint32_t)(acc_c / (n_c ? n_c : 1)); D->dbg[6] = (uint32_t)(acc_rl / (n_rl ? n_rl : 1));
-    D->dbg[7] = (uint32_t)(acc_fetch / (n_c + n_rl + 1)); D->dbg[8] = n_c; D->dbg[9] = n_rl;
+    // (slots the traversal half of k_chain does not overwrite)
     D->dbg[10] = prof_run_syms | (prof_runs << 20); D->dbg[11] = n_c | (n_rl << 16);
+    D->dbg[12] = (uint32_t)(acc_c / (n_c ? n_c : 1)); D->dbg[18] = (uint32_t)(acc_rl / (n_rl ? n_rl : 1));
+    D->dbg[19] = (uint32_t)(acc_fetch / (n_c + n_rl + 1));
 #endif
   }
 #undef CN_FAIL
@@ -1643,7 +1644,9 @@ __global__ __launch_bounds__(WAVE) void k_symbols_wide(uint8_t *arena, const Mes
   for (int r = 0; r < 32; ++r) {
     const uint32_t i = (uint32_t)r * WAVE + lane;
     const uint32_t c0 = i < nsym ? gtab[i] : 0x1FFFFu, c1 = i < nsym ? gtab[i + 1] : 0x1FFFFu;      // gtab[nsym] = precision (set below)
-    tab[r] = i < nsym ? (c0 | ((c1 - c0) << 16)) : 0xFFFFFFFFu;
+    // entries of zero frequency at the end of a non-compact table have cum = precision: at 16 bits that is 0x10000, whose low half
+    // (0) would count for every rem -- they are padding as well (the reference's slot table, RAnsSymbolDecoder.cs:50-59, never maps to them)
+    tab[r] = (i < nsym && c0 < 0x10000u) ? (c0 | ((c1 - c0) << 16)) : 0xFFFFFFFFu;
   }
   const uint32_t coarse = lane < nblocks ? gtab[lane * WAVE] : 0xFFFFFFFFu;     // lane l: first cumulative frequency of block l
   // 4. initial state from the stream tail

@@ -6,6 +6,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <numeric>
 #include <thread>
 
@@ -13,10 +14,14 @@ struct dsa_pool {
   std::vector<dsa_context *> ctx;
   uint32_t chunk = 256;
   std::string err;
+  std::mutex busy;                       // one dsa_pool_decode at a time
+  std::atomic<uint32_t> live_jobs{0};    // jobs not yet freed: their batches point at this pool's contexts
+  bool doomed = false;                   // dsa_pool_destroy was called while jobs were alive: the last job frees the pool
 };
 
 struct dsa_pool_job {
   struct Where { uint32_t chunk, index; };
+  dsa_pool *pool = nullptr;
   std::vector<dsa_batch *> batches;      // one per chunk
   std::vector<uint32_t> worker;          // which context decoded the chunk
   std::vector<Where> where;              // per stream of the job
@@ -54,23 +59,54 @@ dsa_status dsa_pool_create(const int *devices, uint32_t num_devices, uint32_t ch
   DSA_GUARD((dsa_context *)nullptr, pool_create(devices, num_devices, chunk_meshes, out));
 }
 
-void dsa_pool_destroy(dsa_pool *pool) {
-  if (!pool) return;
+static void pool_really_destroy(dsa_pool *pool) {
   for (dsa_context *c : pool->ctx) dsa_context_destroy(c);
   delete pool;
+}
+// Jobs hold batches that live on the pool's contexts: a pool destroyed before its jobs stays alive until the last of them is
+// freed (the order of the two calls does not matter to the caller).
+void dsa_pool_destroy(dsa_pool *pool) {
+  if (!pool) return;
+  bool now;
+  { std::lock_guard<std::mutex> g(pool->busy); pool->doomed = true; now = pool->live_jobs.load() == 0; }
+  if (now) pool_really_destroy(pool);
 }
 uint32_t dsa_pool_size(const dsa_pool *pool) { return pool ? (uint32_t)pool->ctx.size() : 0; }
 const char *dsa_pool_last_error(const dsa_pool *pool) { return pool ? pool->err.c_str() : "null pool"; }
 
-void dsa_pool_job_free(dsa_pool_job *job) {
-  if (!job) return;
+static void job_release(dsa_pool_job *job) {
   for (dsa_batch *b : job->batches) if (b) dsa_batch_free(b);
   delete job;
 }
+void dsa_pool_job_free(dsa_pool_job *job) {
+  if (!job) return;
+  dsa_pool *pool = job->pool;
+  job_release(job);
+  if (!pool) return;
+  bool last;
+  { std::lock_guard<std::mutex> g(pool->busy); last = pool->live_jobs.fetch_sub(1) == 1 && pool->doomed; }
+  if (last) pool_really_destroy(pool);
+}
 uint32_t dsa_pool_job_chunks(const dsa_pool_job *job) { return job ? (uint32_t)job->batches.size() : 0; }
 
+// Joins every thread it holds when it goes out of scope, whatever path leaves the function (a std::thread destroyed while
+// joinable calls std::terminate).
+struct JoinAll {
+  std::vector<std::thread> threads;
+  ~JoinAll() { for (std::thread &t : threads) if (t.joinable()) t.join(); }
+};
+struct JobOwner {       // frees the job (and the batches it holds) unless released
+  dsa_pool_job *job;
+  ~JobOwner() { if (job) job_release(job); }        // never counted among the pool's live jobs
+  dsa_pool_job *release() { dsa_pool_job *j = job; job = nullptr; return j; }
+};
+
+// One decode at a time per pool (the contexts' streams and events are not shared between concurrent jobs): pool->busy.
 static dsa_status pool_decode(dsa_pool *pool, uint32_t n, const uint8_t *const *streams, const size_t *lengths, dsa_pool_job **out) {
-  dsa_pool_job *job = new dsa_pool_job();
+  std::lock_guard<std::mutex> one_job(pool->busy);
+  JobOwner owner{new dsa_pool_job()};
+  dsa_pool_job *job = owner.job;
+  job->pool = pool;
   std::vector<uint32_t> order(n), begin(n + 1);
   const uint32_t chunks = dsa_pool_plan(n, lengths, pool->chunk, order.data(), begin.data());
   job->batches.assign(chunks, nullptr);
@@ -81,34 +117,59 @@ static dsa_status pool_decode(dsa_pool *pool, uint32_t n, const uint8_t *const *
   std::atomic<uint32_t> next{0};
   std::atomic<int> failed{DSA_OK};
   std::vector<std::string> errs(pool->ctx.size());
-  auto work = [&](uint32_t w) {
-    dsa_context *ctx = pool->ctx[w];
-    std::vector<const uint8_t *> ptrs;
-    std::vector<size_t> lens;
-    for (;;) {
-      const uint32_t c = next.fetch_add(1, std::memory_order_relaxed);
-      if (c >= chunks || failed.load(std::memory_order_relaxed) != DSA_OK) break;
-      ptrs.clear(); lens.clear();
-      for (uint32_t k = begin[c]; k < begin[c + 1]; ++k) { ptrs.push_back(streams[order[k]]); lens.push_back(lengths[order[k]]); }
-      dsa_batch *b = nullptr;
-      dsa_status st = dsa_batch_create(ctx, (uint32_t)ptrs.size(), ptrs.data(), lens.data(), &b);
-      if (st == DSA_OK) st = dsa_batch_decode(b);
-      if (st == DSA_OK) st = dsa_batch_wait(b);
-      job->batches[c] = b;
-      job->worker[c] = w;
-      if (st != DSA_OK) { errs[w] = dsa_last_error(ctx); failed.store(st, std::memory_order_relaxed); break; }
+  // A worker keeps two chunks in flight on its context: while the kernels of chunk k run, the streams of chunk k + 1 are parsed,
+  // staged and uploaded (dsa_batch_create) and its kernels queued behind; then chunk k is collected.  No exception leaves a worker:
+  // a failed host allocation or anything else becomes the job's status.
+  auto work = [&](uint32_t w) noexcept {
+    try {
+      dsa_context *ctx = pool->ctx[w];
+      std::vector<const uint8_t *> ptrs;
+      std::vector<size_t> lens;
+      dsa_batch *inflight = nullptr;
+      auto collect = [&]() {
+        if (!inflight) return;
+        const dsa_status st = dsa_batch_wait(inflight);
+        inflight = nullptr;
+        if (st != DSA_OK) { errs[w] = dsa_last_error(ctx); int ok = DSA_OK; failed.compare_exchange_strong(ok, st); }
+      };
+      for (;;) {
+        const uint32_t c = next.fetch_add(1, std::memory_order_relaxed);
+        if (c >= chunks || failed.load(std::memory_order_relaxed) != DSA_OK) break;
+        ptrs.clear(); lens.clear();
+        for (uint32_t k = begin[c]; k < begin[c + 1]; ++k) { ptrs.push_back(streams[order[k]]); lens.push_back(lengths[order[k]]); }
+        dsa_batch *b = nullptr;
+        dsa_status st = dsa_batch_create(ctx, (uint32_t)ptrs.size(), ptrs.data(), lens.data(), &b);
+        job->batches[c] = b;                 // owned by the job from here on, whatever happens next
+        job->worker[c] = w;
+        if (st == DSA_OK) st = dsa_batch_decode(b);
+        if (st != DSA_OK) { errs[w] = dsa_last_error(ctx); int ok = DSA_OK; failed.compare_exchange_strong(ok, st); break; }
+        collect();                           // the previous chunk, whose kernels ran while this one was prepared
+        inflight = b;
+      }
+      collect();
+    } catch (const std::bad_alloc &) {
+      int ok = DSA_OK; failed.compare_exchange_strong(ok, DSA_ERR_OUT_OF_MEMORY);
+    } catch (...) {
+      int ok = DSA_OK; failed.compare_exchange_strong(ok, DSA_ERR_DEVICE);
     }
   };
-  std::vector<std::thread> threads;
-  for (uint32_t w = 1; w < pool->ctx.size(); ++w) threads.emplace_back(work, w);
-  work(0);                                   // the calling thread is worker 0
-  for (std::thread &t : threads) t.join();
+  {
+    JoinAll workers;
+    workers.threads.reserve(pool->ctx.size());
+    try {
+      for (uint32_t w = 1; w < pool->ctx.size(); ++w) workers.threads.emplace_back(work, w);
+    } catch (...) {                          // a thread could not be started: the ones that run finish the job between them
+      if (workers.threads.empty() && pool->ctx.size() > 1) pool->err = "worker threads could not be started; decoding on one device";
+    }
+    work(0);                                 // the calling thread is worker 0
+  }                                          // joined here
   if (failed.load() != DSA_OK) {
+    pool->err = "a worker failed";
     for (const std::string &e : errs) if (!e.empty()) { pool->err = e; break; }
-    dsa_pool_job_free(job);
-    return (dsa_status)failed.load();
+    return (dsa_status)failed.load();        // the owner frees the job and its batches
   }
-  *out = job;
+  pool->live_jobs.fetch_add(1, std::memory_order_relaxed);
+  *out = owner.release();
   return DSA_OK;
 }
 dsa_status dsa_pool_decode(dsa_pool *pool, uint32_t n, const uint8_t *const *streams, const size_t *lengths, dsa_pool_job **out) {

@@ -290,6 +290,53 @@ class Batch:
         if st != 0:
             _raise(st, self.ctx.error())
 
+    def download(self, wait=True):
+        """Queues ONE device -> host transfer of every output array of the batch (faces, attribute values, point maps) into a
+        pinned mirror the library owns, behind the batch's kernels (dsa_batch_download); result() and host_views() then read the
+        mirror instead of copying array by array."""
+        st = self._L.dsa_batch_download(self._h, None, 0)
+        if st != 0:
+            _raise(st, self.ctx.error())
+        if wait:
+            self.wait()
+
+    @property
+    def output_bytes(self):
+        return int(self._L.dsa_batch_output_bytes(self._h))
+
+    def host_views(self, i):
+        """Zero-copy numpy views of mesh i's arrays in the downloaded output block: {"faces": int32[F, 3], "attributes":
+        [{"values": [entries, components], "point_map": uint32[points]}]}.  Valid until the batch is closed or decoded again."""
+        L = self._L
+        info = self.mesh_info(i)
+        if info.status != 0:
+            _raise(info.status, "stream %d: decode failed (status %d, site %d)" % (i, info.status, info.detail))
+        lay = native.MeshOutput()
+        st = L.dsa_batch_output_layout(self._h, i, C.byref(lay))
+        if st != 0:
+            _raise(st, self.ctx.error())
+        base = L.dsa_batch_host_output(self._h, lay.block)
+        if not base:
+            raise RuntimeError("the batch has not been downloaded (Batch.download)")
+
+        def view(off, count, dtype, shape):
+            if count == 0:
+                return np.zeros(shape, dtype)
+            nbytes = count * np.dtype(dtype).itemsize
+            return np.frombuffer((C.c_uint8 * nbytes).from_address(base + off), dtype, count).reshape(shape)
+
+        out = {"faces": view(lay.faces, info.num_faces * 3, np.int32, (info.num_faces, 3)), "attributes": []}
+        for a in range(info.num_attributes):
+            ai = native.AttributeInfo()
+            st = L.dsa_batch_attribute_info(self._h, i, a, C.byref(ai))
+            if st != 0:
+                _raise(st, self.ctx.error())
+            out["attributes"].append({
+                "info": ai,
+                "values": view(lay.values[a], ai.num_entries * ai.num_components, _DT_NUMPY[ai.data_type], (ai.num_entries, ai.num_components)),
+                "point_map": view(lay.point_map[a], info.num_points, np.uint32, (info.num_points,))})
+        return out
+
     @property
     def algorithmic_bytes(self):
         return int(self._L.dsa_batch_algorithmic_bytes(self._h))
@@ -546,11 +593,20 @@ class Pool:
     def error(self):
         return self._L.dsa_pool_last_error(self._h).decode() if self._h else "pool closed"
 
-    def decode(self, streams):
-        n = len(streams)
-        bufs = [(C.c_uint8 * max(1, len(s))).from_buffer_copy(s if len(s) else b"\0") for s in streams]
-        ptrs = (C.c_void_p * max(1, n))(*[C.addressof(b) for b in bufs])
-        lens = (C.c_size_t * max(1, n))(*[len(s) for s in streams])
+    def decode(self, streams=None, blob=None, offsets=None):
+        if blob is not None:                    # streams back to back in one array: no per-stream copies
+            blob = np.ascontiguousarray(blob, np.uint8)
+            offsets = np.ascontiguousarray(offsets, np.uint64)
+            n = len(offsets) - 1
+            addr = (offsets[:-1] + np.uint64(blob.ctypes.data)).astype(np.uint64)
+            size = np.diff(offsets).astype(np.uint64)
+            ptrs = C.cast(addr.ctypes.data, C.POINTER(C.c_void_p))
+            lens = C.cast(size.ctypes.data, C.POINTER(C.c_size_t))
+        else:
+            n = len(streams)
+            bufs = [(C.c_uint8 * max(1, len(s))).from_buffer_copy(s if len(s) else b"\0") for s in streams]
+            ptrs = (C.c_void_p * max(1, n))(*[C.addressof(b) for b in bufs])
+            lens = (C.c_size_t * max(1, n))(*[len(s) for s in streams])
         h = C.c_void_p()
         st = self._L.dsa_pool_decode(self._h, n, ptrs, lens, C.byref(h))
         if st != 0:

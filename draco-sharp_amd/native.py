@@ -17,7 +17,8 @@ EXPORTS = [
     "dsa_batch_size", "dsa_batch_algorithmic_bytes", "dsa_batch_arena_bytes", "dsa_batch_mesh_info",
     "dsa_batch_attribute_info", "dsa_batch_copy_faces", "dsa_batch_copy_attribute_values", "dsa_batch_copy_point_map",
     "dsa_batch_copy_portable_values", "dsa_batch_device_faces", "dsa_batch_device_attribute_values",
-    "dsa_batch_device_point_map", "dsa_batch_copy_metadata", "dsa_batch_copy_debug", "dsa_context_set_profiling", "dsa_batch_stage_times",
+    "dsa_batch_device_point_map", "dsa_batch_output_bytes", "dsa_batch_download", "dsa_batch_host_output", "dsa_batch_output_layout",
+    "dsa_host_alloc", "dsa_host_free", "dsa_host_register", "dsa_host_unregister", "dsa_batch_copy_metadata", "dsa_batch_copy_debug", "dsa_context_set_profiling", "dsa_batch_stage_times",
     "dsa_encode_default_options", "dsa_encode_batch", "dsa_encoded_size", "dsa_encoded_stream", "dsa_encoded_free",
     "dsa_pool_create", "dsa_pool_destroy", "dsa_pool_size", "dsa_pool_last_error", "dsa_pool_decode", "dsa_pool_job_locate",
     "dsa_pool_job_chunks", "dsa_pool_job_free", "dsa_pool_plan",
@@ -42,6 +43,10 @@ class MeshInfo(C.Structure):
                 ("drc_bytes", C.c_uint64)]
 
 
+class MeshOutput(C.Structure):
+    _fields_ = [("block", C.c_uint32), ("reserved", C.c_uint32), ("faces", C.c_uint64), ("values", C.c_uint64 * 16), ("point_map", C.c_uint64 * 16)]
+
+
 class AttributeInfo(C.Structure):
     _fields_ = [("attribute_type", C.c_int32), ("data_type", C.c_int32), ("num_components", C.c_int32),
                 ("normalized", C.c_int32), ("unique_id", C.c_uint32), ("num_entries", C.c_uint32),
@@ -52,11 +57,8 @@ class AttributeInfo(C.Structure):
 
 def build(force=False):
     """Compiles the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_DIR, f) for f in ("dsa_api.hip", "dsa_kernels.h", "dsa_general.h", "dsa_common.h", "dsa_host_parse.h",
-                                            "dsa_encode.h", "dsa_encode_host.h", "dsa_types.h", "dsa_lanes.h", "dsa_locate.h", "dsa_pool.h")]
-    srcs.append(os.path.join(_DIR, "..", "..", "include", "draco_mi355x.h"))
-    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["make", "-C", _DIR, "-s"])
+    # make knows the prerequisites (compiler-written depfile)
+    subprocess.check_call(["make", "-C", _DIR, "-s"] + (["-B"] if force else []))
     return LIB_PATH
 
 
@@ -99,6 +101,18 @@ def lib():
         for f in ("dsa_batch_device_attribute_values", "dsa_batch_device_point_map"):
             getattr(L, f).restype = vp
             getattr(L, f).argtypes = [vp, u32, u32]
+        L.dsa_batch_output_bytes.restype = C.c_uint64
+        L.dsa_batch_output_bytes.argtypes = [vp]
+        L.dsa_batch_download.argtypes = [vp, vp, C.c_size_t]
+        L.dsa_batch_host_output.restype = vp
+        L.dsa_batch_host_output.argtypes = [vp, u32]
+        L.dsa_batch_output_layout.argtypes = [vp, u32, C.POINTER(MeshOutput)]
+        L.dsa_host_alloc.restype = vp
+        L.dsa_host_alloc.argtypes = [C.c_size_t]
+        L.dsa_host_free.restype = None
+        L.dsa_host_free.argtypes = [vp]
+        L.dsa_host_register.argtypes = [vp, C.c_size_t]
+        L.dsa_host_unregister.argtypes = [vp]
         L.dsa_batch_copy_metadata.argtypes = [vp, u32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.dsa_batch_copy_debug.argtypes = [vp, u32, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.dsa_context_set_profiling.argtypes = [vp, C.c_int]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DSA_ABI_VERSION 1
+#define DSA_ABI_VERSION 2
 #define DSA_MAX_ATTRIBUTES 16  /* attributes per mesh handled by the device path; more: DSA_ERR_NOT_IMPLEMENTED */
 #define DSA_NUM_STAGES 8
 
@@ -91,8 +91,12 @@ void dsa_context_destroy(dsa_context *ctx);
 const char *dsa_last_error(const dsa_context *ctx);
 
 /* Builds a batch from n host-resident .drc streams: parses the fixed headers to
- * size the device arena, allocates it and uploads the compressed bytes.  The
- * streams are copied; the caller's buffers are not referenced afterwards. */
+ * size the device arena, takes it from the context's cache (or allocates it) and
+ * queues the upload of the compressed bytes.  The streams are copied into pinned
+ * staging memory before the call returns -- the caller's buffers are not
+ * referenced afterwards -- and travel in one DMA on the context's upload stream,
+ * beside the kernels of a batch decoded meanwhile; dsa_batch_decode orders its
+ * kernels behind that transfer. */
 dsa_status dsa_batch_create(dsa_context *ctx, uint32_t n, const uint8_t *const *streams, const size_t *lengths,
                             dsa_batch **out);
 /* Same, for streams stored back to back in one blob: stream i is
@@ -103,7 +107,11 @@ dsa_status dsa_batch_create_packed(dsa_context *ctx, uint32_t n, const uint8_t *
  * HBM -> faces, attribute values and point maps in HBM) on the context's
  * stream.  Asynchronous. */
 dsa_status dsa_batch_decode(dsa_batch *batch);
-/* Waits for the decode and collects the per-mesh results. */
+/* Waits for the decode (and for a download queued with dsa_batch_download) and collects
+ * the per-mesh results.  Waits for this batch only: another batch of the same context may
+ * be queued behind it (upload of batch k+1 beside the kernels of batch k beside the
+ * download of batch k-1 is the intended use; a context keeps up to three arenas and
+ * pinned mirrors of freed batches for that). */
 dsa_status dsa_batch_wait(dsa_batch *batch);
 void dsa_batch_free(dsa_batch *batch);
 
@@ -123,6 +131,34 @@ dsa_status dsa_batch_copy_attribute_values(const dsa_batch *batch, uint32_t mesh
 dsa_status dsa_batch_copy_point_map(const dsa_batch *batch, uint32_t mesh, uint32_t attribute, uint32_t *dst /* num_points */);
 /* Portable (pre-transform) int32 values, for integer-exactness checks. */
 dsa_status dsa_batch_copy_portable_values(const dsa_batch *batch, uint32_t mesh, uint32_t attribute, int32_t *dst);
+
+/* Whole-batch copy-out, what DracoDecoder.Decode's caller needs (src/Draco/IO/DracoDecoder.cs:19-42 returns host
+ * objects: Mesh.Faces, PointAttribute buffers, src/Draco/IO/Attributes/PointAttribute.cs:38-63).  The arrays a caller
+ * receives -- faces, attribute values and point maps of every mesh -- lie in one block of the batch's arena
+ * (dsa_batch_output_bytes long).  dsa_batch_download queues ONE device -> host transfer of that block on the context's
+ * download stream, ordered behind the batch's kernels, into `dst` (at least dsa_batch_output_bytes; pinned memory --
+ * dsa_host_alloc or dsa_host_register -- for the link's full rate) or, with dst == NULL, into a pinned mirror the library
+ * owns (valid until dsa_batch_free or the next dsa_batch_decode of the batch).  Asynchronous: dsa_batch_wait waits for it.
+ * dsa_batch_output_layout gives the byte offsets of a mesh's arrays inside the block (array lengths: dsa_batch_mesh_info /
+ * dsa_batch_attribute_info).  Meshes that were decoded a second time through the general path
+ * live in a second block (block == 1), always mirrored by the library.  After a download the dsa_batch_copy_* calls above
+ * are served from the host copy. */
+typedef struct dsa_mesh_output {
+  uint32_t block;                               /* 0: the batch's block (dst / mirror), 1: the block of the re-decoded meshes */
+  uint32_t reserved;
+  uint64_t faces;                               /* int32[num_faces * 3] */
+  uint64_t values[DSA_MAX_ATTRIBUTES];          /* attribute a: num_entries * byte_stride bytes */
+  uint64_t point_map[DSA_MAX_ATTRIBUTES];       /* attribute a: uint32[num_points] */
+} dsa_mesh_output;
+uint64_t dsa_batch_output_bytes(const dsa_batch *batch);
+dsa_status dsa_batch_download(dsa_batch *batch, void *dst, size_t dst_bytes);
+const void *dsa_batch_host_output(const dsa_batch *batch, uint32_t block);   /* NULL until dsa_batch_wait has seen the download finish */
+dsa_status dsa_batch_output_layout(const dsa_batch *batch, uint32_t mesh, dsa_mesh_output *out);
+/* Pinned host memory for download destinations (and for inputs a caller reuses). */
+void *dsa_host_alloc(size_t bytes);
+void dsa_host_free(void *p);
+dsa_status dsa_host_register(void *p, size_t bytes);
+dsa_status dsa_host_unregister(void *p);
 
 /* Device pointers of the results, for consumers that stay on the GPU.  Valid
  * until dsa_batch_free. */
@@ -148,8 +184,10 @@ dsa_status dsa_batch_stage_times(const dsa_batch *batch, float ms[DSA_NUM_STAGES
 
 /* ------------------------------------------------------------------ encode direction
  * Drop-in for DracoEncoder.Encode(BinaryWriter, Config, PointCloud, attributes)   src/Draco/IO/DracoEncoder.cs:22-41
- * on a batch of triangle meshes with per-vertex attributes: Edgebreaker (standard traversal) connectivity on the
- * host, quantisation / prediction / symbol statistics / rANS coding as HIP kernels (BASELINE.json configs[4]).
+ * on a batch of triangle meshes with per-vertex attributes: Edgebreaker (standard traversal) connectivity, quantisation,
+ * prediction, symbol statistics, scheme selection and rANS coding as HIP kernels (BASELINE.json configs[4]); the host
+ * checks index ranges before and lays the bytes of each stream out after (batches below 256 meshes let the host
+ * threads do connectivity and symbol plans as well: the device's fixed latency exceeds their work).
  * Options mirror the reference's Config (src/Draco/IO/Config.cs): quantisation bits per attribute type, speed
  * (compression_level = 10 - speed), prediction scheme overrides. */
 typedef struct dsa_encode_options {

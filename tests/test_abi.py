@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     assert sorted(names) == sorted(native.EXPORTS)
-    assert L.dsa_abi_version() == 1
+    assert L.dsa_abi_version() == 2          # 2: whole-batch download (dsa_batch_download, dsa_mesh_output), pinned host memory
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -41,3 +41,4 @@ def test_struct_layouts_match_header():
     import ctypes as C
     assert C.sizeof(native.MeshInfo) == 40
     assert C.sizeof(native.AttributeInfo) == 64
+    assert C.sizeof(native.MeshOutput) == 8 + 8 + 2 * 16 * 8

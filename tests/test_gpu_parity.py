@@ -589,3 +589,58 @@ def test_high_precision_symbol_streams(ctx):
         seen.update(int(p) for src, _, p, _ in info if src == 1)
     assert 16 in seen and len(seen) >= 3               # several precisions, the table's widest among them, were really met
     b.close()
+
+
+def _pad_raw_tables(data, mbl, extra):
+    """Every raw symbol section of `data` whose max_bit_length byte is `mbl`: `extra` (<= 64) more symbols of zero frequency appended
+    to its probability table (one zero-run token, RAnsSymbolDecoder.cs:28-37) -- a table a stock encoder never writes (it trims
+    trailing zeros) and the reference's slot table decodes like the trimmed one.  Sections are found by a validating scan: scheme byte 1,
+    the length byte, a table whose frequencies sum to the precision."""
+    precision = 1 << max(12, min(20, 3 * mbl // 2))
+    out, at, done = bytearray(), 0, 0
+    o = 0
+    while o + 3 < len(data):
+        if data[o] == 1 and data[o + 1] == mbl:
+            q, n, sh = o + 2, 0, 0
+            while q < len(data):
+                n |= (data[q] & 0x7F) << sh; sh += 7; q += 1
+                if not data[q - 1] & 0x80: break
+            total, i, ok, tq = 0, 0, 64 < n <= 2048 - extra, q
+            while ok and i < n and tq < len(data):
+                tok = data[tq] & 3
+                if tok == 3: i += (data[tq] >> 2) + 1; tq += 1
+                else:
+                    pr = data[tq] >> 2
+                    for k in range(tok): pr |= data[tq + 1 + k] << (8 * (k + 1) - 2)
+                    total += pr; i += 1; tq += 1 + tok
+            if ok and i == n and total == precision:
+                m, var = n + extra, bytearray()
+                while True:
+                    var.append((m & 0x7F) | (0x80 if m > 0x7F else 0)); m >>= 7
+                    if not m: break
+                out += data[at:o + 2] + var + data[q:tq] + bytes([((extra - 1) << 2) | 3])
+                at, o, done = tq, tq, done + 1
+                continue
+        o += 1
+    return bytes(out + data[at:]), done
+
+
+def test_trailing_zero_frequencies_at_16_bit_precision(ctx):
+    """a non-compact table whose last symbols have zero frequency has cumulative frequency 2^16 there, which the
+    16 + 16-bit register table of k_symbols_wide must treat as padding."""
+    cases = []
+    for k, extra in enumerate((1, 17, 64)):
+        # 10-bit octahedral normals at compression level 8: 1023 symbols, max_bit_length 11 -> 16-bit precision, table not compacted
+        pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 96, 80, 90)
+        data = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(force_scheme=1, pos_bits=11, uv_bits=10, normal_bits=10, compression_level=8))
+        padded, done = _pad_raw_tables(data, 11, extra)
+        assert done >= 1, "no 16-bit-precision raw section found to pad"
+        want, got = oracle.decode(data), oracle.decode(padded)
+        assert all(np.array_equal(x.portable, y.portable) for x, y in zip(want.attributes, got.attributes))   # same symbols, longer table
+        cases.append(padded)
+    b = dsa.Batch(ctx, cases)
+    b.decode()
+    for i, data in enumerate(cases):
+        assert b.status(i) == 0, b.mesh_info(i).detail
+        assert_same(b.result(i), oracle.decode(data), b, i)
+    b.close()

@@ -15,17 +15,16 @@ import draco_sharp_amd.synth as synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "hostcheck", "lanes_host.cpp")
-EXE = os.path.join(HERE, "hostcheck", "lanes_host")
 CSRC = os.path.join(HERE, "..", "draco-sharp_amd", "csrc")
 
 
 @pytest.fixture(scope="module")
-def exe():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("dsa_lanes.h", "dsa_locate.h", "dsa_common.h", "dsa_host_parse.h", "dsa_types.h")]
-    if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
-        subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize=signed-integer-overflow",
-                        "-fno-sanitize-recover=undefined", "-o", EXE, SRC], check=True)
-    return EXE
+def exe(tmp_path_factory):
+    # always built from the sources of this checkout (a binary left in the tree could be older than they are)
+    out = str(tmp_path_factory.mktemp("hostcheck") / "lanes_host")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize=signed-integer-overflow",
+                    "-fno-sanitize-recover=undefined", "-o", out, SRC], check=True)
+    return out
 
 
 def lanes_decode(exe, data, tmp_path, ref=None):
