@@ -402,7 +402,7 @@ def main():
             else:
                 pblob, poffs = synth.make_batch(synth.GRID, nx, ny, 1000, args.meshes, normals=True, uvs=True, threads=threads)
             devices = [0] * world if rehearse else list(range(world))
-            pool = pool_leg(dsa, devices, pblob, poffs, 256, 3)
+            pool = pool_leg(dsa, devices, pblob, poffs, 0, 3)
         barrier()
     if rank == 0:
         if out is None:                                              # --scaling strong: the strong leg is the line

@@ -47,7 +47,7 @@ struct dsa_context {
   // Arenas and pinned mirrors of freed batches are kept for the next batch of the context: hipMalloc / hipFree of tens of GB and
   // pinning GBs of host memory cost as much as the decode itself.  Three of each: two batches in flight + one being built.
   struct Spare { uint8_t *p; uint64_t bytes; };
-  std::vector<Spare> spare_arenas, spare_mirrors;
+  std::vector<Spare> spare_arenas, spare_mirrors, spare_descs;   // spare_descs: pinned landing zones of the mesh descriptors
   static constexpr size_t kSpares = 3;
   // batches point at their context: a context destroyed first lives on until its last batch is freed
   int live_batches = 0;
@@ -78,6 +78,7 @@ struct dsa_batch {
   // so nothing here waits for a whole stream)
   hipEvent_t ev_uploaded = nullptr, ev_done = nullptr, ev_descs = nullptr, ev_down = nullptr;
   MeshDesc *descs_pin = nullptr;     // pinned landing zone of the descriptors
+  uint64_t descs_pin_bytes = 0;
   // host copy of the output block: a library-owned pinned mirror or the caller's buffer
   uint8_t *mirror = nullptr;
   uint64_t mirror_bytes = 0;
@@ -239,7 +240,13 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
   HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_descs, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_down, hipEventDisableTiming));
-  HIP_TRY(ctx, hipHostMalloc((void **)&b->descs_pin, sizeof(MeshDesc) * (size_t)(n ? n : 1), hipHostMallocDefault));
+  {   // pinned landing zone of the descriptors, from the context's cache (hipHostMalloc / hipHostFree wait for the device: with
+      // another batch in flight they would serialise the pipeline)
+    const uint64_t need = sizeof(MeshDesc) * (uint64_t)(n ? n : 1);
+    uint8_t *p = take_spare(ctx->spare_descs, need, &b->descs_pin_bytes);
+    if (!p) { HIP_TRY(ctx, hipHostMalloc((void **)&p, need + need / 2, hipHostMallocDefault)); b->descs_pin_bytes = need + need / 2; }
+    b->descs_pin = (MeshDesc *)p;
+  }
   // ---- upload: layouts, globals and all streams staged in pinned memory (host threads), one DMA on the upload stream.  The
   // caller's buffers are not referenced once this function returns; the kernels wait for ev_uploaded, the host does not.
   {
@@ -326,6 +333,7 @@ void dsa_context_destroy(dsa_context *ctx) {
   if (ctx->down) { (void)hipStreamSynchronize(ctx->down); (void)hipStreamDestroy(ctx->down); }
   drop_spares(ctx->spare_arenas, false);
   drop_spares(ctx->spare_mirrors, true);
+  drop_spares(ctx->spare_descs, true);
   if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
   if (ctx->ev_trav) (void)hipEventDestroy(ctx->ev_trav);
   if (ctx->ev_maps) (void)hipEventDestroy(ctx->ev_maps);
@@ -645,7 +653,7 @@ void dsa_batch_free(dsa_batch *b) {
   if (b->ev_done) { if (b->decoded) (void)hipEventSynchronize(b->ev_done); (void)hipEventDestroy(b->ev_done); }
   if (b->ev_descs) { if (b->decoded) (void)hipEventSynchronize(b->ev_descs); (void)hipEventDestroy(b->ev_descs); }
   if (b->ev_down) { if (b->download_queued) (void)hipEventSynchronize(b->ev_down); (void)hipEventDestroy(b->ev_down); }
-  if (b->descs_pin) (void)hipHostFree(b->descs_pin);
+  give_spare(b->ctx->spare_descs, (uint8_t *)b->descs_pin, b->descs_pin_bytes, [](uint8_t *p) { (void)hipHostFree(p); });
   if (b->mirror && b->mirror_owned) give_spare(b->ctx->spare_mirrors, b->mirror, b->mirror_bytes, [](uint8_t *p) { (void)hipHostFree(p); });
   give_spare(b->ctx->spare_arenas, b->arena, b->arena_cap, [](uint8_t *p) { (void)hipFree(p); });
   dsa_context *ctx = b->ctx;
@@ -872,12 +880,21 @@ dsa_status dsa_batch_copy_debug(const dsa_batch *b, uint32_t mesh, int what, voi
         if (st == DSA_OK && written) *written = (size_t)bytes;
         return st;
       }
-      std::vector<uint32_t> rec((size_t)D.num_faces * 8);
-      dsa_status st = copy_out(b, rec.data(), L.frec, 32ull * D.num_faces);
+      const uint32_t words = L.rec_compact ? 4u : 8u;
+      std::vector<uint32_t> rec((size_t)D.num_faces * words);
+      dsa_status st = copy_out(b, rec.data(), L.frec, 4ull * words * D.num_faces);
       if (st != DSA_OK) return st;
       uint32_t *o = (uint32_t *)dst;
       for (uint32_t f = 0; f < D.num_faces; ++f)
-        for (uint32_t k = 0; k < 3; ++k) o[3 * f + k] = what == 0 ? unquad(rec[(size_t)f * 8 + 4 + k]) : rec[(size_t)f * 8 + k];
+        for (uint32_t k = 0; k < 3; ++k) {
+          uint32_t vtx, opp;
+          if (L.rec_compact) {       // two 64-bit words of three sign-extended 21-bit fields (dsa_kernels.h, Rec<true>)
+            const uint64_t vv = rec[(size_t)f * 4] | ((uint64_t)rec[(size_t)f * 4 + 1] << 32), oo = rec[(size_t)f * 4 + 2] | ((uint64_t)rec[(size_t)f * 4 + 3] << 32);
+            vtx = (uint32_t)((int32_t)((uint32_t)(vv >> (21 * k)) << 11) >> 11);
+            opp = (uint32_t)((int32_t)((uint32_t)(oo >> (21 * k)) << 11) >> 11);
+          } else { vtx = rec[(size_t)f * 8 + k]; opp = rec[(size_t)f * 8 + 4 + k]; }
+          o[3 * f + k] = what == 0 ? unquad(opp) : vtx;
+        }
       if (written) *written = (size_t)bytes;
       return DSA_OK;
     }

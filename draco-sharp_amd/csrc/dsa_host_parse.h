@@ -227,7 +227,9 @@ static inline uint64_t layout_mesh(const HostMesh &h, uint64_t stream_len, MeshL
   L.cap_splits = h.splits;
   auto take = [&](uint64_t bytes) { uint64_t at = cur; cur = align_up(cur + bytes + slack, 256); if (regions) regions->push_back({at, bytes}); return at; };
   auto take_out = [&](uint64_t bytes) { if (!out_cur) return take(bytes); uint64_t at = *out_cur; *out_cur = align_up(*out_cur + bytes + slack, 256); return at; };
-  L.frec = take(32 * F);
+  // the fast kernels' face records: 16 bytes while every id fits 20 bits (the general path keeps plain arrays here: 24 F)
+  L.rec_compact = (!h.general && 4 * F <= (1u << 20) && V < (1u << 20)) ? 1u : 0u;
+  L.frec = take(L.rec_compact ? 16 * F : 32 * F);
   L.vrec = take(8 * V);
   L.d2c = take(4 * V); L.v2d = take(4 * V);
   L.fvis = take(F); L.vvis = take(V);

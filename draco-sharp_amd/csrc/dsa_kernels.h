@@ -82,6 +82,80 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t *total) 
 }
 
 // =========================================================================
+// Face records of the fast path: per face the three vertices and the three opposite corners (corner ids are quad coded, 4 * face + k).
+// Two formats, chosen per mesh by the host from the header's counts (MeshLayout::rec_compact):
+//   wide     32 B  {v0, v1, v2, 0, o0, o1, o2, 0}                                      any size
+//   compact  16 B  {vv, oo}: two 64-bit words of three 21-bit fields, sign-extended on read so that "no opposite" is all ones in
+//                  either format; corners and vertices below 2^20 (F <= 262 144).  Half the bytes per hop of the traversal's
+//                  gathers, per staged store of the connectivity and per face of k_faces.
+// An opposite slot is only ever set once, from "none" (MeshEdgeBreakerDecoder.cs:254,272,314,392 reject a second link; here
+// the census of k_faces / k_seal does): in the compact format that is an atomic AND on the 64-bit word -- no read, no wait.
+// =========================================================================
+template <bool CP> struct Rec;
+struct FaceIds { uint32_t v0, v1, v2, o0, o1, o2; };
+template <> struct Rec<false> {
+  static constexpr uint32_t WORDS = 8;          // dwords per record
+  struct Raw { uint4 v, o; };
+  static __device__ __forceinline__ Raw load(const uint32_t *frec, uint32_t f) { Raw r; r.v = ((const uint4 *)frec)[(size_t)f * 2]; r.o = ((const uint4 *)frec)[(size_t)f * 2 + 1]; return r; }
+  static __device__ __forceinline__ Raw none() { Raw r; r.v = make_uint4(0, 0, 0, 0); r.o = make_uint4(DSA_INVALID, DSA_INVALID, DSA_INVALID, 0); return r; }
+  // (operands by value: a conditional expression over members of a referenced struct selects an ADDRESS, which keeps the struct in scratch)
+  static __device__ __forceinline__ uint32_t sel3(uint32_t k, uint32_t x, uint32_t y, uint32_t z) { return k == 0 ? x : (k == 1 ? y : z); }
+  static __device__ __forceinline__ uint32_t vertex(const Raw &r, uint32_t k) { return sel3(k, r.v.x, r.v.y, r.v.z); }
+  static __device__ __forceinline__ uint32_t opp(const Raw &r, uint32_t k) { return sel3(k, r.o.x, r.o.y, r.o.z); }
+  // single fields straight from memory (rare paths and the element-parallel passes)
+  static __device__ __forceinline__ uint32_t get_v(const uint32_t *frec, uint32_t c) { return frec[fv_idx(c)]; }
+  static __device__ __forceinline__ uint32_t get_o(const uint32_t *frec, uint32_t c) { return frec[fo_idx(c)]; }
+  static __device__ __forceinline__ void set_v(uint32_t *frec, uint32_t c, uint32_t val) { frec[fv_idx(c)] = val; }
+  static __device__ __forceinline__ void link(uint32_t *frec, uint32_t c, uint32_t val) { frec[fo_idx(c)] = val; }           // opposite slot: none -> val
+  static __device__ __forceinline__ void link_lds(uint32_t *stage, uint32_t c_rel, uint32_t val) { stage[fo_idx(c_rel)] = val; }
+  static __device__ __forceinline__ void store(uint32_t *frec, uint32_t f, const FaceIds &x) {
+    ((uint4 *)frec)[(size_t)f * 2] = make_uint4(x.v0, x.v1, x.v2, 0u); ((uint4 *)frec)[(size_t)f * 2 + 1] = make_uint4(x.o0, x.o1, x.o2, 0u);
+  }
+  static __device__ __forceinline__ void store_lds(uint32_t *stage, uint32_t slot, const FaceIds &x) {
+    *(uint4 *)&stage[slot * 8] = make_uint4(x.v0, x.v1, x.v2, 0u); *(uint4 *)&stage[slot * 8 + 4] = make_uint4(x.o0, x.o1, x.o2, 0u);
+  }
+  static __device__ __forceinline__ uint4 vertices_of(const uint32_t *frec, uint32_t f) { return ((const uint4 *)frec)[(size_t)f * 2]; }   // .x .y .z
+};
+template <> struct Rec<true> {
+  static constexpr uint32_t WORDS = 4;
+  static constexpr uint32_t M = 0x1FFFFFu;
+  struct Raw { uint64_t v, o; };
+  static __device__ __forceinline__ uint64_t pack(uint32_t a, uint32_t b, uint32_t c) { return (uint64_t)(a & M) | ((uint64_t)(b & M) << 21) | ((uint64_t)(c & M) << 42); }
+  static __device__ __forceinline__ uint32_t field(uint64_t w, uint32_t k) { return (uint32_t)((int32_t)((uint32_t)(w >> (21u * k)) << 11) >> 11); }   // sign-extended
+  static __device__ __forceinline__ Raw load(const uint32_t *frec, uint32_t f) { const uint4 q = ((const uint4 *)frec)[f]; Raw r; r.v = (uint64_t)q.x | ((uint64_t)q.y << 32); r.o = (uint64_t)q.z | ((uint64_t)q.w << 32); return r; }
+  static __device__ __forceinline__ Raw none() { Raw r; r.v = 0; r.o = ~0ull; return r; }
+  static __device__ __forceinline__ uint32_t vertex(const Raw &r, uint32_t k) { return field(r.v, k); }
+  static __device__ __forceinline__ uint32_t opp(const Raw &r, uint32_t k) { return field(r.o, k); }
+  static __device__ __forceinline__ uint32_t get_v(const uint32_t *frec, uint32_t c) { return field(((const uint64_t *)frec)[(size_t)(c >> 2) * 2], c & 3u); }
+  // opposite words are changed by atomics (performed in L2, this CU's L1 keeps what it has): read them past L1
+  static __device__ __forceinline__ uint32_t get_o(const uint32_t *frec, uint32_t c) {
+    return field(__hip_atomic_load((const unsigned long long *)frec + (size_t)(c >> 2) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c & 3u);
+  }
+  static __device__ __forceinline__ void set_v(uint32_t *frec, uint32_t c, uint32_t val) {      // plain read-modify-write: lane 0 on synchronised memory only
+    uint64_t *w = (uint64_t *)frec + (size_t)(c >> 2) * 2;
+    const uint32_t sh = 21u * (c & 3u);
+    *w = (*w & ~((uint64_t)M << sh)) | ((uint64_t)(val & M) << sh);
+  }
+  static __device__ __forceinline__ void link(uint32_t *frec, uint32_t c, uint32_t val) {
+    const uint32_t sh = 21u * (c & 3u);
+    atomicAnd((unsigned long long *)frec + (size_t)(c >> 2) * 2 + 1, ((unsigned long long)(val & M) << sh) | ~((unsigned long long)M << sh));
+  }
+  static __device__ __forceinline__ void link_lds(uint32_t *stage, uint32_t c_rel, uint32_t val) {
+    const uint32_t sh = 21u * (c_rel & 3u);
+    atomicAnd((unsigned long long *)stage + (size_t)(c_rel >> 2) * 2 + 1, ((unsigned long long)(val & M) << sh) | ~((unsigned long long)M << sh));
+  }
+  static __device__ __forceinline__ uint4 quad(const FaceIds &x) { const uint64_t v = pack(x.v0, x.v1, x.v2), o = pack(x.o0, x.o1, x.o2); return make_uint4((uint32_t)v, (uint32_t)(v >> 32), (uint32_t)o, (uint32_t)(o >> 32)); }
+  static __device__ __forceinline__ void store(uint32_t *frec, uint32_t f, const FaceIds &x) { ((uint4 *)frec)[f] = quad(x); }
+  static __device__ __forceinline__ void store_lds(uint32_t *stage, uint32_t slot, const FaceIds &x) { *(uint4 *)&stage[slot * 4] = quad(x); }
+  static __device__ __forceinline__ uint4 vertices_of(const uint32_t *frec, uint32_t f) {
+    const uint64_t v = ((const uint64_t *)frec)[(size_t)f * 2];
+    return make_uint4(field(v, 0), field(v, 1), field(v, 2), 0u);
+  }
+};
+__device__ __forceinline__ uint32_t k_next(uint32_t k) { return k == 2u ? 0u : k + 1u; }
+__device__ __forceinline__ uint32_t k_prev(uint32_t k) { return k == 0u ? 2u : k - 1u; }
+
+// =========================================================================
 // k_locate: one wave per mesh, lane 0 walks the stream (dsa_locate.h).
 // =========================================================================
 __global__ __launch_bounds__(WAVE, 4) void k_locate(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, BatchGlobals *G) {
@@ -121,7 +195,9 @@ __global__ __launch_bounds__(WAVE, 4) void k_locate(uint8_t *arena, const MeshLa
 #define CN_LDS_WORDS (CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2 + CN_WIN)
 // The body of k_connectivity for one mesh on one wave; LDS: sh_stage[CN_STAGE * 8] and sh_rec[CN_REC_BLOCKS * 128] 16-byte
 // aligned, sh_win[CN_WIN].  Also the first half of k_chain.
+template <bool CP>
 __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t *sh_stage, uint32_t *sh_rec, uint32_t *sh_win) {
+  typedef Rec<CP> R;
   if (D->status != ST_OK || D->encoder_type == 0 || D->general) return;   // point clouds have no connectivity; general meshes: k_general
   const uint8_t *s = arena + L.stream;
   uint32_t *frec = (uint32_t *)(arena + L.frec);
@@ -208,13 +284,13 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
 #define REC_DIRTY(v_, hit_) {}
   // opposite slot of corner c: staged or already in global memory
 #define SET_OPP(c_, val_)                                                                \
-  { if ((c_) >= 4 * stage_base) sh_stage[fo_idx(c_) - 8 * stage_base] = (val_);          \
-    else frec[fo_idx(c_)] = (val_); }
+  { if ((c_) >= 4 * stage_base) R::link_lds(sh_stage, (c_) - 4 * stage_base, (val_));    \
+    else R::link(frec, (c_), (val_)); }
   // staged faces [stage_base, upto) -> global memory, 16 bytes per lane and store
   auto flush_stage = [&](uint32_t upto) {
-    const uint32_t quads = (upto - stage_base) * 2;
+    const uint32_t quads = (upto - stage_base) * (R::WORDS / 4);
     __syncthreads();
-    for (uint32_t i = lane; i < quads; i += WAVE) ((uint4 *)frec)[(size_t)stage_base * 2 + i] = ((const uint4 *)sh_stage)[i];
+    for (uint32_t i = lane; i < quads; i += WAVE) ((uint4 *)frec)[(size_t)stage_base * (R::WORDS / 4) + i] = ((const uint4 *)sh_stage)[i];
     stage_base = upto;
   };
   // everything to global memory, record cache emptied (before lane 0 works on global memory directly)
@@ -301,13 +377,11 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
             const uint32_t vb = rj.y, cb = qnext(rj.x);
             const uint32_t va = j == 0 ? va0 : nv0 + j - 1, nvj = nv0 + j;
             // C_j: face (vx, vb, va), opposites (R_j corner 2, previous face corner 0, cb)
-            ((uint4 *)frec)[(size_t)fc * 2] = make_uint4(vxj, vb, va, 0u);
-            ((uint4 *)frec)[(size_t)fc * 2 + 1] = make_uint4(cr + 2, cc - 4, cb, 0u);
+            { FaceIds x = {vxj, vb, va, cr + 2, cc - 4, cb}; R::store(frec, fc, x); }
             // R_j: face (va, vb, nv), opposites (next C corner 1 | open, open, C_j corner 0)
-            ((uint4 *)frec)[(size_t)fr * 2] = make_uint4(va, vb, nvj, 0u);
-            ((uint4 *)frec)[(size_t)fr * 2 + 1] = make_uint4(j + 1 < k ? cr + 4 + 1 : DSA_INVALID, DSA_INVALID, cc, 0u);
-            frec[fo_idx(cb)] = cc + 2;                                   // old boundary edge now faces C_j corner 2
-            if (j == 0) frec[fo_idx(cc - 4)] = cc + 1;                   // the previous top faces C_0 corner 1
+            { FaceIds x = {va, vb, nvj, j + 1 < k ? cr + 4 + 1 : DSA_INVALID, DSA_INVALID, cc}; R::store(frec, fr, x); }
+            R::link(frec, cb, cc + 2);                                   // old boundary edge now faces C_j corner 2
+            if (j == 0) R::link(frec, cc - 4, cc + 1);                   // the previous top faces C_0 corner 1
             // vertex records after the run (the last SetLeftMostCorner of each vertex wins)
             vrec[va] = make_uint2(cr, nvj);                              // R_j: left-most corner = R_j corner 0
             if (j + 1 == k) vrec[nvj] = make_uint2(cr + 2, vb);          // later pairs overwrite this for j < k-1
@@ -357,7 +431,7 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
     // MeshEdgeBreakerTraversalDecoder.cs:89-99: 1 bit, then 2 more unless C
     const uint32_t b3 = (uint32_t)bb & 7u;
     const uint32_t face = sid, corner = 4 * face, ca = corner - 4;
-    const uint32_t so = (face - stage_base) * 8;
+    const uint32_t so = face - stage_base;       // slot of the new face in the staging block
     if ((b3 & 1u) == 0) {                 // C, :247-267
       if (!have_top) CN_FAIL(210);
       const uint32_t vx = T1, va_prev = T2;
@@ -370,8 +444,7 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
       bb >>= 1; bcnt -= 1; bits_used += 1;
       const bool hit_a = REC_HIT(va_prev);
       if (lane == 0) {
-        *(uint4 *)&sh_stage[so] = make_uint4(vx, vb_next, va_prev, 0u);
-        *(uint4 *)&sh_stage[so + 4] = make_uint4(DSA_INVALID, ca, cb, 0u);
+        { FaceIds x = {vx, vb_next, va_prev, DSA_INVALID, ca, cb}; R::store_lds(sh_stage, so, x); }
         SET_OPP(ca, corner + 1);
         SET_OPP(cb, corner + 2);
         REC_STORE(va_prev, hit_a, corner + 2, vb_next);   // SetLeftMostCorner(va_prev, corner + 2) + the vertex before that corner
@@ -395,30 +468,29 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
           if (nsplits) { ca2 = split_map[sid]; pushed = ca2 != DSA_INVALID; }     // topologySplitActiveCorners lookup (:305)
           if (!pushed) { if (sp2 == 0) { fail(D, ST_INVALID, 232); break; } ca2 = stack_mem[--sp2]; }
           if (ca2 >= corner || (ca2 & 3u) == 3u) { fail(D, ST_INVALID, 237); break; }
-          if (ca2 == cb || frec[fo_idx(ca2)] != DSA_INVALID || frec[fo_idx(cb)] != DSA_INVALID) { fail(D, ST_INVALID, 233); break; }
-          uint32_t vp = frec[fv_idx(qprev(ca2))], vq = frec[fv_idx(qnext(ca2))], vb_prev = frec[fv_idx(qprev(cb))];
+          if (ca2 == cb || R::get_o(frec, ca2) != DSA_INVALID || R::get_o(frec, cb) != DSA_INVALID) { fail(D, ST_INVALID, 233); break; }
+          uint32_t vp = R::get_v(frec, qprev(ca2)), vq = R::get_v(frec, qnext(ca2)), vb_prev = R::get_v(frec, qprev(cb));
           uint32_t cn = qnext(cb);
-          uint32_t vn = frec[fv_idx(cn)];
+          uint32_t vn = R::get_v(frec, cn);
           if (vn >= num_verts || vp >= num_verts || vq >= num_verts || vb_prev >= num_verts) { fail(D, ST_INVALID, 234); break; }
-          frec[fo_idx(ca2)] = corner + 2; frec[fo_idx(cb)] = corner + 1;
-          frec[8 * face + 0] = vp; frec[8 * face + 1] = vq; frec[8 * face + 2] = vb_prev; frec[8 * face + 3] = 0;
-          frec[8 * face + 4] = DSA_INVALID; frec[8 * face + 5] = cb; frec[8 * face + 6] = ca2; frec[8 * face + 7] = 0;
+          R::link(frec, ca2, corner + 2); R::link(frec, cb, corner + 1);
+          { FaceIds x = {vp, vq, vb_prev, DSA_INVALID, cb, ca2}; R::store(frec, face, x); }
           vrec[vb_prev] = make_uint2(corner + 2, vq);
           uint32_t lm_n = vrec[vn].x;
           uint32_t first = cn, guard = 0;
           bool bad = false;
           while (cn != DSA_INVALID) {
-            frec[fv_idx(cn)] = vp;
+            R::set_v(frec, cn, vp);
             // the record of the vertex whose left-most corner follows cn caches the vertex at cn
-            uint32_t w = frec[fv_idx(qnext(cn))];
+            uint32_t w = R::get_v(frec, qnext(cn));
             if (w < num_verts && vrec[w].x == qnext(cn)) vrec[w].y = vp;
-            uint32_t o = frec[fo_idx(qnext(cn))];          // SwingLeft
+            uint32_t o = R::get_o(frec, qnext(cn));          // SwingLeft
             cn = o == DSA_INVALID ? DSA_INVALID : qnext(o);
             if (cn == first || ++guard > 3 * F) { bad = true; break; }
           }
           if (bad) { fail(D, ST_INVALID, 235); break; }
           if (lm_n >= corner + 4 || (lm_n & 3u) == 3u) { fail(D, ST_INVALID, 238); break; }
-          vrec[vp] = make_uint2(lm_n, frec[fv_idx(qprev(lm_n))]);
+          vrec[vp] = make_uint2(lm_n, R::get_v(frec, qprev(lm_n)));
           vrec[vn] = make_uint2(DSA_INVALID, DSA_INVALID);
           if (remove_invalid) { if (r_inv >= VMAX) { fail(D, ST_INVALID, 236); break; } invalid_list[r_inv++] = vn; }
           r_sp = sp2;                     // the new top replaces the pushed or the exposed entry
@@ -445,8 +517,7 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
       n_links += 1;
       if (b3 == 5u) {
         if (lane == 0) {
-          *(uint4 *)&sh_stage[so] = make_uint4(T2, T1, nv, 0u);
-          *(uint4 *)&sh_stage[so + 4] = make_uint4(DSA_INVALID, DSA_INVALID, ca, 0u);
+          { FaceIds x = {T2, T1, nv, DSA_INVALID, DSA_INVALID, ca}; R::store_lds(sh_stage, so, x); }
           SET_OPP(ca, corner + 2);
           REC_STORE(nv, hit_n, corner + 2, T1);
           REC_STORE(T2, hit_2, corner, nv);
@@ -455,8 +526,7 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
         T2 = nv;                          // face (T2, T1, nv): corner 1 keeps T1
       } else {
         if (lane == 0) {
-          *(uint4 *)&sh_stage[so] = make_uint4(T1, nv, T2, 0u);
-          *(uint4 *)&sh_stage[so + 4] = make_uint4(DSA_INVALID, ca, DSA_INVALID, 0u);
+          { FaceIds x = {T1, nv, T2, DSA_INVALID, ca, DSA_INVALID}; R::store_lds(sh_stage, so, x); }
           SET_OPP(ca, corner + 1);
           REC_STORE(nv, hit_n, corner + 1, T1);
           REC_STORE(T2, hit_2, corner + 2, nv);
@@ -471,8 +541,7 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
       num_verts += 3;
       const bool h0 = REC_HIT(v0), h1 = REC_HIT(v0 + 1), h2 = REC_HIT(v0 + 2);
       if (lane == 0) {
-        *(uint4 *)&sh_stage[so] = make_uint4(v0, v0 + 1, v0 + 2, 0u);
-        *(uint4 *)&sh_stage[so + 4] = make_uint4(DSA_INVALID, DSA_INVALID, DSA_INVALID, 0u);
+        { FaceIds x = {v0, v0 + 1, v0 + 2, DSA_INVALID, DSA_INVALID, DSA_INVALID}; R::store_lds(sh_stage, so, x); }
         REC_STORE(v0, h0, corner, v0 + 2);
         REC_STORE(v0 + 1, h1, corner + 1, v0);
         REC_STORE(v0 + 2, h2, corner + 2, v0 + 1);
@@ -534,21 +603,20 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
         if (!interior) continue;
         if (num_faces >= F || corner >= 4 * num_faces) { fail(D, ST_INVALID, 251); bad = true; break; }
         uint32_t ca = corner;
-        uint32_t vn = frec[fv_idx(qnext(ca))];
+        uint32_t vn = R::get_v(frec, qnext(ca));
         if (vn >= num_verts || vrec[vn].x >= 4 * num_faces) { fail(D, ST_INVALID, 252); bad = true; break; }
         uint32_t cb = qnext(vrec[vn].x);
-        uint32_t vx = frec[fv_idx(qnext(cb))];
+        uint32_t vx = R::get_v(frec, qnext(cb));
         if (vx >= num_verts || vrec[vx].x >= 4 * num_faces) { fail(D, ST_INVALID, 253); bad = true; break; }
         uint32_t cc = qnext(vrec[vx].x);
         if (ca == cb || ca == cc || cb == cc) { fail(D, ST_INVALID, 254); bad = true; break; }
-        if (frec[fo_idx(ca)] != DSA_INVALID || frec[fo_idx(cb)] != DSA_INVALID || frec[fo_idx(cc)] != DSA_INVALID) { fail(D, ST_INVALID, 255); bad = true; break; }
-        uint32_t vp = frec[fv_idx(qnext(cc))];
+        if (R::get_o(frec, ca) != DSA_INVALID || R::get_o(frec, cb) != DSA_INVALID || R::get_o(frec, cc) != DSA_INVALID) { fail(D, ST_INVALID, 255); bad = true; break; }
+        uint32_t vp = R::get_v(frec, qnext(cc));
         if (vp >= num_verts) { fail(D, ST_INVALID, 262); bad = true; break; }
         uint32_t face = num_faces++;
         uint32_t nc = 4 * face;
-        frec[fo_idx(ca)] = nc; frec[fo_idx(cb)] = nc + 1; frec[fo_idx(cc)] = nc + 2;
-        frec[8 * face + 0] = vx; frec[8 * face + 1] = vp; frec[8 * face + 2] = vn; frec[8 * face + 3] = 0;
-        frec[8 * face + 4] = ca; frec[8 * face + 5] = cb; frec[8 * face + 6] = cc; frec[8 * face + 7] = 0;
+        R::link(frec, ca, nc); R::link(frec, cb, nc + 1); R::link(frec, cc, nc + 2);
+        { FaceIds x = {vx, vp, vn, ca, cb, cc}; R::store(frec, face, x); }
       }
       if (bad) break;
       if (num_faces != F) { fail(D, ST_INVALID, 256); break; }
@@ -564,15 +632,15 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
         uint32_t start = vrec[src].x, c = start, guard = 0;
         bool left = true;
         while (c != DSA_INVALID) {   // VertexCornersIterator (D-10: starts at the left-most corner itself)
-          if (c >= 4 * F || (c & 3u) == 3u || frec[fv_idx(c)] != src || ++guard > 3 * F) { fail(D, ST_INVALID, 259); bad = true; break; }
-          frec[fv_idx(c)] = inv;
+          if (c >= 4 * F || (c & 3u) == 3u || R::get_v(frec, c) != src || ++guard > 3 * F) { fail(D, ST_INVALID, 259); bad = true; break; }
+          R::set_v(frec, c, inv);
           if (left) {
-            uint32_t o = frec[fo_idx(qnext(c))];
+            uint32_t o = R::get_o(frec, qnext(c));
             c = o == DSA_INVALID ? DSA_INVALID : qnext(o);
-            if (c == DSA_INVALID) { uint32_t o2 = frec[fo_idx(qprev(start))]; c = o2 == DSA_INVALID ? DSA_INVALID : qprev(o2); left = false; }
+            if (c == DSA_INVALID) { uint32_t o2 = R::get_o(frec, qprev(start)); c = o2 == DSA_INVALID ? DSA_INVALID : qprev(o2); left = false; }
             else if (c == start) c = DSA_INVALID;
           } else {
-            uint32_t o = frec[fo_idx(qprev(c))];
+            uint32_t o = R::get_o(frec, qprev(c));
             c = o == DSA_INVALID ? DSA_INVALID : qprev(o);
           }
         }
@@ -620,7 +688,7 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
     for (uint32_t v = lane; v < NVALL; v += WAVE) {
       const uint32_t lm = vrec[v].x;
       uint8_t fl = 0;
-      if (lm != DSA_INVALID && lm < 4 * F && (lm & 3u) != 3u) fl = frec[fo_idx(qnext(lm))] == DSA_INVALID ? 2 : 0;
+      if (lm != DSA_INVALID && lm < 4 * F && (lm & 3u) != 3u) fl = R::get_o(frec, qnext(lm)) == DSA_INVALID ? 2 : 0;
       vflag[v] = fl;
     }
   }
@@ -649,7 +717,8 @@ __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const Mes
   __builtin_amdgcn_s_setprio(3);   // critical path: issue ahead of the entropy-decode waves sharing the CU
   const uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
-  connectivity_wave(arena, layouts[mesh], &descs[mesh], sh, sh + CN_STAGE * 8, sh + CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2);
+  if (layouts[mesh].rec_compact) connectivity_wave<true>(arena, layouts[mesh], &descs[mesh], sh, sh + CN_STAGE * 8, sh + CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2);
+  else connectivity_wave<false>(arena, layouts[mesh], &descs[mesh], sh, sh + CN_STAGE * 8, sh + CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2);
 }
 
 // =========================================================================
@@ -736,6 +805,9 @@ __global__ __launch_bounds__(256) void k_init(uint8_t *arena, const MeshLayout *
   }
 }
 
+template <bool CP>
+__device__ __forceinline__ void para_operands_flat(uint32_t p, const uint32_t *frec, const uint32_t *d2c, const int32_t *v2d, uint32_t F, uint32_t NV,
+                                                   uint32_t &en, uint32_t &ep, uint32_t &eo);
 __global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n) {
   uint32_t mesh = blockIdx.y;
   if (mesh >= n) return;
@@ -747,7 +819,13 @@ __global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const Mes
   const int32_t *v2d = (const int32_t *)(arena + L.v2d);
   uint32_t *para = (uint32_t *)(arena + L.para);
   const uint32_t entries = D->num_entries, F = D->num_faces, NV = D->num_vertices;
-  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < entries; p += gridDim.x * blockDim.x) para_operands_of(p, frec, d2c, v2d, F, NV, para);
+  const bool compact = L.rec_compact != 0;
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < entries; p += gridDim.x * blockDim.x) {
+    uint32_t en, ep, eo;
+    if (compact) para_operands_flat<true>(p, frec, d2c, v2d, F, NV, en, ep, eo);
+    else para_operands_flat<false>(p, frec, d2c, v2d, F, NV, en, ep, eo);
+    para[3 * p] = en; para[3 * p + 1] = ep; para[3 * p + 2] = eo;
+  }
 }
 
 // k_traverse speculation: from a corner whose tip is new and interior the DFS usually repeats the pair
@@ -766,13 +844,15 @@ __global__ __launch_bounds__(256) void k_para_operands(uint8_t *arena, const Mes
 #define TR_SLOTS (1u << TR_SLOT_BITS)
 struct Triple { uint32_t a, b, c; };
 // para_operands_of (dsa_common.h) without branches: every load happens, at a clamped index when its guard is false.
+template <bool CP>
 __device__ __forceinline__ void para_operands_flat(uint32_t p, const uint32_t *frec, const uint32_t *d2c, const int32_t *v2d, uint32_t F, uint32_t NV,
                                                    uint32_t &en, uint32_t &ep, uint32_t &eo) {
+  typedef Rec<CP> R;
   const uint32_t c0 = d2c[p];
   const bool ok0 = p > 0 && c0 < 4 * F && (c0 & 3u) != 3u;
-  const uint32_t oci = frec[ok0 ? fo_idx(c0) : 4u];
+  const uint32_t oci = R::get_o(frec, ok0 ? c0 : 0u);
   const bool ok1 = ok0 && oci != DSA_INVALID && oci < 4 * F && (oci & 3u) != 3u;
-  const uint4 fr = *(const uint4 *)(frec + (size_t)(ok1 ? (oci >> 2) : 0u) * 8);
+  const uint4 fr = R::vertices_of(frec, ok1 ? (oci >> 2) : 0u);
   const uint32_t k = oci & 3u;
   const uint32_t a = k == 0 ? fr.x : (k == 1 ? fr.y : fr.z), b = k == 0 ? fr.y : (k == 1 ? fr.z : fr.x), c = k == 0 ? fr.z : (k == 1 ? fr.x : fr.y);
   const bool ok2 = ok1 && a < NV && b < NV && c < NV;
@@ -783,7 +863,22 @@ __device__ __forceinline__ void para_operands_flat(uint32_t p, const uint32_t *f
 
 // The body of k_traverse for one mesh on one wave; LDS: sh_tf[TR_SLOTS], sh_tv[TR_SLOTS] (in-run membership of faces / tips),
 // zeroed by the caller.  Also the second half of k_chain.
+//
+// A step of the speculative traversal is bound by dependent memory round trips (0.5 - 1 us each on the busy chip), so the loop is
+// built to need as few as possible:
+//   * "fast" attempt (the common case along a strip): everything a pair needs -- the record at a, the record at b = Opposite(Next(a)),
+//     the visited marks of both faces, of the faces behind their other edges and of both tips -- is loaded in ONE round trip at ids
+//     extrapolated from the previous run (six arithmetic progressions: a, b, the two tips, the corner left of a, the corner right of
+//     b); each lane then checks every extrapolated id against what the records it loaded say, and only lanes whose ids all agree take
+//     part.  The decision logic is the same as in the dependent attempt, on the same data.
+//   * dependent attempt (after a turn, or when the extrapolation failed): exact hops seed the path, then records of a, records of b
+//     and the marks in three round trips, as the data dependences dictate.
+//   * a fast attempt that fails on its first pair hands that pair's record -- and, when its extrapolated ids were right, its marks --
+//     to the scalar step, which then needs no load at all.
+template <bool CP>
 __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t fuse_operands, unsigned long long *sh_tf, unsigned long long *sh_tv) {
+  typedef Rec<CP> R;
+  typedef typename R::Raw Raw;
   if (status_of(D) != ST_OK || D->encoder_type == 0 || D->general) return;   // point clouds have no connectivity; general meshes: k_general
   const uint32_t *frec = (const uint32_t *)(arena + L.frec);
   uint32_t *d2c = (uint32_t *)(arena + L.d2c);
@@ -796,24 +891,35 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
   uint32_t *stack = (uint32_t *)(arena + L.fstamp);
   const uint32_t stack_cap = F;
   const uint32_t lane = lane_id();
+  const uint32_t tri = lane * (lane - 1u) / 2u;              // i (i - 1) / 2 (lane 0: 0 * 0xFFFFFFFF / 2 = 0)
   const uint64_t t_start = clk(), r_start = realclk();
 
   uint32_t count = 0, sp = 0, f_scan = 0;
   uint32_t run_id = 0;        // stamps of newer runs compare smaller, so atomicMin always replaces older ones
-  bool have_step = false;     // (step, dd) of the candidate path carried over from the previous run
-  int64_t step = 0, dd = 0;
+  // Progressions carried from the last run: lane i of the next run expects  q0 + i qs + qd i (i - 1) / 2  (32-bit wrap-around
+  // arithmetic: a wrong value is merely a wrong guess, every id is checked against the records)
+  bool have_prog = false;
+  uint32_t pa_s = 0, pa_d = 0;                                  // a: starts at `corner`
+  uint32_t pb_0 = 0, pb_s = 0, pb_d = 0, pta_0 = 0, pta_s = 0, pta_d = 0, ptb_0 = 0, ptb_s = 0, ptb_d = 0;
+  uint32_t pla_0 = 0, pla_s = 0, pla_d = 0, prb_0 = 0, prb_s = 0, prb_d = 0;
   uint32_t backoff = 0;       // scalar steps to take before speculating again
   uint32_t fail_streak = 0;   // attempts in a row that retired nothing
   // Pairs the next attempt loads and checks (its memory traffic is proportional to it).  A run that ended on a turn
   // of the spiral predicts the following sides: they grow by one pair per ring, and sides cut by the boundary
   // alternate, so the window is the longer of the last two such runs plus a margin; anything else opens it fully.
   uint32_t window = WAVE, side1 = WAVE, side2 = WAVE;
-  uint32_t n_run = 0, n_run_faces = 0, n_scalar = 0, n_fail = 0;
+  uint32_t n_run = 0, n_run_faces = 0, n_scalar = 0, n_fail = 0, n_fast = 0;
   bool failed = false;
-  bool carry = false;         // (v, rc, lc) of the current corner handed over by the run that ended on it
+  bool carry = false;         // (v, rc, lc) of the current corner handed over by the attempt that ended on it
   uint32_t c_v = 0, c_rc = 0, c_lc = 0;
-#ifdef DSA_TRAV_HIST
-  uint32_t hist[6] = {0, 0, 0, 0, 0, 0}, hist_len[6] = {0, 0, 0, 0, 0, 0}, why0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, whyK[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef DSA_TRAV_PROFILE
+  // shader clocks by phase: [0] fast loads (issue -> ids checked), [1] head loads, [2] dependent hops + loads, [3] tables + verdict,
+  // [4] retirement + progressions, [5] scalar step; counts: fast attempts, fast hits, dependent attempts, heads
+  uint64_t tp_acc[6] = {0, 0, 0, 0, 0, 0}, tp_last = clk();
+  uint32_t np_fast_hit = 0, np_dep = 0, np_head = 0, np_fast_scalar = 0;
+#define TPROF(slot_) { const uint64_t t_ = clk(); tp_acc[slot_] += t_ - tp_last; tp_last = t_; }
+#else
+#define TPROF(slot_)
 #endif
 #define TR_FAIL(site) { if (lane == 0) fail(D, ST_INVALID, (site)); failed = true; break; }
 #define VISIT_SCALAR(v_, c_) { if (lane == 0) { vflag[v_] = (uint8_t)(uni_flag | 1u); d2c[count] = (c_); v2d[v_] = (int32_t)count; } ++count; }
@@ -835,42 +941,135 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
       if (lane == 0) stack[0] = corner;
       sp = 1;
       // DepthFirstTraverser.cs:17-30: the two vertices of the start edge
-      const uint4 vv = ((const uint4 *)frec)[(size_t)found * 2];
+      const uint4 vv = R::vertices_of(frec, found);
       const uint32_t nv = uni(vv.y), pv = uni(vv.z);       // Next(corner 0) = corner 1, Previous = corner 2
       if (nv >= NV || pv >= NV) TR_FAIL(300);
       { uint32_t uni_flag = uni((uint32_t)vflag[nv]); if (!(uni_flag & 1u)) { if (count >= L.cap_vertices) TR_FAIL(302); VISIT_SCALAR(nv, corner + 1); } }
       WAIT_VM0();
       { uint32_t uni_flag = uni((uint32_t)vflag[pv]); if (!(uni_flag & 1u)) { if (count >= L.cap_vertices) TR_FAIL(302); VISIT_SCALAR(pv, corner + 2); } }
       WAIT_VM0();
+      have_prog = false; carry = false;
     }
     uint32_t corner = uni(stack[sp - 1]);
-    if (corner == DSA_INVALID || corner >= 4 * F || uni((uint32_t)fvis[corner >> 2])) { --sp; continue; }
+    if (corner == DSA_INVALID || corner >= 4 * F || uni((uint32_t)fvis[corner >> 2])) { --sp; have_prog = false; carry = false; continue; }
 
     for (;;) {   // DepthFirstTraverser.cs:39-97 inner loop
       const uint32_t face = corner >> 2;
-      uint32_t v, rc, lc;
-      if (carry) {             // the record of this corner was lane K's in the run that just ended: no read
-        v = c_v; rc = c_rc; lc = c_lc;
-        carry = false;
-      } else {
-        const uint4 vv0 = ((const uint4 *)frec)[(size_t)face * 2], oo0 = ((const uint4 *)frec)[(size_t)face * 2 + 1];
-        const uint32_t kc0 = corner & 3u;
-        v = uni(kc0 == 0 ? vv0.x : (kc0 == 1 ? vv0.y : vv0.z));
-        rc = uni(kc0 == 0 ? oo0.y : (kc0 == 1 ? oo0.z : oo0.x));
-        lc = uni(kc0 == 0 ? oo0.z : (kc0 == 1 ? oo0.x : oo0.y));
-      }
-      if (v >= NV || (rc != DSA_INVALID && !corner_ok(rc)) || (lc != DSA_INVALID && !corner_ok(lc))) TR_FAIL(301);
-      // tip flag and the state of both sides, issued together (the scalar step needs them as well)
-      const uint32_t tip_flag = vflag[v];
-      const uint32_t side_r = rc != DSA_INVALID ? (uint32_t)fvis[rc >> 2] : 1u, side_l = lc != DSA_INVALID ? (uint32_t)fvis[lc >> 2] : 1u;
-      const uint32_t uni_flag = uni(tip_flag);
-      const bool rdone = rc == DSA_INVALID || (rc >> 2) == face || uni(side_r) != 0;
-      const bool ldone = lc == DSA_INVALID || (lc >> 2) == face || uni(side_l) != 0;
-      // this element moves right: tip new & interior, or only the right side is open
-      const bool moves_right = uni_flag == 0 || (!rdone && ldone);
+      // inputs of the scalar step
+      uint32_t v = 0, rc = 0, lc = 0, uni_flag = 0;
+      bool rdone = false, ldone = false;
+      // per-lane state of an attempt (pair `lane`: N element at a, face A; L element at b = Opposite(Next(a)), face B)
+      bool attempt = false, fast = false;
+      uint32_t a = 0, b = 0, tipA = 0, lcA = DSA_INVALID, tipB = 0, rcB = DSA_INVALID, lcB = DSA_INVALID;
+      uint32_t fA_before = 0, fB_before = 1, fR_before = 1, fL_before = 1, fLA_before = 1, flA = 1, flB = 0;
+      bool in_chain = false, pair_ok = false;
+      uint32_t len = 0;
 
-      // ------------------------------------------------------------------ speculative (right left)^k run
-      if (moves_right && backoff == 0) {
+      if (have_prog && backoff == 0) {
+        // ---------------------------------------------------------------- fast attempt: one round trip at extrapolated ids
+        attempt = true; fast = true; ++n_fast;
+        a = corner + lane * pa_s + pa_d * tri;
+        const uint32_t a_nx = corner + (lane + 1u) * pa_s + pa_d * (tri + lane);     // a of pair lane + 1
+        const uint32_t b_p = pb_0 + lane * pb_s + pb_d * tri, tA_p = pta_0 + lane * pta_s + pta_d * tri, tB_p = ptb_0 + lane * ptb_s + ptb_d * tri;
+        const uint32_t lA_p = pla_0 + lane * pla_s + pla_d * tri, rB_p = prb_0 + lane * prb_s + prb_d * tri;
+        const bool a_ok = lane < window && corner_ok(a);
+        const bool bp_ok = a_ok && corner_ok(b_p);
+        Raw ra = R::none(), rb = R::none();
+        if (a_ok) ra = R::load(frec, a >> 2);
+        if (bp_ok) rb = R::load(frec, b_p >> 2);
+        if (bp_ok) {
+          fA_before = lane == 0 ? 0u : fvis[a >> 2];
+          fB_before = fvis[b_p >> 2];
+          fLA_before = corner_ok(lA_p) ? fvis[lA_p >> 2] : 1u;
+          fR_before = corner_ok(rB_p) ? fvis[rB_p >> 2] : 1u;
+          fL_before = corner_ok(a_nx) ? fvis[a_nx >> 2] : 1u;
+          flA = tA_p < NV ? vflag[tA_p] : 1u;
+          flB = tB_p < NV ? vflag[tB_p] : 1u;
+        }
+        const uint32_t ka = a & 3u, kb = b_p & 3u;
+        tipA = R::vertex(ra, ka); b = R::opp(ra, k_next(ka)); lcA = R::opp(ra, k_prev(ka));
+        tipB = R::vertex(rb, kb); rcB = R::opp(rb, k_next(kb)); lcB = R::opp(rb, k_prev(kb));
+        // every extrapolated id against the records; then the ranges the dependent attempt checks
+        const bool match = bp_ok && b == b_p && tipA == tA_p && lcA == lA_p && tipB == tB_p && rcB == rB_p && lcB == a_nx &&
+                           tipA < NV && tipB < NV && corner_ok(lcB) && (lcA == DSA_INVALID || corner_ok(lcA)) && (rcB == DSA_INVALID || corner_ok(rcB));
+        len = leading_lanes(match);
+        in_chain = lane < len;
+        pair_ok = in_chain;
+        TPROF(0);
+      } else {
+        // ---------------------------------------------------------------- head: the record and the marks of the current corner
+        if (carry) {             // the record of this corner was loaded by the attempt that ended on it: no read
+          v = c_v; rc = c_rc; lc = c_lc;
+          carry = false;
+        } else {
+          const Raw r0 = R::load(frec, face);
+          const uint32_t kc0 = corner & 3u;
+          v = uni(R::vertex(r0, kc0)); rc = uni(R::opp(r0, k_next(kc0))); lc = uni(R::opp(r0, k_prev(kc0)));
+        }
+        if (v >= NV || (rc != DSA_INVALID && !corner_ok(rc)) || (lc != DSA_INVALID && !corner_ok(lc))) TR_FAIL(301);
+        // tip flag and the state of both sides, issued together
+        const uint32_t tip_flag = vflag[v];
+        const uint32_t side_r = rc != DSA_INVALID ? (uint32_t)fvis[rc >> 2] : 1u, side_l = lc != DSA_INVALID ? (uint32_t)fvis[lc >> 2] : 1u;
+        uni_flag = uni(tip_flag);
+        rdone = rc == DSA_INVALID || (rc >> 2) == face || uni(side_r) != 0;
+        ldone = lc == DSA_INVALID || (lc >> 2) == face || uni(side_l) != 0;
+        // this element moves right: tip new & interior, or only the right side is open
+        const bool moves_right = uni_flag == 0 || (!rdone && ldone);
+#ifdef DSA_TRAV_PROFILE
+        ++np_head;
+#endif
+        TPROF(1);
+        if (moves_right && backoff == 0) {
+          // -------------------------------------------------------------- dependent attempt: exact hops seed the candidate path
+          // a_0, a_1 = succ(a_0), a_2 with succ(a) = Opposite(Previous(Opposite(Next(a)))); lanes 3.. extrapolate with constant
+          // second difference; every link is verified from the records the lanes load anyway
+          attempt = true;
+          const uint32_t a0 = corner;
+          auto opp_prev_of = [&](uint32_t b1) -> uint32_t {          // Opposite(Previous(b1)), uniform
+            if (!corner_ok(b1)) return DSA_INVALID;
+            return uni(R::get_o(frec, qprev(b1)));
+          };
+          auto opp_next_of = [&](uint32_t c) -> uint32_t { return corner_ok(c) ? uni(R::get_o(frec, qnext(c))) : DSA_INVALID; };
+          // Opposite(Next(a0)) is `rc`, read by the head: the first hop needs one read, not two
+          const uint32_t a1 = opp_prev_of(rc), a2 = opp_prev_of(opp_next_of(a1));
+          const uint32_t d1 = a1 - a0, d2 = a2 - a1, ddh = d2 - d1;
+          const uint32_t exact = corner_ok(a2) ? 3u : (corner_ok(a1) ? 2u : 1u);
+          a = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : a2 + (lane - 2u) * (d2 + ddh) + ddh * ((lane - 2u) * (lane - 3u) / 2u);
+          bool a_ok = lane < window && corner_ok(a) && (lane < exact || exact == 3);
+          Raw ra = R::none(), rb = R::none();
+          if (a_ok) ra = R::load(frec, a >> 2);
+          const uint32_t ka = a & 3u;
+          tipA = R::vertex(ra, ka); b = R::opp(ra, k_next(ka)); lcA = R::opp(ra, k_prev(ka));
+          const bool b_ok = a_ok && corner_ok(b) && tipA < NV && (lcA == DSA_INVALID || corner_ok(lcA));
+          if (b_ok) rb = R::load(frec, b >> 2);
+          const uint32_t kb = b & 3u;
+          tipB = R::vertex(rb, kb); rcB = R::opp(rb, k_next(kb)); lcB = R::opp(rb, k_prev(kb));
+          const uint32_t next_a = b_ok ? lcB : DSA_INVALID;           // succ(a)
+          {
+            const uint32_t prev_next = lane_prev(next_a);
+            a_ok = a_ok && (lane == 0 || prev_next == a);
+          }
+          len = leading_lanes(a_ok);                 // verified chain a_0 .. a_(len-1)
+          in_chain = lane < len;
+          pair_ok = in_chain && b_ok && tipB < NV && corner_ok(lcB) && (rcB == DSA_INVALID || corner_ok(rcB));
+          if (pair_ok) {                             // state before the step
+            fA_before = lane == 0 ? 0u : fvis[a >> 2];
+            fLA_before = lcA != DSA_INVALID ? fvis[lcA >> 2] : 1u;
+            fB_before = fvis[b >> 2];
+            fR_before = rcB != DSA_INVALID ? fvis[rcB >> 2] : 1u;
+            fL_before = fvis[lcB >> 2];
+            flA = vflag[tipA]; flB = vflag[tipB];
+          }
+#ifdef DSA_TRAV_PROFILE
+          { const uint64_t m_ = __ballot(pair_ok && (fA_before | fB_before | flA | flB) == 0x12345u); (void)m_; ++np_dep; }     // forces the loads
+#endif
+          TPROF(2);
+        } else if (backoff) {
+          --backoff;
+        }
+      }
+
+      if (attempt) {
         if (++run_id >= 0x00FFFFF0u) {        // 24-bit run tags: start over with empty tables (meshes with > 16 M runs)
           __syncthreads();
           for (uint32_t i = lane; i < TR_SLOTS; i += WAVE) { sh_tf[i] = 0; sh_tv[i] = 0; }
@@ -878,77 +1077,7 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
           run_id = 1;
         }
         const uint32_t base = (0x00FFFFFFu - run_id) << 8;
-        // candidate path a_i = a_0 + i*step + dd*i*(i-1)/2.  (step, dd) carry over from the previous run
-        // (its last step + dd); if the first link then fails, three exact hops re-seed them.
-        const uint32_t a0 = corner;
-        auto succ = [&](uint32_t c) -> uint32_t {       // uniform: two dependent record loads
-          if (!corner_ok(c)) return DSA_INVALID;
-          const uint4 o1 = ((const uint4 *)frec)[(size_t)(c >> 2) * 2 + 1];
-          const uint32_t k1 = c & 3u;
-          const uint32_t b1 = uni(k1 == 0 ? o1.y : (k1 == 1 ? o1.z : o1.x));
-          if (!corner_ok(b1)) return DSA_INVALID;
-          const uint4 o2 = ((const uint4 *)frec)[(size_t)(b1 >> 2) * 2 + 1];
-          const uint32_t k2 = b1 & 3u;
-          return uni(k2 == 0 ? o2.z : (k2 == 1 ? o2.x : o2.y));
-        };
-        int64_t ai;
-        bool a_ok;
-        uint32_t exact = 1;                      // lanes < exact hold hopped (exact) corners
-        if (have_step) {
-          const int64_t i = lane;
-          ai = (int64_t)a0 + i * step + dd * i * (i - 1) / 2;
-        } else {
-          // two exact hops (four dependent record loads) seed the step and its change; the links of the
-          // extrapolated path are verified from the loaded records anyway
-          // Opposite(Next(a0)) is `rc`, read by the head of this iteration: the first hop needs one read, not two
-          auto succ_b = [&](uint32_t b1) -> uint32_t {
-            if (!corner_ok(b1)) return DSA_INVALID;
-            const uint4 o2 = ((const uint4 *)frec)[(size_t)(b1 >> 2) * 2 + 1];
-            const uint32_t k2 = b1 & 3u;
-            return uni(k2 == 0 ? o2.z : (k2 == 1 ? o2.x : o2.y));
-          };
-          const uint32_t a1 = succ_b(rc), a2 = succ(a1);
-          const int64_t d1 = (int64_t)a1 - a0, d2 = (int64_t)a2 - a1;
-          const int64_t ddh = d2 - d1;
-          const int64_t i = lane;
-          ai = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : (int64_t)a2 + (i - 2) * (d2 + ddh) + ddh * (i - 2) * (i - 3) / 2;
-          exact = corner_ok(a2) ? 3 : (corner_ok(a1) ? 2 : 1);
-          step = d1; dd = ddh;               // provisional; replaced below from the verified chain
-        }
-        a_ok = lane < window && ai >= 0 && ai < (int64_t)4 * F && ((uint32_t)ai & 3u) != 3u && (lane < exact || have_step || exact == 3);
-        const uint32_t a = a_ok ? (uint32_t)ai : 0u;
-        // pair `lane`: N element at a (face A), L element at b = Opposite(Next(a)) (face B)
-        const uint32_t fa = a >> 2, ka = a & 3u;
-        uint4 va = make_uint4(0, 0, 0, 0), oa = make_uint4(DSA_INVALID, DSA_INVALID, DSA_INVALID, 0);
-        if (a_ok) { va = ((const uint4 *)frec)[(size_t)fa * 2]; oa = ((const uint4 *)frec)[(size_t)fa * 2 + 1]; }
-        const uint32_t tipA = ka == 0 ? va.x : (ka == 1 ? va.y : va.z);
-        const uint32_t b = ka == 0 ? oa.y : (ka == 1 ? oa.z : oa.x);
-        const uint32_t lcA = ka == 0 ? oa.z : (ka == 1 ? oa.x : oa.y);
-        const bool b_ok = a_ok && corner_ok(b) && tipA < NV && (lcA == DSA_INVALID || corner_ok(lcA));
-        const uint32_t fb = b >> 2, kb = b & 3u;
-        uint4 vb = make_uint4(0, 0, 0, 0), ob = make_uint4(DSA_INVALID, DSA_INVALID, DSA_INVALID, 0);
-        if (b_ok) { vb = ((const uint4 *)frec)[(size_t)fb * 2]; ob = ((const uint4 *)frec)[(size_t)fb * 2 + 1]; }
-        const uint32_t tipB = kb == 0 ? vb.x : (kb == 1 ? vb.y : vb.z);
-        const uint32_t rcB = kb == 0 ? ob.y : (kb == 1 ? ob.z : ob.x);
-        const uint32_t lcB = kb == 0 ? ob.z : (kb == 1 ? ob.x : ob.y);
-        const uint32_t next_a = b_ok ? lcB : DSA_INVALID;           // succ(a)
-        {
-          const uint32_t prev_next = lane_prev(next_a);
-          a_ok = a_ok && (lane == 0 || prev_next == a);
-        }
-        uint32_t len = leading_lanes(a_ok);                 // verified chain a_0 .. a_(len-1)
-        const bool in_chain = lane < len;
-        const bool pair_ok = in_chain && b_ok && tipB < NV && corner_ok(lcB) && (rcB == DSA_INVALID || corner_ok(rcB));
-        // state before the step (plain loads, issued ahead of the stamp atomics)
-        uint32_t fA_before = 0, fB_before = 1, fR_before = 1, fL_before = 1, fLA_before = 1, flA = 1, flB = 0;
-        if (pair_ok) {
-          fA_before = lane == 0 ? 0u : fvis[fa];
-          fLA_before = lcA != DSA_INVALID ? fvis[lcA >> 2] : 1u;
-          fB_before = fvis[fb];
-          fR_before = rcB != DSA_INVALID ? fvis[rcB >> 2] : 1u;
-          fL_before = fvis[lcB >> 2];
-          flA = vflag[tipA]; flB = vflag[tipB];
-        }
+        const uint32_t fa = a >> 2, fb = b >> 2;
         // First position of every face / tip in the candidate list: two small open-addressing tables in LDS,
         // slot = run tag (24) | id (32) | position (8); a slot of an older run counts as empty, so nothing is
         // cleared between runs.  Exact: the smallest position per id wins (ds_min_u64).
@@ -982,9 +1111,6 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
           if (!(flB & 1u)) tbl_insert(sh_tv, tipB, 2 * lane + 1);
         }
         __syncthreads();
-#ifdef DSA_TRAV_HIST
-        uint32_t why = pair_ok ? 0u : (in_chain ? 6u : 7u);
-#endif
         bool good = false, newA = false, newB = false;
         if (pair_ok) {
           const uint32_t sfa = tbl_lookup(sh_tf, fa), sfb = tbl_lookup(sh_tf, fb);
@@ -1006,15 +1132,9 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
           const bool l_open = (lcB >> 2) != fb && fL_before == 0 && !((slf >> 8) == run_tag && slf < keyL);
           const bool y_ok = fB_before == 0 && sfb == keyL && !(newB && !(flB & 2u)) && r_done && l_open;
           good = x_ok && y_ok;
-#ifdef DSA_TRAV_HIST
-          why = !x_ok ? 1u : (fB_before != 0 || sfb != keyL) ? 2u : (newB && !(flB & 2u)) ? 3u : !r_done ? 4u : !l_open ? 5u : 0u;
-#endif
         }
         const uint32_t K = leading_lanes(good);
-#ifdef DSA_TRAV_HIST
-        if (K < 64) { const uint32_t w = rdlane(why, K); if (K == 0) why0[w]++; else whyK[w]++; }
-        { const uint32_t bin = K == 0 ? 0 : K < 4 ? 1 : K < 16 ? 2 : K < 48 ? 3 : K < 64 ? 4 : 5; hist[bin]++; hist_len[len == 0 ? 0 : len < 4 ? 1 : len < 16 ? 2 : len < 48 ? 3 : len < 64 ? 4 : 5]++; }
-#endif
+        TPROF(3);
         // entries made by the retired pairs: a new tip is numbered when its element is reached (:53-58)
         const uint64_t kmask = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
         const uint64_t mA = __ballot(newA) & kmask, mB = __ballot(newB) & kmask;
@@ -1027,22 +1147,28 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
             if (newA) { vflag[tipA] = (uint8_t)(flA | 1u); d2c[posA] = a; v2d[tipA] = (int32_t)posA; }
             if (newB) { const uint32_t posB = posA + (newA ? 1u : 0u); vflag[tipB] = (uint8_t)(flB | 1u); d2c[posB] = b; v2d[tipB] = (int32_t)posB; }
           }
-          const uint32_t nxt = rdlane(next_a, K - 1);          // Opposite(Previous(b_(K-1))): where the DFS continues
+          const uint32_t nxt = rdlane(lcB, K - 1);             // Opposite(Previous(b_(K-1))): where the DFS continues
           count += made;
-          if (K >= 3) {       // next run: continue the verified progression
-            const int64_t aK1 = rdlane(a, K - 1), aK2 = rdlane(a, K - 2), aK3 = rdlane(a, K - 3);
-            const int64_t s1 = (int64_t)nxt - aK1, s0 = aK1 - aK2, sm = aK2 - aK3;
-            dd = (s1 - s0 == s0 - sm) ? s1 - s0 : 0;
-            step = s1 + dd;
-            have_step = true;
-          } else have_step = false;
+          have_prog = false;
+          if (K >= 3 && !(K < WAVE && len > K)) {       // next run: continue the verified progressions
+            const uint32_t aK1 = rdlane(a, K - 1), aK2 = rdlane(a, K - 2), aK3 = rdlane(a, K - 3);
+            const uint32_t s1 = nxt - aK1, s0 = aK1 - aK2, sm = aK2 - aK3;
+            pa_d = (s1 - s0 == s0 - sm) ? s1 - s0 : 0u;
+            pa_s = s1 + pa_d;
+#define TR_PROG(q_, q0_, qs_, qd_) { const uint32_t x1 = rdlane(q_, K - 1), x2 = rdlane(q_, K - 2), x3 = rdlane(q_, K - 3); \
+                                     const uint32_t t0 = x1 - x2, tm = x2 - x3; qd_ = t0 - tm; q0_ = x1 + t0 + qd_; qs_ = t0 + 2u * qd_; }
+            TR_PROG(b, pb_0, pb_s, pb_d); TR_PROG(tipA, pta_0, pta_s, pta_d); TR_PROG(tipB, ptb_0, ptb_s, ptb_d);
+            TR_PROG(lcA, pla_0, pla_s, pla_d); TR_PROG(rcB, prb_0, prb_s, prb_d);
+#undef TR_PROG
+            have_prog = true;
+          }
           corner = nxt;
           n_run += 1; n_run_faces += 2 * K;
           fail_streak = 0;
           // Pair K lies on the verified path but is not an (N L) pair (a turn of the spiral, a boundary
           // vertex, a split): re-attempting from it would reach the same verdict, so step over it first.
           if (K < WAVE && len > K) {
-            backoff = 1; have_step = false;
+            backoff = 1;
             // pair K was loaded and its link verified: its corner is where the DFS stands now, and its tip and the
             // corners behind its two other edges are what the next iteration would read first
             c_v = rdlane(tipA, K); c_rc = rdlane(b, K); c_lc = rdlane(lcA, K);
@@ -1050,15 +1176,31 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
           }
           if ((fuse_operands & 2u) && K < window && len > K) { side2 = side1; side1 = K; const uint32_t m = (side1 > side2 ? side1 : side2) + 4; window = m < WAVE ? m : WAVE; }
           else window = WAVE;
+#ifdef DSA_TRAV_PROFILE
+          if (fast) ++np_fast_hit;
+#endif
+          TPROF(4);
           continue;
         }
         ++n_fail;
-        if (have_step && len < 2) { have_step = false; continue; }   // the extrapolated path broke at once: re-seed it with exact hops
-        have_step = false;
-        backoff = fail_streak < 3 ? fail_streak : 3;                   // this step is taken by the scalar path below
-        ++fail_streak;
-      } else if (backoff) {
-        --backoff;
+        have_prog = false;
+        if (fast) {
+          // lane 0 loaded the record of the current corner whatever the other ids were worth
+          c_v = rdlane(tipA, 0); c_rc = rdlane(b, 0); c_lc = rdlane(lcA, 0);
+          if (len == 0) { carry = true; continue; }          // its marks were read at wrong ids: the head reads them
+          // the extrapolated ids of pair 0 were right, so were the marks: the verdict "not an (N L) pair" stands, and the scalar
+          // step has all it needs
+#ifdef DSA_TRAV_PROFILE
+          ++np_fast_scalar;
+#endif
+          v = c_v; rc = c_rc; lc = c_lc;
+          uni_flag = rdlane(flA, 0);
+          rdone = (rc >> 2) == face || rdlane(fB_before, 0) != 0;         // rc is a corner: pair 0 matched
+          ldone = lc == DSA_INVALID || (lc >> 2) == face || rdlane(fLA_before, 0) != 0;
+        } else {
+          backoff = fail_streak < 3 ? fail_streak : 3;                   // this step is taken by the scalar path below
+          ++fail_streak;
+        }
       }
       // ------------------------------------------------------------------ scalar step (reference loop body)
       ++n_scalar;
@@ -1081,21 +1223,24 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
           if (sp >= stack_cap) TR_FAIL(304);
           if (lane == 0) { stack[sp - 1] = lc; stack[sp] = rc; }
           ++sp;
+          TPROF(5);
           break;
         }
       }
+      TPROF(5);
     }
     if (failed) break;
+    have_prog = false; carry = false;
   }
   if (failed) return;
   if (lane == 0) {
     D->num_entries = count;
     D->dbg[5] = n_fail; D->dbg[6] = (uint32_t)(clk() - t_start);
     D->dbg[16] = (uint32_t)r_start; D->dbg[17] = (uint32_t)(realclk() - r_start);
-    D->dbg[7] = n_run; D->dbg[8] = n_run_faces; D->dbg[9] = n_scalar;
-#ifdef DSA_TRAV_HIST
-    for (int i = 0; i < 8; ++i) D->dbg[i] = why0[i] | (whyK[i] << 16);
-    D->dbg[10] = hist[5]; D->dbg[11] = hist_len[5];
+    D->dbg[7] = n_run; D->dbg[8] = n_run_faces; D->dbg[9] = n_scalar; D->dbg[3] = n_fast;
+#ifdef DSA_TRAV_PROFILE
+    for (int i = 0; i < 5; ++i) D->dbg[10 + (i < 3 ? i : i + 5)] = (uint32_t)(tp_acc[i] >> 4);   // [10] [11] [12] [18] [19], in units of 16 clocks
+    D->dbg[0] = (uint32_t)(tp_acc[5] >> 4); D->dbg[1] = np_fast_hit; D->dbg[2] = np_dep; D->dbg[4] = np_head; D->dbg[13] = np_fast_scalar;
 #endif
     // a valid stream carries exactly one entry per encoded vertex (k_locate sized the symbol streams on that)
     if (count != D->num_enc_vertices) fail(D, ST_INVALID, 305);
@@ -1113,7 +1258,7 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const uint32_t p = p0 + u * WAVE + lane;
-        para_operands_flat(p < count ? p : 0u, frec, d2c, v2d, F, NV, en[u], ep[u], eo[u]);
+        para_operands_flat<CP>(p < count ? p : 0u, frec, d2c, v2d, F, NV, en[u], ep[u], eo[u]);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -1145,6 +1290,7 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
   }
 #undef TR_FAIL
 #undef VISIT_SCALAR
+#undef TPROF
 }
 
 __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t fuse_operands) {
@@ -1154,7 +1300,8 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   __builtin_amdgcn_s_setprio(3);   // critical path: issue ahead of the entropy-decode waves sharing the CU
   const uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
-  traverse_wave(arena, layouts[mesh], &descs[mesh], fuse_operands, sh_tf, sh_tv);
+  if (layouts[mesh].rec_compact) traverse_wave<true>(arena, layouts[mesh], &descs[mesh], fuse_operands, sh_tf, sh_tv);
+  else traverse_wave<false>(arena, layouts[mesh], &descs[mesh], fuse_operands, sh_tf, sh_tv);
 }
 
 // k_chain: connectivity and traversal of a mesh by the same wave, back to back.  As two kernels the traversal's waves
@@ -1164,7 +1311,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
 // LDS (CN_LDS_WORDS * 4 bytes) is passed at launch: with the size hidden from the compiler, the launch bound alone sets the
 // register budget (64 VGPRs: four of these waves and three entropy-decode waves of 80 share a SIMD's 512).
 extern __shared__ __attribute__((aligned(16))) uint32_t sh_chain[];
-__global__ __launch_bounds__(WAVE, 8) void k_chain(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t fuse_operands) {
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_num_vgpr(64), amdgpu_num_sgpr(96))) void k_chain(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t fuse_operands) {
   uint32_t *sh = sh_chain;
   static_assert(CN_LDS_WORDS * 4 >= 2 * TR_SLOTS * 8, "the traversal's tables reuse the connectivity's LDS");
   __builtin_amdgcn_s_setprio(3);
@@ -1172,14 +1319,17 @@ __global__ __launch_bounds__(WAVE, 8) void k_chain(uint8_t *arena, const MeshLay
   if (mesh >= n) return;
   const MeshLayout &L = layouts[mesh];
   MeshDesc *D = &descs[mesh];
-  connectivity_wave(arena, L, D, sh, sh + CN_STAGE * 8, sh + CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2);
+  const bool compact = uni(L.rec_compact) != 0;
+  if (compact) connectivity_wave<true>(arena, L, D, sh, sh + CN_STAGE * 8, sh + CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2);
+  else connectivity_wave<false>(arena, L, D, sh, sh + CN_STAGE * 8, sh + CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2);
   // the traversal reads what this wave (all lanes) just wrote: records, ranks, flags
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
   __syncthreads();
   unsigned long long *sh_tf = (unsigned long long *)sh, *sh_tv = sh_tf + TR_SLOTS;
   for (uint32_t i = threadIdx.x; i < TR_SLOTS; i += WAVE) { sh_tf[i] = 0; sh_tv[i] = 0; }
   __syncthreads();
-  traverse_wave(arena, L, D, fuse_operands, sh_tf, sh_tv);
+  if (compact) traverse_wave<true>(arena, L, D, fuse_operands, sh_tf, sh_tv);
+  else traverse_wave<false>(arena, L, D, fuse_operands, sh_tf, sh_tv);
 }
 
 
@@ -2276,15 +2426,18 @@ __global__ __launch_bounds__(256) void k_faces(uint8_t *arena, const MeshLayout 
   if (D->status != ST_OK || D->general || D->encoder_type == 0) return;   // k_general writes the faces of its meshes
   const MeshLayout &L = layouts[mesh];
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-  const uint4 *frec = (const uint4 *)(arena + L.frec);
+  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
   const uint32_t *vrank = (const uint32_t *)(arena + L.vrank);
   int32_t *faces = (int32_t *)(arena + L.faces);
   const uint32_t NV = D->num_vertices;
+  const bool compact = L.rec_compact != 0;
   // Every link k_connectivity makes sets two corners; a corner linked twice ("corner already has an
   // opposite", MeshEdgeBreakerDecoder.cs:254,272,314,392) leaves fewer linked corners than 2 x links.
   uint32_t linked = 0, bad = 0;
   for (uint32_t f = tid; f < D->num_faces; f += stride) {
-    const uint4 vv = frec[(size_t)f * 2], oo = frec[(size_t)f * 2 + 1];
+    uint4 vv, oo;
+    if (compact) { const Rec<true>::Raw r = Rec<true>::load(frec, f); vv = make_uint4(Rec<true>::vertex(r, 0), Rec<true>::vertex(r, 1), Rec<true>::vertex(r, 2), 0u); oo = make_uint4(Rec<true>::opp(r, 0), Rec<true>::opp(r, 1), Rec<true>::opp(r, 2), 0u); }
+    else { const Rec<false>::Raw r = Rec<false>::load(frec, f); vv = r.v; oo = r.o; }
     linked += (oo.x != DSA_INVALID) + (oo.y != DSA_INVALID) + (oo.z != DSA_INVALID);
     if (vv.x < NV && vv.y < NV && vv.z < NV) {
       faces[3 * f] = (int32_t)vrank[vv.x]; faces[3 * f + 1] = (int32_t)vrank[vv.y]; faces[3 * f + 2] = (int32_t)vrank[vv.z];

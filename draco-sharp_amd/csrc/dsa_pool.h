@@ -42,7 +42,7 @@ uint32_t dsa_pool_plan(uint32_t n, const size_t *lengths, uint32_t chunk_meshes,
 
 static dsa_status pool_create(const int *devices, uint32_t num_devices, uint32_t chunk_meshes, dsa_pool **out) {
   dsa_pool *p = new dsa_pool();
-  p->chunk = chunk_meshes ? std::min<uint32_t>(chunk_meshes, 65535u) : 256u;
+  p->chunk = std::min<uint32_t>(chunk_meshes, 65535u);      // 0: chosen per job (pool_decode)
   for (uint32_t i = 0; i < num_devices; ++i) {
     dsa_context *c = nullptr;
     dsa_status st = dsa_context_create(devices[i], nullptr, &c);
@@ -108,7 +108,15 @@ static dsa_status pool_decode(dsa_pool *pool, uint32_t n, const uint8_t *const *
   dsa_pool_job *job = owner.job;
   job->pool = pool;
   std::vector<uint32_t> order(n), begin(n + 1);
-  const uint32_t chunks = dsa_pool_plan(n, lengths, pool->chunk, order.data(), begin.data());
+  // chunk_meshes == 0 at creation: sized per job -- one chunk per device while a device's share is at most 4096 meshes (a batch
+  // below a few hundred meshes takes as long as one of a thousand: the per-mesh serial chains set its time), 4096-mesh chunks
+  // pulled from the queue beyond that
+  uint32_t chunk = pool->chunk;
+  if (chunk == 0) {
+    const uint64_t per_device = ((uint64_t)n + pool->ctx.size() - 1) / pool->ctx.size();
+    chunk = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(256, per_device));
+  }
+  const uint32_t chunks = dsa_pool_plan(n, lengths, chunk, order.data(), begin.data());
   job->batches.assign(chunks, nullptr);
   job->worker.assign(chunks, 0);
   job->where.resize(n);

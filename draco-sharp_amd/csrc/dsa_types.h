@@ -166,7 +166,7 @@ struct MeshLayout {
   uint32_t cap_faces;      // F from the header
   uint32_t cap_vertices;   // num_encoded_vertices + num_split_symbols
   uint32_t cap_attributes;
-  uint64_t frec;           // face records, 32 B each: {v0, v1, v2, flags, o0, o1, o2, 0}; corners are quad coded (4*face + k)
+  uint64_t frec;           // face records (dsa_kernels.h, Rec<>): 32 B {v0, v1, v2, 0, o0, o1, o2, 0} or, rec_compact, 16 B of 21-bit fields; corners are quad coded (4*face + k)
   uint64_t vrec;           // uint2[cap_vertices]: .x left-most corner of the vertex, .y vertex at Previous(left-most corner)
   uint64_t d2c;            // u32[cap_vertices]
   uint64_t v2d;            // i32[cap_vertices]
@@ -174,7 +174,7 @@ struct MeshLayout {
   uint64_t fstamp, vstamp; // u32[F], u32[cap_vertices]: (run id, position) stamps of the speculative traversal runs
   uint64_t splits;         // u32[4*cap_splits]: events (source, split|edge<<31), then active pairs (decoder symbol id, corner)
   uint32_t cap_splits;
-  uint32_t pad;
+  uint32_t rec_compact;    // 16-byte face records: every corner and vertex id of the mesh is below 2^20
   uint64_t vrank;          // u32[cap_vertices] vertex -> point id (per-attribute connectivity layout)
   uint64_t para;           // u32[3*cap_vertices] parallelogram operand entries per entry
   uint64_t faces;          // i32[3F] output (DFS stack scratch until k_finalize)

@@ -233,6 +233,9 @@ void dsa_encoded_free(dsa_encoded *encoded);
 typedef struct dsa_pool dsa_pool;
 typedef struct dsa_pool_job dsa_pool_job;
 
+/* chunk_meshes == 0: chosen per job (one chunk per device up to 4096 meshes each, 4096-mesh chunks beyond).  A worker keeps two
+ * chunks in flight on its context (upload of the next beside the kernels of the current).  Jobs may outlive the pool object:
+ * dsa_pool_destroy with jobs alive takes effect when the last of them is freed.  One dsa_pool_decode at a time per pool. */
 dsa_status dsa_pool_create(const int *devices, uint32_t num_devices, uint32_t chunk_meshes, dsa_pool **out);
 void dsa_pool_destroy(dsa_pool *pool);
 uint32_t dsa_pool_size(const dsa_pool *pool);                 /* number of contexts / worker threads */

@@ -130,7 +130,9 @@ int main(int argc, char **argv) {
       const uint32_t F = c[0], NV = c[1], E = c[2];
       const uint32_t *opp = c + 3, *c2v = opp + 3 * (size_t)F, *d2c_ref = c2v + 3 * (size_t)F;
       if (F == L.cap_faces && E <= L.cap_vertices && NV <= L.cap_vertices) {
-        uint32_t *frec = (uint32_t *)(arena.data() + L.frec), *d2c = (uint32_t *)(arena.data() + L.d2c), *para = (uint32_t *)(arena.data() + L.para);
+        // 32-byte records in a buffer of their own (the arena's region holds the kernels' 16-byte records for a mesh of this size)
+        std::vector<uint32_t> frec_wide((size_t)F * 8 + 8);
+        uint32_t *frec = frec_wide.data(), *d2c = (uint32_t *)(arena.data() + L.d2c), *para = (uint32_t *)(arena.data() + L.para);
         int32_t *v2d = (int32_t *)(arena.data() + L.v2d);
         auto quad = [](uint32_t cr) { return cr == DSA_INVALID ? cr : 4u * (cr / 3u) + cr % 3u; };
         for (uint32_t f = 0; f < F; ++f) {
