@@ -909,6 +909,7 @@ dsa_status dsa_batch_copy_debug(const dsa_batch *b, uint32_t mesh, int what, voi
       return DSA_OK;
     }
     case 3: off = L.v2d; bytes = 4ull * D.num_vertices; break;
+    case 6: off = L.vstamp; bytes = std::min<uint64_t>(dst_bytes, 4ull * L.cap_vertices); break;     // traversal trace of a -DDSA_TRAV_TRACE build
     case 5: {   // per attribute: {symbol source, alphabet size, rANS precision bits, rANS payload bytes}
       size_t need = sizeof(uint32_t) * 4 * DSA_MAX_ATT;
       if (dst_bytes < need) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "destination too small");

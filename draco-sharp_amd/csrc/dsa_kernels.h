@@ -105,6 +105,7 @@ template <> struct Rec<false> {
   // single fields straight from memory (rare paths and the element-parallel passes)
   static __device__ __forceinline__ uint32_t get_v(const uint32_t *frec, uint32_t c) { return frec[fv_idx(c)]; }
   static __device__ __forceinline__ uint32_t get_o(const uint32_t *frec, uint32_t c) { return frec[fo_idx(c)]; }
+  static __device__ __forceinline__ uint32_t get_o_plain(const uint32_t *frec, uint32_t c) { return frec[fo_idx(c)]; }
   static __device__ __forceinline__ void set_v(uint32_t *frec, uint32_t c, uint32_t val) { frec[fv_idx(c)] = val; }
   static __device__ __forceinline__ void link(uint32_t *frec, uint32_t c, uint32_t val) { frec[fo_idx(c)] = val; }           // opposite slot: none -> val
   static __device__ __forceinline__ void link_lds(uint32_t *stage, uint32_t c_rel, uint32_t val) { stage[fo_idx(c_rel)] = val; }
@@ -131,6 +132,8 @@ template <> struct Rec<true> {
   static __device__ __forceinline__ uint32_t get_o(const uint32_t *frec, uint32_t c) {
     return field(__hip_atomic_load((const unsigned long long *)frec + (size_t)(c >> 2) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c & 3u);
   }
+  // once nothing links any more (behind the acquire fence of k_chain / the kernel boundary): an ordinary load
+  static __device__ __forceinline__ uint32_t get_o_plain(const uint32_t *frec, uint32_t c) { return field(((const uint64_t *)frec)[(size_t)(c >> 2) * 2 + 1], c & 3u); }
   static __device__ __forceinline__ void set_v(uint32_t *frec, uint32_t c, uint32_t val) {      // plain read-modify-write: lane 0 on synchronised memory only
     uint64_t *w = (uint64_t *)frec + (size_t)(c >> 2) * 2;
     const uint32_t sh = 21u * (c & 3u);
@@ -850,7 +853,7 @@ __device__ __forceinline__ void para_operands_flat(uint32_t p, const uint32_t *f
   typedef Rec<CP> R;
   const uint32_t c0 = d2c[p];
   const bool ok0 = p > 0 && c0 < 4 * F && (c0 & 3u) != 3u;
-  const uint32_t oci = R::get_o(frec, ok0 ? c0 : 0u);
+  const uint32_t oci = R::get_o_plain(frec, ok0 ? c0 : 0u);
   const bool ok1 = ok0 && oci != DSA_INVALID && oci < 4 * F && (oci & 3u) != 3u;
   const uint4 fr = R::vertices_of(frec, ok1 ? (oci >> 2) : 0u);
   const uint32_t k = oci & 3u;
@@ -861,22 +864,28 @@ __device__ __forceinline__ void para_operands_flat(uint32_t p, const uint32_t *f
   en = ok3 ? (uint32_t)vn : DSA_INVALID; ep = ok3 ? (uint32_t)vp : 0u; eo = ok3 ? (uint32_t)vo : 0u;
 }
 
-// The body of k_traverse for one mesh on one wave; LDS: sh_tf[TR_SLOTS], sh_tv[TR_SLOTS] (in-run membership of faces / tips),
-// zeroed by the caller.  Also the second half of k_chain.
+// The body of k_traverse for one mesh on one wave; LDS: sh_tf[TR_SLOTS], sh_tv[TR_SLOTS] (in-run membership of faces / tips) and
+// sh_hist[TR_HIST_WORDS] (step history), zeroed by the caller.  Also the second half of k_chain.
 //
-// A step of the speculative traversal is bound by dependent memory round trips (0.5 - 1 us each on the busy chip), so the loop is
-// built to need as few as possible:
-//   * "fast" attempt (the common case along a strip): everything a pair needs -- the record at a, the record at b = Opposite(Next(a)),
-//     the visited marks of both faces, of the faces behind their other edges and of both tips -- is loaded in ONE round trip at ids
-//     extrapolated from the previous run (six arithmetic progressions: a, b, the two tips, the corner left of a, the corner right of
-//     b); each lane then checks every extrapolated id against what the records it loaded say, and only lanes whose ids all agree take
-//     part.  The decision logic is the same as in the dependent attempt, on the same data.
-//   * dependent attempt (after a turn, or when the extrapolation failed): exact hops seed the path, then records of a, records of b
-//     and the marks in three round trips, as the data dependences dictate.
-//   * a fast attempt that fails on its first pair hands that pair's record -- and, when its extrapolated ids were right, its marks --
-//     to the scalar step, which then needs no load at all.
+// A step of the speculative traversal is bound by dependent memory round trips (0.5 - 1 us each on the busy chip) and by the
+// LDS membership tables, so the loop is built to need few of either:
+//   * "fast" attempt (along a strip): everything a pair needs -- the record at a, the record at b = Opposite(Next(a)), the visited
+//     marks of both faces, of the faces behind their other edges and of both tips -- is loaded in ONE round trip at extrapolated
+//     ids (six progressions: a, b, the two tips, the corner left of a, the corner right of b); each lane then checks every
+//     extrapolated id against what the records it loaded say, and only lanes whose ids all agree take part.  The progressions
+//     continue the previous run, or, at the start of a side, combine the exact ids of the first pair with the steps the same
+//     direction had the last time (step history keyed by the step of a: a spiral has four directions).
+//   * when all six progressions are linear, "which earlier pair of this run holds face / tip X" is arithmetic
+//     ((X - first) / step is an integer below the run length) instead of a search in the LDS tables.
+//   * dependent attempt (no history for the direction): exact hops seed the path, then records of a, records of b and the marks
+//     in three round trips, as the data dependences dictate; membership through the tables.
+//   * the pair a run ends on was loaded and judged like every other: its two elements go to the scalar step with their record
+//     and their marks (as they are after the retired pairs), so a turn of the spiral costs no load until the next side's seed.
+#define TR_HIST_WORDS 32
+#define TR_NONE 0xFFFFFFFFu
 template <bool CP>
-__device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t fuse_operands, unsigned long long *sh_tf, unsigned long long *sh_tv) {
+__device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t fuse_operands, unsigned long long *sh_tf, unsigned long long *sh_tv,
+                                              uint32_t *sh_hist) {
   typedef Rec<CP> R;
   typedef typename R::Raw Raw;
   if (status_of(D) != ST_OK || D->encoder_type == 0 || D->general) return;   // point clouds have no connectivity; general meshes: k_general
@@ -891,17 +900,17 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
   uint32_t *stack = (uint32_t *)(arena + L.fstamp);
   const uint32_t stack_cap = F;
   const uint32_t lane = lane_id();
-  const uint32_t tri = lane * (lane - 1u) / 2u;              // i (i - 1) / 2 (lane 0: 0 * 0xFFFFFFFF / 2 = 0)
   const uint64_t t_start = clk(), r_start = realclk();
 
   uint32_t count = 0, sp = 0, f_scan = 0;
   uint32_t run_id = 0;        // stamps of newer runs compare smaller, so atomicMin always replaces older ones
-  // Progressions carried from the last run: lane i of the next run expects  q0 + i qs + qd i (i - 1) / 2  (32-bit wrap-around
-  // arithmetic: a wrong value is merely a wrong guess, every id is checked against the records)
-  bool have_prog = false;
-  uint32_t pa_s = 0, pa_d = 0;                                  // a: starts at `corner`
-  uint32_t pb_0 = 0, pb_s = 0, pb_d = 0, pta_0 = 0, pta_s = 0, pta_d = 0, ptb_0 = 0, ptb_s = 0, ptb_d = 0;
-  uint32_t pla_0 = 0, pla_s = 0, pla_d = 0, prb_0 = 0, prb_s = 0, prb_d = 0;
+  // Ids the next fast attempt loads at, per lane (32-bit wrap-around arithmetic: a wrong value is merely a wrong guess, every id
+  // is checked against the records): a of this pair and of the next, b, the tips, the corner left of a, the corner right of b
+  bool have_prog = false, prog_lin = false;
+  uint32_t p_a = 0, p_an = 0, p_b = 0, p_ta = 0, p_tb = 0, p_la = 0, p_rb = 0;
+  // Step history: one entry per direction of a spiral (the turns counted modulo 4), holding the step of a it was learned with and
+  // the steps of the other five ids; an entry whose steps stop a run at its second pair twice in a row is forgotten.
+  uint32_t dir = 0, hist_strikes = 0;
   uint32_t backoff = 0;       // scalar steps to take before speculating again
   uint32_t fail_streak = 0;   // attempts in a row that retired nothing
   // Pairs the next attempt loads and checks (its memory traffic is proportional to it).  A run that ended on a turn
@@ -910,19 +919,26 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
   uint32_t window = WAVE, side1 = WAVE, side2 = WAVE;
   uint32_t n_run = 0, n_run_faces = 0, n_scalar = 0, n_fail = 0, n_fast = 0;
   bool failed = false;
-  bool carry = false;         // (v, rc, lc) of the current corner handed over by the attempt that ended on it
-  uint32_t c_v = 0, c_rc = 0, c_lc = 0;
+  // What is already known of the element the DFS stands on (handed over by the attempt that ended on it): its record, its marks
+  // as they are now; and the same for the element behind its right edge, should the step go there.  bits: 1 tip new, 2 tip on
+  // the boundary, 4 right side done, 8 left side done
+  bool have_rec = false, have_state = false, must_scalar = false, have2 = false;
+  bool no_hist = false;       // the step history was tried from this element and was wrong: exact hops
+  uint32_t c_v = 0, c_rc = 0, c_lc = 0, c_bits = 0;
+  uint32_t c2_v = 0, c2_rc = 0, c2_lc = 0, c2_bits = 0;
 #ifdef DSA_TRAV_PROFILE
-  // shader clocks by phase: [0] fast loads (issue -> ids checked), [1] head loads, [2] dependent hops + loads, [3] tables + verdict,
-  // [4] retirement + progressions, [5] scalar step; counts: fast attempts, fast hits, dependent attempts, heads
+  // shader clocks by phase: [0] fast loads (issue -> ids checked), [1] element inputs + seed, [2] dependent hops + loads, [3] membership + verdict,
+  // [4] retirement + progressions, [5] scalar step
   uint64_t tp_acc[6] = {0, 0, 0, 0, 0, 0}, tp_last = clk();
-  uint32_t np_fast_hit = 0, np_dep = 0, np_head = 0, np_fast_scalar = 0;
+  uint32_t np_fast_hit = 0, np_dep = 0, np_head = 0, np_hist = 0, np_lin = 0, np_hand = 0;
 #define TPROF(slot_) { const uint64_t t_ = clk(); tp_acc[slot_] += t_ - tp_last; tp_last = t_; }
+#define TCOUNT(x_) ++x_
 #else
 #define TPROF(slot_)
+#define TCOUNT(x_)
 #endif
 #define TR_FAIL(site) { if (lane == 0) fail(D, ST_INVALID, (site)); failed = true; break; }
-#define VISIT_SCALAR(v_, c_) { if (lane == 0) { vflag[v_] = (uint8_t)(uni_flag | 1u); d2c[count] = (c_); v2d[v_] = (int32_t)count; } ++count; }
+#define VISIT_SCALAR(v_, c_, fl_) { if (lane == 0) { vflag[v_] = (uint8_t)((fl_) | 1u); d2c[count] = (c_); v2d[v_] = (int32_t)count; } ++count; }
   auto corner_ok = [&](uint32_t c) -> bool { return c < 4 * F && (c & 3u) != 3u; };
 
   for (;;) {
@@ -944,202 +960,271 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
       const uint4 vv = R::vertices_of(frec, found);
       const uint32_t nv = uni(vv.y), pv = uni(vv.z);       // Next(corner 0) = corner 1, Previous = corner 2
       if (nv >= NV || pv >= NV) TR_FAIL(300);
-      { uint32_t uni_flag = uni((uint32_t)vflag[nv]); if (!(uni_flag & 1u)) { if (count >= L.cap_vertices) TR_FAIL(302); VISIT_SCALAR(nv, corner + 1); } }
+      { uint32_t uni_flag = uni((uint32_t)vflag[nv]); if (!(uni_flag & 1u)) { if (count >= L.cap_vertices) TR_FAIL(302); VISIT_SCALAR(nv, corner + 1, uni_flag); } }
       WAIT_VM0();
-      { uint32_t uni_flag = uni((uint32_t)vflag[pv]); if (!(uni_flag & 1u)) { if (count >= L.cap_vertices) TR_FAIL(302); VISIT_SCALAR(pv, corner + 2); } }
+      { uint32_t uni_flag = uni((uint32_t)vflag[pv]); if (!(uni_flag & 1u)) { if (count >= L.cap_vertices) TR_FAIL(302); VISIT_SCALAR(pv, corner + 2, uni_flag); } }
       WAIT_VM0();
-      have_prog = false; carry = false;
     }
     uint32_t corner = uni(stack[sp - 1]);
-    if (corner == DSA_INVALID || corner >= 4 * F || uni((uint32_t)fvis[corner >> 2])) { --sp; have_prog = false; carry = false; continue; }
+    have_prog = false; have_rec = false; have_state = false; must_scalar = false; have2 = false;
+    if (corner == DSA_INVALID || corner >= 4 * F || uni((uint32_t)fvis[corner >> 2])) { --sp; continue; }
 
     for (;;) {   // DepthFirstTraverser.cs:39-97 inner loop
-      const uint32_t face = corner >> 2;
+      uint32_t face = corner >> 2;
       // inputs of the scalar step
-      uint32_t v = 0, rc = 0, lc = 0, uni_flag = 0;
-      bool rdone = false, ldone = false;
+      uint32_t v = 0, rc = 0, lc = 0, bits = 0;
       // per-lane state of an attempt (pair `lane`: N element at a, face A; L element at b = Opposite(Next(a)), face B)
-      bool attempt = false, fast = false;
+      uint32_t kind = 0;                 // 0 none, 1 fast attempt at the carried progressions, 2 fast attempt from the step history, 3 dependent attempt
+      bool lin = false;
       uint32_t a = 0, b = 0, tipA = 0, lcA = DSA_INVALID, tipB = 0, rcB = DSA_INVALID, lcB = DSA_INVALID;
-      uint32_t fA_before = 0, fB_before = 1, fR_before = 1, fL_before = 1, fLA_before = 1, flA = 1, flB = 0;
-      bool in_chain = false, pair_ok = false;
+      // marks before the step, packed: bit 0 face A visited, 1 face B, 2 the face right of b, 3 the face left of b, 4 the face left of a;
+      // bits 8-9 flags of a's tip, 16-17 flags of b's tip
+      uint32_t marks = 0x0000011Eu;
+#define fA_before (marks & 1u)
+#define fB_before ((marks >> 1) & 1u)
+#define fR_before ((marks >> 2) & 1u)
+#define fL_before ((marks >> 3) & 1u)
+#define fLA_before ((marks >> 4) & 1u)
+#define flA ((marks >> 8) & 3u)
+#define flB ((marks >> 16) & 3u)
+#define TR_MARKS(fa_, fb_, fr_, fl_, fla_, ta_, tb_) (((fa_) ? 1u : 0u) | ((fb_) ? 2u : 0u) | ((fr_) ? 4u : 0u) | ((fl_) ? 8u : 0u) | ((fla_) ? 16u : 0u) | (((ta_) & 3u) << 8) | (((tb_) & 3u) << 16))
+      bool pair_ok = false;
       uint32_t len = 0;
 
-      if (have_prog && backoff == 0) {
-        // ---------------------------------------------------------------- fast attempt: one round trip at extrapolated ids
-        attempt = true; fast = true; ++n_fast;
-        a = corner + lane * pa_s + pa_d * tri;
-        const uint32_t a_nx = corner + (lane + 1u) * pa_s + pa_d * (tri + lane);     // a of pair lane + 1
-        const uint32_t b_p = pb_0 + lane * pb_s + pb_d * tri, tA_p = pta_0 + lane * pta_s + pta_d * tri, tB_p = ptb_0 + lane * ptb_s + ptb_d * tri;
-        const uint32_t lA_p = pla_0 + lane * pla_s + pla_d * tri, rB_p = prb_0 + lane * prb_s + prb_d * tri;
-        const bool a_ok = lane < window && corner_ok(a);
-        const bool bp_ok = a_ok && corner_ok(b_p);
-        Raw ra = R::none(), rb = R::none();
-        if (a_ok) ra = R::load(frec, a >> 2);
-        if (bp_ok) rb = R::load(frec, b_p >> 2);
-        if (bp_ok) {
-          fA_before = lane == 0 ? 0u : fvis[a >> 2];
-          fB_before = fvis[b_p >> 2];
-          fLA_before = corner_ok(lA_p) ? fvis[lA_p >> 2] : 1u;
-          fR_before = corner_ok(rB_p) ? fvis[rB_p >> 2] : 1u;
-          fL_before = corner_ok(a_nx) ? fvis[a_nx >> 2] : 1u;
-          flA = tA_p < NV ? vflag[tA_p] : 1u;
-          flB = tB_p < NV ? vflag[tB_p] : 1u;
-        }
-        const uint32_t ka = a & 3u, kb = b_p & 3u;
-        tipA = R::vertex(ra, ka); b = R::opp(ra, k_next(ka)); lcA = R::opp(ra, k_prev(ka));
-        tipB = R::vertex(rb, kb); rcB = R::opp(rb, k_next(kb)); lcB = R::opp(rb, k_prev(kb));
-        // every extrapolated id against the records; then the ranges the dependent attempt checks
-        const bool match = bp_ok && b == b_p && tipA == tA_p && lcA == lA_p && tipB == tB_p && rcB == rB_p && lcB == a_nx &&
-                           tipA < NV && tipB < NV && corner_ok(lcB) && (lcA == DSA_INVALID || corner_ok(lcA)) && (rcB == DSA_INVALID || corner_ok(rcB));
-        len = leading_lanes(match);
-        in_chain = lane < len;
-        pair_ok = in_chain;
-        TPROF(0);
-      } else {
-        // ---------------------------------------------------------------- head: the record and the marks of the current corner
-        if (carry) {             // the record of this corner was loaded by the attempt that ended on it: no read
-          v = c_v; rc = c_rc; lc = c_lc;
-          carry = false;
-        } else {
+      if (have_prog && backoff == 0) { kind = 1; lin = prog_lin; }
+      else {
+        // ---------------------------------------------------------------- this element: record, marks; the record behind its right edge
+        Raw rb0 = R::none();
+        bool have_seed = false;
+        if (have_rec) { v = c_v; rc = c_rc; lc = c_lc; }
+        else {
           const Raw r0 = R::load(frec, face);
           const uint32_t kc0 = corner & 3u;
           v = uni(R::vertex(r0, kc0)); rc = uni(R::opp(r0, k_next(kc0))); lc = uni(R::opp(r0, k_prev(kc0)));
         }
         if (v >= NV || (rc != DSA_INVALID && !corner_ok(rc)) || (lc != DSA_INVALID && !corner_ok(lc))) TR_FAIL(301);
-        // tip flag and the state of both sides, issued together
-        const uint32_t tip_flag = vflag[v];
-        const uint32_t side_r = rc != DSA_INVALID ? (uint32_t)fvis[rc >> 2] : 1u, side_l = lc != DSA_INVALID ? (uint32_t)fvis[lc >> 2] : 1u;
-        uni_flag = uni(tip_flag);
-        rdone = rc == DSA_INVALID || (rc >> 2) == face || uni(side_r) != 0;
-        ldone = lc == DSA_INVALID || (lc >> 2) == face || uni(side_l) != 0;
-        // this element moves right: tip new & interior, or only the right side is open
-        const bool moves_right = uni_flag == 0 || (!rdone && ldone);
-#ifdef DSA_TRAV_PROFILE
-        ++np_head;
-#endif
-        TPROF(1);
-        if (moves_right && backoff == 0) {
-          // -------------------------------------------------------------- dependent attempt: exact hops seed the candidate path
-          // a_0, a_1 = succ(a_0), a_2 with succ(a) = Opposite(Previous(Opposite(Next(a)))); lanes 3.. extrapolate with constant
-          // second difference; every link is verified from the records the lanes load anyway
-          attempt = true;
-          const uint32_t a0 = corner;
-          auto opp_prev_of = [&](uint32_t b1) -> uint32_t {          // Opposite(Previous(b1)), uniform
-            if (!corner_ok(b1)) return DSA_INVALID;
-            return uni(R::get_o(frec, qprev(b1)));
-          };
-          auto opp_next_of = [&](uint32_t c) -> uint32_t { return corner_ok(c) ? uni(R::get_o(frec, qnext(c))) : DSA_INVALID; };
-          // Opposite(Next(a0)) is `rc`, read by the head: the first hop needs one read, not two
-          const uint32_t a1 = opp_prev_of(rc), a2 = opp_prev_of(opp_next_of(a1));
-          const uint32_t d1 = a1 - a0, d2 = a2 - a1, ddh = d2 - d1;
-          const uint32_t exact = corner_ok(a2) ? 3u : (corner_ok(a1) ? 2u : 1u);
-          a = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : a2 + (lane - 2u) * (d2 + ddh) + ddh * ((lane - 2u) * (lane - 3u) / 2u);
-          bool a_ok = lane < window && corner_ok(a) && (lane < exact || exact == 3);
-          Raw ra = R::none(), rb = R::none();
-          if (a_ok) ra = R::load(frec, a >> 2);
-          const uint32_t ka = a & 3u;
-          tipA = R::vertex(ra, ka); b = R::opp(ra, k_next(ka)); lcA = R::opp(ra, k_prev(ka));
-          const bool b_ok = a_ok && corner_ok(b) && tipA < NV && (lcA == DSA_INVALID || corner_ok(lcA));
-          if (b_ok) rb = R::load(frec, b >> 2);
-          const uint32_t kb = b & 3u;
-          tipB = R::vertex(rb, kb); rcB = R::opp(rb, k_next(kb)); lcB = R::opp(rb, k_prev(kb));
-          const uint32_t next_a = b_ok ? lcB : DSA_INVALID;           // succ(a)
-          {
-            const uint32_t prev_next = lane_prev(next_a);
-            a_ok = a_ok && (lane == 0 || prev_next == a);
-          }
-          len = leading_lanes(a_ok);                 // verified chain a_0 .. a_(len-1)
-          in_chain = lane < len;
-          pair_ok = in_chain && b_ok && tipB < NV && corner_ok(lcB) && (rcB == DSA_INVALID || corner_ok(rcB));
-          if (pair_ok) {                             // state before the step
-            fA_before = lane == 0 ? 0u : fvis[a >> 2];
-            fLA_before = lcA != DSA_INVALID ? fvis[lcA >> 2] : 1u;
-            fB_before = fvis[b >> 2];
-            fR_before = rcB != DSA_INVALID ? fvis[rcB >> 2] : 1u;
-            fL_before = fvis[lcB >> 2];
-            flA = vflag[tipA]; flB = vflag[tipB];
-          }
-#ifdef DSA_TRAV_PROFILE
-          { const uint64_t m_ = __ballot(pair_ok && (fA_before | fB_before | flA | flB) == 0x12345u); (void)m_; ++np_dep; }     // forces the loads
-#endif
-          TPROF(2);
-        } else if (backoff) {
-          --backoff;
+        if (have_state) bits = c_bits;
+        else {
+          // tip flag and the state of both sides, and the record a run from here would need next, issued together
+          const uint32_t tip_flag = vflag[v];
+          const uint32_t side_r = rc != DSA_INVALID ? (uint32_t)fvis[rc >> 2] : 1u, side_l = lc != DSA_INVALID ? (uint32_t)fvis[lc >> 2] : 1u;
+          if (rc != DSA_INVALID && backoff == 0) { rb0 = R::load(frec, rc >> 2); have_seed = true; }
+          const uint32_t uf = uni(tip_flag);
+          const bool rdone = rc == DSA_INVALID || (rc >> 2) == face || uni(side_r) != 0;
+          const bool ldone = lc == DSA_INVALID || (lc >> 2) == face || uni(side_l) != 0;
+          bits = ((uf & 1u) ? 0u : 1u) | (uf & 2u) | (rdone ? 4u : 0u) | (ldone ? 8u : 0u);
+          TCOUNT(np_head);
         }
+        have_rec = false; have_state = false;
+        // this element moves right: tip new & interior, or only the right side is open
+        const bool moves_right = (bits & 3u) == 1u || ((bits & 12u) == 8u);
+        if (moves_right && backoff == 0 && !must_scalar && rc != DSA_INVALID) {
+          if (!have_seed) rb0 = R::load(frec, rc >> 2);
+          // the first pair exactly: a_0 = corner, b_0 = rc, and from b_0's record its tip, the corner right of it and a_1
+          const uint32_t kb0 = rc & 3u;
+          const uint32_t tB0 = uni(R::vertex(rb0, kb0)), rB0 = uni(R::opp(rb0, k_next(kb0))), a1 = uni(R::opp(rb0, k_prev(kb0)));
+          const uint32_t d1 = a1 - corner;
+          // steps this direction had the last time (keyed by the step of a)
+          const uint32_t e = dir & 3u;
+          const bool hm = !no_hist && d1 != 0u && corner_ok(a1) && uni(sh_hist[8 * e]) == d1;
+          if (hm) {
+            const uint32_t s_b = uni(sh_hist[8 * e + 1]), s_ta = uni(sh_hist[8 * e + 2]), s_tb = uni(sh_hist[8 * e + 3]), s_la = uni(sh_hist[8 * e + 4]), s_rb = uni(sh_hist[8 * e + 5]);
+            p_a = corner + lane * d1; p_an = p_a + d1; p_b = rc + lane * s_b; p_ta = v + lane * s_ta; p_tb = tB0 + lane * s_tb;
+            p_la = lc == DSA_INVALID ? DSA_INVALID : lc + lane * s_la; p_rb = rB0 == DSA_INVALID ? DSA_INVALID : rB0 + lane * s_rb;
+            kind = 2; lin = true;
+            TCOUNT(np_hist);
+          } else {
+            // ------------------------------------------------------------ dependent attempt: exact hops seed the candidate path
+            // a_0, a_1, a_2 = succ(a_1) with succ(a) = Opposite(Previous(Opposite(Next(a)))); lanes 3.. extrapolate with constant
+            // second difference; every link is verified from the records the lanes load anyway
+            kind = 3;
+            auto opp_prev_of = [&](uint32_t b1) -> uint32_t { return corner_ok(b1) ? uni(R::get_o_plain(frec, qprev(b1))) : DSA_INVALID; };
+            auto opp_next_of = [&](uint32_t c) -> uint32_t { return corner_ok(c) ? uni(R::get_o_plain(frec, qnext(c))) : DSA_INVALID; };
+            const uint32_t a0 = corner;
+            const uint32_t a2 = opp_prev_of(opp_next_of(a1));
+            const uint32_t d2 = a2 - a1, ddh = d2 - d1;
+            const uint32_t exact = corner_ok(a2) ? 3u : (corner_ok(a1) ? 2u : 1u);
+            a = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : a2 + (lane - 2u) * (d2 + ddh) + ddh * ((lane - 2u) * (lane - 3u) / 2u);
+            bool a_ok = lane < window && corner_ok(a) && (lane < exact || exact == 3);
+            Raw ra = R::none(), rb = R::none();
+            if (a_ok) ra = R::load(frec, a >> 2);
+            const uint32_t ka = a & 3u;
+            tipA = R::vertex(ra, ka); b = R::opp(ra, k_next(ka)); lcA = R::opp(ra, k_prev(ka));
+            const bool b_ok = a_ok && corner_ok(b) && tipA < NV && (lcA == DSA_INVALID || corner_ok(lcA));
+            if (b_ok) rb = R::load(frec, b >> 2);
+            const uint32_t kb = b & 3u;
+            tipB = R::vertex(rb, kb); rcB = R::opp(rb, k_next(kb)); lcB = R::opp(rb, k_prev(kb));
+            const uint32_t next_a = b_ok ? lcB : DSA_INVALID;           // succ(a)
+            {
+              const uint32_t prev_next = lane_prev(next_a);
+              a_ok = a_ok && (lane == 0 || prev_next == a);
+            }
+            len = leading_lanes(a_ok);                 // verified chain a_0 .. a_(len-1)
+            pair_ok = lane < len && b_ok && tipB < NV && corner_ok(lcB) && (rcB == DSA_INVALID || corner_ok(rcB));
+            if (pair_ok) {                             // state before the step
+              const uint32_t m0 = lane == 0 ? 0u : fvis[a >> 2], m4 = lcA != DSA_INVALID ? fvis[lcA >> 2] : 1u, m1 = fvis[b >> 2];
+              const uint32_t m2 = rcB != DSA_INVALID ? fvis[rcB >> 2] : 1u, m3 = fvis[lcB >> 2], ta = vflag[tipA], tb = vflag[tipB];
+              marks = TR_MARKS(m0, m1, m2, m3, m4, ta, tb);
+            }
+            TCOUNT(np_dep);
+          }
+        } else if (backoff) --backoff;
+        must_scalar = false;
+        TPROF(1);
       }
 
-      if (attempt) {
-        if (++run_id >= 0x00FFFFF0u) {        // 24-bit run tags: start over with empty tables (meshes with > 16 M runs)
-          __syncthreads();
-          for (uint32_t i = lane; i < TR_SLOTS; i += WAVE) { sh_tf[i] = 0; sh_tv[i] = 0; }
-          __syncthreads();
-          run_id = 1;
+      if (kind == 1 || kind == 2) {
+        // ---------------------------------------------------------------- fast attempt: one round trip at the extrapolated ids
+        ++n_fast;
+        a = p_a;
+        const bool a_ok = lane < window && corner_ok(a);
+        const bool bp_ok = a_ok && corner_ok(p_b);
+        Raw ra = R::none(), rb = R::none();
+        if (a_ok) ra = R::load(frec, a >> 2);
+        if (bp_ok) rb = R::load(frec, p_b >> 2);
+        if (bp_ok) {
+          const uint32_t m0 = lane == 0 ? 0u : fvis[a >> 2], m1 = fvis[p_b >> 2], m4 = corner_ok(p_la) ? fvis[p_la >> 2] : 1u;
+          const uint32_t m2 = corner_ok(p_rb) ? fvis[p_rb >> 2] : 1u, m3 = corner_ok(p_an) ? fvis[p_an >> 2] : 1u;
+          const uint32_t ta = p_ta < NV ? vflag[p_ta] : 1u, tb = p_tb < NV ? vflag[p_tb] : 1u;
+          marks = TR_MARKS(m0, m1, m2, m3, m4, ta, tb);
         }
-        const uint32_t base = (0x00FFFFFFu - run_id) << 8;
+        const uint32_t ka = a & 3u, kb = p_b & 3u;
+        tipA = R::vertex(ra, ka); b = R::opp(ra, k_next(ka)); lcA = R::opp(ra, k_prev(ka));
+        tipB = R::vertex(rb, kb); rcB = R::opp(rb, k_next(kb)); lcB = R::opp(rb, k_prev(kb));
+        // every extrapolated id against the records; then the ranges the dependent attempt checks
+        const bool match = bp_ok && b == p_b && tipA == p_ta && lcA == p_la && tipB == p_tb && rcB == p_rb && lcB == p_an &&
+                           tipA < NV && tipB < NV && corner_ok(lcB) && (lcA == DSA_INVALID || corner_ok(lcA)) && (rcB == DSA_INVALID || corner_ok(rcB));
+        len = leading_lanes(match);
+        pair_ok = lane < len;
+        if (kind == 1) {       // the scalar step, should it come to that, starts from lane 0's record
+          v = rdlane(tipA, 0); rc = rdlane(b, 0); lc = rdlane(lcA, 0);
+          if (v >= NV || (rc != DSA_INVALID && !corner_ok(rc)) || (lc != DSA_INVALID && !corner_ok(lc))) TR_FAIL(301);
+        }
+        TPROF(0);
+      } else if (kind == 3) { TPROF(2); }
+
+      if (kind) {
         const uint32_t fa = a >> 2, fb = b >> 2;
-        // First position of every face / tip in the candidate list: two small open-addressing tables in LDS,
-        // slot = run tag (24) | id (32) | position (8); a slot of an older run counts as empty, so nothing is
-        // cleared between runs.  Exact: the smallest position per id wins (ds_min_u64).
-        const uint32_t keyN = base | (2 * lane), keyL = base | (2 * lane + 1);
-        const uint32_t run_tag = base >> 8;
-        auto tbl_insert = [&](unsigned long long *t, uint32_t id, uint32_t pos) {
-          const unsigned long long want = ((unsigned long long)run_tag << 40) | ((unsigned long long)id << 8) | pos;
-          uint32_t sl = (id * 2654435761u) >> (32 - TR_SLOT_BITS);
-          for (;;) {
-            const unsigned long long cur = __hip_atomic_load(&t[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((uint32_t)(cur >> 40) != run_tag) { if (atomicCAS(&t[sl], cur, want) == cur) break; continue; }
-            if ((uint32_t)(cur >> 8) == id) { atomicMin(&t[sl], want); break; }
-            sl = (sl + 1) & (TR_SLOTS - 1);
+        const uint32_t keyN = 2 * lane, keyL = 2 * lane + 1;
+        // First position (N element of pair j: 2j, L element: 2j + 1) of a face / a tip among the candidates, TR_NONE if it is none
+        // of them.  A tip that was visited before the run can never count as new, so only unvisited tips are looked up; the
+        // neighbour faces only where their state before the run leaves the question open.
+        uint32_t sfa = TR_NONE, sfb = TR_NONE, sta = TR_NONE, stb = TR_NONE, srf = TR_NONE, slf = TR_NONE, sla = TR_NONE;
+        if (lin) {
+          // all four id sequences are arithmetic (verified lane by lane above): X is element j of one iff (X - first) = j * step
+          TCOUNT(np_lin);
+          // (first element and step from lanes 0 and 1 of the verified ids; a run of one pair has no step to speak of)
+          const bool two = len >= 2;
+          const int32_t fa0 = (int32_t)(rdlane(a, 0) >> 2), fb0 = (int32_t)(rdlane(b, 0) >> 2), ta0 = (int32_t)rdlane(tipA, 0), tb0 = (int32_t)rdlane(tipB, 0);
+          const int32_t sA = two ? (int32_t)(rdlane(a, 1) - rdlane(a, 0)) >> 2 : 1, sB = two ? (int32_t)(rdlane(b, 1) - rdlane(b, 0)) >> 2 : 1;
+          const int32_t sTA = two ? (int32_t)(rdlane(tipA, 1) - rdlane(tipA, 0)) : 1, sTB = two ? (int32_t)(rdlane(tipB, 1) - rdlane(tipB, 0)) : 1;
+          const float iA = 1.0f / (float)sA, iB = 1.0f / (float)sB, iTA = 1.0f / (float)sTA, iTB = 1.0f / (float)sTB;
+          auto pos_in = [&](uint32_t X, int32_t first, int32_t step, float inv, uint32_t odd) -> uint32_t {
+            const int32_t d = (int32_t)X - first;
+            const int32_t j = (int32_t)__builtin_rintf((float)d * inv);
+            return (j >= 0 && (uint32_t)j < len && j * step == d) ? 2u * (uint32_t)j + odd : TR_NONE;
+          };
+          auto face_pos = [&](uint32_t X) -> uint32_t { const uint32_t x = pos_in(X, fa0, sA, iA, 0u), y = pos_in(X, fb0, sB, iB, 1u); return x < y ? x : y; };
+          auto tip_pos = [&](uint32_t X) -> uint32_t { const uint32_t x = pos_in(X, ta0, sTA, iTA, 0u), y = pos_in(X, tb0, sTB, iTB, 1u); return x < y ? x : y; };
+          if (pair_ok) {
+            sfa = face_pos(fa); sfb = face_pos(fb);
+            if (!(flA & 1u)) sta = tip_pos(tipA);
+            if (!(flB & 1u)) stb = tip_pos(tipB);
+            if (rcB != DSA_INVALID && fR_before == 0) srf = face_pos(rcB >> 2);
+            if (fL_before == 0) slf = face_pos(lcB >> 2);
+            if (lcA != DSA_INVALID && fLA_before == 0 && flA != 0) sla = face_pos(lcA >> 2);
           }
-        };
-        auto tbl_lookup = [&](unsigned long long *t, uint32_t id) -> uint32_t {
-          uint32_t sl = (id * 2654435761u) >> (32 - TR_SLOT_BITS);
-          for (uint32_t probes = 0; probes < TR_SLOTS; ++probes) {
-            const unsigned long long cur = __hip_atomic_load(&t[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((uint32_t)(cur >> 40) != run_tag) return 0xFFFFFFFFu;
-            if ((uint32_t)(cur >> 8) == id) return base | (uint32_t)(cur & 0xFFu);
-            sl = (sl + 1) & (TR_SLOTS - 1);
+        } else {
+          // two small open-addressing tables in LDS, slot = run tag (24) | id (32) | position (8); a slot of an older run counts
+          // as empty, so nothing is cleared between runs.  Exact: the smallest position per id wins (ds_min_u64).
+          if (++run_id >= 0x00FFFFF0u) {        // 24-bit run tags: start over with empty tables (meshes with > 16 M runs)
+            __syncthreads();
+            for (uint32_t i = lane; i < TR_SLOTS; i += WAVE) { sh_tf[i] = 0; sh_tv[i] = 0; }
+            __syncthreads();
+            run_id = 1;
           }
-          return 0xFFFFFFFFu;
-        };
-        // A tip that was visited before the run can never count as new, so only unvisited tips are entered; the
-        // neighbour faces are looked up only where their state before the run leaves the question open.
-        if (pair_ok) {
-          tbl_insert(sh_tf, fa, 2 * lane); tbl_insert(sh_tf, fb, 2 * lane + 1);
-          if (!(flA & 1u)) tbl_insert(sh_tv, tipA, 2 * lane);
-          if (!(flB & 1u)) tbl_insert(sh_tv, tipB, 2 * lane + 1);
+          const uint32_t run_tag = 0x00FFFFFFu - run_id;
+          auto tbl_insert = [&](unsigned long long *t, uint32_t id, uint32_t pos) {
+            const unsigned long long want = ((unsigned long long)run_tag << 40) | ((unsigned long long)id << 8) | pos;
+            uint32_t sl = (id * 2654435761u) >> (32 - TR_SLOT_BITS);
+            for (;;) {
+              const unsigned long long cur = __hip_atomic_load(&t[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if ((uint32_t)(cur >> 40) != run_tag) { if (atomicCAS(&t[sl], cur, want) == cur) break; continue; }
+              if ((uint32_t)(cur >> 8) == id) { atomicMin(&t[sl], want); break; }
+              sl = (sl + 1) & (TR_SLOTS - 1);
+            }
+          };
+          auto tbl_lookup = [&](unsigned long long *t, uint32_t id) -> uint32_t {
+            uint32_t sl = (id * 2654435761u) >> (32 - TR_SLOT_BITS);
+            for (uint32_t probes = 0; probes < TR_SLOTS; ++probes) {
+              const unsigned long long cur = __hip_atomic_load(&t[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if ((uint32_t)(cur >> 40) != run_tag) return TR_NONE;
+              if ((uint32_t)(cur >> 8) == id) return (uint32_t)(cur & 0xFFu);
+              sl = (sl + 1) & (TR_SLOTS - 1);
+            }
+            return TR_NONE;
+          };
+          if (pair_ok) {
+            tbl_insert(sh_tf, fa, 2 * lane); tbl_insert(sh_tf, fb, 2 * lane + 1);
+            if (!(flA & 1u)) tbl_insert(sh_tv, tipA, 2 * lane);
+            if (!(flB & 1u)) tbl_insert(sh_tv, tipB, 2 * lane + 1);
+          }
+          __syncthreads();
+          if (pair_ok) {
+            sfa = tbl_lookup(sh_tf, fa); sfb = tbl_lookup(sh_tf, fb);
+            if (!(flA & 1u)) sta = tbl_lookup(sh_tv, tipA);
+            if (!(flB & 1u)) stb = tbl_lookup(sh_tv, tipB);
+            if (rcB != DSA_INVALID && fR_before == 0) srf = tbl_lookup(sh_tf, rcB >> 2);
+            if (fL_before == 0) slf = tbl_lookup(sh_tf, lcB >> 2);
+            if (lcA != DSA_INVALID && fLA_before == 0 && flA != 0) sla = tbl_lookup(sh_tf, lcA >> 2);
+          }
         }
-        __syncthreads();
         bool good = false, newA = false, newB = false;
+        uint32_t hand = 0;                  // what the scalar step needs of this pair's two elements, should the run end on it
         if (pair_ok) {
-          const uint32_t sfa = tbl_lookup(sh_tf, fa), sfb = tbl_lookup(sh_tf, fb);
-          const uint32_t sta = !(flA & 1u) ? tbl_lookup(sh_tv, tipA) : 0xFFFFFFFFu;
-          const uint32_t stb = !(flB & 1u) ? tbl_lookup(sh_tv, tipB) : 0xFFFFFFFFu;
-          const uint32_t srf = (rcB != DSA_INVALID && fR_before == 0) ? tbl_lookup(sh_tf, rcB >> 2) : 0xFFFFFFFFu;
-          const uint32_t slf = fL_before == 0 ? tbl_lookup(sh_tf, lcB >> 2) : 0xFFFFFFFFu;
-          const uint32_t sla = (lcA != DSA_INVALID && fLA_before == 0 && flA != 0) ? tbl_lookup(sh_tf, lcA >> 2) : 0xFFFFFFFFu;
           // first element (at a, face A): the face is first seen here and the DFS moves right -- because the
           // tip is new and interior (DepthFirstTraverser.cs:53-64), or because the left side is done
           // (:66-87; that the right side is open is the second element's "face B first seen")
           newA = !(flA & 1u) && sta == keyN;
-          const bool la_done = lcA == DSA_INVALID || (lcA >> 2) == fa || fLA_before != 0 || ((sla >> 8) == run_tag && sla < keyN);
+          const bool la_done = lcA == DSA_INVALID || (lcA >> 2) == fa || fLA_before != 0 || sla < keyN;
           const bool x_ok = fA_before == 0 && sfa == keyN && ((newA && !(flA & 2u)) || la_done);
           // second element (at b, face B): face first seen here, the tip does not send the DFS right (new and
           // interior), right side done, left side open -> left
           newB = !(flB & 1u) && stb == keyL;
-          const bool r_done = rcB == DSA_INVALID || (rcB >> 2) == fb || fR_before != 0 || ((srf >> 8) == run_tag && srf < keyL);
-          const bool l_open = (lcB >> 2) != fb && fL_before == 0 && !((slf >> 8) == run_tag && slf < keyL);
+          const bool r_done = rcB == DSA_INVALID || (rcB >> 2) == fb || fR_before != 0 || srf < keyL;
+          const bool l_open = (lcB >> 2) != fb && fL_before == 0 && !(slf < keyL);
           const bool y_ok = fB_before == 0 && sfb == keyL && !(newB && !(flB & 2u)) && r_done && l_open;
           good = x_ok && y_ok;
+          // the element at a as the scalar step sees it once the pairs before this one are retired, and the element at b once the
+          // step has gone right from a (its face and tip are then visited: positions keyN < keyL)
+          const bool ra_done = fb == fa || fB_before != 0 || sfb < keyN;
+          hand = 1u | (newA ? 2u : 0u) | ((flA & 2u) ? 4u : 0u) | (ra_done ? 8u : 0u) | (la_done ? 16u : 0u) |
+                 (newB ? 32u : 0u) | ((flB & 2u) ? 64u : 0u) | (r_done ? 128u : 0u) | (l_open ? 0u : 256u) |
+                 ((fA_before == 0 && sfa == keyN) ? 512u : 0u) | ((fB_before == 0 && sfb == keyL) ? 1024u : 0u);
         }
         const uint32_t K = leading_lanes(good);
+#ifdef DSA_TRAV_TRACE
+        // one word per attempt in the vertex-stamp scratch: kind | K << 4 | len << 12 | window << 20 (+ per-lane detail of attempts 2000 .. 2007)
+        { uint32_t *tr = (uint32_t *)(arena + L.vstamp); const uint32_t at = n_run + n_fail;
+          if (at < 8000 && lane == 0) { tr[0] = at + 1; tr[1 + at] = kind | (K << 4) | (len << 12) | (window << 20) | ((lin ? 1u : 0u) << 28); }
+          if (at >= 1000 && at < 1008 && L.cap_vertices > 20000) { uint32_t *dt = tr + 8192 + (at - 1000) * 64 * 16 + lane * 16; dt[0] = a; dt[1] = b; dt[2] = tipA; dt[3] = tipB; dt[4] = lcA; dt[5] = rcB; dt[6] = lcB; dt[7] = marks | (good ? 1u << 31 : 0u) | (pair_ok ? 1u << 30 : 0u) | (hand << 20);
+            dt[8] = p_a; dt[9] = p_b; dt[10] = p_ta; dt[11] = p_tb; dt[12] = p_la; dt[13] = p_rb; dt[14] = p_an; dt[15] = kind; } }
+#endif
         TPROF(3);
         // entries made by the retired pairs: a new tip is numbered when its element is reached (:53-58)
         const uint64_t kmask = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
         const uint64_t mA = __ballot(newA) & kmask, mB = __ballot(newB) & kmask;
         const uint32_t made = (uint32_t)__popcll(mA) + (uint32_t)__popcll(mB);
-        if (K >= 1 && count + made <= L.cap_vertices) {
+        const bool retire = K >= 1 && count + made <= L.cap_vertices;
+        const uint32_t win_used = window;          // lanes that took part in this attempt
+        have_prog = false;
+        if (kind == 2) {
+          // steps that let the first pair through and fail the second, twice in a row, are stale (a side along the boundary has
+          // no face right of b, the next ring has): forget them, the exact hops of the dependent attempt learn them again
+          if (K == len && len <= 2 && len < window) { if (++hist_strikes >= 2) { if (lane == 0) sh_hist[8 * (dir & 3u)] = 0; hist_strikes = 0; } }
+          else if (K >= 3) hist_strikes = 0;
+        }
+        if (retire) {
           if (lane < K) {
             const uint64_t lt = (1ull << lane) - 1ull;
             const uint32_t posA = count + (uint32_t)__popcll(mA & lt) + (uint32_t)__popcll(mB & lt);
@@ -1149,88 +1234,108 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
           }
           const uint32_t nxt = rdlane(lcB, K - 1);             // Opposite(Previous(b_(K-1))): where the DFS continues
           count += made;
-          have_prog = false;
-          if (K >= 3 && !(K < WAVE && len > K)) {       // next run: continue the verified progressions
+          if (K >= 3) {
+            // the verified progressions: continued by the next attempt when the run filled its window, remembered as the steps
+            // of this direction when they are linear
             const uint32_t aK1 = rdlane(a, K - 1), aK2 = rdlane(a, K - 2), aK3 = rdlane(a, K - 3);
             const uint32_t s1 = nxt - aK1, s0 = aK1 - aK2, sm = aK2 - aK3;
-            pa_d = (s1 - s0 == s0 - sm) ? s1 - s0 : 0u;
-            pa_s = s1 + pa_d;
-#define TR_PROG(q_, q0_, qs_, qd_) { const uint32_t x1 = rdlane(q_, K - 1), x2 = rdlane(q_, K - 2), x3 = rdlane(q_, K - 3); \
-                                     const uint32_t t0 = x1 - x2, tm = x2 - x3; qd_ = t0 - tm; q0_ = x1 + t0 + qd_; qs_ = t0 + 2u * qd_; }
-            TR_PROG(b, pb_0, pb_s, pb_d); TR_PROG(tipA, pta_0, pta_s, pta_d); TR_PROG(tipB, ptb_0, ptb_s, ptb_d);
-            TR_PROG(lcA, pla_0, pla_s, pla_d); TR_PROG(rcB, prb_0, prb_s, prb_d);
+            const uint32_t a_d = (s1 - s0 == s0 - sm) ? s1 - s0 : 0u, a_s = s1 + a_d;
+            uint32_t any_d = a_d | (s1 ^ s0);
+            const bool cont = K == window;           // the run filled its window: nothing stopped it
+            const uint32_t l1 = lane + 1u, tri1 = l1 * (l1 + 1u) / 2u;
+            if (cont) { p_a = nxt + lane * a_s + a_d * (lane * (lane - 1u) / 2u); p_an = nxt + l1 * a_s + a_d * (l1 * lane / 2u); }
+            uint32_t st_b, st_ta, st_tb, st_la, st_rb;
+#define TR_PROG(q_, p_, st_) { const uint32_t x1 = rdlane(q_, K - 1), x2 = rdlane(q_, K - 2), x3 = rdlane(q_, K - 3); \
+                               const uint32_t t0 = x1 - x2, qd = t0 - (x2 - x3); any_d |= qd; st_ = t0; if (cont) p_ = x1 + l1 * t0 + qd * tri1; }
+            TR_PROG(b, p_b, st_b); TR_PROG(tipA, p_ta, st_ta); TR_PROG(tipB, p_tb, st_tb); TR_PROG(lcA, p_la, st_la); TR_PROG(rcB, p_rb, st_rb);
 #undef TR_PROG
-            have_prog = true;
+            // linear, faces and tips all distinct along the run: membership by arithmetic
+            const bool linear = any_d == 0 && (s0 & 3u) == 0 && (st_b & 3u) == 0 && s0 != 0 && st_b != 0 && st_ta != 0 && st_tb != 0;
+            have_prog = cont; prog_lin = linear;
+            if (linear && kind == 3) {       // remember the steps of this direction (a fast run only confirms what it was given)
+              const uint32_t e = dir & 3u;
+              if (lane == 0) { sh_hist[8 * e] = s0; sh_hist[8 * e + 1] = st_b; sh_hist[8 * e + 2] = st_ta; sh_hist[8 * e + 3] = st_tb; sh_hist[8 * e + 4] = st_la; sh_hist[8 * e + 5] = st_rb; }
+            }
           }
           corner = nxt;
+          face = corner >> 2;
           n_run += 1; n_run_faces += 2 * K;
-          fail_streak = 0;
-          // Pair K lies on the verified path but is not an (N L) pair (a turn of the spiral, a boundary
-          // vertex, a split): re-attempting from it would reach the same verdict, so step over it first.
-          if (K < WAVE && len > K) {
-            backoff = 1;
-            // pair K was loaded and its link verified: its corner is where the DFS stands now, and its tip and the
-            // corners behind its two other edges are what the next iteration would read first
-            c_v = rdlane(tipA, K); c_rc = rdlane(b, K); c_lc = rdlane(lcA, K);
-            carry = true;
-          }
+          fail_streak = 0; no_hist = false;
           if ((fuse_operands & 2u) && K < window && len > K) { side2 = side1; side1 = K; const uint32_t m = (side1 > side2 ? side1 : side2) + 4; window = m < WAVE ? m : WAVE; }
           else window = WAVE;
-#ifdef DSA_TRAV_PROFILE
-          if (fast) ++np_fast_hit;
-#endif
+          if (kind != 3) TCOUNT(np_fast_hit);
           TPROF(4);
-          continue;
-        }
-        ++n_fail;
-        have_prog = false;
-        if (fast) {
-          // lane 0 loaded the record of the current corner whatever the other ids were worth
-          c_v = rdlane(tipA, 0); c_rc = rdlane(b, 0); c_lc = rdlane(lcA, 0);
-          if (len == 0) { carry = true; continue; }          // its marks were read at wrong ids: the head reads them
-          // the extrapolated ids of pair 0 were right, so were the marks: the verdict "not an (N L) pair" stands, and the scalar
-          // step has all it needs
-#ifdef DSA_TRAV_PROFILE
-          ++np_fast_scalar;
-#endif
-          v = c_v; rc = c_rc; lc = c_lc;
-          uni_flag = rdlane(flA, 0);
-          rdone = (rc >> 2) == face || rdlane(fB_before, 0) != 0;         // rc is a corner: pair 0 matched
-          ldone = lc == DSA_INVALID || (lc >> 2) == face || rdlane(fLA_before, 0) != 0;
+          if (K >= win_used) continue;
+          if (K < len) ++dir;                    // stopped by a verdict, not by a wrong guess: a turn
+          // Pair K was loaded too.  If it lies on the verified path it is not an (N L) pair (a turn of the spiral, a boundary vertex,
+          // a split): re-attempting from it would reach the same verdict, so its first element takes the scalar step -- from what
+          // lane K holds.  If the path ended on it (an extrapolated id was wrong), its record at least is the right one.
         } else {
-          backoff = fail_streak < 3 ? fail_streak : 3;                   // this step is taken by the scalar path below
-          ++fail_streak;
+          ++n_fail;
+          if (kind == 3) { backoff = fail_streak < 3 ? fail_streak : 3; ++fail_streak; }
+          if (kind == 2) no_hist = true;
+        }
+        // ---- the pair the DFS stands on now (K if pairs were retired, else 0) was loaded by its lane: hand its elements over
+        {
+          const uint32_t h_lane = retire ? K : 0u;
+          const uint32_t h = (h_lane < win_used && h_lane < len) ? rdlane(hand, h_lane) : 0u;
+          if (h & 1u) {
+            v = rdlane(tipA, h_lane); rc = rdlane(b, h_lane); lc = rdlane(lcA, h_lane);
+            // (fA_before | first occurrence) failing means the face was visited meanwhile: the stack logic below handles a visited face
+            // only at a pop, so such a pair goes back to the loads
+            if (h & 512u) {
+              bits = ((h & 2u) ? 1u : 0u) | ((h & 4u) ? 2u : 0u) | ((h & 8u) ? 4u : 0u) | ((h & 16u) ? 8u : 0u);
+              have2 = (h & 1024u) != 0;
+              c2_v = rdlane(tipB, h_lane); c2_rc = rdlane(rcB, h_lane); c2_lc = rdlane(lcB, h_lane);
+              c2_bits = ((h & 32u) ? 1u : 0u) | ((h & 64u) ? 2u : 0u) | ((h & 128u) ? 4u : 0u) | ((h & 256u) ? 8u : 0u);
+              TCOUNT(np_hand);
+            } else { have_rec = true; c_v = v; c_rc = rc; c_lc = lc; must_scalar = true; continue; }
+          } else if (kind != 3 || retire) {
+            // no marks for this element (its ids were guessed wrong, or the chain ended here): its record if lane h_lane loaded the
+            // right face (a_(h_lane) is exact: lane 0 is the corner itself, lane K is where lane K - 1's record points), then the loads
+            const bool rec_ok = h_lane < WAVE && h_lane < win_used && (kind != 3 || h_lane < len);
+            if (rec_ok && rdlane(a, h_lane) == corner) { have_rec = true; c_v = rdlane(tipA, h_lane); c_rc = rdlane(b, h_lane); c_lc = rdlane(lcA, h_lane); }
+            must_scalar = retire && h_lane < len;
+            continue;
+          }
+          // (a dependent attempt that retired nothing: the element's inputs are the ones loaded above)
         }
       }
       // ------------------------------------------------------------------ scalar step (reference loop body)
       ++n_scalar;
+      no_hist = false;
       if (lane == 0) fvis[face] = 1;
-      if (!(uni_flag & 1u)) {
+      bool went_right = false;
+      if (bits & 1u) {
         if (count >= L.cap_vertices) TR_FAIL(302);
-        VISIT_SCALAR(v, corner);
-        if (!(uni_flag & 2u)) {
+        VISIT_SCALAR(v, corner, bits & 2u);
+        if (!(bits & 2u)) {
           if (rc == DSA_INVALID) TR_FAIL(303);
           corner = rc;
-          continue;
+          went_right = true;
         }
       }
-      if (rdone) {
-        if (ldone) { --sp; break; }
-        corner = lc;
-      } else {
-        if (ldone) corner = rc;
-        else {
-          if (sp >= stack_cap) TR_FAIL(304);
-          if (lane == 0) { stack[sp - 1] = lc; stack[sp] = rc; }
-          ++sp;
-          TPROF(5);
-          break;
+      if (!went_right) {
+        if (bits & 4u) {
+          if (bits & 8u) { --sp; TPROF(5); break; }
+          corner = lc;
+        } else {
+          if (bits & 8u) { corner = rc; went_right = true; }
+          else {
+            if (sp >= stack_cap) TR_FAIL(304);
+            if (lane == 0) { stack[sp - 1] = lc; stack[sp] = rc; }
+            ++sp;
+            TPROF(5);
+            break;
+          }
         }
       }
+      // the element behind the right edge is known too when the attempt judged it
+      if (went_right && have2) { have_rec = true; have_state = true; c_v = c2_v; c_rc = c2_rc; c_lc = c2_lc; c_bits = c2_bits; }
+      have2 = false;
       TPROF(5);
     }
     if (failed) break;
-    have_prog = false; carry = false;
   }
   if (failed) return;
   if (lane == 0) {
@@ -1240,7 +1345,7 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
     D->dbg[7] = n_run; D->dbg[8] = n_run_faces; D->dbg[9] = n_scalar; D->dbg[3] = n_fast;
 #ifdef DSA_TRAV_PROFILE
     for (int i = 0; i < 5; ++i) D->dbg[10 + (i < 3 ? i : i + 5)] = (uint32_t)(tp_acc[i] >> 4);   // [10] [11] [12] [18] [19], in units of 16 clocks
-    D->dbg[0] = (uint32_t)(tp_acc[5] >> 4); D->dbg[1] = np_fast_hit; D->dbg[2] = np_dep; D->dbg[4] = np_head; D->dbg[13] = np_fast_scalar;
+    D->dbg[0] = (uint32_t)(tp_acc[5] >> 4); D->dbg[1] = np_fast_hit; D->dbg[2] = np_dep; D->dbg[4] = np_head; D->dbg[13] = np_hist; D->dbg[14] = np_lin; D->dbg[15] = np_hand;
 #endif
     // a valid stream carries exactly one entry per encoded vertex (k_locate sized the symbol streams on that)
     if (count != D->num_enc_vertices) fail(D, ST_INVALID, 305);
@@ -1291,17 +1396,28 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
 #undef TR_FAIL
 #undef VISIT_SCALAR
 #undef TPROF
+#undef TCOUNT
+#undef fA_before
+#undef fB_before
+#undef fR_before
+#undef fL_before
+#undef fLA_before
+#undef flA
+#undef flB
+#undef TR_MARKS
 }
 
 __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t fuse_operands) {
   __shared__ unsigned long long sh_tf[TR_SLOTS], sh_tv[TR_SLOTS];
+  __shared__ uint32_t sh_hist[TR_HIST_WORDS];
   for (uint32_t i = threadIdx.x; i < TR_SLOTS; i += WAVE) { sh_tf[i] = 0; sh_tv[i] = 0; }
+  if (threadIdx.x < TR_HIST_WORDS) sh_hist[threadIdx.x] = 0;
   __syncthreads();
   __builtin_amdgcn_s_setprio(3);   // critical path: issue ahead of the entropy-decode waves sharing the CU
   const uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
-  if (layouts[mesh].rec_compact) traverse_wave<true>(arena, layouts[mesh], &descs[mesh], fuse_operands, sh_tf, sh_tv);
-  else traverse_wave<false>(arena, layouts[mesh], &descs[mesh], fuse_operands, sh_tf, sh_tv);
+  if (layouts[mesh].rec_compact) traverse_wave<true>(arena, layouts[mesh], &descs[mesh], fuse_operands, sh_tf, sh_tv, sh_hist);
+  else traverse_wave<false>(arena, layouts[mesh], &descs[mesh], fuse_operands, sh_tf, sh_tv, sh_hist);
 }
 
 // k_chain: connectivity and traversal of a mesh by the same wave, back to back.  As two kernels the traversal's waves
@@ -1311,9 +1427,9 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
 // LDS (CN_LDS_WORDS * 4 bytes) is passed at launch: with the size hidden from the compiler, the launch bound alone sets the
 // register budget (64 VGPRs: four of these waves and three entropy-decode waves of 80 share a SIMD's 512).
 extern __shared__ __attribute__((aligned(16))) uint32_t sh_chain[];
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_num_vgpr(64), amdgpu_num_sgpr(96))) void k_chain(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t fuse_operands) {
+__global__ __launch_bounds__(WAVE, 8) void k_chain(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t fuse_operands) {
   uint32_t *sh = sh_chain;
-  static_assert(CN_LDS_WORDS * 4 >= 2 * TR_SLOTS * 8, "the traversal's tables reuse the connectivity's LDS");
+  static_assert(CN_LDS_WORDS * 4 >= 2 * TR_SLOTS * 8 + TR_HIST_WORDS * 4, "the traversal's tables reuse the connectivity's LDS");
   __builtin_amdgcn_s_setprio(3);
   const uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
@@ -1326,10 +1442,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_num_vgpr(64), amdgpu_nu
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
   __syncthreads();
   unsigned long long *sh_tf = (unsigned long long *)sh, *sh_tv = sh_tf + TR_SLOTS;
+  uint32_t *sh_hist = sh + 2 * TR_SLOTS * 2;
   for (uint32_t i = threadIdx.x; i < TR_SLOTS; i += WAVE) { sh_tf[i] = 0; sh_tv[i] = 0; }
+  if (threadIdx.x < TR_HIST_WORDS) sh_hist[threadIdx.x] = 0;
   __syncthreads();
-  if (compact) traverse_wave<true>(arena, L, D, fuse_operands, sh_tf, sh_tv);
-  else traverse_wave<false>(arena, L, D, fuse_operands, sh_tf, sh_tv);
+  if (compact) traverse_wave<true>(arena, L, D, fuse_operands, sh_tf, sh_tv, sh_hist);
+  else traverse_wave<false>(arena, L, D, fuse_operands, sh_tf, sh_tv, sh_hist);
 }
 
 

@@ -11,8 +11,8 @@ print({k: round(v, 2) for k, v in b.stage_times().items()})
 d = np.array([b.debug_array(i, 4, np.uint32, 20) for i in range(0, n, max(1, n // 64))]).astype(np.int64)
 m = np.median(d, axis=0).astype(np.int64)
 print("traversal: %d ticks; runs %d covering %d faces, scalar steps %d, failed attempts %d, fast attempts %d" % (m[6], m[7], m[8], m[9], m[5], m[3]))
-print("  fast hits %d, fast -> scalar without loads %d, dependent attempts %d, heads %d" % (m[1], m[13], m[2], m[4]))
-names = ("fast loads", "head loads", "dependent hops+loads", "tables+verdict", "retire+progressions")
+print("  fast hits %d, from step history %d, arithmetic membership %d, elements handed over %d, dependent attempts %d, element loads %d" % (m[1], m[13], m[14], m[15], m[2], m[4]))
+names = ("fast loads", "element inputs + seed", "dependent hops+loads", "membership + verdict", "retire+progressions")
 for k, slot in enumerate((10, 11, 12, 18, 19)):
     print("  %-22s %9d ticks" % (names[k], m[slot] * 16))
 print("  %-22s %9d ticks" % ("scalar step", m[0] * 16))
