@@ -327,17 +327,21 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
     // corner; along a regular strip these ids are consecutive, which each lane verifies on its own record.
     // Then every face record, opposite link and vertex record of the run is a closed form of j.
     if (have_top && bcnt >= 16 && ((uint32_t)bb & 0xFFFFu) == 0xAAAAu) {
-      // candidate pairs: nibbles still in the bit buffer, then in the LDS window
-      const uint32_t buf_pairs = bcnt >> 2;
+      // candidate pairs: nibble `lane` lies 4 * lane bits ahead -- in the bit buffer, across its end, or in the LDS window (whose
+      // dword widx, bit 0, follows the buffer's last bit), at whatever alignment the symbols before left
       uint32_t nib;
       {
-        const uint32_t bitoff = 4 * lane;
-        if (lane < buf_pairs) nib = (uint32_t)(bb >> bitoff) & 0xFu;
+        const uint32_t q = 4 * lane;
+        if (q + 4 <= bcnt) nib = (uint32_t)(bb >> q) & 0xFu;
         else {
-          // bits beyond the buffer start at window dword widx (bit 0) -- only when the buffer holds whole nibbles
-          const uint32_t rel = bitoff - (bcnt & ~3u);
-          const uint32_t wi = widx - wbase + (rel >> 5);
-          nib = ((bcnt & 3u) == 0 && drop_bits == 0 && wi < CN_WIN) ? ((sh_win[wi] >> (rel & 31u)) & 0xFu) : 0u;
+          const uint32_t have = q < bcnt ? bcnt - q : 0u;              // bits of the nibble still in the buffer (0 .. 3)
+          const uint32_t rel = q + have - bcnt;                        // window bit the rest starts at
+          const uint32_t wi = widx - wbase + (rel >> 5), sh = rel & 31u;
+          const bool in_win = drop_bits == 0 && wi < CN_WIN && (sh + (4u - have) <= 32u || wi + 1 < CN_WIN);
+          uint64_t w = 0;
+          if (in_win) { w = sh_win[wi]; if (wi + 1 < CN_WIN) w |= (uint64_t)sh_win[wi + 1] << 32; }
+          const uint32_t from_win = (uint32_t)(w >> sh);
+          nib = in_win ? (((have ? (uint32_t)(bb >> q) : 0u) | (from_win << have)) & 0xFu) : 0u;
         }
       }
       uint32_t cand = leading_lanes(nib == 0xAu);       // leading 0xA nibbles
@@ -973,6 +977,9 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
       uint32_t face = corner >> 2;
       // inputs of the scalar step
       uint32_t v = 0, rc = 0, lc = 0, bits = 0;
+      // (tip, corner right, corner left) of the corners behind this element's two other edges, when their records were loaded with its marks
+      bool have_kids = false;
+      uint32_t kr_v = 0, kr_rc = 0, kr_lc = 0, kl_v = 0, kl_rc = 0, kl_lc = 0;
       // per-lane state of an attempt (pair `lane`: N element at a, face A; L element at b = Opposite(Next(a)), face B)
       uint32_t kind = 0;                 // 0 none, 1 fast attempt at the carried progressions, 2 fast attempt from the step history, 3 dependent attempt
       bool lin = false;
@@ -1008,7 +1015,14 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
           // tip flag and the state of both sides, and the record a run from here would need next, issued together
           const uint32_t tip_flag = vflag[v];
           const uint32_t side_r = rc != DSA_INVALID ? (uint32_t)fvis[rc >> 2] : 1u, side_l = lc != DSA_INVALID ? (uint32_t)fvis[lc >> 2] : 1u;
-          if (rc != DSA_INVALID && backoff == 0) { rb0 = R::load(frec, rc >> 2); have_seed = true; }
+          // (the records behind both edges ride along: whichever way the step goes, the next element's record is here)
+          Raw rl0 = R::none();
+          if (rc != DSA_INVALID) { rb0 = R::load(frec, rc >> 2); have_seed = true; }
+          if (lc != DSA_INVALID) rl0 = R::load(frec, lc >> 2);
+          have_kids = true;
+          { const uint32_t kr = rc & 3u, kl = lc & 3u;
+            kr_v = uni(R::vertex(rb0, kr)); kr_rc = uni(R::opp(rb0, k_next(kr))); kr_lc = uni(R::opp(rb0, k_prev(kr)));
+            kl_v = uni(R::vertex(rl0, kl)); kl_rc = uni(R::opp(rl0, k_next(kl))); kl_lc = uni(R::opp(rl0, k_prev(kl))); }
           const uint32_t uf = uni(tip_flag);
           const bool rdone = rc == DSA_INVALID || (rc >> 2) == face || uni(side_r) != 0;
           const bool ldone = lc == DSA_INVALID || (lc >> 2) == face || uni(side_l) != 0;
@@ -1110,22 +1124,51 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
         // of them.  A tip that was visited before the run can never count as new, so only unvisited tips are looked up; the
         // neighbour faces only where their state before the run leaves the question open.
         uint32_t sfa = TR_NONE, sfb = TR_NONE, sta = TR_NONE, stb = TR_NONE, srf = TR_NONE, slf = TR_NONE, sla = TR_NONE;
-        if (lin) {
-          // all four id sequences are arithmetic (verified lane by lane above): X is element j of one iff (X - first) = j * step
-          TCOUNT(np_lin);
-          // (first element and step from lanes 0 and 1 of the verified ids; a run of one pair has no step to speak of)
-          const bool two = len >= 2;
-          const int32_t fa0 = (int32_t)(rdlane(a, 0) >> 2), fb0 = (int32_t)(rdlane(b, 0) >> 2), ta0 = (int32_t)rdlane(tipA, 0), tb0 = (int32_t)rdlane(tipB, 0);
-          const int32_t sA = two ? (int32_t)(rdlane(a, 1) - rdlane(a, 0)) >> 2 : 1, sB = two ? (int32_t)(rdlane(b, 1) - rdlane(b, 0)) >> 2 : 1;
-          const int32_t sTA = two ? (int32_t)(rdlane(tipA, 1) - rdlane(tipA, 0)) : 1, sTB = two ? (int32_t)(rdlane(tipB, 1) - rdlane(tipB, 0)) : 1;
-          const float iA = 1.0f / (float)sA, iB = 1.0f / (float)sB, iTA = 1.0f / (float)sTA, iTB = 1.0f / (float)sTB;
-          auto pos_in = [&](uint32_t X, int32_t first, int32_t step, float inv, uint32_t odd) -> uint32_t {
-            const int32_t d = (int32_t)X - first;
-            const int32_t j = (int32_t)__builtin_rintf((float)d * inv);
-            return (j >= 0 && (uint32_t)j < len && j * step == d) ? 2u * (uint32_t)j + odd : TR_NONE;
+        // Are the four id sequences (faces of a, faces of b, tips of a, tips of b) closed forms over the verified lanes?  A fast
+        // attempt checked every lane against its progression; a dependent one built a by formula, the others are checked here against
+        // the fit through lanes 0 .. 2.  Strictly monotonic sequences with a constant second difference: "which pair holds X" is a
+        // division (linear) or a six-step bisection on the closed form -- no LDS tables.
+        int32_t fa0, fas, fad, fb0, fbs, fbd, ta0, tas, tad, tb0, tbs, tbd;
+        bool arith;
+        {
+          const uint32_t tri = lane * (lane - 1u) / 2u;
+          const bool two = len >= 2, three = len >= 3;
+          auto fit = [&](uint32_t x, int32_t &q0, int32_t &qs, int32_t &qd) {
+            const uint32_t x0 = rdlane(x, 0), x1 = rdlane(x, 1), x2 = rdlane(x, 2);
+            q0 = (int32_t)x0; qs = two ? (int32_t)(x1 - x0) : 1; qd = three ? (int32_t)((x2 - x1) - (x1 - x0)) : 0;
           };
-          auto face_pos = [&](uint32_t X) -> uint32_t { const uint32_t x = pos_in(X, fa0, sA, iA, 0u), y = pos_in(X, fb0, sB, iB, 1u); return x < y ? x : y; };
-          auto tip_pos = [&](uint32_t X) -> uint32_t { const uint32_t x = pos_in(X, ta0, sTA, iTA, 0u), y = pos_in(X, tb0, sTB, iTB, 1u); return x < y ? x : y; };
+          auto mono = [&](int32_t s_, int32_t d_) -> bool {
+            const int32_t last = s_ + d_ * (int32_t)(two ? len - 2u : 0u);
+            return s_ != 0 && last != 0 && ((s_ ^ last) >= 0) && d_ > -(1 << 24) && d_ < (1 << 24);
+          };
+          int32_t a0, as_, ad, b0, bs_, bd;
+          fit(a, a0, as_, ad); fit(b, b0, bs_, bd); fit(tipA, ta0, tas, tad); fit(tipB, tb0, tbs, tbd);
+          arith = ((as_ | ad | bs_ | bd) & 3) == 0 && mono(as_, ad) && mono(bs_, bd) && mono(tas, tad) && mono(tbs, tbd);
+          if (arith && kind == 3)
+            arith = __ballot(lane < len && (a != (uint32_t)a0 + lane * (uint32_t)as_ + (uint32_t)ad * tri || b != (uint32_t)b0 + lane * (uint32_t)bs_ + (uint32_t)bd * tri ||
+                                            tipA != (uint32_t)ta0 + lane * (uint32_t)tas + (uint32_t)tad * tri || tipB != (uint32_t)tb0 + lane * (uint32_t)tbs + (uint32_t)tbd * tri)) == 0;
+          fa0 = a0 >> 2; fas = as_ >> 2; fad = ad >> 2; fb0 = b0 >> 2; fbs = bs_ >> 2; fbd = bd >> 2;
+        }
+        if (arith) {
+          TCOUNT(np_lin);
+          const float iA = 1.0f / (float)fas, iB = 1.0f / (float)fbs, iTA = 1.0f / (float)tas, iTB = 1.0f / (float)tbs;
+          auto pos_in = [&](uint32_t X, int32_t first, int32_t step, int32_t dd, float inv, uint32_t odd) -> uint32_t {
+            if (dd == 0) {                                    // X = first + j step
+              const int32_t d = (int32_t)X - first;
+              const int32_t j = (int32_t)__builtin_rintf((float)d * inv);
+              return (j >= 0 && (uint32_t)j < len && j * step == d) ? 2u * (uint32_t)j + odd : TR_NONE;
+            }
+            int32_t j = 0;                                    // the last j whose element is not beyond X
+#pragma unroll
+            for (int32_t bit = 32; bit >= 1; bit >>= 1) {
+              const int32_t t = j + bit;
+              const int32_t qt = first + t * step + dd * (t * (t - 1) / 2);
+              if ((uint32_t)t < len && (step > 0 ? qt <= (int32_t)X : qt >= (int32_t)X)) j = t;
+            }
+            return first + j * step + dd * (j * (j - 1) / 2) == (int32_t)X ? 2u * (uint32_t)j + odd : TR_NONE;
+          };
+          auto face_pos = [&](uint32_t X) -> uint32_t { const uint32_t x = pos_in(X, fa0, fas, fad, iA, 0u), y = pos_in(X, fb0, fbs, fbd, iB, 1u); return x < y ? x : y; };
+          auto tip_pos = [&](uint32_t X) -> uint32_t { const uint32_t x = pos_in(X, ta0, tas, tad, iTA, 0u), y = pos_in(X, tb0, tbs, tbd, iTB, 1u); return x < y ? x : y; };
           if (pair_ok) {
             sfa = face_pos(fa); sfb = face_pos(fb);
             if (!(flA & 1u)) sta = tip_pos(tipA);
@@ -1259,6 +1302,7 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
           }
           corner = nxt;
           face = corner >> 2;
+          have_kids = false;                 // (they were the neighbours of the corner the run started from)
           n_run += 1; n_run_faces += 2 * K;
           fail_streak = 0; no_hist = false;
           if ((fuse_operands & 2u) && K < window && len > K) { side2 = side1; side1 = K; const uint32_t m = (side1 > side2 ? side1 : side2) + 4; window = m < WAVE ? m : WAVE; }
@@ -1315,10 +1359,12 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
           went_right = true;
         }
       }
+      bool went_left = false;
       if (!went_right) {
         if (bits & 4u) {
           if (bits & 8u) { --sp; TPROF(5); break; }
           corner = lc;
+          went_left = true;
         } else {
           if (bits & 8u) { corner = rc; went_right = true; }
           else {
@@ -1332,6 +1378,8 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
       }
       // the element behind the right edge is known too when the attempt judged it
       if (went_right && have2) { have_rec = true; have_state = true; c_v = c2_v; c_rc = c2_rc; c_lc = c2_lc; c_bits = c2_bits; }
+      else if (have_kids && went_right) { have_rec = true; c_v = kr_v; c_rc = kr_rc; c_lc = kr_lc; }
+      else if (have_kids && went_left) { have_rec = true; c_v = kl_v; c_rc = kl_rc; c_lc = kl_lc; }
       have2 = false;
       TPROF(5);
     }
