@@ -444,6 +444,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // element-parallel kernel behind the traversal when it does not
   static const char *fuse_env = getenv("DSA_FUSE_OPERANDS");                              // diagnostics: 0 / 1 overrides the rule
   const bool fuse_operands = fuse_env ? atoi(fuse_env) != 0 : n >= 2048;
+  static const uint32_t lane_flags = getenv("DSA_LANES") ? (uint32_t)atoi(getenv("DSA_LANES")) : PW_FLAG;
   const uint32_t trav_flags = (fuse_operands ? 1u : 0u) | (getenv("DSA_TRAV_NO_WINDOW") ? 0u : 2u);   // bit 1: adaptive run window (diagnostics switch)
   // connectivity and traversal of a mesh by one wave (k_chain) unless DSA_CHAIN=0 asks for the two kernels: as two kernels,
   // the slots the connectivity waves leave go to waiting entropy-decode waves and most traversal waves start late
@@ -480,7 +481,6 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // default (profiles/README.md).  bit 2 = wrap prediction by k_predict_wrap (default on), bit 3 = octahedral delta
   // one lane per stream (k_predict_oct_lanes: frees 2 G scalar + 2 G vector instructions per step, but its own chain is
   // longer than the wave-per-stream kernel's and the traversal beside it does not speed up: measured 2 ms slower, off)
-  static const uint32_t lane_flags = getenv("DSA_LANES") ? (uint32_t)atoi(getenv("DSA_LANES")) : PW_FLAG;
   if (lane_flags & LN_FLAG_SYMBOLS) {
     const uint32_t groups = (n + WAVE - 1) / WAVE;
     hipLaunchKernelGGL(dsa::lanes::k_symbols_lanes<LN_T2_SYMS>, dim3(groups, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
@@ -499,11 +499,14 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   const uint32_t tier_blocks = (uint32_t)std::min<uint64_t>((uint64_t)n * na, SYM_TIER_BLOCKS);
   auto launch_symbols = [&](hipStream_t s, uint32_t fl) {
     fl |= wide_flag;
-    hipLaunchKernelGGL(dsa::k_symbols_reg, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
+    // The kernels for everything but 12-bit-precision streams go first: for most batches they find nothing to do, which takes
+    // them microseconds while the machine is still filling and a millisecond and a half once every slot is held by a decoder
+    // (they used to follow k_symbols_reg: 1.7 ms of empty launches in front of the early attributes' prediction).
     if (wide_flag) hipLaunchKernelGGL(dsa::k_symbols_wide, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
     hipLaunchKernelGGL(dsa::k_symbols<1>, dim3(tier_blocks), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, na, fl);
     hipLaunchKernelGGL(dsa::k_symbols<0>, dim3(tier_blocks), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, na, fl);
     hipLaunchKernelGGL(dsa::k_symbols<2>, dim3(tier_blocks), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, na, fl);
+    hipLaunchKernelGGL(dsa::k_symbols_reg, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
   };
   {
     // The identity maps of point clouds (nothing to do for meshes) go first on the symbol stream, and the symbol kernels of

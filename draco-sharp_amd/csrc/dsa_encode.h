@@ -23,6 +23,7 @@
 // bit-exactly to the quantised input.
 #pragma once
 #include <chrono>
+#include <memory>
 #include <thread>
 
 #include "dsa_encode_host.h"
@@ -366,6 +367,7 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
   opt.pos_prediction = od.position_prediction; opt.uv_prediction = od.texcoord_prediction;
   dsa_encoded *E = new (std::nothrow) dsa_encoded();
   if (!E) return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "host allocation failed");
+  std::unique_ptr<dsa_encoded> E_owner(E);      // released into *out at the very end; every other exit frees it
   E->ctx = ctx;
   E->streams.resize(n); E->status.assign(n, DSA_OK); E->messages.resize(n);
   // ---- host phase 1: connectivity, traversal order, operand entries (threads over meshes)
@@ -414,26 +416,32 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
       }
     } catch (const std::exception &e) { E->status[i] = DSA_ERR_INVALID_DATA; E->messages[i] = e.what(); }
   };
-  {
-    const uint32_t nt = std::max(1u, std::min<uint32_t>(n, std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 8));
-    std::vector<std::thread> th;
-    for (uint32_t t = 0; t < nt; ++t) th.emplace_back([&, t]() { for (uint32_t i = t; i < n; i += nt) plan_one(i); });
-    for (auto &x : th) x.join();
-  }
+  hostutil::parallel_for(n, plan_one);          // capped thread count, every thread joined on every path (dsa_host_util.h)
   lap("host checks / plan");
   // ---- device layout
   std::vector<dsa::EncStream> hs;
   std::vector<dsa::EncConn> hc(host_conn ? 0 : n);
   std::vector<uint32_t> first_stream(n + 1, 0);
-  uint64_t cur = 0;
+  // What the host provides (faces, raw attribute values; with host connectivity the traversal order and operands) lies at the
+  // front of the arena in one run, so that it travels in a few large transfers out of pinned staging; everything else behind it.
+  auto al = [](uint64_t b) { return (b + 255) & ~255ull; };
+  uint64_t in_total = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (E->status[i] != DSA_OK) continue;
+    const uint64_t V = meshes[i].num_vertices, F = meshes[i].num_faces;
+    in_total += host_conn ? al(4 * V) + al(12 * V) : al(12 * F);
+    for (auto &a : plans[i].atts) in_total += al(4 * V * (uint64_t)a.nc_out);
+  }
+  uint64_t cur = in_total, cur_in = 0;
   auto take = [&](uint64_t bytes) { uint64_t at = cur; cur = (cur + bytes + 255) & ~255ull; return at; };
+  auto take_in = [&](uint64_t bytes) { uint64_t at = cur_in; cur_in = (cur_in + bytes + 255) & ~255ull; return at; };
   struct Upload { uint64_t off; const void *src; size_t bytes; };
   std::vector<Upload> uploads;
   for (uint32_t i = 0; i < n; ++i) {
     first_stream[i] = (uint32_t)hs.size();
     if (E->status[i] != DSA_OK) continue;
     const uint32_t V = meshes[i].num_vertices;
-    const uint64_t o_e2v = take(4ull * V), o_ops = take(12ull * V);
+    const uint64_t o_e2v = host_conn ? take_in(4ull * V) : take(4ull * V), o_ops = host_conn ? take_in(12ull * V) : take(12ull * V);
     if (host_conn) {
       uploads.push_back({o_e2v, e2v[i].data(), 4ull * V});
       uploads.push_back({o_ops, ops[i].data(), 12ull * V});
@@ -442,7 +450,7 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
       dsa::EncConn &C = hc[i];
       memset(&C, 0, sizeof(C));
       C.F = F; C.V = V; C.split_cap = F;
-      C.faces = take(12ull * F); uploads.push_back({C.faces, meshes[i].faces, 12ull * F});
+      C.faces = take_in(12ull * F); uploads.push_back({C.faces, meshes[i].faces, 12ull * F});
       C.opp = take(12ull * F); C.voff = take(4ull * (V + 1)); C.vcur = take(4ull * V); C.vlist = take(12ull * F); C.vcorner = take(4ull * V);
       C.fvis = take(F); C.vvis = take(V); C.hole_id = take(4ull * V); C.hole_vis = take(V); C.split_sym = take(4ull * F);
       C.stack = take(4ull * F); C.processed = take(4ull * F); C.init_corners = take(4ull * F);
@@ -456,7 +464,7 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
       const float *src = a.att_type == 0 ? meshes[i].positions : (a.att_type == 1 ? meshes[i].normals : meshes[i].texcoords);
       S.nv = V; S.nc_out = (uint32_t)a.nc_out; S.nc = (uint32_t)a.nc; S.kind = a.seq_type == 3 ? 1u : 0u;
       S.bits = (uint32_t)a.bits; S.prediction = (uint32_t)a.prediction;
-      S.src = take(4ull * V * S.nc_out);
+      S.src = take_in(4ull * V * S.nc_out);
       uploads.push_back({S.src, src, 4ull * V * S.nc_out});
       S.e2v = o_e2v; S.ops = o_ops;
       S.vals = take(4ull * V * S.nc); S.d = take(4ull * V * S.nc); S.syms = take(4ull * V * S.nc); S.bl = take(V);
@@ -475,8 +483,9 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
   uint8_t *arena = nullptr;
   dsa::EncStream *d_streams = nullptr;
   dsa::EncConn *d_conns = nullptr;
-  auto cleanup = [&]() { if (arena) (void)hipFree(arena); if (d_streams) (void)hipFree(d_streams); if (d_conns) (void)hipFree(d_conns); };
-#define ENC_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); delete E; return set_err(ctx, e_ == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
+  auto cleanup = [&]() { if (arena) (void)hipFree(arena); if (d_streams) (void)hipFree(d_streams); if (d_conns) (void)hipFree(d_conns); arena = nullptr; d_streams = nullptr; d_conns = nullptr; };
+  struct AtExit { decltype(cleanup) &f; ~AtExit() { f(); } } at_exit{cleanup};     // also when a host allocation throws in between
+#define ENC_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { return set_err(ctx, e_ == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
   // pieces of the arena -> one host buffer (items[k].packed_off filled in); host buffer -> pieces of the arena
   auto gather = [&](std::vector<dsa::PackItem> &items, std::vector<uint8_t> &host) -> dsa_status {
     uint64_t total = 0;
@@ -488,8 +497,13 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     if (e == hipSuccess) e = hipMalloc((void **)&d_items, sizeof(dsa::PackItem) * items.size());
     if (e == hipSuccess) e = hipMemcpyAsync(d_items, items.data(), sizeof(dsa::PackItem) * items.size(), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) { hipLaunchKernelGGL(dsa::k_enc_pack, dim3((uint32_t)items.size()), dim3(256), 0, ctx->stream, arena, d_packed, d_items, (uint32_t)items.size()); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d_packed, total, hipMemcpyDeviceToHost, ctx->stream);
+    // through pinned staging (a pageable destination is staged by the runtime at a fraction of the link's rate)
+    hostutil::Staging &stg = ctx->stage[ctx->stage_next];
+    ctx->stage_next ^= 1;
+    if (e == hipSuccess) e = stg.acquire((size_t)total);
+    if (e == hipSuccess) e = hipMemcpyAsync(stg.buf.p, d_packed, total, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) hostutil::parallel_memcpy(host.data(), stg.buf.p, (size_t)total);
     if (d_packed) (void)hipFree(d_packed);
     if (d_items) (void)hipFree(d_items);
     return e == hipSuccess ? DSA_OK : (e == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE);
@@ -507,13 +521,32 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     if (d_items) (void)hipFree(d_items);
     return e == hipSuccess ? DSA_OK : (e == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE);
   };
-#define ENC_ST(call) do { dsa_status s_ = (call); if (s_ != DSA_OK) { cleanup(); delete E; return set_err(ctx, s_, "%s failed", #call); } } while (0)
+#define ENC_ST(call) do { dsa_status s_ = (call); if (s_ != DSA_OK) { return set_err(ctx, s_, "%s failed", #call); } } while (0)
   if (ns) {
     hipStream_t st = ctx->stream;
     ENC_TRY(hipMalloc((void **)&arena, cur ? cur : 256));
     ENC_TRY(hipMalloc((void **)&d_streams, sizeof(dsa::EncStream) * ns));
     ENC_TRY(hipMemsetAsync(arena, 0, cur, st));              // histograms start at zero
-    for (auto &u : uploads) ENC_TRY(hipMemcpyAsync(arena + u.off, u.src, u.bytes, hipMemcpyHostToDevice, st));
+    // uploads in chunks through the context's two pinned staging buffers: host threads fill one while the DMA engine drains the
+    // other (a pageable source would be staged by the runtime, one thread, a few GB/s)
+    {
+      const uint64_t chunk_cap = 192ull << 20;
+      size_t i0 = 0;
+      while (i0 < uploads.size()) {
+        const uint64_t lo = uploads[i0].off;
+        size_t i1 = i0 + 1;
+        while (i1 < uploads.size() && uploads[i1].off + uploads[i1].bytes - lo <= chunk_cap) ++i1;
+        const uint64_t hi = uploads[i1 - 1].off + uploads[i1 - 1].bytes;
+        hostutil::Staging &stg = ctx->stage[ctx->stage_next];
+        ctx->stage_next ^= 1;
+        ENC_TRY(stg.acquire((size_t)(hi - lo)));
+        uint8_t *h = stg.buf.p;
+        hostutil::parallel_for((uint32_t)(i1 - i0), [&](uint32_t k) { const Upload &u = uploads[i0 + k]; memcpy(h + (u.off - lo), u.src, u.bytes); }, 2);
+        ENC_TRY(hipMemcpyAsync(arena + lo, h, (size_t)(hi - lo), hipMemcpyHostToDevice, st));
+        ENC_TRY(stg.submitted(st));
+        i0 = i1;
+      }
+    }
     ENC_TRY(hipMemcpyAsync(d_streams, hs.data(), sizeof(dsa::EncStream) * ns, hipMemcpyHostToDevice, st));
     uint32_t maxv = 0;
     for (auto &S : hs) maxv = std::max(maxv, S.nv);
@@ -607,12 +640,7 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
       synth::check(splans[s].coder.num_symbols <= std::max<uint32_t>(hs[s].hist_cap, 64), "alphabet larger than the table region");
     } catch (const std::exception &e) { plan_error[s] = e.what(); if (plan_error[s].empty()) plan_error[s] = "symbol plan failed"; hs[s].overflow = 1; }
   };
-  {
-    const uint32_t nt = std::max(1u, std::min<uint32_t>(ns, std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 8));
-    std::vector<std::thread> th;
-    for (uint32_t t = 0; t < nt; ++t) th.emplace_back([&, t]() { for (uint32_t s = t; s < ns; s += nt) plan_stream(s); });
-    for (auto &x : th) x.join();
-  }
+  hostutil::parallel_for(ns, plan_stream);
   {
     std::vector<dsa::PackItem> items;
     std::vector<uint8_t> host;
@@ -708,14 +736,9 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     } catch (const std::exception &e) { E->status[i] = DSA_ERR_INVALID_DATA; E->messages[i] = e.what(); return; }
     E->streams[i].swap(w.d);
   };
-  {
-    const uint32_t nt = std::max(1u, std::min<uint32_t>(n, std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 8));
-    std::vector<std::thread> th;
-    for (uint32_t t = 0; t < nt; ++t) th.emplace_back([&, t]() { for (uint32_t i = t; i < n; i += nt) layout_one(i); });
-    for (auto &x : th) x.join();
-  }
+  hostutil::parallel_for(n, layout_one);
   lap("stream layout");
-  *out = E;
+  *out = E_owner.release();
   return DSA_OK;
 }
 

@@ -36,6 +36,12 @@ __device__ __forceinline__ uint32_t cnext(uint32_t c) { return (c % 3u == 2u) ? 
 __device__ __forceinline__ uint32_t cprev(uint32_t c) { return (c % 3u == 0u) ? c + 2u : c - 1u; }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+// a wave-uniform pointer the compiler took for a per-lane value (it came out of a vector load): into scalar registers
+template <class T>
+__device__ __forceinline__ T *uni_ptr(T *p) {
+  const uint64_t v = (uint64_t)p;
+  return (T *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+}
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 // The symbol kernels are launched twice when the batch is decoded on four streams: once for the attributes whose prediction
 // waits for the traversal (parallelogram: "late") and once, on a stream of higher priority that goes on to predict and
@@ -689,14 +695,21 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
     }
     if (lane == 0) D->num_points = base;
   }
-  // ---- IsOnBoundary per vertex (CornerTable.cs:174-178) for the traversal: bit1 of the vertex flag
+  // ---- IsOnBoundary per vertex (CornerTable.cs:174-178) for the traversal: bit1 of the vertex flag.  A record load, then a
+  // gather that depends on it: four vertices per lane in flight.
   {
     uint8_t *vflag = arena + L.vvis;
-    for (uint32_t v = lane; v < NVALL; v += WAVE) {
-      const uint32_t lm = vrec[v].x;
-      uint8_t fl = 0;
-      if (lm != DSA_INVALID && lm < 4 * F && (lm & 3u) != 3u) fl = R::get_o(frec, qnext(lm)) == DSA_INVALID ? 2 : 0;
-      vflag[v] = fl;
+    for (uint32_t v0 = 0; v0 < NVALL; v0 += 4 * WAVE) {
+      uint32_t lm[4], oo[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const uint32_t v = v0 + u * WAVE + lane; lm[u] = v < NVALL ? vrec[v].x : DSA_INVALID; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = lm[u] != DSA_INVALID && lm[u] < 4 * F && (lm[u] & 3u) != 3u;
+        oo[u] = ok ? R::get_o(frec, qnext(lm[u])) : 0u;          // (not a corner: not on the boundary)
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const uint32_t v = v0 + u * WAVE + lane; if (v < NVALL) vflag[v] = oo[u] == DSA_INVALID ? 2 : 0; }
     }
   }
   if (lane == 0) {
@@ -2352,6 +2365,11 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
   MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
   if (phase == 0 && D->att[ai].early_done) return;
+  // (issue priority for the early attributes' prediction -- the serial octahedral chains their strand ends on -- was measured: the
+  // late symbols lose what it gains)
+#ifdef DSA_PREDICT_PRIO
+  if (phase == 0) __builtin_amdgcn_s_setprio(DSA_PREDICT_PRIO);
+#endif
   predict_wave(arena, layouts[mesh], D, ai, phase, flags);
 }
 
