@@ -414,8 +414,23 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // fork: entropy decode of every attribute stream on the second stream (it only needs k_locate's offsets)
   // DSA_SERIAL=1 (diagnostics): everything on the main stream, so that stage times are stand-alone kernel times
   static const bool serial = getenv("DSA_SERIAL") != nullptr;
-  static const char *diag_env = getenv("DSA_DIAG");         // timing experiments only (results are wrong with it): 4 = no early prediction
-  static const uint32_t diag = diag_env ? (uint32_t)atoi(diag_env) : 0u;
+  // Everything else the schedule could vary by is fixed in the product library; a -DDSA_EXPERIMENTS build (csrc/Makefile, EXTRA=)
+  // reads the switches profiles/README.md reports on from the environment: the schedules and the lane-per-chain kernels that
+  // were measured and lost.
+#ifdef DSA_EXPERIMENTS
+  auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+  static const int fuse_choice = env_int("DSA_FUSE_OPERANDS", -1), chain_choice = env_int("DSA_CHAIN", -1);
+  static const uint32_t lane_flags = (uint32_t)env_int("DSA_LANES", (int)PW_FLAG);
+  static const bool run_window = env_int("DSA_TRAV_NO_WINDOW", 0) == 0;
+  static const int trav_split = env_int("DSA_TRAV_SPLIT", 1), split_mode = env_int("DSA_SYM_SPLIT", 1);
+  static const uint32_t wide_flag = env_int("DSA_SYM_WIDE", 1) ? SYM_WIDE : 0u;
+  static const bool early_fuse_on = env_int("DSA_EARLY_FUSE", 0) != 0;
+  static const uint32_t oct_lpw = (uint32_t)env_int("DSA_OCT_LPW", 16);
+#else
+  const int fuse_choice = -1, chain_choice = -1, trav_split = 1, split_mode = 1;
+  const uint32_t lane_flags = PW_FLAG, wide_flag = SYM_WIDE;
+  const bool run_window = true, early_fuse_on = false;
+#endif
   hipStream_t st2 = serial ? st : ctx->stream2, st3 = serial ? st : ctx->stream3;
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_fork, 0));
@@ -442,15 +457,12 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   }
   // parallelogram operands: by the traversal waves themselves when the batch keeps the machine busy anyway, by an
   // element-parallel kernel behind the traversal when it does not
-  static const char *fuse_env = getenv("DSA_FUSE_OPERANDS");                              // diagnostics: 0 / 1 overrides the rule
-  const bool fuse_operands = fuse_env ? atoi(fuse_env) != 0 : n >= 2048;
-  static const uint32_t lane_flags = getenv("DSA_LANES") ? (uint32_t)atoi(getenv("DSA_LANES")) : PW_FLAG;
-  const uint32_t trav_flags = (fuse_operands ? 1u : 0u) | (getenv("DSA_TRAV_NO_WINDOW") ? 0u : 2u);   // bit 1: adaptive run window (diagnostics switch)
+  const bool fuse_operands = fuse_choice >= 0 ? fuse_choice != 0 : n >= 2048;
+  const uint32_t trav_flags = (fuse_operands ? 1u : 0u) | (run_window ? 2u : 0u);   // bit 1: adaptive run window
   // connectivity and traversal of a mesh by one wave (k_chain) unless DSA_CHAIN=0 asks for the two kernels: as two kernels,
   // the slots the connectivity waves leave go to waiting entropy-decode waves and most traversal waves start late
   // (a small batch leaves slots free anyway, and is quicker with the faces converted beside the traversal)
-  static const char *chain_env = getenv("DSA_CHAIN");
-  const bool chain = chain_env ? atoi(chain_env) != 0 : n > 2048;       // measured: equal at 2048, 1.3 ms slower at 1024, 4 ms faster at 4096
+  const bool chain = chain_choice >= 0 ? chain_choice != 0 : n > 2048;       // measured: equal at 2048, 1.3 ms slower at 1024, 4 ms faster at 4096
   auto launch_faces = [&]() -> hipError_t {      // faces as point ids + link census need the connectivity: third stream
     hipError_t e = hipEventRecord(ctx->ev_trav, st);
     if (e == hipSuccess) e = hipStreamWaitEvent(st3, ctx->ev_trav, 0);
@@ -467,8 +479,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     HIP_TRY(ctx, launch_faces());                      // beside the traversal
     HIP_TRY(ctx, mark());
-    static const int split = getenv("DSA_TRAV_SPLIT") ? atoi(getenv("DSA_TRAV_SPLIT")) : 1;   // diagnostics
-    const uint32_t per = (n + split - 1) / split;
+    const uint32_t per = (n + (uint32_t)trav_split - 1) / (uint32_t)trav_split;
     for (uint32_t m0 = 0; m0 < n; m0 += per) {
       const uint32_t cnt = std::min(per, n - m0);
       hipLaunchKernelGGL(dsa::k_traverse, dim3(cnt), dim3(WAVE), 0, st, b->arena, b->d_layouts + m0, b->d_descs + m0, cnt, trav_flags);
@@ -481,21 +492,20 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // default (profiles/README.md).  bit 2 = wrap prediction by k_predict_wrap (default on), bit 3 = octahedral delta
   // one lane per stream (k_predict_oct_lanes: frees 2 G scalar + 2 G vector instructions per step, but its own chain is
   // longer than the wave-per-stream kernel's and the traversal beside it does not speed up: measured 2 ms slower, off)
+#ifdef DSA_EXPERIMENTS
   if (lane_flags & LN_FLAG_SYMBOLS) {
     const uint32_t groups = (n + WAVE - 1) / WAVE;
     hipLaunchKernelGGL(dsa::lanes::k_symbols_lanes<LN_T2_SYMS>, dim3(groups, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
     hipLaunchKernelGGL(dsa::lanes::k_symbols_lanes<LN_T1_SYMS>, dim3(groups, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
     hipLaunchKernelGGL(dsa::lanes::k_symbols_lanes<LN_T0_SYMS>, dim3(groups, na), dim3(WAVE), 0, st2, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
   }
+#endif
   // Attributes whose prediction does not wait for the traversal ("early": difference, octahedral delta) are decoded,
   // predicted and dequantised on a stream of their own with dispatch priority, beside the traversal; the symbols of the
   // parallelogram attributes ("late") follow on the second stream.  DSA_SYM_SPLIT=0, DSA_SERIAL and the lane-per-chain
   // options keep the single symbol launch.
-  static const bool sym_split = !serial && !(lane_flags & (LN_FLAG_SYMBOLS | LN_FLAG_PREDICT)) &&
-                                !(getenv("DSA_SYM_SPLIT") && atoi(getenv("DSA_SYM_SPLIT")) == 0);
+  const bool sym_split = !serial && !(lane_flags & (LN_FLAG_SYMBOLS | LN_FLAG_PREDICT)) && split_mode != 0;
   hipStream_t st4 = sym_split ? ctx->stream4 : st2;
-  // k_symbols_wide (raw streams of any precision with a search table of <= 2048 entries, in registers) unless DSA_SYM_WIDE=0
-  static const uint32_t wide_flag = (getenv("DSA_SYM_WIDE") && atoi(getenv("DSA_SYM_WIDE")) == 0) ? 0u : SYM_WIDE;
   const uint32_t tier_blocks = (uint32_t)std::min<uint64_t>((uint64_t)n * na, SYM_TIER_BLOCKS);
   auto launch_symbols = [&](hipStream_t s, uint32_t fl) {
     fl |= wide_flag;
@@ -517,11 +527,10 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_point_maps, dim3(gx, n), dim3(256), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st2));
   }
-  static const int split_mode = getenv("DSA_SYM_SPLIT") ? atoi(getenv("DSA_SYM_SPLIT")) : 1;
   // DSA_EARLY_FUSE=1 (measured 1.7 ms slower, off): the wave that decoded an early attribute's symbols also predicts and
   // dequantises it -- the octahedral prediction leaves the tail (7.5 -> 4.7 ms) but its waves keep 80-register slots twice as
   // long and the late symbols end 4.7 ms later
-  static const uint32_t early_fuse = (getenv("DSA_EARLY_FUSE") && atoi(getenv("DSA_EARLY_FUSE")) != 0) && !(lane_flags & (LN_FLAG_PREDICT | LN_FLAG_OCT)) ? SYM_EARLY_FUSE : 0u;
+  const uint32_t early_fuse = early_fuse_on && !(lane_flags & (LN_FLAG_PREDICT | LN_FLAG_OCT)) ? SYM_EARLY_FUSE : 0u;
   if (sym_split && split_mode == 2) {          // early attributes first, then the late ones beside the early prediction
     launch_symbols(st2, lane_flags | SYM_EARLY_ONLY | early_fuse);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st2));
@@ -536,17 +545,21 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   HIP_TRY(ctx, hipEventRecord(ctx->ev_join, st2));           // corrections of the late attributes (without the split: of every attribute) are ready
   // attributes whose prediction needs no traversal data (difference, octahedral delta) are finished on this stream,
   // beside the traversal and the parallelogram attributes; joined before k_seal
+#ifdef DSA_EXPERIMENTS
   if (lane_flags & LN_FLAG_PREDICT) hipLaunchKernelGGL(dsa::lanes::k_predict_lanes<16>, dim3((n + 15) / 16, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u);
-  else {
-    if (!(diag & 4u)) hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
+  else
+#endif
+  {
+    hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
     if (lane_flags & PW_FLAG) hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
+#ifdef DSA_EXPERIMENTS
     if (lane_flags & LN_FLAG_OCT) {
-      static const uint32_t lpw = getenv("DSA_OCT_LPW") ? (uint32_t)atoi(getenv("DSA_OCT_LPW")) : 16u;   // meshes per wave (diagnostics: 8, 16, 32, 64)
-      if (lpw == 8) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes<8>, dim3((n + 7) / 8, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
-      else if (lpw == 32) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes<32>, dim3((n + 31) / 32, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
-      else if (lpw == 64) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes<64>, dim3((n + 63) / 64, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
+      if (oct_lpw == 8) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes<8>, dim3((n + 7) / 8, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
+      else if (oct_lpw == 32) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes<32>, dim3((n + 31) / 32, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
+      else if (oct_lpw == 64) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes<64>, dim3((n + 63) / 64, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
       else hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes<16>, dim3((n + 15) / 16, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
     }
+#endif
   }
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
@@ -562,8 +575,11 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));   // join: corrections are ready
   if (b->any_general) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join3, 0));   // join: the general path's integers are ready
   HIP_TRY(ctx, mark());
+#ifdef DSA_EXPERIMENTS
   if (lane_flags & LN_FLAG_PREDICT) hipLaunchKernelGGL(dsa::lanes::k_predict_lanes<32>, dim3((n + 31) / 32, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u);
-  else {
+  else
+#endif
+  {
     if (lane_flags & PW_FLAG) hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags);
     hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags);
   }

@@ -28,7 +28,17 @@
 
 #include "dsa_common.h"
 #include "dsa_locate.h"
-#include "dsa_lanes.h"
+#ifdef DSA_EXPERIMENTS
+#include "dsa_lanes.h"       // lane-per-chain kernels: bit-exact, measured slower on every workload tried (profiles/README.md); not in the product library
+#else
+#define LN_FLAG_SYMBOLS 1u
+#define LN_FLAG_PREDICT 2u
+#define LN_FLAG_OCT 8u
+namespace dsa { namespace lanes {
+__device__ __forceinline__ bool ln_sym_eligible(const AttrDesc &, const MeshLayout &, uint32_t, uint32_t) { return false; }
+__device__ __forceinline__ bool ln_oct_eligible(const AttrDesc &, uint32_t) { return false; }
+} }
+#endif
 
 namespace dsa {
 
