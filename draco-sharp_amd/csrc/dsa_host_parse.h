@@ -154,7 +154,8 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m, bool want_gene
     if (method > 1) return bad(ST_INVALID);
     uint32_t traversal = r.u8();
     if (!r.ok || traversal > 2) return bad(ST_INVALID);
-    if (traversal != 0) m.general = true;                       // valence / predictive symbols: general path
+    if (traversal == 1) m.general = true;                       // predictive symbols (deprecated by the format): general path
+    // valence symbols (what stock encoders write for larger meshes): fast kernels while the ids fit their 16-byte face records
     uint64_t nv = r.varint(), nf = r.varint();
     if (!r.ok || nf > 0x7FFFFFFFu / 3 || nv > nf * 3 || nf > 1024ull * len) return bad(ST_INVALID);
     uint32_t nad = r.u8();
@@ -166,6 +167,7 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m, bool want_gene
     uint64_t nsplits = r.varint();
     if (!r.ok || nsplits > nf) return bad(ST_INVALID);
     m.faces = (uint32_t)nf; m.enc_vertices = (uint32_t)nv; m.split_symbols = (uint32_t)nss; m.splits = (uint32_t)nsplits; m.num_att_data = nad;
+    if (traversal == 2 && (4 * nf > (1u << 20) || nv + nss >= (1u << 20))) m.general = true;
     for (uint64_t i = 0; i < 2 * nsplits && r.ok; ++i) (void)r.varint();
     r.skip((nsplits + 7) >> 3);
     uint64_t sz;

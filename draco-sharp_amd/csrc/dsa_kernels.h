@@ -211,12 +211,65 @@ __global__ __launch_bounds__(WAVE, 4) void k_locate(uint8_t *arena, const MeshLa
 #define CN_STAGE 32          // faces per staging block (LDS per wave: 1 KB stage + 4 KB records + 256 B window = 5.4 KB)
 #define CN_WIN 64            // dwords of symbol bits per window
 
-#define CN_LDS_WORDS (CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2 + CN_WIN)
+#define CN_CTX_WORDS (6 * 64)     // valence traversal: a 64-symbol window of each of the six context lists
+#define CN_LDS_WORDS (CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2 + CN_WIN + CN_CTX_WORDS)
 // The body of k_connectivity for one mesh on one wave; LDS: sh_stage[CN_STAGE * 8] and sh_rec[CN_REC_BLOCKS * 128] 16-byte
 // aligned, sh_win[CN_WIN].  Also the first half of k_chain.
-template <bool CP>
-__device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t *sh_stage, uint32_t *sh_rec, uint32_t *sh_win) {
+// VAL: valence traversal (MeshEdgeBreakerTraversalValenceDecoder.cs:22-154).  The symbols come from six lists, chosen by the valence
+// of the vertex at corner 1 of the newest face; the machine keeps the valences of the two gate vertices (and their records) in
+// scalar registers and every other vertex's valence in the upper 11 bits of its record's first word (the 16-byte face records
+// this mode requires keep corners below 2^20; a valence saturates at 2047, far above the 7 the contexts distinguish).  The lists
+// are rANS streams over five symbols: the wave decodes them first, into the faces output region (written by k_faces much later).
+// Strip runs are found in this mode too: the lanes work out the lists their symbols come from and look the symbols up.
+#define VAL_LM(x_) ((x_) == DSA_INVALID ? DSA_INVALID : ((x_) & 0x1FFFFFu))
+#define VAL_OF(x_) ((x_) >> 21)
+__device__ __forceinline__ uint32_t val_pack(uint32_t lm, uint32_t val) { return (lm & 0x1FFFFFu) | ((val < 2047u ? val : 2047u) << 21); }
+// One context list: raw rANS stream over at most 64 symbols (Entropy/RAnsSymbolDecoder.cs:12-59, RAnsDecoder.cs:20-99), decoded by the
+// whole wave: cumulative frequencies across the lanes, one ballot per symbol.  sh_tmp: 64 words of LDS.
+__device__ __forceinline__ bool valence_decode_list(MeshDesc *D, const uint8_t *stream, uint32_t stream_len, uint32_t off_table, uint32_t nsym, uint32_t P,
+                                                    uint32_t off_rans, uint32_t size_rans, uint32_t count, uint32_t *out, uint32_t *sh_tmp) {
+  const uint32_t lane = lane_id();
+  const uint32_t precision = 1u << P, l_base = precision * 4;
+  __syncthreads();
+  if (lane == 0) { Rd r(stream, stream_len, off_table); if (!read_prob_table(r, nsym, sh_tmp)) fail(D, ST_INVALID, 400); }
+  __syncthreads();
+  if (status_of(D) != ST_OK) return false;
+  const uint32_t pr = lane < nsym ? sh_tmp[lane] : 0u;
+  uint32_t tot;
+  const uint32_t ex = wave_excl_scan(pr, &tot);
+  if (tot != precision) { if (lane == 0) fail(D, ST_INVALID, 401); return false; }
+  const uint32_t cum = lane < nsym ? ex : precision;            // beyond the alphabet: never <= rem
+  const uint8_t *buf = stream + off_rans;
+  uint32_t x, off;
+  { uint32_t st = 0, o = 0; if (!rans_init(buf, size_rans, l_base, &st, &o)) { if (lane == 0) fail(D, ST_INVALID, 402); return false; } x = uni(st); off = uni(o); }
+  const uintptr_t base_addr = (uintptr_t)buf;
+  const uint32_t mis = (uint32_t)(base_addr & 3u);
+  const uint32_t *abuf = (const uint32_t *)(base_addr - mis);
+  uint32_t chunk = 0xFFFFFFFFu, W = 0, mine = 0;
+  const uint32_t mask = precision - 1;
+  for (uint32_t i = 0; i < count; ++i) {
+    while (x < l_base && off > 0) {
+      --off;
+      const uint32_t q = off + mis, ch = q >> 8;
+      if (ch != chunk) { chunk = ch; W = abuf[(size_t)ch * 64 + lane]; }      // arena padding makes the over-read safe
+      x = (x << 8) | ((rdlane(W, (q & 255u) >> 2) >> ((q & 3u) * 8)) & 0xFFu);
+    }
+    const uint32_t rem = x & mask;
+    const uint32_t j = (uint32_t)__popcll(__ballot(cum <= rem)) - 1u;         // cum of lane 0 is 0: at least one
+    const uint32_t cs = rdlane(cum, j), nx = j < 63 ? rdlane(cum, j + 1) : precision;
+    x = (nx - cs) * (x >> P) + rem - cs;
+    if ((i & 63u) == lane) mine = j;
+    if ((i & 63u) == 63u) out[i - 63u + lane] = mine;
+  }
+  const uint32_t tail = count & 63u;
+  if (tail && lane < tail) out[count - tail + lane] = mine;
+  return true;
+}
+
+template <bool CP, bool VAL>
+__device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t *sh_stage, uint32_t *sh_rec, uint32_t *sh_win, uint32_t *sh_ctx) {
   typedef Rec<CP> R;
+  static_assert(!VAL || CP, "valence traversal on the fast kernels needs the 16-byte face records");
   if (D->status != ST_OK || D->encoder_type == 0 || D->general) return;   // point clouds have no connectivity; general meshes: k_general
   const uint8_t *s = arena + L.stream;
   uint32_t *frec = (uint32_t *)(arena + L.frec);
@@ -273,6 +326,26 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
   bool failed = false;
   uint32_t n_links = 0;                 // opposite links made (each sets two corners)
 
+  // ---- valence traversal: the six lists, and what the machine knows of the two gate vertices
+  uint32_t valT1 = 0, valT2 = 0, lmT1 = 0, nvT1 = 0, lmT2 = 0, nvT2 = 0;
+  uint32_t active_ctx = 6;              // 6: none yet (the first symbol is E by definition, :77-98)
+  uint32_t val_backoff = 0;             // symbols to take one by one before the next attempt at a strip run
+  uint32_t cntv = 0, offv = 0, wbv = 0x7FFFFFC0u;   // lane c < 6: symbols left in list c, its offset in ctx_syms, first index of its LDS window
+  const uint32_t *ctx_syms = (const uint32_t *)(arena + L.faces);
+  if (VAL) {
+    uint32_t off_c = 0;
+    for (uint32_t c = 0; c < 6; ++c) {
+      const uint32_t num = uni(D->val_count[c]);
+      if (lane == c) { cntv = num; offv = off_c; }
+      if (num) {
+        if (!valence_decode_list(D, s, L.stream_len, uni(D->val_off_table[c]), uni(D->val_nsym[c]), uni((uint32_t)D->val_prec[c]), uni(D->val_off_rans[c]),
+                                 uni(D->val_size_rans[c]), num, (uint32_t *)(arena + L.faces) + off_c, sh_win)) return;
+      }
+      off_c += num;
+    }
+    WAIT_VM0();
+    __syncthreads();
+  }
   // write back one dirty block of the record cache (all lanes)
   auto rec_writeback = [&](uint32_t slot) {
     uint32_t v = TAG(slot) * 64 + lane;
@@ -297,9 +370,10 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
   // LDS or in global memory is decided on uniform values, so the branches inside stay scalar.
   // record store: LDS if the block is resident, else straight to global memory
 #define REC_HIT(v_) (TAG(((v_) >> 6) & (CN_REC_BLOCKS - 1)) == ((v_) >> 6))
-#define REC_STORE(v_, hit_, lm_, nv_)                                                                         \
-  { if (hit_) *(uint2 *)&sh_rec[((((v_) >> 6) & (CN_REC_BLOCKS - 1)) * 64 + ((v_) & 63u)) * 2] = make_uint2((lm_), (nv_)); \
-    vrec[(v_)] = make_uint2((lm_), (nv_)); }   /* write-through: global memory is always current */
+#define REC_STORE(v_, hit_, lm_, nv_, val_)                                                                   \
+  { const uint32_t x_ = VAL ? val_pack((lm_), (val_)) : (lm_);                                                \
+    if (hit_) *(uint2 *)&sh_rec[((((v_) >> 6) & (CN_REC_BLOCKS - 1)) * 64 + ((v_) & 63u)) * 2] = make_uint2(x_, (nv_)); \
+    vrec[(v_)] = make_uint2(x_, (nv_)); }   /* write-through: global memory is always current */
 #define REC_DIRTY(v_, hit_) {}
   // opposite slot of corner c: staged or already in global memory
 #define SET_OPP(c_, val_)                                                                \
@@ -342,25 +416,37 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
     // boundary vertex vx_j and creates vertex nv0+j.  vx_{j+1} is the vertex stored behind vx_j's left-most
     // corner; along a regular strip these ids are consecutive, which each lane verifies on its own record.
     // Then every face record, opposite link and vertex record of the run is a closed form of j.
-    if (have_top && bcnt >= 16 && ((uint32_t)bb & 0xFFFFu) == 0xAAAAu) {
-      // candidate pairs: nibble `lane` lies 4 * lane bits ahead -- in the bit buffer, across its end, or in the LDS window (whose
-      // dword widx, bit 0, follows the buffer's last bit), at whatever alignment the symbols before left
-      uint32_t nib;
-      {
-        const uint32_t q = 4 * lane;
-        if (q + 4 <= bcnt) nib = (uint32_t)(bb >> q) & 0xFu;
-        else {
-          const uint32_t have = q < bcnt ? bcnt - q : 0u;              // bits of the nibble still in the buffer (0 .. 3)
-          const uint32_t rel = q + have - bcnt;                        // window bit the rest starts at
-          const uint32_t wi = widx - wbase + (rel >> 5), sh = rel & 31u;
-          const bool in_win = drop_bits == 0 && wi < CN_WIN && (sh + (4u - have) <= 32u || wi + 1 < CN_WIN);
-          uint64_t w = 0;
-          if (in_win) { w = sh_win[wi]; if (wi + 1 < CN_WIN) w |= (uint64_t)sh_win[wi + 1] << 32; }
-          const uint32_t from_win = (uint32_t)(w >> sh);
-          nib = in_win ? (((have ? (uint32_t)(bb >> q) : 0u) | (from_win << have)) & 0xFu) : 0u;
+    bool try_run = false;
+    uint32_t cand = 0;
+    if (!VAL) {
+      if (have_top && bcnt >= 16 && ((uint32_t)bb & 0xFFFFu) == 0xAAAAu) {
+        // candidate pairs: nibble `lane` lies 4 * lane bits ahead -- in the bit buffer, across its end, or in the LDS window (whose
+        // dword widx, bit 0, follows the buffer's last bit), at whatever alignment the symbols before left
+        uint32_t nib;
+        {
+          const uint32_t q = 4 * lane;
+          if (q + 4 <= bcnt) nib = (uint32_t)(bb >> q) & 0xFu;
+          else {
+            const uint32_t have = q < bcnt ? bcnt - q : 0u;              // bits of the nibble still in the buffer (0 .. 3)
+            const uint32_t rel = q + have - bcnt;                        // window bit the rest starts at
+            const uint32_t wi = widx - wbase + (rel >> 5), sh = rel & 31u;
+            const bool in_win = drop_bits == 0 && wi < CN_WIN && (sh + (4u - have) <= 32u || wi + 1 < CN_WIN);
+            uint64_t w = 0;
+            if (in_win) { w = sh_win[wi]; if (wi + 1 < CN_WIN) w |= (uint64_t)sh_win[wi + 1] << 32; }
+            const uint32_t from_win = (uint32_t)(w >> sh);
+            nib = in_win ? (((have ? (uint32_t)(bb >> q) : 0u) | (from_win << have)) & 0xFu) : 0u;
+          }
         }
+        cand = leading_lanes(nib == 0xAu);       // leading 0xA nibbles
+        try_run = true;
       }
-      uint32_t cand = leading_lanes(nib == 0xAu);       // leading 0xA nibbles
+    } else if (have_top && active_ctx < 6 && val_backoff == 0) {
+      // valence mode: which symbols come next is only known once the valences along the strip are (below); the attempt is made
+      // when the next symbol is a C (a look at the list's window, nothing consumed)
+      const uint32_t left = rdlane(cntv, active_ctx);
+      if (left != 0 && ((left - 1u) & ~63u) == rdlane(wbv, active_ctx) && uni(sh_ctx[active_ctx * 64 + ((left - 1u) & 63u)]) == 0u) { cand = WAVE - 1; try_run = true; }
+    } else if (VAL && val_backoff) --val_backoff;
+    if (try_run) {
       if (2 * cand > num_symbols - sid) cand = (num_symbols - sid) / 2;
       if (cand > VMAX - num_verts) cand = VMAX - num_verts;
       if (splits_left > 0) {               // stop before the symbol that carries the next topology-split event
@@ -372,32 +458,60 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
         const uint32_t f0 = sid, nv0 = num_verts;
         const uint32_t vx0 = T1, va0 = T2;
         // vertex records of the candidate pairs in both directions at once (lane 0 holds vx0's own record in
-        // either); the direction is the step to the vertex behind vx0's left-most corner
+        // either); the direction is the step to the vertex behind vx0's left-most corner.  (Valence mode loads one record more
+        // than it can retire pairs: pair j needs the valence of the vertex it moves the gate to, which is lane j + 1's record.)
+        const uint32_t lanes_in = VAL ? cand + 1 : cand;
         const int64_t idp = (int64_t)vx0 + (int64_t)lane, idm = (int64_t)vx0 - (int64_t)lane;
-        const bool okp = lane < cand && idp < (int64_t)nv0, okm = lane < cand && idm >= 0 && idm < (int64_t)nv0;
+        const bool okp = lane < lanes_in && idp < (int64_t)nv0, okm = lane < lanes_in && idm >= 0 && idm < (int64_t)nv0;
         uint2 rp = make_uint2(DSA_INVALID, DSA_INVALID), rm = rp;
         if (okp) rp = vrec[(uint32_t)idp];
         if (okm) rm = vrec[(uint32_t)idm];
         const int32_t delta = (int32_t)rdlane(rp.y, 0) - (int32_t)vx0;
         uint32_t k = 0;
         uint2 rj = make_uint2(DSA_INVALID, DSA_INVALID);
-        uint32_t vxj = 0;
+        uint32_t vxj = 0, lmj = DSA_INVALID;
         if (delta == 1 || delta == -1) {
           const int64_t id = delta == 1 ? idp : idm;
           const bool idok = (delta == 1 ? okp : okm) && (uint32_t)id != va0;
           vxj = (uint32_t)id;
           rj = delta == 1 ? rp : rm;
+          lmj = VAL ? VAL_LM(rj.x) : rj.x;
           const uint32_t prev_nv = lane_prev(rj.y);
           // own record must be sane, and the previous pair must hand over exactly this vertex
-          bool ok = idok && rj.x < 4 * f0 && (rj.x & 3u) != 3u && rj.y < nv0 && rj.y != vxj && (lane == 0 || prev_nv == vxj);
+          bool ok = idok && lmj < 4 * f0 && (lmj & 3u) != 3u && rj.y < nv0 && rj.y != vxj && (lane == 0 || prev_nv == vxj);
           k = leading_lanes(ok);
         }
+        // ---- valence mode: are the next 2k symbols really (C R)^k?  Pair j's C comes from the list the valence of vx_j selects
+        // (after R_(j-1): its stored valence + 2; pair 0: the list in effect now), its R from the list of vb_j after C_j (stored
+        // valence + 1, lane j + 1's record).  How far into its list a symbol lies = how many earlier symbols of the run use that list.
+        uint32_t ctxC = 0, ctxR = 0;
+        if (VAL && k >= 3) {
+          const uint32_t kmax = k - 1;                     // lane k - 1's record only serves as pair k - 2's gate vertex
+          const uint32_t val_own = VAL_OF(rj.x), val_next = VAL_OF(dpp_mov<0x130>(rj.x));     // wave_shl:1 -- lane j + 1's word
+          { const uint32_t v = val_own + 2u; ctxC = lane == 0 ? active_ctx : (v < 2u ? 2u : (v > 7u ? 7u : v)) - 2u; }
+          { const uint32_t v = val_next + 1u; ctxR = (v < 2u ? 2u : (v > 7u ? 7u : v)) - 2u; }
+          const uint64_t lt = (1ull << lane) - 1ull, le = lt | (1ull << lane), in = (1ull << kmax) - 1ull;
+          uint32_t idxC = DSA_INVALID, idxR = DSA_INVALID;
+          for (uint32_t c = 0; c < 6; ++c) {
+            const uint64_t mC = __ballot(ctxC == c) & in, mR = __ballot(ctxR == c) & in;
+            if (!(mC | mR)) continue;
+            const uint32_t left = rdlane(cntv, c), o = rdlane(offv, c);
+            const uint32_t nC = (uint32_t)__popcll(mC & lt) + (uint32_t)__popcll(mR & lt), nR = (uint32_t)__popcll(mC & le) + (uint32_t)__popcll(mR & lt);
+            if (ctxC == c && nC < left) idxC = o + left - 1u - nC;
+            if (ctxR == c && nR < left) idxR = o + left - 1u - nR;
+          }
+          uint32_t idC = 9, idR = 9;
+          if (lane < kmax && idxC != DSA_INVALID) idC = ctx_syms[idxC];
+          if (lane < kmax && idxR != DSA_INVALID) idR = ctx_syms[idxR];
+          const uint32_t ks = leading_lanes(lane < kmax && idC == 0u && idR == 3u);
+          k = ks;
+        } else if (VAL) k = 0;
         if (k >= 2) {
           if (lane < k) {
             const uint32_t j = lane;
             const uint32_t fc = f0 + 2 * j, fr = fc + 1;                 // faces of C_j and R_j
             const uint32_t cc = 4 * fc, cr = 4 * fr;                     // their corner 0
-            const uint32_t vb = rj.y, cb = qnext(rj.x);
+            const uint32_t vb = rj.y, cb = qnext(lmj);
             const uint32_t va = j == 0 ? va0 : nv0 + j - 1, nvj = nv0 + j;
             // C_j: face (vx, vb, va), opposites (R_j corner 2, previous face corner 0, cb)
             { FaceIds x = {vxj, vb, va, cr + 2, cc - 4, cb}; R::store(frec, fc, x); }
@@ -405,9 +519,10 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
             { FaceIds x = {va, vb, nvj, j + 1 < k ? cr + 4 + 1 : DSA_INVALID, DSA_INVALID, cc}; R::store(frec, fr, x); }
             R::link(frec, cb, cc + 2);                                   // old boundary edge now faces C_j corner 2
             if (j == 0) R::link(frec, cc - 4, cc + 1);                   // the previous top faces C_0 corner 1
-            // vertex records after the run (the last SetLeftMostCorner of each vertex wins)
-            vrec[va] = make_uint2(cr, nvj);                              // R_j: left-most corner = R_j corner 0
-            if (j + 1 == k) vrec[nvj] = make_uint2(cr + 2, vb);          // later pairs overwrite this for j < k-1
+            // vertex records after the run (the last SetLeftMostCorner of each vertex wins).  Valence mode: va gained an edge from
+            // C_j and one from R_j on top of the 2 it was created with (pair 0: on top of what the gate vertex had)
+            vrec[va] = make_uint2(VAL ? val_pack(cr, j == 0 ? valT2 + 2u : 4u) : cr, nvj);   // R_j: left-most corner = R_j corner 0
+            if (j + 1 == k) vrec[nvj] = make_uint2(VAL ? val_pack(cr + 2, 2u) : cr + 2, vb);          // later pairs overwrite this for j < k-1
           }
           // keep the LDS copy of touched record blocks coherent: drop them (write-through makes this safe)
           {
@@ -417,6 +532,18 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
           }
           // advance the machine past 2k symbols
           const uint32_t vb_last = rdlane(rj.y, k - 1);
+          if (VAL) {
+            // the lists give up what the run used; the gate is (vb_last, the newest vertex): vb_last's record is lane k's
+            for (uint32_t c = 0; c < 6; ++c) {
+              const uint64_t in = (1ull << k) - 1ull;
+              const uint32_t used = (uint32_t)__popcll(__ballot(ctxC == c) & in) + (uint32_t)__popcll(__ballot(ctxR == c) & in);
+              if (lane == c) cntv -= used;
+            }
+            const uint32_t gx = rdlane(rj.x, k), gy = rdlane(rj.y, k);
+            valT1 = VAL_OF(gx) + 2u; lmT1 = VAL_LM(gx); nvT1 = gy;
+            valT2 = 2u; lmT2 = 4 * (f0 + 2 * (k - 1) + 1) + 2; nvT2 = vb_last;
+            active_ctx = (valT1 < 2u ? 2u : (valT1 > 7u ? 7u : valT1)) - 2u;
+          }
           T1 = vb_last; T2 = nv0 + k - 1;
           num_verts = nv0 + k;
           sid += 2 * k;
@@ -425,18 +552,41 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
           prof_run_syms += 2 * k; ++prof_runs;
 #endif
           stage_base = sid;
-          bits_used += 4ull * k;
-          {                                 // consume 4k bits: first from the buffer, the rest from the window
-            uint32_t need = 4 * k;
-            if (need <= bcnt) { bb = need >= 64 ? 0 : bb >> need; bcnt -= need; }
-            else { need -= bcnt; bb = 0; bcnt = 0; widx += need >> 5; const uint32_t rem = need & 31u; if (rem) { const uint32_t wv = uni(sh_win[widx - wbase]); bb = (uint64_t)(wv >> rem); bcnt = 32 - rem; ++widx; } }
+          if (!VAL) {
+            bits_used += 4ull * k;
+            {                                 // consume 4k bits: first from the buffer, the rest from the window
+              uint32_t need = 4 * k;
+              if (need <= bcnt) { bb = need >= 64 ? 0 : bb >> need; bcnt -= need; }
+              else { need -= bcnt; bb = 0; bcnt = 0; widx += need >> 5; const uint32_t rem = need & 31u; if (rem) { const uint32_t wv = uni(sh_win[widx - wbase]); bb = (uint64_t)(wv >> rem); bcnt = 32 - rem; ++widx; } }
+            }
           }
           __syncthreads();                   // the wave's own stores are seen by its later loads: no drain needed
           continue;
         }
+        if (VAL) val_backoff = 6;            // not a strip here: the next few symbols go one by one
       }
     }
 #endif
+    uint32_t val_b3 = 7u;
+    if (VAL) {
+      if (active_ctx < 6) {                // the next symbol of the list the gate vertex's valence selects, taken from its end (:77-98)
+        const uint32_t left = rdlane(cntv, active_ctx);
+        if (left == 0) CN_FAIL(642);
+        const uint32_t i = left - 1u;
+        if ((i & ~63u) != rdlane(wbv, active_ctx)) {          // this list's window: 64 symbols around i
+          const uint32_t o = rdlane(offv, active_ctx), at = (i & ~63u) + lane;
+          __syncthreads();
+          sh_ctx[active_ctx * 64 + lane] = at <= i ? ctx_syms[o + at] : 0u;
+          if (lane == active_ctx) wbv = i & ~63u;
+          WAIT_VM0();
+          __syncthreads();
+        }
+        const uint32_t id = uni(sh_ctx[active_ctx * 64 + (i & 63u)]);
+        if (lane == active_ctx) cntv = i;
+        if (id > 4) CN_FAIL(643);
+        val_b3 = id == 0 ? 0u : id == 1 ? 1u : id == 2 ? 3u : id == 3 ? 5u : 7u;      // C, S, L, R, E
+      }
+    } else
     if (bcnt < 3) {                       // refill the bit buffer from the LDS window
       if (widx - wbase >= CN_WIN) {
         __syncthreads();
@@ -452,7 +602,7 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
       if (bcnt < 3) continue;
     }
     // MeshEdgeBreakerTraversalDecoder.cs:89-99: 1 bit, then 2 more unless C
-    const uint32_t b3 = (uint32_t)bb & 7u;
+    const uint32_t b3 = VAL ? val_b3 : ((uint32_t)bb & 7u);
     const uint32_t face = sid, corner = 4 * face, ca = corner - 4;
     const uint32_t so = face - stage_base;       // slot of the new face in the staging block
     if ((b3 & 1u) == 0) {                 // C, :247-267
@@ -461,19 +611,33 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
       const uint32_t blk = vx >> 6, slot = blk & (CN_REC_BLOCKS - 1);
       if (TAG(slot) != blk) rec_make_resident(blk, true);
       const uint2 rr = *(const uint2 *)&sh_rec[(slot * 64 + (vx & 63u)) * 2];
-      const uint32_t lm = uni(rr.x), vb_next = uni(rr.y);
+      const uint32_t lm = VAL ? VAL_LM(uni(rr.x)) : uni(rr.x), vb_next = uni(rr.y);
       const uint32_t cb = qnext(lm);
       if (lm >= corner || (lm & 3u) == 3u || ca == cb || vx == va_prev || vx == vb_next || vb_next >= num_verts) CN_FAIL(213);
-      bb >>= 1; bcnt -= 1; bits_used += 1;
+      if (!VAL) { bb >>= 1; bcnt -= 1; bits_used += 1; }
+      uint32_t nxt_x = 0, nxt_y = 0;              // valence mode: the record of the vertex the gate moves to
+      if (VAL) {
+        // a face with a vertex twice: the reference's single valence array and the two registers here would part ways
+        if (vb_next == va_prev) { if (lane == 0) fail(D, ST_NOTIMPL, DSA_SITE_RETRY_GENERAL); failed = true; break; }
+        const uint32_t blk2 = vb_next >> 6, slot2 = blk2 & (CN_REC_BLOCKS - 1);
+        if (TAG(slot2) != blk2) rec_make_resident(blk2, true);
+        const uint2 r2 = *(const uint2 *)&sh_rec[(slot2 * 64 + (vb_next & 63u)) * 2];
+        nxt_x = uni(r2.x); nxt_y = uni(r2.y);
+      }
       const bool hit_a = REC_HIT(va_prev);
       if (lane == 0) {
         { FaceIds x = {vx, vb_next, va_prev, DSA_INVALID, ca, cb}; R::store_lds(sh_stage, so, x); }
         SET_OPP(ca, corner + 1);
         SET_OPP(cb, corner + 2);
-        REC_STORE(va_prev, hit_a, corner + 2, vb_next);   // SetLeftMostCorner(va_prev, corner + 2) + the vertex before that corner
+        REC_STORE(va_prev, hit_a, corner + 2, vb_next, valT2 + 1u);   // SetLeftMostCorner(va_prev, corner + 2) + the vertex before that corner
       }
       REC_DIRTY(va_prev, hit_a);
       T1 = vb_next;                              // face (vx, vb_next, va_prev)
+      if (VAL) {                                 // NewActiveCornerReached after C (:100-149): corners 1 and 2 gain an edge
+        valT1 = VAL_OF(nxt_x) + 1u; lmT1 = VAL_LM(nxt_x); nvT1 = nxt_y;
+        valT2 += 1u; lmT2 = corner + 2; nvT2 = vb_next;
+        active_ctx = (valT1 < 2u ? 2u : (valT1 > 7u ? 7u : valT1)) - 2u;
+      }
       n_links += 2;
       ++sid;
       PROF(acc_c, n_c);
@@ -481,9 +645,15 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
     }
     if (b3 == 1u) {                       // S, :300-343 -- rare: on global memory, lane 0
       if (!have_top) CN_FAIL(230);
-      bb >>= 3; bcnt -= 3; bits_used += 3;
+      if (!VAL) { bb >>= 3; bcnt -= 3; bits_used += 3; }
+      if (VAL && lane == 0) {               // the gate vertices' valences join the others in memory
+        const bool h1 = REC_HIT(T1), h2 = REC_HIT(T2);
+        REC_STORE(T1, h1, lmT1, nvT1, valT1);
+        REC_STORE(T2, h2, lmT2, nvT2, valT2);
+      }
       sync_all();
       uint32_t ok = 0, r_sp = sp, r_inv = num_invalid, rT1 = 0, rT2 = 0;
+      uint32_t rv1 = 0, rv2 = 0, rl1 = 0, rn1 = 0, rl2 = 0, rn2 = 0;
       if (lane == 0) {
         do {
           uint32_t cb = ca, ca2 = DSA_INVALID, sp2 = sp;
@@ -498,32 +668,44 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
           if (vn >= num_verts || vp >= num_verts || vq >= num_verts || vb_prev >= num_verts) { fail(D, ST_INVALID, 234); break; }
           R::link(frec, ca2, corner + 2); R::link(frec, cb, corner + 1);
           { FaceIds x = {vp, vq, vb_prev, DSA_INVALID, cb, ca2}; R::store(frec, face, x); }
-          vrec[vb_prev] = make_uint2(corner + 2, vq);
-          uint32_t lm_n = vrec[vn].x;
+          const uint32_t val_n = VAL ? VAL_OF(vrec[vn].x) : 0u, val_b = VAL ? VAL_OF(vrec[vb_prev].x) : 0u;
+          vrec[vb_prev] = make_uint2(VAL ? val_pack(corner + 2, val_b) : corner + 2, vq);
+          uint32_t lm_n = VAL ? VAL_LM(vrec[vn].x) : vrec[vn].x;
           uint32_t first = cn, guard = 0;
           bool bad = false;
           while (cn != DSA_INVALID) {
             R::set_v(frec, cn, vp);
             // the record of the vertex whose left-most corner follows cn caches the vertex at cn
             uint32_t w = R::get_v(frec, qnext(cn));
-            if (w < num_verts && vrec[w].x == qnext(cn)) vrec[w].y = vp;
+            if (w < num_verts && (VAL ? VAL_LM(vrec[w].x) : vrec[w].x) == qnext(cn)) vrec[w].y = vp;
             uint32_t o = R::get_o(frec, qnext(cn));          // SwingLeft
             cn = o == DSA_INVALID ? DSA_INVALID : qnext(o);
             if (cn == first || ++guard > 3 * F) { bad = true; break; }
           }
           if (bad) { fail(D, ST_INVALID, 235); break; }
           if (lm_n >= corner + 4 || (lm_n & 3u) == 3u) { fail(D, ST_INVALID, 238); break; }
-          vrec[vp] = make_uint2(lm_n, R::get_v(frec, qprev(lm_n)));
+          // (valence mode: MergeVertices :151-154, the merged-away vertex's edges become vp's)
+          vrec[vp] = make_uint2(VAL ? val_pack(lm_n, VAL_OF(vrec[vp].x) + val_n) : lm_n, R::get_v(frec, qprev(lm_n)));
           vrec[vn] = make_uint2(DSA_INVALID, DSA_INVALID);
           if (remove_invalid) { if (r_inv >= VMAX) { fail(D, ST_INVALID, 236); break; } invalid_list[r_inv++] = vn; }
           r_sp = sp2;                     // the new top replaces the pushed or the exposed entry
           rT1 = vq; rT2 = vb_prev;
+          if (VAL) {                      // the new gate: (vq, vb_prev), each one edge richer (NewActiveCornerReached after S)
+            const uint2 q1 = vrec[vq], q2 = vrec[vb_prev];
+            if (q1.x == DSA_INVALID || q2.x == DSA_INVALID || vq == vb_prev) { fail(D, ST_NOTIMPL, DSA_SITE_RETRY_GENERAL); break; }
+            rv1 = VAL_OF(q1.x) + 1u; rl1 = VAL_LM(q1.x); rn1 = q1.y;
+            rv2 = VAL_OF(q2.x) + 1u; rl2 = VAL_LM(q2.x); rn2 = q2.y;
+          }
           ok = 1;
         } while (0);
         WAIT_VM0();
       }
       if (!uni(ok)) { failed = true; break; }
       sp = uni(r_sp); num_invalid = uni(r_inv); T1 = uni(rT1); T2 = uni(rT2);
+      if (VAL) {
+        valT1 = uni(rv1); lmT1 = uni(rl1); nvT1 = uni(rn1); valT2 = uni(rv2); lmT2 = uni(rl2); nvT2 = uni(rn2);
+        active_ctx = (valT1 < 2u ? 2u : (valT1 > 7u ? 7u : valT1)) - 2u;
+      }
       n_links += 2;
       ++sid;
       stage_base = sid;                   // the new face went straight to global memory
@@ -534,7 +716,7 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
       if (!have_top || num_verts >= VMAX) CN_FAIL(220);
       const uint32_t nv = num_verts;
       if ((nv & 63u) == 0 && !REC_HIT(nv)) rec_make_resident(nv >> 6, false);
-      bb >>= 3; bcnt -= 3; bits_used += 3;
+      if (!VAL) { bb >>= 3; bcnt -= 3; bits_used += 3; }
       ++num_verts;
       const bool hit_n = REC_HIT(nv), hit_2 = REC_HIT(T2);
       n_links += 1;
@@ -542,40 +724,50 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
         if (lane == 0) {
           { FaceIds x = {T2, T1, nv, DSA_INVALID, DSA_INVALID, ca}; R::store_lds(sh_stage, so, x); }
           SET_OPP(ca, corner + 2);
-          REC_STORE(nv, hit_n, corner + 2, T1);
-          REC_STORE(T2, hit_2, corner, nv);
+          REC_STORE(nv, hit_n, corner + 2, T1, 2u);
+          REC_STORE(T2, hit_2, corner, nv, valT2 + 1u);
         }
         REC_DIRTY(nv, hit_n); REC_DIRTY(T2, hit_2);
+        if (VAL) { lmT2 = corner + 2; nvT2 = T1; valT2 = 2u; valT1 += 1u; }      // R: corner 0 (the old T2, left behind) +1, corner 1 +1, the new vertex +2
         T2 = nv;                          // face (T2, T1, nv): corner 1 keeps T1
       } else {
         if (lane == 0) {
           { FaceIds x = {T1, nv, T2, DSA_INVALID, ca, DSA_INVALID}; R::store_lds(sh_stage, so, x); }
           SET_OPP(ca, corner + 1);
-          REC_STORE(nv, hit_n, corner + 1, T1);
-          REC_STORE(T2, hit_2, corner + 2, nv);
+          REC_STORE(nv, hit_n, corner + 1, T1, 2u);
+          REC_STORE(T2, hit_2, corner + 2, nv, valT2 + 1u);
+          if (VAL) { const bool h1 = REC_HIT(T1); REC_STORE(T1, h1, lmT1, nvT1, valT1 + 1u); }   // the old T1 leaves the gate: corner 0 +1
         }
         REC_DIRTY(nv, hit_n); REC_DIRTY(T2, hit_2);
+        if (VAL) { lmT2 = corner + 2; nvT2 = nv; valT2 += 1u; lmT1 = corner + 1; nvT1 = T1; valT1 = 2u; }      // L: the new vertex (corner 1) +2, corner 2 +1
         T1 = nv;                          // face (T1, nv, T2)
       }
     } else {                              // E, :344-357
       if (num_verts + 3 > VMAX || sp >= VMAX) CN_FAIL(240);
       const uint32_t v0 = num_verts;
-      bb >>= 3; bcnt -= 3; bits_used += 3;
+      if (!VAL) { bb >>= 3; bcnt -= 3; bits_used += 3; }
       num_verts += 3;
+      if (VAL && have_top && lane == 0) {       // the gate that goes onto the stack: its vertices' valences to memory
+        const bool g1 = REC_HIT(T1), g2 = REC_HIT(T2);
+        REC_STORE(T1, g1, lmT1, nvT1, valT1);
+        REC_STORE(T2, g2, lmT2, nvT2, valT2);
+      }
       const bool h0 = REC_HIT(v0), h1 = REC_HIT(v0 + 1), h2 = REC_HIT(v0 + 2);
       if (lane == 0) {
         { FaceIds x = {v0, v0 + 1, v0 + 2, DSA_INVALID, DSA_INVALID, DSA_INVALID}; R::store_lds(sh_stage, so, x); }
-        REC_STORE(v0, h0, corner, v0 + 2);
-        REC_STORE(v0 + 1, h1, corner + 1, v0);
-        REC_STORE(v0 + 2, h2, corner + 2, v0 + 1);
+        REC_STORE(v0, h0, corner, v0 + 2, 2u);
+        REC_STORE(v0 + 1, h1, corner + 1, v0, 2u);
+        REC_STORE(v0 + 2, h2, corner + 2, v0 + 1, 2u);
         if (have_top) stack_mem[sp] = ca;
       }
+      if (VAL) { lmT1 = corner + 1; nvT1 = v0; valT1 = 2u; lmT2 = corner + 2; nvT2 = v0 + 1; valT2 = 2u; }      // E: every corner +2
       REC_DIRTY(v0, h0); REC_DIRTY(v0 + 1, h1); REC_DIRTY(v0 + 2, h2);
       if (have_top) ++sp;
       have_top = true;
       T1 = v0 + 1; T2 = v0 + 2;
     }
     ++sid;
+    if (VAL) active_ctx = (valT1 < 2u ? 2u : (valT1 > 7u ? 7u : valT1)) - 2u;
     PROF(acc_rl, n_rl);
     if (splits_left > 0) {                // :363-375 (sid already advanced: the symbol just decoded is sid-1)
       const uint32_t enc_id = num_symbols - sid;
@@ -603,7 +795,7 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
     }
   }
   if (failed) return;
-  if (bits_used > bit_end) { if (lane == 0) fail(D, ST_INVALID, 246); return; }   // symbols ran past their section
+  if (!VAL && bits_used > bit_end) { if (lane == 0) fail(D, ST_INVALID, 246); return; }   // symbols ran past their section
   sync_all();
   const uint64_t t_loop = clk();
 
@@ -627,11 +819,13 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
         if (num_faces >= F || corner >= 4 * num_faces) { fail(D, ST_INVALID, 251); bad = true; break; }
         uint32_t ca = corner;
         uint32_t vn = R::get_v(frec, qnext(ca));
-        if (vn >= num_verts || vrec[vn].x >= 4 * num_faces) { fail(D, ST_INVALID, 252); bad = true; break; }
-        uint32_t cb = qnext(vrec[vn].x);
+        const uint32_t lm_vn = VAL ? VAL_LM(vrec[vn < num_verts ? vn : 0].x) : vrec[vn < num_verts ? vn : 0].x;
+        if (vn >= num_verts || lm_vn >= 4 * num_faces) { fail(D, ST_INVALID, 252); bad = true; break; }
+        uint32_t cb = qnext(lm_vn);
         uint32_t vx = R::get_v(frec, qnext(cb));
-        if (vx >= num_verts || vrec[vx].x >= 4 * num_faces) { fail(D, ST_INVALID, 253); bad = true; break; }
-        uint32_t cc = qnext(vrec[vx].x);
+        const uint32_t lm_vx = VAL ? VAL_LM(vrec[vx < num_verts ? vx : 0].x) : vrec[vx < num_verts ? vx : 0].x;
+        if (vx >= num_verts || lm_vx >= 4 * num_faces) { fail(D, ST_INVALID, 253); bad = true; break; }
+        uint32_t cc = qnext(lm_vx);
         if (ca == cb || ca == cc || cb == cc) { fail(D, ST_INVALID, 254); bad = true; break; }
         if (R::get_o(frec, ca) != DSA_INVALID || R::get_o(frec, cb) != DSA_INVALID || R::get_o(frec, cc) != DSA_INVALID) { fail(D, ST_INVALID, 255); bad = true; break; }
         uint32_t vp = R::get_v(frec, qnext(cc));
@@ -652,7 +846,7 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
         while (vrec[src].x == DSA_INVALID) { if (nvert <= 1) { bad = true; break; } src = --nvert - 1; }
         if (bad) { fail(D, ST_INVALID, 258); break; }
         if (src < inv) continue;
-        uint32_t start = vrec[src].x, c = start, guard = 0;
+        uint32_t start = VAL ? VAL_LM(vrec[src].x) : vrec[src].x, c = start, guard = 0;
         bool left = true;
         while (c != DSA_INVALID) {   // VertexCornersIterator (D-10: starts at the left-most corner itself)
           if (c >= 4 * F || (c & 3u) == 3u || R::get_v(frec, c) != src || ++guard > 3 * F) { fail(D, ST_INVALID, 259); bad = true; break; }
@@ -712,7 +906,7 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
     for (uint32_t v0 = 0; v0 < NVALL; v0 += 4 * WAVE) {
       uint32_t lm[4], oo[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const uint32_t v = v0 + u * WAVE + lane; lm[u] = v < NVALL ? vrec[v].x : DSA_INVALID; }
+      for (int u = 0; u < 4; ++u) { const uint32_t v = v0 + u * WAVE + lane; lm[u] = v < NVALL ? vrec[v].x : DSA_INVALID; if (VAL) lm[u] = VAL_LM(lm[u]); }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const bool ok = lm[u] != DSA_INVALID && lm[u] < 4 * F && (lm[u] & 3u) != 3u;
@@ -741,14 +935,18 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
 #undef REC_DIRTY
 #undef SET_OPP
 }
+#undef VAL_LM
+#undef VAL_OF
 
 __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   __shared__ __attribute__((aligned(16))) uint32_t sh[CN_LDS_WORDS];
   __builtin_amdgcn_s_setprio(3);   // critical path: issue ahead of the entropy-decode waves sharing the CU
   const uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
-  if (layouts[mesh].rec_compact) connectivity_wave<true>(arena, layouts[mesh], &descs[mesh], sh, sh + CN_STAGE * 8, sh + CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2);
-  else connectivity_wave<false>(arena, layouts[mesh], &descs[mesh], sh, sh + CN_STAGE * 8, sh + CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2);
+  uint32_t *sh_rec = sh + CN_STAGE * 8, *sh_win = sh_rec + CN_REC_BLOCKS * 64 * 2, *sh_ctx = sh_win + CN_WIN;
+  if (!layouts[mesh].rec_compact) connectivity_wave<false, false>(arena, layouts[mesh], &descs[mesh], sh, sh_rec, sh_win, sh_ctx);
+  else if (descs[mesh].traversal_type == 2) connectivity_wave<true, true>(arena, layouts[mesh], &descs[mesh], sh, sh_rec, sh_win, sh_ctx);
+  else connectivity_wave<true, false>(arena, layouts[mesh], &descs[mesh], sh, sh_rec, sh_win, sh_ctx);
 }
 
 // =========================================================================
@@ -1507,8 +1705,10 @@ __global__ __launch_bounds__(WAVE, 8) void k_chain(uint8_t *arena, const MeshLay
   const MeshLayout &L = layouts[mesh];
   MeshDesc *D = &descs[mesh];
   const bool compact = uni(L.rec_compact) != 0;
-  if (compact) connectivity_wave<true>(arena, L, D, sh, sh + CN_STAGE * 8, sh + CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2);
-  else connectivity_wave<false>(arena, L, D, sh, sh + CN_STAGE * 8, sh + CN_STAGE * 8 + CN_REC_BLOCKS * 64 * 2);
+  uint32_t *sh_rec = sh + CN_STAGE * 8, *sh_win = sh_rec + CN_REC_BLOCKS * 64 * 2, *sh_ctx = sh_win + CN_WIN;
+  if (!compact) connectivity_wave<false, false>(arena, L, D, sh, sh_rec, sh_win, sh_ctx);
+  else if (uni((uint32_t)D->traversal_type) == 2u) connectivity_wave<true, true>(arena, L, D, sh, sh_rec, sh_win, sh_ctx);
+  else connectivity_wave<true, false>(arena, L, D, sh, sh_rec, sh_win, sh_ctx);
   // the traversal reads what this wave (all lanes) just wrote: records, ranks, flags
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
   __syncthreads();

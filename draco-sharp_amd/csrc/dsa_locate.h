@@ -281,7 +281,7 @@ __device__ inline void locate_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc
     if (D->encoder_method == 0) NOTIMPL(108);                 // sequential mesh
     D->traversal_type = (uint8_t)r.u8();
     REQUIRE(r.ok && D->traversal_type <= 2, 109);
-    if (D->traversal_type != 0) NOTIMPL(110);                 // valence / predictive traversal
+    if (D->traversal_type == 1) NOTIMPL(110);                 // predictive traversal: general path (the host parse routes it there)
     // MeshEdgeBreakerDecoder.cs:35-56
     uint64_t nv = r.varint(), nf = r.varint();
     REQUIRE(r.ok && nf <= 0x7FFFFFFFu / 3 && nv <= nf * 3, 111);
@@ -305,12 +305,15 @@ __device__ inline void locate_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc
     D->off_split_bits = r.pos;
     r.skip((nsplits + 7) >> 3);
     REQUIRE(r.ok, 118);
-    // traversal sections, MeshEdgeBreakerTraversalDecoder.cs:27-61 (symbol section is `size` bytes, D-3)
-    uint64_t sym_size = r.varint();
-    D->off_symbols = r.pos;
-    r.skip(sym_size);
-    REQUIRE(r.ok, 119);
-    D->size_symbols = (uint32_t)sym_size;
+    // traversal sections, MeshEdgeBreakerTraversalDecoder.cs:27-61 (symbol section is `size` bytes, D-3); valence traversal has
+    // no explicit symbol section (MeshEdgeBreakerTraversalValenceDecoder.cs:22-35)
+    if (D->traversal_type == 0) {
+      uint64_t sym_size = r.varint();
+      D->off_symbols = r.pos;
+      r.skip(sym_size);
+      REQUIRE(r.ok, 119);
+      D->size_symbols = (uint32_t)sym_size;
+    }
     D->off_start_faces = r.pos;
     { (void)r.u8(); uint64_t sz = r.varint(); r.skip(sz); REQUIRE(r.ok && sz >= 1, 120); }
     for (uint32_t i = 0; i < nad; ++i) {
@@ -319,6 +322,37 @@ __device__ inline void locate_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc
       uint64_t sz = r.varint();
       r.skip(sz);
       REQUIRE(r.ok && sz >= 1, 121);
+    }
+    if (D->traversal_type == 2) {
+      // the six context lists, :36-69: count, then a DecodeSymbols block of one component.  The connectivity wave decodes raw
+      // streams over small alphabets itself; anything else (tagged scheme, an alphabet no encoder writes) goes to the general path
+      if (!L.rec_compact) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+      uint64_t total = 0;
+      for (int c = 0; c < 6; ++c) {
+        const uint64_t num = r.varint();
+        REQUIRE(r.ok && num <= nf && total + num <= nf, 641);
+        D->val_count[c] = (uint32_t)num;
+        total += num;
+        if (num == 0) continue;
+        const uint32_t scheme = r.u8();
+        REQUIRE(r.ok && scheme <= 1, 146);
+        if (scheme != 1) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+        const uint32_t mbl = r.u8();
+        REQUIRE(r.ok && mbl >= 1 && mbl <= 18, 147);
+        D->val_prec[c] = (uint8_t)rans_precision_bits(mbl);
+        const uint64_t ns = r.varint();
+        REQUIRE(r.ok && ns >= 1 && ns <= (1u << 20), 148);
+        if (ns > 64) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+        D->val_nsym[c] = (uint32_t)ns;
+        D->val_off_table[c] = r.pos;
+        uint32_t distinct = 0;
+        REQUIRE(skip_prob_table(r, (uint32_t)ns, &distinct), 149);
+        const uint64_t size = r.varint();
+        D->val_off_rans[c] = r.pos;
+        r.skip(size);
+        REQUIRE(r.ok && size >= 1, 150);
+        D->val_size_rans[c] = (uint32_t)size;
+      }
     }
   }
   D->off_attributes = r.pos;

@@ -81,6 +81,11 @@ struct MeshDesc {
   uint32_t gen_dec_entries[DSA_MAX_ATT];   // general path: entries of every attributes decoder (phase 3 sequence -> maps -> values)
   uint32_t interior_corners;   // 2 x opposite links made by k_connectivity; one seam bit per link and attribute data
   uint32_t linked_corners;     // corners that hold an opposite, counted by k_point_maps (k_seal compares the two)
+  // valence traversal (traversal_type 2, MeshEdgeBreakerTraversalValenceDecoder.cs:22-69) on the fast kernels: the six symbol lists,
+  // one per valence class of the vertex the decoder stands on -- raw rANS streams over at most 64 symbols each
+  uint32_t val_count[6], val_nsym[6], val_off_table[6], val_off_rans[6], val_size_rans[6];
+  uint8_t val_prec[6];
+  uint8_t pad_val[2];
   uint32_t dbg[20];        // diagnostics of the per-mesh kernels (tools/dbg_phases.py, bench.py): s_memtime deltas between phases;
                            // k_connectivity: [13] its s_memtime ticks, [14] its start and [15] its duration in s_memrealtime ticks
                            // (100 MHz); k_traverse: [6] ticks, [16] start, [17] duration: ticks / duration = the shader clock
