@@ -87,7 +87,7 @@ def encode_leg(dsa, synth, ctx, nx, ny, count, comm=None, barrier=None, world=1)
         pos, nrm, uv, faces = distinct[i % len(distinct)]
         meshes.append(dsa.MeshData(pos, faces, nrm, uv))
     enc = dsa.DracoEncoder(ctx)
-    enc.EncodeBatch(meshes[:2])
+    enc.EncodeBatch(meshes)                  # untimed: the encoder's lanes pin their staging buffers and size their device memory once
     if barrier is not None:
         barrier()
     t0 = time.perf_counter()
@@ -217,6 +217,7 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-pool", action="store_true")
     ap.add_argument("--e2e-batches", type=int, default=6)
+    ap.add_argument("--encode-meshes", type=int, default=4096, help="meshes per GPU of the encode leg (BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true")
     ap.add_argument("--check", type=int, default=64, help="meshes of the rank-0 batch compared with the oracle after the timed region")
@@ -385,7 +386,7 @@ def main():
         batch.close()
     encode = None
     if not args.no_encode:                                           # every rank: the leg's clock is the slowest rank's
-        encode = encode_leg(dsa, synth, ctx, nx, ny, 1024, comm if world > 1 else None, barrier if world > 1 else None, world)
+        encode = encode_leg(dsa, synth, ctx, nx, ny, args.encode_meshes, comm if world > 1 else None, barrier if world > 1 else None, world)
     e2e = None
     if not args.no_end_to_end and weak_blob is not None:             # every rank its own batches: the clock is the slowest rank's
         e2e = end_to_end_leg(dsa, ctx, weak_blob, weak_offsets, args.e2e_batches, 2, comm if world > 1 else None, barrier if world > 1 else None, world)

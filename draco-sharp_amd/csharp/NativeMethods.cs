@@ -24,7 +24,7 @@ internal struct DsaMeshInfo
     public int Detail;
     public byte MajorVersion, MinorVersion, EncoderType, EncoderMethod;
     public ushort Flags;
-    public ushort Reserved;
+    public ushort DecodePath;   // 0 wave-per-mesh kernels, 1 general path, 2 general path at the second attempt
     public uint NumFaces;
     public uint NumPoints;
     public uint NumAttributes;

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -26,6 +27,32 @@ static const char *kStageNames[DSA_NUM_STAGES] = {"locate", "connectivity", "tra
 
 
 }  // namespace
+
+// One lane of the encode pipeline (dsa_encode.h): a stream of its own and two pinned staging buffers, so that several chunks of a
+// batch are in flight at once -- the uploads of one beside the kernels of another beside the stream layout of a third.
+struct EncLane {
+  int device = 0;
+  hipStream_t st = nullptr;
+  hostutil::Staging stage[2];
+  int next = 0;
+  // device memory of the lane, grown on demand and kept: hipMalloc / hipFree wait for every stream of the device, which would
+  // put the chunks of a batch back in single file
+  struct Buf {
+    void *p = nullptr; uint64_t cap = 0;
+    hipError_t ensure(uint64_t bytes) {
+      if (bytes <= cap) return hipSuccess;
+      if (p) (void)hipFree(p);
+      p = nullptr; cap = 0;
+      const uint64_t want = bytes + bytes / 4;
+      hipError_t e = hipMalloc(&p, want);
+      if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; e = hipMalloc(&p, bytes); if (e == hipSuccess) cap = bytes; else p = nullptr; return e; }
+      cap = want;
+      return hipSuccess;
+    }
+    ~Buf() { if (p) (void)hipFree(p); }
+  } arena, streams, conns, packed, items;
+  ~EncLane() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }
+};
 
 struct dsa_context {
   int device = 0;
@@ -52,6 +79,7 @@ struct dsa_context {
   // batches point at their context: a context destroyed first lives on until its last batch is freed
   int live_batches = 0;
   bool doomed = false;
+  std::vector<std::unique_ptr<EncLane>> enc_lanes;    // kept between dsa_encode_batch calls (pinning their staging costs more than a small batch)
 };
 
 struct dsa_batch {
@@ -726,6 +754,7 @@ dsa_status dsa_batch_mesh_info(const dsa_batch *b, uint32_t mesh, dsa_mesh_info 
   out->major_version = D.major; out->minor_version = D.minor; out->encoder_type = D.encoder_type; out->encoder_method = D.encoder_method;
   out->flags = D.flags;
   out->drc_bytes = b->layouts[mesh].stream_len;
+  out->decode_path = D.general ? (b->all_general ? 2 : 1) : 0;
   if (D.status == ST_OK) { out->num_faces = D.num_faces; out->num_points = D.num_points; out->num_attributes = D.num_attributes; }
   return DSA_OK;
 }

@@ -349,13 +349,63 @@ void dsa_encode_default_options(dsa_encode_options *o) {
   o->position_prediction = d.pos_prediction; o->texcoord_prediction = d.uv_prediction;
 }
 
+static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out);
 static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out);
 dsa_status dsa_encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out) {
   if (!ctx || !out || (n && !meshes)) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "null argument");
   DSA_GUARD(ctx, encode_batch(ctx, n, meshes, options, out));     // host vectors and threads inside: nothing may unwind into the caller
 }
+// A batch is coded in chunks, several of them in flight (each on a lane of its own: stream + pinned staging): the device stages of a
+// chunk are serial per mesh and take 0.15 - 0.35 s whatever its size, which leaves the machine nearly empty -- other chunks' kernels
+// fill it, their uploads and the host's stream layout run beside.  Small batches are one chunk.
 static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint32_t chunk = n <= 512 ? (n ? n : 1) : 512;
+  const uint32_t chunks = (n + chunk - 1) / chunk, lanes = std::max(1u, std::min(chunks, 6u));
+  while (ctx->enc_lanes.size() < lanes) {
+    std::unique_ptr<EncLane> l(new EncLane());
+    l->device = ctx->device;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&l->st, hipStreamNonBlocking));
+    ctx->enc_lanes.push_back(std::move(l));
+  }
+  std::unique_ptr<dsa_encoded> E(new dsa_encoded());
+  E->ctx = ctx;
+  E->streams.resize(n); E->status.assign(n, DSA_OK); E->messages.resize(n);
+  std::atomic<uint32_t> next{0};
+  std::atomic<int> failed{DSA_OK};
+  std::vector<std::string> errs(lanes);
+  auto work = [&](uint32_t l) noexcept {
+    try {
+      dsa_context sink;                              // receives this lane's error text (set_err writes ctx->err: not from several threads)
+      sink.device = ctx->device;
+      if (hipSetDevice(ctx->device) != hipSuccess) { int ok = DSA_OK; failed.compare_exchange_strong(ok, DSA_ERR_DEVICE); return; }
+      for (;;) {
+        const uint32_t c = next.fetch_add(1, std::memory_order_relaxed);
+        if (c >= chunks || failed.load(std::memory_order_relaxed) != DSA_OK) break;
+        const uint32_t base = c * chunk, cnt = std::min(chunk, n - base);
+        dsa_encoded *part = nullptr;
+        const dsa_status st = encode_chunk(&sink, *ctx->enc_lanes[l], cnt, meshes + base, options, &part);
+        if (st != DSA_OK) { errs[l] = sink.err; int ok = DSA_OK; failed.compare_exchange_strong(ok, st); break; }
+        std::unique_ptr<dsa_encoded> owner(part);
+        for (uint32_t i = 0; i < cnt; ++i) { E->streams[base + i].swap(part->streams[i]); E->status[base + i] = part->status[i]; E->messages[base + i].swap(part->messages[i]); }
+      }
+    } catch (const std::bad_alloc &) { int ok = DSA_OK; failed.compare_exchange_strong(ok, DSA_ERR_OUT_OF_MEMORY); }
+    catch (...) { int ok = DSA_OK; failed.compare_exchange_strong(ok, DSA_ERR_DEVICE); }
+  };
+  {
+    struct Joiner { std::vector<std::thread> t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner;
+    try { joiner.t.reserve(lanes); for (uint32_t l = 1; l < lanes; ++l) joiner.t.emplace_back(work, l); } catch (...) {}
+    work(0);
+  }
+  if (failed.load() != DSA_OK) {
+    for (const std::string &e : errs) if (!e.empty()) return set_err(ctx, (dsa_status)failed.load(), "%s", e.c_str());
+    return set_err(ctx, (dsa_status)failed.load(), "encoding failed");
+  }
+  *out = E.release();
+  return DSA_OK;
+}
+static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out) {
+  HIP_TRY(ctx, hipSetDevice(lane.device));
   dsa_encode_options od;
   dsa_encode_default_options(&od);
   if (options) od = *options;
@@ -483,8 +533,7 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
   uint8_t *arena = nullptr;
   dsa::EncStream *d_streams = nullptr;
   dsa::EncConn *d_conns = nullptr;
-  auto cleanup = [&]() { if (arena) (void)hipFree(arena); if (d_streams) (void)hipFree(d_streams); if (d_conns) (void)hipFree(d_conns); arena = nullptr; d_streams = nullptr; d_conns = nullptr; };
-  struct AtExit { decltype(cleanup) &f; ~AtExit() { f(); } } at_exit{cleanup};     // also when a host allocation throws in between
+  auto cleanup = [&]() {};      // the lane owns its device memory (EncLane::Buf): nothing to release per chunk
 #define ENC_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { return set_err(ctx, e_ == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
   // pieces of the arena -> one host buffer (items[k].packed_off filled in); host buffer -> pieces of the arena
   auto gather = [&](std::vector<dsa::PackItem> &items, std::vector<uint8_t> &host) -> dsa_status {
@@ -493,39 +542,38 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     host.resize(total);
     if (items.empty() || total == 0) return DSA_OK;
     uint8_t *d_packed = nullptr; dsa::PackItem *d_items = nullptr;
-    hipError_t e = hipMalloc((void **)&d_packed, total);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_items, sizeof(dsa::PackItem) * items.size());
-    if (e == hipSuccess) e = hipMemcpyAsync(d_items, items.data(), sizeof(dsa::PackItem) * items.size(), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) { hipLaunchKernelGGL(dsa::k_enc_pack, dim3((uint32_t)items.size()), dim3(256), 0, ctx->stream, arena, d_packed, d_items, (uint32_t)items.size()); e = hipGetLastError(); }
+    hipError_t e = lane.packed.ensure(total);
+    if (e == hipSuccess) e = lane.items.ensure(sizeof(dsa::PackItem) * items.size());
+    d_packed = (uint8_t *)lane.packed.p; d_items = (dsa::PackItem *)lane.items.p;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_items, items.data(), sizeof(dsa::PackItem) * items.size(), hipMemcpyHostToDevice, lane.st);
+    if (e == hipSuccess) { hipLaunchKernelGGL(dsa::k_enc_pack, dim3((uint32_t)items.size()), dim3(256), 0, lane.st, arena, d_packed, d_items, (uint32_t)items.size()); e = hipGetLastError(); }
     // through pinned staging (a pageable destination is staged by the runtime at a fraction of the link's rate)
-    hostutil::Staging &stg = ctx->stage[ctx->stage_next];
-    ctx->stage_next ^= 1;
+    hostutil::Staging &stg = lane.stage[lane.next];
+    lane.next ^= 1;
     if (e == hipSuccess) e = stg.acquire((size_t)total);
-    if (e == hipSuccess) e = hipMemcpyAsync(stg.buf.p, d_packed, total, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(stg.buf.p, d_packed, total, hipMemcpyDeviceToHost, lane.st);
+    if (e == hipSuccess) e = hipStreamSynchronize(lane.st);
     if (e == hipSuccess) hostutil::parallel_memcpy(host.data(), stg.buf.p, (size_t)total);
-    if (d_packed) (void)hipFree(d_packed);
-    if (d_items) (void)hipFree(d_items);
     return e == hipSuccess ? DSA_OK : (e == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE);
   };
   auto scatter = [&](std::vector<dsa::PackItem> &items, const std::vector<uint8_t> &host) -> dsa_status {
     if (items.empty() || host.empty()) return DSA_OK;
     uint8_t *d_packed = nullptr; dsa::PackItem *d_items = nullptr;
-    hipError_t e = hipMalloc((void **)&d_packed, host.size());
-    if (e == hipSuccess) e = hipMalloc((void **)&d_items, sizeof(dsa::PackItem) * items.size());
-    if (e == hipSuccess) e = hipMemcpyAsync(d_items, items.data(), sizeof(dsa::PackItem) * items.size(), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_packed, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) { hipLaunchKernelGGL(dsa::k_enc_unpack, dim3((uint32_t)items.size()), dim3(256), 0, ctx->stream, arena, d_packed, d_items, (uint32_t)items.size()); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (d_packed) (void)hipFree(d_packed);
-    if (d_items) (void)hipFree(d_items);
+    hipError_t e = lane.packed.ensure(host.size());
+    if (e == hipSuccess) e = lane.items.ensure(sizeof(dsa::PackItem) * items.size());
+    d_packed = (uint8_t *)lane.packed.p; d_items = (dsa::PackItem *)lane.items.p;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_items, items.data(), sizeof(dsa::PackItem) * items.size(), hipMemcpyHostToDevice, lane.st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_packed, host.data(), host.size(), hipMemcpyHostToDevice, lane.st);
+    if (e == hipSuccess) { hipLaunchKernelGGL(dsa::k_enc_unpack, dim3((uint32_t)items.size()), dim3(256), 0, lane.st, arena, d_packed, d_items, (uint32_t)items.size()); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(lane.st);
     return e == hipSuccess ? DSA_OK : (e == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE);
   };
 #define ENC_ST(call) do { dsa_status s_ = (call); if (s_ != DSA_OK) { return set_err(ctx, s_, "%s failed", #call); } } while (0)
   if (ns) {
-    hipStream_t st = ctx->stream;
-    ENC_TRY(hipMalloc((void **)&arena, cur ? cur : 256));
-    ENC_TRY(hipMalloc((void **)&d_streams, sizeof(dsa::EncStream) * ns));
+    hipStream_t st = lane.st;
+    ENC_TRY(lane.arena.ensure(cur ? cur : 256));
+    ENC_TRY(lane.streams.ensure(sizeof(dsa::EncStream) * ns));
+    arena = (uint8_t *)lane.arena.p; d_streams = (dsa::EncStream *)lane.streams.p;
     ENC_TRY(hipMemsetAsync(arena, 0, cur, st));              // histograms start at zero
     // uploads in chunks through the context's two pinned staging buffers: host threads fill one while the DMA engine drains the
     // other (a pageable source would be staged by the runtime, one thread, a few GB/s)
@@ -537,8 +585,8 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
         size_t i1 = i0 + 1;
         while (i1 < uploads.size() && uploads[i1].off + uploads[i1].bytes - lo <= chunk_cap) ++i1;
         const uint64_t hi = uploads[i1 - 1].off + uploads[i1 - 1].bytes;
-        hostutil::Staging &stg = ctx->stage[ctx->stage_next];
-        ctx->stage_next ^= 1;
+        hostutil::Staging &stg = lane.stage[lane.next];
+        lane.next ^= 1;
         ENC_TRY(stg.acquire((size_t)(hi - lo)));
         uint8_t *h = stg.buf.p;
         hostutil::parallel_for((uint32_t)(i1 - i0), [&](uint32_t k) { const Upload &u = uploads[i0 + k]; memcpy(h + (u.off - lo), u.src, u.bytes); }, 2);
@@ -555,7 +603,8 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     // ---- device phase 0: corner table, Edgebreaker symbols, attribute order, operand entries (one wave per mesh); meshes that
     // failed the host's checks have F = 0 and no arrays
     if (!host_conn) {
-      ENC_TRY(hipMalloc((void **)&d_conns, sizeof(dsa::EncConn) * n));
+      ENC_TRY(lane.conns.ensure(sizeof(dsa::EncConn) * n));
+      d_conns = (dsa::EncConn *)lane.conns.p;
       for (uint32_t i = 0; i < n; ++i) if (E->status[i] != DSA_OK) { memset(&hc[i], 0, sizeof(hc[i])); hc[i].status = dsa::ENC_ISOLATED; }
       ENC_TRY(hipMemcpyAsync(d_conns, hc.data(), sizeof(dsa::EncConn) * n, hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(dsa::k_enc_connectivity, dim3(n), dim3(WAVE), 0, st, arena, d_conns, n);
@@ -670,7 +719,7 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
   // ---- device phase 2: entropy coding
   std::vector<std::vector<uint8_t>> rans(ns), bits(ns);
   if (ns) {
-    hipStream_t st = ctx->stream;
+    hipStream_t st = lane.st;
     if (host_plan) {
       ENC_TRY(hipMemcpyAsync(d_streams, hs.data(), sizeof(dsa::EncStream) * ns, hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(dsa::k_enc_rans, dim3((ns + WAVE - 1) / WAVE), dim3(WAVE), 0, st, arena, d_streams, ns);

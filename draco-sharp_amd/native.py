@@ -38,7 +38,7 @@ class MeshInput(C.Structure):
 
 class MeshInfo(C.Structure):
     _fields_ = [("status", C.c_int32), ("detail", C.c_int32), ("major_version", C.c_uint8), ("minor_version", C.c_uint8),
-                ("encoder_type", C.c_uint8), ("encoder_method", C.c_uint8), ("flags", C.c_uint16), ("reserved", C.c_uint16),
+                ("encoder_type", C.c_uint8), ("encoder_method", C.c_uint8), ("flags", C.c_uint16), ("decode_path", C.c_uint16),
                 ("num_faces", C.c_uint32), ("num_points", C.c_uint32), ("num_attributes", C.c_uint32),
                 ("drc_bytes", C.c_uint64)]
 

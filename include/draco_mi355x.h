@@ -55,7 +55,9 @@ typedef struct dsa_mesh_info {
                               * 6xx general path (valence, seams, corner attributes, sequential meshes) */
   uint8_t major_version, minor_version, encoder_type, encoder_method;
   uint16_t flags;
-  uint16_t reserved;
+  uint16_t decode_path;      /* which kernels decoded the stream: 0 the wave-per-mesh kernels, 1 the general path (predictive traversal,
+                              * attribute seams, corner attributes, sequential meshes, the schemes of INTEGRATION.md section 5),
+                              * 2 the general path at the second attempt (what the fast kernels found behind the symbol streams) */
   uint32_t num_faces;
   uint32_t num_points;
   uint32_t num_attributes;

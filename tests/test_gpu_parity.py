@@ -441,7 +441,7 @@ def test_prediction_degree_traversal(ctx):
         assert b.status(i) == 0, (i, b.status(i), b.mesh_info(i).detail)
         ref = oracle.decode(sbytes)
         assert ref.decoders[0]["traversal_method"] == (1 if i % 3 else 0)
-        assert ref.traversal_type == (1, 0, 2, 2, 1, 1, 2)[i]    # predictive / valence Edgebreaker symbols: general path as well
+        assert ref.traversal_type == (1, 0, 2, 2, 1, 1, 2)[i]    # predictive Edgebreaker symbols: general path as well (valence ones: with the prediction-degree order)
         assert_same(b.result(i), ref, b, i)
     b.close()
 
@@ -643,4 +643,34 @@ def test_trailing_zero_frequencies_at_16_bit_precision(ctx):
     for i, data in enumerate(cases):
         assert b.status(i) == 0, b.mesh_info(i).detail
         assert_same(b.result(i), oracle.decode(data), b, i)
+    b.close()
+
+
+def test_valence_streams_take_the_fast_kernels(ctx):
+    """Valence-coded Edgebreaker symbols (MeshEdgeBreakerTraversalValenceDecoder.cs:22-154, what stock encoders write for meshes
+    of a thousand faces and more) on the wave-per-mesh kernels: the six context lists decoded by the connectivity wave, strip
+    runs checked against them.  Every topology -- handles (topology splits), holes, several components --, both connectivity
+    layouts, and a 64k-triangle mesh; connectivity, order and values against the oracle."""
+    cases = []
+    for k, (kind, nx, ny) in enumerate(KINDS):
+        for single in (0, 1):
+            pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 30 + k)
+            cases.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(predictive_connectivity=2, single_connectivity=single)))
+    pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 128, 256, 77)
+    cases.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(predictive_connectivity=2)))
+    pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 128, 256, 78)
+    cases.append(synth.encode_mesh(pos, faces, None, None, opt=synth.options(predictive_connectivity=2, pos_bits=14)))
+    b = run_batch(ctx, cases)
+    fast = 0
+    for i, data in enumerate(cases):
+        ref = oracle.decode(data)
+        assert ref.traversal_type == 2
+        info = b.mesh_info(i)
+        assert info.status == 0, (i, info.detail)
+        # (a list the encoder wrote with the tagged scheme -- it does for the few symbols of a tiny mesh -- sends the mesh to the
+        # general path at the second attempt; a mesh of the size stock encoders use valence symbols for must not go there)
+        assert info.decode_path == 0 or (ref.num_faces < 1000 and info.decode_path == 2), "valence stream %d (%d faces) was sent to the general path" % (i, ref.num_faces)
+        fast += info.decode_path == 0
+        assert_same(b.result(i), ref, b, i)
+    assert fast >= 6
     b.close()
