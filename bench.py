@@ -7,10 +7,14 @@ independent, so there is no data-path collective: torch.distributed (RCCL) carri
 barrier and the MAX / SUM of the timing.  Two partitions of the work are measured:
 
   weak    every rank decodes its own batch of --meshes streams (seeds 1000 + rank * meshes ...): BASELINE.json
-          configs[2] per GPU.  This is the line's `value` and `"scaling": "weak"`.
+          configs[2] per GPU.  With one GPU this is the line's `value`.
   strong  BASELINE.json configs[3]: the SAME --meshes streams (seeds 1000 ...) split over the N ranks by
-          sharding.balanced_assignment (longest compressed stream first); reported next to it as "strong_scaling".
-          `--scaling strong` makes it the line's `value` instead (and skips the weak leg).
+          sharding.balanced_assignment (longest compressed stream first).  With several GPUs THIS is the line's `value`
+          ("scaling": "strong"; the weak leg is reported beside it as "weak_scaling").  `--scaling weak|strong|both` override.
+
+Beside the line's value: `end_to_end` (host .drc bytes -> host arrays: pinned staging, one upload and one download per batch,
+two batches in flight), `pool` (the in-library work queue over all GPUs of the job, from rank 0), `encode` (configs[4]),
+`cpu_baseline` (the oracle on the host cores), `oracle_check` (decoded meshes against the oracle, after the timed region).
 
 The timed region of each leg is bracketed by a barrier + synchronize, the MAX over ranks is reported.  Rank 0 prints
 one JSON line.
@@ -70,7 +74,10 @@ def measured_traffic(kernel, meshes, triangles):
         with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             t = json.load(f)
         if t["meshes_per_gpu"] == meshes and t["triangles_per_mesh"] == triangles and kernel in t["kernels"]:
-            return t["kernels"][kernel]["hbm_bytes"], TRAFFIC_FILE, t.get("total_hbm_bytes")
+            k = t["kernels"][kernel]
+            # every launch of the kernel in one decode (the symbol kernels are launched twice: early and late attributes), to go
+            # with a duration that spans them
+            return k["hbm_bytes"] * k.get("launches_per_decode", 1.0), TRAFFIC_FILE, t.get("total_hbm_bytes")
     except (OSError, KeyError, ValueError):
         pass
     return None, None, None

@@ -50,6 +50,16 @@ internal unsafe struct DsaAttributeInfo
 }
 
 [StructLayout(LayoutKind.Sequential)]
+internal unsafe struct DsaMeshOutput       // byte offsets of a mesh's arrays inside the batch's output block (dsa_batch_download)
+{
+    public uint Block;        // 0: the batch's block, 1: the block of the meshes decoded a second time (general path)
+    public uint Reserved;
+    public ulong Faces;
+    public fixed ulong Values[16];
+    public fixed ulong PointMap[16];
+}
+
+[StructLayout(LayoutKind.Sequential)]
 internal struct DsaEncodeOptions
 {
     public int PositionBits, TexcoordBits, NormalBits;
@@ -95,6 +105,15 @@ internal static unsafe partial class NativeMethods
     [DllImport(Lib)] internal static extern IntPtr dsa_batch_device_faces(IntPtr batch, uint mesh);
     [DllImport(Lib)] internal static extern IntPtr dsa_batch_device_attribute_values(IntPtr batch, uint mesh, uint attribute);
     [DllImport(Lib)] internal static extern IntPtr dsa_batch_device_point_map(IntPtr batch, uint mesh, uint attribute);
+    // whole-batch copy-out: one transfer of every output array into a pinned mirror (or caller memory), beside the next batch's kernels
+    [DllImport(Lib)] internal static extern ulong dsa_batch_output_bytes(IntPtr batch);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_download(IntPtr batch, void* dst, nuint dstBytes);
+    [DllImport(Lib)] internal static extern IntPtr dsa_batch_host_output(IntPtr batch, uint block);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_output_layout(IntPtr batch, uint mesh, out DsaMeshOutput layout);
+    [DllImport(Lib)] internal static extern IntPtr dsa_host_alloc(nuint bytes);
+    [DllImport(Lib)] internal static extern void dsa_host_free(IntPtr p);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_host_register(void* p, nuint bytes);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_host_unregister(void* p);
     [DllImport(Lib)] internal static extern DsaStatus dsa_batch_copy_metadata(IntPtr batch, uint mesh, byte* dst, nuint dstBytes, out nuint length);
     [DllImport(Lib)] internal static extern DsaStatus dsa_batch_copy_debug(IntPtr batch, uint mesh, int what, void* dst, nuint dstBytes, out nuint written);
     [DllImport(Lib)] internal static extern DsaStatus dsa_context_set_profiling(IntPtr ctx, int enabled);
