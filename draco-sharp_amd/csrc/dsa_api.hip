@@ -96,6 +96,7 @@ struct dsa_batch {
   BatchGlobals globals = {};
   uint64_t out_base = 0, out_bytes = 0;   // the output block: faces, attribute values and point maps of every mesh
   uint32_t max_faces = 0, max_vertices = 0, max_atts = 0, max_att_data = 0;
+  uint64_t sum_vertices = 0;
   bool any_general = false;
   bool decoded = false, collected = false;
   hipEvent_t ev[DSA_NUM_STAGES + 1] = {};
@@ -216,6 +217,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
     cur = scratch_begin;
     uint64_t ocur = 0;
     b->max_faces = b->max_vertices = b->max_atts = b->max_att_data = 0;
+    b->sum_vertices = 0;
     b->any_general = false;
     for (uint32_t i = 0; i < n; ++i) {
       HostMesh &h = b->host[i];
@@ -230,6 +232,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
       claim[i] = (cur - before) + (ocur - obefore);
       b->max_faces = std::max<uint32_t>(b->max_faces, (uint32_t)F);
       b->max_vertices = std::max<uint32_t>(b->max_vertices, (uint32_t)V);
+      b->sum_vertices += V;
       b->max_atts = std::max<uint32_t>(b->max_atts, (uint32_t)h.atts.size());
       b->max_att_data = std::max<uint32_t>(b->max_att_data, h.num_att_data);
       b->any_general = b->any_general || h.general;
@@ -459,6 +462,13 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   const uint32_t lane_flags = PW_FLAG, wide_flag = SYM_WIDE;
   const bool run_window = true, early_fuse_on = false;
 #endif
+  // The octahedral delta one lane per stream (k_predict_oct_streams) when the batch fills the machine anyway -- measured on the
+  // bench meshes: 0.5 - 0.8 ms slower up to 3072 meshes (nothing waits for the instructions it saves, and its waves share SIMDs
+  // with chain waves), 1.5 - 2 ms faster at 4096 -- and no mesh is much larger than the rest (the kernel takes as long as the
+  // longest stream's chain).  DSA_OCT_STREAMS=0|1 (diagnostics, read per decode so that a test can set it) overrides the rule.
+  const int oct_choice = []() { const char *e = getenv("DSA_OCT_STREAMS"); return e ? atoi(e) : -1; }();
+  const bool oct_rule = n >= 3584 && (uint64_t)b->max_vertices * n <= 4 * b->sum_vertices;
+  const uint32_t oct_flag = (oct_choice >= 0 ? oct_choice != 0 : oct_rule) && !(lane_flags & (LN_FLAG_OCT | LN_FLAG_PREDICT)) ? OS_FLAG : 0u;
   hipStream_t st2 = serial ? st : ctx->stream2, st3 = serial ? st : ctx->stream3;
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_fork, 0));
@@ -578,7 +588,10 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   else
 #endif
   {
-    hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
+    // the octahedral delta of a crowded batch one lane per stream (64 streams per wave: 1/30 of the instructions; the kernel takes
+    // as long as the longest stream's chain whatever the batch size, which a small batch does not want)
+    if (oct_flag) hipLaunchKernelGGL(dsa::k_predict_oct_streams, dim3((n + WAVE - 1) / WAVE, na), dim3(WAVE), OS_RING * 1024u, st4, b->arena, b->d_layouts, b->d_descs, n);
+    hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags | oct_flag);
     if (lane_flags & PW_FLAG) hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
 #ifdef DSA_EXPERIMENTS
     if (lane_flags & LN_FLAG_OCT) {

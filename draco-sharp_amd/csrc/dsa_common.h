@@ -293,6 +293,168 @@ __device__ __forceinline__ void oct_original(const OctParams &o, bool canonical,
   if (!in_d) oct_invert_diamond(o.center, os, ot);
   os += o.center; ot += o.center;
 }
+
+// The canonicalised transform as a recursion in the canonical frame.  ComputeOriginalValue maps the previous value p
+// (centred) through T = R_k . I^inv (I = InvertDiamond if p lies outside the diamond, R_k = the rotation that takes the result to
+// the bottom-left quadrant), adds the correction there (w = T p + corr), wraps (ModMax) and maps back: p' = I^inv R_-k w.
+// With q = R_-k w and w (after ModMax) within the square the next step's frame follows from w alone:
+//   |w|_1 <= center (w inside the diamond; strictly, when inv):  I(p') = q again (I undoes itself on the open diamond), the
+//       rotation counts add up (rotcount(R_-k w) = k + rotcount(w) mod 4: the four half-open quadrants are each other's
+//       images) and the next canonical point is w turned into the bottom-left quadrant: (-|w.x|, -|w.y|), swapped when
+//       rotcount(w) is odd; inv stays (it ends on the edge itself, which I leaves in place);
+//   |w|_1 > center (the normal crosses to the other half of the octahedron): with y = I(q), the next step starts from y
+//       whether p' = q (it will invert it) or p' = y (inside the diamond): canonical point and rotation count of y, inv flips.
+// (I and the rotations do not commute on the axes, so y is computed from q, as the reference does, not from w.)
+// The state (u, k, inv) advances in 10-30 dependent operations; the value, (inv ? I(q) : q) + center, hangs off the chain.
+// A correction that leaves the square, and out-of-range garbage, take the reference's own function and re-derive the state
+// from its result.
+struct OctLane { int32_t ux, uy, vs, vt; uint32_t k; bool inv, regular; };
+__device__ __forceinline__ uint32_t oct_rotcount(int32_t x, int32_t y) {
+  return (y < 0 && x >= 0) ? 1u : ((x > 0 && y >= 0) ? 2u : ((y > 0 && x <= 0) ? 3u : 0u));
+}
+__device__ __forceinline__ void oct_lane_state(const OctParams &o, OctLane &s) {       // from s.vs, s.vt, as ComputeOriginalValue starts
+  int32_t ps = (int32_t)((uint32_t)s.vs - (uint32_t)o.center), pt = (int32_t)((uint32_t)s.vt - (uint32_t)o.center);
+  const int32_t aps = ps < 0 ? -ps : ps, apt = pt < 0 ? -pt : pt;
+  const bool in_d = (uint32_t)aps + (uint32_t)apt <= (uint32_t)o.center;
+  // values far outside the square (only a damaged stream has them) stay on the reference's function
+  const bool tame = (uint32_t)aps <= 2u * (uint32_t)o.center + 2u && (uint32_t)apt <= 2u * (uint32_t)o.center + 2u;
+  if (!tame) { s.regular = false; s.ux = 0; s.uy = 0; s.k = 0; s.inv = false; return; }
+  if (!in_d) oct_invert_diamond(o.center, ps, pt);
+  const uint32_t rot = oct_rotcount(ps, pt);
+  oct_rotate(ps, pt, (int)rot);
+  s.ux = ps; s.uy = pt; s.k = rot; s.inv = !in_d;
+  s.regular = ps <= 0 && pt <= 0 && ps >= -o.center && pt >= -o.center;
+}
+// One entry on the fast path only: advances (u, k, inv) and returns the value; the result says whether the step was entitled
+// to (when it is not, state and value are garbage and the caller redoes the entry with oct_lane_exact).
+__device__ __forceinline__ bool oct_lane_fast(const OctParams &o, OctLane &s, int32_t cx, int32_t cy, int32_t &os, int32_t &ot) {
+  const int32_t C = o.center;
+  // ModMax once, as the reference does (corrections are stored modulo max_q: -2 arrives as max_q - 2); whatever is still
+  // outside the square afterwards is not this path's business
+  const int32_t wx = oct_mod_max(o, (int32_t)((uint32_t)s.ux + (uint32_t)cx)), wy = oct_mod_max(o, (int32_t)((uint32_t)s.uy + (uint32_t)cy));
+  const int32_t ax = wx < 0 ? -wx : wx, ay = wy < 0 ? -wy : wy;
+  const bool sane = (uint32_t)(cx + (1 << 30)) <= (1u << 31) && (uint32_t)(cy + (1 << 30)) <= (1u << 31);   // no overflow above (|u| <= center < 2^29)
+  const bool ok = s.regular && sane && (uint32_t)ax <= (uint32_t)C && (uint32_t)ay <= (uint32_t)C;
+  const int32_t l1 = ax + ay;                   // meaningful when ok
+  const bool out = l1 > C;
+  const uint32_t k = s.k;
+  int32_t qs = wx, qt = wy;
+  oct_rotate(qs, qt, (int)((4u - k) & 3u));
+  int32_t ys = qs, yt = qt;
+  if (s.inv || out) oct_invert_diamond(C, ys, yt);
+  os = (s.inv ? ys : qs) + C; ot = (s.inv ? yt : qt) + C;
+  // ---- the next frame
+  const int32_t bx = out ? ys : wx, by = out ? yt : wy;
+  const int32_t abx = bx < 0 ? -bx : bx, aby = by < 0 ? -by : by;
+  const uint32_t kk = oct_rotcount(bx, by);
+  const bool odd = (kk & 1u) != 0;
+  s.ux = -(odd ? aby : abx); s.uy = -(odd ? abx : aby);
+  s.k = out ? kk : ((abx | aby) == 0 ? 0u : ((k + kk) & 3u));
+  s.inv = out ? !s.inv : (s.inv && l1 < C);
+  return ok;
+}
+// One entry by the reference's function on the previous value (s.vs, s.vt), then the state from its result.
+__device__ __forceinline__ void oct_lane_exact(const OctParams &o, OctLane &s, int32_t cx, int32_t cy, int32_t &os, int32_t &ot) {
+  oct_original(o, true, s.vs, s.vt, cx, cy, os, ot);
+  s.vs = os; s.vt = ot;
+  oct_lane_state(o, s);
+}
+
+
+// ---- The same step on both components at once (16-bit halves of one register), for octahedra of up to 14 bits.
+// With x = I^s(p) (s: p outside the diamond), k = the rotation that takes x to the bottom-left quadrant and ModMax commuting with
+// the rotations of the square,  p' = I^s( ModMax( x + R_-k c ) ):  the correction is turned into the frame of x instead of x into
+// the canonical frame -- R_-k c = ((odd ? cy : cx) negated if k in {1,2}, (odd ? cx : cy) negated if k in {2,3}), and
+//   k in {1,2}  <=>  x > 0 || (x == 0 && y < 0)          k in {2,3}  <=>  y > 0 || (y == 0 && x > 0)        odd  <=>  exactly one of them
+// (oct_rotcount).  I(s, t) = (sgn(s) (C - |t|), sgn(t) (C - |s|)) with sgn(0) taken from the other coordinate (oct_invert_diamond);
+// a point of the square outside the diamond has no zero coordinate, so the forward I needs no such care, the final one does.
+// Valid for |p| <= C componentwise (kept by the step itself) and 0 <= c <= max_q; anything else goes to oct_original.
+// pk_*: two int16 lanes of a uint32_t: v_pk_* instructions on the device, plain C on the host (tests/hostcheck).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef short pk_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short pk_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (pk_s16x2)(__builtin_bit_cast(pk_s16x2, a) + __builtin_bit_cast(pk_s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (pk_s16x2)(__builtin_bit_cast(pk_s16x2, a) - __builtin_bit_cast(pk_s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_max_i(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pk_s16x2, a), __builtin_bit_cast(pk_s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(pk_u16x2, a), __builtin_bit_cast(pk_u16x2, b))); }
+__device__ __forceinline__ uint32_t pk_sign(uint32_t a) { return __builtin_bit_cast(uint32_t, (pk_s16x2)(__builtin_bit_cast(pk_s16x2, a) >> (pk_s16x2)(15))); }
+#else
+__host__ __device__ __forceinline__ uint32_t pk_make(int32_t lo, int32_t hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
+__host__ __device__ __forceinline__ int32_t pk_lo(uint32_t a) { return (int32_t)(int16_t)(a & 0xFFFFu); }
+__host__ __device__ __forceinline__ int32_t pk_hi(uint32_t a) { return (int32_t)(int16_t)(a >> 16); }
+__host__ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_make(pk_lo(a) + pk_lo(b), pk_hi(a) + pk_hi(b)); }
+__host__ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_make(pk_lo(a) - pk_lo(b), pk_hi(a) - pk_hi(b)); }
+__host__ __device__ __forceinline__ uint32_t pk_max_i(uint32_t a, uint32_t b) { return pk_make(pk_lo(a) > pk_lo(b) ? pk_lo(a) : pk_lo(b), pk_hi(a) > pk_hi(b) ? pk_hi(a) : pk_hi(b)); }
+__host__ __device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b) { const uint32_t al = a & 0xFFFFu, bl = b & 0xFFFFu, ah = a >> 16, bh = b >> 16; return (al < bl ? al : bl) | ((ah < bh ? ah : bh) << 16); }
+__host__ __device__ __forceinline__ uint32_t pk_sign(uint32_t a) { return pk_make(pk_lo(a) >> 15, pk_hi(a) >> 15); }
+#endif
+__device__ __forceinline__ uint32_t pk_swap(uint32_t a) { return (a >> 16) | (a << 16); }
+__device__ __forceinline__ uint32_t pk_pick(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }   // v_bfi_b32
+__device__ __forceinline__ uint32_t pk_abs(uint32_t a) { return pk_max_i(a, pk_sub(0u, a)); }
+#define OCT_PK_MAX_BITS 14
+// all ones (both halves) when the centred point P lies outside the diamond; A = |P|, SA = A with its halves exchanged
+__device__ __forceinline__ uint32_t oct_pk_outside(uint32_t Cv, uint32_t P, uint32_t &A, uint32_t &SA) {
+  A = pk_abs(P);
+  SA = pk_swap(A);
+  return pk_sign(pk_sub(Cv, pk_add(A, SA)));
+}
+// INV = false: no lane of the wave is outside (OUT == 0 everywhere): the step without either inversion
+template <bool INV>
+__device__ __forceinline__ uint32_t oct_pk_step(uint32_t Cv, uint32_t Mv, uint32_t P, uint32_t A, uint32_t SA, uint32_t OUT, uint32_t Cc) {
+  uint32_t X = P, NG = pk_sign(P);
+  if (INV) {
+    const uint32_t A1 = pk_pick(OUT, pk_sub(Cv, SA), A);
+    X = pk_sub(A1 ^ NG, NG);                        // a magnitude of 0 loses its sign here
+    NG = pk_sign(X);
+  }
+  const uint32_t PS = pk_sign(pk_sub(0u, X));
+  // low half: x > 0 || (y < 0 && x >= 0); high half: y > 0 || (x > 0 && y >= 0)
+  const uint32_t U = pk_swap(pk_pick(0x0000FFFFu, PS, NG));       // (y < 0, x > 0)
+  const uint32_t FL = PS | (U & ~NG);
+  const uint32_t ODD = FL ^ pk_swap(FL);
+  uint32_t CP = pk_pick(ODD, pk_swap(Cc), Cc);
+  CP = pk_sub(CP ^ FL, FL);
+  uint32_t t = pk_add(pk_add(X, Cv), CP);           // in (-max_q, 2 max_q): into [0, max_q)
+  t = pk_min_u(t, pk_add(t, Mv));
+  t = pk_min_u(t, pk_sub(t, Mv));
+  const uint32_t W = pk_sub(t, Cv);
+  if (!INV) return W;
+  const uint32_t IW = pk_sub(Cv, pk_swap(pk_abs(W)));
+  const uint32_t SG = pk_sign(pk_add(pk_add(W, W), pk_swap(pk_sign(W))));      // s < 0 || (s == 0 && t < 0)
+  return pk_pick(OUT, pk_sub(IW ^ SG, SG), W);
+}
+// One stream, entry by entry, as a lane of k_predict_oct_streams runs it (the kernel interleaves 64 of these; the host check
+// runs this function): packed steps while the stream behaves, the reference's function for an entry that does not.
+struct OctPkLane { uint32_t P, Cv, Mv, q; int32_t vs, vt; bool wild; };
+__device__ __forceinline__ void oct_pk_init(OctPkLane &s, const OctParams &o, uint32_t q) {
+  s.q = q;
+  s.Cv = (uint32_t)o.center * 0x00010001u; s.Mv = (uint32_t)o.max_q * 0x00010001u;
+  s.P = ((0u - (uint32_t)o.center) & 0xFFFFu) * 0x00010001u;    // the value (0, 0), centred
+  s.vs = 0; s.vt = 0; s.wild = false;
+}
+// the entry by the reference's function, from the lane's state whichever form it has; leaves the packed form behind when the
+// result is back inside the square
+__device__ __forceinline__ void oct_pk_careful(OctPkLane &s, const OctParams &o, int32_t cx, int32_t cy, int32_t &os, int32_t &ot) {
+  if (!s.wild) { s.vs = (int32_t)(int16_t)(s.P & 0xFFFFu) + o.center; s.vt = (int32_t)(int16_t)(s.P >> 16) + o.center; }
+  oct_original(o, true, s.vs, s.vt, cx, cy, os, ot);
+  s.vs = os; s.vt = ot;
+  const int32_t x = (int32_t)((uint32_t)os - (uint32_t)o.center), y = (int32_t)((uint32_t)ot - (uint32_t)o.center);
+  s.wild = !(x >= -o.center && x <= o.center && y >= -o.center && y <= o.center);
+  if (!s.wild) s.P = ((uint32_t)x & 0xFFFFu) | ((uint32_t)y << 16);
+}
+__device__ __forceinline__ bool oct_pk_entitled(const OctPkLane &s, int32_t cx, int32_t cy) {
+  return !s.wild && ((((uint32_t)cx | (uint32_t)cy) >> s.q) == 0u);
+}
+__device__ __forceinline__ void oct_pk_entry(OctPkLane &s, const OctParams &o, int32_t cx, int32_t cy, int32_t &os, int32_t &ot) {
+  if (!oct_pk_entitled(s, cx, cy)) { oct_pk_careful(s, o, cx, cy, os, ot); return; }
+  uint32_t A, SA;
+  const uint32_t OUT = oct_pk_outside(s.Cv, s.P, A, SA);
+  const uint32_t Cc = ((uint32_t)cx & 0xFFFFu) | ((uint32_t)cy << 16);
+  s.P = OUT ? oct_pk_step<true>(s.Cv, s.Mv, s.P, A, SA, OUT, Cc) : oct_pk_step<false>(s.Cv, s.Mv, s.P, A, SA, OUT, Cc);
+  const uint32_t v = pk_add(s.P, s.Cv);
+  os = (int32_t)(v & 0xFFFFu); ot = (int32_t)(v >> 16);
+}
+
 __device__ __forceinline__ int32_t wrap_original(int32_t pred, int32_t corr, int32_t mn, int32_t mx, int32_t max_dif) {
   int32_t p = pred > mx ? mx : (pred < mn ? mn : pred);       // PredictionSchemeWrapTransform.cs:67-86
   int32_t o = (int32_t)((uint32_t)p + (uint32_t)corr);       // PredictionSchemeWrapDecodingTransform.cs:46-67

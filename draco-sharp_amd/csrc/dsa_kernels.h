@@ -40,6 +40,10 @@ __device__ __forceinline__ bool ln_oct_eligible(const AttrDesc &, uint32_t) { re
 } }
 #endif
 
+#ifndef DSA_CHAIN_PRIO
+#define DSA_CHAIN_PRIO 3      // issue priority of the connectivity / traversal waves
+#endif
+
 namespace dsa {
 
 __device__ __forceinline__ uint32_t cnext(uint32_t c) { return (c % 3u == 2u) ? c - 2u : c + 1u; }
@@ -940,7 +944,7 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
 
 __global__ __launch_bounds__(WAVE) void k_connectivity(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   __shared__ __attribute__((aligned(16))) uint32_t sh[CN_LDS_WORDS];
-  __builtin_amdgcn_s_setprio(3);   // critical path: issue ahead of the entropy-decode waves sharing the CU
+  __builtin_amdgcn_s_setprio(DSA_CHAIN_PRIO);   // critical path: issue ahead of the entropy-decode waves sharing the CU
   const uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
   uint32_t *sh_rec = sh + CN_STAGE * 8, *sh_win = sh_rec + CN_REC_BLOCKS * 64 * 2, *sh_ctx = sh_win + CN_WIN;
@@ -1682,7 +1686,7 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   for (uint32_t i = threadIdx.x; i < TR_SLOTS; i += WAVE) { sh_tf[i] = 0; sh_tv[i] = 0; }
   if (threadIdx.x < TR_HIST_WORDS) sh_hist[threadIdx.x] = 0;
   __syncthreads();
-  __builtin_amdgcn_s_setprio(3);   // critical path: issue ahead of the entropy-decode waves sharing the CU
+  __builtin_amdgcn_s_setprio(DSA_CHAIN_PRIO);   // critical path: issue ahead of the entropy-decode waves sharing the CU
   const uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
   if (layouts[mesh].rec_compact) traverse_wave<true>(arena, layouts[mesh], &descs[mesh], fuse_operands, sh_tf, sh_tv, sh_hist);
@@ -1699,7 +1703,7 @@ extern __shared__ __attribute__((aligned(16))) uint32_t sh_chain[];
 __global__ __launch_bounds__(WAVE, 8) void k_chain(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t fuse_operands) {
   uint32_t *sh = sh_chain;
   static_assert(CN_LDS_WORDS * 4 >= 2 * TR_SLOTS * 8 + TR_HIST_WORDS * 4, "the traversal's tables reuse the connectivity's LDS");
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(DSA_CHAIN_PRIO);
   const uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
   const MeshLayout &L = layouts[mesh];
@@ -2345,12 +2349,18 @@ __device__ __forceinline__ uint32_t addmod(uint32_t a, uint32_t b, uint32_t m) {
 // kernels on their stream; phase 1: parallelogram schemes, after the traversal.
 __device__ __forceinline__ bool wrap_fast_ok(const AttrDesc &a, uint32_t flags);
 __device__ __forceinline__ bool pw_dequant_fused(const AttrDesc &a, uint32_t flags);
+#define OS_FLAG 16u   // the canonicalised octahedral delta is k_predict_oct_streams' (crowded batches)
+__device__ __forceinline__ bool oct_stream_eligible(const AttrDesc &a) {
+  return a.have_scheme && a.source != SRC_BYTES && a.pred_transform == 3 && a.pred_kind == 0 && a.num_entries != 0 && !a.early_done &&
+         a.oct_max_q >= 3 && a.oct_max_q < (1 << OCT_PK_MAX_BITS);      // the packed step's range; finer octahedra stay with k_predict
+}
 // The body of k_predict for one attribute on one wave (also the tail of an entropy-decode wave, see early_tail).
 __device__ __forceinline__ void predict_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t phase, uint32_t flags) {
   const AttrDesc &a = D->att[ai];
   if (!a.have_scheme || a.source == SRC_BYTES) return;
   if (wrap_fast_ok(a, flags)) return;                    // k_predict_wrap
   if (lanes::ln_oct_eligible(a, flags)) return;          // k_predict_oct_lanes
+  if ((flags & OS_FLAG) && oct_stream_eligible(a)) return;   // k_predict_oct_streams
   if ((a.pred_kind == 1) != (phase == 1)) return;
   int32_t *w = (int32_t *)(arena + L.work[ai]);
   const uint32_t nc = a.nc_portable, entries = a.num_entries;
@@ -2581,6 +2591,96 @@ __global__ __launch_bounds__(WAVE) void k_predict(uint8_t *arena, const MeshLayo
   if (phase == 0) __builtin_amdgcn_s_setprio(DSA_PREDICT_PRIO);
 #endif
   predict_wave(arena, layouts[mesh], D, ai, phase, flags);
+}
+
+// =========================================================================
+// k_predict_oct_streams: the canonicalised octahedral delta (PredictionSchemeDeltaDecoder.cs:23-37 over
+// PredictionSchemeNormalOctahedronCanonicalizedDecodingTransform.ComputeOriginalValue) of a crowded batch, ONE LANE PER
+// STREAM.  The chain has nothing a wave could scan when consecutive normals keep changing their class (which side of the
+// diamond, which quadrant: height fields straddle an axis all the time) -- k_predict then retires three entries per 64-lane
+// step, 2 G scalar + 2 G vector instructions per 4096-mesh batch at the tail of the early strand.  With both components in the
+// 16-bit halves of one register (dsa_common.h: oct_pk_step, about 35 packed operations per entry, no branches but one wave-uniform
+// one) on 64 streams per wave the batch needs 1/30 of the instructions, and the time of the kernel is the length of the longest
+// stream's chain, whatever the batch size.
+// A lone wave cannot hide a memory round trip behind other waves, so the corrections come through a ring in LDS filled by
+// LDS-DMA (global_load_lds: no registers in flight): slot s = 64 lanes x 16 bytes = the next two entries of every lane's own
+// stream, requested OS_AHEAD slots before they are used (a gather of 64 lines per instruction -- a cycle of the address unit
+// each, 1/6 of what the recursion costs -- every line serving eight consecutive requests from L1 / L2).  Results leave with a
+// 16-byte store per lane and slot.  The streams of a wave may differ in length: finished lanes keep requesting their last
+// pair (the count of requests in flight must not depend on the lane) and store nothing.
+// =========================================================================
+#ifndef DSA_OCT_PRIO
+#define DSA_OCT_PRIO 3
+#endif
+#define OS_RING 32u       // slots of 1 KB
+#define OS_AHEAD 28u      // requests in flight (vmcnt counts 63 at most; stores share the counter)
+static_assert(OS_AHEAD < OS_RING && OS_AHEAD < 60u, "the slot being filled is never the one being read");
+__global__ __launch_bounds__(WAVE, 8) void k_predict_oct_streams(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  // the ring is dynamic LDS (OS_RING KB at launch): a size the compiler can see makes it budget registers for the two waves per
+  // SIMD that much LDS allows (176), and the wave then finds no room beside the decoders
+  extern __shared__ __attribute__((aligned(1024))) uint8_t ring[];
+  const uint32_t lane = lane_id(), mesh = blockIdx.x * WAVE + lane, ai = blockIdx.y;
+  uint32_t entries = 0;
+  uint8_t *w = arena;                 // lanes without a stream read the front of the arena (always there) and never store
+  OctParams o;
+  uint32_t q = 2;
+  if (mesh < n) {
+    const MeshDesc *D = &descs[mesh];
+    if (D->status == ST_OK && !D->general && ai < D->num_attributes && oct_stream_eligible(D->att[ai])) {
+      const AttrDesc &a = D->att[ai];
+      entries = a.num_entries;
+      w = arena + layouts[mesh].work[ai];
+      q = 32u - (uint32_t)__clz(a.oct_max_q);
+    }
+  }
+  o.center = ((1 << q) - 2) / 2;
+  o.max_q = (1 << q) - 1;
+  const uint32_t pairs = (entries + 1u) / 2u;
+  uint32_t most = pairs;
+  for (int d = 32; d >= 1; d >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)most, d, WAVE); most = x > most ? x : most; }
+  most = uni(most);
+  if (most == 0) return;
+  __builtin_amdgcn_s_setprio(DSA_OCT_PRIO);      // a handful of long chains
+  const uint32_t last = pairs ? pairs - 1u : 0u;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  auto request = [&](uint32_t pr) {
+    const uint32_t at = pr < last ? pr : last;
+    __builtin_amdgcn_global_load_lds((glb_void *)(w + 16ull * at), (lds_void *)(ring + (pr % OS_RING) * 1024u), 16, 0, 0);
+  };
+  for (uint32_t s = 0; s < OS_AHEAD; ++s) request(s);
+  OctPkLane st;
+  oct_pk_init(st, o, q);
+  const uint32_t lds_lane = (uint32_t)(uintptr_t)(lds_void *)ring + lane * 16u;
+  for (uint32_t i = 0; i < most; ++i) {
+    request(i + OS_AHEAD);
+    // the request for slot i is OS_AHEAD requests old: at most that many memory operations may still be under way (stores
+    // issued in between only make the wait stricter)
+    uint4 c;
+    asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(c) : "v"(lds_lane + (i % OS_RING) * 1024u), "n"(OS_AHEAD) : "memory");
+    // both entries of the slot on the packed step (dsa_common.h), straight-line but for one wave-uniform choice per entry (does
+    // any lane's previous value lie outside the diamond: the step then carries the two inversions); a lane that was not
+    // entitled to it -- a correction outside [0, max_q], a value that left the square -- does its entries again by the
+    // reference's function
+    const bool entitled = !st.wild && (((c.x | c.y | c.z | c.w) >> q) == 0u);
+    uint32_t A, SA;
+    uint32_t OUT = oct_pk_outside(st.Cv, st.P, A, SA);
+    const uint32_t C1 = c.x | (c.y << 16), C2 = c.z | (c.w << 16);
+    const uint32_t P1 = __builtin_amdgcn_ballot_w64(OUT != 0u) ? oct_pk_step<true>(st.Cv, st.Mv, st.P, A, SA, OUT, C1) : oct_pk_step<false>(st.Cv, st.Mv, st.P, A, SA, OUT, C1);
+    OUT = oct_pk_outside(st.Cv, P1, A, SA);
+    const uint32_t P2 = __builtin_amdgcn_ballot_w64(OUT != 0u) ? oct_pk_step<true>(st.Cv, st.Mv, P1, A, SA, OUT, C2) : oct_pk_step<false>(st.Cv, st.Mv, P1, A, SA, OUT, C2);
+    const uint32_t v1 = pk_add(P1, st.Cv), v2 = pk_add(P2, st.Cv);
+    int32_t a0 = (int32_t)(v1 & 0xFFFFu), a1 = (int32_t)(v1 >> 16), b0 = (int32_t)(v2 & 0xFFFFu), b1 = (int32_t)(v2 >> 16);
+    const bool both = 2u * i + 1u < entries;
+    if (entitled) st.P = P2;
+    else if (i < pairs) {
+      oct_pk_entry(st, o, (int32_t)c.x, (int32_t)c.y, a0, a1);
+      if (both) oct_pk_entry(st, o, (int32_t)c.z, (int32_t)c.w, b0, b1);
+    }
+    if (both) *(uint4 *)(w + 16ull * i) = make_uint4((uint32_t)a0, (uint32_t)a1, (uint32_t)b0, (uint32_t)b1);
+    else if (i < pairs) *(uint2 *)(w + 16ull * i) = make_uint2((uint32_t)a0, (uint32_t)a1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // nothing may land in the ring after the wave has given it back
 }
 
 // =========================================================================

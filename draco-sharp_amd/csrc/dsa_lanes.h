@@ -324,72 +324,7 @@ __device__ __forceinline__ void ln_predict_wrap(int32_t *w, const uint32_t *para
 // per entry (below).  Blocks of 8 entries, fully unrolled: the corrections of the block are in registers, those of the next
 // two blocks are loading, the results leave with four 16-byte stores at the block's end -- nothing inside a block waits
 // for memory, and the kernel fits the registers one entropy-decode wave leaves behind (it starts beside them).
-// The canonicalised transform as a recursion in the canonical frame.  ComputeOriginalValue maps the previous value p
-// (centred) through T = R_k . I^inv (I = InvertDiamond if p lies outside the diamond, R_k = the rotation that takes the result to
-// the bottom-left quadrant), adds the correction there (w = T p + corr), wraps (ModMax) and maps back: p' = I^inv R_-k w.
-// With q = R_-k w and w (after ModMax) within the square the next step's frame follows from w alone:
-//   |w|_1 <= center (w inside the diamond; strictly, when inv):  I(p') = q again (I undoes itself on the open diamond), the
-//       rotation counts add up (rotcount(R_-k w) = k + rotcount(w) mod 4: the four half-open quadrants are each other's
-//       images) and the next canonical point is w turned into the bottom-left quadrant: (-|w.x|, -|w.y|), swapped when
-//       rotcount(w) is odd; inv stays (it ends on the edge itself, which I leaves in place);
-//   |w|_1 > center (the normal crosses to the other half of the octahedron): with y = I(q), the next step starts from y
-//       whether p' = q (it will invert it) or p' = y (inside the diamond): canonical point and rotation count of y, inv flips.
-// (I and the rotations do not commute on the axes, so y is computed from q, as the reference does, not from w.)
-// The state (u, k, inv) advances in 10-30 dependent operations; the value, (inv ? I(q) : q) + center, hangs off the chain.
-// A correction that leaves the square, and out-of-range garbage, take the reference's own function and re-derive the state
-// from its result.
-struct OctLane { int32_t ux, uy, vs, vt; uint32_t k; bool inv, regular; };
-__device__ __forceinline__ uint32_t oct_rotcount(int32_t x, int32_t y) {
-  return (y < 0 && x >= 0) ? 1u : ((x > 0 && y >= 0) ? 2u : ((y > 0 && x <= 0) ? 3u : 0u));
-}
-__device__ __forceinline__ void oct_lane_state(const OctParams &o, OctLane &s) {       // from s.vs, s.vt, as ComputeOriginalValue starts
-  int32_t ps = (int32_t)((uint32_t)s.vs - (uint32_t)o.center), pt = (int32_t)((uint32_t)s.vt - (uint32_t)o.center);
-  const int32_t aps = ps < 0 ? -ps : ps, apt = pt < 0 ? -pt : pt;
-  const bool in_d = (uint32_t)aps + (uint32_t)apt <= (uint32_t)o.center;
-  // values far outside the square (only a damaged stream has them) stay on the reference's function
-  const bool tame = (uint32_t)aps <= 2u * (uint32_t)o.center + 2u && (uint32_t)apt <= 2u * (uint32_t)o.center + 2u;
-  if (!tame) { s.regular = false; s.ux = 0; s.uy = 0; s.k = 0; s.inv = false; return; }
-  if (!in_d) oct_invert_diamond(o.center, ps, pt);
-  const uint32_t rot = oct_rotcount(ps, pt);
-  oct_rotate(ps, pt, (int)rot);
-  s.ux = ps; s.uy = pt; s.k = rot; s.inv = !in_d;
-  s.regular = ps <= 0 && pt <= 0 && ps >= -o.center && pt >= -o.center;
-}
-// One entry on the fast path only: advances (u, k, inv) and returns the value; the result says whether the step was entitled
-// to (when it is not, state and value are garbage and the caller redoes the entry with oct_lane_exact).
-__device__ __forceinline__ bool oct_lane_fast(const OctParams &o, OctLane &s, int32_t cx, int32_t cy, int32_t &os, int32_t &ot) {
-  const int32_t C = o.center;
-  // ModMax once, as the reference does (corrections are stored modulo max_q: -2 arrives as max_q - 2); whatever is still
-  // outside the square afterwards is not this path's business
-  const int32_t wx = oct_mod_max(o, (int32_t)((uint32_t)s.ux + (uint32_t)cx)), wy = oct_mod_max(o, (int32_t)((uint32_t)s.uy + (uint32_t)cy));
-  const int32_t ax = wx < 0 ? -wx : wx, ay = wy < 0 ? -wy : wy;
-  const bool sane = (uint32_t)(cx + (1 << 30)) <= (1u << 31) && (uint32_t)(cy + (1 << 30)) <= (1u << 31);   // no overflow above (|u| <= center < 2^29)
-  const bool ok = s.regular && sane && (uint32_t)ax <= (uint32_t)C && (uint32_t)ay <= (uint32_t)C;
-  const int32_t l1 = ax + ay;                   // meaningful when ok
-  const bool out = l1 > C;
-  const uint32_t k = s.k;
-  int32_t qs = wx, qt = wy;
-  oct_rotate(qs, qt, (int)((4u - k) & 3u));
-  int32_t ys = qs, yt = qt;
-  if (s.inv || out) oct_invert_diamond(C, ys, yt);
-  os = (s.inv ? ys : qs) + C; ot = (s.inv ? yt : qt) + C;
-  // ---- the next frame
-  const int32_t bx = out ? ys : wx, by = out ? yt : wy;
-  const int32_t abx = bx < 0 ? -bx : bx, aby = by < 0 ? -by : by;
-  const uint32_t kk = oct_rotcount(bx, by);
-  const bool odd = (kk & 1u) != 0;
-  s.ux = -(odd ? aby : abx); s.uy = -(odd ? abx : aby);
-  s.k = out ? kk : ((abx | aby) == 0 ? 0u : ((k + kk) & 3u));
-  s.inv = out ? !s.inv : (s.inv && l1 < C);
-  return ok;
-}
-// One entry by the reference's function on the previous value (s.vs, s.vt), then the state from its result.
-__device__ __forceinline__ void oct_lane_exact(const OctParams &o, OctLane &s, int32_t cx, int32_t cy, int32_t &os, int32_t &ot) {
-  oct_original(o, true, s.vs, s.vt, cx, cy, os, ot);
-  s.vs = os; s.vt = ot;
-  oct_lane_state(o, s);
-}
-
+// The canonicalised transform runs as the recursion in the canonical frame of dsa_common.h (OctLane, oct_lane_fast, oct_lane_exact).
 #define LN_OCT_BLOCK 8u
 __device__ __forceinline__ void ln_predict_oct(int32_t *w, uint32_t entries, int32_t max_q, bool canonical) {
   OctParams o;

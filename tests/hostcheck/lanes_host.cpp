@@ -37,12 +37,14 @@ static std::vector<uint8_t> read_file(const char *path) {
 static uint64_t rng_state = 1;
 static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 11); }
 static int octcheck(uint64_t seed, int sequences) {
+  uint64_t packed_steps = 0;
   rng_state = seed * 2654435761ull + 88172645463325252ull;
   for (int it = 0; it < sequences; ++it) {
-    const int q = 2 + (int)(rnd() % 29);                        // 2..30 quantisation bits
+    const int q = (it & 1) ? 2 + (int)(rnd() % 13) : 2 + (int)(rnd() % 29);     // 2..30 quantisation bits, half of the sequences within the packed step's 14
     const int32_t max_q = (int32_t)((1u << q) - 1u);
     const uint32_t entries = 1 + rnd() % 400;
     const int mode = (int)(rnd() % 5);
+    const bool stored = rnd() % 3 != 0;        // corrections as a stream holds them: reduced modulo max_q
     std::vector<int32_t> w(2 * entries + 8), ref(2 * entries);
     const int64_t span = ((int64_t)1 << q);
     for (uint32_t i = 0; i < 2 * entries; ++i) {
@@ -53,6 +55,7 @@ static int octcheck(uint64_t seed, int sequences) {
       else if (mode == 2) c = (int64_t)(r % (uint32_t)(2 * span)) - span;              // beyond the range: ModMax, edges
       else if (mode == 3) c = (r % 50 == 0) ? (int64_t)(int32_t)(rnd() * 2654435761u) : (int64_t)(r % 5) - 2;   // garbage now and then
       else c = (r % 9 == 0) ? ((int64_t)(r % (uint32_t)span) - span / 2) : (int64_t)(r % 3) - 1;
+      if (stored && !(mode == 3 && r % 50 == 0)) { c %= (int64_t)max_q; if (c < 0) c += max_q; }
       w[i] = (int32_t)c;
     }
     dsa::OctParams o;
@@ -64,15 +67,50 @@ static int octcheck(uint64_t seed, int sequences) {
       dsa::oct_original(o, true, ps, pt, w[2 * e], w[2 * e + 1], os, ot);
       ref[2 * e] = os; ref[2 * e + 1] = ot; ps = os; pt = ot;
     }
+    // the packed 16-bit step of k_predict_oct_streams (octahedra of up to 14 bits), entry by entry as a lane runs it
+    if (q <= OCT_PK_MAX_BITS) {
+      dsa::OctPkLane st;
+      dsa::oct_pk_init(st, o, (uint32_t)q);
+      for (uint32_t e = 0; e < entries; ++e) {
+        int32_t os, ot;
+        if (dsa::oct_pk_entitled(st, w[2 * e], w[2 * e + 1])) ++packed_steps;
+        dsa::oct_pk_entry(st, o, w[2 * e], w[2 * e + 1], os, ot);
+        if (os != ref[2 * e] || ot != ref[2 * e + 1]) { fprintf(stderr, "octcheck: packed step, sequence %d (q %d, mode %d) differs at entry %u: (%d, %d) vs (%d, %d)\n", it, q, mode, e, os, ot, ref[2 * e], ref[2 * e + 1]); return 1; }
+      }
+    }
     dsa::lanes::ln_predict_oct(w.data(), entries, max_q, true);
     for (uint32_t i = 0; i < 2 * entries; ++i)
       if (w[i] != ref[i]) { fprintf(stderr, "octcheck: sequence %d (q %d, mode %d) differs at value %u: %d vs %d\n", it, q, mode, i, w[i], ref[i]); return 1; }
   }
-  printf("octcheck: %d sequences equal\n", sequences);
+  printf("octcheck: %d sequences equal (%llu entries on the packed step)\n", sequences, (unsigned long long)packed_steps);
+  return 0;
+}
+
+// lanes_host octexhaust <bits>: the packed step against the reference's function on EVERY value of the square x every correction
+// in [0, max_q], for octahedra of 2 .. <bits> bits
+static int octexhaust(int bits) {
+  for (int q = 2; q <= bits; ++q) {
+    dsa::OctParams o;
+    o.center = ((1 << q) - 2) / 2; o.max_q = (1 << q) - 1;
+    long n = 0;
+    for (int vs = 0; vs <= 2 * o.center; ++vs) for (int vt = 0; vt <= 2 * o.center; ++vt)
+      for (int cx = 0; cx <= o.max_q; ++cx) for (int cy = 0; cy <= o.max_q; ++cy) {
+        int32_t os, ot, rs, rt;
+        dsa::oct_original(o, true, vs, vt, cx, cy, rs, rt);
+        dsa::OctPkLane st;
+        dsa::oct_pk_init(st, o, (uint32_t)q);
+        st.P = ((uint32_t)(vs - o.center) & 0xFFFFu) | ((uint32_t)(vt - o.center) << 16);
+        dsa::oct_pk_entry(st, o, cx, cy, os, ot);
+        ++n;
+        if (os != rs || ot != rt) { fprintf(stderr, "octexhaust: q %d value (%d, %d) correction (%d, %d): (%d, %d) vs (%d, %d)\n", q, vs, vt, cx, cy, os, ot, rs, rt); return 1; }
+      }
+    printf("octexhaust: %d bits, %ld pairs equal\n", q, n);
+  }
   return 0;
 }
 
 int main(int argc, char **argv) {
+  if (argc >= 3 && strcmp(argv[1], "octexhaust") == 0) return octexhaust(atoi(argv[2]));
   if (argc >= 4 && strcmp(argv[1], "octcheck") == 0) return octcheck(strtoull(argv[2], nullptr, 10), atoi(argv[3]));
   if (argc < 4 || strcmp(argv[1], "decode") != 0) { fprintf(stderr, "usage: lanes_host decode <in.drc> <out.bin> [conn.bin]\n"); return 2; }
   const std::vector<uint8_t> data = read_file(argv[2]);

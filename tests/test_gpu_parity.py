@@ -674,3 +674,34 @@ def test_valence_streams_take_the_fast_kernels(ctx):
         assert_same(b.result(i), ref, b, i)
     assert fast >= 6
     b.close()
+
+
+def test_octahedral_delta_one_lane_per_stream(ctx, monkeypatch):
+    """k_predict_oct_streams (what crowded batches use for the octahedral delta of normals): 64 streams of different lengths per
+    wave -- odd and even entry counts, every topology (spheres and tori cover both halves of the octahedron and every
+    quadrant), 2 - 14 bits -- equal to the oracle; then a crowded batch (3 648 meshes: the chain kernel and the batch-size
+    rule itself) without the switch."""
+    monkeypatch.setenv("DSA_OCT_STREAMS", "1")
+    streams = []
+    for j, (kind, nx, ny) in enumerate(KINDS + [(synth.SPHERE, 21, 17), (synth.TORUS, 13, 11), (synth.GRID, 3, 2), (synth.GRID, 2, 2)]):
+        for bits in (2, 5, 8, 11, 14):
+            pos, nrm, uv, faces = synth.make_mesh(kind, nx + (bits % 3), ny, 40 + j)
+            streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(normal_bits=bits)))
+    b = run_batch(ctx, streams)
+    entries = set()
+    for i, s in enumerate(streams):
+        assert b.status(i) == 0, (i, b.mesh_info(i).detail)
+        ref = oracle.decode(s)
+        entries.add(ref.attributes[1].num_entries % 2)
+        assert_same(b.result(i), ref, b, i)
+    assert entries == {0, 1}
+    b.close()
+    monkeypatch.delenv("DSA_OCT_STREAMS")
+    crowd = [streams[i % len(streams)] for i in range(3648)]
+    b = run_batch(ctx, crowd)
+    refs = [oracle.decode(s) for s in streams]
+    for i in range(len(crowd)):
+        assert b.status(i) == 0, (i, b.mesh_info(i).detail)
+    for i in list(range(0, 3648, 37)) + [3647]:
+        assert_same(b.result(i), refs[i % len(streams)], b, i)
+    b.close()

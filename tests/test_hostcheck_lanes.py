@@ -141,3 +141,12 @@ def test_canonical_octahedral_recursion_equals_the_reference_step(exe):
     for seed in (1, 2, 3):
         r = subprocess.run([exe, "octcheck", str(seed), "4000"], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+
+
+def test_packed_octahedral_step_is_exact_on_every_value(exe):
+    """oct_pk_step (dsa_common.h: both components of the canonicalised octahedral delta in the 16-bit halves of one register,
+    what k_predict_oct_streams runs) against ComputeOriginalValue on every value of the square x every correction in
+    [0, max_q], octahedra of 2 - 5 bits (a million pairs); the random walks of the test above cover it up to 14 bits."""
+    r = subprocess.run([exe, "octexhaust", "5"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+    assert "5 bits, 984064 pairs equal" in r.stdout
