@@ -182,3 +182,27 @@ def test_vertex_of_huge_valence(ctx, monkeypatch):
     assert got == synth.encode_mesh(pos, faces, None, None)
     ref = oracle.decode(got)
     assert ref.num_faces == n
+
+
+def _tool(name, *args):
+    import os
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    return subprocess.run([sys.executable, os.path.join("tools", name)] + [str(a) for a in args], cwd=root, capture_output=True, text=True, timeout=900)
+
+
+def test_damaged_meshes_get_the_same_verdict_from_device_and_host_connectivity():
+    """A slice of tools/fuzz_encode.py (a process of its own: it sets the encoder's switches for the whole run): flipped, rewired,
+    duplicated faces and random face soups -- the device connectivity codes the same meshes to the same bytes and refuses the same
+    ones as the host coder."""
+    r = _tool("fuzz_encode.py", 200)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    assert "0 verdicts / streams differ" in r.stdout
+
+
+def test_randomised_encoder_options_slice():
+    """A slice of tools/soak_encode.py: random topology / size / bit depths / compression level per mesh, device paths against the
+    CPU coder byte for byte, every stream decoded again."""
+    r = _tool("soak_encode.py", 60, 5)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]

@@ -261,6 +261,7 @@ def test_corrupt_streams_agree_with_the_oracle(ctx, house04_bytes):
                [base, house04_bytes, stock, rare])
     b = run_batch(ctx, streams)
     agree_ok = agree_bad = gpu_stricter = 0
+    stricter_sites = {}
     for i, sbytes in enumerate(streams):
         try:
             ref = oracle.decode(sbytes)
@@ -274,9 +275,16 @@ def test_corrupt_streams_agree_with_the_oracle(ctx, house04_bytes):
             assert st != 0, (i, "GPU accepted a stream the oracle rejects")
             agree_bad += 1
         else:
-            gpu_stricter += 1          # e.g. the link census or a sizing bound rejects what the oracle lets through
+            gpu_stricter += 1          # a check of the device path that the oracle does not make
+            info = b.mesh_info(i)
+            stricter_sites[(info.status, info.detail)] = stricter_sites.get((info.status, info.detail), 0) + 1
     assert agree_ok >= 4 and agree_bad > 0
-    assert gpu_stricter <= len(streams) // 10, (agree_ok, agree_bad, gpu_stricter)
+    # Where the device path refuses what the oracle lets through, it is one of its own validations, by site: 123 (a traversal
+    # method byte above 1, which the oracle reads as depth-first), 263 (the census of linked corners) and 681 (the general path's
+    # bound on attribute seam data).  Four seeds of this mix gave 0 - 1 such streams of 292 (sites 123, 681); anything else, or
+    # more than a handful, is a difference to look at.
+    assert set(stricter_sites) <= {(1, 123), (1, 263), (1, 681)}, stricter_sites
+    assert gpu_stricter <= 3, (agree_ok, agree_bad, stricter_sites)
     b.close()
 
 
