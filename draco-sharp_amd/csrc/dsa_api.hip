@@ -62,7 +62,7 @@ struct dsa_context {
   hipStream_t stream4 = nullptr;     // early attributes: symbols, prediction, dequantisation (dispatch priority)
   hipStream_t up = nullptr;          // host -> device: compressed streams of the next batch, beside the kernels of this one
   hipStream_t down = nullptr;        // device -> host: the output block and the mesh descriptors of the previous one
-  hipEvent_t ev_join3 = nullptr, ev_trav = nullptr, ev_maps = nullptr, ev_early = nullptr;
+  hipEvent_t ev_join3 = nullptr, ev_trav = nullptr, ev_maps = nullptr, ev_early = nullptr, ev_flips = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_conn = nullptr;
   bool own_stream = false;
   bool profiling = false;
@@ -342,6 +342,7 @@ dsa_status dsa_context_create(int device, void *stream, dsa_context **out) {
       hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_trav, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_maps, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_flips, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
@@ -368,6 +369,7 @@ void dsa_context_destroy(dsa_context *ctx) {
   if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
   if (ctx->ev_trav) (void)hipEventDestroy(ctx->ev_trav);
   if (ctx->ev_maps) (void)hipEventDestroy(ctx->ev_maps);
+  if (ctx->ev_flips) (void)hipEventDestroy(ctx->ev_flips);
   if (ctx->ev_early) (void)hipEventDestroy(ctx->ev_early);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -492,6 +494,14 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     while (lpm < b->max_att_data) lpm *= 2;
     const uint32_t per_wave = WAVE / lpm;
     hipLaunchKernelGGL(dsa::k_conn_checks, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, lpm);
+  }
+  {
+    // the flip bits of GeometricNormal attributes (one serial rABS stream per attribute), beside everything else
+    uint32_t lpm = 1;
+    while (lpm < na) lpm *= 2;
+    const uint32_t per_wave = WAVE / lpm;
+    hipLaunchKernelGGL(dsa::k_flip_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, lpm);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_flips, st3));
   }
   // parallelogram operands: by the traversal waves themselves when the batch keeps the machine busy anyway, by an
   // element-parallel kernel behind the traversal when it does not
@@ -626,11 +636,17 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   }
   HIP_TRY(ctx, mark());
   {
+    // GeometricNormal attributes: from the final positions (of whichever strand) and the flip bits
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_early, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_flips, 0));
+    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 4095) / 4096, 8));
+    hipLaunchKernelGGL(dsa::k_predict_geometric, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+  }
+  {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
     hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags);
   }
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_maps, 0));
-  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_early, 0));
   hipLaunchKernelGGL(dsa::k_seal, dim3((n + 255) / 256), dim3(256), 0, st, b->d_descs, n);
   HIP_TRY(ctx, mark());
   HIP_TRY(ctx, hipGetLastError());

@@ -455,6 +455,48 @@ __device__ __forceinline__ void oct_pk_entry(OctPkLane &s, const OctParams &o, i
   os = (int32_t)(v & 0xFFFFu); ot = (int32_t)(v >> 16);
 }
 
+// GeometricNormal, from the summed face normals n around the vertex to the value (MeshPredictionSchemeGeometricNormalPredictorArea.cs:43-63,
+// MeshPredictionSchemeGeometricNormalDecoder.cs:56-69, OctahedronToolBox.cs:28-77,121-137 with the bitstream's 64-bit arithmetic,
+// D-9, D-23..D-25): scale into 2^29, project on the octahedron of the transform, flip, canonical (s, t), then the octahedral
+// transform's ComputeOriginalValue with the correction (c0, c1).  Shared by the general path and k_predict_geometric.
+__device__ __forceinline__ void geometric_normal_finish(const OctParams &o, bool canonical, const uint64_t n[3], bool flip, int32_t c0, int32_t c1,
+                                                        int32_t &os, int32_t &ot) {
+  const int32_t max_value = o.max_q - 1;
+  int64_t nv[3] = {(int64_t)n[0], (int64_t)n[1], (int64_t)n[2]};
+  uint64_t as = 0;
+  bool sat = false;
+  for (int k = 0; k < 3; ++k) {
+    const uint64_t x = nv[k] < 0 ? (uint64_t)0 - (uint64_t)nv[k] : (uint64_t)nv[k];
+    if (x > 0x7FFFFFFFFFFFFFFFull || as > 0x7FFFFFFFFFFFFFFFull - x) sat = true; else as += x;
+  }
+  const int64_t abs_sum = sat ? 0x7FFFFFFFFFFFFFFFll : (int64_t)as, upper = (int64_t)1 << 29;
+  if (abs_sum > upper) { const int64_t q = abs_sum / upper; for (int k = 0; k < 3; ++k) nv[k] /= q; }
+  int32_t v3[3] = {(int32_t)nv[0], (int32_t)nv[1], (int32_t)nv[2]};
+  auto abs64 = [](int32_t x) { return x < 0 ? -(int64_t)x : (int64_t)x; };
+  const int64_t s3 = abs64(v3[0]) + abs64(v3[1]) + abs64(v3[2]);
+  if (s3 == 0) v3[0] = o.center;
+  else {
+    v3[0] = (int32_t)(((int64_t)v3[0] * o.center) / s3);
+    v3[1] = (int32_t)(((int64_t)v3[1] * o.center) / s3);
+    const int32_t rest = o.center - (int32_t)abs64(v3[0]) - (int32_t)abs64(v3[1]);
+    v3[2] = v3[2] >= 0 ? rest : -rest;
+  }
+  if (flip) { v3[0] = -v3[0]; v3[1] = -v3[1]; v3[2] = -v3[2]; }
+  int32_t ps, pt;
+  if (v3[0] >= 0) { ps = v3[1] + o.center; pt = v3[2] + o.center; }
+  else {
+    const int32_t a1 = (int32_t)abs64(v3[1]), a2 = (int32_t)abs64(v3[2]);
+    ps = v3[1] < 0 ? a2 : max_value - a2;
+    pt = v3[2] < 0 ? a1 : max_value - a1;
+  }
+  if ((ps == 0 && pt == 0) || (ps == 0 && pt == max_value) || (ps == max_value && pt == 0)) { ps = max_value; pt = max_value; }
+  else if (ps == 0 && pt > o.center) pt = o.center - (pt - o.center);
+  else if (ps == max_value && pt < o.center) pt = o.center + (o.center - pt);
+  else if (pt == max_value && ps < o.center) ps = o.center + (o.center - ps);
+  else if (pt == 0 && ps > o.center) ps = o.center - (ps - o.center);
+  oct_original(o, canonical, ps, pt, c0, c1, os, ot);
+}
+
 __device__ __forceinline__ int32_t wrap_original(int32_t pred, int32_t corr, int32_t mn, int32_t mx, int32_t max_dif) {
   int32_t p = pred > mx ? mx : (pred < mn ? mn : pred);       // PredictionSchemeWrapTransform.cs:67-86
   int32_t o = (int32_t)((uint32_t)p + (uint32_t)corr);       // PredictionSchemeWrapDecodingTransform.cs:46-67

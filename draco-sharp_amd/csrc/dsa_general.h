@@ -520,7 +520,6 @@ __device__ __forceinline__ bool geometric_normal_oct(MeshDesc *D, const T &t, co
                                      const uint32_t *entry_to_point, uint32_t v2d_size, const int32_t *pos, const uint32_t *pos_map,
                                      uint32_t num_points, uint32_t pos_entries, const uint8_t *flips, const OctParams &o, bool canonical, uint32_t max_steps,
                                      uint32_t lane, uint32_t nl) {
-  const int32_t max_value = o.max_q - 1;
   for (uint32_t p = lane; p < entries; p += nl) {                // entries are independent of each other: element parallel
     const uint32_t ci = d2c[p];
     int64_t center[3] = {0, 0, 0};
@@ -558,40 +557,8 @@ __device__ __forceinline__ bool geometric_normal_oct(MeshDesc *D, const T &t, co
       } else c = t.swing_right(c);
     }
 #undef G_POS
-    int64_t nv[3] = {(int64_t)n[0], (int64_t)n[1], (int64_t)n[2]};
-    uint64_t as = 0;
-    bool sat = false;
-    for (int k = 0; k < 3; ++k) {
-      const uint64_t x = nv[k] < 0 ? (uint64_t)0 - (uint64_t)nv[k] : (uint64_t)nv[k];
-      if (x > 0x7FFFFFFFFFFFFFFFull || as > 0x7FFFFFFFFFFFFFFFull - x) sat = true; else as += x;
-    }
-    const int64_t abs_sum = sat ? 0x7FFFFFFFFFFFFFFFll : (int64_t)as, upper = (int64_t)1 << 29;
-    if (abs_sum > upper) { const int64_t q = abs_sum / upper; for (int k = 0; k < 3; ++k) nv[k] /= q; }
-    int32_t v3[3] = {(int32_t)nv[0], (int32_t)nv[1], (int32_t)nv[2]};
-    auto abs64 = [](int32_t x) { return x < 0 ? -(int64_t)x : (int64_t)x; };
-    const int64_t s3 = abs64(v3[0]) + abs64(v3[1]) + abs64(v3[2]);
-    if (s3 == 0) v3[0] = o.center;
-    else {
-      v3[0] = (int32_t)(((int64_t)v3[0] * o.center) / s3);
-      v3[1] = (int32_t)(((int64_t)v3[1] * o.center) / s3);
-      const int32_t rest = o.center - (int32_t)abs64(v3[0]) - (int32_t)abs64(v3[1]);
-      v3[2] = v3[2] >= 0 ? rest : -rest;
-    }
-    if (flips[p]) { v3[0] = -v3[0]; v3[1] = -v3[1]; v3[2] = -v3[2]; }
-    int32_t ps, pt;
-    if (v3[0] >= 0) { ps = v3[1] + o.center; pt = v3[2] + o.center; }
-    else {
-      const int32_t a1 = (int32_t)abs64(v3[1]), a2 = (int32_t)abs64(v3[2]);
-      ps = v3[1] < 0 ? a2 : max_value - a2;
-      pt = v3[2] < 0 ? a1 : max_value - a1;
-    }
-    if ((ps == 0 && pt == 0) || (ps == 0 && pt == max_value) || (ps == max_value && pt == 0)) { ps = max_value; pt = max_value; }
-    else if (ps == 0 && pt > o.center) pt = o.center - (pt - o.center);
-    else if (ps == max_value && pt < o.center) pt = o.center + (o.center - pt);
-    else if (pt == max_value && ps < o.center) ps = o.center + (o.center - ps);
-    else if (pt == 0 && ps > o.center) ps = o.center - (ps - o.center);
     int32_t os, ot;
-    oct_original(o, canonical, ps, pt, w[2 * p], w[2 * p + 1], os, ot);
+    geometric_normal_finish(o, canonical, n, flips[p] != 0, w[2 * p], w[2 * p + 1], os, ot);
     w[2 * p] = os; w[2 * p + 1] = ot;
   }
   return true;

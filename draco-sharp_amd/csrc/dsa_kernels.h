@@ -64,7 +64,7 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uin
 #define SYM_EARLY_ONLY 0x100u
 #define SYM_LATE_ONLY 0x200u
 __device__ __forceinline__ bool sym_filtered(const AttrDesc &a, uint32_t flags) {
-  const bool late = a.have_scheme && a.pred_kind == 1;
+  const bool late = a.have_scheme && a.pred_kind != 0;      // parallelogram, geometric normal: after the traversal
   return ((flags & SYM_EARLY_ONLY) && late) || ((flags & SYM_LATE_ONLY) && !late);
 }
 __device__ __forceinline__ uint64_t clk() { return __builtin_amdgcn_s_memtime(); }
@@ -1881,7 +1881,7 @@ __device__ __forceinline__ void finalize_attribute(uint8_t *arena, const MeshLay
 __device__ __forceinline__ void early_tail(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t flags) {
   if (!(flags & SYM_EARLY_FUSE) || D->general) return;
   const AttrDesc &a = D->att[ai];
-  if (a.have_scheme && a.pred_kind == 1) return;                 // late: waits for the traversal
+  if (a.have_scheme && a.pred_kind != 0) return;                 // late: waits for the traversal
   WAIT_VM0();
   __threadfence_block();
   __syncthreads();
@@ -2361,6 +2361,7 @@ __device__ __forceinline__ void predict_wave(uint8_t *arena, const MeshLayout &L
   if (wrap_fast_ok(a, flags)) return;                    // k_predict_wrap
   if (lanes::ln_oct_eligible(a, flags)) return;          // k_predict_oct_lanes
   if ((flags & OS_FLAG) && oct_stream_eligible(a)) return;   // k_predict_oct_streams
+  if (a.pred_kind == 2) return;                                // k_predict_geometric
   if ((a.pred_kind == 1) != (phase == 1)) return;
   int32_t *w = (int32_t *)(arena + L.work[ai]);
   const uint32_t nc = a.nc_portable, entries = a.num_entries;
@@ -2853,7 +2854,7 @@ __global__ __launch_bounds__(WAVE) void k_predict_wrap(uint8_t *arena, const Mes
 // One attribute's share of k_finalize for the threads (tid, tid + stride, ...): a 256-thread grid slice, or one wave.
 __device__ __forceinline__ void finalize_attribute(uint8_t *arena, const MeshLayout &L, const MeshDesc *D, uint32_t ai, uint32_t phase, uint32_t flags, uint32_t tid, uint32_t stride) {
   const AttrDesc &a = D->att[ai];
-  const bool late = D->general || (a.have_scheme && a.pred_kind == 1);
+  const bool late = D->general || (a.have_scheme && a.pred_kind != 0);
   if (late != (phase == 1)) return;
   if (!D->general && pw_dequant_fused(a, flags)) return;      // k_predict_wrap wrote the floats
   const int32_t *w = (const int32_t *)(arena + L.work[ai]);
@@ -2908,6 +2909,123 @@ __global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayo
   if (D->status != ST_OK || ai >= D->num_attributes) return;
   if (phase == 0 && D->att[ai].early_done) return;
   finalize_attribute(arena, layouts[mesh], D, ai, phase, flags, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// =========================================================================
+// GeometricNormal prediction on the fast kernels (MeshPredictionSchemeGeometricNormalDecoder.cs:44-82, what stock encoders pick
+// for normals at their default level).  The prediction of an entry is the area-weighted sum of the face normals around its
+// vertex, from the decoded quantised positions: nothing of it depends on other normals, so the entries of a mesh are
+// independent -- but for the flip bit each carries, a serial rABS stream.
+//   k_flip_bits         one lane per (mesh, attribute), from the start of the decode (it needs k_locate's offsets only): the bits,
+//                       packed 32 to a word, into the mesh's vertex-stamp region (4 bytes per vertex that only the general path
+//                       uses: room for the bits of 32 attributes; the attribute's own output region holds the symbol
+//                       kernels' tables until the values are written)
+//   k_predict_geometric one thread per entry, behind the traversal and the prediction of the positions: the fan of corners
+//                       around the vertex on the face records (VertexCornersIterator.cs: left from the corner the entry was
+//                       reached through, then right from it; D-10), the sums in the bitstream's 64-bit arithmetic, then
+//                       geometric_normal_finish (dsa_common.h) with the entry's correction, in place.
+// =========================================================================
+__device__ __forceinline__ uint32_t *flip_bits_of(uint8_t *arena, const MeshLayout &L, uint32_t ai) {
+  return (uint32_t *)(arena + L.vstamp) + (size_t)ai * ((L.cap_vertices + 31u) / 32u);
+}
+__global__ __launch_bounds__(WAVE) void k_flip_bits(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t lanes_per_mesh) {
+  const uint32_t lane = lane_id();
+  const uint32_t mesh = blockIdx.x * (WAVE / lanes_per_mesh) + lane / lanes_per_mesh, ai = lane % lanes_per_mesh;
+  if (mesh >= n) return;
+  const MeshLayout &L = layouts[mesh];
+  MeshDesc *D = &descs[mesh];
+  if (status_of(D) != ST_OK || D->general || ai >= D->num_attributes) return;
+  const AttrDesc &a = D->att[ai];
+  if (!a.have_scheme || a.pred_kind != 2 || a.source == SRC_BYTES) return;
+  Rabs rb;
+  uint32_t endp;
+  rb.start(arena + L.stream, L.stream_len, a.off_flips, &endp);
+  if (!rb.ok) { fail(D, ST_INVALID, 655); return; }
+  uint32_t *bits = flip_bits_of(arena, L, ai);
+  const uint32_t entries = a.num_entries;
+  if (entries > L.cap_vertices) { fail(D, ST_INVALID, 657); return; }
+  uint32_t word = 0;
+  for (uint32_t p = 0; p < entries; ++p) {              // RAnsBitDecoder.cs:12-24, AnsDecoder.cs:42-56
+    word |= rb.next() << (p & 31u);
+    if ((p & 31u) == 31u) { bits[p >> 5] = word; word = 0; }
+  }
+  if (entries & 31u) bits[entries >> 5] = word;
+}
+
+template <bool CP>
+__device__ __forceinline__ void geometric_entries(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t pa, uint32_t tid, uint32_t stride) {
+  typedef Rec<CP> R;
+  const AttrDesc &a = D->att[ai];
+  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
+  const uint32_t *d2c = (const uint32_t *)(arena + L.d2c);
+  const int32_t *v2d = (const int32_t *)(arena + L.v2d);
+  const int32_t *pos = (const int32_t *)(arena + L.work[pa]);
+  const uint32_t *bits = flip_bits_of(arena, L, ai);
+  int32_t *w = (int32_t *)(arena + L.work[ai]);
+  const uint32_t entries = a.num_entries, pos_entries = D->att[pa].num_entries, NV = D->num_vertices, F = D->num_faces;
+  OctParams o;
+  const int q = 32 - __clz(a.oct_max_q);
+  o.center = ((1 << q) - 2) / 2;
+  o.max_q = (1 << q) - 1;
+  const bool canonical = a.pred_transform == 3;
+  for (uint32_t p = tid; p < entries; p += stride) {
+    const uint32_t ci = d2c[p];
+    bool ok = (ci >> 2) < F && (ci & 3u) != 3u;
+    // position of the vertex at a corner: corner -> vertex -> entry (attributes of a seam-free mesh share their sequence)
+    auto position = [&](uint32_t corner, int64_t dst[3]) {
+      const uint32_t v = R::get_v(frec, corner);
+      const int32_t d = v < NV ? v2d[v] : -1;
+      if (d < 0 || (uint32_t)d >= pos_entries) { ok = false; dst[0] = dst[1] = dst[2] = 0; return; }
+      for (int k = 0; k < 3; ++k) dst[k] = pos[(size_t)d * 3 + k];
+    };
+    uint64_t nsum[3] = {0, 0, 0};
+    if (ok) {
+      int64_t center[3];
+      position(ci, center);
+      uint32_t c = ci, steps = 0;
+      bool left = true;
+      while (c != DSA_INVALID && ok) {
+        if (++steps > 3u * F + 1u || (c >> 2) >= F) { ok = false; break; }
+        int64_t pn[3], pp[3];
+        position(qnext(c), pn);
+        position(qprev(c), pp);
+        uint64_t u[3], v[3];
+        for (int k = 0; k < 3; ++k) { u[k] = (uint64_t)(pn[k] - center[k]); v[k] = (uint64_t)(pp[k] - center[k]); }
+        nsum[0] += u[1] * v[2] - u[2] * v[1];
+        nsum[1] += u[2] * v[0] - u[0] * v[2];
+        nsum[2] += u[0] * v[1] - u[1] * v[0];
+        if (left) {
+          const uint32_t ol = R::get_o_plain(frec, qnext(c));                 // SwingLeft: Next(Opposite(Next(c)))
+          c = ol == DSA_INVALID ? DSA_INVALID : qnext(ol);
+          if (c == DSA_INVALID) { const uint32_t orr = R::get_o_plain(frec, qprev(ci)); c = orr == DSA_INVALID ? DSA_INVALID : qprev(orr); left = false; }
+          else if (c == ci) break;
+        } else {
+          const uint32_t orr = R::get_o_plain(frec, qprev(c));                // SwingRight: Previous(Opposite(Previous(c)))
+          c = orr == DSA_INVALID ? DSA_INVALID : qprev(orr);
+        }
+      }
+    }
+    if (!ok) { fail(D, ST_INVALID, 650); continue; }
+    const bool flip = (bits[p >> 5] >> (p & 31u)) & 1u;
+    int32_t os, ot;
+    geometric_normal_finish(o, canonical, nsum, flip, w[2 * p], w[2 * p + 1], os, ot);
+    w[2 * p] = os; w[2 * p + 1] = ot;
+  }
+}
+__global__ __launch_bounds__(256) void k_predict_geometric(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  const uint32_t mesh = blockIdx.y, ai = blockIdx.z;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
+  const AttrDesc &a = D->att[ai];
+  if (!a.have_scheme || a.pred_kind != 2 || a.source == SRC_BYTES || a.num_entries == 0) return;
+  uint32_t pa = ai;
+  for (uint32_t k = 0; k < ai; ++k) if (D->att[k].att_type == 0 && D->att[k].seq_type != 0) { pa = k; break; }
+  if (pa == ai) { if (threadIdx.x == 0 && blockIdx.x == 0) fail(D, ST_INVALID, 656); return; }
+  const MeshLayout &L = layouts[mesh];
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  if (L.rec_compact) geometric_entries<true>(arena, L, D, ai, pa, tid, stride);
+  else geometric_entries<false>(arena, L, D, ai, pa, tid, stride);
 }
 
 // k_faces: faces as point ids (Mesh.cs:15-69; MeshEdgeBreakerDecoder.cs:537-553,627-637) and the census of linked corners,

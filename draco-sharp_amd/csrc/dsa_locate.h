@@ -198,8 +198,9 @@ __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, Attr
       if (!(method == 0 || method == 1 || method == 6)) NOTIMPL(161);
       a.pred_kind = method == 1 ? 1 : 0;
     } else {
-      if (method == 6) NOTIMPL(DSA_SITE_RETRY_GENERAL);
-      a.pred_kind = 0;
+      // GeometricNormal (MeshPredictionSchemeGeometricNormalDecoder.cs:44-82): predicted from the decoded positions, entry by entry
+      // independently (k_predict_geometric); needs the portable positions before it in the same decoder
+      a.pred_kind = method == 6 ? 2 : 0;
     }
     if (a.pred_transform == 1) {           // PredictionSchemeWrapDecodingTransform.cs:69-75
       a.wrap_min = (int32_t)r.u32();
@@ -214,6 +215,18 @@ __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, Attr
       int q = 32 - __clz(max_q);
       REQUIRE(q >= 2 && q <= 30, 165);
       a.oct_max_q = max_q;
+      if (a.pred_kind == 2) {              // the flip bits, one per entry, behind the transform data (:71-82): an rABS block
+        Rabs rd;
+        uint32_t endp;
+        rd.start(s, L.stream_len, r.pos, &endp);
+        REQUIRE(rd.ok, 655);
+        a.off_flips = r.pos;
+        r.pos = endp;
+        int pa = -1;                       // parent = portable positions, SequentialAttributeDecoder.cs:58-73
+        for (int k = 0; k < ai; ++k) if (D->att[k].att_type == 0 && D->att[k].seq_type != 0) { pa = k; break; }
+        REQUIRE(pa >= 0 && D->att[pa].nc_portable == 3, 656);
+        REQUIRE(num_entries <= L.cap_vertices, 657);                  // the decoded flip bits wait in the vertex-stamp region
+      }
     }
   }
   return true;

@@ -26,7 +26,7 @@ struct AttrDesc {
   uint8_t seq_type;        // SequentialAttributeEncoderType 0..3
   int8_t decoder_id;
   int8_t pred_method;      // PredictionSchemeMethod as stored in the stream
-  int8_t pred_kind;        // scheme that runs: 0 delta, 1 parallelogram (PredictionSchemeDecoderFactory.cs:24-36)
+  int8_t pred_kind;        // scheme that runs: 0 delta, 1 parallelogram, 2 geometric normal (PredictionSchemeDecoderFactory.cs:24-36)
   int8_t pred_transform;   // PredictionSchemeTransformType
   uint8_t nc_portable;
   uint8_t source;          // SRC_*
@@ -49,6 +49,7 @@ struct AttrDesc {
   float q_range;
   uint32_t num_entries;
   uint32_t num_distinct;   // raw scheme: symbols of the alphabet with a non-zero frequency (k_locate counts them while it skips the table)
+  uint32_t off_flips;      // geometric normal: stream offset of the rABS block of flip bits (probability byte first)
   uint64_t table;          // arena offset of a cumulative table taken from the batch pool (large alphabets), else 0
 };
 

@@ -394,9 +394,10 @@ def test_many_large_alphabets_in_one_batch(ctx):
     b.close()
 
 
-def test_geometric_normal_meshes_take_the_second_chance(ctx):
-    """GeometricNormal prediction (method 6) needs the general path's tables, and the host parse cannot see the
-    method byte behind the symbol streams: k_locate hands such meshes back (DSA_SITE_RETRY_GENERAL) and
+def test_schemes_behind_the_symbol_streams_take_the_second_chance(ctx):
+    """Which prediction scheme an attribute uses stands behind its symbol stream, where the host parse does not go.
+    GeometricNormal (method 6) runs on the fast kernels (k_flip_bits, k_predict_geometric); TexCoordsPortable and the
+    multi-parallelogram schemes need the general path's tables: k_locate hands such meshes back (DSA_SITE_RETRY_GENERAL) and
     dsa_batch_wait decodes them again through k_general, next to meshes that stay on the fast kernels."""
     streams, geo = [], []
     for k, (kind, nx, ny) in enumerate(KINDS):
@@ -404,8 +405,8 @@ def test_geometric_normal_meshes_take_the_second_chance(ctx):
         g = k % 3 != 1
         streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(normal_prediction=6 if g else 0, single_connectivity=k & 1,
                                                                                   pos_bits=11 + k, normal_bits=8 + (k % 5))))
-        geo.append(g)
-    # TexCoordsPortable with standard traversal goes the same way
+        geo.append(False)
+    # TexCoordsPortable with standard traversal goes to the general path
     pos, nrm, uv, faces = synth.make_mesh(synth.HOLES, 20, 16, 22)
     for npred in (0, 6):
         streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(uv_prediction=5, normal_prediction=npred)))
@@ -418,7 +419,7 @@ def test_geometric_normal_meshes_take_the_second_chance(ctx):
     for i, sbytes in enumerate(streams):
         assert b.status(i) == 0, (i, b.status(i), b.mesh_info(i).detail)
         ref = oracle.decode(sbytes)
-        assert any(x.pred_method in (2, 4, 5, 6) for x in ref.attributes) == geo[i]
+        assert any(x.pred_method in (2, 4, 5) for x in ref.attributes) == geo[i]
         assert_same(b.result(i), ref, b, i)
         assert (b.debug_array(i, 4, np.uint32, 12)[6] == 0) == geo[i]      # decoded by k_general / by the fast kernels
     # decoding the same batch again rebuilds the second-chance batch
@@ -712,4 +713,34 @@ def test_octahedral_delta_one_lane_per_stream(ctx, monkeypatch):
         assert b.status(i) == 0, (i, b.mesh_info(i).detail)
     for i in list(range(0, 3648, 37)) + [3647]:
         assert_same(b.result(i), refs[i % len(streams)], b, i)
+    b.close()
+
+
+def test_geometric_normals_on_the_fast_kernels(ctx):
+    """GeometricNormal prediction (what stock encoders pick for normals at their default level) without the general path:
+    every topology (fans around boundary vertices, handles, several components), valence-coded connectivity as stock encoders
+    write it, octahedra of 2 - 14 bits, positions by parallelogram or by difference (the early strand) -- equal to the oracle,
+    decode_path 0; and a 64k-triangle mesh."""
+    streams = []
+    for k, (kind, nx, ny) in enumerate(KINDS + [(synth.SPHERE, 21, 17), (synth.HOLES, 33, 29), (synth.GRID, 128, 256)]):
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 60 + k)
+        for j, (bits, conn, ppred) in enumerate(((8, 0, 1), (10, 2, 1), (3, 0, 0), (14, 2, 0))):
+            if kind == synth.GRID and nx == 128 and j > 1:
+                continue
+            with_uv = (k + j) % 2 == 0
+            streams.append(synth.encode_mesh(pos, faces, nrm, uv if with_uv else None,
+                                             opt=synth.options(normal_prediction=6, normal_bits=bits, predictive_connectivity=conn, pos_prediction=ppred,
+                                                               single_connectivity=1)))
+    b = run_batch(ctx, streams)
+    fast = 0
+    for i, s in enumerate(streams):
+        assert b.status(i) == 0, (i, b.mesh_info(i).detail)
+        ref = oracle.decode(s)
+        assert any(x.pred_method == 6 for x in ref.attributes)
+        assert_same(b.result(i), ref, b, i)
+        info = b.mesh_info(i)
+        # small valence-coded meshes may carry tagged context lists, which the general path decodes (decode_path 2)
+        assert info.decode_path == 0 or (info.decode_path == 2 and ref.num_faces < 1000 and ref.traversal_type == 2), (i, info.decode_path)
+        fast += info.decode_path == 0
+    assert fast >= len(streams) * 2 // 3
     b.close()
