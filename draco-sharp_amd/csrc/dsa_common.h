@@ -455,6 +455,22 @@ __device__ __forceinline__ void oct_pk_entry(OctPkLane &s, const OctParams &o, i
   os = (int32_t)(v & 0xFFFFu); ot = (int32_t)(v >> 16);
 }
 
+// x / y for y > 0, truncated toward zero as the C# and C++ operators do, without the compiler's 64-bit division routine (a hundred
+// vector instructions on the device): for |x| < 2^52 the quotient of the magnitudes from a double division, which is off by at
+// most two, then put right by comparing remainders -- exact whatever the rounding was.  Larger dividends take the operator.
+__device__ __forceinline__ int64_t div_trunc_pos(int64_t x, int64_t y) {
+  const uint64_t ax = x < 0 ? (uint64_t)0 - (uint64_t)x : (uint64_t)x, uy = (uint64_t)y;
+  if (ax >> 52) return x / y;
+  uint64_t q = (uint64_t)((double)ax / (double)uy);
+  int64_t r = (int64_t)(ax - q * uy);
+  if (r < 0) { --q; r += y; }
+  if (r < 0) { --q; r += y; }
+  if (r < 0) { --q; r += y; }
+  if (r >= y) { ++q; r -= y; }
+  if (r >= y) { ++q; r -= y; }
+  if (r >= y) { ++q; r -= y; }
+  return x < 0 ? -(int64_t)q : (int64_t)q;
+}
 // GeometricNormal, from the summed face normals n around the vertex to the value (MeshPredictionSchemeGeometricNormalPredictorArea.cs:43-63,
 // MeshPredictionSchemeGeometricNormalDecoder.cs:56-69, OctahedronToolBox.cs:28-77,121-137 with the bitstream's 64-bit arithmetic,
 // D-9, D-23..D-25): scale into 2^29, project on the octahedron of the transform, flip, canonical (s, t), then the octahedral
@@ -470,14 +486,14 @@ __device__ __forceinline__ void geometric_normal_finish(const OctParams &o, bool
     if (x > 0x7FFFFFFFFFFFFFFFull || as > 0x7FFFFFFFFFFFFFFFull - x) sat = true; else as += x;
   }
   const int64_t abs_sum = sat ? 0x7FFFFFFFFFFFFFFFll : (int64_t)as, upper = (int64_t)1 << 29;
-  if (abs_sum > upper) { const int64_t q = abs_sum / upper; for (int k = 0; k < 3; ++k) nv[k] /= q; }
+  if (abs_sum > upper) { const int64_t q = abs_sum >> 29; for (int k = 0; k < 3; ++k) nv[k] = div_trunc_pos(nv[k], q); }      // abs_sum / upper
   int32_t v3[3] = {(int32_t)nv[0], (int32_t)nv[1], (int32_t)nv[2]};
   auto abs64 = [](int32_t x) { return x < 0 ? -(int64_t)x : (int64_t)x; };
   const int64_t s3 = abs64(v3[0]) + abs64(v3[1]) + abs64(v3[2]);
   if (s3 == 0) v3[0] = o.center;
   else {
-    v3[0] = (int32_t)(((int64_t)v3[0] * o.center) / s3);
-    v3[1] = (int32_t)(((int64_t)v3[1] * o.center) / s3);
+    v3[0] = (int32_t)div_trunc_pos((int64_t)v3[0] * o.center, s3);
+    v3[1] = (int32_t)div_trunc_pos((int64_t)v3[1] * o.center, s3);
     const int32_t rest = o.center - (int32_t)abs64(v3[0]) - (int32_t)abs64(v3[1]);
     v3[2] = v3[2] >= 0 ? rest : -rest;
   }

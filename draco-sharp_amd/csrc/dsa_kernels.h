@@ -2952,17 +2952,19 @@ __global__ __launch_bounds__(WAVE) void k_flip_bits(uint8_t *arena, const MeshLa
   if (entries & 31u) bits[entries >> 5] = word;
 }
 
-template <bool CP>
-__device__ __forceinline__ void geometric_entries(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t pa, uint32_t tid, uint32_t stride) {
+// NARROW: the positions are quantised (below 2^30), so the edge vectors fit 32 bits and a term of the cross product is one
+// 32 x 32 -> 64 multiplication (the same value as the bitstream's 64-bit product)
+template <bool CP, bool NARROW>
+__device__ __forceinline__ void geometric_entries(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t tid, uint32_t stride) {
+  typedef typename std::conditional<NARROW, int32_t, int64_t>::type coord;
   typedef Rec<CP> R;
   const AttrDesc &a = D->att[ai];
   const uint32_t *frec = (const uint32_t *)(arena + L.frec);
   const uint32_t *d2c = (const uint32_t *)(arena + L.d2c);
-  const int32_t *v2d = (const int32_t *)(arena + L.v2d);
-  const int32_t *pos = (const int32_t *)(arena + L.work[pa]);
+  const int32_t *posv = (const int32_t *)(arena + L.para);       // k_vertex_positions
   const uint32_t *bits = flip_bits_of(arena, L, ai);
   int32_t *w = (int32_t *)(arena + L.work[ai]);
-  const uint32_t entries = a.num_entries, pos_entries = D->att[pa].num_entries, NV = D->num_vertices, F = D->num_faces;
+  const uint32_t entries = a.num_entries, NV = D->num_vertices, F = D->num_faces;
   OctParams o;
   const int q = 32 - __clz(a.oct_max_q);
   o.center = ((1 << q) - 2) / 2;
@@ -2971,38 +2973,52 @@ __device__ __forceinline__ void geometric_entries(uint8_t *arena, const MeshLayo
   for (uint32_t p = tid; p < entries; p += stride) {
     const uint32_t ci = d2c[p];
     bool ok = (ci >> 2) < F && (ci & 3u) != 3u;
-    // position of the vertex at a corner: corner -> vertex -> entry (attributes of a seam-free mesh share their sequence)
-    auto position = [&](uint32_t corner, int64_t dst[3]) {
-      const uint32_t v = R::get_v(frec, corner);
-      const int32_t d = v < NV ? v2d[v] : -1;
-      if (d < 0 || (uint32_t)d >= pos_entries) { ok = false; dst[0] = dst[1] = dst[2] = 0; return; }
-      for (int k = 0; k < 3; ++k) dst[k] = pos[(size_t)d * 3 + k];
+    auto position = [&](uint32_t v, coord dst[3]) {
+      if (v >= NV) { ok = false; dst[0] = dst[1] = dst[2] = 0; return; }
+      for (int k = 0; k < 3; ++k) dst[k] = posv[(size_t)v * 3 + k];
     };
     uint64_t nsum[3] = {0, 0, 0};
     if (ok) {
-      int64_t center[3];
-      position(ci, center);
+      // One record load per face of the fan (its vertices and its opposites), one new position per face: two faces in a row
+      // share an edge, so going left the vertex behind the corner becomes the one ahead of it, going right the other way round.
+      typename R::Raw rec = R::load(frec, ci >> 2);
+      const typename R::Raw first = rec;
+      coord center[3], pn[3], pp[3], pn0[3];
+      position(R::vertex(rec, ci & 3u), center);
+      position(R::vertex(rec, k_next(ci & 3u)), pn);
+      position(R::vertex(rec, k_prev(ci & 3u)), pp);
+      for (int k = 0; k < 3; ++k) pn0[k] = pn[k];
       uint32_t c = ci, steps = 0;
       bool left = true;
-      while (c != DSA_INVALID && ok) {
-        if (++steps > 3u * F + 1u || (c >> 2) >= F) { ok = false; break; }
-        int64_t pn[3], pp[3];
-        position(qnext(c), pn);
-        position(qprev(c), pp);
-        uint64_t u[3], v[3];
-        for (int k = 0; k < 3; ++k) { u[k] = (uint64_t)(pn[k] - center[k]); v[k] = (uint64_t)(pp[k] - center[k]); }
-        nsum[0] += u[1] * v[2] - u[2] * v[1];
-        nsum[1] += u[2] * v[0] - u[0] * v[2];
-        nsum[2] += u[0] * v[1] - u[1] * v[0];
+      while (ok) {
+        coord u[3], v[3];
+        for (int k = 0; k < 3; ++k) { u[k] = pn[k] - center[k]; v[k] = pp[k] - center[k]; }
+        nsum[0] += (uint64_t)((int64_t)u[1] * v[2]) - (uint64_t)((int64_t)u[2] * v[1]);
+        nsum[1] += (uint64_t)((int64_t)u[2] * v[0]) - (uint64_t)((int64_t)u[0] * v[2]);
+        nsum[2] += (uint64_t)((int64_t)u[0] * v[1]) - (uint64_t)((int64_t)u[1] * v[0]);
+        if (++steps > 3u * F + 1u) { ok = false; break; }
         if (left) {
-          const uint32_t ol = R::get_o_plain(frec, qnext(c));                 // SwingLeft: Next(Opposite(Next(c)))
-          c = ol == DSA_INVALID ? DSA_INVALID : qnext(ol);
-          if (c == DSA_INVALID) { const uint32_t orr = R::get_o_plain(frec, qprev(ci)); c = orr == DSA_INVALID ? DSA_INVALID : qprev(orr); left = false; }
-          else if (c == ci) break;
-        } else {
-          const uint32_t orr = R::get_o_plain(frec, qprev(c));                // SwingRight: Previous(Opposite(Previous(c)))
-          c = orr == DSA_INVALID ? DSA_INVALID : qprev(orr);
+          const uint32_t ol = R::opp(rec, k_next(c & 3u));                    // SwingLeft: Next(Opposite(Next(c)))
+          if (ol != DSA_INVALID) {
+            c = qnext(ol);
+            if (c == ci) break;                                               // all the way round
+            if ((c >> 2) >= F || (c & 3u) == 3u) { ok = false; break; }
+            rec = R::load(frec, c >> 2);
+            for (int k = 0; k < 3; ++k) pn[k] = pp[k];                         // the shared edge's far vertex is now ahead of the corner
+            position(R::vertex(rec, k_prev(c & 3u)), pp);
+            continue;
+          }
+          left = false;                                                       // a boundary: the rest of the fan to the right of the start corner
+          c = ci; rec = first;
+          for (int k = 0; k < 3; ++k) pn[k] = pn0[k];
         }
+        const uint32_t orr = R::opp(rec, k_prev(c & 3u));                     // SwingRight: Previous(Opposite(Previous(c)))
+        if (orr == DSA_INVALID) break;
+        c = qprev(orr);
+        if ((c >> 2) >= F || (c & 3u) == 3u) { ok = false; break; }
+        rec = R::load(frec, c >> 2);
+        for (int k = 0; k < 3; ++k) pp[k] = pn[k];                             // the shared edge's far vertex is now behind the corner
+        position(R::vertex(rec, k_next(c & 3u)), pn);
       }
     }
     if (!ok) { fail(D, ST_INVALID, 650); continue; }
@@ -3019,13 +3035,42 @@ __global__ __launch_bounds__(256) void k_predict_geometric(uint8_t *arena, const
   if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
   const AttrDesc &a = D->att[ai];
   if (!a.have_scheme || a.pred_kind != 2 || a.source == SRC_BYTES || a.num_entries == 0) return;
-  uint32_t pa = ai;
-  for (uint32_t k = 0; k < ai; ++k) if (D->att[k].att_type == 0 && D->att[k].seq_type != 0) { pa = k; break; }
-  if (pa == ai) { if (threadIdx.x == 0 && blockIdx.x == 0) fail(D, ST_INVALID, 656); return; }
   const MeshLayout &L = layouts[mesh];
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-  if (L.rec_compact) geometric_entries<true>(arena, L, D, ai, pa, tid, stride);
-  else geometric_entries<false>(arena, L, D, ai, pa, tid, stride);
+  const bool narrow = D->geo_wide == 0;      // every position below 2^30 in magnitude (any quantised attribute of a sound stream)
+  if (L.rec_compact) { if (narrow) geometric_entries<true, true>(arena, L, D, ai, tid, stride); else geometric_entries<true, false>(arena, L, D, ai, tid, stride); }
+  else { if (narrow) geometric_entries<false, true>(arena, L, D, ai, tid, stride); else geometric_entries<false, false>(arena, L, D, ai, tid, stride); }
+}
+// The portable positions by vertex id (vertex -> entry -> position: the attributes of a seam-free mesh share their sequence), for
+// meshes with a GeometricNormal attribute, into the parallelogram-operand region, which the wrap prediction in front of this
+// kernel was the last to read: k_predict_geometric looks up a position per face of every fan, this saves it a hop each time.
+__global__ __launch_bounds__(256) void k_vertex_positions(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  const uint32_t mesh = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->general) return;
+  bool any = false;
+  for (uint32_t k = 0; k < D->num_attributes; ++k) any = any || (D->att[k].have_scheme && D->att[k].pred_kind == 2 && D->att[k].source != SRC_BYTES);
+  if (!any) return;
+  uint32_t pa = DSA_INVALID;
+  for (uint32_t k = 0; k < D->num_attributes; ++k) if (D->att[k].att_type == 0 && D->att[k].seq_type != 0) { pa = k; break; }
+  if (pa == DSA_INVALID || D->att[pa].nc_portable != 3) { if (threadIdx.x == 0 && blockIdx.x == 0) fail(D, ST_INVALID, 656); return; }
+  const MeshLayout &L = layouts[mesh];
+  const int32_t *v2d = (const int32_t *)(arena + L.v2d);
+  const int32_t *pos = (const int32_t *)(arena + L.work[pa]);
+  int32_t *posv = (int32_t *)(arena + L.para);
+  const uint32_t NV = D->num_vertices < L.cap_vertices ? D->num_vertices : L.cap_vertices, pos_entries = D->att[pa].num_entries;
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < NV; v += gridDim.x * blockDim.x) {
+    const int32_t d = v2d[v];
+    const bool there = d >= 0 && (uint32_t)d < pos_entries;      // a vertex of a face always is (the traversal visits every face)
+    bool big = false;
+    for (int k = 0; k < 3; ++k) {
+      const int32_t x = there ? pos[(size_t)d * 3 + k] : 0;
+      big = big || x <= -(1 << 30) || x >= (1 << 30);
+      posv[(size_t)v * 3 + k] = x;
+    }
+    if (big) D->geo_wide = 1;      // (every writer writes the same value)
+  }
 }
 
 // k_faces: faces as point ids (Mesh.cs:15-69; MeshEdgeBreakerDecoder.cs:537-553,627-637) and the census of linked corners,

@@ -86,7 +86,8 @@ struct MeshDesc {
   // one per valence class of the vertex the decoder stands on -- raw rANS streams over at most 64 symbols each
   uint32_t val_count[6], val_nsym[6], val_off_table[6], val_off_rans[6], val_size_rans[6];
   uint8_t val_prec[6];
-  uint8_t pad_val[2];
+  uint8_t geo_wide;        // k_vertex_positions: some position is not below 2^30 in magnitude (k_predict_geometric then keeps 64-bit edge vectors)
+  uint8_t pad_val;
   uint32_t dbg[20];        // diagnostics of the per-mesh kernels (tools/dbg_phases.py, bench.py): s_memtime deltas between phases;
                            // k_connectivity: [13] its s_memtime ticks, [14] its start and [15] its duration in s_memrealtime ticks
                            // (100 MHz); k_traverse: [6] ticks, [16] start, [17] duration: ticks / duration = the shader clock
