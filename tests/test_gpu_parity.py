@@ -257,8 +257,10 @@ def test_corrupt_streams_agree_with_the_oracle(ctx, house04_bytes):
     # rarer one (predictive symbols, both multi-parallelogram schemes): all general-path code
     stock = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(predictive_connectivity=2, uv_prediction=5, normal_prediction=6, traversal_method=1))
     rare = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(predictive_connectivity=1, pos_prediction=4, uv_prediction=2, single_connectivity=1))
+    # GeometricNormal on the fast kernels (the flip-bit block, the corner fans) with valence-coded connectivity
+    geo = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(predictive_connectivity=2, normal_prediction=6))
     streams = (_corruptions(base, 96, 5) + _corruptions(house04_bytes, 64, 6) + _corruptions(stock, 64, 7) + _corruptions(rare, 64, 8) +
-               [base, house04_bytes, stock, rare])
+               _corruptions(geo, 96, 9) + [base, house04_bytes, stock, rare, geo])
     b = run_batch(ctx, streams)
     agree_ok = agree_bad = gpu_stricter = 0
     stricter_sites = {}
@@ -282,9 +284,9 @@ def test_corrupt_streams_agree_with_the_oracle(ctx, house04_bytes):
     # Where the device path refuses what the oracle lets through, it is one of its own validations, by site: 123 (a traversal
     # method byte above 1, which the oracle reads as depth-first), 263 (the census of linked corners) and 681 (the general path's
     # bound on attribute seam data).  Four seeds of this mix gave 0 - 1 such streams of 292 (sites 123, 681); anything else, or
-    # more than a handful, is a difference to look at.
+    # more than a handful, is a difference to look at.  (389 streams with the GeometricNormal family.)
     assert set(stricter_sites) <= {(1, 123), (1, 263), (1, 681)}, stricter_sites
-    assert gpu_stricter <= 3, (agree_ok, agree_bad, stricter_sites)
+    assert gpu_stricter <= 4, (agree_ok, agree_bad, stricter_sites)
     b.close()
 
 
