@@ -203,46 +203,61 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
       splits[3 * nsplit] = (uint32_t)src_symbol; splits[3 * nsplit + 1] = (uint32_t)s; splits[3 * nsplit + 2] = edge;
       ++nsplit;
     };
-    auto face_done = [&](uint32_t o) { return o == DSA_INVALID || fvis[o / 3] != 0; };
+    // A step of either walk reads a handful of words that hang off each other (corner -> vertex and the corners across its two
+    // edges -> the marks of that vertex and of those two faces), and on the device every dependent read is a round trip to memory
+    // that nothing else of the wave hides.  So the reads of a step are issued together, level by level, and the first level of
+    // the next step -- for both corners it can move to -- rides along with the second level of this one: one round trip per
+    // step instead of four.  Same reads, same decisions (a face across an edge is never the face itself, whose mark this step sets).
+    struct Hop { uint32_t v, rc, lc; };                                           // vertex at a corner, corners across its right / left edge
+    auto hop = [&](uint32_t c) {
+      const uint32_t cc = c == DSA_INVALID ? 0u : c;
+      Hop h;
+      h.v = c2v[cc]; h.rc = opp[ec_next(cc)]; h.lc = opp[ec_prev(cc)];
+      return h;
+    };
     auto encode_from_corner = [&](uint32_t corner0) {                             // :185-274
       uint32_t sp = 0;
       stack[sp++] = corner0;
       while (sp && !failed) {
         uint32_t corner = stack[sp - 1];
         if (corner == DSA_INVALID || fvis[corner / 3]) { --sp; continue; }
+        Hop cur = hop(corner);
         for (;;) {
           if (runaway() || nsym >= F || nproc >= F || sp >= F) { failed = true; break; }
           ++last_symbol_id;
           const uint32_t face = corner / 3;
+          const uint32_t v = cur.v, rc = cur.rc, lc = cur.lc;
+          const uint32_t rf = rc == DSA_INVALID ? DSA_INVALID : rc / 3, lf = lc == DSA_INVALID ? DSA_INVALID : lc / 3;
+          const int32_t hid = hole_id[v];
+          const bool seen = vvis[v] != 0;
+          const bool r_done = rf == DSA_INVALID || rf == face || fvis[rf] != 0, l_done = lf == DSA_INVALID || lf == face || fvis[lf] != 0;
+          const Hop hr = hop(rc), hl = hop(lc);
           fvis[face] = 1;
           processed[nproc++] = corner;
-          const uint32_t v = c2v[corner];
-          const bool on_boundary = hole_id[v] != -1;
-          if (!vvis[v]) {
+          const bool on_boundary = hid != -1;
+          if (!seen) {
             vvis[v] = 1;
-            if (!on_boundary) { symbols[nsym++] = 0; corner = ct.right_corner(corner); continue; }
+            if (!on_boundary) { symbols[nsym++] = 0; corner = rc; cur = hr; continue; }
           }
-          const uint32_t rc = ct.right_corner(corner), lc = ct.left_corner(corner);
-          const uint32_t rf = rc == DSA_INVALID ? DSA_INVALID : rc / 3, lf = lc == DSA_INVALID ? DSA_INVALID : lc / 3;
-          if (face_done(rc)) {
+          if (r_done) {
             if (rf != DSA_INVALID) check_split(last_symbol_id, 1, rf);
-            if (face_done(lc)) {
+            if (l_done) {
               if (lf != DSA_INVALID) check_split(last_symbol_id, 0, lf);
               symbols[nsym++] = 7;
               --sp;
               break;
             }
             symbols[nsym++] = 5;
-            corner = lc;
+            corner = lc; cur = hl;
           } else {
-            if (face_done(lc)) {
+            if (l_done) {
               if (lf != DSA_INVALID) check_split(last_symbol_id, 0, lf);
               symbols[nsym++] = 3;
-              corner = rc;
+              corner = rc; cur = hr;
             } else {
               symbols[nsym++] = 1;
               ++nsplit_sym;
-              if (on_boundary) { const int32_t hid = hole_id[v]; if (!hole_vis[hid]) encode_hole(corner, false); }
+              if (on_boundary) { if (!hole_vis[hid]) encode_hole(corner, false); }
               split_sym[face] = last_symbol_id;
               stack[sp - 1] = lc;
               stack[sp++] = rc;                       // sp <= F: every push marks a face first
@@ -313,22 +328,28 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
         uint32_t corner = stack[sp - 1];
         uint32_t face = corner == DSA_INVALID ? DSA_INVALID : corner / 3;
         if (corner == DSA_INVALID || fdone(face)) { --sp; continue; }
+        // (the reads of a step together, the next step's first reads with them: see the Edgebreaker walk above.  A vertex is
+        // on a boundary -- SwingLeft of its left-most corner is invalid -- exactly when the hole pass gave it an id.)
+        uint32_t cv = c2v[corner], crc = opp[ec_next(corner)], clc = opp[ec_prev(corner)];
         for (;;) {
           if (++dfs_steps > 64u * NC + 4096u || sp >= F || count > V) { stuck = true; break; }
-          fvis[face] = 1;
-          const uint32_t v = c2v[corner];
-          if (!vvis[v]) {
-            const bool ob = ct.swing_left(vcorner[v]) == DSA_INVALID;
-            visit(v, corner);
-            if (!ob) { corner = ct.right_corner(corner); face = corner / 3; continue; }
-          }
-          const uint32_t rc = ct.right_corner(corner), lc = ct.left_corner(corner);
+          const uint32_t v = cv, rc = crc, lc = clc;
           const uint32_t rf = rc == DSA_INVALID ? DSA_INVALID : rc / 3, lf = lc == DSA_INVALID ? DSA_INVALID : lc / 3;
-          if (fdone(rf)) {
-            if (fdone(lf)) { --sp; break; }
-            corner = lc; face = lf;
+          const bool seen = vvis[v] != 0, ob = hole_id[v] != -1;
+          const bool r_done = rf == DSA_INVALID || rf == face || fvis[rf] != 0, l_done = lf == DSA_INVALID || lf == face || fvis[lf] != 0;
+          const uint32_t rcc = rc == DSA_INVALID ? 0u : rc, lcc = lc == DSA_INVALID ? 0u : lc;
+          const uint32_t rv = c2v[rcc], rrc = opp[ec_next(rcc)], rlc = opp[ec_prev(rcc)];
+          const uint32_t lv = c2v[lcc], lrc = opp[ec_next(lcc)], llc = opp[ec_prev(lcc)];
+          fvis[face] = 1;
+          if (!seen) {
+            visit(v, corner);
+            if (!ob) { corner = rc; face = rf; cv = rv; crc = rrc; clc = rlc; continue; }
+          }
+          if (r_done) {
+            if (l_done) { --sp; break; }
+            corner = lc; face = lf; cv = lv; crc = lrc; clc = llc;
           } else {
-            if (fdone(lf)) { corner = rc; face = rf; }
+            if (l_done) { corner = rc; face = rf; cv = rv; crc = rrc; clc = rlc; }
             else { stack[sp - 1] = lc; stack[sp++] = rc; break; }
           }
         }
