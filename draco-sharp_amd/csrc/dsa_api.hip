@@ -554,16 +554,18 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // options keep the single symbol launch.
   const bool sym_split = !serial && !(lane_flags & (LN_FLAG_SYMBOLS | LN_FLAG_PREDICT)) && split_mode != 0;
   hipStream_t st4 = sym_split ? ctx->stream4 : st2;
-  const uint32_t tier_blocks = (uint32_t)std::min<uint64_t>((uint64_t)n * na, SYM_TIER_BLOCKS);
-  auto launch_symbols = [&](hipStream_t s, uint32_t fl) {
+  // (gate: k_register_gate in front of the 12-bit kernel, see the crowded-batch schedule below)
+  auto launch_symbols = [&](hipStream_t s, uint32_t fl, bool gate = false) {
     fl |= wide_flag;
+    const uint32_t tier_blocks = (uint32_t)std::min<uint64_t>((uint64_t)n * na, SYM_TIER_BLOCKS);
     // The kernels for everything but 12-bit-precision streams go first: for most batches they find nothing to do, which takes
     // them microseconds while the machine is still filling and a millisecond and a half once every slot is held by a decoder
     // (they used to follow k_symbols_reg: 1.7 ms of empty launches in front of the early attributes' prediction).
     if (wide_flag) hipLaunchKernelGGL(dsa::k_symbols_wide, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
-    hipLaunchKernelGGL(dsa::k_symbols<1>, dim3(tier_blocks), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, na, fl);
-    hipLaunchKernelGGL(dsa::k_symbols<0>, dim3(tier_blocks), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, na, fl);
-    hipLaunchKernelGGL(dsa::k_symbols<2>, dim3(tier_blocks), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, na, fl);
+    hipLaunchKernelGGL(dsa::k_symbols<1>, dim3(tier_blocks), dim3(WAVE), dsa::sym_tier_lds_bytes(1), s, b->arena, b->d_layouts, b->d_descs, n, na, fl);
+    hipLaunchKernelGGL(dsa::k_symbols<0>, dim3(tier_blocks), dim3(WAVE), dsa::sym_tier_lds_bytes(0), s, b->arena, b->d_layouts, b->d_descs, n, na, fl);
+    hipLaunchKernelGGL(dsa::k_symbols<2>, dim3(tier_blocks), dim3(WAVE), dsa::sym_tier_lds_bytes(2), s, b->arena, b->d_layouts, b->d_descs, n, na, fl);
+    if (gate) hipLaunchKernelGGL(dsa::k_register_gate, dim3(SYM_TIER_BLOCKS), dim3(WAVE), 0, s);
     hipLaunchKernelGGL(dsa::k_symbols_reg, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
   };
   {
@@ -584,6 +586,18 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st2));
     HIP_TRY(ctx, hipStreamWaitEvent(st4, ctx->ev_conn, 0));
     launch_symbols(st2, lane_flags | SYM_LATE_ONLY);
+  } else if (sym_split && oct_flag) {
+    // The early attributes have the longer tail behind their symbols when the octahedral delta runs one lane per stream (a
+    // chain of 10 - 14 ms), so they get a head start: the late attributes' 12-bit kernel stands behind k_register_gate, idle
+    // waves that ask for 136 registers each -- which a SIMD holding four chain waves and three decoders only has once decoders
+    // leave and no block of the early kernel is waiting to take their place, i.e. when the early kernel is dispatched to its
+    // last block (9 ms into the decode).  The early symbols then end at 17 ms of 33 instead of 27, and the stream kernel in the
+    // shadow of the chain.  (Late after ALL early symbols: a millisecond slower.  Early symbols in two launches with the late
+    // ones behind the first: the second launch shares the freed slots with the late kernel block for block and ends at 28 ms.
+    // Until the registers of the 16 KB tier were put right its idle waves did this by accident.)
+    HIP_TRY(ctx, hipStreamWaitEvent(st4, ctx->ev_conn, 0));
+    launch_symbols(st4, lane_flags | SYM_EARLY_ONLY | early_fuse);
+    launch_symbols(st2, lane_flags | SYM_LATE_ONLY, true);
   } else if (sym_split) {                      // both at once, the early ones on the stream with priority
     HIP_TRY(ctx, hipStreamWaitEvent(st4, ctx->ev_conn, 0));
     launch_symbols(st4, lane_flags | SYM_EARLY_ONLY | early_fuse);

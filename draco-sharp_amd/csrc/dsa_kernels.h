@@ -2317,16 +2317,25 @@ __device__ __forceinline__ void symbols_tier_item(uint8_t *arena, const MeshLayo
 // 17 KB for tier 2) even to find that out, which beside the chain and decoder waves it gets one at a time.  So a launch is a
 // fixed number of waves that walk the (mesh, attribute) items with a stride, instead of one wave per item.
 #define SYM_TIER_BLOCKS 2048u
+// The cumulative table is dynamic LDS (sym_tier_lds_bytes at launch): with a size the compiler can see it allocates the registers
+// that size's occupancy would allow -- 136 for the 16 KB tier where the kernel needs 46 -- and the waves of a tier that has
+// nothing to do then wait, 8 ms on the bench batch, for SIMDs with that many registers free.
+constexpr uint32_t sym_tier_lds_bytes(int tier) { return ((tier == 0 ? 64u : (tier == 1 ? 960u : (uint32_t)SYM_MAX_LDS)) + WAVE + 1u) * 4u; }
+extern __shared__ __attribute__((aligned(16))) uint32_t sh_tier[];
 template <int TIER>
-__global__ __launch_bounds__(WAVE) void k_symbols(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t na, uint32_t flags) {
-  constexpr uint32_t LDS_SYMS = TIER == 0 ? 64 : (TIER == 1 ? 960 : SYM_MAX_LDS);
-  __shared__ uint32_t lds_cum[LDS_SYMS + WAVE + 1];
+__global__ __launch_bounds__(WAVE, 8) void k_symbols(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t na, uint32_t flags) {
+  uint32_t *lds_cum = sh_tier;
   const uint64_t items = (uint64_t)n * na;
   for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
     symbols_tier_item<TIER>(arena, layouts, descs, (uint32_t)(it % n), (uint32_t)(it / n), flags, lds_cum);
     __syncthreads();                                     // the next item reuses the LDS table
   }
 }
+
+// k_register_gate: waves that do nothing but need 136 vector registers to be placed.  On a stream it holds back what follows until
+// SIMDs have that many free -- on a machine filled by an earlier launch of 80-register decoders beside the 64-register chain
+// waves, until that launch has no block left waiting for a slot (dsa_api.hip: the crowded-batch schedule of the symbol kernels).
+__global__ __launch_bounds__(WAVE) void k_register_gate() { asm volatile("v_mov_b32 v135, 0" ::: "v135"); }
 
 // =========================================================================
 // k_predict: inverse prediction, in place on the work buffer.
