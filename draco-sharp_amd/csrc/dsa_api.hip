@@ -653,7 +653,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     // GeometricNormal attributes: from the final positions (of whichever strand) and the flip bits
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_early, 0));
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_flips, 0));
-    uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 4095) / 4096, 8));
+    const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 1023) / 1024, 32));     // four entries per thread: 11.6 -> 9.7 ms against sixteen
     const uint32_t gv = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 1023) / 1024, 64));     // two dependent gathers per vertex: many short threads
     hipLaunchKernelGGL(dsa::k_vertex_positions, dim3(gv, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_predict_geometric, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
