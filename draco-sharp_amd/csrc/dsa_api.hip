@@ -442,6 +442,12 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_init, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, n);
   }
   hipLaunchKernelGGL(dsa::k_locate, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, b->d_globals);
+  // tagged symbol streams: a round of {tag stream on a wave of its own, the walk taken up behind it} per attribute a mesh can
+  // have (what follows a tagged attribute is only found by decoding its tags); nothing to do without them
+  for (uint32_t r = 0; r < std::max<uint32_t>(1, b->max_atts); ++r) {
+    hipLaunchKernelGGL(dsa::k_tags, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+    hipLaunchKernelGGL(dsa::k_locate_resume, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, b->d_globals);
+  }
   HIP_TRY(ctx, mark());
   const uint32_t na = std::max<uint32_t>(1, b->max_atts);
   // fork: entropy decode of every attribute stream on the second stream (it only needs k_locate's offsets)

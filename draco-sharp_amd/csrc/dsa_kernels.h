@@ -179,14 +179,31 @@ __device__ __forceinline__ uint32_t k_next(uint32_t k) { return k == 2u ? 0u : k
 __device__ __forceinline__ uint32_t k_prev(uint32_t k) { return k == 0u ? 2u : k - 1u; }
 
 // =========================================================================
-// k_locate: one wave per mesh, lane 0 walks the stream (dsa_locate.h).
+// k_locate, k_locate_resume: one wave per mesh, lane 0 walks the stream (dsa_locate.h).  k_locate goes to the end of the stream
+// or to the first tagged symbol stream; k_tags (below, with the symbol kernels) decodes that tag stream on the whole wave, and
+// k_locate_resume takes the walk up behind it, to the next tag stream or the end -- the host queues as many rounds of the two as
+// a mesh of the batch has attributes; without tagged streams they find nothing to do.  (A tag stream k_tags is not made for -- a
+// mesh too small for its tables, a one-tag alphabet -- is decoded by the resuming lane itself, as every tag stream used to be:
+// 23 ms in front of everything for the bench batch with tagged symbols.)
 // =========================================================================
 __global__ __launch_bounds__(WAVE, 4) void k_locate(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, BatchGlobals *G) {
-  __shared__ uint32_t s_cum[LOC_MAX_TAGS + 1];
-  __shared__ __attribute__((aligned(16))) uint32_t s_lut[LOC_LDS_WORDS];     // tag streams of the tagged scheme: slot table, byte ring, tags of a block
   uint32_t mesh = blockIdx.x;
   if (mesh >= n || threadIdx.x != 0) return;
-  locate_all(arena, layouts[mesh], &descs[mesh], G, s_cum, s_lut);
+  MeshDesc *D = &descs[mesh];
+  locate_mesh(arena, layouts[mesh], D);
+  if (D->status != ST_OK || D->general) return;
+  locate_attribute_headers(arena, layouts[mesh], D);
+  if (D->status != ST_OK) return;
+  locate_attribute_values(arena, layouts[mesh], D, G, nullptr, nullptr, LOC_UNTIL_TAGS);
+}
+__global__ __launch_bounds__(WAVE, 4) void k_locate_resume(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, BatchGlobals *G) {
+  __shared__ uint32_t s_cum[LOC_MAX_TAGS + 1];
+  __shared__ __attribute__((aligned(16))) uint32_t s_lut[LOC_LDS_WORDS];     // a tag stream decoded by the walk itself: slot table, byte ring, tags of a block
+  uint32_t mesh = blockIdx.x;
+  if (mesh >= n || threadIdx.x != 0) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->general || !D->values_pending) return;
+  locate_attribute_values(arena, layouts[mesh], D, G, s_cum, s_lut, LOC_RESUME);
 }
 
 // =========================================================================
@@ -1896,28 +1913,37 @@ __device__ __forceinline__ void early_tail(uint8_t *arena, const MeshLayout &L, 
   if (lane_id() == 0) D->att[ai].early_done = 1;
 }
 
-__global__ __launch_bounds__(WAVE, 6) void k_symbols_reg(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t flags) {
-  uint32_t mesh = blockIdx.x, ai = blockIdx.y;
-  if (mesh >= n) return;
-  MeshDesc *D = &descs[mesh];
-  if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
-  const MeshLayout &L = layouts[mesh];
-  const AttrDesc &a = D->att[ai];
-  if (lanes::ln_sym_eligible(a, L, ai, flags)) return;             // k_symbols_lanes
-  if (sym_filtered(a, flags)) return;                              // the other launch of the early / late pair
-  // one non-zero symbol = a frequency of 4096, which the packed {freq, rem - cum} word cannot hold: k_symbols<T> takes it
-  if (a.source != SRC_RAW || a.precision_bits != 12 || a.num_symbols > REG_MAX_SYMS || a.num_symbols <= 64 || a.num_distinct <= 1) return;
-  if (L.out_cap[ai] < 4096 * 6 + REG_MAX_SYMS * 4) return;      // scratch for the tables (k_symbols<T> takes the stream instead)
+// TAGS: the tag stream of a tagged attribute (SymbolDecoding.cs:30-50: one 5-bit tag per entry, a 12-bit-precision rANS stream like
+// any other) instead of a raw symbol stream: the attribute the walk of the mesh stopped at (k_locate / k_locate_resume); the tags go to
+// the attribute's output region as bytes, where k_symbols<0> expects them, and their bit total to the descriptor, where the walk needs
+// it to find what follows.  The tables then live behind the slots in the work region (the output region holds the tags).
+template <bool TAGS>
+__device__ __forceinline__ void reg_decode_stream(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t flags) {
+  AttrDesc &a = D->att[ai];
+  uint8_t *scratch;
+  if (TAGS) {
+    if (a.source != SRC_TAGGED || a.tags_done || a.num_symbols > LOC_MAX_TAGS || a.num_distinct <= 1 || a.num_entries == 0) return;
+    const uint64_t slots = ((uint64_t)a.num_entries * 4 + 15) & ~15ull;
+    if ((uint64_t)L.work_cap[ai] * 4 < slots + 4096 * 6 + REG_MAX_SYMS * 4) return;      // (small meshes: the walk decodes the tags itself)
+    scratch = arena + L.work[ai] + slots;
+  } else {
+    if (lanes::ln_sym_eligible(a, L, ai, flags)) return;             // k_symbols_lanes
+    if (sym_filtered(a, flags)) return;                              // the other launch of the early / late pair
+    // one non-zero symbol = a frequency of 4096, which the packed {freq, rem - cum} word cannot hold: k_symbols<T> takes it
+    if (a.source != SRC_RAW || a.precision_bits != 12 || a.num_symbols > REG_MAX_SYMS || a.num_symbols <= 64 || a.num_distinct <= 1) return;
+    if (L.out_cap[ai] < 4096 * 6 + REG_MAX_SYMS * 4) return;      // scratch for the tables (k_symbols<T> takes the stream instead)
+    scratch = arena + L.out[ai];
+  }
   const uint8_t *stream = arena + L.stream;
   uint32_t *out = (uint32_t *)(arena + L.work[ai]);
-  uint32_t *slot_tab = (uint32_t *)(arena + L.out[ai]);            // {freq | (rem - cum) << 16} per slot
-  uint16_t *slot_sym = (uint16_t *)(arena + L.out[ai] + 4096 * 4); // symbol per slot
+  uint32_t *slot_tab = (uint32_t *)scratch;                        // {freq | (rem - cum) << 16} per slot
+  uint16_t *slot_sym = (uint16_t *)(scratch + 4096 * 4);           // symbol per slot
   // probabilities, then packed {freq << 12 | cum} per symbol: global scratch rather than LDS, which the
   // connectivity and traversal waves sharing the CU need for their caches and tables
-  uint32_t *lds = (uint32_t *)(arena + L.out[ai] + 4096 * 6);
+  uint32_t *lds = (uint32_t *)(scratch + 4096 * 6);
   const uint32_t lane = lane_id();
   const uint32_t nsym = uni(a.num_symbols);
-  const uint32_t num_values = uni(a.num_entries) * a.nc_portable;
+  const uint32_t num_values = uni(a.num_entries) * (TAGS ? 1u : (uint32_t)a.nc_portable);
   if (num_values == 0) return;
   // 1. probability table -> LDS (lane 0), RAnsSymbolDecoder.cs:21-48
   if (lane == 0) {
@@ -2084,6 +2110,28 @@ __global__ __launch_bounds__(WAVE, 6) void k_symbols_reg(uint8_t *arena, const M
   }
   WAIT_VM0();
   __syncthreads();
+  if (TAGS) {
+    // 5. slot -> tag, as bytes into the output region; the bit total (tag x components, SymbolDecoding.cs:41-47) and the largest tag
+    uint8_t *tags = arena + L.out[ai];
+    uint64_t bits = 0;
+    uint32_t worst = 0;
+    const uint32_t nc = a.nc_portable;
+    for (uint32_t i = lane; i < num_values; i += WAVE) {
+      const uint32_t v = slot_sym[out[i] & 4095u];
+      tags[i] = (uint8_t)v;
+      bits += (uint64_t)v * nc;
+      worst = v > worst ? v : worst;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      bits += ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), d, WAVE) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)bits, d, WAVE);
+      const uint32_t w2 = (uint32_t)__shfl_xor((int)worst, d, WAVE);
+      worst = w2 > worst ? w2 : worst;
+    }
+    WAIT_VM0();
+    __syncthreads();
+    if (lane == 0) { a.table = (bits & 0x00FFFFFFFFFFFFFFull) | ((uint64_t)(worst > 255u ? 255u : worst) << 56); a.tags_done = 1; }
+    return;
+  }
   // 5. slot -> symbol (lane parallel), then zig-zag unless the transform's corrections are positive (D-4)
   const bool positive = a.have_scheme && (a.pred_transform == 2 || a.pred_transform == 3);
   for (uint32_t i = lane; i < num_values; i += WAVE) {
@@ -2091,6 +2139,22 @@ __global__ __launch_bounds__(WAVE, 6) void k_symbols_reg(uint8_t *arena, const M
     out[i] = positive ? v : ((v & 1u) ? (uint32_t)(-(int32_t)(v >> 1) - 1) : (v >> 1));
   }
   early_tail(arena, L, D, ai, flags);
+}
+
+__global__ __launch_bounds__(WAVE, 6) void k_symbols_reg(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t flags) {
+  uint32_t mesh = blockIdx.x, ai = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
+  reg_decode_stream<false>(arena, layouts[mesh], D, ai, flags);
+}
+// The tag stream in front of which the walk of a mesh stopped (see dsa_locate.h): one wave per mesh.
+__global__ __launch_bounds__(WAVE, 6) void k_tags(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  uint32_t mesh = blockIdx.x;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->general || !D->values_pending || D->resume_att >= D->num_attributes) return;
+  reg_decode_stream<true>(arena, layouts[mesh], D, D->resume_att, 0u);
 }
 
 // Launched once per tier so that the LDS footprint of the cumulative table does not cap occupancy:
@@ -3136,6 +3200,7 @@ __global__ __launch_bounds__(256) void k_seal(MeshDesc *descs, uint32_t n) {
   MeshDesc *D = &descs[mesh];
   if (status_of(D) != ST_OK) return;
   if (D->general) return;                              // the general path's phase 2 has compared its own census
+  if (D->values_pending) { fail(D, ST_INVALID, 159); return; }          // (the walk of the attribute sections did not get to its end)
   if (__hip_atomic_load(&D->linked_corners, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != D->interior_corners) { fail(D, ST_INVALID, 263); return; }
   // a seam among the coded bits (k_conn_checks): the attribute has a corner table of its own, which the general path builds
   if (D->encoder_type != 0)

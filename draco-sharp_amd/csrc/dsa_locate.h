@@ -21,10 +21,15 @@ static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long 
 #define LOC_LUT_SLOTS 4096   // slot table of a tag stream (12-bit precision)
 #define LOC_LDS_WORDS (LOC_LUT_SLOTS / 4 + 4 * LN_RING_CHUNKS + LN_BLOCK / 4)   // one byte per slot + byte ring + the tags of one block
 
+// One attribute's data section.  Returns 1, 0 after a failed check (status set), or 2 when the attribute's symbols are tagged and
+// the tag stream is still to be decoded (tags: LOC_TAGS_LATER): everything up to the tag stream is recorded, the caller comes back
+// to the attribute when k_tags has decoded it (a.tags_done) or decodes it here after all (LOC_TAGS_HERE).
+#define LOC_TAGS_HERE 0
+#define LOC_TAGS_LATER 1
 #undef RET
-#define RET false
-__device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, AttrDesc &a, const MeshLayout &L, int ai, uint8_t *arena,
-                                        uint32_t *s_cum, uint32_t *s_lut, uint32_t num_entries, BatchGlobals *G) {
+#define RET 0
+__device__ __forceinline__ int locate_attribute_section(Rd &r, MeshDesc *D, AttrDesc &a, const MeshLayout &L, int ai, uint8_t *arena,
+                                        uint32_t *s_cum, uint32_t *s_lut, uint32_t num_entries, BatchGlobals *G, int tags) {
   const uint8_t *s = r.p;
   a.num_entries = num_entries;
   if (a.seq_type == 0) {   // generic: raw bytes, SequentialAttributeDecoder.cs:75-86
@@ -35,7 +40,7 @@ __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, Attr
     REQUIRE(bytes <= L.out_cap[ai], 140);
     r.skip(bytes);
     REQUIRE(r.ok, 141);
-    return true;
+    return 1;
   }
   uint32_t nc = a.seq_type == 3 ? 2u : a.nc;   // normals are (s,t) in portable form
   a.nc_portable = (uint8_t)nc;
@@ -94,80 +99,98 @@ __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, Attr
         REQUIRE(r.ok && ns >= 1 && ns <= LOC_MAX_TAGS, 151);
         a.num_symbols = (uint32_t)ns;
         a.off_table = r.pos;
-        REQUIRE(read_prob_table(r, a.num_symbols, s_cum), 152);
-        uint32_t c = 0;
-        for (uint32_t i = 0; i < a.num_symbols; ++i) { uint32_t pr = s_cum[i]; REQUIRE(pr <= 4096u - c, 153); s_cum[i] = c; c += pr; }
-        s_cum[a.num_symbols] = c;
-        REQUIRE(c == 4096, 153);
-        uint64_t size = r.varint();
-        a.off_rans = r.pos;
-        r.skip(size);
-        REQUIRE(r.ok && size >= 1, 154);
-        a.size_rans = (uint32_t)size;
-        a.off_bits = r.pos;
-        // decode the tag stream; tags -> out buffer (bytes).  This chain sits in front of everything else of the mesh
-        // (the bit section behind it has no length field), so it is kept short: the tag from a byte-per-slot table of the
-        // 4096 slots (RAnsDecoder.cs:69-88), its range from the cumulative table, stream bytes from the LDS ring, the
-        // tags of a 16-entry block staged in LDS and stored with one 16-byte store at the block's boundary -- nothing
-        // inside a block waits for global memory.
-        REQUIRE(num_entries <= L.out_cap[ai], 155);
-        uint8_t *tags = arena + L.out[ai];
-        uint32_t state, off;
-        REQUIRE(rans_init(s + a.off_rans, a.size_rans, 16384, &state, &off), 156);
-        uint8_t *lut8 = (uint8_t *)s_lut;                   // slot -> tag: 4 KB, so that every mesh of a 4096-mesh batch is resident at once
-        for (uint32_t i = 0; i < a.num_symbols; ++i)
-          for (uint32_t j = s_cum[i]; j < s_cum[i + 1]; ++j) lut8[j] = (uint8_t)i;
-        uint32_t *ring = s_lut + LOC_LUT_SLOTS / 4, *tagbuf = ring + 4 * LN_RING_CHUNKS;
-        const uint8_t *ring8 = (const uint8_t *)ring;
-        uint8_t *tagbuf8 = (uint8_t *)tagbuf;
-        const uint64_t lowest = L.stream & ~15ull;
-        const uint64_t last = L.stream + a.off_rans + (off ? off - 1u : 0u);
-        const uint64_t base = (last + 16ull) & ~15ull;
-        uint32_t loaded = 0;
-        for (; loaded < 6; ++loaded) {
-          const Chunk c = ln_load_chunk(arena, base, lowest, loaded);
-          for (int k = 0; k < 4; ++k) ring[((loaded & (LN_RING_CHUNKS - 1u)) << 2) + k] = c.d[k];
-        }
-        Chunk in0 = ln_load_chunk(arena, base, lowest, loaded), in1 = ln_load_chunk(arena, base, lowest, loaded + 1);
-        bool inflight = true;
-        uint32_t q = (uint32_t)(base - 1 - last);
-        const uint32_t q_end = q + off;
-        while (state < 16384 && q < q_end) { state = (state << 8) | ring8[(q ^ 15u) & 127u]; ++q; }
         uint64_t total_bits = 0;
         uint32_t worst = 0;
-        for (uint32_t b0 = 0; b0 < num_entries; b0 += LN_BLOCK) {
-          const uint32_t cnt = num_entries - b0 < LN_BLOCK ? num_entries - b0 : LN_BLOCK;
-          for (uint32_t j = 0; j < cnt; ++j) {
-            const uint32_t y0 = ring8[(q ^ 15u) & 127u], y1 = ring8[((q + 1u) ^ 15u) & 127u];
-            const uint32_t rem = state & 4095u, sym = lut8[rem];
-            const uint32_t cs = s_cum[sym], f = s_cum[sym + 1] - cs;
-            state = (state >> 12) * f + rem - cs;
-            tagbuf8[j] = (uint8_t)sym;
-            worst = sym > worst ? sym : worst;
-            total_bits += (uint64_t)sym * nc;
-            uint32_t nb = (state < 16384u ? 1u : 0u) + (state < 64u ? 1u : 0u);      // state >= 4 after a step: two bytes reach 2^14
-            const uint32_t left = q_end - q;
-            nb = nb < left ? nb : left;
-            state = (state << (8u * nb)) | (((y0 << 8) | y1) >> (16u - 8u * nb));
-            q += nb;
-            while (state < 16384 && q < q_end) { state = (state << 8) | ring8[(q ^ 15u) & 127u]; ++q; }
+        if (a.tags_done || tags == LOC_TAGS_LATER) {
+          // the tag stream is k_tags' (the hand-scheduled register-table decoder on one wave per stream): its place is recorded on
+          // the way there, its bit total read on the way back
+          uint32_t distinct = 0;
+          REQUIRE(skip_prob_table(r, a.num_symbols, &distinct), 152);
+          a.num_distinct = distinct;
+          uint64_t size = r.varint();
+          a.off_rans = r.pos;
+          r.skip(size);
+          REQUIRE(r.ok && size >= 1, 154);
+          a.size_rans = (uint32_t)size;
+          a.off_bits = r.pos;
+          REQUIRE(num_entries <= L.out_cap[ai], 155);
+          if (!a.tags_done) return 2;
+          total_bits = a.table & 0x00FFFFFFFFFFFFFFull;
+          worst = (uint32_t)(a.table >> 56);
+        } else {
+          REQUIRE(read_prob_table(r, a.num_symbols, s_cum), 152);
+          uint32_t c = 0;
+          for (uint32_t i = 0; i < a.num_symbols; ++i) { uint32_t pr = s_cum[i]; REQUIRE(pr <= 4096u - c, 153); s_cum[i] = c; c += pr; }
+          s_cum[a.num_symbols] = c;
+          REQUIRE(c == 4096, 153);
+          uint64_t size = r.varint();
+          a.off_rans = r.pos;
+          r.skip(size);
+          REQUIRE(r.ok && size >= 1, 154);
+          a.size_rans = (uint32_t)size;
+          a.off_bits = r.pos;
+          // decode the tag stream; tags -> out buffer (bytes).  This chain sits in front of everything else of the mesh
+          // (the bit section behind it has no length field), so it is kept short: the tag from a byte-per-slot table of the
+          // 4096 slots (RAnsDecoder.cs:69-88), its range from the cumulative table, stream bytes from the LDS ring, the
+          // tags of a 16-entry block staged in LDS and stored with one 16-byte store at the block's boundary -- nothing
+          // inside a block waits for global memory.
+          REQUIRE(num_entries <= L.out_cap[ai], 155);
+          uint8_t *tags = arena + L.out[ai];
+          uint32_t state, off;
+          REQUIRE(rans_init(s + a.off_rans, a.size_rans, 16384, &state, &off), 156);
+          uint8_t *lut8 = (uint8_t *)s_lut;                   // slot -> tag: 4 KB, so that every mesh of a 4096-mesh batch is resident at once
+          for (uint32_t i = 0; i < a.num_symbols; ++i)
+            for (uint32_t j = s_cum[i]; j < s_cum[i + 1]; ++j) lut8[j] = (uint8_t)i;
+          uint32_t *ring = s_lut + LOC_LUT_SLOTS / 4, *tagbuf = ring + 4 * LN_RING_CHUNKS;
+          const uint8_t *ring8 = (const uint8_t *)ring;
+          uint8_t *tagbuf8 = (uint8_t *)tagbuf;
+          const uint64_t lowest = L.stream & ~15ull;
+          const uint64_t last = L.stream + a.off_rans + (off ? off - 1u : 0u);
+          const uint64_t base = (last + 16ull) & ~15ull;
+          uint32_t loaded = 0;
+          for (; loaded < 6; ++loaded) {
+            const Chunk c = ln_load_chunk(arena, base, lowest, loaded);
+            for (int k = 0; k < 4; ++k) ring[((loaded & (LN_RING_CHUNKS - 1u)) << 2) + k] = c.d[k];
           }
-          // block boundary: the chunks requested one boundary ago go into the ring, the block's tags leave, two more chunks are requested
-          if (inflight) {
-            for (int k = 0; k < 4; ++k) { ring[((loaded & (LN_RING_CHUNKS - 1u)) << 2) + k] = in0.d[k]; ring[(((loaded + 1u) & (LN_RING_CHUNKS - 1u)) << 2) + k] = in1.d[k]; }
-            loaded += 2;
-          }
-          if (cnt == LN_BLOCK) {
+          Chunk in0 = ln_load_chunk(arena, base, lowest, loaded), in1 = ln_load_chunk(arena, base, lowest, loaded + 1);
+          bool inflight = true;
+          uint32_t q = (uint32_t)(base - 1 - last);
+          const uint32_t q_end = q + off;
+          while (state < 16384 && q < q_end) { state = (state << 8) | ring8[(q ^ 15u) & 127u]; ++q; }
+          for (uint32_t b0 = 0; b0 < num_entries; b0 += LN_BLOCK) {
+            const uint32_t cnt = num_entries - b0 < LN_BLOCK ? num_entries - b0 : LN_BLOCK;
+            for (uint32_t j = 0; j < cnt; ++j) {
+              const uint32_t y0 = ring8[(q ^ 15u) & 127u], y1 = ring8[((q + 1u) ^ 15u) & 127u];
+              const uint32_t rem = state & 4095u, sym = lut8[rem];
+              const uint32_t cs = s_cum[sym], f = s_cum[sym + 1] - cs;
+              state = (state >> 12) * f + rem - cs;
+              tagbuf8[j] = (uint8_t)sym;
+              worst = sym > worst ? sym : worst;
+              total_bits += (uint64_t)sym * nc;
+              uint32_t nb = (state < 16384u ? 1u : 0u) + (state < 64u ? 1u : 0u);      // state >= 4 after a step: two bytes reach 2^14
+              const uint32_t left = q_end - q;
+              nb = nb < left ? nb : left;
+              state = (state << (8u * nb)) | (((y0 << 8) | y1) >> (16u - 8u * nb));
+              q += nb;
+              while (state < 16384 && q < q_end) { state = (state << 8) | ring8[(q ^ 15u) & 127u]; ++q; }
+            }
+            // block boundary: the chunks requested one boundary ago go into the ring, the block's tags leave, two more chunks are requested
+            if (inflight) {
+              for (int k = 0; k < 4; ++k) { ring[((loaded & (LN_RING_CHUNKS - 1u)) << 2) + k] = in0.d[k]; ring[(((loaded + 1u) & (LN_RING_CHUNKS - 1u)) << 2) + k] = in1.d[k]; }
+              loaded += 2;
+            }
+            if (cnt == LN_BLOCK) {
 #if defined(__HIPCC__)
-            *(uint4 *)(tags + b0) = make_uint4(tagbuf[0], tagbuf[1], tagbuf[2], tagbuf[3]);     // out regions are 256-byte aligned
+              *(uint4 *)(tags + b0) = make_uint4(tagbuf[0], tagbuf[1], tagbuf[2], tagbuf[3]);     // out regions are 256-byte aligned
 #else
-            memcpy(tags + b0, tagbuf8, LN_BLOCK);
+              memcpy(tags + b0, tagbuf8, LN_BLOCK);
 #endif
-          } else {
-            for (uint32_t j = 0; j < cnt; ++j) tags[b0 + j] = tagbuf8[j];
+            } else {
+              for (uint32_t j = 0; j < cnt; ++j) tags[b0 + j] = tagbuf8[j];
+            }
+            inflight = loaded + 2u - (q >> 4) <= LN_RING_CHUNKS;
+            if (inflight) { in0 = ln_load_chunk(arena, base, lowest, loaded); in1 = ln_load_chunk(arena, base, lowest, loaded + 1); }
           }
-          inflight = loaded + 2u - (q >> 4) <= LN_RING_CHUNKS;
-          if (inflight) { in0 = ln_load_chunk(arena, base, lowest, loaded); in1 = ln_load_chunk(arena, base, lowest, loaded + 1); }
         }
         REQUIRE(worst <= 32, 157);
         r.skip((total_bits + 7) >> 3);
@@ -229,7 +252,7 @@ __device__ __forceinline__ bool locate_attribute_values(Rd &r, MeshDesc *D, Attr
       }
     }
   }
-  return true;
+  return 1;
 }
 #undef RET
 #define RET
@@ -370,18 +393,26 @@ __device__ inline void locate_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc
   }
   D->off_attributes = r.pos;
 }
-__device__ inline void locate_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D, BatchGlobals *G, uint32_t *s_cum, uint32_t *s_lut);
-// The whole walk of one stream (the body of k_locate's lane 0).
+__device__ inline void locate_attribute_headers(uint8_t *arena, const MeshLayout &L, MeshDesc *D);
+#define LOC_WHOLE 0        // every data section, tag streams decoded on the way (host; the device when it has no choice)
+#define LOC_UNTIL_TAGS 1   // from the first data section up to the first tagged symbol stream (k_locate)
+#define LOC_RESUME 2       // from the attribute the walk stopped at (k_locate_resume): its tags are k_tags' by now, as a rule
+__device__ inline void locate_attribute_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, BatchGlobals *G, uint32_t *s_cum, uint32_t *s_lut, int mode);
+// The whole walk of one stream.  On the device it comes in pieces: the bit section behind a tag stream has no length field, so
+// what follows a tagged attribute is only found by decoding its tags -- a serial chain of 33 000 steps for a bench mesh that
+// one lane of k_locate used to walk in front of everything (23 ms for the bench batch with tagged symbols).  Now k_locate stops in
+// front of a tag stream, k_tags decodes it with the register-table decoder (one wave per stream, nine instructions per tag), and
+// k_locate_resume takes the walk up behind it -- up to the next tag stream; the host queues as many rounds as a mesh has attributes.
 __device__ inline void locate_all(uint8_t *arena, const MeshLayout &L, MeshDesc *D, BatchGlobals *G, uint32_t *s_cum, uint32_t *s_lut) {
   locate_mesh(arena, L, D);
   if (D->status != ST_OK || D->general) return;
-  locate_attributes(arena, L, D, G, s_cum, s_lut);
+  locate_attribute_headers(arena, L, D);
+  if (D->status != ST_OK) return;
+  locate_attribute_values(arena, L, D, G, s_cum, s_lut, LOC_WHOLE);
 }
 
-// Second half of the walk: the attribute section (ConnectivityDecoder.cs:16-44) from D->off_attributes on.  (Measured as
-// a kernel of its own beside k_connectivity: the connectivity waves hold nearly all LDS of a CU, so the tag decoders
-// trickle through one per CU and a tagged batch takes longer than with the walk in front: profiles/README.md.)
-__device__ inline void locate_attributes(uint8_t *arena, const MeshLayout &L, MeshDesc *D, BatchGlobals *G, uint32_t *s_cum, uint32_t *s_lut) {
+// Second part of the walk: the headers of the attribute section (ConnectivityDecoder.cs:16-44) from D->off_attributes on.
+__device__ inline void locate_attribute_headers(uint8_t *arena, const MeshLayout &L, MeshDesc *D) {
   const uint8_t *s = arena + L.stream;
   Rd r(s, L.stream_len, D->off_attributes);
   const bool point_cloud = D->encoder_type == 0;
@@ -437,11 +468,34 @@ __device__ inline void locate_attributes(uint8_t *arena, const MeshLayout &L, Me
   }
   first_att[ndec] = natt;
   D->num_attributes = natt;
+  for (uint32_t i = 0; i <= ndec; ++i) D->dec_first[i] = (uint8_t)first_att[i];
+  D->off_att_values = r.pos;
+}
+
+// Third part: the data sections of the attributes (their symbol streams, prediction data, quantisation parameters).
+__device__ inline void locate_attribute_values(uint8_t *arena, const MeshLayout &L, MeshDesc *D, BatchGlobals *G, uint32_t *s_cum, uint32_t *s_lut, int mode) {
+  const uint8_t *s = arena + L.stream;
+  Rd r(s, L.stream_len, D->off_att_values);
+  const uint32_t ndec = D->num_decoders;
+  const uint8_t *first_att = D->dec_first;
+  uint32_t i0 = 0, a0 = 0;
+  if (mode == LOC_RESUME) {
+    if (!D->values_pending) return;
+    i0 = D->resume_dec; a0 = D->resume_att; r.pos = D->resume_pos;
+    D->values_pending = 0;
+  }
   // every vertex attribute of a valid stream carries one entry per encoded vertex
   uint32_t num_entries = D->num_enc_vertices;
-  for (uint32_t i = 0; i < ndec; ++i) {           // AttributesDecoder.cs:65-70
-    for (uint32_t ai = first_att[i]; ai < first_att[i + 1]; ++ai) {
-      if (!locate_attribute_values(r, D, D->att[ai], L, (int)ai, arena, s_cum, s_lut, num_entries, G)) return;
+  for (uint32_t i = i0; i < ndec; ++i) {           // AttributesDecoder.cs:65-70
+    for (uint32_t ai = (i == i0 && a0 > first_att[i]) ? a0 : first_att[i]; ai < first_att[i + 1]; ++ai) {
+      const uint32_t at = r.pos;
+      // a tag stream ahead is left to k_tags -- unless this IS the attribute the walk stopped at and k_tags did not take it
+      // (a stream it is not made for): then its tags are decoded here
+      const bool again = mode == LOC_RESUME && i == i0 && ai == a0;
+      const int rc = locate_attribute_section(r, D, D->att[ai], L, (int)ai, arena, s_cum, s_lut, num_entries, G,
+                                              mode == LOC_WHOLE || again ? LOC_TAGS_HERE : LOC_TAGS_LATER);
+      if (rc == 0) return;
+      if (rc == 2) { D->resume_dec = (uint8_t)i; D->resume_att = (uint8_t)ai; D->resume_pos = at; D->values_pending = 1; return; }
     }
     for (uint32_t ai = first_att[i]; ai < first_att[i + 1]; ++ai) {
       AttrDesc &a = D->att[ai];

@@ -35,7 +35,7 @@ struct AttrDesc {
   uint8_t precision_bits;  // rANS precision of the symbol (raw) or tag (tagged) stream
   uint8_t q_bits;          // quantisation bits / octahedron bits
   uint8_t early_done;      // the symbol wave itself predicted and dequantised the attribute (k_predict / k_finalize of phase 0 skip it)
-  uint8_t pad1;
+  uint8_t tags_done;       // tagged scheme: k_tags decoded the tag stream (tags in the output region, their bit total in `table`)
   uint32_t unique_id;
   uint32_t num_symbols;    // alphabet size
   uint32_t off_table;      // stream offset of the first probability-table byte
@@ -80,6 +80,10 @@ struct MeshDesc {
   uint32_t gen_act_nv[DSA_MAX_ATT_DATA];   // general path: vertices of every attribute corner table (phase 2 -> phase 3)
   uint32_t gen_seam_pos[DSA_MAX_ATT_DATA]; // general path: stream offset of every attribute seam rABS block (phase 1 -> phase 2)
   uint32_t gen_dec_entries[DSA_MAX_ATT];   // general path: entries of every attributes decoder (phase 3 sequence -> maps -> values)
+  uint32_t off_att_values;     // stream offset of the first attribute data section (behind the attribute headers)
+  uint8_t dec_first[DSA_MAX_ATT + 4];   // first attribute of every attributes decoder (+ the total behind the last)
+  uint32_t resume_pos;         // the walk stopped in front of a tagged symbol stream: where it is taken up again
+  uint8_t values_pending, resume_dec, resume_att, pad_resume;
   uint32_t interior_corners;   // 2 x opposite links made by k_connectivity; one seam bit per link and attribute data
   uint32_t linked_corners;     // corners that hold an opposite, counted by k_point_maps (k_seal compares the two)
   // valence traversal (traversal_type 2, MeshEdgeBreakerTraversalValenceDecoder.cs:22-69) on the fast kernels: the six symbol lists,
