@@ -259,8 +259,11 @@ def test_corrupt_streams_agree_with_the_oracle(ctx, house04_bytes):
     rare = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(predictive_connectivity=1, pos_prediction=4, uv_prediction=2, single_connectivity=1))
     # GeometricNormal on the fast kernels (the flip-bit block, the corner fans) with valence-coded connectivity
     geo = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(predictive_connectivity=2, normal_prediction=6))
+    # tagged symbol streams of a mesh large enough for k_tags (the tag stream on a wave of its own, the walk resumed behind it)
+    bpos, bnrm, buv, bfaces = synth.make_mesh(synth.GRID, 128, 128, 4)
+    big_tagged = synth.encode_mesh(bpos, bfaces, bnrm, buv, opt=synth.options(force_scheme=0))
     streams = (_corruptions(base, 96, 5) + _corruptions(house04_bytes, 64, 6) + _corruptions(stock, 64, 7) + _corruptions(rare, 64, 8) +
-               _corruptions(geo, 96, 9) + [base, house04_bytes, stock, rare, geo])
+               _corruptions(geo, 96, 9) + _corruptions(big_tagged, 64, 10) + [base, house04_bytes, stock, rare, geo, big_tagged])
     b = run_batch(ctx, streams)
     agree_ok = agree_bad = gpu_stricter = 0
     stricter_sites = {}
@@ -284,7 +287,7 @@ def test_corrupt_streams_agree_with_the_oracle(ctx, house04_bytes):
     # Where the device path refuses what the oracle lets through, it is one of its own validations, by site: 123 (a traversal
     # method byte above 1, which the oracle reads as depth-first), 263 (the census of linked corners) and 681 (the general path's
     # bound on attribute seam data).  Four seeds of this mix gave 0 - 1 such streams of 292 (sites 123, 681); anything else, or
-    # more than a handful, is a difference to look at.  (389 streams with the GeometricNormal family.)
+    # more than a handful, is a difference to look at.  (454 streams with the GeometricNormal and the large tagged family.)
     assert set(stricter_sites) <= {(1, 123), (1, 263), (1, 681)}, stricter_sites
     assert gpu_stricter <= 4, (agree_ok, agree_bad, stricter_sites)
     b.close()
@@ -745,4 +748,29 @@ def test_geometric_normals_on_the_fast_kernels(ctx):
         assert info.decode_path == 0 or (info.decode_path == 2 and ref.num_faces < 1000 and ref.traversal_type == 2), (i, info.decode_path)
         fast += info.decode_path == 0
     assert fast >= len(streams) * 2 // 3
+    b.close()
+
+
+def test_tag_streams_on_a_wave_of_their_own(ctx):
+    """Tagged symbol streams of meshes large enough for k_tags (the register-table decoder on the tag stream, the walk taken up
+    behind it by k_locate_resume, one round per attribute): every attribute tagged, some tagged and some raw in one mesh, a batch
+    mixing both with small meshes whose tags the walk decodes itself, 9 - 16 bit attributes, valence symbols and GeometricNormal
+    normals on top -- equal to the oracle."""
+    streams = []
+    for j, (kind, nx, ny) in enumerate(((synth.GRID, 128, 256), (synth.TORUS, 96, 128), (synth.HOLES, 70, 90), (synth.GRID, 9, 7), (synth.SPHERE, 40, 60))):
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 70 + j)
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(force_scheme=0)))
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(force_scheme=0, pos_bits=14, uv_bits=16, normal_bits=9,
+                                                                                predictive_connectivity=2 if j % 2 else 0, normal_prediction=6 if j % 3 == 0 else 0)))
+        # the encoder's own choice at 16 bits: high-entropy attributes come out tagged, the others raw
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_bits=16, uv_bits=9)))
+    b = run_batch(ctx, streams)
+    tagged = 0
+    for i, s in enumerate(streams):
+        assert b.status(i) == 0, (i, b.mesh_info(i).detail)
+        ref = oracle.decode(s)
+        assert_same(b.result(i), ref, b, i)
+        info = b.debug_array(i, 5, np.uint32, 64).reshape(16, 4)[:3]
+        tagged += int((info[:, 0] == 0).sum())
+    assert tagged >= 20          # source 0 = tagged
     b.close()
