@@ -97,7 +97,7 @@ struct dsa_batch {
   uint64_t out_base = 0, out_bytes = 0;   // the output block: faces, attribute values and point maps of every mesh
   uint32_t max_faces = 0, max_vertices = 0, max_atts = 0, max_att_data = 0;
   uint64_t sum_vertices = 0;
-  bool any_general = false;
+  bool any_general = false, any_valence = false;
   bool decoded = false, collected = false;
   hipEvent_t ev[DSA_NUM_STAGES + 1] = {};
   hipEvent_t ev_sym[2] = {};
@@ -219,6 +219,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
     b->max_faces = b->max_vertices = b->max_atts = b->max_att_data = 0;
     b->sum_vertices = 0;
     b->any_general = false;
+    b->any_valence = false;
     for (uint32_t i = 0; i < n; ++i) {
       HostMesh &h = b->host[i];
       MeshLayout &L = b->layouts[i];
@@ -236,6 +237,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
       b->max_atts = std::max<uint32_t>(b->max_atts, (uint32_t)h.atts.size());
       b->max_att_data = std::max<uint32_t>(b->max_att_data, h.num_att_data);
       b->any_general = b->any_general || h.general;
+      b->any_valence = b->any_valence || (h.valence && !h.general);
     }
     // pool for the cumulative tables of large-alphabet streams (bump-allocated by k_locate)
     {
@@ -448,6 +450,9 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_tags, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_locate_resume, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, b->d_globals);
   }
+  // valence-coded connectivity: the six context lists of every mesh on waves of their own (the register-table decoder), in front
+  // of the connectivity waves, which would otherwise decode them one after the other at a third of the speed each
+  if (b->any_valence) hipLaunchKernelGGL(dsa::k_valence_lists, dim3(n, 6), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   HIP_TRY(ctx, mark());
   const uint32_t na = std::max<uint32_t>(1, b->max_atts);
   // fork: entropy decode of every attribute stream on the second stream (it only needs k_locate's offsets)

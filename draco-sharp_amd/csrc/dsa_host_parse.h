@@ -22,6 +22,7 @@ struct HostMesh {
   int status = 0;   // failure of the sizing parse (the device parse decides the reported status)
   uint32_t faces = 0, enc_vertices = 0, split_symbols = 0, splits = 0, num_att_data = 0;
   bool general = false;   // valence traversal or corner attributes: decoded by k_general
+  bool valence = false;   // valence-coded connectivity on the fast kernels (k_valence_lists in front of the connectivity waves)
   uint32_t meta_off = 0, meta_len = 0;   // metadata block of the stream (flag 0x8000), for dsa_batch_copy_metadata
   std::vector<HostAttr> atts;
 };
@@ -168,6 +169,7 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m, bool want_gene
     if (!r.ok || nsplits > nf) return bad(ST_INVALID);
     m.faces = (uint32_t)nf; m.enc_vertices = (uint32_t)nv; m.split_symbols = (uint32_t)nss; m.splits = (uint32_t)nsplits; m.num_att_data = nad;
     if (traversal == 2 && (4 * nf > (1u << 20) || nv + nss >= (1u << 20))) m.general = true;
+    m.valence = traversal == 2 && !m.general;
     for (uint64_t i = 0; i < 2 * nsplits && r.ok; ++i) (void)r.varint();
     r.skip((nsplits + 7) >> 3);
     uint64_t sz;

@@ -358,7 +358,7 @@ __device__ __forceinline__ void connectivity_wave(uint8_t *arena, const MeshLayo
     for (uint32_t c = 0; c < 6; ++c) {
       const uint32_t num = uni(D->val_count[c]);
       if (lane == c) { cntv = num; offv = off_c; }
-      if (num) {
+      if (num && !((uni(D->val_lists_done) >> c) & 1u)) {           // (k_valence_lists has decoded it, as a rule)
         if (!valence_decode_list(D, s, L.stream_len, uni(D->val_off_table[c]), uni(D->val_nsym[c]), uni((uint32_t)D->val_prec[c]), uni(D->val_off_rans[c]),
                                  uni(D->val_size_rans[c]), num, (uint32_t *)(arena + L.faces) + off_c, sh_win)) return;
       }
@@ -1913,18 +1913,41 @@ __device__ __forceinline__ void early_tail(uint8_t *arena, const MeshLayout &L, 
   if (lane_id() == 0) D->att[ai].early_done = 1;
 }
 
-// TAGS: the tag stream of a tagged attribute (SymbolDecoding.cs:30-50: one 5-bit tag per entry, a 12-bit-precision rANS stream like
-// any other) instead of a raw symbol stream: the attribute the walk of the mesh stopped at (k_locate / k_locate_resume); the tags go to
-// the attribute's output region as bytes, where k_symbols<0> expects them, and their bit total to the descriptor, where the walk needs
-// it to find what follows.  The tables then live behind the slots in the work region (the output region holds the tags).
-template <bool TAGS>
+// The decoder serves three kinds of 12-bit-precision streams (MODE):
+//   REG_ATTR   the raw symbol stream of attribute ai
+//   REG_TAGS   the tag stream of a tagged attribute (SymbolDecoding.cs:30-50: one 5-bit tag per entry) -- the attribute the walk of the
+//              mesh stopped at (k_locate / k_locate_resume); the tags go to the attribute's output region as bytes, where k_symbols<0>
+//              expects them, and their bit total to the descriptor, where the walk needs it to find what follows.  The tables then live
+//              behind the slots in the work region (the output region holds the tags)
+//   REG_VLIST  context list ai (0..5) of valence-coded connectivity (MeshEdgeBreakerTraversalValenceDecoder.cs:22-69), into the
+//              face-output region, where the connectivity wave reads the lists; tables in the face-record region, which that
+//              wave fills later.  The connectivity wave decodes a list itself when this kernel could not (val_lists_done)
+#define REG_ATTR 0
+#define REG_TAGS 1
+#define REG_VLIST 2
+#define REG_SCRATCH_BYTES (4096u * 6u + REG_MAX_SYMS * 4u)
+template <int MODE>
 __device__ __forceinline__ void reg_decode_stream(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t flags) {
-  AttrDesc &a = D->att[ai];
+  constexpr bool TAGS = MODE == REG_TAGS, VLIST = MODE == REG_VLIST;
+  AttrDesc &a = D->att[VLIST ? 0u : ai];
   uint8_t *scratch;
-  if (TAGS) {
+  uint32_t st_off_table = a.off_table, st_off_rans = a.off_rans, st_size_rans = a.size_rans, st_nsym = a.num_symbols;
+  uint32_t st_values = a.num_entries * (TAGS ? 1u : (uint32_t)a.nc_portable);
+  uint32_t *out = (uint32_t *)(arena + L.work[VLIST ? 0u : ai]);
+  if (VLIST) {
+    st_values = D->val_count[ai];
+    if (st_values == 0 || D->val_prec[ai] != 12 || D->val_nsym[ai] > 64) return;
+    if ((uint64_t)L.rec_compact * 16ull * D->num_faces < 6ull * REG_SCRATCH_BYTES) return;     // (small meshes: the connectivity wave decodes its lists)
+    st_off_table = D->val_off_table[ai]; st_off_rans = D->val_off_rans[ai]; st_size_rans = D->val_size_rans[ai]; st_nsym = D->val_nsym[ai];
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < ai; ++k) before += D->val_count[k];
+    if ((uint64_t)before + st_values > 3ull * D->num_faces) return;                                // (the lists of a sound stream hold one symbol per face)
+    out = (uint32_t *)(arena + L.faces) + before;
+    scratch = arena + L.frec + (size_t)ai * REG_SCRATCH_BYTES;
+  } else if (TAGS) {
     if (a.source != SRC_TAGGED || a.tags_done || a.num_symbols > LOC_MAX_TAGS || a.num_distinct <= 1 || a.num_entries == 0) return;
     const uint64_t slots = ((uint64_t)a.num_entries * 4 + 15) & ~15ull;
-    if ((uint64_t)L.work_cap[ai] * 4 < slots + 4096 * 6 + REG_MAX_SYMS * 4) return;      // (small meshes: the walk decodes the tags itself)
+    if ((uint64_t)L.work_cap[ai] * 4 < slots + REG_SCRATCH_BYTES) return;      // (small meshes: the walk decodes the tags itself)
     scratch = arena + L.work[ai] + slots;
   } else {
     if (lanes::ln_sym_eligible(a, L, ai, flags)) return;             // k_symbols_lanes
@@ -1935,35 +1958,48 @@ __device__ __forceinline__ void reg_decode_stream(uint8_t *arena, const MeshLayo
     scratch = arena + L.out[ai];
   }
   const uint8_t *stream = arena + L.stream;
-  uint32_t *out = (uint32_t *)(arena + L.work[ai]);
   uint32_t *slot_tab = (uint32_t *)scratch;                        // {freq | (rem - cum) << 16} per slot
   uint16_t *slot_sym = (uint16_t *)(scratch + 4096 * 4);           // symbol per slot
   // probabilities, then packed {freq << 12 | cum} per symbol: global scratch rather than LDS, which the
   // connectivity and traversal waves sharing the CU need for their caches and tables
   uint32_t *lds = (uint32_t *)(scratch + 4096 * 6);
   const uint32_t lane = lane_id();
-  const uint32_t nsym = uni(a.num_symbols);
-  const uint32_t num_values = uni(a.num_entries) * (TAGS ? 1u : (uint32_t)a.nc_portable);
+  const uint32_t nsym = uni(st_nsym);
+  const uint32_t num_values = uni(st_values);
   if (num_values == 0) return;
   // 1. probability table -> LDS (lane 0), RAnsSymbolDecoder.cs:21-48
   if (lane == 0) {
-    Rd r(stream, L.stream_len, a.off_table);
+    Rd r(stream, L.stream_len, st_off_table);
     if (!read_prob_table(r, nsym, lds)) fail(D, ST_INVALID, 400);
   }
   __syncthreads();
   if (status_of(D) != ST_OK) return;
   // 2. cumulative frequencies; a frequency of 4096 (one-symbol alphabet) does not fit the packing
-  uint32_t carry = 0;
+  uint32_t carry = 0, one_at = DSA_INVALID;
   bool over = false;
   for (uint32_t b0 = 0; b0 < REG_MAX_SYMS; b0 += WAVE) {
     uint32_t i = b0 + lane;
     uint32_t pr = i < nsym ? lds[i] : 0u;
-    if (pr > 4095) over = true;
+    if (pr > 4095) { over = true; one_at = i; }
     uint32_t tot;
     uint32_t ex = wave_excl_scan(pr, &tot);
     lds[i] = (pr << 12) | ((carry + ex) & 4095u);
     carry += tot;
     if (carry > 4096) over = true;
+  }
+  if (VLIST && carry == 4096 && __ballot(over)) {
+    // A list of one symbol (frequency 4096, which the packed word cannot hold) -- the rule for the busiest context of a regular
+    // mesh, where the valence of the gate vertex settles the symbol: the state of the coder never moves (x' = 4096 (x >> 12) +
+    // (x & 4095)) and no byte is read, so the list is that symbol `count` times, once the stream's tail has passed rans_init.
+    uint32_t st = 0, o = 0;
+    if (!rans_init(stream + st_off_rans, st_size_rans, 16384, &st, &o)) { if (lane == 0) fail(D, ST_INVALID, 402); return; }
+    const uint32_t one = (uint32_t)__builtin_ctzll(__ballot(one_at != DSA_INVALID));
+    const uint32_t sym = rdlane(one_at, one);
+    for (uint32_t i = lane; i < num_values; i += WAVE) out[i] = sym;
+    WAIT_VM0();
+    __syncthreads();
+    if (lane == 0) atomicOr(&D->val_lists_done, 1u << ai);
+    return;
   }
   if (__ballot(over) || carry != 4096) { if (lane == 0) fail(D, carry != 4096 ? ST_INVALID : ST_NOTIMPL, 401); return; }
   __syncthreads();
@@ -1978,17 +2014,17 @@ __device__ __forceinline__ void reg_decode_stream(uint8_t *arena, const MeshLayo
 #pragma unroll
   for (int k = 0; k < 32; ++k) { tab_lo[k] = slot_tab[k * WAVE + lane]; tab_hi[k] = slot_tab[(k + 32) * WAVE + lane]; }
   // 4. initial state from the stream tail, RAnsDecoder.cs:20-54
-  const uint8_t *buf = stream + a.off_rans;
+  const uint8_t *buf = stream + st_off_rans;
   uint32_t x, off;
   {
     uint32_t st = 0, o = 0;
-    bool ok = rans_init(buf, a.size_rans, 16384, &st, &o);
+    bool ok = rans_init(buf, st_size_rans, 16384, &st, &o);
     if (!ok) { if (lane == 0) fail(D, ST_INVALID, 402); return; }
     x = uni(st); off = uni(o);
   }
   // byte window: lane l holds the dword at aligned byte (chunk*256 + 4l) of the stream
-  const uint32_t mis = (uint32_t)((L.stream + a.off_rans) & 3u);
-  const uint32_t *abuf = (const uint32_t *)(arena + (L.stream + a.off_rans - mis));
+  const uint32_t mis = (uint32_t)((L.stream + st_off_rans) & 3u);
+  const uint32_t *abuf = (const uint32_t *)(arena + (L.stream + st_off_rans - mis));
   uint32_t chunk = 0x7FFFFFFFu, W = 0;
   uint32_t mine = 0;
   WAIT_VM0();
@@ -2110,6 +2146,14 @@ __device__ __forceinline__ void reg_decode_stream(uint8_t *arena, const MeshLayo
   }
   WAIT_VM0();
   __syncthreads();
+  if (VLIST) {
+    // 5. slot -> symbol of the list
+    for (uint32_t i = lane; i < num_values; i += WAVE) out[i] = slot_sym[out[i] & 4095u];
+    WAIT_VM0();
+    __syncthreads();
+    if (lane == 0) atomicOr(&D->val_lists_done, 1u << ai);
+    return;
+  }
   if (TAGS) {
     // 5. slot -> tag, as bytes into the output region; the bit total (tag x components, SymbolDecoding.cs:41-47) and the largest tag
     uint8_t *tags = arena + L.out[ai];
@@ -2146,7 +2190,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_symbols_reg(uint8_t *arena, const M
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK || D->general || ai >= D->num_attributes) return;
-  reg_decode_stream<false>(arena, layouts[mesh], D, ai, flags);
+  reg_decode_stream<REG_ATTR>(arena, layouts[mesh], D, ai, flags);
 }
 // The tag stream in front of which the walk of a mesh stopped (see dsa_locate.h): one wave per mesh.
 __global__ __launch_bounds__(WAVE, 6) void k_tags(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
@@ -2154,7 +2198,15 @@ __global__ __launch_bounds__(WAVE, 6) void k_tags(uint8_t *arena, const MeshLayo
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK || D->general || !D->values_pending || D->resume_att >= D->num_attributes) return;
-  reg_decode_stream<true>(arena, layouts[mesh], D, D->resume_att, 0u);
+  reg_decode_stream<REG_TAGS>(arena, layouts[mesh], D, D->resume_att, 0u);
+}
+// The six context lists of valence-coded connectivity, a wave per list, in front of the connectivity waves that read them.
+__global__ __launch_bounds__(WAVE, 6) void k_valence_lists(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  uint32_t mesh = blockIdx.x, c = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK || D->general || D->encoder_type == 0 || D->traversal_type != 2) return;
+  reg_decode_stream<REG_VLIST>(arena, layouts[mesh], D, c, 0u);
 }
 
 // Launched once per tier so that the LDS footprint of the cumulative table does not cap occupancy:

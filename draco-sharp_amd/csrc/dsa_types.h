@@ -89,6 +89,7 @@ struct MeshDesc {
   // valence traversal (traversal_type 2, MeshEdgeBreakerTraversalValenceDecoder.cs:22-69) on the fast kernels: the six symbol lists,
   // one per valence class of the vertex the decoder stands on -- raw rANS streams over at most 64 symbols each
   uint32_t val_count[6], val_nsym[6], val_off_table[6], val_off_rans[6], val_size_rans[6];
+  uint32_t val_lists_done; // bit c: k_valence_lists decoded list c into the face-output region
   uint8_t val_prec[6];
   uint8_t geo_wide;        // k_vertex_positions: some position is not below 2^30 in magnitude (k_predict_geometric then keeps 64-bit edge vectors)
   uint8_t pad_val;
