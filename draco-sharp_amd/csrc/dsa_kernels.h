@@ -1885,7 +1885,8 @@ __device__ __forceinline__ void rans_decode_serial(MeshDesc *D, const uint8_t *s
 // every position; which symbol a slot belongs to is looked up afterwards by all 64 lanes in parallel
 // (slot -> symbol table in the attribute's scratch), fused with the zig-zag step.
 typedef uint32_t v32u __attribute__((ext_vector_type(32)));   // largest vector the backend indexes through M0
-#define REG_MAX_SYMS 2048
+#define REG_MAX_SYMS 4096     // a 12-bit-precision table has 4096 slots: no more symbols than that can have a frequency
+#define WIDE_MAX_SYMS 2048    // k_symbols_wide: 32 registers of 64 {cumulative, frequency} words
 
 // SYM_EARLY_FUSE (option, off by default): the wave that decoded the symbols of an "early" attribute (its prediction needs no
 // traversal data) goes on to predict and dequantise it -- what k_predict / k_predict_wrap / k_finalize of phase 0 do behind the
@@ -2223,7 +2224,7 @@ __device__ __forceinline__ bool sym_wide_eligible(const AttrDesc &a, const MeshL
   if (a.source != SRC_RAW || a.num_distinct <= 1 || sym_reg_eligible(a, L, ai)) return false;
   const bool compact = a.num_symbols > SYM_MAX_LDS;
   const uint32_t nse = compact ? a.num_distinct : a.num_symbols;
-  if (nse <= 64 || nse > REG_MAX_SYMS || a.precision_bits > 16) return false;     // {cum, freq} packed in 16 + 16 bits
+  if (nse <= 64 || nse > WIDE_MAX_SYMS || a.precision_bits > 16) return false;     // {cum, freq} packed in 16 + 16 bits
   return compact ? (a.table != 0 && 2ull * nse + 1 <= (unsigned long long)a.num_symbols + 2) : (L.out_cap[ai] >= 4ull * (nse + 1));
 }
 
