@@ -1954,7 +1954,7 @@ __device__ __forceinline__ void reg_decode_stream(uint8_t *arena, const MeshLayo
     if (lanes::ln_sym_eligible(a, L, ai, flags)) return;             // k_symbols_lanes
     if (sym_filtered(a, flags)) return;                              // the other launch of the early / late pair
     // one non-zero symbol = a frequency of 4096, which the packed {freq, rem - cum} word cannot hold: k_symbols<T> takes it
-    if (a.source != SRC_RAW || a.precision_bits != 12 || a.num_symbols > REG_MAX_SYMS || a.num_symbols <= 64 || a.num_distinct <= 1) return;
+    if (a.source != SRC_RAW || a.precision_bits != 12 || a.num_symbols > REG_MAX_SYMS || a.num_distinct <= 1) return;
     if (L.out_cap[ai] < 4096 * 6 + REG_MAX_SYMS * 4) return;      // scratch for the tables (k_symbols<T> takes the stream instead)
     scratch = arena + L.out[ai];
   }
@@ -2213,9 +2213,9 @@ __global__ __launch_bounds__(WAVE, 6) void k_valence_lists(uint8_t *arena, const
 // Launched once per tier so that the LDS footprint of the cumulative table does not cap occupancy:
 //   TIER 0: alphabets <= 64 (table in one register per lane) + tagged / fixed-width sources
 //   TIER 1: alphabets <= 960      TIER 2: alphabets <= SYM_MAX_LDS and the large-alphabet fallback
-// Which raw streams k_symbols_reg takes (12-bit precision, 64 < alphabet <= 2048, table scratch in the attribute's output region).
+// Which raw streams k_symbols_reg takes (12-bit precision, at most 4096 symbols more than one of which occurs, table scratch in the attribute's output region).
 __device__ __forceinline__ bool sym_reg_eligible(const AttrDesc &a, const MeshLayout &L, uint32_t ai) {
-  return a.source == SRC_RAW && a.precision_bits == 12 && a.num_symbols > 64 && a.num_symbols <= REG_MAX_SYMS && a.num_distinct > 1 &&
+  return a.source == SRC_RAW && a.precision_bits == 12 && a.num_symbols <= REG_MAX_SYMS && a.num_distinct > 1 &&
          L.out_cap[ai] >= 4096 * 6 + REG_MAX_SYMS * 4;
 }
 // Which raw streams k_symbols_wide takes: any precision, at most 2048 symbols to search -- those of the alphabet, or, for a sparse
