@@ -3,7 +3,7 @@ f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # last decode: take the last k_locate and everything after
-idx = max(i for i, r in enumerate(rows) if 'k_locate' in r['Kernel_Name'])
+idx = max(i for i, r in enumerate(rows) if r['Kernel_Name'].split('(')[0].replace('dsa::', '') == 'k_locate')
 t0 = int(rows[idx]['Start_Timestamp'])
 for r in rows[idx:]:
     name = r['Kernel_Name'].split('(')[0].replace('dsa::', '')
