@@ -109,7 +109,26 @@ static int octexhaust(int bits) {
   return 0;
 }
 
+// lanes_host divcheck <seed> <count>: div_trunc_pos (the 64-bit division of the GeometricNormal arithmetic through a double estimate
+// put right by remainders) against the operator, on dividends of every magnitude and around exact multiples
+static int divcheck(uint64_t seed, long count) {
+  rng_state = seed * 2654435761ull + 88172645463325252ull;
+  auto r64 = []() { return ((uint64_t)rnd() << 42) ^ ((uint64_t)rnd() << 21) ^ rnd(); };
+  for (long it = 0; it < count; ++it) {
+    const int bx = 1 + (int)(rnd() % 62), by = 1 + (int)(rnd() % 40);
+    int64_t x = (int64_t)(r64() >> (64 - bx));
+    if (rnd() & 1) x = -x;
+    int64_t y = (int64_t)(r64() >> (64 - by));
+    if (y <= 0) y = 1 + (int64_t)(rnd() % 7);
+    if (it % 5 == 0) { const int64_t k = (int64_t)(rnd() % 1000000) - 500000; x = k * y + ((it % 3) - 1); }
+    if (dsa::div_trunc_pos(x, y) != x / y) { fprintf(stderr, "divcheck: %lld / %lld: %lld vs %lld\n", (long long)x, (long long)y, (long long)dsa::div_trunc_pos(x, y), (long long)(x / y)); return 1; }
+  }
+  printf("divcheck: %ld divisions equal\n", count);
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc >= 4 && strcmp(argv[1], "divcheck") == 0) return divcheck(strtoull(argv[2], nullptr, 10), atol(argv[3]));
   if (argc >= 3 && strcmp(argv[1], "octexhaust") == 0) return octexhaust(atoi(argv[2]));
   if (argc >= 4 && strcmp(argv[1], "octcheck") == 0) return octcheck(strtoull(argv[2], nullptr, 10), atoi(argv[3]));
   if (argc < 4 || strcmp(argv[1], "decode") != 0) { fprintf(stderr, "usage: lanes_host decode <in.drc> <out.bin> [conn.bin]\n"); return 2; }

@@ -150,3 +150,11 @@ def test_packed_octahedral_step_is_exact_on_every_value(exe):
     r = subprocess.run([exe, "octexhaust", "5"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
     assert "5 bits, 984064 pairs equal" in r.stdout
+
+
+def test_division_through_a_double_estimate_is_exact(exe):
+    """div_trunc_pos (dsa_common.h): the 64-bit divisions of the GeometricNormal arithmetic, on the device a double-precision estimate
+    corrected by remainders instead of the compiler's division routine -- equal to the operator on two million random pairs of every
+    magnitude, a fifth of them next to exact multiples."""
+    r = subprocess.run([exe, "divcheck", "5", "2000000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
