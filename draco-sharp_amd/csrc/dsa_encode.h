@@ -502,7 +502,7 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
       C.F = F; C.V = V; C.split_cap = F;
       C.faces = take_in(12ull * F); uploads.push_back({C.faces, meshes[i].faces, 12ull * F});
       C.opp = take(12ull * F); C.voff = take(4ull * (V + 1)); C.vcur = take(4ull * V); C.vlist = take(12ull * F); C.vcorner = take(4ull * V);
-      C.fvis = take(F); C.vvis = take(V); C.hole_id = take(4ull * V); C.hole_vis = take(V); C.split_sym = take(4ull * F);
+      C.fvis = take(F); C.vvis = take(V); C.hole_id = take(4ull * V); C.hole_vis = take(V); C.hrec = take(48ull * F);
       C.stack = take(4ull * F); C.processed = take(4ull * F); C.init_corners = take(4ull * F);
       C.symbols = take(F); C.start_bits = take(F); C.splits = take(12ull * C.split_cap);
       C.d2c = take(4ull * V); C.v2d = take(4ull * V);
@@ -622,6 +622,15 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
     if (!host_conn) ENC_TRY(hipMemcpyAsync(hc.data(), d_conns, sizeof(dsa::EncConn) * n, hipMemcpyDeviceToHost, st));
     ENC_TRY(hipStreamSynchronize(st));
     lap("device phases 0 + 1");
+#ifdef DSA_ENC_CLOCKS
+    if (timing && !host_conn) {
+      unsigned long long clk[16] = {0}, zero[16] = {0};
+      (void)hipMemcpyFromSymbol(clk, HIP_SYMBOL(dsa::g_enc_clocks), sizeof(clk));
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(dsa::g_enc_clocks), zero, sizeof(zero));
+      static const char *names[7] = {"corners by vertex", "opposites", "left-most + checks", "hole ids", "edgebreaker walk", "dfs walk", "operands"};
+      for (int i = 0; i < 7; ++i) fprintf(stderr, "[k_enc_connectivity] %-20s %8.2f ms per mesh\n", names[i], clk[i] / 100e3 / n);
+    }
+#endif
     if (!host_conn) {
       // what the stream layout needs of the connectivity: symbols, start-face bits, split events, two counts
       std::vector<dsa::PackItem> conn_items;

@@ -21,7 +21,7 @@ struct EncConn {                   // one per mesh; device memory, mirrored on t
   uint64_t vcorner;                // u32[V] left-most corner
   uint64_t fvis, vvis;             // u8[F], u8[V]
   uint64_t hole_id, hole_vis;      // i32[V], u8[V]
-  uint64_t split_sym;              // i32[F]: symbol id of the S coded at the face, or -1
+  uint64_t hrec;                   // uint4[3F] per corner: vertex, corners across the right / left edge, mark of the face
   uint64_t stack;                  // u32[F]
   uint64_t processed, init_corners;// u32[F] each
   uint64_t symbols;                // u8[F] OUTPUT encoder order, bit patterns 0 1 3 5 7
@@ -64,6 +64,13 @@ struct EcTable {                   // the corner table as the traversals see it
 __device__ __forceinline__ void ec_fail(EncConn *E, uint32_t status, uint32_t detail) { if (atomicCAS(&E->status, 0u, status) == 0u) E->detail = detail; }
 __device__ __forceinline__ void ec_sync() { __threadfence_block(); __syncthreads(); }
 
+#ifdef DSA_ENC_CLOCKS
+__device__ unsigned long long g_enc_clocks[16];
+#define ENC_CLK(i) do { if (lane == 0) { const uint64_t t_ = realclk(); atomicAdd(&g_enc_clocks[i], (unsigned long long)(t_ - t_last)); t_last = t_; } } while (0)
+#else
+#define ENC_CLK(i)
+#endif
+
 __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncConn *conns, uint32_t n) {
   const uint32_t mesh = blockIdx.x, lane = threadIdx.x;
   if (mesh >= n) return;
@@ -73,6 +80,9 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
   uint32_t *opp = (uint32_t *)(arena + E->opp), *voff = (uint32_t *)(arena + E->voff), *vcur = (uint32_t *)(arena + E->vcur);
   uint32_t *vlist = (uint32_t *)(arena + E->vlist), *vcorner = (uint32_t *)(arena + E->vcorner);
   if (E->status != ENC_OK) return;
+#ifdef DSA_ENC_CLOCKS
+  uint64_t t_last = realclk();
+#endif
 
   // ---- corners by vertex (counting sort: counts -> offsets -> lists), CornerTable.cs:41-67 needs them implicitly
   for (uint32_t v = lane; v <= V; v += WAVE) voff[v] = 0;
@@ -97,6 +107,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
   ec_sync();
   for (uint32_t c = lane; c < NC; c += WAVE) vlist[atomicAdd(&vcur[c2v[c]], 1u)] = c;
   ec_sync();
+  ENC_CLK(0);
   // ---- opposites: corner c faces the edge next(c) -> prev(c) = a -> b; its opposite is the corner facing b -> a.  That face has a
   // corner k at b whose next is a (opposite: prev(k)) and a corner k' at a whose previous is b (opposite: next(k')): the shorter of
   // the two vertex lists is searched, so that a vertex of huge valence (the apex of a cone) costs its neighbours nothing.  The same
@@ -122,6 +133,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
     opp[c] = found;
   }
   ec_sync();
+  ENC_CLK(1);
   if (E->status != ENC_OK) return;
   EcTable ct;
   ct.c2v = c2v; ct.opp = opp; ct.vcorner = vcorner;
@@ -146,221 +158,259 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
   ec_sync();
   if (E->status != ENC_OK) return;
 
+  ENC_CLK(2);
   uint8_t *fvis = arena + E->fvis, *vvis = arena + E->vvis, *hole_vis = arena + E->hole_vis;
-  int32_t *hole_id = (int32_t *)(arena + E->hole_id), *split_sym = (int32_t *)(arena + E->split_sym);
+  int32_t *hole_id = (int32_t *)(arena + E->hole_id);
   uint32_t *stack = (uint32_t *)(arena + E->stack), *processed = (uint32_t *)(arena + E->processed), *init_corners = (uint32_t *)(arena + E->init_corners);
   uint8_t *symbols = arena + E->symbols, *start_bits = arena + E->start_bits;
   uint32_t *splits = (uint32_t *)(arena + E->splits);
   uint32_t *d2c = (uint32_t *)(arena + E->d2c);
   int32_t *v2d = (int32_t *)(arena + E->v2d);
-  for (uint32_t f = lane; f < F; f += WAVE) { fvis[f] = 0; split_sym[f] = -1; }
-  for (uint32_t v = lane; v < V; v += WAVE) { vvis[v] = 0; hole_id[v] = -1; hole_vis[v] = 0; v2d[v] = -1; }
+  // ---- what a step of either walk needs of a corner, in ONE 16-byte record: the vertex at it, the corners across its right and left
+  // edge, and the mark of its face (0: not visited; 1: visited; s + 2: visited, and the S with symbol id s was coded at it -- what
+  // MeshEdgeBreakerEncoder.cs keeps in a face -> split symbol map).  A walk reads the records of the two corners it can move to and
+  // has the next step's operands AND this step's "is that face done" in the same round trip.
+  uint4 *hrec = (uint4 *)(arena + E->hrec);
+  for (uint32_t c = lane; c < NC; c += WAVE) hrec[c] = make_uint4(c2v[c], opp[ec_next(c)], opp[ec_prev(c)], 0u);
+  for (uint32_t f = lane; f < F; f += WAVE) fvis[f] = 0;
+  for (uint32_t v = lane; v < V; v += WAVE) { hole_id[v] = -1; hole_vis[v] = 0; v2d[v] = -1; }
   ec_sync();
 
-  if (lane == 0) {
-    // Every walk below ends by itself on a mesh that passed the checks above (the host coder, which has no such counter, was fuzzed
-    // with 20 000 damaged meshes); the counter only makes sure that a kernel can never spin: a GPU does not take Ctrl-C.
-    uint32_t steps = 0;
-    bool failed = false;
-    const uint32_t step_limit = 64u * NC + 4096u;
-    auto runaway = [&]() { if (++steps > step_limit) failed = true; return failed; };
-    // ---- hole ids, MeshEdgeBreakerEncoder.cs:331-361
+  // The walks are sequential by nature and run on lane 0; what the whole wave does for them is LOOK: "the next corner without an
+  // opposite", "the next face not visited" are found 64 candidates at a time, and lane 0 -- which checks again, in order, since
+  // its own work may have settled a candidate meanwhile -- only ever sees the hits.
+  // Every walk below ends by itself on a mesh that passed the checks above (the host coder, which has no such counter, was fuzzed
+  // with 20 000 damaged meshes); the counter only makes sure that a kernel can never spin: a GPU does not take Ctrl-C.
+  uint32_t steps = 0;
+  bool failed = false;
+  const uint32_t step_limit = 64u * NC + 4096u;
+  auto runaway = [&]() { if (++steps > step_limit) failed = true; return failed; };
+  // ---- hole ids, MeshEdgeBreakerEncoder.cs:331-361
+  {
     uint32_t num_holes = 0;
-    for (uint32_t i = 0; i < NC; ++i) {
-      if (opp[i] != DSA_INVALID) continue;
-      uint32_t bv = c2v[ec_next(i)];
-      if (hole_id[bv] != -1) continue;
-      const int32_t id = (int32_t)num_holes++;
-      uint32_t c = i;
-      while (hole_id[bv] == -1 && !runaway()) {
-        hole_id[bv] = id;
-        c = ec_next(c);
-        while (opp[c] != DSA_INVALID && !runaway()) c = ec_next(opp[c]);
-        bv = c2v[ec_next(c)];
+    for (uint32_t base = 0; base < NC; base += WAVE) {
+      const uint32_t i = base + lane;
+      uint64_t open = __builtin_amdgcn_ballot_w64(i < NC && opp[i] == DSA_INVALID);
+      while (open) {
+        const uint32_t at = base + (uint32_t)__builtin_ctzll(open);
+        open &= open - 1;
+        if (lane != 0) continue;
+        uint32_t bv = c2v[ec_next(at)];
+        if (hole_id[bv] != -1) continue;
+        const int32_t id = (int32_t)num_holes++;
+        uint32_t c = at;
+        while (hole_id[bv] == -1 && !runaway()) {
+          hole_id[bv] = id;
+          c = ec_next(c);
+          while (opp[c] != DSA_INVALID && !runaway()) c = ec_next(opp[c]);
+          bv = c2v[ec_next(c)];
+        }
       }
     }
-    // ---- Edgebreaker symbols
-    uint32_t nsym = 0, nproc = 0, ninit = 0, nstart = 0, nsplit = 0, nsplit_sym = 0;
-    int32_t last_symbol_id = -1;
-    auto encode_hole = [&](uint32_t start_corner, bool encode_first) {          // :276-303
-      uint32_t c = ec_prev(start_corner);
+  }
+  ec_sync();
+  // a vertex's marks in one byte: 1 visited, 2 on a boundary (it has a hole id)
+  for (uint32_t v = lane; v < V; v += WAVE) vvis[v] = hole_id[v] != -1 ? 2 : 0;
+  ec_sync();
+  ENC_CLK(3);
+
+  struct Hop { uint32_t v, rc, lc, mark; };                                     // the record of a corner
+  auto hop = [&](uint32_t c) {
+    const uint4 r = hrec[c == DSA_INVALID ? 0u : c];
+    Hop h;
+    h.v = r.x; h.rc = r.y; h.lc = r.z; h.mark = r.w;
+    return h;
+  };
+  auto mark_face = [&](uint32_t first_corner, uint32_t mark) {                  // first_corner = 3 * face
+    hrec[first_corner].w = mark; hrec[first_corner + 1].w = mark; hrec[first_corner + 2].w = mark;
+    fvis[first_corner / 3] = 1;
+  };
+  // ---- Edgebreaker symbols
+  uint32_t nsym = 0, nproc = 0, ninit = 0, nstart = 0, nsplit = 0, nsplit_sym = 0;
+  int32_t last_symbol_id = -1;
+  auto encode_hole = [&](uint32_t start_corner, bool encode_first) {            // :276-303
+    uint32_t c = ec_prev(start_corner);
+    while (opp[c] != DSA_INVALID && !runaway()) c = ec_next(opp[c]);
+    const uint32_t start_v = c2v[start_corner];
+    if (encode_first) vvis[start_v] |= 1;
+    if (hole_id[start_v] >= 0) hole_vis[hole_id[start_v]] = 1;
+    uint32_t act = c2v[ec_prev(c)];
+    while (act != start_v && !runaway()) {
+      vvis[act] |= 1;
+      c = ec_next(c);
       while (opp[c] != DSA_INVALID && !runaway()) c = ec_next(opp[c]);
-      const uint32_t start_v = c2v[start_corner];
-      if (encode_first) vvis[start_v] = 1;
-      if (hole_id[start_v] >= 0) hole_vis[hole_id[start_v]] = 1;
-      uint32_t act = c2v[ec_prev(c)];
-      while (act != start_v && !runaway()) {
-        vvis[act] = 1;
-        c = ec_next(c);
-        while (opp[c] != DSA_INVALID && !runaway()) c = ec_next(opp[c]);
-        act = c2v[ec_prev(c)];
-      }
-    };
-    auto check_split = [&](int32_t src_symbol, uint32_t edge, uint32_t neighbor_face) {   // :373-390
-      const int32_t s = split_sym[neighbor_face];
-      if (s < 0) return;
-      if (nsplit >= E->split_cap) { failed = true; return; }
-      splits[3 * nsplit] = (uint32_t)src_symbol; splits[3 * nsplit + 1] = (uint32_t)s; splits[3 * nsplit + 2] = edge;
-      ++nsplit;
-    };
-    // A step of either walk reads a handful of words that hang off each other (corner -> vertex and the corners across its two
-    // edges -> the marks of that vertex and of those two faces), and on the device every dependent read is a round trip to memory
-    // that nothing else of the wave hides.  So the reads of a step are issued together, level by level, and the first level of
-    // the next step -- for both corners it can move to -- rides along with the second level of this one: one round trip per
-    // step instead of four.  Same reads, same decisions (a face across an edge is never the face itself, whose mark this step sets).
-    struct Hop { uint32_t v, rc, lc; };                                           // vertex at a corner, corners across its right / left edge
-    auto hop = [&](uint32_t c) {
-      const uint32_t cc = c == DSA_INVALID ? 0u : c;
-      Hop h;
-      h.v = c2v[cc]; h.rc = opp[ec_next(cc)]; h.lc = opp[ec_prev(cc)];
-      return h;
-    };
-    auto encode_from_corner = [&](uint32_t corner0) {                             // :185-274
-      uint32_t sp = 0;
-      stack[sp++] = corner0;
-      while (sp && !failed) {
-        uint32_t corner = stack[sp - 1];
-        if (corner == DSA_INVALID || fvis[corner / 3]) { --sp; continue; }
-        Hop cur = hop(corner);
-        for (;;) {
-          if (runaway() || nsym >= F || nproc >= F || sp >= F) { failed = true; break; }
-          ++last_symbol_id;
-          const uint32_t face = corner / 3;
-          const uint32_t v = cur.v, rc = cur.rc, lc = cur.lc;
-          const uint32_t rf = rc == DSA_INVALID ? DSA_INVALID : rc / 3, lf = lc == DSA_INVALID ? DSA_INVALID : lc / 3;
-          const int32_t hid = hole_id[v];
-          const bool seen = vvis[v] != 0;
-          const bool r_done = rf == DSA_INVALID || rf == face || fvis[rf] != 0, l_done = lf == DSA_INVALID || lf == face || fvis[lf] != 0;
-          const Hop hr = hop(rc), hl = hop(lc);
-          fvis[face] = 1;
-          processed[nproc++] = corner;
-          const bool on_boundary = hid != -1;
-          if (!seen) {
-            vvis[v] = 1;
-            if (!on_boundary) { symbols[nsym++] = 0; corner = rc; cur = hr; continue; }
+      act = c2v[ec_prev(c)];
+    }
+  };
+  auto check_split = [&](int32_t src_symbol, uint32_t edge, uint32_t neighbor_mark) {     // :373-390
+    if (neighbor_mark < 2u) return;
+    if (nsplit >= E->split_cap) { failed = true; return; }
+    splits[3 * nsplit] = (uint32_t)src_symbol; splits[3 * nsplit + 1] = neighbor_mark - 2u; splits[3 * nsplit + 2] = edge;
+    ++nsplit;
+  };
+  // A step reads three things that all hang off what the previous step loaded -- the marks of the vertex, the records of the two
+  // corners across -- and issues them together: one round trip per step (a face across an edge is never the face itself on a
+  // manifold mesh; the test stays, the mark of the face itself being what this step sets).
+  auto encode_from_corner = [&](uint32_t corner0) {                             // :185-274
+    uint32_t sp = 0;
+    stack[sp++] = corner0;
+    while (sp && !failed) {
+      uint32_t corner = stack[sp - 1];
+      if (corner == DSA_INVALID || fvis[corner / 3]) { --sp; continue; }
+      Hop cur = hop(corner);
+      for (;;) {
+        if (runaway() || nsym >= F || nproc >= F || sp >= F) { failed = true; break; }
+        ++last_symbol_id;
+        const uint32_t first = corner - corner % 3;
+        const uint32_t v = cur.v, rc = cur.rc, lc = cur.lc;
+        const uint32_t vm = vvis[v];
+        const Hop hr = hop(rc), hl = hop(lc);
+        const bool r_self = rc - first < 3u, l_self = lc - first < 3u;            // (an invalid corner is far from any face)
+        const bool r_done = rc == DSA_INVALID || r_self || hr.mark != 0, l_done = lc == DSA_INVALID || l_self || hl.mark != 0;
+        const bool seen = (vm & 1u) != 0, on_boundary = (vm & 2u) != 0;
+        mark_face(first, 1u);
+        processed[nproc++] = corner;
+        if (!seen) {
+          vvis[v] = (uint8_t)(vm | 1u);
+          if (!on_boundary) { symbols[nsym++] = 0; corner = rc; cur = hr; continue; }
+        }
+        if (r_done) {
+          if (rc != DSA_INVALID && !r_self) check_split(last_symbol_id, 1, hr.mark);
+          if (l_done) {
+            if (lc != DSA_INVALID && !l_self) check_split(last_symbol_id, 0, hl.mark);
+            symbols[nsym++] = 7;
+            --sp;
+            break;
           }
-          if (r_done) {
-            if (rf != DSA_INVALID) check_split(last_symbol_id, 1, rf);
-            if (l_done) {
-              if (lf != DSA_INVALID) check_split(last_symbol_id, 0, lf);
-              symbols[nsym++] = 7;
-              --sp;
-              break;
-            }
-            symbols[nsym++] = 5;
-            corner = lc; cur = hl;
+          symbols[nsym++] = 5;
+          corner = lc; cur = hl;
+        } else {
+          if (l_done) {
+            if (lc != DSA_INVALID && !l_self) check_split(last_symbol_id, 0, hl.mark);
+            symbols[nsym++] = 3;
+            corner = rc; cur = hr;
           } else {
-            if (l_done) {
-              if (lf != DSA_INVALID) check_split(last_symbol_id, 0, lf);
-              symbols[nsym++] = 3;
-              corner = rc; cur = hr;
-            } else {
-              symbols[nsym++] = 1;
-              ++nsplit_sym;
-              if (on_boundary) { if (!hole_vis[hid]) encode_hole(corner, false); }
-              split_sym[face] = last_symbol_id;
-              stack[sp - 1] = lc;
-              stack[sp++] = rc;                       // sp <= F: every push marks a face first
-              break;
-            }
+            symbols[nsym++] = 1;
+            ++nsplit_sym;
+            if (on_boundary) { const int32_t hid = hole_id[v]; if (!hole_vis[hid]) encode_hole(corner, false); }
+            mark_face(first, (uint32_t)last_symbol_id + 2u);
+            stack[sp - 1] = lc;
+            stack[sp++] = rc;                         // sp <= F: every push marks a face first
+            break;
           }
         }
-      }
-    };
-    for (uint32_t c = 0; c < NC && !failed; ++c) {                                 // :38-124
-      const uint32_t face = c / 3;
-      if (fvis[face]) continue;
-      // find_init_face, :158-183
-      uint32_t corner = 3 * face, start = DSA_INVALID;
-      bool interior_face = true;
-      for (int i = 0; i < 3; ++i) {
-        if (opp[corner] == DSA_INVALID) { start = corner; interior_face = false; break; }
-        if (hole_id[c2v[corner]] != -1) {
-          uint32_t rc = corner;
-          while (rc != DSA_INVALID && !runaway()) { corner = rc; rc = ct.swing_right(rc); }
-          start = ec_prev(corner);
-          interior_face = false;
-          break;
-        }
-        corner = ec_next(corner);
-      }
-      if (interior_face) start = corner;
-      start_bits[nstart++] = interior_face ? 1 : 0;
-      if (interior_face) {
-        vvis[c2v[start]] = 1; vvis[c2v[ec_next(start)]] = 1; vvis[c2v[ec_prev(start)]] = 1;
-        fvis[face] = 1;
-        init_corners[ninit++] = ec_next(start);
-        const uint32_t o = opp[ec_next(start)];
-        if (o != DSA_INVALID && !fvis[o / 3]) encode_from_corner(o);
-      } else {
-        encode_hole(ec_next(start), true);
-        encode_from_corner(start);
       }
     }
+  };
+  for (uint32_t base = 0; base < F; base += WAVE) {                               // :38-124
+    const uint32_t fl = base + lane;
+    uint64_t fresh = __builtin_amdgcn_ballot_w64(fl < F && fvis[fl] == 0);
+    while (fresh) {
+      const uint32_t face = base + (uint32_t)__builtin_ctzll(fresh);
+      fresh &= fresh - 1;
+      if (lane != 0) continue;
+      // (the reference asks at each of the three corners of a face whether the face is still to do)
+      for (int rep = 0; rep < 3 && !failed && !fvis[face]; ++rep) {
+        // find_init_face, :158-183
+        uint32_t corner = 3 * face, start = DSA_INVALID;
+        bool interior_face = true;
+        for (int i = 0; i < 3; ++i) {
+          if (opp[corner] == DSA_INVALID) { start = corner; interior_face = false; break; }
+          if (hole_id[c2v[corner]] != -1) {
+            uint32_t rc = corner;
+            while (rc != DSA_INVALID && !runaway()) { corner = rc; rc = ct.swing_right(rc); }
+            start = ec_prev(corner);
+            interior_face = false;
+            break;
+          }
+          corner = ec_next(corner);
+        }
+        if (interior_face) start = corner;
+        start_bits[nstart++] = interior_face ? 1 : 0;
+        if (interior_face) {
+          vvis[c2v[start]] |= 1; vvis[c2v[ec_next(start)]] |= 1; vvis[c2v[ec_prev(start)]] |= 1;
+          mark_face(3 * face, 1u);
+          init_corners[ninit++] = ec_next(start);
+          const uint32_t o = opp[ec_next(start)];
+          if (o != DSA_INVALID && !fvis[o / 3]) encode_from_corner(o);
+        } else {
+          encode_hole(ec_next(start), true);
+          encode_from_corner(start);
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    ENC_CLK(4);
     if (failed) ec_fail(E, steps > step_limit ? ENC_RING : ENC_SPLITS, nsplit);
     E->num_symbols = nsym; E->num_start_bits = nstart; E->num_splits = nsplit; E->num_split_symbols = nsplit_sym;
     E->num_processed = nproc; E->num_init = ninit; E->interior_edges = interior / 2;
-    __threadfence_block();
   }
-  __syncthreads();
+  ec_sync();
   if (E->status != ENC_OK) return;
   // the traversal marks start over for the attribute order
+  for (uint32_t c = lane; c < NC; c += WAVE) hrec[c].w = 0;
   for (uint32_t f = lane; f < F; f += WAVE) fvis[f] = 0;
-  for (uint32_t v = lane; v < V; v += WAVE) vvis[v] = 0;
+  for (uint32_t v = lane; v < V; v += WAVE) vvis[v] &= 2;
   ec_sync();
-  if (lane == 0) {
+  {
     // ---- depth-first attribute order over the decoder's face order (processed corners last to first, then the init
-    // corners), DepthFirstTraverser.cs:9-99
-    const uint32_t nproc = E->num_processed, ninit = E->num_init;
+    // corners), DepthFirstTraverser.cs:9-99.  A vertex is on a boundary -- SwingLeft of its left-most corner is invalid -- exactly
+    // when the hole pass gave it an id.
+    const uint32_t nproc = E->num_processed, ninit = E->num_init, nstarts = nproc + ninit;
     uint32_t count = 0, dfs_steps = 0;
     bool stuck = false;
-    auto visit = [&](uint32_t v, uint32_t c) { vvis[v] = 1; v2d[v] = (int32_t)count; if (count < V) d2c[count] = c; ++count; };
-    auto fdone = [&](uint32_t f) { return f == DSA_INVALID || fvis[f] != 0; };
-    for (uint32_t i = 0; i < nproc + ninit; ++i) {
-      const uint32_t start = i < nproc ? processed[nproc - 1 - i] : init_corners[i - nproc];
-      if (fdone(start / 3)) continue;
-      uint32_t sp = 0;
-      stack[sp++] = start;
-      const uint32_t nvx = c2v[ec_next(start)], pvx = c2v[ec_prev(start)];
-      if (!vvis[nvx]) visit(nvx, ec_next(start));
-      if (!vvis[pvx]) visit(pvx, ec_prev(start));
-      while (sp && !stuck) {
-        uint32_t corner = stack[sp - 1];
-        uint32_t face = corner == DSA_INVALID ? DSA_INVALID : corner / 3;
-        if (corner == DSA_INVALID || fdone(face)) { --sp; continue; }
-        // (the reads of a step together, the next step's first reads with them: see the Edgebreaker walk above.  A vertex is
-        // on a boundary -- SwingLeft of its left-most corner is invalid -- exactly when the hole pass gave it an id.)
-        uint32_t cv = c2v[corner], crc = opp[ec_next(corner)], clc = opp[ec_prev(corner)];
-        for (;;) {
-          if (++dfs_steps > 64u * NC + 4096u || sp >= F || count > V) { stuck = true; break; }
-          const uint32_t v = cv, rc = crc, lc = clc;
-          const uint32_t rf = rc == DSA_INVALID ? DSA_INVALID : rc / 3, lf = lc == DSA_INVALID ? DSA_INVALID : lc / 3;
-          const bool seen = vvis[v] != 0, ob = hole_id[v] != -1;
-          const bool r_done = rf == DSA_INVALID || rf == face || fvis[rf] != 0, l_done = lf == DSA_INVALID || lf == face || fvis[lf] != 0;
-          const uint32_t rcc = rc == DSA_INVALID ? 0u : rc, lcc = lc == DSA_INVALID ? 0u : lc;
-          const uint32_t rv = c2v[rcc], rrc = opp[ec_next(rcc)], rlc = opp[ec_prev(rcc)];
-          const uint32_t lv = c2v[lcc], lrc = opp[ec_next(lcc)], llc = opp[ec_prev(lcc)];
-          fvis[face] = 1;
-          if (!seen) {
-            visit(v, corner);
-            if (!ob) { corner = rc; face = rf; cv = rv; crc = rrc; clc = rlc; continue; }
-          }
-          if (r_done) {
-            if (l_done) { --sp; break; }
-            corner = lc; face = lf; cv = lv; crc = lrc; clc = llc;
-          } else {
-            if (l_done) { corner = rc; face = rf; cv = rv; crc = rrc; clc = rlc; }
-            else { stack[sp - 1] = lc; stack[sp++] = rc; break; }
+    auto visit = [&](uint32_t v, uint32_t vm, uint32_t c) { vvis[v] = (uint8_t)(vm | 1u); v2d[v] = (int32_t)count; if (count < V) d2c[count] = c; ++count; };
+    for (uint32_t base = 0; base < nstarts; base += WAVE) {
+      const uint32_t i = base + lane;
+      const uint32_t mine = i < nstarts ? (i < nproc ? processed[nproc - 1 - i] : init_corners[i - nproc]) : DSA_INVALID;
+      uint64_t fresh = __builtin_amdgcn_ballot_w64(mine != DSA_INVALID && fvis[mine / 3] == 0);
+      while (fresh) {
+        const int from = __builtin_ctzll(fresh);
+        fresh &= fresh - 1;
+        const uint32_t start = (uint32_t)__shfl((int)mine, from, WAVE);
+        if (lane != 0 || stuck) continue;
+        if (fvis[start / 3]) continue;
+        uint32_t sp = 0;
+        stack[sp++] = start;
+        const uint32_t nvx = c2v[ec_next(start)], pvx = c2v[ec_prev(start)];
+        { const uint32_t m = vvis[nvx]; if (!(m & 1u)) visit(nvx, m, ec_next(start)); }
+        { const uint32_t m = vvis[pvx]; if (!(m & 1u)) visit(pvx, m, ec_prev(start)); }
+        while (sp && !stuck) {
+          uint32_t corner = stack[sp - 1];
+          if (corner == DSA_INVALID || fvis[corner / 3]) { --sp; continue; }
+          Hop cur = hop(corner);
+          for (;;) {
+            if (++dfs_steps > 64u * NC + 4096u || sp >= F || count > V) { stuck = true; break; }
+            const uint32_t first = corner - corner % 3;
+            const uint32_t v = cur.v, rc = cur.rc, lc = cur.lc;
+            const uint32_t vm = vvis[v];
+            const Hop hr = hop(rc), hl = hop(lc);
+            const bool r_done = rc == DSA_INVALID || rc - first < 3u || hr.mark != 0, l_done = lc == DSA_INVALID || lc - first < 3u || hl.mark != 0;
+            mark_face(first, 1u);
+            if (!(vm & 1u)) {
+              visit(v, vm, corner);
+              if (!(vm & 2u)) { corner = rc; cur = hr; continue; }
+            }
+            if (r_done) {
+              if (l_done) { --sp; break; }
+              corner = lc; cur = hl;
+            } else {
+              if (l_done) { corner = rc; cur = hr; }
+              else { stack[sp - 1] = lc; stack[sp++] = rc; break; }
+            }
           }
         }
       }
     }
-    E->num_entries = count;
-    if (stuck) ec_fail(E, ENC_RING, count);
-    else if (count != V) ec_fail(E, ENC_UNREACHED, count);
-    __threadfence_block();
+    if (lane == 0) {
+      ENC_CLK(5);
+      E->num_entries = count;
+      if (stuck) ec_fail(E, ENC_RING, count);
+      else if (count != V) ec_fail(E, ENC_UNREACHED, count);
+    }
   }
-  __syncthreads();
+  ec_sync();
   if (E->status != ENC_OK) return;
   // ---- entry -> vertex and the parallelogram operand entries of every entry (MeshPredictionSchemeParallelogramEncoder.cs:35-56)
   uint32_t *e2v = (uint32_t *)(arena + E->e2v);
@@ -378,6 +428,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
     }
     ops[3 * p] = on; ops[3 * p + 1] = op; ops[3 * p + 2] = oo;
   }
+  ENC_CLK(6);
 }
 
 }  // namespace dsa
