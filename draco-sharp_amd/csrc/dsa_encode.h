@@ -14,7 +14,7 @@
 //                              k_enc_corr        prediction, correction, zig-zag, symbol statistics     MeshPredictionSchemeParallelogramEncoder.cs:35-56,
 //                                                                                                       PredictionSchemeWrapEncodingTransform.cs:45-90,
 //                                                                                                       ...NormalOctahedronCanonicalizedEncodingTransform.cs:47-83
-//                              k_enc_rans        rANS coding of every stream, one lane per stream        RAnsEncoder.cs:22-30, AnsEncoder.cs:34-64, SymbolEncoding.cs:92-193
+//                              k_enc_rans        rANS coding of every stream, one wave per stream        RAnsEncoder.cs:22-30, AnsEncoder.cs:34-64, SymbolEncoding.cs:92-193
 //                              k_enc_plan        symbol-scheme choice + frequency-table normalisation from the histograms, one lane per
 //                                                stream (dsa_symbol_plan.h, the code the host coder runs)   SymbolEncoding.cs:8-40, RAnsSymbolEncoder.cs:15-123
 //   host  (dsa_encode_host.h)  input checks; at the end the stream layout: bit-packing of the Edgebreaker symbols, table bytes, section order
@@ -257,11 +257,14 @@ __global__ __launch_bounds__(WAVE) void k_enc_plan(uint8_t *arena, EncStream *st
   S.method = (uint32_t)method; S.usbl = (uint32_t)usbl; S.precision_bits = (uint32_t)pb; S.num_symbols = nsym;
 }
 
-// rANS coding, one lane per stream (no cross-lane traffic; the wave shares the instruction stream).
+// rANS coding, one WAVE per stream.  The coder state is a serial chain (x' = (x / p) << bits + x % p + cum after the renormalisation
+// bytes), so it lives in scalar registers; what the wave does in parallel is everything off the chain: 64 symbols at a time are
+// looked up (frequency, cumulative count, and the reciprocal that turns the division into a multiply-high with one correction),
+// and the bytes collect in a register, a lane each, and leave 64 at a time.
 // Symbols are fed last -> first (SymbolEncoding.cs:177-183); bytes are written in coding order, the decoder reads
 // them from the end (RAnsEncoder.cs:22-30, AnsEncoder.cs:34-64).
 __global__ __launch_bounds__(WAVE) void k_enc_rans(uint8_t *arena, EncStream *streams, uint32_t ns) {
-  const uint32_t si = blockIdx.x * WAVE + threadIdx.x;
+  const uint32_t si = blockIdx.x, lane = threadIdx.x;
   if (si >= ns) return;
   EncStream &S = streams[si];
   if (S.overflow) return;
@@ -269,17 +272,44 @@ __global__ __launch_bounds__(WAVE) void k_enc_rans(uint8_t *arena, EncStream *st
   const uint32_t *syms = (const uint32_t *)(arena + S.syms);
   const uint8_t *bl = arena + S.bl;
   uint8_t *out = arena + S.out_rans;
-  const uint32_t pb = S.precision_bits, precision = 1u << pb, l_base = precision * 4u;
+  const uint32_t pb = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.precision_bits), precision = 1u << pb, l_base = precision * 4u;
   const bool tagged = S.method == 0;
-  const uint32_t n = tagged ? S.nv : S.nv * S.nc;
-  uint32_t state = l_base, len = 0;
-  const uint32_t cap = S.out_cap;
-  for (uint32_t k = n; k-- > 0;) {
-    const uint32_t s = tagged ? (uint32_t)bl[k] : syms[k];
-    const uint32_t p = prob[s];
-    const uint64_t lim = (uint64_t)(l_base / precision) * 256u * p;
-    while ((uint64_t)state >= lim) { if (len < cap) out[len] = (uint8_t)(state & 0xFF); ++len; state >>= 8; }
-    state = (state / p) * precision + state % p + cum[s];
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tagged ? S.nv : S.nv * S.nc));
+  const uint32_t cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.out_cap);
+  uint32_t state = l_base, len = 0;                 // wave-uniform
+  uint32_t held = 0, bytes = 0;                     // bytes of lane j of `bytes`: out[len - held + j], j < held
+  auto emit = [&](uint32_t byte) {
+    bytes = lane == held ? byte : bytes;
+    ++held; ++len;
+    if (held == WAVE) {
+      const uint32_t at = len - WAVE + lane;
+      if (at < cap) out[at] = (uint8_t)bytes;
+      held = 0;
+    }
+  };
+  for (uint32_t hi = n; hi > 0;) {
+    const uint32_t cnt = hi < WAVE ? hi : WAVE;
+    // lane j holds the j-th symbol of this stretch in coding order
+    uint32_t p = 1, c = 0, magic = 0;
+    if (lane < cnt) {
+      const uint32_t k = hi - 1 - lane;
+      const uint32_t sym = tagged ? (uint32_t)bl[k] : syms[k];
+      p = prob[sym]; c = cum[sym];
+      if (p == 0) p = 1;                              // (a symbol that occurs has a frequency; a zero here must not spin the loop below)
+      magic = p > 1 ? 0xFFFFFFFFu / p + 1u : 0u;      // ceil(2^32 / p)
+    }
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)j), cj = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)j);
+      const uint32_t mj = (uint32_t)__builtin_amdgcn_readlane((int)magic, (int)j);
+      const uint32_t lim = pj << 10;                // (l_base / precision) * 256 * p; p <= precision <= 2^20
+      while (state >= lim) { emit(state & 0xFFu); state >>= 8; }
+      // state / p: the multiply-high by ceil(2^32 / p) is the quotient or one more (state < 2^32, error < state / 2^32 < 1)
+      uint32_t q = pj > 1 ? __umulhi(state, mj) : state;
+      uint32_t r = state - q * pj;
+      if ((int32_t)r < 0) { --q; r += pj; }
+      state = (q << pb) + r + cj;
+    }
+    hi -= cnt;
   }
   const uint32_t fs = state - l_base;
   uint32_t v, nb;
@@ -287,7 +317,9 @@ __global__ __launch_bounds__(WAVE) void k_enc_rans(uint8_t *arena, EncStream *st
   else if (fs < (1u << 14)) { v = 0x4000u + fs; nb = 2; }
   else if (fs < (1u << 22)) { v = 0x800000u + fs; nb = 3; }
   else { v = 0xC0000000u + fs; nb = 4; }
-  for (uint32_t i = 0; i < nb; ++i) { if (len < cap) out[len] = (uint8_t)((v >> (8 * i)) & 0xFF); ++len; }
+  for (uint32_t i = 0; i < nb; ++i) emit((v >> (8 * i)) & 0xFFu);
+  if (lane < held) { const uint32_t at = len - held + lane; if (at < cap) out[at] = (uint8_t)bytes; }
+  if (lane != 0) return;
   S.rans_len = len;
   if (len > cap || fs >= (1u << 30)) S.overflow = 1;
   // tagged scheme: the values follow as raw LSB-first bit fields of their entry's length (SymbolEncoding.cs:117-137)
@@ -499,7 +531,7 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
       const uint32_t F = meshes[i].num_faces;
       dsa::EncConn &C = hc[i];
       memset(&C, 0, sizeof(C));
-      C.F = F; C.V = V; C.split_cap = F;
+      C.F = F; C.V = V; C.split_cap = F; C.fail_key = 0xFFFFFFFFu;
       C.faces = take_in(12ull * F); uploads.push_back({C.faces, meshes[i].faces, 12ull * F});
       C.opp = take(12ull * F); C.voff = take(4ull * (V + 1)); C.vcur = take(4ull * V); C.vlist = take(12ull * F); C.vcorner = take(4ull * V);
       C.fvis = take(F); C.vvis = take(V); C.hole_id = take(4ull * V); C.hole_vis = take(V); C.hrec = take(48ull * F);
@@ -607,7 +639,17 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
       d_conns = (dsa::EncConn *)lane.conns.p;
       for (uint32_t i = 0; i < n; ++i) if (E->status[i] != DSA_OK) { memset(&hc[i], 0, sizeof(hc[i])); hc[i].status = dsa::ENC_ISOLATED; }
       ENC_TRY(hipMemcpyAsync(d_conns, hc.data(), sizeof(dsa::EncConn) * n, hipMemcpyHostToDevice, st));
+      uint32_t maxf = 0;
+      for (uint32_t i = 0; i < n; ++i) maxf = std::max(maxf, hc[i].F);
+      const dim3 gt(std::max(1u, std::min(128u, (3u * maxf + 1023u) / 1024u)), n);        // table kernels: blocks per mesh x meshes
+      hipLaunchKernelGGL(dsa::k_enc_table_clear, gt, dim3(256), 0, st, arena, d_conns, n);
+      hipLaunchKernelGGL(dsa::k_enc_table_count, gt, dim3(256), 0, st, arena, d_conns, n);
+      hipLaunchKernelGGL(dsa::k_enc_table_offsets, dim3(n), dim3(WAVE), 0, st, arena, d_conns, n);
+      hipLaunchKernelGGL(dsa::k_enc_table_lists, gt, dim3(256), 0, st, arena, d_conns, n);
+      hipLaunchKernelGGL(dsa::k_enc_table_opposites, gt, dim3(256), 0, st, arena, d_conns, n);
+      hipLaunchKernelGGL(dsa::k_enc_table_corners, gt, dim3(256), 0, st, arena, d_conns, n);
       hipLaunchKernelGGL(dsa::k_enc_connectivity, dim3(n), dim3(WAVE), 0, st, arena, d_conns, n);
+      hipLaunchKernelGGL(dsa::k_enc_operands, gt, dim3(256), 0, st, arena, d_conns, n);
     }
     // ---- device phase 1: quantise, order, correct, count
     hipLaunchKernelGGL(dsa::k_enc_bounds, dim3(ns), dim3(256), 0, st, arena, d_streams, ns);
@@ -616,7 +658,7 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
     hipLaunchKernelGGL(dsa::k_enc_corr, dim3(gx, ns), dim3(256), 0, st, arena, d_streams, ns);
     if (!host_plan) {       // device phase 2 follows at once: tables by k_enc_plan, no host round trip
       hipLaunchKernelGGL(dsa::k_enc_plan, dim3((ns + WAVE - 1) / WAVE), dim3(WAVE), 0, st, arena, d_streams, ns, (int)opt.force_scheme, (int)opt.compression_level);
-      hipLaunchKernelGGL(dsa::k_enc_rans, dim3((ns + WAVE - 1) / WAVE), dim3(WAVE), 0, st, arena, d_streams, ns);
+      hipLaunchKernelGGL(dsa::k_enc_rans, dim3(ns), dim3(WAVE), 0, st, arena, d_streams, ns);
     }
     ENC_TRY(hipMemcpyAsync(hs.data(), d_streams, sizeof(dsa::EncStream) * ns, hipMemcpyDeviceToHost, st));
     if (!host_conn) ENC_TRY(hipMemcpyAsync(hc.data(), d_conns, sizeof(dsa::EncConn) * n, hipMemcpyDeviceToHost, st));
@@ -627,8 +669,8 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
       unsigned long long clk[16] = {0}, zero[16] = {0};
       (void)hipMemcpyFromSymbol(clk, HIP_SYMBOL(dsa::g_enc_clocks), sizeof(clk));
       (void)hipMemcpyToSymbol(HIP_SYMBOL(dsa::g_enc_clocks), zero, sizeof(zero));
-      static const char *names[7] = {"corners by vertex", "opposites", "left-most + checks", "hole ids", "edgebreaker walk", "dfs walk", "operands"};
-      for (int i = 0; i < 7; ++i) fprintf(stderr, "[k_enc_connectivity] %-20s %8.2f ms per mesh\n", names[i], clk[i] / 100e3 / n);
+      static const char *names[6] = {"", "", "", "hole ids", "edgebreaker walk", "dfs walk"};
+      for (int i = 3; i < 6; ++i) fprintf(stderr, "[k_enc_connectivity] %-20s %8.2f ms per mesh\n", names[i], clk[i] / 100e3 / n);
     }
 #endif
     if (!host_conn) {
@@ -731,7 +773,7 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
     hipStream_t st = lane.st;
     if (host_plan) {
       ENC_TRY(hipMemcpyAsync(d_streams, hs.data(), sizeof(dsa::EncStream) * ns, hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(dsa::k_enc_rans, dim3((ns + WAVE - 1) / WAVE), dim3(WAVE), 0, st, arena, d_streams, ns);
+      hipLaunchKernelGGL(dsa::k_enc_rans, dim3(ns), dim3(WAVE), 0, st, arena, d_streams, ns);
       ENC_TRY(hipMemcpyAsync(hs.data(), d_streams, sizeof(dsa::EncStream) * ns, hipMemcpyDeviceToHost, st));
       ENC_TRY(hipStreamSynchronize(st));
     }

@@ -29,7 +29,8 @@ struct EncConn {                   // one per mesh; device memory, mirrored on t
   uint64_t splits;                 // u32[3 * split_cap] OUTPUT (source, split, edge)
   uint64_t d2c, v2d;               // u32[V], i32[V]
   uint64_t e2v, ops;               // u32[V], i32[3V] OUTPUT for the attribute kernels
-  uint32_t F, V, split_cap, pad0;
+  uint32_t F, V, split_cap;
+  uint32_t fail_key;               // k_enc_table_corners: the least status code that any vertex earned (the host coder's order of checks), or ~0
   uint32_t num_symbols, num_start_bits, num_splits, num_split_symbols, num_processed, num_init, num_entries, interior_edges;   // OUTPUT
   uint32_t status, detail;         // 0 ok; else the host coder's complaint (see enc_conn_message)
 };
@@ -71,48 +72,75 @@ __device__ unsigned long long g_enc_clocks[16];
 #define ENC_CLK(i)
 #endif
 
-__global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncConn *conns, uint32_t n) {
-  const uint32_t mesh = blockIdx.x, lane = threadIdx.x;
-  if (mesh >= n) return;
-  EncConn *E = &conns[mesh];
-  const uint32_t F = E->F, V = E->V, NC = 3u * F;
-  const uint32_t *c2v = (const uint32_t *)(arena + E->faces);
-  uint32_t *opp = (uint32_t *)(arena + E->opp), *voff = (uint32_t *)(arena + E->voff), *vcur = (uint32_t *)(arena + E->vcur);
-  uint32_t *vlist = (uint32_t *)(arena + E->vlist), *vcorner = (uint32_t *)(arena + E->vcorner);
-  if (E->status != ENC_OK) return;
-#ifdef DSA_ENC_CLOCKS
-  uint64_t t_last = realclk();
-#endif
+// The corner table is built by kernels of their own, every mesh of the chunk on as many blocks as its corners ask for (grid: blocks
+// per mesh x meshes): nothing in it is sequential, and on one wave per mesh -- where the walks below have to live -- it took a
+// quarter of the connectivity time.  A step that needs the previous one complete for the whole mesh is a launch.
+#define ENC_TABLE_PROLOGUE                                                                          \
+  const uint32_t mesh = blockIdx.y;                                                                 \
+  if (mesh >= n) return;                                                                            \
+  EncConn *E = &conns[mesh];                                                                        \
+  if (E->status != ENC_OK) return;                                                                  \
+  const uint32_t F = E->F, V = E->V, NC = 3u * F;                                                   \
+  const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;       \
+  const uint32_t *c2v = (const uint32_t *)(arena + E->faces);                                       \
+  (void)F; (void)V; (void)NC; (void)t0; (void)stride; (void)c2v;
 
-  // ---- corners by vertex (counting sort: counts -> offsets -> lists), CornerTable.cs:41-67 needs them implicitly
-  for (uint32_t v = lane; v <= V; v += WAVE) voff[v] = 0;
-  ec_sync();
-  for (uint32_t c = lane; c < NC; c += WAVE) {
+// counts start at zero; the marks of the walks too
+__global__ __launch_bounds__(256) void k_enc_table_clear(uint8_t *arena, EncConn *conns, uint32_t n) {
+  ENC_TABLE_PROLOGUE
+  uint32_t *voff = (uint32_t *)(arena + E->voff);
+  uint8_t *fvis = arena + E->fvis, *hole_vis = arena + E->hole_vis;
+  int32_t *hole_id = (int32_t *)(arena + E->hole_id), *v2d = (int32_t *)(arena + E->v2d);
+  for (uint32_t v = t0; v <= V; v += stride) voff[v] = 0;
+  for (uint32_t f = t0; f < F; f += stride) fvis[f] = 0;
+  for (uint32_t v = t0; v < V; v += stride) { hole_id[v] = -1; hole_vis[v] = 0; v2d[v] = -1; }
+}
+
+// ---- corners by vertex (counting sort: counts -> offsets -> lists), CornerTable.cs:41-67 needs them implicitly
+__global__ __launch_bounds__(256) void k_enc_table_count(uint8_t *arena, EncConn *conns, uint32_t n) {
+  ENC_TABLE_PROLOGUE
+  uint32_t *voff = (uint32_t *)(arena + E->voff);
+  for (uint32_t c = t0; c < NC; c += stride) {
     const uint32_t a = c2v[ec_next(c)], b = c2v[ec_prev(c)];
     if (a == b || a == c2v[c] || b == c2v[c]) ec_fail(E, ENC_DEGENERATE, c / 3);
     atomicAdd(&voff[c2v[c] + 1], 1u);
   }
-  ec_sync();
+}
+
+// exclusive prefix sum, one wave per mesh: voff[v + 1] held count(v)
+__global__ __launch_bounds__(WAVE) void k_enc_table_offsets(uint8_t *arena, EncConn *conns, uint32_t n) {
+  const uint32_t mesh = blockIdx.x, lane = threadIdx.x;
+  if (mesh >= n) return;
+  EncConn *E = &conns[mesh];
   if (E->status != ENC_OK) return;
-  {                                                  // exclusive prefix sum: voff[v + 1] held count(v)
-    uint32_t base = 0;
-    for (uint32_t v0 = 0; v0 < V; v0 += WAVE) {
-      const uint32_t v = v0 + lane;
-      uint32_t x = v < V ? voff[v + 1] : 0u, incl = x;
-      for (int d = 1; d < WAVE; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, WAVE); if ((int)lane >= d) incl += y; }
-      if (v < V) { voff[v + 1] = base + incl; vcur[v] = base + incl - x; }
-      base += (uint32_t)__shfl((int)incl, WAVE - 1, WAVE);
-    }
+  const uint32_t V = E->V;
+  uint32_t *voff = (uint32_t *)(arena + E->voff), *vcur = (uint32_t *)(arena + E->vcur);
+  uint32_t base = 0;
+  for (uint32_t v0 = 0; v0 < V; v0 += WAVE) {
+    const uint32_t v = v0 + lane;
+    uint32_t x = v < V ? voff[v + 1] : 0u, incl = x;
+    for (int d = 1; d < WAVE; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, WAVE); if ((int)lane >= d) incl += y; }
+    if (v < V) { voff[v + 1] = base + incl; vcur[v] = base + incl - x; }
+    base += (uint32_t)__shfl((int)incl, WAVE - 1, WAVE);
   }
-  ec_sync();
-  for (uint32_t c = lane; c < NC; c += WAVE) vlist[atomicAdd(&vcur[c2v[c]], 1u)] = c;
-  ec_sync();
-  ENC_CLK(0);
-  // ---- opposites: corner c faces the edge next(c) -> prev(c) = a -> b; its opposite is the corner facing b -> a.  That face has a
-  // corner k at b whose next is a (opposite: prev(k)) and a corner k' at a whose previous is b (opposite: next(k')): the shorter of
-  // the two vertex lists is searched, so that a vertex of huge valence (the apex of a cone) costs its neighbours nothing.  The same
-  // directed edge twice is a non-manifold edge.
-  for (uint32_t c = lane; c < NC; c += WAVE) {
+}
+
+__global__ __launch_bounds__(256) void k_enc_table_lists(uint8_t *arena, EncConn *conns, uint32_t n) {
+  ENC_TABLE_PROLOGUE
+  uint32_t *vcur = (uint32_t *)(arena + E->vcur), *vlist = (uint32_t *)(arena + E->vlist);
+  for (uint32_t c = t0; c < NC; c += stride) vlist[atomicAdd(&vcur[c2v[c]], 1u)] = c;
+}
+
+// ---- opposites: corner c faces the edge next(c) -> prev(c) = a -> b; its opposite is the corner facing b -> a.  That face has a
+// corner k at b whose next is a (opposite: prev(k)) and a corner k' at a whose previous is b (opposite: next(k')): the shorter of
+// the two vertex lists is searched, so that a vertex of huge valence (the apex of a cone) costs its neighbours nothing.  The same
+// directed edge twice is a non-manifold edge.  (The lists of a vertex come out of the atomic counter in any order; nothing below
+// depends on it.)
+__global__ __launch_bounds__(256) void k_enc_table_opposites(uint8_t *arena, EncConn *conns, uint32_t n) {
+  ENC_TABLE_PROLOGUE
+  uint32_t *opp = (uint32_t *)(arena + E->opp);
+  const uint32_t *voff = (const uint32_t *)(arena + E->voff), *vlist = (const uint32_t *)(arena + E->vlist);
+  for (uint32_t c = t0; c < NC; c += stride) {
     const uint32_t a = c2v[ec_next(c)], b = c2v[ec_prev(c)];
     const uint32_t na = voff[a + 1] - voff[a], nb = voff[b + 1] - voff[b];
     uint32_t found = DSA_INVALID, same = 0;
@@ -132,32 +160,57 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
     if (same != 1) ec_fail(E, ENC_NONMANIFOLD_EDGE, c);
     opp[c] = found;
   }
-  ec_sync();
-  ENC_CLK(1);
-  if (E->status != ENC_OK) return;
+}
+
+// ---- left-most corner per vertex (first corner in index order, moved left to the boundary if there is one) and the manifold
+// check: every corner of the vertex is reached by swinging right from there; the count of interior half-edges; and what a step
+// of either walk needs of a corner in ONE 16-byte record: the vertex at it, the corners across its right and left edge, and the
+// mark of its face (0: not visited; 1: visited; s + 2: visited, and the S with symbol id s was coded at it -- what
+// MeshEdgeBreakerEncoder.cs keeps in a face -> split symbol map).  A walk reads the records of the two corners it can move to and
+// has the next step's operands AND this step's "is that face done" in the same round trip.
+__global__ __launch_bounds__(256) void k_enc_table_corners(uint8_t *arena, EncConn *conns, uint32_t n) {
+  ENC_TABLE_PROLOGUE
+  const uint32_t *opp = (const uint32_t *)(arena + E->opp), *voff = (const uint32_t *)(arena + E->voff), *vlist = (const uint32_t *)(arena + E->vlist);
+  uint32_t *vcorner = (uint32_t *)(arena + E->vcorner);
+  uint4 *hrec = (uint4 *)(arena + E->hrec);
   EcTable ct;
   ct.c2v = c2v; ct.opp = opp; ct.vcorner = vcorner;
-  // ---- left-most corner per vertex (first corner in index order, moved left to the boundary if there is one) and the
-  // manifold check: every corner of the vertex is reached by swinging right from there
   uint32_t interior = 0;
-  for (uint32_t c = lane; c < NC; c += WAVE) interior += opp[c] != DSA_INVALID ? 1u : 0u;
-  for (int d = 32; d >= 1; d >>= 1) interior += (uint32_t)__shfl_xor((int)interior, d, WAVE);
-  for (uint32_t v = lane; v < V; v += WAVE) {
+  for (uint32_t c = t0; c < NC; c += stride) {
+    interior += opp[c] != DSA_INVALID ? 1u : 0u;
+    hrec[c] = make_uint4(c2v[c], opp[ec_next(c)], opp[ec_prev(c)], 0u);
+  }
+  if (interior) atomicAdd(&E->interior_edges, interior);      // half-edges here; the walk kernel halves it
+  for (uint32_t v = t0; v < V; v += stride) {
     const uint32_t cnt = voff[v + 1] - voff[v];
-    if (cnt == 0) { ec_fail(E, ENC_ISOLATED, v); vcorner[v] = DSA_INVALID; continue; }
+    if (cnt == 0) { atomicMin(&E->fail_key, (uint32_t)ENC_ISOLATED); vcorner[v] = DSA_INVALID; continue; }
     uint32_t first = DSA_INVALID;
     for (uint32_t i = voff[v]; i < voff[v + 1]; ++i) first = vlist[i] < first ? vlist[i] : first;
     uint32_t act = ct.swing_left(first), c = first, guard = 0, lm = first;
-    while (act != DSA_INVALID && act != first) { c = act; act = ct.swing_left(act); if (++guard >= NC) { ec_fail(E, ENC_RING, v); break; } }
+    while (act != DSA_INVALID && act != first) { c = act; act = ct.swing_left(act); if (++guard >= NC) { atomicMin(&E->fail_key, (uint32_t)ENC_RING); break; } }
     if (act != first) lm = c;
     vcorner[v] = lm;
     uint32_t reach = 0, k = lm;
     do { ++reach; k = ct.swing_right(k); } while (k != DSA_INVALID && k != lm && reach <= cnt);
-    if (reach != cnt) ec_fail(E, ENC_NONMANIFOLD_VERTEX, v);
+    if (reach != cnt) atomicMin(&E->fail_key, (uint32_t)ENC_NONMANIFOLD_VERTEX);
   }
-  ec_sync();
-  if (E->status != ENC_OK) return;
+}
 
+// ---- the two walks, one wave per mesh
+__global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncConn *conns, uint32_t n) {
+  const uint32_t mesh = blockIdx.x, lane = threadIdx.x;
+  if (mesh >= n) return;
+  EncConn *E = &conns[mesh];
+  if (E->status != ENC_OK) return;
+  if (E->fail_key != 0xFFFFFFFFu) { if (lane == 0) ec_fail(E, E->fail_key, 0); return; }
+  const uint32_t F = E->F, V = E->V, NC = 3u * F;
+  const uint32_t *c2v = (const uint32_t *)(arena + E->faces);
+  uint32_t *opp = (uint32_t *)(arena + E->opp), *vcorner = (uint32_t *)(arena + E->vcorner);
+  EcTable ct;
+  ct.c2v = c2v; ct.opp = opp; ct.vcorner = vcorner;
+#ifdef DSA_ENC_CLOCKS
+  uint64_t t_last = realclk();
+#endif
   ENC_CLK(2);
   uint8_t *fvis = arena + E->fvis, *vvis = arena + E->vvis, *hole_vis = arena + E->hole_vis;
   int32_t *hole_id = (int32_t *)(arena + E->hole_id);
@@ -166,15 +219,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
   uint32_t *splits = (uint32_t *)(arena + E->splits);
   uint32_t *d2c = (uint32_t *)(arena + E->d2c);
   int32_t *v2d = (int32_t *)(arena + E->v2d);
-  // ---- what a step of either walk needs of a corner, in ONE 16-byte record: the vertex at it, the corners across its right and left
-  // edge, and the mark of its face (0: not visited; 1: visited; s + 2: visited, and the S with symbol id s was coded at it -- what
-  // MeshEdgeBreakerEncoder.cs keeps in a face -> split symbol map).  A walk reads the records of the two corners it can move to and
-  // has the next step's operands AND this step's "is that face done" in the same round trip.
-  uint4 *hrec = (uint4 *)(arena + E->hrec);
-  for (uint32_t c = lane; c < NC; c += WAVE) hrec[c] = make_uint4(c2v[c], opp[ec_next(c)], opp[ec_prev(c)], 0u);
-  for (uint32_t f = lane; f < F; f += WAVE) fvis[f] = 0;
-  for (uint32_t v = lane; v < V; v += WAVE) { hole_id[v] = -1; hole_vis[v] = 0; v2d[v] = -1; }
-  ec_sync();
+  uint4 *hrec = (uint4 *)(arena + E->hrec);             // k_enc_table_corners
 
   // The walks are sequential by nature and run on lane 0; what the whole wave does for them is LOOK: "the next corner without an
   // opposite", "the next face not visited" are found 64 candidates at a time, and lane 0 -- which checks again, in order, since
@@ -344,7 +389,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
     ENC_CLK(4);
     if (failed) ec_fail(E, steps > step_limit ? ENC_RING : ENC_SPLITS, nsplit);
     E->num_symbols = nsym; E->num_start_bits = nstart; E->num_splits = nsplit; E->num_split_symbols = nsplit_sym;
-    E->num_processed = nproc; E->num_init = ninit; E->interior_edges = interior / 2;
+    E->num_processed = nproc; E->num_init = ninit; E->interior_edges /= 2;
   }
   ec_sync();
   if (E->status != ENC_OK) return;
@@ -412,10 +457,16 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
   }
   ec_sync();
   if (E->status != ENC_OK) return;
-  // ---- entry -> vertex and the parallelogram operand entries of every entry (MeshPredictionSchemeParallelogramEncoder.cs:35-56)
+}
+
+// ---- entry -> vertex and the parallelogram operand entries of every entry (MeshPredictionSchemeParallelogramEncoder.cs:35-56)
+__global__ __launch_bounds__(256) void k_enc_operands(uint8_t *arena, EncConn *conns, uint32_t n) {
+  ENC_TABLE_PROLOGUE
+  const uint32_t *opp = (const uint32_t *)(arena + E->opp), *d2c = (const uint32_t *)(arena + E->d2c);
+  const int32_t *v2d = (const int32_t *)(arena + E->v2d);
   uint32_t *e2v = (uint32_t *)(arena + E->e2v);
   int32_t *ops = (int32_t *)(arena + E->ops);
-  for (uint32_t p = lane; p < V; p += WAVE) {
+  for (uint32_t p = t0; p < V; p += stride) {
     const uint32_t ci = d2c[p];
     e2v[p] = c2v[ci];
     int32_t on = -1, op = -1, oo = -1;
@@ -428,7 +479,6 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
     }
     ops[3 * p] = on; ops[3 * p + 1] = op; ops[3 * p + 2] = oo;
   }
-  ENC_CLK(6);
 }
 
 }  // namespace dsa
