@@ -4,6 +4,7 @@
 // HIP stream, result queries and copy-out.  No torch types, no CPU decode path:
 // every byte of geometry is produced by the kernels in dsa_kernels.h.
 #include <hip/hip_runtime.h>
+#include <mutex>
 
 #include <cstdarg>
 #include <cstdio>
@@ -35,6 +36,12 @@ struct EncLane {
   hipStream_t st = nullptr;
   hostutil::Staging stage[2];
   int next = 0;
+  hostutil::UploadTurns *upload_turn = nullptr;     // of the batch being coded: the chunks' uploads go over the link one after the other
+  uint32_t upload_chunk = 0;                         // the chunk this lane is coding: its place in the order of the uploads
+  // the walks of a chunk (k_enc_connectivity: 0.1 - 0.2 s of memory latency) on a stream of their own, so that the chunk's
+  // attribute values upload and quantise behind them on `st`
+  hipStream_t walk_st = nullptr;
+  hipEvent_t tables_done = nullptr, walk_done = nullptr;
   // device memory of the lane, grown on demand and kept: hipMalloc / hipFree wait for every stream of the device, which would
   // put the chunks of a batch back in single file
   struct Buf {
@@ -51,7 +58,12 @@ struct EncLane {
     }
     ~Buf() { if (p) (void)hipFree(p); }
   } arena, streams, conns, packed, items;
-  ~EncLane() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }
+  ~EncLane() {
+    if (walk_st) { (void)hipStreamSynchronize(walk_st); (void)hipStreamDestroy(walk_st); }
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (tables_done) (void)hipEventDestroy(tables_done);
+    if (walk_done) (void)hipEventDestroy(walk_done);
+  }
 };
 
 struct dsa_context {

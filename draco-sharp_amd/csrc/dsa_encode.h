@@ -165,6 +165,11 @@ __global__ __launch_bounds__(256) void k_enc_corr(uint8_t *arena, EncStream *str
   __shared__ uint32_t s_tag[33];
   __shared__ uint32_t s_max;
   __shared__ unsigned long long s_bl;
+  // the block counts its symbols in LDS and adds what it counted to the stream's histogram once (alphabets of up to 12 bits; a
+  // global atomic per symbol was a third of the attribute kernels' time)
+  __shared__ uint32_t s_hist[4098];
+  const bool lds_hist = S.hist_cap <= 4098u;
+  if (lds_hist) for (uint32_t i = threadIdx.x; i < S.hist_cap; i += blockDim.x) s_hist[i] = 0;
   if (threadIdx.x < 33) s_tag[threadIdx.x] = 0;
   if (threadIdx.x == 0) { s_max = 0; s_bl = 0; }
   __syncthreads();
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256) void k_enc_corr(uint8_t *arena, EncStream *str
         if (cr < min_corr) cr += max_dif; else if (cr > max_corr) cr -= max_dif;
         const uint32_t sy = enc_zigzag(cr);
         syms[(size_t)p * nc + c] = sy;
-        if (sy < S.hist_cap) atomicAdd(&hist[sy], 1u); else S.overflow = 1;
+        if (sy < S.hist_cap) atomicAdd(lds_hist ? &s_hist[sy] : &hist[sy], 1u); else S.overflow = 1;
         mc = sy > mc ? sy : mc;
       }
     } else {                        // PredictionSchemeNormalOctahedronCanonicalizedEncodingTransform.cs:47-83
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256) void k_enc_corr(uint8_t *arena, EncStream *str
       const uint32_t sy[2] = {(uint32_t)c0, (uint32_t)c1};     // positive: no zig-zag
       for (uint32_t c = 0; c < 2; ++c) {
         syms[2 * p + c] = sy[c];
-        if (sy[c] < S.hist_cap) atomicAdd(&hist[sy[c]], 1u); else S.overflow = 1;
+        if (sy[c] < S.hist_cap) atomicAdd(lds_hist ? &s_hist[sy[c]] : &hist[sy[c]], 1u); else S.overflow = 1;
         mc = sy[c] > mc ? sy[c] : mc;
       }
     }
@@ -229,6 +234,7 @@ __global__ __launch_bounds__(256) void k_enc_corr(uint8_t *arena, EncStream *str
     atomicAdd(&s_bl, (unsigned long long)b);
   }
   __syncthreads();
+  if (lds_hist) for (uint32_t i = threadIdx.x; i < S.hist_cap; i += blockDim.x) { const uint32_t c = s_hist[i]; if (c) atomicAdd(&hist[i], c); }
   if (threadIdx.x < 33 && s_tag[threadIdx.x]) atomicAdd(&S.hist_tag[threadIdx.x], s_tag[threadIdx.x]);
   if (threadIdx.x == 0) { atomicMax(&S.max_value, s_max); atomicAdd(&S.total_bl, s_bl); }
 }
@@ -381,25 +387,47 @@ void dsa_encode_default_options(dsa_encode_options *o) {
   o->position_prediction = d.pos_prediction; o->texcoord_prediction = d.uv_prediction;
 }
 
-static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out);
+static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, uint32_t batch_n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out);
 static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out);
 dsa_status dsa_encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out) {
   if (!ctx || !out || (n && !meshes)) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "null argument");
   DSA_GUARD(ctx, encode_batch(ctx, n, meshes, options, out));     // host vectors and threads inside: nothing may unwind into the caller
 }
-// A batch is coded in chunks, several of them in flight (each on a lane of its own: stream + pinned staging): the device stages of a
-// chunk are serial per mesh and take 0.15 - 0.35 s whatever its size, which leaves the machine nearly empty -- other chunks' kernels
-// fill it, their uploads and the host's stream layout run beside.  Small batches are one chunk.
+// A batch is coded in chunks, several of them in flight (each on a lane of its own: stream + pinned staging + device memory).  The
+// device stages of a chunk are bound by latency -- the walks of k_enc_connectivity take a memory round trip per step, 0.1 - 0.2 s
+// whatever the number of meshes -- so the more chunks are under way the better: the uploads of the chunks go over the link one
+// after the other (a turn each: the first chunk's kernels start after its own upload, not after everybody's), the kernels of one
+// run beside the walks of the others and beside the host's stream layout of those that are done.  The walks need the faces only:
+// those go first (phase A of every chunk in front of any phase B, hostutil::UploadTurns), the attribute values follow while the
+// walks run, on a stream of their own.  Streams of one priority share four hardware queues, on which the kernels of different
+// streams wait for each other: four lanes, their walk streams at another priority.  Small batches are one chunk.
 static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const uint32_t chunk = n <= 512 ? (n ? n : 1) : 512;
-  const uint32_t chunks = (n + chunk - 1) / chunk, lanes = std::max(1u, std::min(chunks, 6u));
+  const uint32_t max_lanes = [&]() { const char *e = getenv("DSA_ENC_LANES"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 16 ? v : 4); }();
+  const uint32_t chunk_max = [&]() { const char *e = getenv("DSA_ENC_CHUNK"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 ? v : 0); }();
+  // as many chunks as lanes, of 512 to 1024 meshes (a chunk's device memory: about 9 MB per 64k-triangle mesh)
+  const uint32_t chunk = chunk_max ? std::min(std::max(n, 1u), chunk_max) : (n <= 512 ? std::max(n, 1u) : std::min(1024u, std::max(512u, (n + max_lanes - 1) / max_lanes)));
+  const uint32_t chunks = (n + chunk - 1) / chunk, lanes = std::max(1u, std::min(chunks, max_lanes));
+  // (Tapering the last chunks -- the batch is over when its last chunk is, and what shrinks with a chunk is everything around its
+  // walks -- was measured and lost to equal chunks, 470 - 490 against 410 ms for 4096 meshes: the large chunks' stream layout
+  // then stands at the end.)
+  std::vector<uint32_t> bounds(chunks + 1, 0);
+  for (uint32_t c = 0; c <= chunks; ++c) bounds[c] = (uint32_t)std::min<uint64_t>(n, (uint64_t)c * chunk);
   while (ctx->enc_lanes.size() < lanes) {
     std::unique_ptr<EncLane> l(new EncLane());
     l->device = ctx->device;
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     HIP_TRY(ctx, hipStreamCreateWithFlags(&l->st, hipStreamNonBlocking));
+    // (a priority has its own few hardware queues: the walk streams are dealt over two, so that four walks run side by side)
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&l->walk_st, hipStreamNonBlocking, (ctx->enc_lanes.size() & 1) ? greatest : least));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&l->tables_done, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&l->walk_done, hipEventDisableTiming));
     ctx->enc_lanes.push_back(std::move(l));
   }
+  hostutil::UploadTurns upload_turn(chunks);
+  for (uint32_t l = 0; l < lanes; ++l) ctx->enc_lanes[l]->upload_turn = &upload_turn;
+  struct Unhook { dsa_context *c; ~Unhook() { for (auto &l : c->enc_lanes) l->upload_turn = nullptr; } } unhook{ctx};
   std::unique_ptr<dsa_encoded> E(new dsa_encoded());
   E->ctx = ctx;
   E->streams.resize(n); E->status.assign(n, DSA_OK); E->messages.resize(n);
@@ -414,9 +442,13 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
       for (;;) {
         const uint32_t c = next.fetch_add(1, std::memory_order_relaxed);
         if (c >= chunks || failed.load(std::memory_order_relaxed) != DSA_OK) break;
-        const uint32_t base = c * chunk, cnt = std::min(chunk, n - base);
+        const uint32_t base = bounds[c], cnt = bounds[c + 1] - base;
+        if (cnt == 0) { upload_turn.finish_a(c, false); continue; }
+        ctx->enc_lanes[l]->upload_chunk = c;
         dsa_encoded *part = nullptr;
-        const dsa_status st = encode_chunk(&sink, *ctx->enc_lanes[l], cnt, meshes + base, options, &part);
+        const auto t_chunk = std::chrono::steady_clock::now();
+        const dsa_status st = encode_chunk(&sink, *ctx->enc_lanes[l], cnt, n, meshes + base, options, &part);
+        if (getenv("DSA_ENC_TIMING")) fprintf(stderr, "[dsa_encode_batch] chunk %u (%u meshes) returned after %8.2f ms\n", c, cnt, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_chunk).count());
         if (st != DSA_OK) { errs[l] = sink.err; int ok = DSA_OK; failed.compare_exchange_strong(ok, st); break; }
         std::unique_ptr<dsa_encoded> owner(part);
         for (uint32_t i = 0; i < cnt; ++i) { E->streams[base + i].swap(part->streams[i]); E->status[base + i] = part->status[i]; E->messages[base + i].swap(part->messages[i]); }
@@ -433,10 +465,12 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
     for (const std::string &e : errs) if (!e.empty()) return set_err(ctx, (dsa_status)failed.load(), "%s", e.c_str());
     return set_err(ctx, (dsa_status)failed.load(), "encoding failed");
   }
+  if (getenv("DSA_ENC_TIMING")) fprintf(stderr, "[dsa_encode_batch] batch of %u done\n", n);
   *out = E.release();
   return DSA_OK;
 }
-static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out) {
+static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, uint32_t batch_n, const dsa_mesh_input *meshes, const dsa_encode_options *options, dsa_encoded **out) {
+  hostutil::TurnGuard turn(lane.upload_turn, lane.upload_chunk);      // (whatever happens below, the other chunks' uploads do not wait for this one's)
   HIP_TRY(ctx, hipSetDevice(lane.device));
   dsa_encode_options od;
   dsa_encode_default_options(&od);
@@ -463,14 +497,17 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
   auto lap = [&](const char *what) {
     if (!timing) return;
     const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "[dsa_encode_batch] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    static const auto t_zero = now;
+    fprintf(stderr, "[dsa_encode_batch] lane %p at %9.2f ms: %-28s %8.2f ms\n", (void *)&lane, std::chrono::duration<double, std::milli>(now - t_zero).count(), what, std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now;
   };
   // Both device stages are the serial algorithms on one lane per mesh / per stream: a batch takes 150 - 250 ms (connectivity) and
   // about 40 ms (plans) whatever its size, which the host threads beat on a small batch (measured: 64 meshes 84 ms on the host, 128 meshes 252 ms on the device).  Below 256 meshes the host does both
   // (DSA_ENC_HOST_CONN / DSA_ENC_HOST_PLAN = 1 or 0 force one or the other; read per call: the tests compare the paths).
-  auto choice = [&](const char *name) { const char *e = getenv(name); return e ? atoi(e) != 0 : n < 256; };
+  auto choice = [&](const char *name) { const char *e = getenv(name); return e ? atoi(e) != 0 : batch_n < 256; };
   const bool host_conn = choice("DSA_ENC_HOST_CONN");
+  // meshes to a wave of the walks (k_enc_connectivity: one lane per mesh); DSA_ENC_WALK_LANES = 1 .. 64 for measurements
+  const uint32_t walk_lanes = [&]() { const char *e = getenv("DSA_ENC_WALK_LANES"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 64 ? v : 16); }();
   const bool host_plan = choice("DSA_ENC_HOST_PLAN");
   auto plan_one = [&](uint32_t i) {
     const dsa_mesh_input &m = meshes[i];
@@ -479,6 +516,7 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
     try {
       synth::check(m.positions && m.faces && m.num_vertices >= 3 && m.num_faces >= 1, "mesh needs positions and faces");
       for (size_t k = 0; k < (size_t)m.num_faces * 3; ++k) synth::check(m.faces[k] < m.num_vertices, "face index out of range");
+      synth::check(host_conn || (uint64_t)m.num_faces * 3 <= (uint64_t)dsa::EC_CORNER_MASK, "mesh too large for the device connectivity coder");
       if (!host_conn) { synth::plan_attributes(in, opt, plans[i]); return; }      // the rest of the plan comes from the device
       synth::plan_mesh(in, opt, plans[i]);
       const synth::MeshPlan &pl = plans[i];
@@ -518,7 +556,14 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
   auto take = [&](uint64_t bytes) { uint64_t at = cur; cur = (cur + bytes + 255) & ~255ull; return at; };
   auto take_in = [&](uint64_t bytes) { uint64_t at = cur_in; cur_in = (cur_in + bytes + 255) & ~255ull; return at; };
   struct Upload { uint64_t off; const void *src; size_t bytes; };
-  std::vector<Upload> uploads;
+  std::vector<Upload> uploads_a, uploads;          // phase A: what the walks need (the faces); the rest
+  std::vector<uint64_t> faces_at(n, 0);
+  if (!host_conn)
+    for (uint32_t i = 0; i < n; ++i) {
+      if (E->status[i] != DSA_OK) continue;
+      faces_at[i] = take_in(12ull * meshes[i].num_faces);
+      uploads_a.push_back({faces_at[i], meshes[i].faces, 12ull * meshes[i].num_faces});
+    }
   for (uint32_t i = 0; i < n; ++i) {
     first_stream[i] = (uint32_t)hs.size();
     if (E->status[i] != DSA_OK) continue;
@@ -532,9 +577,9 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
       dsa::EncConn &C = hc[i];
       memset(&C, 0, sizeof(C));
       C.F = F; C.V = V; C.split_cap = F; C.fail_key = 0xFFFFFFFFu;
-      C.faces = take_in(12ull * F); uploads.push_back({C.faces, meshes[i].faces, 12ull * F});
+      C.faces = faces_at[i];
       C.opp = take(12ull * F); C.voff = take(4ull * (V + 1)); C.vcur = take(4ull * V); C.vlist = take(12ull * F); C.vcorner = take(4ull * V);
-      C.fvis = take(F); C.vvis = take(V); C.hole_id = take(4ull * V); C.hole_vis = take(V); C.hrec = take(48ull * F);
+      C.vvis = take(V); C.frec = take(32ull * F);
       C.stack = take(4ull * F); C.processed = take(4ull * F); C.init_corners = take(4ull * F);
       C.symbols = take(F); C.start_bits = take(F); C.splits = take(12ull * C.split_cap);
       C.d2c = take(4ull * V); C.v2d = take(4ull * V);
@@ -568,10 +613,11 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
   auto cleanup = [&]() {};      // the lane owns its device memory (EncLane::Buf): nothing to release per chunk
 #define ENC_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { return set_err(ctx, e_ == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
   // pieces of the arena -> one host buffer (items[k].packed_off filled in); host buffer -> pieces of the arena
-  auto gather = [&](std::vector<dsa::PackItem> &items, std::vector<uint8_t> &host) -> dsa_status {
+  // (with `view`: no copy into `host`; *view points at the pieces in the lane's pinned staging buffer, valid until the gather after next)
+  auto gather = [&](std::vector<dsa::PackItem> &items, std::vector<uint8_t> &host, const uint8_t **view) -> dsa_status {
     uint64_t total = 0;
     for (auto &it : items) { it.packed_off = total; total += ((uint64_t)it.len + 15) & ~15ull; }
-    host.resize(total);
+    if (view) *view = nullptr; else host.resize(total);
     if (items.empty() || total == 0) return DSA_OK;
     uint8_t *d_packed = nullptr; dsa::PackItem *d_items = nullptr;
     hipError_t e = lane.packed.ensure(total);
@@ -585,7 +631,7 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
     if (e == hipSuccess) e = stg.acquire((size_t)total);
     if (e == hipSuccess) e = hipMemcpyAsync(stg.buf.p, d_packed, total, hipMemcpyDeviceToHost, lane.st);
     if (e == hipSuccess) e = hipStreamSynchronize(lane.st);
-    if (e == hipSuccess) hostutil::parallel_memcpy(host.data(), stg.buf.p, (size_t)total);
+    if (e == hipSuccess) { if (view) *view = stg.buf.p; else hostutil::parallel_memcpy(host.data(), stg.buf.p, (size_t)total); }
     return e == hipSuccess ? DSA_OK : (e == hipErrorOutOfMemory ? DSA_ERR_OUT_OF_MEMORY : DSA_ERR_DEVICE);
   };
   auto scatter = [&](std::vector<dsa::PackItem> &items, const std::vector<uint8_t> &host) -> dsa_status {
@@ -606,27 +652,34 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
     ENC_TRY(lane.arena.ensure(cur ? cur : 256));
     ENC_TRY(lane.streams.ensure(sizeof(dsa::EncStream) * ns));
     arena = (uint8_t *)lane.arena.p; d_streams = (dsa::EncStream *)lane.streams.p;
+    if (lane.walk_st) ENC_TRY(hipStreamSynchronize(lane.walk_st));     // (idle unless a previous chunk on this lane ended in an error)
     ENC_TRY(hipMemsetAsync(arena, 0, cur, st));              // histograms start at zero
-    // uploads in chunks through the context's two pinned staging buffers: host threads fill one while the DMA engine drains the
+    // uploads in pieces through the lane's two pinned staging buffers: host threads fill one while the DMA engine drains the
     // other (a pageable source would be staged by the runtime, one thread, a few GB/s)
-    {
-      const uint64_t chunk_cap = 192ull << 20;
+    auto upload = [&](const std::vector<Upload> &ups) -> hipError_t {
+      const uint64_t piece_cap = 192ull << 20;
       size_t i0 = 0;
-      while (i0 < uploads.size()) {
-        const uint64_t lo = uploads[i0].off;
+      while (i0 < ups.size()) {
+        const uint64_t lo = ups[i0].off;
         size_t i1 = i0 + 1;
-        while (i1 < uploads.size() && uploads[i1].off + uploads[i1].bytes - lo <= chunk_cap) ++i1;
-        const uint64_t hi = uploads[i1 - 1].off + uploads[i1 - 1].bytes;
+        while (i1 < ups.size() && ups[i1].off + ups[i1].bytes - lo <= piece_cap) ++i1;
+        const uint64_t hi = ups[i1 - 1].off + ups[i1 - 1].bytes;
         hostutil::Staging &stg = lane.stage[lane.next];
         lane.next ^= 1;
-        ENC_TRY(stg.acquire((size_t)(hi - lo)));
+        hipError_t e = stg.acquire((size_t)(hi - lo));
+        if (e != hipSuccess) return e;
         uint8_t *h = stg.buf.p;
-        hostutil::parallel_for((uint32_t)(i1 - i0), [&](uint32_t k) { const Upload &u = uploads[i0 + k]; memcpy(h + (u.off - lo), u.src, u.bytes); }, 2);
-        ENC_TRY(hipMemcpyAsync(arena + lo, h, (size_t)(hi - lo), hipMemcpyHostToDevice, st));
-        ENC_TRY(stg.submitted(st));
+        hostutil::parallel_for((uint32_t)(i1 - i0), [&](uint32_t k) { const Upload &u = ups[i0 + k]; memcpy(h + (u.off - lo), u.src, u.bytes); }, 2);
+        e = hipMemcpyAsync(arena + lo, h, (size_t)(hi - lo), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = stg.submitted(st);
+        if (e != hipSuccess) return e;
         i0 = i1;
       }
-    }
+      return hipSuccess;
+    };
+    turn.acquire_a();
+    ENC_TRY(upload(host_conn ? uploads : uploads_a));
+    if (host_conn) turn.release();
     ENC_TRY(hipMemcpyAsync(d_streams, hs.data(), sizeof(dsa::EncStream) * ns, hipMemcpyHostToDevice, st));
     uint32_t maxv = 0;
     for (auto &S : hs) maxv = std::max(maxv, S.nv);
@@ -648,12 +701,24 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
       hipLaunchKernelGGL(dsa::k_enc_table_lists, gt, dim3(256), 0, st, arena, d_conns, n);
       hipLaunchKernelGGL(dsa::k_enc_table_opposites, gt, dim3(256), 0, st, arena, d_conns, n);
       hipLaunchKernelGGL(dsa::k_enc_table_corners, gt, dim3(256), 0, st, arena, d_conns, n);
-      hipLaunchKernelGGL(dsa::k_enc_connectivity, dim3(n), dim3(WAVE), 0, st, arena, d_conns, n);
+      // the walks on their stream; the attribute values travel and are quantised meanwhile
+      ENC_TRY(hipEventRecord(lane.tables_done, st));
+      ENC_TRY(hipStreamWaitEvent(lane.walk_st, lane.tables_done, 0));
+      hipLaunchKernelGGL(dsa::k_enc_connectivity, dim3((n + walk_lanes - 1) / walk_lanes), dim3(WAVE), 0, lane.walk_st, arena, d_conns, n, walk_lanes);
+      ENC_TRY(hipEventRecord(lane.walk_done, lane.walk_st));
+      turn.release();
+      turn.acquire_b();
+      ENC_TRY(upload(uploads));
+      turn.release();
+      hipLaunchKernelGGL(dsa::k_enc_bounds, dim3(ns), dim3(256), 0, st, arena, d_streams, ns);
+      hipLaunchKernelGGL(dsa::k_enc_quantize, dim3(gx, ns), dim3(256), 0, st, arena, d_streams, ns);
+      ENC_TRY(hipStreamWaitEvent(st, lane.walk_done, 0));
       hipLaunchKernelGGL(dsa::k_enc_operands, gt, dim3(256), 0, st, arena, d_conns, n);
+    } else {
+      hipLaunchKernelGGL(dsa::k_enc_bounds, dim3(ns), dim3(256), 0, st, arena, d_streams, ns);
+      hipLaunchKernelGGL(dsa::k_enc_quantize, dim3(gx, ns), dim3(256), 0, st, arena, d_streams, ns);
     }
     // ---- device phase 1: quantise, order, correct, count
-    hipLaunchKernelGGL(dsa::k_enc_bounds, dim3(ns), dim3(256), 0, st, arena, d_streams, ns);
-    hipLaunchKernelGGL(dsa::k_enc_quantize, dim3(gx, ns), dim3(256), 0, st, arena, d_streams, ns);
     hipLaunchKernelGGL(dsa::k_enc_gather, dim3(ns), dim3(256), 0, st, arena, d_streams, ns);
     hipLaunchKernelGGL(dsa::k_enc_corr, dim3(gx, ns), dim3(256), 0, st, arena, d_streams, ns);
     if (!host_plan) {       // device phase 2 follows at once: tables by k_enc_plan, no host round trip
@@ -664,15 +729,6 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
     if (!host_conn) ENC_TRY(hipMemcpyAsync(hc.data(), d_conns, sizeof(dsa::EncConn) * n, hipMemcpyDeviceToHost, st));
     ENC_TRY(hipStreamSynchronize(st));
     lap("device phases 0 + 1");
-#ifdef DSA_ENC_CLOCKS
-    if (timing && !host_conn) {
-      unsigned long long clk[16] = {0}, zero[16] = {0};
-      (void)hipMemcpyFromSymbol(clk, HIP_SYMBOL(dsa::g_enc_clocks), sizeof(clk));
-      (void)hipMemcpyToSymbol(HIP_SYMBOL(dsa::g_enc_clocks), zero, sizeof(zero));
-      static const char *names[6] = {"", "", "", "hole ids", "edgebreaker walk", "dfs walk"};
-      for (int i = 3; i < 6; ++i) fprintf(stderr, "[k_enc_connectivity] %-20s %8.2f ms per mesh\n", names[i], clk[i] / 100e3 / n);
-    }
-#endif
     if (!host_conn) {
       // what the stream layout needs of the connectivity: symbols, start-face bits, split events, two counts
       std::vector<dsa::PackItem> conn_items;
@@ -684,23 +740,26 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
           for (uint32_t sk = first_stream[i]; sk < first_stream[i + 1]; ++sk) hs[sk].overflow = 1;       // its attribute streams are not coded
           continue;
         }
-        synth::EbResult &eb = plans[i].eb;
-        eb.symbols.resize(C.num_symbols); eb.start_face_bits.resize(C.num_start_bits); eb.num_split_symbols = C.num_split_symbols;
-        eb.splits.resize(C.num_splits);
         conn_items.push_back({C.symbols, 0, C.num_symbols, i});
         conn_items.push_back({C.start_bits, 0, C.num_start_bits, i});
         conn_items.push_back({C.splits, 0, 12u * C.num_splits, i});
         plans[i].interior_edges = (int64_t)C.interior_edges;
       }
-      std::vector<uint8_t> conn_host;
-      ENC_ST(gather(conn_items, conn_host));
-      for (size_t k = 0; k + 2 < conn_items.size(); k += 3) {
-        synth::EbResult &eb = plans[conn_items[k].pad].eb;
-        if (conn_items[k].len) memcpy(eb.symbols.data(), conn_host.data() + conn_items[k].packed_off, conn_items[k].len);
-        if (conn_items[k + 1].len) memcpy(eb.start_face_bits.data(), conn_host.data() + conn_items[k + 1].packed_off, conn_items[k + 1].len);
-        const uint32_t *sp = (const uint32_t *)(conn_host.data() + conn_items[k + 2].packed_off);
+      std::vector<uint8_t> unused;
+      const uint8_t *conn_host = nullptr;
+      ENC_ST(gather(conn_items, unused, &conn_host));
+      hostutil::parallel_for((uint32_t)(conn_items.size() / 3), [&](uint32_t m) {
+        const size_t k = 3 * (size_t)m;
+        const uint32_t i = conn_items[k].pad;
+        const dsa::EncConn &C = hc[i];
+        synth::EbResult &eb = plans[i].eb;
+        eb.num_split_symbols = C.num_split_symbols;
+        if (conn_items[k].len) eb.symbols.assign(conn_host + conn_items[k].packed_off, conn_host + conn_items[k].packed_off + conn_items[k].len);
+        if (conn_items[k + 1].len) eb.start_face_bits.assign(conn_host + conn_items[k + 1].packed_off, conn_host + conn_items[k + 1].packed_off + conn_items[k + 1].len);
+        eb.splits.resize(C.num_splits);
+        const uint32_t *sp = C.num_splits ? (const uint32_t *)(conn_host + conn_items[k + 2].packed_off) : nullptr;
         for (size_t q = 0; q < eb.splits.size(); ++q) eb.splits[q] = {sp[3 * q], sp[3 * q + 1], sp[3 * q + 2]};
-      }
+      }, 8);
     }
   }
   lap("connectivity results");
@@ -717,7 +776,7 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
       items.push_back({hs[s].hist_raw, 0, 4u * (hs[s].max_value + 1u), s});
     }
     std::vector<uint8_t> host;
-    ENC_ST(gather(items, host));
+    ENC_ST(gather(items, host, nullptr));
     for (auto &it : items) {
       hists[it.pad].resize(it.len / 4);
       memcpy(hists[it.pad].data(), host.data() + it.packed_off, it.len);
@@ -785,22 +844,25 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, cons
       items.push_back({hs[s].out_bits, 0, hs[s].bits_len, s});
       items.push_back({hs[s].prob, 0, host_plan ? 0u : 4u * hs[s].num_symbols, s});
     }
-    std::vector<uint8_t> host;
-    ENC_ST(gather(items, host));
-    for (size_t k = 0; k + 2 < items.size(); k += 3) {
+    std::vector<uint8_t> unused;
+    const uint8_t *host = nullptr;
+    ENC_ST(gather(items, unused, &host));
+    hostutil::parallel_for((uint32_t)(items.size() / 3), [&](uint32_t m) {
+      const size_t k = 3 * (size_t)m;
       const uint32_t s = items[k].pad;
-      rans[s].assign(host.begin() + (ptrdiff_t)items[k].packed_off, host.begin() + (ptrdiff_t)(items[k].packed_off + items[k].len));
-      bits[s].assign(host.begin() + (ptrdiff_t)items[k + 1].packed_off, host.begin() + (ptrdiff_t)(items[k + 1].packed_off + items[k + 1].len));
+      if (items[k].len) rans[s].assign(host + items[k].packed_off, host + items[k].packed_off + items[k].len);
+      if (items[k + 1].len) bits[s].assign(host + items[k + 1].packed_off, host + items[k + 1].packed_off + items[k + 1].len);
       if (!host_plan) {                      // the bytes in front of the payload: scheme, (raw: unique-symbols bit length), table
         synth::SymbolPlan &pl = splans[s];
         pl.method = (int)hs[s].method;
         pl.coder.num_symbols = hs[s].num_symbols;
-        pl.coder.prob.assign((const uint32_t *)(host.data() + items[k + 2].packed_off), (const uint32_t *)(host.data() + items[k + 2].packed_off) + hs[s].num_symbols);
+        const uint32_t *pr = (const uint32_t *)(host + items[k + 2].packed_off);
+        pl.coder.prob.assign(pr, pr + hs[s].num_symbols);
         pl.head.u8((uint8_t)pl.method);
         if (pl.method != 0) pl.head.u8((uint8_t)hs[s].usbl);
         pl.coder.write_table(pl.head);
       }
-    }
+    }, 8);
   }
 #undef ENC_TRY
 #undef ENC_ST

@@ -6,9 +6,11 @@
 //   Edgebreaker traversal   MeshEdgeBreakerEncoder.cs:38-124 (start faces), :158-183 (init face), :185-274 (symbols),
 //                           :276-303 (holes), :331-361 (hole ids), :373-390 (topology splits)
 //   attribute order         Traverser/DepthFirstTraverser.cs:9-99, MeshTraversalSequencer.cs:13-31
-// It is the host coder of dsa_encode_host.h (CornerTable::build, EbEncoder, dfs_sequence) statement by statement on
-// arrays in device memory: the table construction and the operand entries on the whole wave, the two traversals --
-// sequential by nature, every step decides the next from what is visited -- on lane 0, meshes of a batch in parallel.
+// It is the host coder of dsa_encode_host.h (CornerTable::build, EbEncoder, dfs_sequence) on arrays in device memory.  The table
+// construction and the operand entries are grid-parallel kernels (blocks per mesh x meshes).  The two traversals are sequential
+// by nature -- every step decides the next from what is visited -- and bound by the latency of one memory round trip per step:
+// they run ONE LANE PER MESH, several meshes to a wave (k_enc_connectivity), so that a memory instruction carries the step of
+// every mesh of the wave and thousands of walks are in flight on a handful of waves per CU.
 // The byte stream that results is the CPU coder's (tests/test_gpu_encode.py compares them).
 #pragma once
 
@@ -19,12 +21,11 @@ struct EncConn {                   // one per mesh; device memory, mirrored on t
   uint64_t opp;                    // u32[3F] opposite corner or INVALID
   uint64_t voff, vcur, vlist;      // u32[V+1], u32[V], u32[3F]: corners by vertex
   uint64_t vcorner;                // u32[V] left-most corner
-  uint64_t fvis, vvis;             // u8[F], u8[V]
-  uint64_t hole_id, hole_vis;      // i32[V], u8[V]
-  uint64_t hrec;                   // uint4[3F] per corner: vertex, corners across the right / left edge, mark of the face
+  uint64_t vvis;                   // u8[V] marks of a vertex: 1 visited by the Edgebreaker walk, 2 on a boundary, 4 visited by the attribute walk, 8 its hole is coded
+  uint64_t frec;                   // EcFace[F]: what a step of either walk needs of a face, in one 32-byte record
   uint64_t stack;                  // u32[F]
-  uint64_t processed, init_corners;// u32[F] each
-  uint64_t symbols;                // u8[F] OUTPUT encoder order, bit patterns 0 1 3 5 7
+  uint64_t processed, init_corners;// u32[F] each; processed: corner | symbol << 29
+  uint64_t symbols;                // u8[F] OUTPUT encoder order, bit patterns 0 1 3 5 7 (k_enc_operands takes them out of `processed`)
   uint64_t start_bits;             // u8[F] OUTPUT
   uint64_t splits;                 // u32[3 * split_cap] OUTPUT (source, split, edge)
   uint64_t d2c, v2d;               // u32[V], i32[V]
@@ -34,6 +35,12 @@ struct EncConn {                   // one per mesh; device memory, mirrored on t
   uint32_t num_symbols, num_start_bits, num_splits, num_split_symbols, num_processed, num_init, num_entries, interior_edges;   // OUTPUT
   uint32_t status, detail;         // 0 ok; else the host coder's complaint (see enc_conn_message)
 };
+// A face as the walks see it: the vertices at its corners, the corners across its edges (o[k] = opposite of corner 3f + k), and two
+// marks -- mark: 0 not visited by the Edgebreaker walk; 1 visited; s + 2 visited, and the S with symbol id s was coded at it (what
+// MeshEdgeBreakerEncoder.cs keeps in a face -> split symbol map); mark2: visited by the attribute walk.  From a corner of the face,
+// the vertex at it and the corners across its right and left edge are fields of this record; the faces across are one load each.
+struct EcFace { uint32_t v0, v1, v2, o0, o1, o2, mark, mark2; };
+static_assert(sizeof(EcFace) == 32, "face record");
 
 enum { ENC_OK = 0, ENC_DEGENERATE = 1, ENC_NONMANIFOLD_EDGE = 2, ENC_RING = 3, ENC_NONMANIFOLD_VERTEX = 4, ENC_ISOLATED = 5, ENC_UNREACHED = 6, ENC_SPLITS = 7 };
 static inline const char *enc_conn_message(uint32_t status) {
@@ -65,12 +72,6 @@ struct EcTable {                   // the corner table as the traversals see it
 __device__ __forceinline__ void ec_fail(EncConn *E, uint32_t status, uint32_t detail) { if (atomicCAS(&E->status, 0u, status) == 0u) E->detail = detail; }
 __device__ __forceinline__ void ec_sync() { __threadfence_block(); __syncthreads(); }
 
-#ifdef DSA_ENC_CLOCKS
-__device__ unsigned long long g_enc_clocks[16];
-#define ENC_CLK(i) do { if (lane == 0) { const uint64_t t_ = realclk(); atomicAdd(&g_enc_clocks[i], (unsigned long long)(t_ - t_last)); t_last = t_; } } while (0)
-#else
-#define ENC_CLK(i)
-#endif
 
 // The corner table is built by kernels of their own, every mesh of the chunk on as many blocks as its corners ask for (grid: blocks
 // per mesh x meshes): nothing in it is sequential, and on one wave per mesh -- where the walks below have to live -- it took a
@@ -89,11 +90,10 @@ __device__ unsigned long long g_enc_clocks[16];
 __global__ __launch_bounds__(256) void k_enc_table_clear(uint8_t *arena, EncConn *conns, uint32_t n) {
   ENC_TABLE_PROLOGUE
   uint32_t *voff = (uint32_t *)(arena + E->voff);
-  uint8_t *fvis = arena + E->fvis, *hole_vis = arena + E->hole_vis;
-  int32_t *hole_id = (int32_t *)(arena + E->hole_id), *v2d = (int32_t *)(arena + E->v2d);
+  uint8_t *vvis = arena + E->vvis;
+  int32_t *v2d = (int32_t *)(arena + E->v2d);
   for (uint32_t v = t0; v <= V; v += stride) voff[v] = 0;
-  for (uint32_t f = t0; f < F; f += stride) fvis[f] = 0;
-  for (uint32_t v = t0; v < V; v += stride) { hole_id[v] = -1; hole_vis[v] = 0; v2d[v] = -1; }
+  for (uint32_t v = t0; v < V; v += stride) { vvis[v] = 0; v2d[v] = -1; }
 }
 
 // ---- corners by vertex (counting sort: counts -> offsets -> lists), CornerTable.cs:41-67 needs them implicitly
@@ -163,22 +163,29 @@ __global__ __launch_bounds__(256) void k_enc_table_opposites(uint8_t *arena, Enc
 }
 
 // ---- left-most corner per vertex (first corner in index order, moved left to the boundary if there is one) and the manifold
-// check: every corner of the vertex is reached by swinging right from there; the count of interior half-edges; and what a step
-// of either walk needs of a corner in ONE 16-byte record: the vertex at it, the corners across its right and left edge, and the
-// mark of its face (0: not visited; 1: visited; s + 2: visited, and the S with symbol id s was coded at it -- what
-// MeshEdgeBreakerEncoder.cs keeps in a face -> split symbol map).  A walk reads the records of the two corners it can move to and
-// has the next step's operands AND this step's "is that face done" in the same round trip.
+// check: every corner of the vertex is reached by swinging right from there; the count of interior half-edges; the face records
+// of the walks; and the boundary mark of a vertex: the end of an edge without an opposite.  (MeshEdgeBreakerEncoder.cs:331-361
+// numbers the boundary loops and keeps "loop coded" per number; the walks below only ever ask "is this vertex on a boundary" and
+// "is the loop through this vertex coded", which a mark on every vertex of a loop answers -- a vertex that passed the manifold
+// check lies on one loop at most.)
 __global__ __launch_bounds__(256) void k_enc_table_corners(uint8_t *arena, EncConn *conns, uint32_t n) {
   ENC_TABLE_PROLOGUE
   const uint32_t *opp = (const uint32_t *)(arena + E->opp), *voff = (const uint32_t *)(arena + E->voff), *vlist = (const uint32_t *)(arena + E->vlist);
   uint32_t *vcorner = (uint32_t *)(arena + E->vcorner);
-  uint4 *hrec = (uint4 *)(arena + E->hrec);
+  uint8_t *vvis = arena + E->vvis;
+  uint4 *frec = (uint4 *)(arena + E->frec);
   EcTable ct;
   ct.c2v = c2v; ct.opp = opp; ct.vcorner = vcorner;
   uint32_t interior = 0;
-  for (uint32_t c = t0; c < NC; c += stride) {
-    interior += opp[c] != DSA_INVALID ? 1u : 0u;
-    hrec[c] = make_uint4(c2v[c], opp[ec_next(c)], opp[ec_prev(c)], 0u);
+  for (uint32_t f = t0; f < F; f += stride) {
+    const uint32_t c = 3u * f;
+    const uint32_t o0 = opp[c], o1 = opp[c + 1], o2 = opp[c + 2], v0 = c2v[c], v1 = c2v[c + 1], v2 = c2v[c + 2];
+    interior += (o0 != DSA_INVALID ? 1u : 0u) + (o1 != DSA_INVALID ? 1u : 0u) + (o2 != DSA_INVALID ? 1u : 0u);
+    frec[2 * f] = make_uint4(v0, v1, v2, o0);
+    frec[2 * f + 1] = make_uint4(o1, o2, 0u, 0u);
+    if (o0 == DSA_INVALID) { vvis[v1] = 2; vvis[v2] = 2; }      // (every writer stores the same byte)
+    if (o1 == DSA_INVALID) { vvis[v2] = 2; vvis[v0] = 2; }
+    if (o2 == DSA_INVALID) { vvis[v0] = 2; vvis[v1] = 2; }
   }
   if (interior) atomicAdd(&E->interior_edges, interior);      // half-edges here; the walk kernel halves it
   for (uint32_t v = t0; v < V; v += stride) {
@@ -196,92 +203,78 @@ __global__ __launch_bounds__(256) void k_enc_table_corners(uint8_t *arena, EncCo
   }
 }
 
-// ---- the two walks, one wave per mesh
-__global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncConn *conns, uint32_t n) {
-  const uint32_t mesh = blockIdx.x, lane = threadIdx.x;
+// ---- the two walks, one lane per mesh
+__device__ __forceinline__ EcFace ec_face(const uint4 *frec, uint32_t f) {
+  const uint4 a = frec[2 * f], b = frec[2 * f + 1];
+  EcFace r;
+  r.v0 = a.x; r.v1 = a.y; r.v2 = a.z; r.o0 = a.w; r.o1 = b.x; r.o2 = b.y; r.mark = b.z; r.mark2 = b.w;
+  return r;
+}
+struct EcHop { uint32_t v, rc, lc; };                  // from corner 3f + k: the vertex at it, the corners across its right and left edge
+__device__ __forceinline__ EcHop ec_hop(const EcFace &r, uint32_t k) {
+  EcHop h;
+  h.v = k == 0 ? r.v0 : (k == 1 ? r.v1 : r.v2);
+  h.rc = k == 0 ? r.o1 : (k == 1 ? r.o2 : r.o0);       // opposite of the next corner
+  h.lc = k == 0 ? r.o2 : (k == 1 ? r.o0 : r.o1);       // opposite of the previous corner
+  return h;
+}
+enum { EC_MARK = 6, EC_MARK2 = 7, EC_CORNER_MASK = 0x1FFFFFFF, EC_SYMBOL_SHIFT = 29 };    // words of a face record; fields of a `processed` entry
+
+// Lane l of block b walks mesh b * lanes_per_wave + l.  A step of either walk is one memory round trip -- the marks of the vertex
+// at the corner and the records of the two faces across, which all hang off what the previous step loaded, are issued together --
+// and two stores (the mark of the face; the corner and its symbol).  Lanes whose meshes differ in shape diverge and rejoin by
+// the compiler's rules; meshes of one shape (a batch of scans of one kind) step in lockstep.
+// Every walk below ends by itself on a mesh that passed the checks above (the host coder, which has no such counter, was fuzzed
+// with 20 000 damaged meshes); the counter only makes sure that a kernel can never spin: a GPU does not take Ctrl-C.
+__global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncConn *conns, uint32_t n, uint32_t lanes_per_wave) {
+  if (threadIdx.x >= lanes_per_wave) return;
+  const uint32_t mesh = blockIdx.x * lanes_per_wave + threadIdx.x;
   if (mesh >= n) return;
   EncConn *E = &conns[mesh];
   if (E->status != ENC_OK) return;
-  if (E->fail_key != 0xFFFFFFFFu) { if (lane == 0) ec_fail(E, E->fail_key, 0); return; }
+  if (E->fail_key != 0xFFFFFFFFu) { ec_fail(E, E->fail_key, 0); return; }
   const uint32_t F = E->F, V = E->V, NC = 3u * F;
   const uint32_t *c2v = (const uint32_t *)(arena + E->faces);
-  uint32_t *opp = (uint32_t *)(arena + E->opp), *vcorner = (uint32_t *)(arena + E->vcorner);
+  const uint32_t *opp = (const uint32_t *)(arena + E->opp);
   EcTable ct;
-  ct.c2v = c2v; ct.opp = opp; ct.vcorner = vcorner;
-#ifdef DSA_ENC_CLOCKS
-  uint64_t t_last = realclk();
-#endif
-  ENC_CLK(2);
-  uint8_t *fvis = arena + E->fvis, *vvis = arena + E->vvis, *hole_vis = arena + E->hole_vis;
-  int32_t *hole_id = (int32_t *)(arena + E->hole_id);
+  ct.c2v = c2v; ct.opp = opp; ct.vcorner = (const uint32_t *)(arena + E->vcorner);
+  uint8_t *vvis = arena + E->vvis;
   uint32_t *stack = (uint32_t *)(arena + E->stack), *processed = (uint32_t *)(arena + E->processed), *init_corners = (uint32_t *)(arena + E->init_corners);
-  uint8_t *symbols = arena + E->symbols, *start_bits = arena + E->start_bits;
+  uint8_t *start_bits = arena + E->start_bits;
   uint32_t *splits = (uint32_t *)(arena + E->splits);
   uint32_t *d2c = (uint32_t *)(arena + E->d2c);
   int32_t *v2d = (int32_t *)(arena + E->v2d);
-  uint4 *hrec = (uint4 *)(arena + E->hrec);             // k_enc_table_corners
+  const uint4 *frec = (const uint4 *)(arena + E->frec);
+  uint32_t *fw = (uint32_t *)(arena + E->frec);                                   // the records as words: marks at 8 f + EC_MARK, 8 f + EC_MARK2
 
-  // The walks are sequential by nature and run on lane 0; what the whole wave does for them is LOOK: "the next corner without an
-  // opposite", "the next face not visited" are found 64 candidates at a time, and lane 0 -- which checks again, in order, since
-  // its own work may have settled a candidate meanwhile -- only ever sees the hits.
-  // Every walk below ends by itself on a mesh that passed the checks above (the host coder, which has no such counter, was fuzzed
-  // with 20 000 damaged meshes); the counter only makes sure that a kernel can never spin: a GPU does not take Ctrl-C.
   uint32_t steps = 0;
   bool failed = false;
   const uint32_t step_limit = 64u * NC + 4096u;
   auto runaway = [&]() { if (++steps > step_limit) failed = true; return failed; };
-  // ---- hole ids, MeshEdgeBreakerEncoder.cs:331-361
-  {
-    uint32_t num_holes = 0;
-    for (uint32_t base = 0; base < NC; base += WAVE) {
-      const uint32_t i = base + lane;
-      uint64_t open = __builtin_amdgcn_ballot_w64(i < NC && opp[i] == DSA_INVALID);
-      while (open) {
-        const uint32_t at = base + (uint32_t)__builtin_ctzll(open);
-        open &= open - 1;
-        if (lane != 0) continue;
-        uint32_t bv = c2v[ec_next(at)];
-        if (hole_id[bv] != -1) continue;
-        const int32_t id = (int32_t)num_holes++;
-        uint32_t c = at;
-        while (hole_id[bv] == -1 && !runaway()) {
-          hole_id[bv] = id;
-          c = ec_next(c);
-          while (opp[c] != DSA_INVALID && !runaway()) c = ec_next(opp[c]);
-          bv = c2v[ec_next(c)];
-        }
-      }
+  // the first face at or behind `from` whose mark (word w of its record) is still zero, or F: eight records a round trip
+  auto next_fresh = [&](uint32_t from, uint32_t w) {
+    while (from < F) {
+      uint32_t m[8];
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) { const uint32_t f = from + j < F ? from + j : F - 1; m[j] = fw[8 * f + w]; }
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) if (from + j < F && m[j] == 0) return from + j;
+      from += 8;
     }
-  }
-  ec_sync();
-  // a vertex's marks in one byte: 1 visited, 2 on a boundary (it has a hole id)
-  for (uint32_t v = lane; v < V; v += WAVE) vvis[v] = hole_id[v] != -1 ? 2 : 0;
-  ec_sync();
-  ENC_CLK(3);
+    return F;
+  };
 
-  struct Hop { uint32_t v, rc, lc, mark; };                                     // the record of a corner
-  auto hop = [&](uint32_t c) {
-    const uint4 r = hrec[c == DSA_INVALID ? 0u : c];
-    Hop h;
-    h.v = r.x; h.rc = r.y; h.lc = r.z; h.mark = r.w;
-    return h;
-  };
-  auto mark_face = [&](uint32_t first_corner, uint32_t mark) {                  // first_corner = 3 * face
-    hrec[first_corner].w = mark; hrec[first_corner + 1].w = mark; hrec[first_corner + 2].w = mark;
-    fvis[first_corner / 3] = 1;
-  };
   // ---- Edgebreaker symbols
-  uint32_t nsym = 0, nproc = 0, ninit = 0, nstart = 0, nsplit = 0, nsplit_sym = 0;
+  uint32_t nproc = 0, ninit = 0, nstart = 0, nsplit = 0, nsplit_sym = 0;
   int32_t last_symbol_id = -1;
-  auto encode_hole = [&](uint32_t start_corner, bool encode_first) {            // :276-303
+  auto encode_hole = [&](uint32_t start_corner, bool encode_first) {            // MeshEdgeBreakerEncoder.cs:276-303
     uint32_t c = ec_prev(start_corner);
     while (opp[c] != DSA_INVALID && !runaway()) c = ec_next(opp[c]);
     const uint32_t start_v = c2v[start_corner];
-    if (encode_first) vvis[start_v] |= 1;
-    if (hole_id[start_v] >= 0) hole_vis[hole_id[start_v]] = 1;
+    { const uint32_t m = vvis[start_v]; vvis[start_v] = (uint8_t)(m | (encode_first ? 1u : 0u) | ((m & 2u) ? 8u : 0u)); }
     uint32_t act = c2v[ec_prev(c)];
     while (act != start_v && !runaway()) {
-      vvis[act] |= 1;
+      vvis[act] |= 9;                                                             // visited; its loop is coded
       c = ec_next(c);
       while (opp[c] != DSA_INVALID && !runaway()) c = ec_next(opp[c]);
       act = c2v[ec_prev(c)];
@@ -293,179 +286,171 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
     splits[3 * nsplit] = (uint32_t)src_symbol; splits[3 * nsplit + 1] = neighbor_mark - 2u; splits[3 * nsplit + 2] = edge;
     ++nsplit;
   };
-  // A step reads three things that all hang off what the previous step loaded -- the marks of the vertex, the records of the two
-  // corners across -- and issues them together: one round trip per step (a face across an edge is never the face itself on a
-  // manifold mesh; the test stays, the mark of the face itself being what this step sets).
   auto encode_from_corner = [&](uint32_t corner0) {                             // :185-274
     uint32_t sp = 0;
     stack[sp++] = corner0;
     while (sp && !failed) {
       uint32_t corner = stack[sp - 1];
-      if (corner == DSA_INVALID || fvis[corner / 3]) { --sp; continue; }
-      Hop cur = hop(corner);
+      if (corner == DSA_INVALID) { --sp; continue; }
+      uint32_t f = corner / 3u;
+      EcFace cur = ec_face(frec, f);
+      if (cur.mark != 0) { --sp; continue; }
       for (;;) {
-        if (runaway() || nsym >= F || nproc >= F || sp >= F) { failed = true; break; }
+        if (runaway() || nproc >= F || sp >= F) { failed = true; break; }
         ++last_symbol_id;
-        const uint32_t first = corner - corner % 3;
-        const uint32_t v = cur.v, rc = cur.rc, lc = cur.lc;
-        const uint32_t vm = vvis[v];
-        const Hop hr = hop(rc), hl = hop(lc);
-        const bool r_self = rc - first < 3u, l_self = lc - first < 3u;            // (an invalid corner is far from any face)
-        const bool r_done = rc == DSA_INVALID || r_self || hr.mark != 0, l_done = lc == DSA_INVALID || l_self || hl.mark != 0;
+        const EcHop h = ec_hop(cur, corner - 3u * f);
+        const uint32_t fr = h.rc == DSA_INVALID ? 0u : h.rc / 3u, fl = h.lc == DSA_INVALID ? 0u : h.lc / 3u;
+        const uint32_t vm = vvis[h.v];
+        const EcFace R = ec_face(frec, fr), L = ec_face(frec, fl);
+        // (a face across an edge is never the face itself on a manifold mesh; the test stays, the mark of the face itself being
+        // what this step sets)
+        const bool r_self = h.rc != DSA_INVALID && fr == f, l_self = h.lc != DSA_INVALID && fl == f;
+        const bool r_done = h.rc == DSA_INVALID || r_self || R.mark != 0, l_done = h.lc == DSA_INVALID || l_self || L.mark != 0;
         const bool seen = (vm & 1u) != 0, on_boundary = (vm & 2u) != 0;
-        mark_face(first, 1u);
-        processed[nproc++] = corner;
-        if (!seen) {
-          vvis[v] = (uint8_t)(vm | 1u);
-          if (!on_boundary) { symbols[nsym++] = 0; corner = rc; cur = hr; continue; }
-        }
-        if (r_done) {
-          if (rc != DSA_INVALID && !r_self) check_split(last_symbol_id, 1, hr.mark);
+        uint32_t sym, mark = 1u, move;                                             // move: 0 end of the strip, 1 right, 2 left, 3 split
+        if (!seen) vvis[h.v] = (uint8_t)(vm | 1u);
+        if (!seen && !on_boundary) { sym = 0; move = 1; }
+        else if (r_done) {
+          if (h.rc != DSA_INVALID && !r_self) check_split(last_symbol_id, 1, R.mark);
           if (l_done) {
-            if (lc != DSA_INVALID && !l_self) check_split(last_symbol_id, 0, hl.mark);
-            symbols[nsym++] = 7;
-            --sp;
-            break;
-          }
-          symbols[nsym++] = 5;
-          corner = lc; cur = hl;
+            if (h.lc != DSA_INVALID && !l_self) check_split(last_symbol_id, 0, L.mark);
+            sym = 7; move = 0;
+          } else { sym = 5; move = 2; }
+        } else if (l_done) {
+          if (h.lc != DSA_INVALID && !l_self) check_split(last_symbol_id, 0, L.mark);
+          sym = 3; move = 1;
         } else {
-          if (l_done) {
-            if (lc != DSA_INVALID && !l_self) check_split(last_symbol_id, 0, hl.mark);
-            symbols[nsym++] = 3;
-            corner = rc; cur = hr;
-          } else {
-            symbols[nsym++] = 1;
-            ++nsplit_sym;
-            if (on_boundary) { const int32_t hid = hole_id[v]; if (!hole_vis[hid]) encode_hole(corner, false); }
-            mark_face(first, (uint32_t)last_symbol_id + 2u);
-            stack[sp - 1] = lc;
-            stack[sp++] = rc;                         // sp <= F: every push marks a face first
-            break;
-          }
+          sym = 1; move = 3;
+          ++nsplit_sym;
+          if (on_boundary && !(vm & 8u)) encode_hole(corner, false);
+          mark = (uint32_t)last_symbol_id + 2u;
         }
+        fw[8 * f + EC_MARK] = mark;
+        processed[nproc++] = corner | (sym << EC_SYMBOL_SHIFT);
+        if (move == 1) { corner = h.rc; f = fr; cur = R; continue; }
+        if (move == 2) { corner = h.lc; f = fl; cur = L; continue; }
+        if (move == 3) { stack[sp - 1] = h.lc; stack[sp++] = h.rc; }              // sp <= F: every push marks a face first
+        else --sp;
+        break;
       }
     }
   };
-  for (uint32_t base = 0; base < F; base += WAVE) {                               // :38-124
-    const uint32_t fl = base + lane;
-    uint64_t fresh = __builtin_amdgcn_ballot_w64(fl < F && fvis[fl] == 0);
-    while (fresh) {
-      const uint32_t face = base + (uint32_t)__builtin_ctzll(fresh);
-      fresh &= fresh - 1;
-      if (lane != 0) continue;
-      // (the reference asks at each of the three corners of a face whether the face is still to do)
-      for (int rep = 0; rep < 3 && !failed && !fvis[face]; ++rep) {
-        // find_init_face, :158-183
-        uint32_t corner = 3 * face, start = DSA_INVALID;
-        bool interior_face = true;
-        for (int i = 0; i < 3; ++i) {
-          if (opp[corner] == DSA_INVALID) { start = corner; interior_face = false; break; }
-          if (hole_id[c2v[corner]] != -1) {
-            uint32_t rc = corner;
-            while (rc != DSA_INVALID && !runaway()) { corner = rc; rc = ct.swing_right(rc); }
-            start = ec_prev(corner);
-            interior_face = false;
-            break;
-          }
-          corner = ec_next(corner);
+  for (uint32_t face = 0; !failed && nproc + ninit < F; ++face) {                 // :38-124 (every face is coded once: the scan is over when all are)
+    face = next_fresh(face, EC_MARK);
+    if (face >= F) break;
+    // (the reference asks at each of the three corners of a face whether the face is still to do)
+    for (int rep = 0; rep < 3 && !failed && fw[8 * face + EC_MARK] == 0; ++rep) {
+      // find_init_face, :158-183
+      uint32_t corner = 3 * face, start = DSA_INVALID;
+      bool interior_face = true;
+      for (int i = 0; i < 3; ++i) {
+        if (opp[corner] == DSA_INVALID) { start = corner; interior_face = false; break; }
+        if (vvis[c2v[corner]] & 2u) {
+          uint32_t rc = corner;
+          while (rc != DSA_INVALID && !runaway()) { corner = rc; rc = ct.swing_right(rc); }
+          start = ec_prev(corner);
+          interior_face = false;
+          break;
         }
-        if (interior_face) start = corner;
-        start_bits[nstart++] = interior_face ? 1 : 0;
-        if (interior_face) {
-          vvis[c2v[start]] |= 1; vvis[c2v[ec_next(start)]] |= 1; vvis[c2v[ec_prev(start)]] |= 1;
-          mark_face(3 * face, 1u);
-          init_corners[ninit++] = ec_next(start);
-          const uint32_t o = opp[ec_next(start)];
-          if (o != DSA_INVALID && !fvis[o / 3]) encode_from_corner(o);
+        corner = ec_next(corner);
+      }
+      if (interior_face) start = corner;
+      start_bits[nstart++] = interior_face ? 1 : 0;
+      if (interior_face) {
+        vvis[c2v[start]] |= 1; vvis[c2v[ec_next(start)]] |= 1; vvis[c2v[ec_prev(start)]] |= 1;
+        fw[8 * face + EC_MARK] = 1u;
+        init_corners[ninit++] = ec_next(start);
+        const uint32_t o = opp[ec_next(start)];
+        if (o != DSA_INVALID && fw[8 * (o / 3u) + EC_MARK] == 0) encode_from_corner(o);
+      } else {
+        encode_hole(ec_next(start), true);
+        encode_from_corner(start);
+      }
+    }
+  }
+  if (failed) ec_fail(E, steps > step_limit ? ENC_RING : ENC_SPLITS, nsplit);
+  E->num_symbols = nproc; E->num_start_bits = nstart; E->num_splits = nsplit; E->num_split_symbols = nsplit_sym;
+  E->num_processed = nproc; E->num_init = ninit; E->interior_edges /= 2;
+  if (failed) return;
+
+  // ---- depth-first attribute order over the decoder's face order (processed corners last to first, then the init
+  // corners), DepthFirstTraverser.cs:9-99.  A vertex is on a boundary -- SwingLeft of its left-most corner is invalid -- exactly
+  // when it is the end of an edge without an opposite.  The marks of this walk are its own (mark2, bit 4 of a vertex).
+  const uint32_t nstarts = nproc + ninit;
+  uint32_t count = 0, dfs_steps = 0, nfaces = 0;
+  bool stuck = false;
+  auto visit = [&](uint32_t v, uint32_t vm, uint32_t c) { vvis[v] = (uint8_t)(vm | 4u); v2d[v] = (int32_t)count; if (count < V) d2c[count] = c; ++count; };
+  for (uint32_t i = 0; i < nstarts && !stuck && nfaces < F;) {
+    // the next start whose face is still to do: eight candidates a round trip
+    uint32_t cand[8], m2[8];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+      const uint32_t k = i + j;
+      cand[j] = k < nstarts ? (k < nproc ? processed[nproc - 1 - k] & (uint32_t)EC_CORNER_MASK : init_corners[k - nproc]) : DSA_INVALID;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) m2[j] = cand[j] != DSA_INVALID ? fw[8 * (cand[j] / 3u) + EC_MARK2] : 1u;
+    uint32_t start = DSA_INVALID, hit = 8;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) if (hit == 8 && m2[j] == 0) { hit = j; start = cand[j]; }
+    if (hit == 8) { i += 8; continue; }
+    i += hit + 1;
+    uint32_t sp = 0;
+    stack[sp++] = start;
+    {
+      const EcFace sf = ec_face(frec, start / 3u);
+      const uint32_t k = start - 3u * (start / 3u);
+      const uint32_t nvx = k == 0 ? sf.v1 : (k == 1 ? sf.v2 : sf.v0), pvx = k == 0 ? sf.v2 : (k == 1 ? sf.v0 : sf.v1);
+      { const uint32_t m = vvis[nvx]; if (!(m & 4u)) visit(nvx, m, ec_next(start)); }
+      { const uint32_t m = vvis[pvx]; if (!(m & 4u)) visit(pvx, m, ec_prev(start)); }
+    }
+    while (sp && !stuck) {
+      uint32_t corner = stack[sp - 1];
+      if (corner == DSA_INVALID) { --sp; continue; }
+      uint32_t f = corner / 3u;
+      EcFace cur = ec_face(frec, f);
+      if (cur.mark2 != 0) { --sp; continue; }
+      for (;;) {
+        if (++dfs_steps > step_limit || sp >= F || count > V) { stuck = true; break; }
+        const EcHop h = ec_hop(cur, corner - 3u * f);
+        const uint32_t fr = h.rc == DSA_INVALID ? 0u : h.rc / 3u, fl = h.lc == DSA_INVALID ? 0u : h.lc / 3u;
+        const uint32_t vm = vvis[h.v];
+        const EcFace R = ec_face(frec, fr), L = ec_face(frec, fl);
+        const bool r_done = h.rc == DSA_INVALID || fr == f || R.mark2 != 0, l_done = h.lc == DSA_INVALID || fl == f || L.mark2 != 0;
+        fw[8 * f + EC_MARK2] = 1u;
+        ++nfaces;
+        if (!(vm & 4u)) {
+          visit(h.v, vm, corner);
+          if (!(vm & 2u)) { corner = h.rc; f = fr; cur = R; continue; }
+        }
+        if (r_done) {
+          if (l_done) { --sp; break; }
+          corner = h.lc; f = fl; cur = L;
         } else {
-          encode_hole(ec_next(start), true);
-          encode_from_corner(start);
+          if (l_done) { corner = h.rc; f = fr; cur = R; }
+          else { stack[sp - 1] = h.lc; stack[sp++] = h.rc; break; }
         }
       }
     }
   }
-  if (lane == 0) {
-    ENC_CLK(4);
-    if (failed) ec_fail(E, steps > step_limit ? ENC_RING : ENC_SPLITS, nsplit);
-    E->num_symbols = nsym; E->num_start_bits = nstart; E->num_splits = nsplit; E->num_split_symbols = nsplit_sym;
-    E->num_processed = nproc; E->num_init = ninit; E->interior_edges /= 2;
-  }
-  ec_sync();
-  if (E->status != ENC_OK) return;
-  // the traversal marks start over for the attribute order
-  for (uint32_t c = lane; c < NC; c += WAVE) hrec[c].w = 0;
-  for (uint32_t f = lane; f < F; f += WAVE) fvis[f] = 0;
-  for (uint32_t v = lane; v < V; v += WAVE) vvis[v] &= 2;
-  ec_sync();
-  {
-    // ---- depth-first attribute order over the decoder's face order (processed corners last to first, then the init
-    // corners), DepthFirstTraverser.cs:9-99.  A vertex is on a boundary -- SwingLeft of its left-most corner is invalid -- exactly
-    // when the hole pass gave it an id.
-    const uint32_t nproc = E->num_processed, ninit = E->num_init, nstarts = nproc + ninit;
-    uint32_t count = 0, dfs_steps = 0;
-    bool stuck = false;
-    auto visit = [&](uint32_t v, uint32_t vm, uint32_t c) { vvis[v] = (uint8_t)(vm | 1u); v2d[v] = (int32_t)count; if (count < V) d2c[count] = c; ++count; };
-    for (uint32_t base = 0; base < nstarts; base += WAVE) {
-      const uint32_t i = base + lane;
-      const uint32_t mine = i < nstarts ? (i < nproc ? processed[nproc - 1 - i] : init_corners[i - nproc]) : DSA_INVALID;
-      uint64_t fresh = __builtin_amdgcn_ballot_w64(mine != DSA_INVALID && fvis[mine / 3] == 0);
-      while (fresh) {
-        const int from = __builtin_ctzll(fresh);
-        fresh &= fresh - 1;
-        const uint32_t start = (uint32_t)__shfl((int)mine, from, WAVE);
-        if (lane != 0 || stuck) continue;
-        if (fvis[start / 3]) continue;
-        uint32_t sp = 0;
-        stack[sp++] = start;
-        const uint32_t nvx = c2v[ec_next(start)], pvx = c2v[ec_prev(start)];
-        { const uint32_t m = vvis[nvx]; if (!(m & 1u)) visit(nvx, m, ec_next(start)); }
-        { const uint32_t m = vvis[pvx]; if (!(m & 1u)) visit(pvx, m, ec_prev(start)); }
-        while (sp && !stuck) {
-          uint32_t corner = stack[sp - 1];
-          if (corner == DSA_INVALID || fvis[corner / 3]) { --sp; continue; }
-          Hop cur = hop(corner);
-          for (;;) {
-            if (++dfs_steps > 64u * NC + 4096u || sp >= F || count > V) { stuck = true; break; }
-            const uint32_t first = corner - corner % 3;
-            const uint32_t v = cur.v, rc = cur.rc, lc = cur.lc;
-            const uint32_t vm = vvis[v];
-            const Hop hr = hop(rc), hl = hop(lc);
-            const bool r_done = rc == DSA_INVALID || rc - first < 3u || hr.mark != 0, l_done = lc == DSA_INVALID || lc - first < 3u || hl.mark != 0;
-            mark_face(first, 1u);
-            if (!(vm & 1u)) {
-              visit(v, vm, corner);
-              if (!(vm & 2u)) { corner = rc; cur = hr; continue; }
-            }
-            if (r_done) {
-              if (l_done) { --sp; break; }
-              corner = lc; cur = hl;
-            } else {
-              if (l_done) { corner = rc; cur = hr; }
-              else { stack[sp - 1] = lc; stack[sp++] = rc; break; }
-            }
-          }
-        }
-      }
-    }
-    if (lane == 0) {
-      ENC_CLK(5);
-      E->num_entries = count;
-      if (stuck) ec_fail(E, ENC_RING, count);
-      else if (count != V) ec_fail(E, ENC_UNREACHED, count);
-    }
-  }
-  ec_sync();
-  if (E->status != ENC_OK) return;
+  E->num_entries = count;
+  if (stuck) ec_fail(E, ENC_RING, count);
+  else if (count != V) ec_fail(E, ENC_UNREACHED, count);
 }
 
-// ---- entry -> vertex and the parallelogram operand entries of every entry (MeshPredictionSchemeParallelogramEncoder.cs:35-56)
+// ---- the symbols as bytes; entry -> vertex and the parallelogram operand entries of every entry (MeshPredictionSchemeParallelogramEncoder.cs:35-56)
 __global__ __launch_bounds__(256) void k_enc_operands(uint8_t *arena, EncConn *conns, uint32_t n) {
   ENC_TABLE_PROLOGUE
   const uint32_t *opp = (const uint32_t *)(arena + E->opp), *d2c = (const uint32_t *)(arena + E->d2c);
   const int32_t *v2d = (const int32_t *)(arena + E->v2d);
   uint32_t *e2v = (uint32_t *)(arena + E->e2v);
   int32_t *ops = (int32_t *)(arena + E->ops);
+  {
+    const uint32_t *processed = (const uint32_t *)(arena + E->processed);
+    uint8_t *symbols = arena + E->symbols;
+    const uint32_t ns = E->num_symbols;
+    for (uint32_t i = t0; i < ns; i += stride) symbols[i] = (uint8_t)(processed[i] >> EC_SYMBOL_SHIFT);
+  }
   for (uint32_t p = t0; p < V; p += stride) {
     const uint32_t ci = d2c[p];
     e2v[p] = c2v[ci];

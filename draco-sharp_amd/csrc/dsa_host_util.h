@@ -7,10 +7,14 @@
 #include <hip/hip_runtime.h>
 #include <sched.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <exception>
 #include <thread>
 #include <vector>
@@ -27,6 +31,21 @@ inline uint32_t host_threads() {
     if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = (uint32_t)CPU_COUNT(&set);
     if (cores == 0) cores = std::thread::hardware_concurrency();
     if (cores == 0) cores = 8;
+    // a container's CPU quota (cgroup v2 cpu.max, v1 cfs_quota / cfs_period): more runnable threads than the quota pays for are
+    // not slower by their share, they are stopped for the rest of every period
+    auto quota = []() -> uint32_t {
+      long long q = -1, per = 0;
+      if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char first[32] = {0};
+        if (fscanf(f, "%31s %lld", first, &per) == 2 && strcmp(first, "max") != 0) q = atoll(first);
+        fclose(f);
+      } else {
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &q) != 1) q = -1; fclose(g); }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &per) != 1) per = 0; fclose(g); }
+      }
+      return q > 0 && per > 0 ? (uint32_t)((q + per - 1) / per) : 0u;
+    }();
+    if (quota) cores = std::min(cores, std::max(quota, 2u));
     return std::min<uint32_t>(cores, 32u);
   }();
   return n;
@@ -117,6 +136,60 @@ struct Staging {
     return buf.ensure(bytes);
   }
   hipError_t submitted(hipStream_t s) { hipError_t e = hipEventRecord(done, s); if (e == hipSuccess) pending = true; return e; }
+};
+
+// Whose turn it is on the host -> device link.  The chunks of an encode batch upload in two phases: A, what the long latency-bound
+// stage of a chunk needs (the faces), and B, the rest (the attribute values, which only the kernels behind that stage read).
+// Phases A go in the order of the chunks (the large ones of a tapered batch first) and before every waiting phase B, so that
+// every chunk's long stage is under way before the link carries anything that is not needed yet.
+struct UploadTurns {
+  std::mutex m;
+  std::condition_variable cv;
+  bool busy = false;
+  uint32_t next_a = 0;
+  std::vector<char> a_done;               // per chunk: its phase A is over (or will never come)
+  explicit UploadTurns(uint32_t chunks) : a_done(chunks, 0) {}
+  int a_waiting = 0;
+  void acquire_a(uint32_t chunk) {
+    std::unique_lock<std::mutex> lk(m);
+    ++a_waiting;
+    cv.wait(lk, [&] { return !busy && next_a == chunk; });
+    --a_waiting;
+    busy = true;
+  }
+  void acquire_b() {                      // (a chunk in front of a waiting phase A is on its way to its own phase A, never waiting here)
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return !busy && a_waiting == 0; });
+    busy = true;
+  }
+  void finish_a(uint32_t chunk, bool held) {          // also for a chunk that never uploads (held = false)
+    {
+      std::lock_guard<std::mutex> lk(m);
+      if (held) busy = false;
+      if (chunk < a_done.size()) a_done[chunk] = 1;
+      while (next_a < a_done.size() && a_done[next_a]) ++next_a;
+    }
+    cv.notify_all();
+  }
+  void release_b() { { std::lock_guard<std::mutex> lk(m); busy = false; } cv.notify_all(); }
+};
+struct TurnGuard {                       // a turn is given back, and a phase A that never came is struck off, on every exit path
+  UploadTurns *t;
+  uint32_t chunk;
+  int held = 0;                          // 1: phase A, 2: phase B
+  bool a_over = false;
+  TurnGuard(UploadTurns *turns, uint32_t chunk_index) : t(turns), chunk(chunk_index) {}
+  TurnGuard(const TurnGuard &) = delete;
+  TurnGuard &operator=(const TurnGuard &) = delete;
+  void acquire_a() { if (t && !held && !a_over) { t->acquire_a(chunk); held = 1; } }
+  void acquire_b() { if (t && !held) { if (!a_over) { t->finish_a(chunk, false); a_over = true; } t->acquire_b(); held = 2; } }
+  void release() {
+    if (!t) return;
+    if (held == 1) { t->finish_a(chunk, true); a_over = true; }
+    else if (held == 2) t->release_b();
+    held = 0;
+  }
+  ~TurnGuard() { release(); if (t && !a_over) t->finish_a(chunk, false); }
 };
 
 }  // namespace hostutil

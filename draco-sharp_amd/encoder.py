@@ -7,6 +7,8 @@ bound to the dsa_encode_* entry points of libdraco_mi355x.so.  Connectivity (cor
 order), attribute quantisation / prediction / rANS coding are HIP kernels; the library's host side chooses the symbol schemes
 and lays the bytes out; there is no CPU fallback."""
 import ctypes as C
+import os
+import time
 
 import numpy as np
 
@@ -46,12 +48,68 @@ class MeshData:
         self.texcoords = None if texcoords is None else np.ascontiguousarray(texcoords, np.float32)
 
 
+class EncodedStreams:
+    """The .drc streams of a batch, a sequence of `bytes`.  The bytes stay in the library's buffers until a stream is asked
+    for (indexing, iteration), so that a caller who hands the batch on -- to a file, a socket, dsa.Batch -- pays for one copy of
+    what it touches instead of for 4096 fresh allocations up front; `sizes` needs none.  A mesh that could not be encoded raises
+    when the batch is made, like the reference's encoder does for its one mesh."""
+
+    def __init__(self, ctx, handle, n):
+        L = native.lib()
+        self._h, self._free = handle, L.dsa_encoded_free
+        self._ptr, self._len, self._cache = [0] * n, [0] * n, [None] * n
+        p, ln = C.c_void_p(), C.c_size_t()
+        try:
+            for i in range(n):
+                st = L.dsa_encoded_stream(handle, i, C.byref(p), C.byref(ln))
+                if st != 0:
+                    _raise(st, ctx.error())
+                self._ptr[i], self._len[i] = p.value, ln.value
+        except Exception:
+            self.close()
+            raise
+
+    @property
+    def sizes(self):
+        return list(self._len)
+
+    def __len__(self):
+        return len(self._len)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        b = self._cache[i]
+        if b is None:
+            if self._h is None:
+                raise ValueError("the encoded batch was closed")
+            b = self._cache[i] = C.string_at(self._ptr[i], self._len[i])
+        return b
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __eq__(self, other):
+        return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+
+    def close(self):
+        """Releases the library's buffers (streams already taken stay valid)."""
+        if self._h is not None:
+            self._free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
 class DracoEncoder:
     def __init__(self, context=None):
         self._ctx = context
 
     def EncodeBatch(self, meshes, config=None):
-        """meshes: list of MeshData -> list of bytes (.drc streams).  A mesh that cannot be encoded raises."""
+        """meshes: list of MeshData -> sequence of bytes (.drc streams, EncodedStreams).  A mesh that cannot be encoded raises."""
         ctx = self._ctx or default_context()
         L = native.lib()
         n = len(meshes)
@@ -63,20 +121,15 @@ class DracoEncoder:
             arr[i].texcoords = m.texcoords.ctypes.data if m.texcoords is not None else None
         opt = (config or Config())._native()
         h = C.c_void_p()
+        t0 = time.perf_counter()
         st = L.dsa_encode_batch(ctx._h, n, arr, C.byref(opt), C.byref(h))
+        t1 = time.perf_counter()
         if st != 0:
             _raise(st, ctx.error())
-        try:
-            out = []
-            for i in range(n):
-                p, ln = C.c_void_p(), C.c_size_t()
-                st = L.dsa_encoded_stream(h, i, C.byref(p), C.byref(ln))
-                if st != 0:
-                    _raise(st, ctx.error())
-                out.append(C.string_at(p, ln.value))
-            return out
-        finally:
-            L.dsa_encoded_free(h)
+        r = EncodedStreams(ctx, h, n)
+        if os.environ.get("DSA_ENC_TIMING"):            # diagnostics, like the library's own phase clocks
+            print("[EncodeBatch] native call %.1f ms, result handles %.1f ms" % ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3), flush=True)
+        return r
 
     def Encode(self, mesh, config=None):
         return self.EncodeBatch([mesh], config)[0]

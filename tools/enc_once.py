@@ -8,5 +8,5 @@ pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 128, 256, 1000)
 meshes = [dsa.MeshData(pos, faces, nrm, uv) for _ in range(n)]
 ctx = dsa.Context(0); enc = dsa.DracoEncoder(ctx)
 enc.EncodeBatch(meshes)
-t0 = time.perf_counter(); enc.EncodeBatch(meshes); dt = time.perf_counter() - t0
+t0 = time.perf_counter(); out = enc.EncodeBatch(meshes); dt = time.perf_counter() - t0
 print("%d meshes: %.1f ms, %.0f meshes/s" % (n, dt * 1e3, n / dt))
