@@ -38,6 +38,20 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 
 
+def usable_cores():
+    """Cores this process may keep busy: its affinity mask, cut to the container's CPU quota (cgroup cpu.max) -- threads beyond
+    the quota are not slower by their share, they are stopped for the rest of every period."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cores = max(2, min(cores, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(blob, offsets, threads, budget_s, max_meshes):
     """The CPU oracle (C++ scalar restatement of the reference path) on a bounded sample of the rank-0 batch, on
     `threads` host threads (the ctypes call releases the GIL; every mesh is independent)."""
@@ -63,7 +77,7 @@ def cpu_baseline(blob, offsets, threads, budget_s, max_meshes):
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "meshes/s", "cores": threads, "kind": "port",
             "sample": "first %d meshes of the rank-0 batch, full decode incl. numpy export, %.1f s" % (done, dt),
-            "host_cores_available": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()}
+            "host_cores_available": usable_cores()}
 
 
 def measured_traffic(kernel, meshes, triangles):
@@ -268,7 +282,7 @@ def main():
     comm.barrier()                                   # every rank is past the build
 
     nx, ny = args.grid
-    host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    host_cores = usable_cores()
     threads = max(1, min(host_cores, 64) // max(1, world))
     ctx = dsa.Context(local_rank)
     ctx.set_profiling(True)

@@ -206,3 +206,43 @@ def test_randomised_encoder_options_slice():
     CPU coder byte for byte, every stream decoded again."""
     r = _tool("soak_encode.py", 60, 5)
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+
+
+def test_mixed_shapes_over_many_chunks_and_lanes(ctx, monkeypatch):
+    """The chunk pipeline of dsa_encode_batch (uploads in turns by chunk, faces first, the walks on their own stream) and the
+    lane-per-mesh walks with meshes of different shape in one wave: closed surfaces (an interior start face), holes, two
+    components, sizes from 24 to 5000 faces -- every stream byte for byte the CPU coder's, whatever the chunk size and the
+    number of meshes to a wave."""
+    kinds = (synth.GRID, synth.TORUS, synth.SPHERE, synth.HOLES, synth.TWO_PARTS)
+    meshes, expected = [], []
+    for k in range(75):
+        kind = kinds[k % len(kinds)]
+        nx, ny = 4 + (7 * k) % 47, 3 + (5 * k) % 53
+        if kind == synth.HOLES: nx, ny = max(nx, 12), max(ny, 12)
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 100 + k)
+        meshes.append(dsa.MeshData(pos, faces, nrm, uv)); expected.append(synth.encode_mesh(pos, faces, nrm, uv))
+    enc = dsa.DracoEncoder(ctx)
+    monkeypatch.setenv("DSA_ENC_HOST_CONN", "0")
+    monkeypatch.setenv("DSA_ENC_HOST_PLAN", "0")
+    for chunk, walk_lanes in ((8, 8), (16, 3), (7, 64), (75, 16), (20, 1)):
+        monkeypatch.setenv("DSA_ENC_CHUNK", str(chunk))
+        monkeypatch.setenv("DSA_ENC_WALK_LANES", str(walk_lanes))
+        got = enc.EncodeBatch(meshes)
+        assert got.sizes == [len(e) for e in expected]
+        for i, e in enumerate(expected):
+            assert got[i] == e, (chunk, walk_lanes, i)
+
+
+def test_a_chunk_of_nothing_but_bad_meshes_holds_nobody_up(ctx, monkeypatch):
+    """A chunk whose meshes all fail the host's checks uploads nothing; its turn on the link must pass on (the other chunks'
+    uploads wait for their turn in chunk order), and the batch reports the failure instead of standing still."""
+    pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 6, 5, 4)
+    bad = faces.copy(); bad[0, 0] = len(pos) + 5
+    good, broken = dsa.MeshData(pos, faces, nrm, uv), dsa.MeshData(pos, bad, nrm, uv)
+    enc = dsa.DracoEncoder(ctx)
+    monkeypatch.setenv("DSA_ENC_HOST_CONN", "0")
+    monkeypatch.setenv("DSA_ENC_CHUNK", "4")
+    for layout in ([good] * 4 + [broken] * 4 + [good] * 12, [broken] * 4 + [good] * 20, [good] * 20 + [broken] * 4):
+        with pytest.raises(dsa.InvalidDataException):
+            enc.EncodeBatch(layout)
+    assert enc.EncodeBatch([good] * 24)[23] == synth.encode_mesh(pos, faces, nrm, uv)
