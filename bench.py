@@ -284,6 +284,8 @@ def main():
     nx, ny = args.grid
     host_cores = usable_cores()
     threads = max(1, min(host_cores, 64) // max(1, world))
+    if world > 1:      # the ranks of a node share its cores: the library's host fan-outs (staging copies, stream layout) take a rank's share
+        os.environ.setdefault("DSA_HOST_THREADS", str(max(2, min(32, host_cores // world))))
     ctx = dsa.Context(local_rank)
     ctx.set_profiling(True)
 
