@@ -70,7 +70,6 @@ struct EcTable {                   // the corner table as the traversals see it
 };
 
 __device__ __forceinline__ void ec_fail(EncConn *E, uint32_t status, uint32_t detail) { if (atomicCAS(&E->status, 0u, status) == 0u) E->detail = detail; }
-__device__ __forceinline__ void ec_sync() { __threadfence_block(); __syncthreads(); }
 
 
 // The corner table is built by kernels of their own, every mesh of the chunk on as many blocks as its corners ask for (grid: blocks
@@ -116,6 +115,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_table_offsets(uint8_t *arena, EncC
   const uint32_t V = E->V;
   uint32_t *voff = (uint32_t *)(arena + E->voff), *vcur = (uint32_t *)(arena + E->vcur);
   uint32_t base = 0;
+#if defined(__HIPCC__)
   for (uint32_t v0 = 0; v0 < V; v0 += WAVE) {
     const uint32_t v = v0 + lane;
     uint32_t x = v < V ? voff[v + 1] : 0u, incl = x;
@@ -123,6 +123,9 @@ __global__ __launch_bounds__(WAVE) void k_enc_table_offsets(uint8_t *arena, EncC
     if (v < V) { voff[v + 1] = base + incl; vcur[v] = base + incl - x; }
     base += (uint32_t)__shfl((int)incl, WAVE - 1, WAVE);
   }
+#else       // the sanitizer build of tests/hostcheck/encconn_host.cpp runs the lanes of a wave one after the other: lane 0 sums
+  if (lane == 0) for (uint32_t v = 0; v < V; ++v) { const uint32_t x = voff[v + 1]; vcur[v] = base; base += x; voff[v + 1] = base; }
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_enc_table_lists(uint8_t *arena, EncConn *conns, uint32_t n) {
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
       EcFace cur = ec_face(frec, f);
       if (cur.mark != 0) { --sp; continue; }
       for (;;) {
-        if (runaway() || nproc >= F || sp >= F) { failed = true; break; }
+        if (runaway() || nproc >= F) { failed = true; break; }
         ++last_symbol_id;
         const EcHop h = ec_hop(cur, corner - 3u * f);
         const uint32_t fr = h.rc == DSA_INVALID ? 0u : h.rc / 3u, fl = h.lc == DSA_INVALID ? 0u : h.lc / 3u;
@@ -329,8 +332,10 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
         processed[nproc++] = corner | (sym << EC_SYMBOL_SHIFT);
         if (move == 1) { corner = h.rc; f = fr; cur = R; continue; }
         if (move == 2) { corner = h.lc; f = fl; cur = L; continue; }
-        if (move == 3) { stack[sp - 1] = h.lc; stack[sp++] = h.rc; }              // sp <= F: every push marks a face first
-        else --sp;
+        if (move == 3) {                                                          // (sp <= F by itself: every push marks a face first)
+          if (sp >= F) { failed = true; break; }
+          stack[sp - 1] = h.lc; stack[sp++] = h.rc;
+        } else --sp;
         break;
       }
     }
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
       EcFace cur = ec_face(frec, f);
       if (cur.mark2 != 0) { --sp; continue; }
       for (;;) {
-        if (++dfs_steps > step_limit || sp >= F || count > V) { stuck = true; break; }
+        if (++dfs_steps > step_limit || count > V) { stuck = true; break; }
         const EcHop h = ec_hop(cur, corner - 3u * f);
         const uint32_t fr = h.rc == DSA_INVALID ? 0u : h.rc / 3u, fl = h.lc == DSA_INVALID ? 0u : h.lc / 3u;
         const uint32_t vm = vvis[h.v];
@@ -428,7 +433,11 @@ __global__ __launch_bounds__(WAVE) void k_enc_connectivity(uint8_t *arena, EncCo
           corner = h.lc; f = fl; cur = L;
         } else {
           if (l_done) { corner = h.rc; f = fr; cur = R; }
-          else { stack[sp - 1] = h.lc; stack[sp++] = h.rc; break; }
+          else {
+            if (sp >= F) { stuck = true; break; }
+            stack[sp - 1] = h.lc; stack[sp++] = h.rc;
+            break;
+          }
         }
       }
     }

@@ -1,0 +1,151 @@
+// tests/hostcheck/encconn_host.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// The encoder's connectivity kernels of the product (draco-sharp_amd/csrc/dsa_encode_conn.h: corner table, the Edgebreaker walk
+// and the attribute-order walk one lane per mesh, operand entries) compiled for the host with AddressSanitizer + UBSan and run
+// thread by thread, against the host coder (dsa_encode_host.h: CornerTable::build, EbEncoder, dfs_sequence) on the same faces:
+// same symbols, start-face bits, split events, traversal order and operand entries on meshes both accept, the same verdict on
+// damaged ones, and not one access outside a mesh's arrays (the arena's gaps are poisoned).  GPU sanitizers are not available on
+// the pool; a walk that leaves its arrays on the device can take the machine down.  Nothing here is linked into the product.
+//
+//   encconn_host <meshes.bin>       file: u32 count, then per mesh u32 nv, u32 nf, u32 faces[3 nf]
+#include <sanitizer/asan_interface.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../draco-sharp_amd/csrc/dsa_common.h"
+#include "../../draco-sharp_amd/csrc/dsa_types.h"
+#include "../../draco-sharp_amd/csrc/dsa_encode_host.h"
+
+// ---- what the kernels use of the HIP language, for one thread at a time
+struct uint4 { uint32_t x, y, z, w; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+struct Dim3 { uint32_t x = 1, y = 1, z = 1; };
+static Dim3 blockIdx, threadIdx, blockDim, gridDim;
+#define __global__
+#define __launch_bounds__(x)
+static inline uint32_t atomicCAS(uint32_t *p, uint32_t cmp, uint32_t val) { const uint32_t old = *p; if (old == cmp) *p = val; return old; }
+static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { const uint32_t old = *p; *p = old + v; return old; }
+static inline uint32_t atomicMin(uint32_t *p, uint32_t v) { const uint32_t old = *p; if (v < old) *p = v; return old; }
+
+#include "../../draco-sharp_amd/csrc/dsa_encode_conn.h"
+
+template <class K, class... A>
+static void launch(K kernel, uint32_t gx, uint32_t gy, uint32_t block, A... args) {
+  gridDim.x = gx; gridDim.y = gy; blockDim.x = block;
+  for (uint32_t by = 0; by < gy; ++by)
+    for (uint32_t bx = 0; bx < gx; ++bx)
+      for (uint32_t t = 0; t < block; ++t) { blockIdx.x = bx; blockIdx.y = by; threadIdx.x = t; kernel(args...); }
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) { fprintf(stderr, "usage: encconn_host <meshes.bin>\n"); return 2; }
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) { perror(argv[1]); return 2; }
+  uint32_t count = 0;
+  if (fread(&count, 4, 1, f) != 1) return 2;
+  struct In { uint32_t nv, nf; std::vector<uint32_t> faces; };
+  std::vector<In> meshes(count);
+  for (auto &m : meshes) {
+    if (fread(&m.nv, 4, 1, f) != 1 || fread(&m.nf, 4, 1, f) != 1) return 2;
+    m.faces.resize((size_t)3 * m.nf);
+    if (m.nf && fread(m.faces.data(), 4, m.faces.size(), f) != m.faces.size()) return 2;
+  }
+  fclose(f);
+  // ---- the arena, laid out like dsa_encode.h lays a chunk out, every gap poisoned
+  const uint32_t n = count;
+  std::vector<dsa::EncConn> hc(n);
+  uint64_t cur = 0;
+  std::vector<std::pair<uint64_t, uint64_t>> regions;
+  auto take = [&](uint64_t bytes) { cur = (cur + 255) & ~255ull; cur += 64; const uint64_t at = cur; regions.push_back({at, bytes}); cur += bytes + 64; return at; };
+  for (uint32_t i = 0; i < n; ++i) {
+    dsa::EncConn &C = hc[i];
+    memset(&C, 0, sizeof(C));
+    const uint64_t F = meshes[i].nf, V = meshes[i].nv;
+    C.F = (uint32_t)F; C.V = (uint32_t)V; C.split_cap = (uint32_t)F; C.fail_key = 0xFFFFFFFFu;
+    C.faces = take(12 * F);
+    C.opp = take(12 * F); C.voff = take(4 * (V + 1)); C.vcur = take(4 * V); C.vlist = take(12 * F); C.vcorner = take(4 * V);
+    C.vvis = take(V); C.frec = take(32 * F);
+    C.stack = take(4 * F); C.processed = take(4 * F); C.init_corners = take(4 * F);
+    C.symbols = take(F); C.start_bits = take(F); C.splits = take(12ull * C.split_cap);
+    C.d2c = take(4 * V); C.v2d = take(4 * V); C.e2v = take(4 * V); C.ops = take(12 * V);
+    bool in_range = true;                       // (the library's host checks: a mesh with an index out of range never reaches the device)
+    for (uint32_t x : meshes[i].faces) in_range = in_range && x < V;
+    if (!in_range || F == 0 || V < 3) C.status = dsa::ENC_ISOLATED;
+  }
+  std::vector<uint8_t> arena_store(cur + 256, 0);
+  uint8_t *arena = arena_store.data();
+  for (uint32_t i = 0; i < n; ++i) if (meshes[i].nf) memcpy(arena + hc[i].faces, meshes[i].faces.data(), 12ull * meshes[i].nf);
+  ASAN_POISON_MEMORY_REGION(arena, arena_store.size());
+  for (auto &rg : regions) ASAN_UNPOISON_MEMORY_REGION(arena + rg.first, rg.second);
+  uint32_t maxf = 1;
+  for (auto &m : meshes) maxf = std::max(maxf, m.nf);
+  const uint32_t gx = std::max(1u, std::min(4u, (3u * maxf + 1023u) / 1024u));
+  dsa::EncConn *conns = hc.data();
+  launch(dsa::k_enc_table_clear, gx, n, 256, arena, conns, n);
+  launch(dsa::k_enc_table_count, gx, n, 256, arena, conns, n);
+  launch(dsa::k_enc_table_offsets, n, 1, WAVE, arena, conns, n);
+  launch(dsa::k_enc_table_lists, gx, n, 256, arena, conns, n);
+  launch(dsa::k_enc_table_opposites, gx, n, 256, arena, conns, n);
+  launch(dsa::k_enc_table_corners, gx, n, 256, arena, conns, n);
+  const uint32_t lanes = 5;                    // meshes to a wave
+  launch(dsa::k_enc_connectivity, (n + lanes - 1) / lanes, 1, WAVE, arena, conns, n, lanes);
+  launch(dsa::k_enc_operands, gx, n, 256, arena, conns, n);
+  // ---- against the host coder
+  uint32_t coded = 0, refused = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const In &m = meshes[i];
+    const dsa::EncConn &C = hc[i];
+    std::vector<float> pos((size_t)3 * std::max(m.nv, 1u), 0.0f);
+    synth::MeshIn in;
+    in.pos = pos.data(); in.nv = m.nv; in.faces = m.faces.data(); in.nf = m.nf; in.normals = nullptr; in.uvs = nullptr; in.generic = nullptr;
+    synth::MeshPlan pl;
+    synth::Options opt;
+    bool host_ok = true;
+    std::string why;
+    try {
+      synth::check(m.nv >= 3 && m.nf >= 1, "mesh needs positions and faces");
+      for (uint32_t x : m.faces) synth::check(x < m.nv, "face index out of range");
+      synth::plan_mesh(in, opt, pl);
+    } catch (const std::exception &e) { host_ok = false; why = e.what(); }
+    const bool dev_ok = C.status == dsa::ENC_OK;
+    if (host_ok != dev_ok) { fprintf(stderr, "mesh %u: host coder %s (%s), device source status %u\n", i, host_ok ? "codes" : "refuses", why.c_str(), C.status); return 1; }
+    if (!host_ok) {
+      // an index out of range or an empty mesh never reaches the kernels; any other refusal must carry the host coder's words
+      if (C.status != dsa::ENC_ISOLATED || (why != "face index out of range" && why != "mesh needs positions and faces"))
+        if (why != dsa::enc_conn_message(C.status)) { fprintf(stderr, "mesh %u: host coder says '%s', device source '%s'\n", i, why.c_str(), dsa::enc_conn_message(C.status)); return 1; }
+      ++refused;
+      continue;
+    }
+    ++coded;
+#define SAME(cond, what) do { if (!(cond)) { fprintf(stderr, "mesh %u: %s differ\n", i, what); return 1; } } while (0)
+    SAME(C.num_symbols == pl.eb.symbols.size() && memcmp(arena + C.symbols, pl.eb.symbols.data(), C.num_symbols) == 0, "symbols");
+    SAME(C.num_start_bits == pl.eb.start_face_bits.size() && memcmp(arena + C.start_bits, pl.eb.start_face_bits.data(), C.num_start_bits) == 0, "start-face bits");
+    SAME(C.num_split_symbols == pl.eb.num_split_symbols && C.num_splits == pl.eb.splits.size(), "split counts");
+    const uint32_t *sp = (const uint32_t *)(arena + C.splits);
+    for (uint32_t q = 0; q < C.num_splits; ++q) SAME(sp[3 * q] == pl.eb.splits[q].source && sp[3 * q + 1] == pl.eb.splits[q].split && sp[3 * q + 2] == pl.eb.splits[q].edge, "split events");
+    SAME(C.num_entries == m.nv && memcmp(arena + C.d2c, pl.seq.data_to_corner.data(), 4ull * m.nv) == 0, "traversal order");
+    int64_t interior = 0;
+    for (uint32_t c = 0; c < 3 * m.nf; ++c) interior += pl.ct.opposite(c) != synth::kInvalid ? 1 : 0;
+    SAME((int64_t)C.interior_edges == interior / 2, "interior edge counts");
+    const uint32_t *e2v = (const uint32_t *)(arena + C.e2v);
+    const int32_t *ops = (const int32_t *)(arena + C.ops);
+    for (uint32_t p = 0; p < m.nv; ++p) {
+      const uint32_t ci = pl.seq.data_to_corner[p];
+      int32_t want[3] = {-1, -1, -1};
+      if (p > 0) {
+        const uint32_t oci = pl.ct.opposite(ci);
+        if (oci != synth::kInvalid) {
+          const int32_t vo = pl.seq.vertex_to_data[pl.ct.vertex(oci)], vn = pl.seq.vertex_to_data[pl.ct.vertex(synth::CornerTable::next(oci))], vp = pl.seq.vertex_to_data[pl.ct.vertex(synth::CornerTable::prev(oci))];
+          if (vo < (int32_t)p && vn < (int32_t)p && vp < (int32_t)p) { want[0] = vn; want[1] = vp; want[2] = vo; }
+        }
+      }
+      SAME(e2v[p] == pl.ct.vertex(ci) && ops[3 * p] == want[0] && ops[3 * p + 1] == want[1] && ops[3 * p + 2] == want[2], "operand entries");
+    }
+  }
+  printf("encconn: %u meshes, %u coded alike, %u refused alike\n", n, coded, refused);
+  return 0;
+}

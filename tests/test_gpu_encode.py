@@ -246,3 +246,21 @@ def test_a_chunk_of_nothing_but_bad_meshes_holds_nobody_up(ctx, monkeypatch):
         with pytest.raises(dsa.InvalidDataException):
             enc.EncodeBatch(layout)
     assert enc.EncodeBatch([good] * 24)[23] == synth.encode_mesh(pos, faces, nrm, uv)
+
+
+def test_one_triangle_and_other_tiny_meshes_on_the_device_path(ctx, monkeypatch):
+    """A mesh of one face fills its traversal stack with its only entry (the device walks once took a full stack for an
+    overflow); tiny closed and fan-shaped meshes beside it, connectivity and plans forced onto the device."""
+    monkeypatch.setenv("DSA_ENC_HOST_CONN", "0")
+    monkeypatch.setenv("DSA_ENC_HOST_PLAN", "0")
+    p3 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    p4 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    fan = np.array([[0, i, i + 1] for i in range(1, 40)] + [[0, 40, 1]], np.uint32)
+    pf = np.concatenate([[[0, 0, 1]], [[np.cos(a), np.sin(a), 0] for a in np.linspace(0, 2 * np.pi, 40, endpoint=False)]]).astype(np.float32)
+    cases = [(p3, np.array([[0, 1, 2]], np.uint32)), (p4, np.array([[0, 1, 2], [0, 2, 3]], np.uint32)),
+             (p4, np.array([[0, 1, 2], [0, 3, 1], [0, 2, 3], [1, 3, 2]], np.uint32)), (pf, fan)]
+    enc = dsa.DracoEncoder(ctx)
+    got = enc.EncodeBatch([dsa.MeshData(p, f) for p, f in cases])
+    for (p, f), g in zip(cases, got):
+        assert g == synth.encode_mesh(p, f, None, None)
+        assert oracle.decode(g).num_faces == len(f)
