@@ -215,10 +215,17 @@ __device__ __forceinline__ EcFace ec_face(const uint4 *frec, uint32_t f) {
 }
 struct EcHop { uint32_t v, rc, lc; };                  // from corner 3f + k: the vertex at it, the corners across its right and left edge
 __device__ __forceinline__ EcHop ec_hop(const EcFace &r, uint32_t k) {
+  uint32_t v0 = r.v0, v1 = r.v1, v2 = r.v2, o0 = r.o0, o1 = r.o1, o2 = r.o2;
+#if defined(__HIPCC__)
+  // The six words are values in registers from here on.  Without this the optimiser turns "one of three fields by k" into a table
+  // in scratch memory -- the record stored and read back through the memory pipeline in front of every step's loads, a dependent
+  // round trip more per step.
+  asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(o0), "+v"(o1), "+v"(o2));
+#endif
   EcHop h;
-  h.v = k == 0 ? r.v0 : (k == 1 ? r.v1 : r.v2);
-  h.rc = k == 0 ? r.o1 : (k == 1 ? r.o2 : r.o0);       // opposite of the next corner
-  h.lc = k == 0 ? r.o2 : (k == 1 ? r.o0 : r.o1);       // opposite of the previous corner
+  h.v = k == 0 ? v0 : (k == 1 ? v1 : v2);
+  h.rc = k == 0 ? o1 : (k == 1 ? o2 : o0);             // opposite of the next corner
+  h.lc = k == 0 ? o2 : (k == 1 ? o0 : o1);             // opposite of the previous corner
   return h;
 }
 enum { EC_MARK = 6, EC_MARK2 = 7, EC_CORNER_MASK = 0x1FFFFFFF, EC_SYMBOL_SHIFT = 29 };    // words of a face record; fields of a `processed` entry

@@ -54,12 +54,17 @@ struct ByteWriter {
 struct BitWriter {   // LSB-first, EncoderBuffer.cs bit mode
   std::vector<uint8_t> d;
   uint64_t nbits = 0;
-  void put(int count, uint32_t v) {
-    for (int i = 0; i < count; ++i) {
-      if ((nbits & 7) == 0) d.push_back(0);
-      if ((v >> i) & 1) d.back() |= (uint8_t)(1u << (nbits & 7));
-      ++nbits;
+  void put(int count, uint32_t v) {       // the low `count` bits of v, least significant first; d always ends in the byte being filled
+    if (count <= 0) return;
+    uint64_t x = count >= 32 ? (uint64_t)v : (uint64_t)(v & ((1u << count) - 1u));
+    const int off = (int)(nbits & 7);
+    if (off) {
+      d.back() |= (uint8_t)(x << off);
+      const int took = 8 - off;
+      if (count <= took) { nbits += (uint64_t)count; return; }
+      x >>= took; count -= took; nbits += (uint64_t)took;
     }
+    while (count > 0) { d.push_back((uint8_t)x); x >>= 8; const int t = count < 8 ? count : 8; nbits += (uint64_t)t; count -= t; }
   }
 };
 
@@ -77,14 +82,20 @@ static void write_rabs(ByteWriter &w, const std::vector<uint8_t> &bits) {
   if (raw < 255) p0 = (uint8_t)raw;
   if (p0 == 0) p0 = 1;
   std::vector<uint8_t> buf;
+  buf.reserve(bits.size() / 8 + 16);
   uint32_t state = 4096;
-  uint32_t p = 256u - p0;
+  const uint32_t p = 256u - p0;            // 1 .. 255, like p0
+  // state / ls by a multiply-high with ceil(2^32 / ls): the quotient or one more (state < 2^32), one correction
+  const uint32_t ls2[2] = {p0, p}, lim2[2] = {16u * 256u * p0, 16u * 256u * p}, add2[2] = {p, 0u};
+  const uint64_t magic2[2] = {0xFFFFFFFFull / p0 + 1ull, 0xFFFFFFFFull / p + 1ull};
   for (size_t k = bits.size(); k-- > 0;) {
-    bool val = bits[k] != 0;
-    uint32_t ls = val ? p : p0;
-    if (state >= 16u * 256u * ls) { buf.push_back(state & 0xFF); state >>= 8; }
-    uint32_t quot = state / ls, rem = state % ls;
-    state = quot * 256 + rem + (val ? 0 : p);
+    const int val = bits[k] != 0;
+    const uint32_t ls = ls2[val];
+    if (state >= lim2[val]) { buf.push_back(state & 0xFF); state >>= 8; }
+    uint32_t quot = (uint32_t)(((uint64_t)state * magic2[val]) >> 32);
+    uint32_t rem = state - quot * ls;
+    if ((int32_t)rem < 0) { --quot; rem += ls; }
+    state = quot * 256 + rem + add2[val];
   }
   uint32_t s = state - 4096;   // AnsEncoder.cs:34-64
   if (s < (1u << 6)) buf.push_back((uint8_t)s);
@@ -1159,7 +1170,9 @@ static void write_stream(ByteWriter &w, const MeshIn &in, const MeshPlan &pl, Va
           bits.push_back(0);
         }
       }
-      for (uint32_t i = 0; i < pl.num_att_data; ++i) write_rabs(w, bits);
+      ByteWriter once;                       // the same block for every attribute: coded once
+      write_rabs(once, bits);
+      for (uint32_t i = 0; i < pl.num_att_data; ++i) w.bytes(once.d);
     }
     if (pl.valence)        // MeshEdgeBreakerTraversalValenceDecoder.cs:43-68: the six context lists, each through the symbol coder
       for (int i = 0; i < 6; ++i) {
