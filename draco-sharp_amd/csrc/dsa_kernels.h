@@ -1300,7 +1300,11 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
             const uint32_t a2 = opp_prev_of(opp_next_of(a1));
             const uint32_t d2 = a2 - a1, ddh = d2 - d1;
             const uint32_t exact = corner_ok(a2) ? 3u : (corner_ok(a1) ? 2u : 1u);
-            a = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : a2 + (lane - 2u) * (d2 + ddh) + ddh * ((lane - 2u) * (lane - 3u) / 2u);
+            // (the triangular number of the lane is made here from an opaque copy: as a loop invariant the compiler kept it in a
+            // register it then had to spill -- a scratch reload and a full vmcnt wait in this path)
+            uint32_t lq = lane;
+            asm volatile("" : "+v"(lq));
+            a = lane == 0 ? a0 : lane == 1 ? a1 : lane == 2 ? a2 : a2 + (lane - 2u) * (d2 + ddh) + ddh * ((lq - 2u) * (lq - 3u) / 2u);
             bool a_ok = lane < window && corner_ok(a) && (lane < exact || exact == 3);
             Raw ra = R::none(), rb = R::none();
             if (a_ok) ra = R::load(frec, a >> 2);
@@ -1528,7 +1532,11 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
             uint32_t any_d = a_d | (s1 ^ s0);
             const bool cont = K == window;           // the run filled its window: nothing stopped it
             const uint32_t l1 = lane + 1u, tri1 = l1 * (l1 + 1u) / 2u;
-            if (cont) { p_a = nxt + lane * a_s + a_d * (lane * (lane - 1u) / 2u); p_an = nxt + l1 * a_s + a_d * (l1 * lane / 2u); }
+            if (cont) {
+              uint32_t lq = lane;                    // (see the dependent attempt: not a loop invariant to keep and spill)
+              asm volatile("" : "+v"(lq));
+              p_a = nxt + lane * a_s + a_d * (lq * (lq - 1u) / 2u); p_an = nxt + l1 * a_s + a_d * ((lq + 1u) * lq / 2u);
+            }
             uint32_t st_b, st_ta, st_tb, st_la, st_rb;
 #define TR_PROG(q_, p_, st_) { const uint32_t x1 = rdlane(q_, K - 1), x2 = rdlane(q_, K - 2), x3 = rdlane(q_, K - 3); \
                                const uint32_t t0 = x1 - x2, qd = t0 - (x2 - x3); any_d |= qd; st_ = t0; if (cont) p_ = x1 + l1 * t0 + qd * tri1; }
