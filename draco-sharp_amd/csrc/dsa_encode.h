@@ -441,7 +441,8 @@ static dsa_status encode_batch(dsa_context *ctx, uint32_t n, const dsa_mesh_inpu
       if (hipSetDevice(ctx->device) != hipSuccess) { int ok = DSA_OK; failed.compare_exchange_strong(ok, DSA_ERR_DEVICE); return; }
       for (;;) {
         const uint32_t c = next.fetch_add(1, std::memory_order_relaxed);
-        if (c >= chunks || failed.load(std::memory_order_relaxed) != DSA_OK) break;
+        if (c >= chunks) break;
+        if (failed.load(std::memory_order_relaxed) != DSA_OK) { upload_turn.finish_a(c, false); break; }     // (a chunk given up is not one the others' uploads wait for)
         const uint32_t base = bounds[c], cnt = bounds[c + 1] - base;
         if (cnt == 0) { upload_turn.finish_a(c, false); continue; }
         ctx->enc_lanes[l]->upload_chunk = c;
