@@ -550,20 +550,23 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, uint
   for (uint32_t i = 0; i < n; ++i) {
     if (E->status[i] != DSA_OK) continue;
     const uint64_t V = meshes[i].num_vertices, F = meshes[i].num_faces;
-    in_total += host_conn ? al(4 * V) + al(12 * V) : al(12 * F);
+    in_total += host_conn ? al(4 * V) + al(12 * V) : al((V <= 65536 ? 6 : 12) * F);      // (faces of a mesh of up to 65 536 vertices travel as 16-bit indices)
     for (auto &a : plans[i].atts) in_total += al(4 * V * (uint64_t)a.nc_out);
   }
   uint64_t cur = in_total, cur_in = 0;
   auto take = [&](uint64_t bytes) { uint64_t at = cur; cur = (cur + bytes + 255) & ~255ull; return at; };
   auto take_in = [&](uint64_t bytes) { uint64_t at = cur_in; cur_in = (cur_in + bytes + 255) & ~255ull; return at; };
-  struct Upload { uint64_t off; const void *src; size_t bytes; };
+  struct Upload { uint64_t off; const void *src; size_t bytes; bool narrow; };       // narrow: src is u32[bytes / 2], the staging copy keeps the low halves
   std::vector<Upload> uploads_a, uploads;          // phase A: what the walks need (the faces); the rest
   std::vector<uint64_t> faces_at(n, 0);
   if (!host_conn)
     for (uint32_t i = 0; i < n; ++i) {
       if (E->status[i] != DSA_OK) continue;
-      faces_at[i] = take_in(12ull * meshes[i].num_faces);
-      uploads_a.push_back({faces_at[i], meshes[i].faces, 12ull * meshes[i].num_faces});
+      // Half of what the walks wait for is the upload of the faces: indices below 65 536 are narrowed to 16 bits by the copy into
+      // pinned staging (which reads them anyway) and widened by the first kernel of the chunk.
+      const bool narrow = meshes[i].num_vertices <= 65536;
+      faces_at[i] = take_in((narrow ? 6ull : 12ull) * meshes[i].num_faces);
+      uploads_a.push_back({faces_at[i], meshes[i].faces, (narrow ? 6ull : 12ull) * meshes[i].num_faces, narrow});
     }
   for (uint32_t i = 0; i < n; ++i) {
     first_stream[i] = (uint32_t)hs.size();
@@ -571,14 +574,14 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, uint
     const uint32_t V = meshes[i].num_vertices;
     const uint64_t o_e2v = host_conn ? take_in(4ull * V) : take(4ull * V), o_ops = host_conn ? take_in(12ull * V) : take(12ull * V);
     if (host_conn) {
-      uploads.push_back({o_e2v, e2v[i].data(), 4ull * V});
-      uploads.push_back({o_ops, ops[i].data(), 12ull * V});
+      uploads.push_back({o_e2v, e2v[i].data(), 4ull * V, false});
+      uploads.push_back({o_ops, ops[i].data(), 12ull * V, false});
     } else {
       const uint32_t F = meshes[i].num_faces;
       dsa::EncConn &C = hc[i];
       memset(&C, 0, sizeof(C));
       C.F = F; C.V = V; C.split_cap = F; C.fail_key = 0xFFFFFFFFu;
-      C.faces = faces_at[i];
+      if (V <= 65536) { C.faces_narrow = 1; C.faces16 = faces_at[i]; C.faces = take(12ull * F); } else C.faces = faces_at[i];
       C.opp = take(12ull * F); C.voff = take(4ull * (V + 1)); C.vcur = take(4ull * V); C.vlist = take(12ull * F); C.vcorner = take(4ull * V);
       C.vvis = take(V); C.frec = take(32ull * F);
       C.stack = take(4ull * F); C.processed = take(4ull * F); C.init_corners = take(4ull * F);
@@ -593,7 +596,7 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, uint
       S.nv = V; S.nc_out = (uint32_t)a.nc_out; S.nc = (uint32_t)a.nc; S.kind = a.seq_type == 3 ? 1u : 0u;
       S.bits = (uint32_t)a.bits; S.prediction = (uint32_t)a.prediction;
       S.src = take_in(4ull * V * S.nc_out);
-      uploads.push_back({S.src, src, 4ull * V * S.nc_out});
+      uploads.push_back({S.src, src, 4ull * V * S.nc_out, false});
       S.e2v = o_e2v; S.ops = o_ops;
       S.vals = take(4ull * V * S.nc); S.d = take(4ull * V * S.nc); S.syms = take(4ull * V * S.nc); S.bl = take(V);
       S.hist_cap = (1u << S.bits) + 2u;                      // zig-zag of a wrapped correction / a positive octahedral correction fits
@@ -670,7 +673,13 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, uint
         hipError_t e = stg.acquire((size_t)(hi - lo));
         if (e != hipSuccess) return e;
         uint8_t *h = stg.buf.p;
-        hostutil::parallel_for((uint32_t)(i1 - i0), [&](uint32_t k) { const Upload &u = ups[i0 + k]; memcpy(h + (u.off - lo), u.src, u.bytes); }, 2);
+        hostutil::parallel_for((uint32_t)(i1 - i0), [&](uint32_t k) {
+          const Upload &u = ups[i0 + k];
+          if (!u.narrow) { memcpy(h + (u.off - lo), u.src, u.bytes); return; }
+          const uint32_t *src = (const uint32_t *)u.src;
+          uint16_t *dst = (uint16_t *)(h + (u.off - lo));               // (offsets are multiples of 256)
+          for (size_t e = 0, ne = u.bytes / 2; e < ne; ++e) dst[e] = (uint16_t)src[e];
+        }, 2);
         e = hipMemcpyAsync(arena + lo, h, (size_t)(hi - lo), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = stg.submitted(st);
         if (e != hipSuccess) return e;

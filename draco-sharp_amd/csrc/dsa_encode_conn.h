@@ -18,6 +18,7 @@ namespace dsa {
 
 struct EncConn {                   // one per mesh; device memory, mirrored on the host
   uint64_t faces;                  // u32[3F] input: vertex of every corner
+  uint64_t faces16;                // u16[3F], when faces_narrow: the same as it was uploaded (every index fits; k_enc_table_clear widens it into `faces`)
   uint64_t opp;                    // u32[3F] opposite corner or INVALID
   uint64_t voff, vcur, vlist;      // u32[V+1], u32[V], u32[3F]: corners by vertex
   uint64_t vcorner;                // u32[V] left-most corner
@@ -30,7 +31,7 @@ struct EncConn {                   // one per mesh; device memory, mirrored on t
   uint64_t splits;                 // u32[3 * split_cap] OUTPUT (source, split, edge)
   uint64_t d2c, v2d;               // u32[V], i32[V]
   uint64_t e2v, ops;               // u32[V], i32[3V] OUTPUT for the attribute kernels
-  uint32_t F, V, split_cap;
+  uint32_t F, V, split_cap, faces_narrow;
   uint32_t fail_key;               // k_enc_table_corners: the least status code that any vertex earned (the host coder's order of checks), or ~0
   uint32_t num_symbols, num_start_bits, num_splits, num_split_symbols, num_processed, num_init, num_entries, interior_edges;   // OUTPUT
   uint32_t status, detail;         // 0 ok; else the host coder's complaint (see enc_conn_message)
@@ -93,6 +94,11 @@ __global__ __launch_bounds__(256) void k_enc_table_clear(uint8_t *arena, EncConn
   int32_t *v2d = (int32_t *)(arena + E->v2d);
   for (uint32_t v = t0; v <= V; v += stride) voff[v] = 0;
   for (uint32_t v = t0; v < V; v += stride) { vvis[v] = 0; v2d[v] = -1; }
+  if (E->faces_narrow) {
+    const uint16_t *narrow = (const uint16_t *)(arena + E->faces16);
+    uint32_t *wide = (uint32_t *)(arena + E->faces);
+    for (uint32_t c = t0; c < NC; c += stride) wide[c] = narrow[c];
+  }
 }
 
 // ---- corners by vertex (counting sort: counts -> offsets -> lists), CornerTable.cs:41-67 needs them implicitly

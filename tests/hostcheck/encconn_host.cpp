@@ -67,6 +67,7 @@ int main(int argc, char **argv) {
     const uint64_t F = meshes[i].nf, V = meshes[i].nv;
     C.F = (uint32_t)F; C.V = (uint32_t)V; C.split_cap = (uint32_t)F; C.fail_key = 0xFFFFFFFFu;
     C.faces = take(12 * F);
+    if (i % 2 == 0 && V <= 65536) { C.faces_narrow = 1; C.faces16 = take(6 * F); }      // every other mesh as the library uploads it: 16-bit indices, widened by the first kernel
     C.opp = take(12 * F); C.voff = take(4 * (V + 1)); C.vcur = take(4 * V); C.vlist = take(12 * F); C.vcorner = take(4 * V);
     C.vvis = take(V); C.frec = take(32 * F);
     C.stack = take(4 * F); C.processed = take(4 * F); C.init_corners = take(4 * F);
@@ -78,7 +79,13 @@ int main(int argc, char **argv) {
   }
   std::vector<uint8_t> arena_store(cur + 256, 0);
   uint8_t *arena = arena_store.data();
-  for (uint32_t i = 0; i < n; ++i) if (meshes[i].nf) memcpy(arena + hc[i].faces, meshes[i].faces.data(), 12ull * meshes[i].nf);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!meshes[i].nf) continue;
+    if (!hc[i].faces_narrow) { memcpy(arena + hc[i].faces, meshes[i].faces.data(), 12ull * meshes[i].nf); continue; }
+    uint16_t *narrow = (uint16_t *)(arena + hc[i].faces16);
+    for (size_t e = 0; e < meshes[i].faces.size(); ++e) narrow[e] = (uint16_t)meshes[i].faces[e];
+    if (hc[i].status != dsa::ENC_OK) memcpy(arena + hc[i].faces, meshes[i].faces.data(), 12ull * meshes[i].nf);      // (never widened: never read either)
+  }
   ASAN_POISON_MEMORY_REGION(arena, arena_store.size());
   for (auto &rg : regions) ASAN_UNPOISON_MEMORY_REGION(arena + rg.first, rg.second);
   uint32_t maxf = 1;

@@ -264,3 +264,19 @@ def test_one_triangle_and_other_tiny_meshes_on_the_device_path(ctx, monkeypatch)
     for (p, f), g in zip(cases, got):
         assert g == synth.encode_mesh(p, f, None, None)
         assert oracle.decode(g).num_faces == len(f)
+
+
+def test_more_than_65536_vertices_keep_32_bit_faces(ctx, monkeypatch):
+    """Faces travel as 16-bit indices when a mesh has at most 65 536 vertices; a larger one keeps its 32-bit indices, both in
+    one chunk."""
+    monkeypatch.setenv("DSA_ENC_HOST_CONN", "0")
+    monkeypatch.setenv("DSA_ENC_HOST_PLAN", "0")
+    big = synth.make_mesh(synth.GRID, 300, 250, 5)            # 75 551 vertices
+    edge = synth.make_mesh(synth.GRID, 255, 255, 6)           # 65 536 vertices exactly
+    small = synth.make_mesh(synth.TORUS, 20, 12, 7)
+    cases = [big, small, edge, small]
+    assert len(big[0]) > 65536 and len(edge[0]) == 65536
+    enc = dsa.DracoEncoder(ctx)
+    got = enc.EncodeBatch([dsa.MeshData(p, f, n, u) for p, n, u, f in cases])
+    for (p, n, u, f), g in zip(cases, got):
+        assert g == synth.encode_mesh(p, f, n, u)
