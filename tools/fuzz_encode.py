@@ -1,4 +1,4 @@
-"""Damaged meshes (flipped, rewired, duplicated faces; random face soups) through dsa_encode_batch with the connectivity on the
+"""Damaged meshes (flipped, rewired, duplicated, missing faces; random face soups) through dsa_encode_batch with the connectivity on the
 device and on the host: the same meshes must be coded (to the same bytes) and the same refused.  usage: python tools/fuzz_encode.py [count]"""
 import os, sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -8,7 +8,14 @@ rng = np.random.default_rng(11)
 ctx = dsa.Context(0); enc = dsa.DracoEncoder(ctx)
 meshes = []
 for it in range(count):
-    mode = it % 4
+    mode = it % 6
+    if mode >= 4:                 # faces taken away: new holes, new components, now and then a vertex that is no longer manifold
+        p, n, u, f = synth.make_mesh(int(rng.choice([synth.GRID, synth.TORUS, synth.SPHERE, synth.HOLES, synth.TWO_PARTS])), int(rng.integers(4, 24)), int(rng.integers(4, 24)), int(rng.integers(0, 1 << 30)))
+        keep = np.ones(len(f), bool); keep[rng.integers(0, len(f), int(rng.integers(1, 12)))] = False
+        faces = f[keep]; used = np.unique(faces)
+        remap = np.zeros(len(p), np.int64); remap[used] = np.arange(len(used))
+        meshes.append(dsa.MeshData(p[used], np.ascontiguousarray(remap[faces], dtype=np.uint32)))
+        continue
     if mode == 0:
         nv = int(rng.integers(4, 40)); faces = rng.integers(0, nv, (int(rng.integers(1, 80)), 3)).astype(np.uint32)
     else:
