@@ -1224,7 +1224,8 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
       uint32_t kr_v = 0, kr_rc = 0, kr_lc = 0, kl_v = 0, kl_rc = 0, kl_lc = 0;
       // per-lane state of an attempt (pair `lane`: N element at a, face A; L element at b = Opposite(Next(a)), face B)
       uint32_t kind = 0;                 // 0 none, 1 fast attempt at the carried progressions, 2 fast attempt from the step history, 3 dependent attempt
-      bool lin = false;
+      bool lin = false;      // (read by the DSA_TRAV_TRACE build only)
+      (void)lin;
       uint32_t a = 0, b = 0, tipA = 0, lcA = DSA_INVALID, tipB = 0, rcB = DSA_INVALID, lcB = DSA_INVALID;
       // marks before the step, packed: bit 0 face A visited, 1 face B, 2 the face right of b, 3 the face left of b, 4 the face left of a;
       // bits 8-9 flags of a's tip, 16-17 flags of b's tip
