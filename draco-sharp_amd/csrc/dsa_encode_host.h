@@ -293,12 +293,78 @@ struct CornerTable {
   }
 };
 
+// The connectivity of one attribute with seams (MeshAttributeCornerTable.cs, encoder side): the position corner
+// table with every seam edge cut.  Built from a value id per corner (:32-78: an interior edge is a seam when either of
+// its end points carries different value ids on its two faces); vertices are the fans between cuts (:95-155).  Same
+// interface as CornerTable, so that the traversal and the prediction schemes are templates over either.
+struct AttrConn {
+  const CornerTable *ct = nullptr;
+  std::vector<uint8_t> edge_seam, vert_seam;
+  std::vector<uint32_t> c2v, v2lm;
+  bool no_interior_seams = true;
+  uint32_t nf() const { return ct->nf(); }
+  uint32_t nc() const { return ct->nc(); }
+  uint32_t nv() const { return (uint32_t)v2lm.size(); }
+  static uint32_t next(uint32_t c) { return CornerTable::next(c); }
+  static uint32_t prev(uint32_t c) { return CornerTable::prev(c); }
+  uint32_t opposite(uint32_t c) const { return (c == kInvalid || edge_seam[c]) ? kInvalid : ct->opposite(c); }
+  uint32_t vertex(uint32_t c) const { return c == kInvalid ? kInvalid : c2v[c]; }
+  uint32_t swing_right(uint32_t c) const { return prev(opposite(prev(c))); }
+  uint32_t swing_left(uint32_t c) const { return next(opposite(next(c))); }
+  uint32_t right_corner(uint32_t c) const { return opposite(next(c)); }
+  uint32_t left_corner(uint32_t c) const { return opposite(prev(c)); }
+  bool on_boundary(uint32_t v) const { return swing_left(v2lm[v]) == kInvalid; }
+  void mark(uint32_t c) {
+    edge_seam[c] = 1;
+    vert_seam[ct->vertex(next(c))] = 1;
+    vert_seam[ct->vertex(prev(c))] = 1;
+  }
+  void build(const CornerTable &t, const uint32_t *corner_value) {
+    ct = &t;
+    edge_seam.assign(t.nc(), 0);
+    vert_seam.assign(t.nv(), 0);
+    c2v.assign(t.nc(), kInvalid);
+    no_interior_seams = true;
+    for (uint32_t c = 0; c < t.nc(); ++c) {
+      const uint32_t o = t.opposite(c);
+      if (o == kInvalid) { mark(c); continue; }
+      if (o < c) continue;
+      // the edge's end points: next(c) lies on prev(o), prev(c) on next(o)
+      if (corner_value[next(c)] != corner_value[prev(o)] || corner_value[prev(c)] != corner_value[next(o)]) {
+        no_interior_seams = false;
+        mark(c); mark(o);
+      }
+    }
+    // :95-155 vertices: around every position vertex a new one behind every cut
+    v2lm.clear();
+    for (uint32_t v = 0; v < t.nv(); ++v) {
+      uint32_t first_c = t.vcorner[v];
+      if (first_c == kInvalid) continue;
+      if (vert_seam[v]) {
+        uint32_t act = swing_left(first_c);
+        size_t guard = 0;
+        while (act != kInvalid) { first_c = act; act = swing_left(act); check(++guard <= t.nc(), "attribute seam loop"); }
+      }
+      uint32_t id = (uint32_t)v2lm.size();
+      c2v[first_c] = id;
+      v2lm.push_back(first_c);
+      uint32_t act = t.swing_right(first_c);
+      while (act != kInvalid && act != first_c) {
+        if (edge_seam[next(act)]) { id = (uint32_t)v2lm.size(); v2lm.push_back(act); }
+        c2v[act] = id;
+        act = t.swing_right(act);
+      }
+    }
+  }
+};
+
 // DFS traversal shared by attribute sequencing (Traverser/DepthFirstTraverser.cs:9-99)
 struct Sequence {
   std::vector<uint32_t> data_to_corner;   // entry -> corner (source corner table)
   std::vector<int32_t> vertex_to_data;
 };
-static void dfs_sequence(const CornerTable &ct, const std::vector<uint32_t> &corner_order, Sequence &seq) {
+template <class CT>
+static void dfs_sequence(const CT &ct, const std::vector<uint32_t> &corner_order, Sequence &seq) {
   std::vector<uint8_t> fvis(ct.nf(), 0), vvis(ct.nv(), 0);
   seq.vertex_to_data.assign(ct.nv(), -1);
   seq.data_to_corner.clear();
@@ -309,9 +375,9 @@ static void dfs_sequence(const CornerTable &ct, const std::vector<uint32_t> &cor
     if (fdone(start / 3)) continue;
     stack.clear();
     stack.push_back(start);
-    uint32_t nv = ct.vertex(CornerTable::next(start)), pv = ct.vertex(CornerTable::prev(start));
-    if (!vvis[nv]) visit(nv, CornerTable::next(start));
-    if (!vvis[pv]) visit(pv, CornerTable::prev(start));
+    uint32_t nv = ct.vertex(CT::next(start)), pv = ct.vertex(CT::prev(start));
+    if (!vvis[nv]) visit(nv, CT::next(start));
+    if (!vvis[pv]) visit(pv, CT::prev(start));
     while (!stack.empty()) {
       uint32_t corner = stack.back();
       uint32_t face = corner == kInvalid ? kInvalid : corner / 3;
@@ -692,7 +758,8 @@ struct PortableAttr {
   int att_type, nc_out, nc;            // nc = portable components
   int seq_type;                        // 1 integer, 2 quantisation, 3 normals
   int data_type;
-  std::vector<int32_t> vals;           // per vertex, AoS
+  std::vector<int32_t> vals;           // per value id, AoS (value id = vertex unless corner_value is set)
+  const uint32_t *corner_value = nullptr;   // value id per corner of the source mesh (attributes given per corner: seams)
   std::vector<float> qmin; float qrange = 1; int bits = 0;
   int prediction = 1;
 };
@@ -763,6 +830,11 @@ static void oct_canon_corr(const Octa &o, const int32_t orig_in[2], const int32_
 struct MeshIn {
   const float *pos; uint32_t nv; const uint32_t *faces; uint32_t nf;
   const float *normals; const float *uvs; const uint8_t *generic;
+  // Attributes given per corner (the CPU coder only): value ids per corner of `faces` (3 * nf) into `normals` (nn rows) /
+  // `uvs` (nu rows); an interior edge whose end points carry different ids on its two faces is an attribute seam
+  // (MeshAttributeCornerTable.cs:32-78).  Null: one value per vertex.
+  const uint32_t *normal_corners = nullptr; uint32_t nn = 0;
+  const uint32_t *uv_corners = nullptr; uint32_t nu = 0;
 };
 
 // One attribute's value section: method, transform, compressed flag, symbols, prediction data
@@ -770,8 +842,9 @@ struct MeshIn {
 // Area-weighted normal of the faces around a corner's vertex from the quantised positions, canonicalised to the
 // octahedron (MeshPredictionSchemeGeometricNormalPredictorArea.cs:16-63 + OctahedronToolBox.cs:121-137, with the
 // bitstream's 64-bit arithmetic).  Per-vertex attributes only: a data id's position is its vertex's.
-static void geometric_normal_prediction(const Octa &o, const CornerTable &ct, const std::vector<int32_t> &pos, uint32_t ci, int32_t v3[3]) {
-  auto P = [&](uint32_t c, int k) { return (int64_t)pos[(size_t)ct.vertex(c) * 3 + k]; };
+template <class CT>
+static void geometric_normal_prediction(const Octa &o, const CT &ct, const CornerTable &pos_ct, const std::vector<int32_t> &pos, uint32_t ci, int32_t v3[3]) {
+  auto P = [&](uint32_t c, int k) { return (int64_t)pos[(size_t)pos_ct.vertex(c) * 3 + k]; };
   uint64_t n[3] = {0, 0, 0};
   uint32_t c = ci;
   bool left = true;
@@ -818,7 +891,8 @@ static void oct_plain_corr(const Octa &o, const int32_t orig_in[2], const int32_
   out[1] = o.make_positive(ot - pt);
 }
 
-static void write_attribute_values(ByteWriter &w, const PortableAttr &a, const CornerTable &ct, const Sequence &seq, const Options &opt,
+template <class CT>
+static void write_attribute_values(ByteWriter &w, const PortableAttr &a, const CT &ct, const CornerTable &pos_ct, const Sequence &seq, const Options &opt,
                                    const PortableAttr *positions = nullptr) {
   int nc = a.nc;
   size_t entries = seq.data_to_corner.size();
@@ -837,7 +911,8 @@ static void write_attribute_values(ByteWriter &w, const PortableAttr &a, const C
   // values in entry order
   std::vector<int32_t> d(entries * nc);
   for (size_t e = 0; e < entries; ++e) {
-    uint32_t v = ct.vertex(seq.data_to_corner[e]);
+    const uint32_t corner = seq.data_to_corner[e];
+    const uint32_t v = a.corner_value ? a.corner_value[corner] : pos_ct.vertex(corner);
     for (int c = 0; c < nc; ++c) d[e * nc + c] = a.vals[(size_t)v * nc + c];
   }
   std::vector<uint32_t> symbols(entries * nc);
@@ -861,7 +936,7 @@ static void write_attribute_values(ByteWriter &w, const PortableAttr &a, const C
     auto mod_max = [&](int x) { return x > o.center ? x - o.max_q : (x < -o.center ? x + o.max_q : x); };
     for (size_t e = 0; e < entries; ++e) {
       int32_t v3[3];
-      geometric_normal_prediction(o, ct, positions->vals, seq.data_to_corner[e], v3);
+      geometric_normal_prediction(o, ct, pos_ct, positions->vals, seq.data_to_corner[e], v3);
       int32_t pp[2], pn[2], cp[2], cn[2];
       int s, t;
       o.from_int_vector(v3, s, t); pp[0] = s; pp[1] = t;
@@ -915,7 +990,7 @@ static void write_attribute_values(ByteWriter &w, const PortableAttr &a, const C
       do { root = (root + number / root) / 2; } while (root * root > number);
       return root;
     };
-    auto P = [&](int32_t entry, int k) { return (int64_t)positions->vals[(size_t)ct.vertex(seq.data_to_corner[entry]) * 3 + k]; };
+    auto P = [&](int32_t entry, int k) { return (int64_t)positions->vals[(size_t)pos_ct.vertex(seq.data_to_corner[entry]) * 3 + k]; };
     for (size_t p = entries; p-- > 0;) {
       const int32_t data_id = (int32_t)p;
       const uint32_t ci = seq.data_to_corner[p];
@@ -1086,8 +1161,14 @@ struct MeshPlan {
   std::vector<uint32_t> ctx_symbols[6];
   bool predictive = false;           // predictive Edgebreaker traversal: explicit symbols + prediction bits below
   std::vector<uint8_t> explicit_symbols, predictions;   // encoder order
-  bool uses_pd(size_t att) const { return traversal_method == 2 || (traversal_method == 1 && (single || att == 0)); }
-  const Sequence &seq_of(size_t att) const { return uses_pd(att) ? seq_pd : seq; }
+  // Attributes given per corner: conns[att] is the attribute's own connectivity, seq_att[att] its depth-first order
+  // (corner attributes are always sequenced depth first: MeshEdgeBreakerEncoder.cs:556-564); both empty for meshes
+  // whose attributes are all per vertex.
+  std::vector<AttrConn> conns;
+  std::vector<Sequence> seq_att;
+  bool seamed(size_t att) const { return att < conns.size() && conns[att].ct && !conns[att].no_interior_seams; }
+  bool uses_pd(size_t att) const { return !seamed(att) && (traversal_method == 2 || (traversal_method == 1 && (single || att == 0))); }
+  const Sequence &seq_of(size_t att) const { return seamed(att) ? seq_att[att] : (uses_pd(att) ? seq_pd : seq); }
   std::vector<PortableAttr> atts;    // descriptors; vals / quantisation parameters are filled by whoever codes the values
   bool single = false;
   uint32_t num_att_data = 0;
@@ -1097,8 +1178,8 @@ struct MeshPlan {
 static void plan_attributes(const MeshIn &in, const Options &opt, MeshPlan &pl) {
   pl.atts.clear();
   { PortableAttr a; a.att_type = 0; a.nc = a.nc_out = 3; a.seq_type = 2; a.data_type = 9; a.prediction = opt.pos_prediction; a.bits = opt.pos_bits; pl.atts.push_back(a); }
-  if (in.normals) { PortableAttr a; a.att_type = 1; a.nc_out = 3; a.nc = 2; a.seq_type = 3; a.data_type = 9; a.bits = opt.normal_bits; a.prediction = opt.normal_prediction == 6 ? 6 : 0; pl.atts.push_back(a); }
-  if (in.uvs) { PortableAttr a; a.att_type = 3; a.nc = a.nc_out = 2; a.seq_type = 2; a.data_type = 9; a.prediction = opt.uv_prediction; a.bits = opt.uv_bits; pl.atts.push_back(a); }
+  if (in.normals) { PortableAttr a; a.att_type = 1; a.nc_out = 3; a.nc = 2; a.seq_type = 3; a.data_type = 9; a.bits = opt.normal_bits; a.prediction = opt.normal_prediction == 6 ? 6 : 0; a.corner_value = in.normal_corners; pl.atts.push_back(a); }
+  if (in.uvs) { PortableAttr a; a.att_type = 3; a.nc = a.nc_out = 2; a.seq_type = 2; a.data_type = 9; a.prediction = opt.uv_prediction; a.bits = opt.uv_bits; a.corner_value = in.uv_corners; pl.atts.push_back(a); }
   if (in.generic) { PortableAttr a; a.att_type = 4; a.nc = a.nc_out = 1; a.seq_type = 1; a.data_type = 2; a.prediction = 1; pl.atts.push_back(a); }
   pl.single = opt.single_connectivity != 0;
   pl.num_att_data = pl.single ? 0 : (uint32_t)pl.atts.size() - 1;
@@ -1120,6 +1201,22 @@ static void plan_mesh(const MeshIn &in, const Options &opt, MeshPlan &pl) {
   if (pl.traversal_method != 0) {
     prediction_degree_sequence(pl.ct, pl.eb.processed_corners, pl.seq_pd);
     check(pl.seq_pd.data_to_corner.size() == in.nv, "traversal did not reach every vertex");
+  }
+  // attributes given per corner: their seams, their own vertices and traversal order (MeshEdgeBreakerEncoder.cs:403-414,
+  // :545-566: the sequencer of a seamed attribute walks the attribute's corner table in the connectivity's face order)
+  bool per_corner = false;
+  for (auto &a : pl.atts) per_corner = per_corner || a.corner_value != nullptr;
+  if (per_corner) {
+    check(!pl.single, "attributes given per corner need a connectivity of their own (single_connectivity = 0)");
+    pl.conns.assign(pl.atts.size(), AttrConn());
+    pl.seq_att.assign(pl.atts.size(), Sequence());
+    for (size_t i = 1; i < pl.atts.size(); ++i) {
+      if (!pl.atts[i].corner_value) continue;
+      pl.conns[i].build(pl.ct, pl.atts[i].corner_value);
+      if (pl.conns[i].no_interior_seams) continue;
+      dfs_sequence(pl.conns[i], pl.eb.processed_corners, pl.seq_att[i]);
+      check(pl.seq_att[i].data_to_corner.size() == pl.conns[i].nv(), "attribute traversal did not reach every attribute vertex");
+    }
   }
 }
 
@@ -1157,7 +1254,24 @@ static void write_stream(ByteWriter &w, const MeshIn &in, const MeshPlan &pl, Va
       w.bytes(bw.d);
     }
     write_rabs(w, eb.start_face_bits);
-    if (pl.num_att_data) {
+    bool any_seams = false;
+    for (size_t i = 1; i < pl.atts.size(); ++i) any_seams = any_seams || pl.seamed(i);
+    if (pl.num_att_data && any_seams) {
+      // MeshEdgeBreakerEncoder.cs:418-440: in decoder face order, for every interior edge whose other face comes later,
+      // one bit per attribute -- is the edge a seam of that attribute; a block per attribute (MeshEdgeBreakerTraversalEncoder.cs:62-70)
+      std::vector<uint8_t> vis(ct.nf(), 0);
+      std::vector<std::vector<uint8_t>> bits(pl.num_att_data);
+      for (uint32_t c : eb.processed_corners) {
+        const uint32_t corners[3] = {c, CornerTable::next(c), CornerTable::prev(c)};
+        vis[c / 3] = 1;
+        for (int k = 0; k < 3; ++k) {
+          const uint32_t o = ct.opposite(corners[k]);
+          if (o == kInvalid || vis[o / 3]) continue;
+          for (uint32_t i = 0; i < pl.num_att_data; ++i) bits[i].push_back(pl.seamed(i + 1) ? pl.conns[i + 1].edge_seam[corners[k]] : 0);
+        }
+      }
+      for (uint32_t i = 0; i < pl.num_att_data; ++i) write_rabs(w, bits[i]);
+    } else if (pl.num_att_data) {
       // per-vertex attributes: no interior seams, one 0 bit per interior edge in decoder face order
       std::vector<uint8_t> vis(pl.interior_edges >= 0 ? 0 : ct.nf(), 0), bits;
       if (pl.interior_edges >= 0) bits.assign((size_t)pl.interior_edges, 0);
@@ -1189,7 +1303,8 @@ static void write_stream(ByteWriter &w, const MeshIn &in, const MeshPlan &pl, Va
   const std::vector<PortableAttr> &atts = pl.atts;
   uint32_t num_encoders = pl.single ? 1 : (uint32_t)atts.size();
   w.u8((uint8_t)num_encoders);
-  for (uint32_t i = 0; i < num_encoders; ++i) { w.i8(i == 0 ? -1 : (int8_t)(i - 1)); w.u8(0); w.u8(pl.uses_pd(i) ? 1 : 0); }   // MeshTraversalMethod
+  // attribute data id, element type (1: corner attribute -- the attribute's own connectivity is used, :442-466), MeshTraversalMethod
+  for (uint32_t i = 0; i < num_encoders; ++i) { w.i8(i == 0 ? -1 : (int8_t)(i - 1)); w.u8(pl.seamed(i) ? 1 : 0); w.u8(pl.uses_pd(i) ? 1 : 0); }
   auto write_desc = [&](const PortableAttr &a, uint32_t uid) { w.u8((uint8_t)a.att_type); w.u8((uint8_t)a.data_type); w.u8((uint8_t)a.nc_out); w.u8(0); w.varint(uid); };
   if (pl.single) {
     w.varint(atts.size());
@@ -1210,15 +1325,19 @@ static void encode_mesh(const MeshIn &in, const Options &opt, std::vector<uint8_
   for (auto &a : pl.atts) {
     if (a.att_type == 0) quantize(in.pos, in.nv, 3, opt.pos_bits, a);
     else if (a.att_type == 1) {
+      const uint32_t n = in.normal_corners ? in.nn : in.nv;
       Octa o(opt.normal_bits);
-      a.vals.resize((size_t)in.nv * 2);
-      for (uint32_t v = 0; v < in.nv; ++v) { int s, t; o.from_float_vector(in.normals + (size_t)v * 3, s, t); a.vals[(size_t)v * 2] = s; a.vals[(size_t)v * 2 + 1] = t; }
-    } else if (a.att_type == 3) quantize(in.uvs, in.nv, 2, opt.uv_bits, a);
+      a.vals.resize((size_t)n * 2);
+      for (uint32_t v = 0; v < n; ++v) { int s, t; o.from_float_vector(in.normals + (size_t)v * 3, s, t); a.vals[(size_t)v * 2] = s; a.vals[(size_t)v * 2 + 1] = t; }
+    } else if (a.att_type == 3) quantize(in.uvs, in.uv_corners ? in.nu : in.nv, 2, opt.uv_bits, a);
     else { a.vals.resize(in.nv); for (uint32_t v = 0; v < in.nv; ++v) a.vals[v] = in.generic[v]; }
   }
   ByteWriter w;
   write_stream(w, in, pl,
-               [&](ByteWriter &bw, size_t i) { write_attribute_values(bw, pl.atts[i], pl.ct, pl.seq_of(i), opt, &pl.atts[0]); },
+               [&](ByteWriter &bw, size_t i) {
+                 if (pl.seamed(i)) write_attribute_values(bw, pl.atts[i], pl.conns[i], pl.ct, pl.seq_of(i), opt, &pl.atts[0]);
+                 else write_attribute_values(bw, pl.atts[i], pl.ct, pl.ct, pl.seq_of(i), opt, &pl.atts[0]);
+               },
                [&](ByteWriter &bw, size_t i) { write_attribute_transform(bw, pl.atts[i]); });
   out.swap(w.d);
 }
@@ -1273,7 +1392,7 @@ static void encode_mesh_sequential(const MeshIn &in, const Options &opt, bool co
   w.varint(atts.size());
   for (size_t i = 0; i < atts.size(); ++i) { w.u8((uint8_t)atts[i].att_type); w.u8((uint8_t)atts[i].data_type); w.u8((uint8_t)atts[i].nc_out); w.u8(0); w.varint(i); }
   for (auto &a : atts) w.u8((uint8_t)a.seq_type);
-  for (auto &a : atts) write_attribute_values(w, a, ct, seq, opt);
+  for (auto &a : atts) write_attribute_values(w, a, ct, ct, seq, opt);
   for (auto &a : atts) write_attribute_transform(w, a);
   out.swap(w.d);
 }

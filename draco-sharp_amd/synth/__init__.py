@@ -41,6 +41,9 @@ def lib():
         L.synth_default_options.argtypes = [C.POINTER(Options)]
         L.synth_encode_mesh.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.POINTER(Options), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.synth_encode_mesh_corners.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Options), C.POINTER(C.c_void_p),
+                                                C.POINTER(C.c_size_t)]
         L.synth_encode_point_cloud.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Options), C.POINTER(C.c_void_p),
                                                C.POINTER(C.c_size_t)]
         L.synth_encode_mesh_sequential.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,
@@ -98,6 +101,36 @@ def encode_mesh(pos, faces, normals=None, uvs=None, generic=None, opt=None):
     rc = L.synth_encode_mesh(pos.ctypes.data, len(pos), faces.ctypes.data, len(faces),
                              None if nrm is None else nrm.ctypes.data, None if uv is None else uv.ctypes.data,
                              None if gen is None else gen.ctypes.data, C.byref(opt), C.byref(out), C.byref(n))
+    if rc:
+        raise RuntimeError(_err())
+    data = C.string_at(out, n.value)
+    L.synth_free(out)
+    return data
+
+
+def encode_mesh_corners(pos, faces, normals=None, normal_corners=None, uvs=None, uv_corners=None, opt=None):
+    """Mesh whose normals / texture coordinates are given per corner: `faces` [F,3] index `pos`, `normal_corners` /
+    `uv_corners` [F,3] index the rows of `normals` / `uvs` (None: that attribute has one row per vertex).  Edges across
+    which the ids differ become attribute seams in the stream (seam bits, attribute corner table, corner attribute)."""
+    L = lib()
+    pos = np.ascontiguousarray(pos, np.float32)
+    faces = np.ascontiguousarray(faces, np.uint32)
+    nrm = None if normals is None else np.ascontiguousarray(normals, np.float32)
+    uv = None if uvs is None else np.ascontiguousarray(uvs, np.float32)
+    nci = None if normal_corners is None else np.ascontiguousarray(normal_corners, np.uint32)
+    uci = None if uv_corners is None else np.ascontiguousarray(uv_corners, np.uint32)
+    for ids, vals, name in ((nci, nrm, "normal"), (uci, uv, "uv")):
+        if ids is not None and (vals is None or ids.shape != faces.shape):
+            raise ValueError("%s_corners needs %ss and one id per corner of `faces`" % (name, name))
+        if ids is None and vals is not None and len(vals) != len(pos):
+            raise ValueError("per-vertex %ss need one row per vertex" % name)
+    out, n = C.c_void_p(), C.c_size_t()
+    opt = opt or options()
+    rc = L.synth_encode_mesh_corners(pos.ctypes.data, len(pos), faces.ctypes.data, len(faces),
+                                     None if nrm is None else nrm.ctypes.data, 0 if nrm is None else len(nrm),
+                                     None if nci is None else nci.ctypes.data,
+                                     None if uv is None else uv.ctypes.data, 0 if uv is None else len(uv),
+                                     None if uci is None else uci.ctypes.data, C.byref(opt), C.byref(out), C.byref(n))
     if rc:
         raise RuntimeError(_err())
     data = C.string_at(out, n.value)

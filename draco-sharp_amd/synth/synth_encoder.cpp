@@ -156,6 +156,28 @@ int synth_encode_mesh(const float *pos, uint32_t nv, const uint32_t *faces, uint
     return 0;
   } catch (const std::exception &e) { snprintf(g_err, sizeof(g_err), "%s", e.what()); return 1; }
 }
+// Attributes given per corner: value ids per corner of `faces` (3 * nf) into `normals` (nn rows) / `uvs` (nu rows); either
+// id list may be NULL (that attribute is then per vertex, nv rows).  Interior edges whose end points carry different ids
+// on their two faces become attribute seams: seam bits, attribute corner tables and corner attributes in the stream
+// (MeshEdgeBreakerEncoder.cs:403-440, MeshAttributeCornerTable.cs:32-155).
+int synth_encode_mesh_corners(const float *pos, uint32_t nv, const uint32_t *faces, uint32_t nf, const float *normals, uint32_t nn,
+                              const uint32_t *normal_corners, const float *uvs, uint32_t nu, const uint32_t *uv_corners,
+                              const synth_options *opt, uint8_t **out, size_t *out_len) {
+  try {
+    synth::MeshIn in{pos, nv, faces, nf, normals, uvs, nullptr, normals ? normal_corners : nullptr, nn, uvs ? uv_corners : nullptr, nu};
+    for (size_t k = 0; k < (size_t)nf * 3; ++k) {
+      synth::check(faces[k] < nv, "face index out of range");
+      synth::check(!in.normal_corners || in.normal_corners[k] < nn, "normal id out of range");
+      synth::check(!in.uv_corners || in.uv_corners[k] < nu, "texture coordinate id out of range");
+    }
+    std::vector<uint8_t> buf;
+    synth::encode_mesh(in, to_opt(opt), buf);
+    *out = (uint8_t *)malloc(buf.size());
+    memcpy(*out, buf.data(), buf.size());
+    *out_len = buf.size();
+    return 0;
+  } catch (const std::exception &e) { snprintf(g_err, sizeof(g_err), "%s", e.what()); return 1; }
+}
 int synth_encode_mesh_sequential(const float *pos, uint32_t nv, const uint32_t *faces, uint32_t nf, const float *normals,
                                  const float *uvs, int compressed, const synth_options *opt, uint8_t **out, size_t *out_len) {
   try {

@@ -168,3 +168,73 @@ def raw_point_cloud_stream(num_points, attributes, seed=0):
         values.append(v)
         out += v.tobytes()
     return bytes(out), values
+
+
+# ---------------------------------------------------------------- attribute seams
+def chart_of_faces(pos, faces, how, seed=0):
+    """A chart id per face, from the face centroids in the bounding box of the mesh: the edges between charts become
+    attribute seams.  how: 'stripes' (seams from boundary to boundary / closed loops on closed meshes), 'island' (one
+    closed seam loop in the interior), 'checker' (seams crossing each other), 'random' (almost every edge a seam),
+    'single' (one lone face cut out), 'none' (one chart: ids per corner but no seam)."""
+    pos = np.asarray(pos, np.float64)
+    c = pos[np.asarray(faces, np.int64)].mean(axis=1)
+    lo, hi = pos.min(axis=0), pos.max(axis=0)
+    u = (c - lo) / np.where(hi > lo, hi - lo, 1.0)
+    if how == "stripes":
+        return np.minimum((u[:, 0] * 3).astype(np.int64), 2)
+    if how == "island":
+        return (((u[:, 0] - 0.5) ** 2 + (u[:, 1] - 0.5) ** 2) < 0.07).astype(np.int64)
+    if how == "checker":
+        return (np.minimum((u[:, 0] * 4).astype(np.int64), 3) + np.minimum((u[:, 1] * 3).astype(np.int64), 2)) % 2 + \
+            2 * (u[:, 2] > 0.5)
+    if how == "random":
+        return np.random.default_rng(seed).integers(0, 3, len(faces))
+    if how == "single":
+        r = np.zeros(len(faces), np.int64)
+        r[len(faces) // 2] = 1
+        return r
+    if how == "none":
+        return np.zeros(len(faces), np.int64)
+    raise ValueError(how)
+
+
+def split_by_chart(faces, values, chart, shift):
+    """Per-corner value ids for an attribute that is continuous inside a chart and jumps between charts: one value row
+    per (vertex, chart) pair in use, the vertex's value moved by chart * shift.  Returns (ids[F,3] uint32, rows float32)."""
+    faces = np.asarray(faces, np.int64)
+    chart = np.asarray(chart, np.int64)
+    n = int(chart.max()) + 1
+    key = faces * n + chart[:, None]
+    uniq, inv = np.unique(key.ravel(), return_inverse=True)
+    rows = np.asarray(values, np.float32)[uniq // n] + (uniq % n)[:, None].astype(np.float32) * np.asarray(shift, np.float32)[None, :]
+    return inv.reshape(faces.shape).astype(np.uint32), rows.astype(np.float32)
+
+
+def source_corner_faces_seamed(pos, faces, normals, normal_ids, uvs, uv_ids, pos_bits=11, normal_bits=8, uv_bits=10):
+    """source_corner_faces for attributes given per corner (ids None: per vertex): the key of a corner is (quantised
+    position of its vertex, octahedral normal of its normal row, quantised texture coordinate of its uv row)."""
+    faces = np.asarray(faces, np.int64)
+    pmin, prange, qp = source_quantization(pos, pos_bits)
+    cols = [qp[faces.ravel()]]
+    if normals is not None:
+        qn = oct_quantize(normals, normal_bits)
+        cols.append(qn[(faces if normal_ids is None else np.asarray(normal_ids, np.int64)).ravel()])
+    umin = urange = None
+    if uvs is not None:
+        umin, urange, qu = source_quantization(uvs, uv_bits)
+        cols.append(qu[(faces if uv_ids is None else np.asarray(uv_ids, np.int64)).ravel()])
+    keys = np.concatenate(cols, axis=1)
+    return face_multiset_fast(np.arange(len(keys)).reshape(-1, 3), keys), (pmin, prange, umin, urange)
+
+
+def seamed_mesh(synth, kind, nx, ny, seed, normal_charts=None, uv_charts="stripes"):
+    """A synthetic mesh with its normals and / or texture coordinates given per corner (chart_of_faces patterns; None:
+    that attribute stays per vertex).  Returns the arguments of synth.encode_mesh_corners:
+    (pos, faces, normal rows, normal ids or None, uv rows, uv ids or None)."""
+    pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, seed)
+    nid = uid = None
+    if normal_charts:
+        nid, nrm = split_by_chart(faces, nrm, chart_of_faces(pos, faces, normal_charts, seed + 1), [0.3, -0.2, 0.1])
+    if uv_charts:
+        uid, uv = split_by_chart(faces, uv, chart_of_faces(pos, faces, uv_charts, seed + 2), [1.25, 0.5])
+    return pos, faces, nrm, nid, uv, uid

@@ -262,8 +262,12 @@ def test_corrupt_streams_agree_with_the_oracle(ctx, house04_bytes):
     # tagged symbol streams of a mesh large enough for k_tags (the tag stream on a wave of its own, the walk resumed behind it)
     bpos, bnrm, buv, bfaces = synth.make_mesh(synth.GRID, 128, 128, 4)
     big_tagged = synth.encode_mesh(bpos, bfaces, bnrm, buv, opt=synth.options(force_scheme=0))
+    # attribute seams on a torus: two seamed attributes with different seams (seam bits, attribute corner tables, corner attributes)
+    from meshutil import seamed_mesh
+    seamed = synth.encode_mesh_corners(*seamed_mesh(synth, synth.TORUS, 10, 8, 3, "checker", "stripes"), opt=synth.options(uv_prediction=5))
     streams = (_corruptions(base, 96, 5) + _corruptions(house04_bytes, 64, 6) + _corruptions(stock, 64, 7) + _corruptions(rare, 64, 8) +
-               _corruptions(geo, 96, 9) + _corruptions(big_tagged, 64, 10) + [base, house04_bytes, stock, rare, geo, big_tagged])
+               _corruptions(geo, 96, 9) + _corruptions(big_tagged, 64, 10) + _corruptions(seamed, 96, 11) +
+               [base, house04_bytes, stock, rare, geo, big_tagged, seamed])
     b = run_batch(ctx, streams)
     agree_ok = agree_bad = gpu_stricter = 0
     stricter_sites = {}

@@ -29,8 +29,18 @@ def random_case(rng):
         elif raw == 2:
             opt.update(pos_bits=min(opt["pos_bits"], 14), uv_bits=min(opt["uv_bits"], 14))
         opt["raw_integers"] = raw
-    pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, int(rng.integers(0, 1 << 30)))
+    mesh_seed = int(rng.integers(0, 1 << 30))
+    pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, mesh_seed)
     with_n, with_uv = bool(rng.integers(0, 4)), bool(rng.integers(0, 4))
+    # one case in three gives its attributes per corner (attribute seams, corner attributes); they need a connectivity of their own
+    if rng.integers(0, 3) == 0 and (with_n or with_uv):
+        from meshutil import seamed_mesh
+        patterns = ["stripes", "island", "checker", "random", "single", "none", None]
+        charts = (str(rng.choice(patterns[:6])) if with_n and rng.integers(0, 2) else None, str(rng.choice(patterns[:6])) if with_uv and rng.integers(0, 2) else None)
+        opt["single_connectivity"] = 0
+        pos, faces, nrm, nid, uv, uid = seamed_mesh(synth, kind, nx, ny, mesh_seed, *charts)
+        return synth.encode_mesh_corners(pos, faces, nrm if with_n else None, nid if with_n else None, uv if with_uv else None, uid if with_uv else None,
+                                         opt=synth.options(**opt)), (kind, nx, ny, opt, with_n, with_uv, charts)
     return synth.encode_mesh(pos, faces, nrm if with_n else None, uv if with_uv else None, opt=synth.options(**opt)), (kind, nx, ny, opt, with_n, with_uv)
 
 
