@@ -35,7 +35,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
 
 
 def usable_cores():
@@ -207,6 +207,34 @@ def pool_leg(dsa, devices, blob, offsets, chunk, repeats):
             "what": "dsa_pool_decode from host bytes (parse + pinned staging + upload + decode per chunk, two chunks in flight per device), results device-resident"}
 
 
+def sustained_leg(dsa, ctx, blob, offsets, steps, warmup, comm, barrier, world):
+    """Two device-resident batches of the same streams decoded in turn without waiting in between (dsa_batch_decode is
+    asynchronous and the context's two stream sets take the decodes alternately): the next batch's chain and entropy decode start
+    beside the previous batch's issue-light tail.  `steps` decodes, the clock stops when the last one is done; every decode is a
+    whole batch, so meshes/s = steps * meshes / time."""
+    pair = [dsa.Batch(ctx, blob=blob, offsets=offsets) for _ in range(2)]
+    n = pair[0].n
+    for k in range(max(2, warmup)):
+        pair[k % 2].decode(wait=False)
+    for b in pair:
+        b.wait()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        pair[k % 2].decode(wait=False)
+    for b in pair:
+        b.wait()
+    barrier()
+    dt = time.perf_counter() - t0
+    bad = sum(1 for b in pair for i in range(0, n, max(1, n // 256)) if b.status(i) != 0)
+    for b in pair:
+        b.close()
+    if comm is not None:
+        dt = comm.max(dt)
+    return {"value": world * steps * n / dt, "unit": "meshes/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "batches_in_flight": 2, "failed_sampled": bad,
+            "what": "the same device-resident decode as `value`, two batches in flight on the context's two stream sets (no wait between steps)"}
+
+
 def oracle_check(batch, blob, offsets, indices):
     """Outside the timed region: the decoded results of `indices` equal the CPU oracle's (faces, portable integers,
     point maps, floats bit for bit)."""
@@ -237,6 +265,7 @@ def main():
                          "both: like auto but weak stays the line; weak / strong: only that leg")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-pool", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true")
     ap.add_argument("--e2e-batches", type=int, default=6)
     ap.add_argument("--encode-meshes", type=int, default=4096, help="meshes per GPU of the encode leg (BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -304,6 +333,8 @@ def main():
             batch.decode(wait=True)
             for k, v in batch.stage_times().items():
                 stage_sum[k] = stage_sum.get(k, 0.0) + v
+            for k, v in batch.kernel_times().items():
+                stage_sum["kernel:" + k] = stage_sum.get("kernel:" + k, 0.0) + v
         barrier()
         elapsed = time.perf_counter() - t0
         bad = [i for i in range(batch.n) if batch.status(i) != 0]
@@ -333,12 +364,16 @@ def main():
         weak_blob, weak_offsets = blob, offsets
         if rank == 0:
             step_s = elapsed / args.steps
-            kernel_stages = {k: v for k, v in stages.items() if k != "total"}
-            dom = max(kernel_stages, key=kernel_stages.get)
-            kernel_name = {"symbols": "k_symbols_reg"}.get(dom, "k_" + dom)
-            if dom == "traverse" and stages.get("connectivity", 1.0) < 0.2:
-                kernel_name = "k_chain"                   # batches above 2048 meshes: connectivity + traversal by one wave per mesh
-            achieved = alg_bytes / (kernel_stages[dom] * 1e-3) / 1e9
+            # the dominant kernel: the longest of the kernels timed one by one (an event pair around each on its own stream, mean
+            # over the steps) -- a duration that is a row of `rocprofv3 --kernel-trace --stats` of this command (profiles/)
+            kernel_ms = {k[len("kernel:"):]: v for k, v in stages.items() if k.startswith("kernel:")}
+            stages = {k: v for k, v in stages.items() if not k.startswith("kernel:")}
+            dom = max(kernel_ms, key=kernel_ms.get)
+            kernel_name = dom.split("[")[0]
+            dom_ms = kernel_ms[dom]
+            if dom_ms > step_s * 1e3 * 1.02:
+                raise SystemExit("kernel %s timed at %.2f ms, longer than the %.2f ms step it is part of" % (dom, dom_ms, step_s * 1e3))
+            achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
             traffic, traffic_src, traffic_total = measured_traffic(kernel_name, args.meshes, 2 * nx * ny)
             out = {
                 "metric": "decoded_meshes_per_sec",
@@ -364,9 +399,9 @@ def main():
                 # `achieved` follows the contract: the step's algorithmic bytes over the longest kernel's duration (HIP events on
                 # that kernel's own stream).  The kernels of a step overlap on three streams, so the honest whole-path figure is
                 # `step_frac`: the same bytes over the whole step.
-                "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "roofline": {"bound": "hbm", "kernel": kernel_name, "kernel_launch": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                             "kernel_ms": kernel_stages[dom], "algorithmic_bytes": alg_bytes,
+                             "kernel_ms": dom_ms, "kernels_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
                              "step_achieved": alg_bytes / step_s / 1e9, "step_frac": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS,
                              "step_traffic": traffic_total},
                 "setup_s": {"generate": t_gen, "upload_and_layout": t_upload},
@@ -407,6 +442,9 @@ def main():
                       "meshes_per_gpu": shard_sizes, "assignment": "sharding.balanced_assignment (longest compressed stream first)",
                       "gb_per_s": alg_bytes_all / step_s / 1e9, "stage_ms_rank0": stages, "generate_s": t_gen_s}
         batch.close()
+    sustained = None
+    if not args.no_sustained and weak_blob is not None:
+        sustained = sustained_leg(dsa, ctx, weak_blob, weak_offsets, max(4, args.steps), args.warmup, comm if world > 1 else None, barrier, world)
     encode = None
     if not args.no_encode:                                           # every rank: the leg's clock is the slowest rank's
         encode = encode_leg(dsa, synth, ctx, nx, ny, args.encode_meshes, comm if world > 1 else None, barrier if world > 1 else None, world)
@@ -425,9 +463,10 @@ def main():
                 pblob, poffs = weak_blob, weak_offsets
             else:
                 pblob, poffs = synth.make_batch(synth.GRID, nx, ny, 1000, args.meshes, normals=True, uvs=True, threads=threads)
-            devices = [0] * world if rehearse else list(range(world))
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))       # the GPUs of this node
+            devices = [0] * world if rehearse else list(range(local_world))
             pool = pool_leg(dsa, devices, pblob, poffs, 0, 3)
-        barrier()
+        comm.host_barrier()        # the waiting ranks block on the host (gloo): an RCCL barrier would spin on the GPUs rank 0 is measuring on
     if rank == 0:
         if out is None:                                              # --scaling strong: the strong leg is the line
             out = {"metric": "decoded_meshes_per_sec", "value": strong["value"], "unit": "meshes/s", "n_gpus": world, "steps": args.steps,
@@ -450,7 +489,10 @@ def main():
             out["config"]["workload"] = ("one batch of %d x %d-triangle Edgebreaker .drc (positions 11b + octahedral normals 8b + UVs 10b) sharded over %d GPUs "
                                          "by compressed length, device-resident decode" % (args.meshes, 2 * nx * ny, world))
             out["config"]["meshes_in_job"] = args.meshes
+            out["config"]["meshes_per_gpu"] = strong["meshes_per_gpu"]
             out["roofline"]["leg"] = "weak (a full %d-mesh batch per GPU): the kernels' roofline does not depend on the partition" % args.meshes
+        if sustained is not None:
+            out["sustained"] = sustained
         if encode is not None:
             out["encode"] = encode
         if e2e is not None:
@@ -459,10 +501,11 @@ def main():
             out["pool"] = pool
         out["notes"] = ("value / gb_per_s: compressed bytes resident in HBM -> results in HBM (no PCIe in the timed region); end_to_end: host bytes -> host "
                         "arrays; cpu_baseline: the oracle incl. its numpy export on the host")
-        if world == 1 and not args.no_cpu_baseline and weak_blob is not None:
+        if not args.no_cpu_baseline and weak_blob is not None:       # rank 0, on the node's host cores, after every GPU leg
             out["cpu_baseline"] = cpu_baseline(weak_blob, weak_offsets, 1, 10.0, 1024)
             out["cpu_baseline_all_cores"] = cpu_baseline(weak_blob, weak_offsets, min(host_cores, 32), 10.0, 4096)
         print(json.dumps(out))
+    comm.host_barrier()                                               # the other ranks wait on the host while rank 0 times the CPU
     if ctx is not None:
         ctx.close()
     comm.close()

@@ -4,6 +4,7 @@
 // HIP stream, result queries and copy-out.  No torch types, no CPU decode path:
 // every byte of geometry is produced by the kernels in dsa_kernels.h.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <mutex>
 
 #include <cstdarg>
@@ -25,6 +26,12 @@ namespace {
 enum { STG_LOCATE = 0, STG_CONNECTIVITY, STG_TRAVERSE, STG_OPERANDS, STG_SYMBOLS, STG_PREDICT, STG_FINALIZE, STG_TOTAL };
 static const char *kStageNames[DSA_NUM_STAGES] = {"locate", "connectivity", "traverse", "para_operands",
                                                  "symbols", "predict", "finalize", "total"};
+// Kernels timed one by one (dsa_batch_kernel_times): an event pair around each on the stream it is launched on, so that a duration
+// here is a row of `rocprofv3 --kernel-trace --stats` (first launch of that kernel in the decode where a kernel is launched twice).
+enum { KT_CHAIN = 0, KT_CONNECTIVITY, KT_TRAVERSE, KT_SYMBOLS_EARLY, KT_SYMBOLS_LATE, KT_OCT_STREAMS, KT_PREDICT_WRAP_EARLY, KT_PREDICT_WRAP_LATE, KT_FACES,
+       KT_SEAM_TABLES, KT_TRAVERSE_ATT, KT_TEXCOORDS, KT_COUNT };
+static const char *kKernelNames[KT_COUNT] = {"k_chain", "k_connectivity", "k_traverse", "k_symbols_reg[early]", "k_symbols_reg[late]", "k_predict_oct_streams",
+                                             "k_predict_wrap[early]", "k_predict_wrap[late]", "k_faces", "k_seam_tables", "k_traverse_att", "k_texcoords"};
 
 
 }  // namespace
@@ -66,17 +73,45 @@ struct EncLane {
   }
 };
 
-struct dsa_context {
-  int device = 0;
+// The streams one decode runs on, and the events that order them.  A context has two sets, used in turn (unless the caller gave
+// the context a stream of its own: then only the first): a decode queued while the previous one is still running goes to the other
+// set, so that its chain and entropy decode start beside the previous batch's issue-light tail (parallelogram prediction, faces,
+// dequantisation) instead of behind it on the same in-order streams.
+struct StreamSet {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;     // symbol decode runs here, concurrently with connectivity + traversal
   hipStream_t stream3 = nullptr;     // connectivity validation (link symmetry, seam streams)
   hipStream_t stream4 = nullptr;     // early attributes: symbols, prediction, dequantisation (dispatch priority)
-  hipStream_t up = nullptr;          // host -> device: compressed streams of the next batch, beside the kernels of this one
-  hipStream_t down = nullptr;        // device -> host: the output block and the mesh descriptors of the previous one
   hipEvent_t ev_join3 = nullptr, ev_trav = nullptr, ev_maps = nullptr, ev_early = nullptr, ev_flips = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_conn = nullptr;
   bool own_stream = false;
+  hipError_t create(hipStream_t user, int least, int greatest) {
+    // Dispatch priorities (numerically lower = higher): the stream of the per-mesh chain above the stream of the early attributes
+    // above the late symbols, which fill whatever the others leave.
+    hipError_t e = hipSuccess;
+    if (user) { stream = user; own_stream = false; }
+    else { e = hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, greatest); own_stream = e == hipSuccess; }
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&stream4, hipStreamNonBlocking, (least + greatest) / 2);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, least);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking);
+    for (hipEvent_t *ev : {&ev_join3, &ev_trav, &ev_maps, &ev_flips, &ev_early, &ev_fork, &ev_join, &ev_conn})
+      if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    return e;
+  }
+  void destroy() {
+    for (hipEvent_t *ev : {&ev_join3, &ev_trav, &ev_maps, &ev_flips, &ev_early, &ev_fork, &ev_join, &ev_conn}) { if (*ev) (void)hipEventDestroy(*ev); *ev = nullptr; }
+    for (hipStream_t *s : {&stream2, &stream3, &stream4}) { if (*s) (void)hipStreamDestroy(*s); *s = nullptr; }
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    stream = nullptr;
+  }
+};
+
+struct dsa_context {
+  int device = 0;
+  StreamSet sets[2];
+  int num_sets = 0, next_set = 0;
+  hipStream_t up = nullptr;          // host -> device: compressed streams of the next batch, beside the kernels of this one
+  hipStream_t down = nullptr;        // device -> host: the output block and the mesh descriptors of the previous one
   bool profiling = false;
   std::string err;
   // Uploads go through pinned staging (two buffers, used in turn: the DMA of one batch reads its buffer while the next batch is
@@ -89,8 +124,11 @@ struct dsa_context {
   std::vector<Spare> spare_arenas, spare_mirrors, spare_descs;   // spare_descs: pinned landing zones of the mesh descriptors
   static constexpr size_t kSpares = 3;
   // batches point at their context: a context destroyed first lives on until its last batch is freed
-  int live_batches = 0;
-  bool doomed = false;
+  std::atomic<int> live_batches{0};
+  std::atomic<bool> doomed{false};
+  // The caches above, stage_next and next_set are touched by dsa_batch_create / _download / _free, which the pool calls from its
+  // worker threads and from whichever thread frees a job while the next decode runs (dsa_pool.h): one lock for all of them.
+  std::mutex mu;
   std::vector<std::unique_ptr<EncLane>> enc_lanes;    // kept between dsa_encode_batch calls (pinning their staging costs more than a small batch)
 };
 
@@ -113,8 +151,11 @@ struct dsa_batch {
   bool decoded = false, collected = false;
   hipEvent_t ev[DSA_NUM_STAGES + 1] = {};
   hipEvent_t ev_sym[2] = {};
+  hipEvent_t ev_k[KT_COUNT][2] = {};
+  bool k_timed[KT_COUNT] = {};
   bool have_events = false;
   float stage_ms[DSA_NUM_STAGES] = {};
+  float kernel_ms[KT_COUNT] = {};
   // per-batch ordering between the copy streams and the kernels (a second batch may be queued on the same context meanwhile,
   // so nothing here waits for a whole stream)
   hipEvent_t ev_uploaded = nullptr, ev_done = nullptr, ev_descs = nullptr, ev_down = nullptr;
@@ -152,7 +193,8 @@ dsa_status set_err(dsa_context *ctx, dsa_status st, const char *fmt, ...) {
   } while (0)
 
 // Arena / mirror caches of a context (see dsa_context).
-uint8_t *take_spare(std::vector<dsa_context::Spare> &spares, uint64_t need, uint64_t *got) {
+uint8_t *take_spare(dsa_context *ctx, std::vector<dsa_context::Spare> &spares, uint64_t need, uint64_t *got) {
+  std::lock_guard<std::mutex> g(ctx->mu);
   int best = -1;
   for (size_t k = 0; k < spares.size(); ++k)
     if (spares[k].bytes >= need && (best < 0 || spares[k].bytes < spares[(size_t)best].bytes)) best = (int)k;
@@ -163,8 +205,9 @@ uint8_t *take_spare(std::vector<dsa_context::Spare> &spares, uint64_t need, uint
   return p;
 }
 template <class FreeFn>
-void give_spare(std::vector<dsa_context::Spare> &spares, uint8_t *p, uint64_t bytes, FreeFn release) {
+void give_spare(dsa_context *ctx, std::vector<dsa_context::Spare> &spares, uint8_t *p, uint64_t bytes, FreeFn release) {
   if (!p) return;
+  std::lock_guard<std::mutex> g(ctx->mu);
   try { spares.push_back({p, bytes}); } catch (...) { release(p); return; }
   while (spares.size() > dsa_context::kSpares) {       // drop the smallest
     size_t s = 0;
@@ -173,17 +216,23 @@ void give_spare(std::vector<dsa_context::Spare> &spares, uint8_t *p, uint64_t by
     spares.erase(spares.begin() + (ptrdiff_t)s);
   }
 }
-void drop_spares(std::vector<dsa_context::Spare> &spares, bool pinned) {
+void drop_spares(dsa_context *ctx, std::vector<dsa_context::Spare> &spares, bool pinned) {
+  std::lock_guard<std::mutex> g(ctx->mu);
   for (auto &sp : spares) { if (pinned) (void)hipHostFree(sp.p); else (void)hipFree(sp.p); }
   spares.clear();
 }
 hipError_t arena_alloc(dsa_context *ctx, uint64_t need, uint8_t **out, uint64_t *cap) {
-  if (uint8_t *p = take_spare(ctx->spare_arenas, need, cap)) { *out = p; return hipSuccess; }
+  if (uint8_t *p = take_spare(ctx, ctx->spare_arenas, need, cap)) { *out = p; return hipSuccess; }
   hipError_t e = hipMalloc((void **)out, need);
-  if (e != hipSuccess && !ctx->spare_arenas.empty()) {     // the cache may be what is in the way
+  if (e != hipSuccess) {     // what the context keeps idle may be what is in the way: spare arenas, then the encoder's lanes
     (void)hipGetLastError();
-    drop_spares(ctx->spare_arenas, false);
+    drop_spares(ctx, ctx->spare_arenas, false);
     e = hipMalloc((void **)out, need);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      { std::lock_guard<std::mutex> g(ctx->mu); ctx->enc_lanes.clear(); }
+      e = hipMalloc((void **)out, need);
+    }
   }
   *cap = need;
   return e;
@@ -288,15 +337,16 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
   {   // pinned landing zone of the descriptors, from the context's cache (hipHostMalloc / hipHostFree wait for the device: with
       // another batch in flight they would serialise the pipeline)
     const uint64_t need = sizeof(MeshDesc) * (uint64_t)(n ? n : 1);
-    uint8_t *p = take_spare(ctx->spare_descs, need, &b->descs_pin_bytes);
+    uint8_t *p = take_spare(ctx, ctx->spare_descs, need, &b->descs_pin_bytes);
     if (!p) { HIP_TRY(ctx, hipHostMalloc((void **)&p, need + need / 2, hipHostMallocDefault)); b->descs_pin_bytes = need + need / 2; }
     b->descs_pin = (MeshDesc *)p;
   }
   // ---- upload: layouts, globals and all streams staged in pinned memory (host threads), one DMA on the upload stream.  The
   // caller's buffers are not referenced once this function returns; the kernels wait for ev_uploaded, the host does not.
   {
-    hostutil::Staging &stg = ctx->stage[ctx->stage_next];
-    ctx->stage_next ^= 1;
+    int turn;
+    { std::lock_guard<std::mutex> g(ctx->mu); turn = ctx->stage_next; ctx->stage_next ^= 1; }
+    hostutil::Staging &stg = ctx->stage[turn];
     HIP_TRY(ctx, stg.acquire(upload_bytes));
     uint8_t *h = stg.buf.p;
     if (n) memcpy(h + off_layouts, b->layouts.data(), sizeof(MeshLayout) * (size_t)n);
@@ -339,53 +389,31 @@ dsa_status dsa_context_create(int device, void *stream, dsa_context **out) {
   if (!c) return DSA_ERR_OUT_OF_MEMORY;
   c->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete c; return DSA_ERR_DEVICE; }
-  // Dispatch priorities (numerically lower = higher): the stream of the per-mesh chain above the stream of the early attributes
-  // above the late symbols, which fill whatever the others leave.
   int least = 0, greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-  if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
-  else {
-    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest) != hipSuccess) { delete c; return DSA_ERR_DEVICE; }
-    c->own_stream = true;
-  }
-  if (hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, (least + greatest) / 2) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
-  if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_trav, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_maps, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_flips, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_conn, hipEventDisableTiming) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
+  // a caller's stream: every decode runs in its order; otherwise two stream sets used in turn (see StreamSet)
+  c->num_sets = stream ? 1 : 2;
+  for (int k = 0; k < c->num_sets; ++k)
+    if (c->sets[k].create(k == 0 ? (hipStream_t)stream : nullptr, least, greatest) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
+  if (hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
   *out = c;
   return DSA_OK;
 }
 
 void dsa_context_destroy(dsa_context *ctx) {
   if (!ctx) return;
-  if (ctx->live_batches > 0) { ctx->doomed = true; return; }     // dsa_batch_free of the last batch comes back here
+  {   // dsa_batch_free of the last batch comes back here
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (ctx->live_batches.load() > 0) { ctx->doomed = true; return; }
+  }
   (void)hipSetDevice(ctx->device);
-  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-  if (ctx->ev_conn) (void)hipEventDestroy(ctx->ev_conn);
-  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-  if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
-  if (ctx->stream4) (void)hipStreamDestroy(ctx->stream4);
   if (ctx->up) { (void)hipStreamSynchronize(ctx->up); (void)hipStreamDestroy(ctx->up); }
   if (ctx->down) { (void)hipStreamSynchronize(ctx->down); (void)hipStreamDestroy(ctx->down); }
-  drop_spares(ctx->spare_arenas, false);
-  drop_spares(ctx->spare_mirrors, true);
-  drop_spares(ctx->spare_descs, true);
-  if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
-  if (ctx->ev_trav) (void)hipEventDestroy(ctx->ev_trav);
-  if (ctx->ev_maps) (void)hipEventDestroy(ctx->ev_maps);
-  if (ctx->ev_flips) (void)hipEventDestroy(ctx->ev_flips);
-  if (ctx->ev_early) (void)hipEventDestroy(ctx->ev_early);
-  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  drop_spares(ctx, ctx->spare_arenas, false);
+  drop_spares(ctx, ctx->spare_mirrors, true);
+  drop_spares(ctx, ctx->spare_descs, true);
+  for (StreamSet &set : ctx->sets) set.destroy();
   delete ctx;
 }
 
@@ -427,11 +455,15 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   dsa_context *ctx = b->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint32_t n = b->n;
+  const bool was_decoded = b->decoded;
   b->decoded = true;
   b->collected = false;
   if (b->retry) { dsa_batch_free(b->retry); b->retry = nullptr; }
   b->retry_index.clear();
-  hipStream_t st = ctx->stream;
+  int set_turn;
+  { std::lock_guard<std::mutex> g(ctx->mu); set_turn = ctx->next_set; ctx->next_set = (ctx->next_set + 1) % ctx->num_sets; }
+  StreamSet &S = ctx->sets[set_turn];
+  hipStream_t st = S.stream;
   if (n == 0) {
     HIP_TRY(ctx, hipEventRecord(b->ev_done, st));
     HIP_TRY(ctx, hipEventRecord(b->ev_descs, st));
@@ -441,11 +473,17 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   if (prof && !b->have_events) {
     for (int i = 0; i <= DSA_NUM_STAGES; ++i) HIP_TRY(ctx, hipEventCreate(&b->ev[i]));
     for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreate(&b->ev_sym[i]));
+    for (int k = 0; k < KT_COUNT; ++k) for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventCreate(&b->ev_k[k][i]));
     b->have_events = true;
   }
+  for (int k = 0; k < KT_COUNT; ++k) b->k_timed[k] = false;
+  // an event pair around one kernel, on its own stream
+  auto k_begin = [&](int k, hipStream_t s) { if (prof && !b->k_timed[k]) (void)hipEventRecord(b->ev_k[k][0], s); };
+  auto k_end = [&](int k, hipStream_t s) { if (prof && !b->k_timed[k]) { (void)hipEventRecord(b->ev_k[k][1], s); b->k_timed[k] = true; } };
   int evi = 0;
   auto mark = [&]() -> hipError_t { return prof ? hipEventRecord(b->ev[evi++], st) : hipSuccess; };
   if (b->download_queued && !b->downloaded) HIP_TRY(ctx, hipStreamWaitEvent(st, b->ev_down, 0));   // a download of the previous decode still reads the arena
+  if (was_decoded) HIP_TRY(ctx, hipStreamWaitEvent(st, b->ev_done, 0));   // this batch's previous decode may still be running on the other stream set
   b->download_queued = false; b->downloaded = false;
   HIP_TRY(ctx, hipStreamWaitEvent(st, b->ev_uploaded, 0));           // the streams and layouts are in the arena
   HIP_TRY(ctx, hipMemsetAsync(b->d_descs, 0, sizeof(MeshDesc) * n, st));
@@ -494,11 +532,11 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   const int oct_choice = []() { const char *e = getenv("DSA_OCT_STREAMS"); return e ? atoi(e) : -1; }();
   const bool oct_rule = n >= 3584 && (uint64_t)b->max_vertices * n <= 4 * b->sum_vertices;
   const uint32_t oct_flag = (oct_choice >= 0 ? oct_choice != 0 : oct_rule) && !(lane_flags & (LN_FLAG_OCT | LN_FLAG_PREDICT)) ? OS_FLAG : 0u;
-  hipStream_t st2 = serial ? st : ctx->stream2, st3 = serial ? st : ctx->stream3;
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
-  HIP_TRY(ctx, hipStreamWaitEvent(st2, ctx->ev_fork, 0));
+  hipStream_t st2 = serial ? st : S.stream2, st3 = serial ? st : S.stream3;
+  HIP_TRY(ctx, hipEventRecord(S.ev_fork, st));
+  HIP_TRY(ctx, hipStreamWaitEvent(st2, S.ev_fork, 0));
   if (b->any_general) {                 // whole-mesh serial decode of the general-path meshes, beside the fast kernels
-    HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_fork, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(st3, S.ev_fork, 0));
     hipLaunchKernelGGL(dsa::k_general, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_general_tables, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_general_attributes<0>, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
@@ -506,12 +544,12 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     if (n > 2048) hipLaunchKernelGGL(dsa::k_general_values_crowded, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
     else hipLaunchKernelGGL(dsa::k_general_attributes<2>, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_general_attributes<3>, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_join3, st3));        // k_finalize(1) dequantises what these kernels decoded
+    HIP_TRY(ctx, hipEventRecord(S.ev_join3, st3));        // k_finalize(1) dequantises what these kernels decoded
   }
   // ---- the chain of the mesh itself first: its waves must find their slots before the entropy decoders fill the machine
   // the seam streams are checked on the third stream from the start: the check needs k_locate's offsets only (k_seal
   // compares what it finds with the connectivity's edge count)
-  if (!b->any_general) HIP_TRY(ctx, hipStreamWaitEvent(st3, ctx->ev_fork, 0));
+  if (!b->any_general) HIP_TRY(ctx, hipStreamWaitEvent(st3, S.ev_fork, 0));
   {
     uint32_t lpm = 1;                                  // lanes per mesh >= attribute data per mesh (<= DSA_MAX_ATT_DATA = 7)
     while (lpm < b->max_att_data) lpm *= 2;
@@ -524,7 +562,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     while (lpm < na) lpm *= 2;
     const uint32_t per_wave = WAVE / lpm;
     hipLaunchKernelGGL(dsa::k_flip_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, lpm);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_flips, st3));
+    HIP_TRY(ctx, hipEventRecord(S.ev_flips, st3));
   }
   // parallelogram operands: by the traversal waves themselves when the batch keeps the machine busy anyway, by an
   // element-parallel kernel behind the traversal when it does not
@@ -535,26 +573,34 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // (a small batch leaves slots free anyway, and is quicker with the faces converted beside the traversal)
   const bool chain = chain_choice >= 0 ? chain_choice != 0 : n > 2048;       // measured: equal at 2048, 1.3 ms slower at 1024, 4 ms faster at 4096
   auto launch_faces = [&]() -> hipError_t {      // faces as point ids + link census need the connectivity: third stream
-    hipError_t e = hipEventRecord(ctx->ev_trav, st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(st3, ctx->ev_trav, 0);
+    hipError_t e = hipEventRecord(S.ev_trav, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st3, S.ev_trav, 0);
     const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
+    k_begin(KT_FACES, st3);
     hipLaunchKernelGGL(dsa::k_faces, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
-    if (e == hipSuccess) e = hipEventRecord(ctx->ev_maps, st3);
+    k_end(KT_FACES, st3);
+    if (e == hipSuccess) e = hipEventRecord(S.ev_maps, st3);
     return e;
   };
   const bool chain_launched = chain;
   if (chain) {
     HIP_TRY(ctx, mark());                              // the connectivity stage has no time of its own
+    k_begin(KT_CHAIN, st);
     hipLaunchKernelGGL(dsa::k_chain, dim3(n), dim3(WAVE), CN_LDS_WORDS * 4, st, b->arena, b->d_layouts, b->d_descs, n, trav_flags);
+    k_end(KT_CHAIN, st);
   } else {
+    k_begin(KT_CONNECTIVITY, st);
     hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+    k_end(KT_CONNECTIVITY, st);
     HIP_TRY(ctx, launch_faces());                      // beside the traversal
     HIP_TRY(ctx, mark());
     const uint32_t per = (n + (uint32_t)trav_split - 1) / (uint32_t)trav_split;
+    k_begin(KT_TRAVERSE, st);
     for (uint32_t m0 = 0; m0 < n; m0 += per) {
       const uint32_t cnt = std::min(per, n - m0);
       hipLaunchKernelGGL(dsa::k_traverse, dim3(cnt), dim3(WAVE), 0, st, b->arena, b->d_layouts + m0, b->d_descs + m0, cnt, trav_flags);
     }
+    k_end(KT_TRAVERSE, st);
   }
   HIP_TRY(ctx, mark());
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[0], st2));
@@ -576,7 +622,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // parallelogram attributes ("late") follow on the second stream.  DSA_SYM_SPLIT=0, DSA_SERIAL and the lane-per-chain
   // options keep the single symbol launch.
   const bool sym_split = !serial && !(lane_flags & (LN_FLAG_SYMBOLS | LN_FLAG_PREDICT)) && split_mode != 0;
-  hipStream_t st4 = sym_split ? ctx->stream4 : st2;
+  hipStream_t st4 = sym_split ? S.stream4 : st2;
   // (gate: k_register_gate in front of the 12-bit kernel, see the crowded-batch schedule below)
   auto launch_symbols = [&](hipStream_t s, uint32_t fl, bool gate = false) {
     fl |= wide_flag;
@@ -589,7 +635,10 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_symbols<0>, dim3(tier_blocks), dim3(WAVE), dsa::sym_tier_lds_bytes(0), s, b->arena, b->d_layouts, b->d_descs, n, na, fl);
     hipLaunchKernelGGL(dsa::k_symbols<2>, dim3(tier_blocks), dim3(WAVE), dsa::sym_tier_lds_bytes(2), s, b->arena, b->d_layouts, b->d_descs, n, na, fl);
     if (gate) hipLaunchKernelGGL(dsa::k_register_gate, dim3(SYM_TIER_BLOCKS), dim3(WAVE), 0, s);
+    const int kt = (fl & SYM_EARLY_ONLY) ? KT_SYMBOLS_EARLY : KT_SYMBOLS_LATE;
+    k_begin(kt, s);
     hipLaunchKernelGGL(dsa::k_symbols_reg, dim3(n, na), dim3(WAVE), 0, s, b->arena, b->d_layouts, b->d_descs, n, fl);
+    k_end(kt, s);
   };
   {
     // The identity maps of point clouds (nothing to do for meshes) go first on the symbol stream, and the symbol kernels of
@@ -598,7 +647,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     // for a decoder to finish, 5 ms or more (tools/wave_times.py).
     const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 16383) / 16384, 4));
     hipLaunchKernelGGL(dsa::k_point_maps, dim3(gx, n), dim3(256), 0, st2, b->arena, b->d_layouts, b->d_descs, n);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st2));
+    HIP_TRY(ctx, hipEventRecord(S.ev_conn, st2));
   }
   // DSA_EARLY_FUSE=1 (measured 1.7 ms slower, off): the wave that decoded an early attribute's symbols also predicts and
   // dequantises it -- the octahedral prediction leaves the tail (7.5 -> 4.7 ms) but its waves keep 80-register slots twice as
@@ -606,8 +655,8 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   const uint32_t early_fuse = early_fuse_on && !(lane_flags & (LN_FLAG_PREDICT | LN_FLAG_OCT)) ? SYM_EARLY_FUSE : 0u;
   if (sym_split && split_mode == 2) {          // early attributes first, then the late ones beside the early prediction
     launch_symbols(st2, lane_flags | SYM_EARLY_ONLY | early_fuse);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_conn, st2));
-    HIP_TRY(ctx, hipStreamWaitEvent(st4, ctx->ev_conn, 0));
+    HIP_TRY(ctx, hipEventRecord(S.ev_conn, st2));
+    HIP_TRY(ctx, hipStreamWaitEvent(st4, S.ev_conn, 0));
     launch_symbols(st2, lane_flags | SYM_LATE_ONLY);
   } else if (sym_split && oct_flag) {
     // The early attributes have the longer tail behind their symbols when the octahedral delta runs one lane per stream (a
@@ -618,16 +667,16 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     // shadow of the chain.  (Late after ALL early symbols: a millisecond slower.  Early symbols in two launches with the late
     // ones behind the first: the second launch shares the freed slots with the late kernel block for block and ends at 28 ms.
     // Until the registers of the 16 KB tier were put right its idle waves did this by accident.)
-    HIP_TRY(ctx, hipStreamWaitEvent(st4, ctx->ev_conn, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(st4, S.ev_conn, 0));
     launch_symbols(st4, lane_flags | SYM_EARLY_ONLY | early_fuse);
     launch_symbols(st2, lane_flags | SYM_LATE_ONLY, true);
   } else if (sym_split) {                      // both at once, the early ones on the stream with priority
-    HIP_TRY(ctx, hipStreamWaitEvent(st4, ctx->ev_conn, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(st4, S.ev_conn, 0));
     launch_symbols(st4, lane_flags | SYM_EARLY_ONLY | early_fuse);
     launch_symbols(st2, lane_flags | SYM_LATE_ONLY);
   } else launch_symbols(st2, lane_flags | early_fuse);
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[1], st2));
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_join, st2));           // corrections of the late attributes (without the split: of every attribute) are ready
+  HIP_TRY(ctx, hipEventRecord(S.ev_join, st2));           // corrections of the late attributes (without the split: of every attribute) are ready
   // attributes whose prediction needs no traversal data (difference, octahedral delta) are finished on this stream,
   // beside the traversal and the parallelogram attributes; joined before k_seal
 #ifdef DSA_EXPERIMENTS
@@ -637,9 +686,17 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   {
     // the octahedral delta of a crowded batch one lane per stream (64 streams per wave: 1/30 of the instructions; the kernel takes
     // as long as the longest stream's chain whatever the batch size, which a small batch does not want)
-    if (oct_flag) hipLaunchKernelGGL(dsa::k_predict_oct_streams, dim3((n + WAVE - 1) / WAVE, na), dim3(WAVE), OS_RING * 1024u, st4, b->arena, b->d_layouts, b->d_descs, n);
+    if (oct_flag) {
+      k_begin(KT_OCT_STREAMS, st4);
+      hipLaunchKernelGGL(dsa::k_predict_oct_streams, dim3((n + WAVE - 1) / WAVE, na), dim3(WAVE), OS_RING * 1024u, st4, b->arena, b->d_layouts, b->d_descs, n);
+      k_end(KT_OCT_STREAMS, st4);
+    }
     hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags | oct_flag);
-    if (lane_flags & PW_FLAG) hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
+    if (lane_flags & PW_FLAG) {
+      k_begin(KT_PREDICT_WRAP_EARLY, st4);
+      hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
+      k_end(KT_PREDICT_WRAP_EARLY, st4);
+    }
 #ifdef DSA_EXPERIMENTS
     if (lane_flags & LN_FLAG_OCT) {
       if (oct_lpw == 8) hipLaunchKernelGGL(dsa::lanes::k_predict_oct_lanes<8>, dim3((n + 7) / 8, na), dim3(WAVE), 0, st4, b->arena, b->d_layouts, b->d_descs, n, lane_flags);
@@ -653,29 +710,33 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
     hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st4, b->arena, b->d_layouts, b->d_descs, n, 0u, lane_flags);
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_early, st4));
+  HIP_TRY(ctx, hipEventRecord(S.ev_early, st4));
   if (chain_launched) HIP_TRY(ctx, launch_faces());      // behind the chain, beside the parallelogram prediction
   if (!fuse_operands) {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 8191) / 8192, 4));
     hipLaunchKernelGGL(dsa::k_para_operands, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   }
   HIP_TRY(ctx, mark());
-  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));   // join: corrections are ready
-  if (b->any_general) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join3, 0));   // join: the general path's integers are ready
+  HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_join, 0));   // join: corrections are ready
+  if (b->any_general) HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_join3, 0));   // join: the general path's integers are ready
   HIP_TRY(ctx, mark());
 #ifdef DSA_EXPERIMENTS
   if (lane_flags & LN_FLAG_PREDICT) hipLaunchKernelGGL(dsa::lanes::k_predict_lanes<32>, dim3((n + 31) / 32, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u);
   else
 #endif
   {
-    if (lane_flags & PW_FLAG) hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags);
+    if (lane_flags & PW_FLAG) {
+      k_begin(KT_PREDICT_WRAP_LATE, st);
+      hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags);
+      k_end(KT_PREDICT_WRAP_LATE, st);
+    }
     hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags);
   }
   HIP_TRY(ctx, mark());
   {
     // GeometricNormal attributes: from the final positions (of whichever strand) and the flip bits
-    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_early, 0));
-    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_flips, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_early, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_flips, 0));
     const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 1023) / 1024, 32));     // four entries per thread: 11.6 -> 9.7 ms against sixteen
     const uint32_t gv = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 1023) / 1024, 64));     // two dependent gathers per vertex: many short threads
     hipLaunchKernelGGL(dsa::k_vertex_positions, dim3(gv, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
@@ -685,7 +746,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
     hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags);
   }
-  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_maps, 0));
+  HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_maps, 0));
   hipLaunchKernelGGL(dsa::k_seal, dim3((n + 255) / 256), dim3(256), 0, st, b->d_descs, n);
   HIP_TRY(ctx, mark());
   HIP_TRY(ctx, hipGetLastError());
@@ -720,6 +781,10 @@ static dsa_status batch_wait(dsa_batch *b) {
     // the symbol stage runs on the second stream: its own event pair (the slot on the main stream is the join wait)
     HIP_TRY(ctx, hipEventElapsedTime(&b->stage_ms[STG_SYMBOLS], b->ev_sym[0], b->ev_sym[1]));
     HIP_TRY(ctx, hipEventElapsedTime(&b->stage_ms[STG_TOTAL], b->ev[0], b->ev[STG_TOTAL]));
+    for (int k = 0; k < KT_COUNT; ++k) {
+      b->kernel_ms[k] = 0.f;
+      if (b->k_timed[k]) HIP_TRY(ctx, hipEventElapsedTime(&b->kernel_ms[k], b->ev_k[k][0], b->ev_k[k][1]));
+    }
   }
   // a stream the sizing parse set aside as beyond the device path's limits (more than DSA_MAX_ATT attributes) got no
   // regions, so the kernels stop at the first capacity check: the verdict is the host's
@@ -763,17 +828,20 @@ void dsa_batch_free(dsa_batch *b) {
   if (b->retry) { dsa_batch_free(b->retry); b->retry = nullptr; }
   if (b->have_events) for (int i = 0; i <= DSA_NUM_STAGES; ++i) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
   if (b->have_events) for (int i = 0; i < 2; ++i) if (b->ev_sym[i]) (void)hipEventDestroy(b->ev_sym[i]);
+  if (b->have_events) for (int k = 0; k < KT_COUNT; ++k) for (int i = 0; i < 2; ++i) if (b->ev_k[k][i]) (void)hipEventDestroy(b->ev_k[k][i]);
   // nothing of this batch may still be in flight when its arena goes back to the cache (a caller may free without waiting)
   if (b->ev_uploaded) { (void)hipEventSynchronize(b->ev_uploaded); (void)hipEventDestroy(b->ev_uploaded); }
   if (b->ev_done) { if (b->decoded) (void)hipEventSynchronize(b->ev_done); (void)hipEventDestroy(b->ev_done); }
   if (b->ev_descs) { if (b->decoded) (void)hipEventSynchronize(b->ev_descs); (void)hipEventDestroy(b->ev_descs); }
   if (b->ev_down) { if (b->download_queued) (void)hipEventSynchronize(b->ev_down); (void)hipEventDestroy(b->ev_down); }
-  give_spare(b->ctx->spare_descs, (uint8_t *)b->descs_pin, b->descs_pin_bytes, [](uint8_t *p) { (void)hipHostFree(p); });
-  if (b->mirror && b->mirror_owned) give_spare(b->ctx->spare_mirrors, b->mirror, b->mirror_bytes, [](uint8_t *p) { (void)hipHostFree(p); });
-  give_spare(b->ctx->spare_arenas, b->arena, b->arena_cap, [](uint8_t *p) { (void)hipFree(p); });
+  give_spare(b->ctx, b->ctx->spare_descs, (uint8_t *)b->descs_pin, b->descs_pin_bytes, [](uint8_t *p) { (void)hipHostFree(p); });
+  if (b->mirror && b->mirror_owned) give_spare(b->ctx, b->ctx->spare_mirrors, b->mirror, b->mirror_bytes, [](uint8_t *p) { (void)hipHostFree(p); });
+  give_spare(b->ctx, b->ctx->spare_arenas, b->arena, b->arena_cap, [](uint8_t *p) { (void)hipFree(p); });
   dsa_context *ctx = b->ctx;
   delete b;
-  if (--ctx->live_batches == 0 && ctx->doomed) dsa_context_destroy(ctx);
+  bool last;
+  { std::lock_guard<std::mutex> g(ctx->mu); last = --ctx->live_batches == 0 && ctx->doomed.load(); }
+  if (last) dsa_context_destroy(ctx);
 }
 
 uint32_t dsa_batch_size(const dsa_batch *b) { return b ? b->n : 0; }
@@ -904,15 +972,15 @@ dsa_status dsa_batch_download(dsa_batch *b, void *dst, size_t dst_bytes) {
   if (b->download_queued) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "the batch is already being downloaded");
   if (dst && dst_bytes < b->out_bytes) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "destination smaller than dsa_batch_output_bytes");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (b->mirror && b->mirror_owned && dst) { give_spare(ctx->spare_mirrors, b->mirror, b->mirror_bytes, [](uint8_t *p) { (void)hipHostFree(p); }); b->mirror = nullptr; }
+  if (b->mirror && b->mirror_owned && dst) { give_spare(ctx, ctx->spare_mirrors, b->mirror, b->mirror_bytes, [](uint8_t *p) { (void)hipHostFree(p); }); b->mirror = nullptr; }
   if (dst) { b->mirror = (uint8_t *)dst; b->mirror_bytes = dst_bytes; b->mirror_owned = false; }
   else if (!b->mirror || !b->mirror_owned) {
     const uint64_t need = b->out_bytes ? b->out_bytes : 256;
     uint64_t got = 0;
-    uint8_t *p = take_spare(ctx->spare_mirrors, need, &got);
+    uint8_t *p = take_spare(ctx, ctx->spare_mirrors, need, &got);
     if (!p) {
       hipError_t e = hipHostMalloc((void **)&p, need, hipHostMallocDefault);
-      if (e != hipSuccess && !ctx->spare_mirrors.empty()) { (void)hipGetLastError(); drop_spares(ctx->spare_mirrors, true); e = hipHostMalloc((void **)&p, need, hipHostMallocDefault); }
+      if (e != hipSuccess) { (void)hipGetLastError(); drop_spares(ctx, ctx->spare_mirrors, true); e = hipHostMalloc((void **)&p, need, hipHostMallocDefault); }
       if (e != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "pinned host mirror of %llu bytes: %s", (unsigned long long)need, hipGetErrorString(e)); }
       got = need;
     }
@@ -1044,6 +1112,28 @@ dsa_status dsa_batch_copy_debug(const dsa_batch *b, uint32_t mesh, int what, voi
   if (bytes > dst_bytes) return set_err(b->ctx, DSA_ERR_INVALID_ARGUMENT, "destination too small");
   if (written) *written = (size_t)bytes;
   return copy_out(b, dst, off, bytes);
+}
+
+dsa_status dsa_batch_kernel_times(const dsa_batch *b, float *ms, const char **names, uint32_t capacity, uint32_t *count) {
+  if (!b || !count) return DSA_ERR_INVALID_ARGUMENT;
+  uint32_t k_out = 0;
+  for (int k = 0; k < KT_COUNT; ++k) {
+    if (!b->k_timed[k] || !b->collected) continue;
+    if (k_out < capacity) { if (ms) ms[k_out] = b->kernel_ms[k]; if (names) names[k_out] = kKernelNames[k]; }
+    ++k_out;
+  }
+  *count = k_out;
+  return DSA_OK;
+}
+
+dsa_status dsa_context_trim(dsa_context *ctx) {
+  if (!ctx) return DSA_ERR_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  drop_spares(ctx, ctx->spare_arenas, false);
+  drop_spares(ctx, ctx->spare_mirrors, true);
+  drop_spares(ctx, ctx->spare_descs, true);
+  { std::lock_guard<std::mutex> g(ctx->mu); ctx->enc_lanes.clear(); }      // dsa_encode_batch is synchronous: its lanes are idle between calls
+  return DSA_OK;
 }
 
 dsa_status dsa_batch_stage_times(const dsa_batch *b, float ms[DSA_NUM_STAGES], const char *names[DSA_NUM_STAGES]) {

@@ -243,6 +243,10 @@ class Context:
     def set_profiling(self, on=True):
         self._L.dsa_context_set_profiling(self._h, 1 if on else 0)
 
+    def trim(self):
+        """Releases the arenas, pinned mirrors and encoder lanes the context keeps between calls."""
+        self._L.dsa_context_trim(self._h)
+
     def close(self):
         if self._h:
             self._L.dsa_context_destroy(self._h)
@@ -350,6 +354,15 @@ class Batch:
         names = (C.c_char_p * native.DSA_NUM_STAGES)()
         self._L.dsa_batch_stage_times(self._h, C.byref(ms), C.byref(names))
         return {names[i].decode(): float(ms[i]) for i in range(native.DSA_NUM_STAGES)}
+
+    def kernel_times(self):
+        """{kernel name: ms} of the step's main kernels, each from its own event pair on its own stream (profiling on)."""
+        cap = 32
+        ms = (C.c_float * cap)()
+        names = (C.c_char_p * cap)()
+        count = C.c_uint32()
+        self._L.dsa_batch_kernel_times(self._h, ms, names, cap, C.byref(count))
+        return {names[i].decode(): float(ms[i]) for i in range(min(cap, count.value))}
 
     def mesh_info(self, i):
         info = native.MeshInfo()

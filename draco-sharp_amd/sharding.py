@@ -47,10 +47,18 @@ class Comm:
                 kw["device_id"] = device
             dist.init_process_group(backend or "gloo", rank=self.rank, world_size=self.world, **kw)
             self.dist = dist
+            # a second group on gloo for waits that must not touch the GPUs: an RCCL barrier is a kernel that spins on every
+            # waiting rank's device, which is in the way when one rank is measuring on those devices (bench.py's pool leg)
+            self.host_group = dist.new_group(backend="gloo") if (backend or "gloo") != "gloo" else None
 
     def barrier(self):
         if self.dist is not None:
             self.dist.barrier()
+
+    def host_barrier(self):
+        """Barrier over gloo: the waiting ranks block on the host and leave their GPUs idle."""
+        if self.dist is not None:
+            self.dist.barrier(group=getattr(self, "host_group", None))
 
     def _reduce(self, value, op):
         if self.dist is None:

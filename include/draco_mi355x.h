@@ -17,8 +17,12 @@
  * src/Draco/IO/DracoDecoder.cs:49,70,87-97).  One bad stream never poisons the
  * rest of the batch.
  *
- * Threading: a context is bound to one GPU and may be used from one host thread
- * at a time; different contexts (one per GPU) are independent.
+ * Threading: a context is bound to one GPU; its calls that queue work (dsa_batch_create, _decode, _download,
+ * dsa_encode_batch) come from one host thread at a time; different contexts (one per GPU) are independent.
+ * dsa_batch_wait and dsa_batch_free of a batch may run on another thread than the one that is creating or decoding
+ * the context's NEXT batch (the pool does this: a consumer frees job k while the workers decode job k+1): the
+ * context's caches of arenas, pinned mirrors and descriptor zones, its count of live batches and the turn of its
+ * staging buffers and stream sets are behind a lock.  One batch is still used by one thread at a time.
  */
 #ifndef DRACO_MI355X_H_
 #define DRACO_MI355X_H_
@@ -30,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DSA_ABI_VERSION 2
+#define DSA_ABI_VERSION 3
 #define DSA_MAX_ATTRIBUTES 16  /* attributes per mesh handled by the device path; more: DSA_ERR_NOT_IMPLEMENTED */
 #define DSA_NUM_STAGES 8
 
@@ -106,8 +110,12 @@ dsa_status dsa_batch_create(dsa_context *ctx, uint32_t n, const uint8_t *const *
 dsa_status dsa_batch_create_packed(dsa_context *ctx, uint32_t n, const uint8_t *blob, const uint64_t *offsets,
                                    dsa_batch **out);
 /* Enqueues the device-resident decode of the whole batch (compressed bytes in
- * HBM -> faces, attribute values and point maps in HBM) on the context's
- * stream.  Asynchronous. */
+ * HBM -> faces, attribute values and point maps in HBM).  Asynchronous.  A context
+ * created without a stream of the caller's owns two sets of streams and uses them in
+ * turn, so that a decode queued while the previous batch is still running starts beside
+ * that batch's tail instead of behind it (two device-resident batches in flight); a
+ * context created on a caller's stream runs every decode in that stream's order.
+ * Decoding the same batch again waits for its previous decode. */
 dsa_status dsa_batch_decode(dsa_batch *batch);
 /* Waits for the decode (and for a download queued with dsa_batch_download) and collects
  * the per-mesh results.  Waits for this batch only: another batch of the same context may
@@ -175,7 +183,10 @@ dsa_status dsa_batch_copy_metadata(const dsa_batch *batch, uint32_t mesh, uint8_
 
 /* Diagnostics for the parity tests: intermediate products of the path.
  * what: 0 opposite[3F], 1 corner_to_vertex[3F], 2 data_to_corner[entries], 3 vertex_to_data[vertices],
- *       4 uint32[12] shader-clock deltas between kernel phases. */
+ *       4 uint32[20] clocks recorded by the per-mesh kernels (s_memtime deltas between phases; [13..17] ticks, start and
+ *         duration of the connectivity and the traversal wave in s_memrealtime ticks: readable for failed meshes too),
+ *       5 uint32[DSA_MAX_ATTRIBUTES][4] per attribute {symbol source, alphabet size, rANS precision bits, rANS payload bytes},
+ *       6 the traversal trace of a -DDSA_TRAV_TRACE build. */
 dsa_status dsa_batch_copy_debug(const dsa_batch *batch, uint32_t mesh, int what, void *dst, size_t dst_bytes, size_t *written);
 
 /* Per-stage device time of the last dsa_batch_decode, in ms (HIP events on the
@@ -183,6 +194,13 @@ dsa_status dsa_batch_copy_debug(const dsa_batch *batch, uint32_t mesh, int what,
  * static strings. */
 dsa_status dsa_context_set_profiling(dsa_context *ctx, int enabled);
 dsa_status dsa_batch_stage_times(const dsa_batch *batch, float ms[DSA_NUM_STAGES], const char *names[DSA_NUM_STAGES]);
+/* Durations of the step's main kernels, each from an event pair of its own on the stream it was launched on (profiling
+ * enabled): what a row of `rocprofv3 --kernel-trace --stats` shows for that kernel.  *count receives how many kernels
+ * were timed in the last decode; at most `capacity` entries of ms[] / names[] (static strings) are written. */
+dsa_status dsa_batch_kernel_times(const dsa_batch *batch, float *ms, const char **names, uint32_t capacity, uint32_t *count);
+/* Releases what the context keeps between calls: arenas, pinned mirrors and descriptor zones of freed batches, the
+ * encoder's lanes (device buffers + pinned staging).  The library does this itself when an allocation fails. */
+dsa_status dsa_context_trim(dsa_context *ctx);
 
 /* ------------------------------------------------------------------ encode direction
  * Drop-in for DracoEncoder.Encode(BinaryWriter, Config, PointCloud, attributes)   src/Draco/IO/DracoEncoder.cs:22-41

@@ -778,3 +778,55 @@ def test_tag_streams_on_a_wave_of_their_own(ctx):
         tagged += int((info[:, 0] == 0).sum())
     assert tagged >= 20          # source 0 = tagged
     b.close()
+
+
+def test_decodes_alternate_between_the_two_stream_sets(ctx):
+    """A context owns two sets of streams and gives every decode the next one: two batches decoded in turn without waiting in
+    between (the sustained leg of bench.py), and the same batch decoded twice in a row (the second waits for the first), all end
+    equal to the oracle."""
+    sets = []
+    for seed in (5, 6):
+        streams = []
+        for kind, nx, ny in KINDS:
+            pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, seed)
+            streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(predictive_connectivity=2 * (seed & 1))))
+        sets.append(streams)
+    pair = [dsa.Batch(ctx, sets[0]), dsa.Batch(ctx, sets[1])]
+    for k in range(7):
+        pair[k % 2].decode(wait=False)
+    pair[0].decode(wait=False)           # the same batch again, on the other set: ordered behind its previous decode
+    for b in pair:
+        b.wait()
+    for b, streams in zip(pair, sets):
+        for i, s in enumerate(streams):
+            assert b.status(i) == 0, (i, b.mesh_info(i).detail)
+            assert_same(b.result(i), oracle.decode(s), b, i)
+        b.close()
+
+
+def test_the_bench_batch_at_full_size(ctx):
+    """BASELINE.json configs[2] as bench.py times it: 4096 x 65 536-triangle meshes in ONE batch.  Kernel selection depends on the
+    batch size (k_chain above 2048 meshes, k_predict_oct_streams + the gated late symbols from 3584), so the kernels of the
+    headline number are only exercised at this size: 130 meshes spread over the batch, with its first and its last, are compared
+    with the oracle bit for bit, every mesh must have succeeded on the fast kernels, and the crowded-batch kernels must be the
+    ones that ran."""
+    n = 4096
+    blob, offsets = synth.make_batch(synth.GRID, 128, 256, 1000, n, normals=True, uvs=True)
+    ctx.set_profiling(True)
+    try:
+        b = dsa.Batch(ctx, blob=blob, offsets=offsets)
+        b.decode()
+        kernels = b.kernel_times()
+    finally:
+        ctx.set_profiling(False)
+    assert kernels.get("k_chain", 0) > 0 and kernels.get("k_predict_oct_streams", 0) > 0 and "k_traverse" not in kernels, kernels
+    assert all(b.status(i) == 0 for i in range(n))
+    assert all(b.mesh_info(i).decode_path == 0 for i in range(0, n, 37))
+    picks = sorted(set([0, n - 1] + [int(x) for x in np.linspace(0, n - 1, 128)]))
+    for i in picks:
+        s = bytes(blob[int(offsets[i]):int(offsets[i + 1])])
+        ref = oracle.decode(s)
+        assert ref.num_faces == 65536
+        assert_same(b.result(i), ref)
+    b.close()
+    ctx.trim()          # 26 GB of arena go back before the next test

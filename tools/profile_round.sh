@@ -3,11 +3,11 @@
 #   bash tools/profile_round.sh <tag>      ->  gpurun_out/<tag>_{bench.json,kernel_stats.csv,timeline.txt,sq_counters.txt,traffic.json}
 # rocprofv3 is given the program itself (python bench.py ...), counters in passes of their own.
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-encode --no-end-to-end --no-pool --check 0 --scaling weak"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-encode --no-end-to-end --no-pool --no-sustained --check 0 --scaling weak"
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
 echo "bench done"
