@@ -17,6 +17,7 @@
 
 #include "../../include/draco_mi355x.h"
 #include "dsa_kernels.h"
+#include "dsa_seams.h"
 #include "dsa_general.h"
 #include "dsa_host_parse.h"
 #include "dsa_host_util.h"
@@ -84,6 +85,7 @@ struct StreamSet {
   hipStream_t stream4 = nullptr;     // early attributes: symbols, prediction, dequantisation (dispatch priority)
   hipEvent_t ev_join3 = nullptr, ev_trav = nullptr, ev_maps = nullptr, ev_early = nullptr, ev_flips = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_conn = nullptr;
+  hipEvent_t ev_seambits = nullptr, ev_tables = nullptr, ev_att = nullptr;      // fast seam path: seam bits decoded, seam tables built, attribute traversals done
   bool own_stream = false;
   hipError_t create(hipStream_t user, int least, int greatest) {
     // Dispatch priorities (numerically lower = higher): the stream of the per-mesh chain above the stream of the early attributes
@@ -94,12 +96,12 @@ struct StreamSet {
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&stream4, hipStreamNonBlocking, (least + greatest) / 2);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, least);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking);
-    for (hipEvent_t *ev : {&ev_join3, &ev_trav, &ev_maps, &ev_flips, &ev_early, &ev_fork, &ev_join, &ev_conn})
+    for (hipEvent_t *ev : {&ev_join3, &ev_trav, &ev_maps, &ev_flips, &ev_early, &ev_fork, &ev_join, &ev_conn, &ev_seambits, &ev_tables, &ev_att})
       if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     return e;
   }
   void destroy() {
-    for (hipEvent_t *ev : {&ev_join3, &ev_trav, &ev_maps, &ev_flips, &ev_early, &ev_fork, &ev_join, &ev_conn}) { if (*ev) (void)hipEventDestroy(*ev); *ev = nullptr; }
+    for (hipEvent_t *ev : {&ev_join3, &ev_trav, &ev_maps, &ev_flips, &ev_early, &ev_fork, &ev_join, &ev_conn, &ev_seambits, &ev_tables, &ev_att}) { if (*ev) (void)hipEventDestroy(*ev); *ev = nullptr; }
     for (hipStream_t *s : {&stream2, &stream3, &stream4}) { if (*s) (void)hipStreamDestroy(*s); *s = nullptr; }
     if (own_stream && stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
@@ -147,7 +149,7 @@ struct dsa_batch {
   uint64_t out_base = 0, out_bytes = 0;   // the output block: faces, attribute values and point maps of every mesh
   uint32_t max_faces = 0, max_vertices = 0, max_atts = 0, max_att_data = 0;
   uint64_t sum_vertices = 0;
-  bool any_general = false, any_valence = false;
+  bool any_general = false, any_valence = false, any_seamed = false;
   bool decoded = false, collected = false;
   hipEvent_t ev[DSA_NUM_STAGES + 1] = {};
   hipEvent_t ev_sym[2] = {};
@@ -281,6 +283,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
     b->sum_vertices = 0;
     b->any_general = false;
     b->any_valence = false;
+    b->any_seamed = false;
     for (uint32_t i = 0; i < n; ++i) {
       HostMesh &h = b->host[i];
       MeshLayout &L = b->layouts[i];
@@ -299,6 +302,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
       b->max_att_data = std::max<uint32_t>(b->max_att_data, h.num_att_data);
       b->any_general = b->any_general || h.general;
       b->any_valence = b->any_valence || (h.valence && !h.general);
+      b->any_seamed = b->any_seamed || (h.seamed && !h.general);
     }
     // pool for the cumulative tables of large-alphabet streams (bump-allocated by k_locate)
     {
@@ -555,6 +559,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     while (lpm < b->max_att_data) lpm *= 2;
     const uint32_t per_wave = WAVE / lpm;
     hipLaunchKernelGGL(dsa::k_conn_checks, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, lpm);
+    if (b->any_seamed) HIP_TRY(ctx, hipEventRecord(S.ev_seambits, st3));      // the seam bits of the meshes with corner attributes are stored
   }
   {
     // the flip bits of GeometricNormal attributes (one serial rABS stream per attribute), beside everything else
@@ -562,6 +567,8 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     while (lpm < na) lpm *= 2;
     const uint32_t per_wave = WAVE / lpm;
     hipLaunchKernelGGL(dsa::k_flip_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, lpm);
+    // and the orientation bits of TexCoordsPortable attributes, the same way
+    hipLaunchKernelGGL(dsa::k_orient_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, lpm);
     HIP_TRY(ctx, hipEventRecord(S.ev_flips, st3));
   }
   // parallelogram operands: by the traversal waves themselves when the batch keeps the machine busy anyway, by an
@@ -571,7 +578,9 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // connectivity and traversal of a mesh by one wave (k_chain) unless DSA_CHAIN=0 asks for the two kernels: as two kernels,
   // the slots the connectivity waves leave go to waiting entropy-decode waves and most traversal waves start late
   // (a small batch leaves slots free anyway, and is quicker with the faces converted beside the traversal)
-  const bool chain = chain_choice >= 0 ? chain_choice != 0 : n > 2048;       // measured: equal at 2048, 1.3 ms slower at 1024, 4 ms faster at 4096
+  // (a batch with corner attributes runs the two kernels: the tables of the seamed attributes are built between them, so that
+  // their symbols and their traversals start beside the position traversal instead of behind it)
+  const bool chain = (chain_choice >= 0 ? chain_choice != 0 : n > 2048) && !b->any_seamed;       // measured: equal at 2048, 1.3 ms slower at 1024, 4 ms faster at 4096
   auto launch_faces = [&]() -> hipError_t {      // faces as point ids + link census need the connectivity: third stream
     hipError_t e = hipEventRecord(S.ev_trav, st);
     if (e == hipSuccess) e = hipStreamWaitEvent(st3, S.ev_trav, 0);
@@ -593,6 +602,20 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     k_end(KT_CONNECTIVITY, st);
     HIP_TRY(ctx, launch_faces());                      // beside the traversal
+    if (b->any_seamed) {
+      // corner attributes: seam edges, attribute vertices and points per corner from the connectivity and the seam bits; then, beside
+      // the position traversal, the traversal of every seamed attribute on its own table (third stream) and its symbols (below)
+      HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_seambits, 0));
+      k_begin(KT_SEAM_TABLES, st);
+      hipLaunchKernelGGL(dsa::k_seam_tables, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+      k_end(KT_SEAM_TABLES, st);
+      HIP_TRY(ctx, hipEventRecord(S.ev_tables, st));
+      HIP_TRY(ctx, hipStreamWaitEvent(st3, S.ev_tables, 0));
+      k_begin(KT_TRAVERSE_ATT, st3);
+      hipLaunchKernelGGL(dsa::k_traverse_att, dim3(n, std::max<uint32_t>(1, b->max_att_data)), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+      k_end(KT_TRAVERSE_ATT, st3);
+      HIP_TRY(ctx, hipEventRecord(S.ev_att, st3));
+    }
     HIP_TRY(ctx, mark());
     const uint32_t per = (n + (uint32_t)trav_split - 1) / (uint32_t)trav_split;
     k_begin(KT_TRAVERSE, st);
@@ -675,6 +698,10 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     launch_symbols(st4, lane_flags | SYM_EARLY_ONLY | early_fuse);
     launch_symbols(st2, lane_flags | SYM_LATE_ONLY);
   } else launch_symbols(st2, lane_flags | early_fuse);
+  if (b->any_seamed) {       // the symbols of corner attributes: their entry counts are k_seam_tables'
+    HIP_TRY(ctx, hipStreamWaitEvent(st2, S.ev_tables, 0));
+    launch_symbols(st2, lane_flags | SYM_CORNER);
+  }
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[1], st2));
   HIP_TRY(ctx, hipEventRecord(S.ev_join, st2));           // corrections of the late attributes (without the split: of every attribute) are ready
   // attributes whose prediction needs no traversal data (difference, octahedral delta) are finished on this stream,
@@ -718,6 +745,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   }
   HIP_TRY(ctx, mark());
   HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_join, 0));   // join: corrections are ready
+  if (b->any_seamed) HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_att, 0));      // join: orders and operands of the seamed attributes
   if (b->any_general) HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_join3, 0));   // join: the general path's integers are ready
   HIP_TRY(ctx, mark());
 #ifdef DSA_EXPERIMENTS
@@ -741,10 +769,20 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     const uint32_t gv = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 1023) / 1024, 64));     // two dependent gathers per vertex: many short threads
     hipLaunchKernelGGL(dsa::k_vertex_positions, dim3(gv, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_predict_geometric, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+    // TexCoordsPortable attributes: what depends on the mesh and the positions for every entry at once, then the chain over the
+    // decoded texture coordinates, one lane per attribute
+    hipLaunchKernelGGL(dsa::k_texcoords_prepare, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+    k_begin(KT_TEXCOORDS, st);
+    hipLaunchKernelGGL(dsa::k_texcoords, dim3((n + WAVE - 1) / WAVE, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+    k_end(KT_TEXCOORDS, st);
   }
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
     hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags);
+  }
+  if (b->any_seamed) {       // point -> entry maps of the meshes with corner attributes, from the corners
+    const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
+    hipLaunchKernelGGL(dsa::k_seam_maps, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   }
   HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_maps, 0));
   hipLaunchKernelGGL(dsa::k_seal, dim3((n + 255) / 256), dim3(256), 0, st, b->d_descs, n);

@@ -23,6 +23,7 @@ struct HostMesh {
   uint32_t faces = 0, enc_vertices = 0, split_symbols = 0, splits = 0, num_att_data = 0;
   bool general = false;   // valence traversal or corner attributes: decoded by k_general
   bool valence = false;   // valence-coded connectivity on the fast kernels (k_valence_lists in front of the connectivity waves)
+  bool seamed = false;    // corner-attribute decoders (attribute seams) on the fast kernels (k_seam_tables, k_traverse_att)
   uint32_t meta_off = 0, meta_len = 0;   // metadata block of the stream (flag 0x8000), for dsa_batch_copy_metadata
   std::vector<HostAttr> atts;
 };
@@ -189,14 +190,19 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m, bool want_gene
   if (!r.ok) return bad(ST_INVALID);
   if (ndec > DSA_MAX_ATT) return bad(ST_NOTIMPL);               // a valid stream, more attribute decoders than the device path carries
   bool corner_dec[DSA_MAX_ATT + 1] = {};
+  bool any_corner = false;
   if (!linear) for (uint32_t i = 0; i < ndec; ++i) {
     (void)r.u8();
     corner_dec[i] = r.u8() != 0;                                // MeshAttributeElementType: corner attribute
     const bool prediction_degree = r.u8() != 0;                 // MeshTraversalMethod
-    if (corner_dec[i] || prediction_degree) m.general = true;
+    any_corner = any_corner || corner_dec[i];
+    if (prediction_degree) m.general = true;
   }
+  // corner attributes (attribute seams): the fast kernels while the seam masks fit a byte per corner (seven attribute data and a mark)
+  if (any_corner && m.num_att_data > 7) m.general = true;
   const bool force_general = getenv("DSA_FORCE_GENERAL") != nullptr;   // tests: every Edgebreaker mesh through k_general
   if ((force_general || want_general) && !point_cloud) m.general = true;
+  m.seamed = any_corner && !m.general;
   for (uint32_t i = 0; i < ndec; ++i) {
     uint64_t k = r.varint();
     if (!r.ok) return bad(ST_INVALID);
@@ -241,9 +247,14 @@ static inline uint64_t layout_mesh(const HostMesh &h, uint64_t stream_len, MeshL
   L.splits = take(16ull * h.splits);
   L.vrank = take(4 * V); L.para = take(12 * V);
   L.faces = take_out(12 * F);
-  // general path: corner attributes carry up to 3F entries, and seams up to 3F points
-  const uint64_t P = (h.general && h.num_att_data > 0) ? std::max<uint64_t>(3 * F, V) : V;
+  // corner attributes carry up to 3F entries, and seams up to 3F points
+  const uint64_t P = ((h.general || h.seamed) && h.num_att_data > 0) ? std::max<uint64_t>(3 * F, V) : V;
   L.cap_points = (uint32_t)P;
+  if (h.seamed) {
+    const SeamLayout g = seam_layout(F, V, h.num_att_data, L.rec_compact != 0);
+    L.seam = take(g.total);
+    L.seam_bytes = g.total;
+  }
   if (h.general) {
     const GenLayout g = gen_layout(F, V, h.splits, h.num_att_data, stream_len);
     L.gen = take(g.total);
@@ -258,6 +269,7 @@ static inline uint64_t layout_mesh(const HostMesh &h, uint64_t stream_len, MeshL
     L.work[a] = take(4 * wcap); L.work_cap[a] = (uint32_t)wcap;
     L.out[a] = take_out(ocap); L.out_cap[a] = (uint32_t)(ocap > 0xFFFFFFFFu ? 0xFFFFFFFFu : ocap);
     L.map[a] = take_out(4 * P);
+    L.tc[a] = (h.faces != 0 && A.nc == 2 && (A.seq_type == 1 || A.seq_type == 2)) ? take(sizeof(TcPrep) * E) : 0;
   }
   return cur;
 }

@@ -63,8 +63,12 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uin
 #define SYM_WIDE 0x800u        // k_symbols_wide is part of the launch set (DSA_SYM_WIDE=0: its streams stay with the LDS tiers)
 #define SYM_EARLY_ONLY 0x100u
 #define SYM_LATE_ONLY 0x200u
+#define SYM_CORNER 0x1000u     // the launch for corner attributes (behind k_seam_tables, which counts their entries); every other launch skips them
+__device__ __forceinline__ bool att_is_late(const AttrDesc &a) { return (a.have_scheme && a.pred_kind != 0) || a.corner_data != 0; }
 __device__ __forceinline__ bool sym_filtered(const AttrDesc &a, uint32_t flags) {
-  const bool late = a.have_scheme && a.pred_kind != 0;      // parallelogram, geometric normal: after the traversal
+  if (a.corner_data != 0) return !(flags & SYM_CORNER);
+  if (flags & SYM_CORNER) return true;
+  const bool late = a.have_scheme && a.pred_kind != 0;      // parallelogram, geometric normal, texture coordinates: after the traversal
   return ((flags & SYM_EARLY_ONLY) && late) || ((flags & SYM_LATE_ONLY) && !late);
 }
 __device__ __forceinline__ uint64_t clk() { return __builtin_amdgcn_s_memtime(); }
@@ -177,6 +181,18 @@ template <> struct Rec<true> {
 };
 __device__ __forceinline__ uint32_t k_next(uint32_t k) { return k == 2u ? 0u : k + 1u; }
 __device__ __forceinline__ uint32_t k_prev(uint32_t k) { return k == 0u ? 2u : k - 1u; }
+
+// The per-attribute-data block of the fast seam path (SeamLayout) and the parallelogram operands an attribute's prediction reads:
+// the position table's, or those of the attribute's own corner table (k_traverse_att).
+__device__ __forceinline__ uint8_t *seam_block(uint8_t *arena, const MeshLayout &L, const SeamLayout &g, uint32_t d) {
+  return arena + L.seam + g.data + (uint64_t)d * g.data_stride;
+}
+__device__ __forceinline__ const uint32_t *att_para(uint8_t *arena, const MeshLayout &L, const MeshDesc *D, const AttrDesc &a) {
+  if (a.corner_data == 0) return (const uint32_t *)(arena + L.para);
+  const SeamLayout g = seam_layout(L.cap_faces, L.cap_vertices, D->num_att_data, L.rec_compact != 0);
+  return (const uint32_t *)(seam_block(arena, L, g, (uint32_t)a.corner_data - 1u) + g.para);
+}
+
 
 // =========================================================================
 // k_locate, k_locate_resume: one wave per mesh, lane 0 walks the stream (dsa_locate.h).  k_locate goes to the end of the stream
@@ -996,6 +1012,13 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
   uint32_t state = rb.state, off = rb.off, first = DSA_INVALID;
   const uint32_t p = rb.p;
   uint32_t i = 0;
+  // A mesh with corner-attribute decoders (seam scratch): every bit is wanted -- set bits are OR-ed into the attribute data's bit
+  // array (zeroed by k_init; this lane is its only writer), k_seam_tables hands them to the edges once the connectivity is there.
+  uint32_t *store = nullptr;
+  if (L.seam_bytes) {
+    const SeamLayout g = seam_layout(L.cap_faces, L.cap_vertices, D->num_att_data, L.rec_compact != 0);
+    store = (uint32_t *)(seam_block(arena, L, g, d) + g.bits);
+  }
   while (i < edges) {
     if (state < 4096 && off > 0) state = state * 256 + rb.buf[--off];
     if (p <= 16 && state >= 8192 && i + 8 <= edges) {
@@ -1014,8 +1037,12 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
     }
     const uint32_t quot = state >> 8, rem = state & 255u, xn = quot * p;
     const bool val = rem < p;
-    if (val) { first = i; break; }
-    state = state - xn - p;
+    if (val) {
+      if (first == DSA_INVALID) first = i;
+      if (!store) break;
+      store[i >> 5] |= 1u << (i & 31u);
+      state = xn + rem;                      // AnsDecoder.cs:49-52: the set bit's successor
+    } else state = state - xn - p;
     ++i;
   }
   D->seam_first[d] = first;
@@ -1051,6 +1078,21 @@ __global__ __launch_bounds__(256) void k_init(uint8_t *arena, const MeshLayout *
   if (L.cap_splits) {                    // topologySplitActiveCorners as a direct map: decoder symbol id -> corner
     uint32_t *split_map = (uint32_t *)(arena + L.fstamp);
     for (uint32_t f = tid; f < F; f += stride) split_map[f] = DSA_INVALID;
+  }
+  if (L.seam_bytes) {                    // fast seam path: per attribute data the seam bits (set bits are OR-ed in), the face marks and
+                                         // vertex -> entry of the attribute's traversal; per mesh the "touches a seam" flags
+    const uint32_t nad = (uint32_t)((L.seam_bytes - seam_layout(F, V, 0, L.rec_compact != 0).total) / seam_layout(F, V, 1, L.rec_compact != 0).data_stride);
+    const SeamLayout g = seam_layout(F, V, nad, L.rec_compact != 0);
+    uint32_t *vseam4 = (uint32_t *)(arena + L.seam + g.vseam);
+    for (uint32_t w4 = tid; w4 < (V + 3) / 4; w4 += stride) vseam4[w4] = 0;
+    for (uint32_t d = 0; d < nad; ++d) {
+      uint8_t *blk = seam_block(arena, L, g, d);
+      uint32_t *bits = (uint32_t *)(blk + g.bits), *fv4 = (uint32_t *)(blk + g.fvis);
+      int32_t *av2d = (int32_t *)(blk + g.v2d);
+      for (uint32_t w = tid; w < (3 * F / 2 + 31) / 32 + 4; w += stride) bits[w] = 0;
+      for (uint32_t w4 = tid; w4 < (F + 3) / 4; w4 += stride) fv4[w4] = 0;
+      for (uint32_t v = tid; v < 3 * F; v += stride) av2d[v] = -1;
+    }
   }
 }
 
@@ -1129,21 +1171,47 @@ __device__ __forceinline__ void para_operands_flat(uint32_t p, const uint32_t *f
 //     and their marks (as they are after the retired pairs), so a turn of the spiral costs no load until the next side's seed.
 #define TR_HIST_WORDS 32
 #define TR_NONE 0xFFFFFFFFu
+// The tables a traversal runs on: the position corner table of a mesh (trav_position) or the corner table of one of its attributes,
+// cut along the attribute's seams (trav_attribute: the "virtual mesh" k_seam_tables built -- records whose vertices are the
+// attribute's vertices and whose opposites end at the seams, so that DepthFirstTraverser.cs:9-99 over MeshAttributeCornerTable.cs is
+// the same wave program as over CornerTable.cs).
+struct TravIO {
+  const uint32_t *frec; uint32_t *d2c; int32_t *v2d; uint8_t *fvis, *vflag; uint32_t *stack, *para;
+  uint32_t F, NV, cap_entries, expect;     // expect: the entries a valid stream yields (one per encoded vertex / per attribute vertex)
+  int att_data;                            // -1: the position table
+};
+__device__ __forceinline__ TravIO trav_position(uint8_t *arena, const MeshLayout &L, const MeshDesc *D) {
+  TravIO io;
+  io.frec = (const uint32_t *)(arena + L.frec); io.d2c = (uint32_t *)(arena + L.d2c); io.v2d = (int32_t *)(arena + L.v2d);
+  io.fvis = arena + L.fvis; io.vflag = arena + L.vvis; io.stack = (uint32_t *)(arena + L.fstamp); io.para = (uint32_t *)(arena + L.para);
+  io.F = D->num_faces; io.NV = D->num_vertices; io.cap_entries = L.cap_vertices; io.expect = D->num_enc_vertices; io.att_data = -1;
+  return io;
+}
+__device__ __forceinline__ TravIO trav_attribute(uint8_t *arena, const MeshLayout &L, const MeshDesc *D, uint32_t d) {
+  const SeamLayout g = seam_layout(L.cap_faces, L.cap_vertices, D->num_att_data, L.rec_compact != 0);
+  uint8_t *blk = seam_block(arena, L, g, d);
+  TravIO io;
+  io.frec = (const uint32_t *)(blk + g.rec); io.d2c = (uint32_t *)(blk + g.d2c); io.v2d = (int32_t *)(blk + g.v2d);
+  io.fvis = blk + g.fvis; io.vflag = blk + g.vflag; io.stack = (uint32_t *)(blk + g.stack); io.para = (uint32_t *)(blk + g.para);
+  io.F = D->num_faces; io.NV = D->seam_nv[d]; io.cap_entries = 3u * L.cap_faces; io.expect = D->seam_nv[d]; io.att_data = (int)d;
+  return io;
+}
 template <bool CP>
-__device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t fuse_operands, unsigned long long *sh_tf, unsigned long long *sh_tv,
-                                              uint32_t *sh_hist) {
+__device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D, const TravIO &io, uint32_t fuse_operands, unsigned long long *sh_tf,
+                                              unsigned long long *sh_tv, uint32_t *sh_hist) {
   typedef Rec<CP> R;
   typedef typename R::Raw Raw;
   if (status_of(D) != ST_OK || D->encoder_type == 0 || D->general) return;   // point clouds have no connectivity; general meshes: k_general
-  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
-  uint32_t *d2c = (uint32_t *)(arena + L.d2c);
-  int32_t *v2d = (int32_t *)(arena + L.v2d);
-  uint8_t *fvis = arena + L.fvis;
-  uint8_t *vflag = arena + L.vvis;      // bit0 visited, bit1 on boundary
-  const uint32_t F = uni(D->num_faces), NV = uni(D->num_vertices);
+  const uint32_t *frec = io.frec;
+  uint32_t *d2c = io.d2c;
+  int32_t *v2d = io.v2d;
+  uint8_t *fvis = io.fvis;
+  uint8_t *vflag = io.vflag;            // bit0 visited, bit1 on boundary
+  const uint32_t F = uni(io.F), NV = uni(io.NV), cap_entries = uni(io.cap_entries), expect = uni(io.expect);
+  const bool position = io.att_data < 0;
   // DFS stack: the topology-split map of k_connectivity is dead by now (the faces output is being written by k_faces
   // meanwhile).  Only a face with two open sides pushes, and the last face cannot, so F entries always suffice.
-  uint32_t *stack = (uint32_t *)(arena + L.fstamp);
+  uint32_t *stack = io.stack;
   const uint32_t stack_cap = F;
   const uint32_t lane = lane_id();
   const uint64_t t_start = clk(), r_start = realclk();
@@ -1206,9 +1274,9 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
       const uint4 vv = R::vertices_of(frec, found);
       const uint32_t nv = uni(vv.y), pv = uni(vv.z);       // Next(corner 0) = corner 1, Previous = corner 2
       if (nv >= NV || pv >= NV) TR_FAIL(300);
-      { uint32_t uni_flag = uni((uint32_t)vflag[nv]); if (!(uni_flag & 1u)) { if (count >= L.cap_vertices) TR_FAIL(302); VISIT_SCALAR(nv, corner + 1, uni_flag); } }
+      { uint32_t uni_flag = uni((uint32_t)vflag[nv]); if (!(uni_flag & 1u)) { if (count >= cap_entries) TR_FAIL(302); VISIT_SCALAR(nv, corner + 1, uni_flag); } }
       WAIT_VM0();
-      { uint32_t uni_flag = uni((uint32_t)vflag[pv]); if (!(uni_flag & 1u)) { if (count >= L.cap_vertices) TR_FAIL(302); VISIT_SCALAR(pv, corner + 2, uni_flag); } }
+      { uint32_t uni_flag = uni((uint32_t)vflag[pv]); if (!(uni_flag & 1u)) { if (count >= cap_entries) TR_FAIL(302); VISIT_SCALAR(pv, corner + 2, uni_flag); } }
       WAIT_VM0();
     }
     uint32_t corner = uni(stack[sp - 1]);
@@ -1505,7 +1573,7 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
         const uint64_t kmask = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
         const uint64_t mA = __ballot(newA) & kmask, mB = __ballot(newB) & kmask;
         const uint32_t made = (uint32_t)__popcll(mA) + (uint32_t)__popcll(mB);
-        const bool retire = K >= 1 && count + made <= L.cap_vertices;
+        const bool retire = K >= 1 && count + made <= cap_entries;
         const uint32_t win_used = window;          // lanes that took part in this attempt
         have_prog = false;
         if (kind == 2) {
@@ -1602,7 +1670,7 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
       if (lane == 0) fvis[face] = 1;
       bool went_right = false;
       if (bits & 1u) {
-        if (count >= L.cap_vertices) TR_FAIL(302);
+        if (count >= cap_entries) TR_FAIL(302);
         VISIT_SCALAR(v, corner, bits & 2u);
         if (!(bits & 2u)) {
           if (rc == DSA_INVALID) TR_FAIL(303);
@@ -1637,7 +1705,8 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
     if (failed) break;
   }
   if (failed) return;
-  if (lane == 0) {
+  if (lane == 0 && !position) { if (count != expect) fail(D, ST_INVALID, 305); }
+  if (lane == 0 && position) {
     D->num_entries = count;
     D->dbg[5] = n_fail; D->dbg[6] = (uint32_t)(clk() - t_start);
     D->dbg[16] = (uint32_t)r_start; D->dbg[17] = (uint32_t)(realclk() - r_start);
@@ -1647,16 +1716,16 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
     D->dbg[0] = (uint32_t)(tp_acc[5] >> 4); D->dbg[1] = np_fast_hit; D->dbg[2] = np_dep; D->dbg[4] = np_head; D->dbg[13] = np_hist; D->dbg[14] = np_lin; D->dbg[15] = np_hand;
 #endif
     // a valid stream carries exactly one entry per encoded vertex (k_locate sized the symbol streams on that)
-    if (count != D->num_enc_vertices) fail(D, ST_INVALID, 305);
+    if (count != expect) fail(D, ST_INVALID, 305);
   }
   // Large batches: the wave that just produced the order also derives the parallelogram operands of its mesh, while
   // other meshes are still being traversed (small batches use the element-parallel k_para_operands instead).
   // Both passes below are chains of dependent gathers with independent iterations: written without branches (clamped
   // indices, selects) and four iterations at a time, so that four chains are in flight per lane.
-  if ((fuse_operands & 1u) && count == D->num_enc_vertices) {
+  if ((fuse_operands & 1u) && count == expect) {
     WAIT_VM0();
     __threadfence_block();
-    uint32_t *para = (uint32_t *)(arena + L.para);
+    uint32_t *para = io.para;
     for (uint32_t p0 = 0; p0 < count; p0 += 4 * WAVE) {
       uint32_t en[4], ep[4], eo[4];
 #pragma unroll
@@ -1672,7 +1741,8 @@ __device__ __forceinline__ void traverse_wave(uint8_t *arena, const MeshLayout &
     }
   }
   // ---- point -> entry map of every attribute (MeshTraversalSequencer.cs:33-50), from the order just produced
-  if (count == D->num_enc_vertices && NV) {
+  // (a mesh with corner attributes gets every map from k_seam_maps: its points are not its vertices)
+  if (position && !D->seam_fast && count == expect && NV) {
     WAIT_VM0();
     __threadfence_block();
     const uint32_t *vrank = (const uint32_t *)(arena + L.vrank);
@@ -1715,8 +1785,10 @@ __global__ __launch_bounds__(WAVE) void k_traverse(uint8_t *arena, const MeshLay
   __builtin_amdgcn_s_setprio(DSA_CHAIN_PRIO);   // critical path: issue ahead of the entropy-decode waves sharing the CU
   const uint32_t mesh = blockIdx.x;
   if (mesh >= n) return;
-  if (layouts[mesh].rec_compact) traverse_wave<true>(arena, layouts[mesh], &descs[mesh], fuse_operands, sh_tf, sh_tv, sh_hist);
-  else traverse_wave<false>(arena, layouts[mesh], &descs[mesh], fuse_operands, sh_tf, sh_tv, sh_hist);
+  if (status_of(&descs[mesh]) != ST_OK) return;
+  const TravIO io = trav_position(arena, layouts[mesh], &descs[mesh]);
+  if (layouts[mesh].rec_compact) traverse_wave<true>(arena, layouts[mesh], &descs[mesh], io, fuse_operands, sh_tf, sh_tv, sh_hist);
+  else traverse_wave<false>(arena, layouts[mesh], &descs[mesh], io, fuse_operands, sh_tf, sh_tv, sh_hist);
 }
 
 // k_chain: connectivity and traversal of a mesh by the same wave, back to back.  As two kernels the traversal's waves
@@ -1747,8 +1819,10 @@ __global__ __launch_bounds__(WAVE, 8) void k_chain(uint8_t *arena, const MeshLay
   for (uint32_t i = threadIdx.x; i < TR_SLOTS; i += WAVE) { sh_tf[i] = 0; sh_tv[i] = 0; }
   if (threadIdx.x < TR_HIST_WORDS) sh_hist[threadIdx.x] = 0;
   __syncthreads();
-  if (compact) traverse_wave<true>(arena, L, D, fuse_operands, sh_tf, sh_tv, sh_hist);
-  else traverse_wave<false>(arena, L, D, fuse_operands, sh_tf, sh_tv, sh_hist);
+  if (status_of(D) != ST_OK) return;
+  const TravIO io = trav_position(arena, L, D);
+  if (compact) traverse_wave<true>(arena, L, D, io, fuse_operands, sh_tf, sh_tv, sh_hist);
+  else traverse_wave<false>(arena, L, D, io, fuse_operands, sh_tf, sh_tv, sh_hist);
 }
 
 
@@ -1908,7 +1982,7 @@ __device__ __forceinline__ void finalize_attribute(uint8_t *arena, const MeshLay
 __device__ __forceinline__ void early_tail(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t flags) {
   if (!(flags & SYM_EARLY_FUSE) || D->general) return;
   const AttrDesc &a = D->att[ai];
-  if (a.have_scheme && a.pred_kind != 0) return;                 // late: waits for the traversal
+  if (att_is_late(a)) return;                                    // late: waits for the traversal
   WAIT_VM0();
   __threadfence_block();
   __syncthreads();
@@ -2479,14 +2553,13 @@ __global__ __launch_bounds__(WAVE) void k_register_gate() { asm volatile("v_mov_
 // The octahedral normal transform is decoded 64 entries per chunk with the corrections in registers
 // (readlane) and coalesced loads/stores; its step is a short scalar program.
 __device__ __forceinline__ uint32_t addmod(uint32_t a, uint32_t b, uint32_t m) { uint32_t r = a + b; return r >= m ? r - m : r; }
-
 // phase 0: schemes that need no traversal data (difference / octahedral delta) -- launched behind the symbol
 // kernels on their stream; phase 1: parallelogram schemes, after the traversal.
 __device__ __forceinline__ bool wrap_fast_ok(const AttrDesc &a, uint32_t flags);
 __device__ __forceinline__ bool pw_dequant_fused(const AttrDesc &a, uint32_t flags);
 #define OS_FLAG 16u   // the canonicalised octahedral delta is k_predict_oct_streams' (crowded batches)
 __device__ __forceinline__ bool oct_stream_eligible(const AttrDesc &a) {
-  return a.have_scheme && a.source != SRC_BYTES && a.pred_transform == 3 && a.pred_kind == 0 && a.num_entries != 0 && !a.early_done &&
+  return a.have_scheme && a.source != SRC_BYTES && a.pred_transform == 3 && a.pred_kind == 0 && a.corner_data == 0 && a.num_entries != 0 && !a.early_done &&
          a.oct_max_q >= 3 && a.oct_max_q < (1 << OCT_PK_MAX_BITS);      // the packed step's range; finer octahedra stay with k_predict
 }
 // The body of k_predict for one attribute on one wave (also the tail of an entropy-decode wave, see early_tail).
@@ -2496,8 +2569,8 @@ __device__ __forceinline__ void predict_wave(uint8_t *arena, const MeshLayout &L
   if (wrap_fast_ok(a, flags)) return;                    // k_predict_wrap
   if (lanes::ln_oct_eligible(a, flags)) return;          // k_predict_oct_lanes
   if ((flags & OS_FLAG) && oct_stream_eligible(a)) return;   // k_predict_oct_streams
-  if (a.pred_kind == 2) return;                                // k_predict_geometric
-  if ((a.pred_kind == 1) != (phase == 1)) return;
+  if (a.pred_kind == 2 || a.pred_kind == 3) return;            // k_predict_geometric, k_texcoords
+  if (att_is_late(a) != (phase == 1)) return;
   int32_t *w = (int32_t *)(arena + L.work[ai]);
   const uint32_t nc = a.nc_portable, entries = a.num_entries;
   const uint32_t lane = lane_id();
@@ -2507,7 +2580,7 @@ __device__ __forceinline__ void predict_wave(uint8_t *arena, const MeshLayout &L
     const int32_t mn = a.wrap_min, mx = a.wrap_max, max_dif = 1 + mx - mn;
     const uint32_t M = (uint32_t)max_dif;
     const bool para_mode = a.pred_kind == 1;
-    const uint32_t *para = (const uint32_t *)(arena + L.para);
+    const uint32_t *para = att_para(arena, L, D, a);
     // Every lane's prediction has the form  base + (o[ga] - o[gb])  with finished entries ga, gb (or none):
     //   lane 0:   base = o[p-1] (delta, or a parallelogram that contains entry p-1), o[next] for a parallelogram of
     //             three older entries, 0 for the first entry -- read from memory;
@@ -2832,7 +2905,7 @@ __device__ __forceinline__ bool pw_dequant_fused(const AttrDesc &a, uint32_t fla
   return wrap_fast_ok(a, flags) && a.seq_type == 2 && a.nc == a.nc_portable && a.q_bits >= 1 && a.q_bits <= 30;
 }
 __device__ __forceinline__ bool wrap_fast_ok(const AttrDesc &a, uint32_t flags) {
-  return (flags & PW_FLAG) && a.have_scheme && a.source != SRC_BYTES && a.pred_transform == 1 && a.nc_portable >= 1 && a.nc_portable <= 4 &&
+  return (flags & PW_FLAG) && a.have_scheme && a.source != SRC_BYTES && a.pred_transform == 1 && a.pred_kind != 3 && a.nc_portable >= 1 && a.nc_portable <= 4 &&
          (uint32_t)(1 + a.wrap_max - a.wrap_min) < (1u << 25) && a.num_entries != 0;
 }
 // inclusive wave64 prefix sum, one v_add with a DPP operand per step where the backend fuses them
@@ -2949,9 +3022,9 @@ __device__ __forceinline__ void predict_wrap_wave(int32_t *w, const uint32_t *pa
 
 __device__ __forceinline__ void predict_wrap_attribute(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t phase, uint32_t flags) {
   const AttrDesc &a = D->att[ai];
-  if (!wrap_fast_ok(a, flags) || (a.pred_kind == 1) != (phase == 1)) return;
+  if (!wrap_fast_ok(a, flags) || att_is_late(a) != (phase == 1)) return;
   int32_t *w = (int32_t *)(arena + L.work[ai]);
-  const uint32_t *para = (const uint32_t *)(arena + L.para);
+  const uint32_t *para = att_para(arena, L, D, a);
   const uint32_t e = a.num_entries, nc = a.nc_portable;
   const int32_t mn = a.wrap_min, mx = a.wrap_max;
   // quantised floats leave this kernel dequantised (k_finalize skips them)
@@ -2989,7 +3062,7 @@ __global__ __launch_bounds__(WAVE) void k_predict_wrap(uint8_t *arena, const Mes
 // One attribute's share of k_finalize for the threads (tid, tid + stride, ...): a 256-thread grid slice, or one wave.
 __device__ __forceinline__ void finalize_attribute(uint8_t *arena, const MeshLayout &L, const MeshDesc *D, uint32_t ai, uint32_t phase, uint32_t flags, uint32_t tid, uint32_t stride) {
   const AttrDesc &a = D->att[ai];
-  const bool late = D->general || (a.have_scheme && a.pred_kind != 0);
+  const bool late = D->general || att_is_late(a);
   if (late != (phase == 1)) return;
   if (!D->general && pw_dequant_fused(a, flags)) return;      // k_predict_wrap wrote the floats
   const int32_t *w = (const int32_t *)(arena + L.work[ai]);
@@ -3222,7 +3295,7 @@ __global__ __launch_bounds__(256) void k_faces(uint8_t *arena, const MeshLayout 
   const uint32_t *vrank = (const uint32_t *)(arena + L.vrank);
   int32_t *faces = (int32_t *)(arena + L.faces);
   const uint32_t NV = D->num_vertices;
-  const bool compact = L.rec_compact != 0;
+  const bool compact = L.rec_compact != 0, seam_fast = D->seam_fast != 0;
   // Every link k_connectivity makes sets two corners; a corner linked twice ("corner already has an
   // opposite", MeshEdgeBreakerDecoder.cs:254,272,314,392) leaves fewer linked corners than 2 x links.
   uint32_t linked = 0, bad = 0;
@@ -3231,6 +3304,7 @@ __global__ __launch_bounds__(256) void k_faces(uint8_t *arena, const MeshLayout 
     if (compact) { const Rec<true>::Raw r = Rec<true>::load(frec, f); vv = make_uint4(Rec<true>::vertex(r, 0), Rec<true>::vertex(r, 1), Rec<true>::vertex(r, 2), 0u); oo = make_uint4(Rec<true>::opp(r, 0), Rec<true>::opp(r, 1), Rec<true>::opp(r, 2), 0u); }
     else { const Rec<false>::Raw r = Rec<false>::load(frec, f); vv = r.v; oo = r.o; }
     linked += (oo.x != DSA_INVALID) + (oo.y != DSA_INVALID) + (oo.z != DSA_INVALID);
+    if (seam_fast) continue;               // points are not vertices there: k_seam_tables numbers them per corner
     if (vv.x < NV && vv.y < NV && vv.z < NV) {
       faces[3 * f] = (int32_t)vrank[vv.x]; faces[3 * f + 1] = (int32_t)vrank[vv.y]; faces[3 * f + 2] = (int32_t)vrank[vv.z];
     } else bad = 1;
@@ -3264,8 +3338,10 @@ __global__ __launch_bounds__(256) void k_seal(MeshDesc *descs, uint32_t n) {
   if (D->general) return;                              // the general path's phase 2 has compared its own census
   if (D->values_pending) { fail(D, ST_INVALID, 159); return; }          // (the walk of the attribute sections did not get to its end)
   if (__hip_atomic_load(&D->linked_corners, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != D->interior_corners) { fail(D, ST_INVALID, 263); return; }
-  // a seam among the coded bits (k_conn_checks): the attribute has a corner table of its own, which the general path builds
-  if (D->encoder_type != 0)
+  // a seam among the coded bits (k_conn_checks) of a mesh without seam scratch: the general path builds its tables.  (A mesh with
+  // corner-attribute decoders has the scratch, and k_seam_tables has used the bits of every attribute data -- those of a
+  // vertex-attribute decoder too, which split points as well: MeshEdgeBreakerDecoder.cs:537-638.)
+  if (D->encoder_type != 0 && !D->seam_fast)
     for (uint32_t d = 0; d < D->num_att_data; ++d)
       if (D->seam_first[d] < D->interior_corners / 2) { fail(D, ST_NOTIMPL, DSA_SITE_RETRY_GENERAL); return; }
 }

@@ -28,10 +28,17 @@ static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long 
 #define LOC_TAGS_LATER 1
 #undef RET
 #define RET 0
+// A corner attribute (a.corner_data != 0) has one entry per vertex of its own corner table, which only k_seam_tables knows (behind
+// the connectivity): its section is walked with the count open (`num_entries` = LOC_COUNT_OPEN).  That works for what carries its
+// own length -- a raw-coded symbol stream, the prediction data -- and sends anything else (raw bytes, tagged symbols, uncompressed
+// integers: their extent IS the count) to the general path.
+#define LOC_COUNT_OPEN 0xFFFFFFFFu
 __device__ __forceinline__ int locate_attribute_section(Rd &r, MeshDesc *D, AttrDesc &a, const MeshLayout &L, int ai, uint8_t *arena,
                                         uint32_t *s_cum, uint32_t *s_lut, uint32_t num_entries, BatchGlobals *G, int tags) {
   const uint8_t *s = r.p;
-  a.num_entries = num_entries;
+  const bool open = num_entries == LOC_COUNT_OPEN;
+  a.num_entries = open ? 0u : num_entries;
+  if (open && a.seq_type == 0) NOTIMPL(DSA_SITE_RETRY_GENERAL);
   if (a.seq_type == 0) {   // generic: raw bytes, SequentialAttributeDecoder.cs:75-86
     a.source = SRC_BYTES;
     a.nc_portable = a.nc;
@@ -44,7 +51,7 @@ __device__ __forceinline__ int locate_attribute_section(Rd &r, MeshDesc *D, Attr
   }
   uint32_t nc = a.seq_type == 3 ? 2u : a.nc;   // normals are (s,t) in portable form
   a.nc_portable = (uint8_t)nc;
-  uint64_t num_values = (uint64_t)num_entries * nc;
+  uint64_t num_values = open ? 1 : (uint64_t)num_entries * nc;      // (open: "some", the capacity is checked by k_seam_tables)
   REQUIRE(num_values <= L.work_cap[ai], 142);
   int method = (int8_t)r.u8();
   REQUIRE(r.ok && method >= -2 && method < 7, 143);
@@ -93,6 +100,7 @@ __device__ __forceinline__ int locate_attribute_section(Rd &r, MeshDesc *D, Attr
         REQUIRE(r.ok && size >= 1, 150);
         a.size_rans = (uint32_t)size;
       } else {
+        if (open) NOTIMPL(DSA_SITE_RETRY_GENERAL);
         a.source = SRC_TAGGED;
         a.precision_bits = 12;   // SymbolDecoding.cs:34: tag alphabet is 5 bits wide
         uint64_t ns = r.varint();
@@ -201,6 +209,7 @@ __device__ __forceinline__ int locate_attribute_section(Rd &r, MeshDesc *D, Attr
       a.num_symbols = 0;
     }
   } else {
+    if (open) NOTIMPL(DSA_SITE_RETRY_GENERAL);
     a.source = SRC_FIXED;
     uint32_t nb = r.u8();
     REQUIRE(r.ok && nb >= 1 && nb <= 4, 159);
@@ -217,13 +226,32 @@ __device__ __forceinline__ int locate_attribute_section(Rd &r, MeshDesc *D, Attr
     // need the general path's tables send the mesh there: the host decodes it again (site DSA_SITE_RETRY_GENERAL).
     if (D->encoder_type == 0) a.pred_kind = 0;
     else if (a.pred_transform == 1) {
-      if (method == 2 || method == 4 || method == 5) NOTIMPL(DSA_SITE_RETRY_GENERAL);
-      if (!(method == 0 || method == 1 || method == 6)) NOTIMPL(161);
-      a.pred_kind = method == 1 ? 1 : 0;
+      if (method == 2 || method == 4) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+      if (!(method == 0 || method == 1 || method == 5 || method == 6)) NOTIMPL(161);
+      a.pred_kind = method == 1 ? 1 : (method == 5 ? 3 : 0);
+      if (a.pred_kind == 3) {
+        // MeshPredictionSchemeTexCoordsPortableDecoder.cs:66-85: the orientation count and an rABS block of their deltas, in front of
+        // the transform data; the scheme needs two components and the portable positions (three) decoded before it
+        REQUIRE(nc == 2, 666);
+        int pa = -1;
+        for (int k = 0; k < ai; ++k) if (D->att[k].att_type == 0 && D->att[k].seq_type != 0) { pa = k; break; }
+        REQUIRE(pa >= 0 && D->att[pa].nc_portable == 3, 667);
+        if (D->att[pa].corner_data != 0) NOTIMPL(DSA_SITE_RETRY_GENERAL);      // positions with a corner table of their own: no encoder writes that
+        const int32_t num_or = (int32_t)r.u32();
+        REQUIRE(r.ok && num_or >= 0, 668);
+        Rabs rd;
+        uint32_t endp;
+        rd.start(s, L.stream_len, r.pos, &endp);
+        REQUIRE(rd.ok, 669);
+        a.off_flips = r.pos;
+        a.num_orient = (uint32_t)num_or;
+        r.pos = endp;
+      }
     } else {
       // GeometricNormal (MeshPredictionSchemeGeometricNormalDecoder.cs:44-82): predicted from the decoded positions, entry by entry
       // independently (k_predict_geometric); needs the portable positions before it in the same decoder
       a.pred_kind = method == 6 ? 2 : 0;
+      if (a.pred_kind == 2 && a.corner_data != 0) NOTIMPL(DSA_SITE_RETRY_GENERAL);    // normals with seams under GeometricNormal: general path
     }
     if (a.pred_transform == 1) {           // PredictionSchemeWrapDecodingTransform.cs:69-75
       a.wrap_min = (int32_t)r.u32();
@@ -436,11 +464,17 @@ __device__ inline void locate_attribute_headers(uint8_t *arena, const MeshLayout
       REQUIRE(!pos_seen, 125);
       pos_seen = true;
     }
-    if (element_type != 0) { REQUIRE(att_data_id >= 0 && traversal_method == 0, 126); NOTIMPL(127); }   // corner attributes (seams)
+    // Any other element type than "vertex" is a corner attribute (MeshEdgeBreakerDecoder.cs:666-701): the attribute's own corner
+    // table, cut along its seams.  The host sized the seam scratch for such a mesh (MeshLayout::seam).
+    if (element_type != 0) {
+      REQUIRE(att_data_id >= 0 && traversal_method == 0, 126);
+      if (L.seam_bytes == 0 || att_data_id >= 7) NOTIMPL(127);
+      D->corner_mask |= (uint16_t)(1u << att_data_id);
+      D->seam_fast = 1;
+    }
     if (traversal_method != 0) NOTIMPL(DSA_SITE_RETRY_GENERAL);                                     // prediction-degree traversal: general path (the host parse routes it there)
-    att_data_of[i] = att_data_id;
+    att_data_of[i] = element_type != 0 ? att_data_id : -1;
   }
-  (void)att_data_of;
   uint32_t natt = 0;
   uint32_t first_att[DSA_MAX_ATT + 1];
   for (uint32_t i = 0; i < ndec; ++i) {           // AttributesDecoder.cs:19-63 + controller :16-27
@@ -455,6 +489,7 @@ __device__ inline void locate_attribute_headers(uint8_t *arena, const MeshLayout
       REQUIRE(r.ok && a.att_type < 5 && a.data_type != 0 && a.data_type < 12 && a.nc != 0, 130);
       a.unique_id = (uint32_t)r.varint();
       a.decoder_id = (int8_t)i;
+      a.corner_data = (int8_t)((!point_cloud && i < ndec && att_data_of[i] >= 0) ? att_data_of[i] + 1 : 0);
     }
     for (uint32_t j = 0; j < (uint32_t)k; ++j) {
       AttrDesc &a = D->att[natt + j];
@@ -492,7 +527,7 @@ __device__ inline void locate_attribute_values(uint8_t *arena, const MeshLayout 
       // a tag stream ahead is left to k_tags -- unless this IS the attribute the walk stopped at and k_tags did not take it
       // (a stream it is not made for): then its tags are decoded here
       const bool again = mode == LOC_RESUME && i == i0 && ai == a0;
-      const int rc = locate_attribute_section(r, D, D->att[ai], L, (int)ai, arena, s_cum, s_lut, num_entries, G,
+      const int rc = locate_attribute_section(r, D, D->att[ai], L, (int)ai, arena, s_cum, s_lut, D->att[ai].corner_data ? LOC_COUNT_OPEN : num_entries, G,
                                               mode == LOC_WHOLE || again ? LOC_TAGS_HERE : LOC_TAGS_LATER);
       if (rc == 0) return;
       if (rc == 2) { D->resume_dec = (uint8_t)i; D->resume_att = (uint8_t)ai; D->resume_pos = at; D->values_pending = 1; return; }

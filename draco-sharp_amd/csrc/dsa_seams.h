@@ -1,0 +1,637 @@
+// draco-sharp_amd/csrc/dsa_seams.h
+// -----------------------------------------------------------------------------
+// Attribute seams on the wave-per-mesh kernels: corner-attribute decoders -- attributes with a
+// corner table of their own, the position table cut along the attribute's seams -- without the serial general path.
+//   MeshEdgeBreakerDecoder.cs:502-535   seam bits -> seam edges              k_conn_checks (the bits), k_seam_tables (the edges)
+//   MeshAttributeCornerTable.cs:19-155  attribute vertices per corner        k_seam_tables
+//   MeshEdgeBreakerDecoder.cs:537-638   points per corner                    k_seam_tables
+//   DepthFirstTraverser.cs:9-99 on the attribute's table                     k_traverse_att (= traverse_wave on the "virtual mesh")
+//   MeshTraversalSequencer.cs:33-50     point -> entry maps                  k_seam_maps
+//   MeshPredictionSchemeTexCoordsPortablePredictor.cs:46-150                 k_texcoords_prepare + k_texcoords (both kinds of mesh)
+// The idea: what makes an attribute's corner table different from the position table is (a) which opposites exist and (b) what the
+// vertex of a corner is.  k_seam_tables writes both into a second set of face records per seamed attribute; every kernel that
+// works from face records (traversal, parallelogram operands, wrap prediction) then runs on that "virtual mesh" unchanged.
+// Numbering attribute vertices and points is a prefix sum over the position vertices with a walk around the few vertices a seam or
+// the boundary touches; every other vertex owns exactly one of each.
+// -----------------------------------------------------------------------------
+#pragma once
+
+namespace dsa {
+
+template <bool CP>
+__device__ __forceinline__ uint32_t pos_swing_right(const uint32_t *frec, uint32_t c) {
+  const uint32_t o = Rec<CP>::get_o_plain(frec, qprev(c));
+  return o == DSA_INVALID ? DSA_INVALID : qprev(o);
+}
+// field k of the vertex word of a compact record: all ones -> id (the records of a virtual mesh start with every vertex field
+// "unset"; the fields of one word are set by different lanes)
+__device__ __forceinline__ void vrec_set_compact(uint32_t *rec, uint32_t c, uint32_t id) {
+  const uint32_t sh = 21u * (c & 3u);
+  const unsigned long long M = 0x1FFFFFull;
+  atomicAnd((unsigned long long *)rec + (size_t)(c >> 2) * 2, ((unsigned long long)(id & 0x1FFFFFu) << sh) | ~(M << sh));
+}
+
+#define SM_FAIL(code_, site_) { if (lane == 0) fail(D, (code_), (site_)); return; }
+#define SM_SYNC() { WAIT_VM0(); __threadfence_block(); }
+
+// One wave per mesh, behind the connectivity (k_connectivity) and the seam bits (k_conn_checks).
+template <bool CP>
+__device__ __forceinline__ void seam_tables_wave(uint8_t *arena, const MeshLayout &L, MeshDesc *D) {
+  typedef Rec<CP> R;
+  typedef typename R::Raw Raw;
+  const uint32_t lane = lane_id();
+  const uint32_t F = uni(D->num_faces), NVALL = uni(D->num_all_vertices), nad = uni((uint32_t)D->num_att_data);
+  const uint32_t cmask = uni((uint32_t)D->corner_mask), allmask = (1u << nad) - 1u;
+  const bool val = uni((uint32_t)D->traversal_type) == 2u;
+  if (nad == 0 || nad > 7 || F != L.cap_faces || NVALL > L.cap_vertices) SM_FAIL(ST_INVALID, 680);
+  const SeamLayout g = seam_layout(L.cap_faces, L.cap_vertices, nad, CP);
+  uint8_t *S = arena + L.seam;
+  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
+  const uint2 *vrec = (const uint2 *)(arena + L.vrec);
+  const uint8_t *pos_vflag = arena + L.vvis;                 // bit1: the vertex lies on the boundary (k_connectivity)
+  uint32_t *eseam32 = (uint32_t *)(S + g.eseam);
+  const uint8_t *eseam8 = S + g.eseam;                       // byte of corner c (quad coded) = eseam8[c]
+  uint8_t *vseam = S + g.vseam;
+  uint32_t *pbase = (uint32_t *)(S + g.pbase);
+  int32_t *c2p = (int32_t *)(arena + L.faces);
+  uint8_t *blk0 = seam_block(arena, L, g, 0);
+  uint32_t *list = (uint32_t *)(blk0 + g.d2c);               // seam vertices, dense (the traversal's entry -> corner: written later)
+#define SM_BLK(d_) (blk0 + (uint64_t)(d_) * g.data_stride)
+#define SM_VBASE(d_) ((uint32_t *)(SM_BLK(d_) + g.vbase))
+#define SM_REC(d_) ((uint32_t *)(SM_BLK(d_) + g.rec))
+  auto corner_ok = [&](uint32_t c) -> bool { return c < 4u * F && (c & 3u) != 3u; };
+
+  // ---- A. faces: which seam bit belongs to which corner (one bit per interior edge, at the lower of its two faces, in corner
+  // order: a prefix count), and from the bits the seam mask of that corner
+  {
+    uint32_t base = 0;
+    bool bad = false, weird = false;
+    for (uint32_t f0 = 0; f0 < F; f0 += WAVE) {
+      const uint32_t f = f0 + lane;
+      const bool live = f < F;
+      const Raw r = R::load(frec, live ? f : 0u);
+      uint32_t o[3], cnt = 0;
+      bool own[3];
+#pragma unroll
+      for (uint32_t k = 0; k < 3; ++k) {
+        o[k] = live ? R::opp(r, k) : DSA_INVALID;
+        const bool has = o[k] != DSA_INVALID;
+        if (has && !corner_ok(o[k])) { bad = true; o[k] = DSA_INVALID; }
+        if (has && (o[k] >> 2) == f) weird = true;           // a face glued to itself: the general path's business
+        own[k] = o[k] != DSA_INVALID && (o[k] >> 2) >= f;
+        cnt += own[k] ? 1u : 0u;
+      }
+      uint32_t total;
+      uint32_t idx = base + wave_excl_scan(cnt, &total);
+      base += total;
+      uint32_t word = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 3; ++k) {
+        uint32_t m = 0;
+        if (live && o[k] == DSA_INVALID) m = 0xFFu;          // boundary edges are seams of every attribute data (:516-522)
+        else if (own[k]) {
+          for (uint32_t d = 0; d < nad; ++d) m |= ((((const uint32_t *)(SM_BLK(d) + g.bits))[idx >> 5] >> (idx & 31u)) & 1u) << d;
+          ++idx;
+        }
+        word |= m << (8u * k);
+      }
+      if (live) eseam32[f] = word;
+    }
+    if (__ballot(bad)) SM_FAIL(ST_INVALID, 681);
+    if (__ballot(weird)) SM_FAIL(ST_NOTIMPL, DSA_SITE_RETRY_GENERAL);
+    if (2u * base != D->interior_corners) SM_FAIL(ST_INVALID, 263);      // (the census of k_faces / k_seal, seen from here)
+  }
+  SM_SYNC();
+  // ---- B. faces: the other side of every edge takes the mask over; vertices at the ends of cut edges are marked; the virtual
+  // records of the corner-attribute data: opposites cut, vertices unset
+  for (uint32_t f0 = 0; f0 < F; f0 += WAVE) {
+    const uint32_t f = f0 + lane;
+    if (f >= F) continue;
+    const Raw r = R::load(frec, f);
+    uint32_t word = eseam32[f];
+    uint32_t o[3], v[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k) {
+      o[k] = R::opp(r, k); v[k] = R::vertex(r, k);
+      if (o[k] != DSA_INVALID && corner_ok(o[k]) && (o[k] >> 2) < f) word |= (uint32_t)eseam8[o[k]] << (8u * k);
+    }
+    eseam32[f] = word;
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k) {
+      const uint32_t m = (word >> (8u * k)) & 0xFFu;
+      if (m == 0xFFu || (m & allmask)) {                     // the edge opposite corner k: its end points are at the other two corners
+        const uint32_t va = v[k_next(k)], vb = v[k_prev(k)];
+        if (va < NVALL) vseam[va] = 1;
+        if (vb < NVALL) vseam[vb] = 1;
+      }
+    }
+    for (uint32_t d = 0; d < nad; ++d) {
+      if (!((cmask >> d) & 1u)) continue;
+      uint32_t oc[3];
+#pragma unroll
+      for (uint32_t k = 0; k < 3; ++k) oc[k] = ((word >> (8u * k + d)) & 1u) ? DSA_INVALID : o[k];
+      uint32_t *rec = SM_REC(d);
+      if (CP) {
+        const uint64_t oo = Rec<true>::pack(oc[0], oc[1], oc[2]) | (~0ull << 63);
+        ((uint4 *)rec)[f] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, (uint32_t)oo, (uint32_t)(oo >> 32));
+      } else {
+        ((uint4 *)rec)[(size_t)f * 2] = make_uint4(DSA_INVALID, DSA_INVALID, DSA_INVALID, 0u);
+        ((uint4 *)rec)[(size_t)f * 2 + 1] = make_uint4(oc[0], oc[1], oc[2], 0u);
+      }
+    }
+  }
+  SM_SYNC();
+  // ---- P0. vertices in order: one attribute vertex and one point each, unless a seam or the boundary touches the vertex (those go
+  // on a list) or it has no corner at all (none)
+  uint32_t nlist = 0;
+  {
+    bool bad = false;
+    for (uint32_t v0 = 0; v0 < NVALL; v0 += WAVE) {
+      const uint32_t v = v0 + lane;
+      const bool live = v < NVALL;
+      const uint32_t x = live ? vrec[v].x : DSA_INVALID;
+      const uint32_t lm = x == DSA_INVALID ? DSA_INVALID : (val ? (x & 0x1FFFFFu) : x);
+      if (lm != DSA_INVALID && !corner_ok(lm)) bad = true;
+      const bool has = lm != DSA_INVALID;
+      const bool seamv = has && vseam[live ? v : 0u] != 0;
+      const uint64_t m = __ballot(seamv);
+      if (nlist + (uint32_t)__popcll(m) > 3u * F) { bad = true; break; }      // (more vertices with a corner than corners)
+      if (seamv) list[nlist + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
+      nlist += (uint32_t)__popcll(m);
+      if (live && !seamv) {
+        const uint32_t one = has ? 1u : 0u;
+        for (uint32_t d = 0; d < nad; ++d) if ((cmask >> d) & 1u) SM_VBASE(d)[v] = one;
+        pbase[v] = one;
+      }
+    }
+    if (__ballot(bad)) SM_FAIL(ST_INVALID, 651);
+  }
+  SM_SYNC();
+  // ---- P1. the listed vertices: a walk around each counts the cuts per attribute data (k_d cuts make max(k_d, 1) attribute
+  // vertices), then the cuts that separate points
+  {
+    bool bad = false, long_ring = false;
+    for (uint32_t i0 = 0; i0 < nlist; i0 += WAVE) {
+      const uint32_t i = i0 + lane;
+      if (i >= nlist) continue;
+      const uint32_t v = list[i];
+      const uint32_t x = vrec[v].x, lm = val ? (x & 0x1FFFFFu) : x;
+      const bool open = (pos_vflag[v] & 2u) != 0;
+      uint64_t cnt_lo = 0, cnt_hi = 0;                       // eight 16-bit counters
+      uint32_t c = lm, len = 0;
+      for (;;) {
+        const uint32_t xm = (uint32_t)eseam8[qnext(c)] & allmask;
+        cnt_lo += (uint64_t)(xm & 1u) | ((uint64_t)((xm >> 1) & 1u) << 16) | ((uint64_t)((xm >> 2) & 1u) << 32) | ((uint64_t)((xm >> 3) & 1u) << 48);
+        cnt_hi += (uint64_t)((xm >> 4) & 1u) | ((uint64_t)((xm >> 5) & 1u) << 16) | ((uint64_t)((xm >> 6) & 1u) << 32) | ((uint64_t)((xm >> 7) & 1u) << 48);
+        if (++len > 60000u) { long_ring = true; break; }     // (the counters are 16 bits wide: such a fan goes to the general path)
+        const uint32_t nx = pos_swing_right<CP>(frec, c);
+        if (nx == DSA_INVALID || nx == lm) break;
+        if (!corner_ok(nx)) { bad = true; break; }
+        c = nx;
+      }
+      if (bad || long_ring) continue;
+      uint32_t kmask = 0, E = open ? allmask : 0u;
+      for (uint32_t d = 0; d < nad; ++d) {
+        const uint32_t k = (uint32_t)(((d < 4 ? cnt_lo : cnt_hi) >> (16u * (d & 3u))) & 0xFFFFu);
+        if ((cmask >> d) & 1u) SM_VBASE(d)[v] = k > 1u ? k : 1u;
+        if (k >= 1u) kmask |= 1u << d;
+        if (k >= 2u) E |= 1u << d;
+      }
+      // points: cuts of the data in E -- on the boundary every cut separates two attribute vertices, inside only a datum with two
+      // or more cuts has different vertices on the two sides of a cut
+      uint32_t kE = 0;
+      if (E) {
+        c = lm;
+        for (uint32_t step = 0; step < len; ++step) {
+          if ((uint32_t)eseam8[qnext(c)] & E) ++kE;
+          const uint32_t nx = pos_swing_right<CP>(frec, c);
+          if (nx == DSA_INVALID || nx == lm) break;
+          c = nx;
+        }
+      }
+      pbase[v] = kE > 1u ? kE : 1u;
+      vseam[v] = (uint8_t)(kmask | 0x80u);                   // non-zero: "listed"; bit d (< 7): attribute data d has a cut here
+    }
+    if (__ballot(bad)) SM_FAIL(ST_INVALID, 651);
+    if (__ballot(long_ring)) SM_FAIL(ST_NOTIMPL, DSA_SITE_RETRY_GENERAL);
+  }
+  SM_SYNC();
+  // ---- P2. counts -> first ids (exclusive prefix sums over the vertices, one per attribute data and one for the points); the
+  // boundary flag of every attribute vertex (MeshAttributeCornerTable.cs IsOnBoundary: a cut or the mesh boundary at the vertex)
+  uint32_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ptotal = 0;
+  for (uint32_t v0 = 0; v0 < NVALL; v0 += WAVE) {
+    const uint32_t v = v0 + lane;
+    const bool live = v < NVALL;
+    const uint32_t km = live ? (uint32_t)vseam[v] : 0u;
+    for (uint32_t d = 0; d < nad; ++d) {
+      if (!((cmask >> d) & 1u)) continue;
+      uint32_t *vb = SM_VBASE(d);
+      const uint32_t n = live ? vb[v] : 0u;
+      uint32_t total;
+      const uint32_t first = totals[d] + wave_excl_scan(n, &total);
+      totals[d] += total;
+      if (live) vb[v] = first;
+      if (first + n <= 3u * F) {
+        uint8_t *avf = SM_BLK(d) + g.vflag;
+        const uint8_t fl = ((km >> d) & 1u) ? 2 : 0;
+        for (uint32_t j = 0; j < n; ++j) avf[first + j] = fl;
+      }
+    }
+    const uint32_t n = live ? pbase[v] : 0u;
+    uint32_t total;
+    const uint32_t first = ptotal + wave_excl_scan(n, &total);
+    ptotal += total;
+    if (live) pbase[v] = first;
+  }
+  for (uint32_t d = 0; d < nad; ++d) if (((cmask >> d) & 1u) && totals[d] > 3u * F) SM_FAIL(ST_INVALID, 650);
+  if (ptotal > L.cap_points) SM_FAIL(ST_INVALID, 662);
+  SM_SYNC();
+  // ---- P3. the listed vertices again: ids per corner by a walk.  With cum = cuts met so far (the corner's own left edge
+  // included) and s = 1 if the walk starts on a cut: attribute vertex = first + (cum - s) mod n (RecomputeVertices numbers from the
+  // corner behind the last cut, :116-152); point = first + (cum_E - s_E) mod n_P, where the count starts at the corner
+  // AssignPointsToCorners starts from (:559-590: the first corner whose attribute vertex differs from the left-most corner's, for
+  // the first datum that has such a corner; the left-most corner itself on the boundary)
+  {
+    bool bad = false;
+    for (uint32_t i0 = 0; i0 < nlist; i0 += WAVE) {
+      const uint32_t i = i0 + lane;
+      if (i >= nlist) continue;
+      const uint32_t v = list[i];
+      const uint32_t x = vrec[v].x, lm = val ? (x & 0x1FFFFFu) : x;
+      const bool open = (pos_vflag[v] & 2u) != 0;
+      uint32_t first[8], n[8];
+      uint32_t E = open ? allmask : 0u, dstar = 0xFFu;
+      for (uint32_t d = 0; d < 8; ++d) { first[d] = 0; n[d] = 1; }
+      for (uint32_t d = 0; d < nad; ++d) if ((cmask >> d) & 1u) first[d] = SM_VBASE(d)[v];
+      // counts again from the walk (cheaper than a second array): k_d, and from them n_d, E, d*
+      uint64_t cnt_lo = 0, cnt_hi = 0;
+      uint32_t c = lm, len = 0;
+      for (;;) {
+        const uint32_t xm = (uint32_t)eseam8[qnext(c)] & allmask;
+        cnt_lo += (uint64_t)(xm & 1u) | ((uint64_t)((xm >> 1) & 1u) << 16) | ((uint64_t)((xm >> 2) & 1u) << 32) | ((uint64_t)((xm >> 3) & 1u) << 48);
+        cnt_hi += (uint64_t)((xm >> 4) & 1u) | ((uint64_t)((xm >> 5) & 1u) << 16) | ((uint64_t)((xm >> 6) & 1u) << 32) | ((uint64_t)((xm >> 7) & 1u) << 48);
+        ++len;
+        const uint32_t nx = pos_swing_right<CP>(frec, c);
+        if (nx == DSA_INVALID || nx == lm || len > 60000u) break;
+        c = nx;
+      }
+      for (uint32_t d = 0; d < nad; ++d) {
+        const uint32_t k = (uint32_t)(((d < 4 ? cnt_lo : cnt_hi) >> (16u * (d & 3u))) & 0xFFFFu);
+        n[d] = k > 1u ? k : 1u;
+        if (k >= 2u) { E |= 1u << d; if (!open && dstar == 0xFFu) dstar = d; }
+      }
+      // where the points start: s_E = cuts of E up to and including the start corner
+      uint32_t sE = 1, nP = 1;
+      if (E) {
+        uint32_t kE = 0, cumE = 0;
+        bool found = open;                                   // on the boundary the walk starts at the left-most corner, a cut of E itself
+        c = lm;
+        for (uint32_t step = 0; step < len; ++step) {
+          const uint32_t xm = (uint32_t)eseam8[qnext(c)];
+          if (xm & E) { ++kE; }
+          if (!found && step >= 1u && ((xm >> dstar) & 1u)) { found = true; cumE = kE; }
+          const uint32_t nx = pos_swing_right<CP>(frec, c);
+          if (nx == DSA_INVALID || nx == lm) break;
+          c = nx;
+        }
+        nP = kE > 1u ? kE : 1u;
+        sE = open ? 1u : (found ? cumE : 0u);
+      }
+      // the assignment
+      const uint32_t pfirst = pbase[v];
+      uint32_t cum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s[8], cumE = 0;
+      c = lm;
+      for (uint32_t step = 0; step < len; ++step) {
+        const uint32_t xm = (uint32_t)eseam8[qnext(c)];
+        if (step == 0) for (uint32_t d = 0; d < 8; ++d) s[d] = (xm >> d) & 1u;
+        for (uint32_t d = 0; d < nad; ++d) {
+          cum[d] += (xm >> d) & 1u;
+          if (!((cmask >> d) & 1u)) continue;
+          uint32_t off = cum[d] - s[d];
+          off = off >= n[d] ? off - n[d] : off;
+          const uint32_t id = first[d] + off;
+          if (CP) vrec_set_compact(SM_REC(d), c, id);
+          else SM_REC(d)[fv_idx(c)] = id;
+        }
+        if (xm & E) ++cumE;
+        uint32_t poff = E ? cumE + nP - sE : 0u;
+        while (poff >= nP) poff -= nP;
+        c2p[3u * (c >> 2) + (c & 3u)] = (int32_t)(pfirst + poff);
+        const uint32_t nx = pos_swing_right<CP>(frec, c);
+        if (nx == DSA_INVALID || nx == lm) break;
+        c = nx;
+      }
+    }
+    if (__ballot(bad)) SM_FAIL(ST_INVALID, 651);
+  }
+  // ---- P4. faces: the corners of every vertex that is not listed take the vertex's one id and its one point
+  {
+    bool bad = false;
+    for (uint32_t f0 = 0; f0 < F; f0 += WAVE) {
+      const uint32_t f = f0 + lane;
+      if (f >= F) continue;
+      const uint4 vv = R::vertices_of(frec, f);
+      const uint32_t v[3] = {vv.x, vv.y, vv.z};
+      bool plain[3];
+#pragma unroll
+      for (uint32_t k = 0; k < 3; ++k) {
+        if (v[k] >= NVALL) { bad = true; plain[k] = false; continue; }
+        plain[k] = vseam[v[k]] == 0;
+        if (plain[k]) c2p[3u * f + k] = (int32_t)pbase[v[k]];
+      }
+      for (uint32_t d = 0; d < nad; ++d) {
+        if (!((cmask >> d) & 1u)) continue;
+        const uint32_t *vb = SM_VBASE(d);
+        uint32_t id[3];
+#pragma unroll
+        for (uint32_t k = 0; k < 3; ++k) id[k] = plain[k] ? vb[v[k]] : 0x1FFFFFu;
+        uint32_t *rec = SM_REC(d);
+        if (CP) {
+          if (plain[0] || plain[1] || plain[2])
+            atomicAnd((unsigned long long *)rec + (size_t)f * 2, Rec<true>::pack(id[0], id[1], id[2]) | (~0ull << 63));
+        } else {
+#pragma unroll
+          for (uint32_t k = 0; k < 3; ++k) if (plain[k]) rec[fv_idx(4u * f + k)] = id[k];
+        }
+      }
+    }
+    if (__ballot(bad)) SM_FAIL(ST_INVALID, 681);
+  }
+  // ---- results: points of the mesh, vertices of every attribute table = entries of its decoder's attributes
+  if (lane == 0) {
+    D->num_points = ptotal;
+    for (uint32_t d = 0; d < nad; ++d) D->seam_nv[d] = totals[d];
+    for (uint32_t ai = 0; ai < D->num_attributes; ++ai) {
+      AttrDesc &a = D->att[ai];
+      if (a.corner_data == 0) continue;
+      const uint32_t e = totals[(uint32_t)a.corner_data - 1u];
+      a.num_entries = e;
+      const uint64_t nvals = (uint64_t)e * a.nc_portable, bytes = (uint64_t)e * a.nc * data_type_length(a.data_type);
+      if (nvals > L.work_cap[ai] || bytes > L.out_cap[ai]) { fail(D, ST_INVALID, 142); break; }
+    }
+  }
+#undef SM_BLK
+#undef SM_VBASE
+#undef SM_REC
+}
+
+__global__ __launch_bounds__(WAVE) void k_seam_tables(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  const uint32_t mesh = blockIdx.x;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (status_of(D) != ST_OK || D->general || !D->seam_fast || D->encoder_type == 0) return;
+  const MeshLayout &L = layouts[mesh];
+  if (L.seam_bytes == 0) return;
+  if (L.rec_compact) seam_tables_wave<true>(arena, L, D);
+  else seam_tables_wave<false>(arena, L, D);
+}
+
+// k_traverse_att: the depth-first order of every corner-attribute decoder on its own table -- one wave per (mesh, attribute
+// data), the program of k_traverse on the virtual mesh -- and the parallelogram operands of its entries.
+__global__ __launch_bounds__(WAVE) void k_traverse_att(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  __shared__ unsigned long long sh_tf[TR_SLOTS], sh_tv[TR_SLOTS];
+  __shared__ uint32_t sh_hist[TR_HIST_WORDS];
+  for (uint32_t i = threadIdx.x; i < TR_SLOTS; i += WAVE) { sh_tf[i] = 0; sh_tv[i] = 0; }
+  if (threadIdx.x < TR_HIST_WORDS) sh_hist[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t mesh = blockIdx.x, d = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (status_of(D) != ST_OK || D->general || !D->seam_fast || d >= D->num_att_data || !((D->corner_mask >> d) & 1u)) return;
+  const MeshLayout &L = layouts[mesh];
+  const TravIO io = trav_attribute(arena, L, D, d);
+  if (L.rec_compact) traverse_wave<true>(arena, L, D, io, 1u | 2u, sh_tf, sh_tv, sh_hist);
+  else traverse_wave<false>(arena, L, D, io, 1u | 2u, sh_tf, sh_tv, sh_hist);
+}
+
+// k_seam_maps: point -> entry of every attribute of a mesh with corner attributes (MeshTraversalSequencer.cs:33-50), from the
+// corners: the point of a corner, the attribute's vertex at that corner, the entry that vertex was given.  All corners of a point
+// carry the same vertex of every table (that is what made them one point), so concurrent writers agree.
+__global__ __launch_bounds__(256) void k_seam_maps(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  const uint32_t mesh = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (status_of(D) != ST_OK || D->general || !D->seam_fast) return;
+  const MeshLayout &L = layouts[mesh];
+  const uint32_t F = D->num_faces, na = D->num_attributes, npts = D->num_points, nad = D->num_att_data;
+  const SeamLayout g = seam_layout(L.cap_faces, L.cap_vertices, nad, L.rec_compact != 0);
+  const uint32_t *frec = (const uint32_t *)(arena + L.frec);
+  const int32_t *c2p = (const int32_t *)(arena + L.faces);
+  const int32_t *v2d_pos = (const int32_t *)(arena + L.v2d);
+  const bool compact = L.rec_compact != 0;
+  bool bad = false;
+  for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < F; f += gridDim.x * blockDim.x) {
+    const uint4 pv = compact ? Rec<true>::vertices_of(frec, f) : Rec<false>::vertices_of(frec, f);
+    const uint32_t pvert[3] = {pv.x, pv.y, pv.z};
+    uint32_t point[3];
+    for (uint32_t k = 0; k < 3; ++k) { point[k] = (uint32_t)c2p[3 * f + k]; if (point[k] >= npts) bad = true; }
+    for (uint32_t ai = 0; ai < na; ++ai) {
+      const AttrDesc &a = D->att[ai];
+      uint32_t vert[3];
+      const int32_t *v2d = v2d_pos;
+      uint32_t nverts = D->num_vertices;
+      if (a.corner_data) {
+        const uint32_t d = (uint32_t)a.corner_data - 1u;
+        const uint8_t *blk = seam_block(arena, L, g, d);
+        const uint4 av = compact ? Rec<true>::vertices_of((const uint32_t *)(blk + g.rec), f) : Rec<false>::vertices_of((const uint32_t *)(blk + g.rec), f);
+        vert[0] = av.x; vert[1] = av.y; vert[2] = av.z;
+        v2d = (const int32_t *)(blk + g.v2d);
+        nverts = D->seam_nv[d];
+      } else { vert[0] = pvert[0]; vert[1] = pvert[1]; vert[2] = pvert[2]; }
+      uint32_t *map = (uint32_t *)(arena + L.map[ai]);
+      for (uint32_t k = 0; k < 3; ++k) {
+        if (vert[k] >= nverts || point[k] >= npts) { bad = true; continue; }
+        const int32_t e = v2d[vert[k]];
+        if (e < 0 || (uint32_t)e >= npts) { bad = true; continue; }
+        map[point[k]] = (uint32_t)e;
+      }
+    }
+  }
+  if (__ballot(bad) && lane_id() == 0) fail(D, ST_INVALID, 670);
+}
+
+#undef SM_FAIL
+#undef SM_SYNC
+
+// =========================================================================
+// TexCoordsPortable (MeshPredictionSchemeTexCoordsPortableDecoder.cs:50-85, ...PortablePredictor.cs:46-150; what stock encoders
+// pick for texture coordinates at their default level) on the fast kernels, for meshes with and without seams.
+// The prediction of an entry reads the DECODED texture coordinates of the entries at Next / Previous of its corner: a serial chain
+// over the entries of an attribute.  But everything else it needs -- which entries those are, the positions of the three
+// corners, the squared edge length, the foot of the tip on the edge, the 64-bit integer square root -- depends on the mesh and
+// on the positions only.  So:
+//   k_flip_bits (extended)   the orientation bits (one serial rABS stream per attribute), from the start of the decode
+//   k_texcoords_prepare      one thread per entry, behind the traversals and the prediction of the positions: TcPrep
+//   k_texcoords              one LANE per attribute (64 attributes to a wave: no cross-lane traffic in the chain, so the
+//                            instruction stream is shared): per entry two multiply-adds, two divisions by an estimate put
+//                            right by remainders, the wrap transform
+// =========================================================================
+__device__ __forceinline__ uint64_t isqrt_floor(uint64_t n) {   // = Core/MathUtilities.cs:5-25 IntSqrt (its Newton iteration ends on floor(sqrt(n)))
+  if (n == 0) return 0;
+  uint64_t r = (uint64_t)__dsqrt_rn((double)n);
+  if (r > 0xFFFFFFFFull) r = 0xFFFFFFFFull;
+  while (r * r > n) --r;
+  while (r < 0xFFFFFFFFull && (r + 1) * (r + 1) <= n) ++r;
+  return r;
+}
+__device__ __forceinline__ int64_t div_trunc(int64_t x, int64_t y) { return y > 0 ? div_trunc_pos(x, y) : x / y; }
+
+__device__ __forceinline__ uint32_t *orient_bits_of(uint8_t *arena, const MeshLayout &L, const MeshDesc *D, uint32_t ai, uint32_t *capacity) {
+  const AttrDesc &a = D->att[ai];
+  if (a.corner_data == 0) { *capacity = L.cap_vertices; return flip_bits_of(arena, L, ai); }
+  const SeamLayout g = seam_layout(L.cap_faces, L.cap_vertices, D->num_att_data, L.rec_compact != 0);
+  *capacity = 3u * L.cap_faces;
+  return (uint32_t *)(seam_block(arena, L, g, (uint32_t)a.corner_data - 1u) + g.orient);
+}
+
+// The orientation bits as the decoder will use them (:66-85: a bit says "same as the one before", starting from true).
+__global__ __launch_bounds__(WAVE) void k_orient_bits(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t lanes_per_mesh) {
+  const uint32_t lane = lane_id();
+  const uint32_t mesh = blockIdx.x * (WAVE / lanes_per_mesh) + lane / lanes_per_mesh, ai = lane % lanes_per_mesh;
+  if (mesh >= n) return;
+  const MeshLayout &L = layouts[mesh];
+  MeshDesc *D = &descs[mesh];
+  if (status_of(D) != ST_OK || D->general || ai >= D->num_attributes) return;
+  const AttrDesc &a = D->att[ai];
+  if (!a.have_scheme || a.pred_kind != 3 || a.source == SRC_BYTES) return;
+  if (L.tc[ai] == 0) { fail(D, ST_NOTIMPL, DSA_SITE_RETRY_GENERAL); return; }
+  Rabs rb;
+  uint32_t endp;
+  rb.start(arena + L.stream, L.stream_len, a.off_flips, &endp);
+  if (!rb.ok) { fail(D, ST_INVALID, 669); return; }
+  uint32_t cap;
+  uint32_t *bits = orient_bits_of(arena, L, D, ai, &cap);
+  const uint32_t count = a.num_orient;
+  if (count > cap) { fail(D, ST_INVALID, 668); return; }
+  uint32_t word = 0, last = 1;
+  for (uint32_t p = 0; p < count; ++p) {
+    if (rb.next() == 0) last ^= 1u;
+    word |= last << (p & 31u);
+    if ((p & 31u) == 31u) { bits[p >> 5] = word; word = 0; }
+  }
+  if (count & 31u) bits[count >> 5] = word;
+}
+
+template <bool CP>
+__device__ __forceinline__ void texcoords_prepare_entries(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t pa, uint32_t tid, uint32_t stride) {
+  typedef Rec<CP> R;
+  const AttrDesc &a = D->att[ai];
+  const uint32_t entries = a.num_entries, F = D->num_faces;
+  TravIO io = a.corner_data ? trav_attribute(arena, L, D, (uint32_t)a.corner_data - 1u) : trav_position(arena, L, D);
+  const uint32_t *frec_pos = (const uint32_t *)(arena + L.frec);
+  const int32_t *v2d_pos = (const int32_t *)(arena + L.v2d);
+  const int32_t *posv = (const int32_t *)(arena + L.work[pa]);
+  const uint32_t pos_entries = D->att[pa].num_entries, NVP = D->num_vertices;
+  TcPrep *prep = (TcPrep *)(arena + L.tc[ai]);
+  bool bad = false;
+  for (uint32_t p = tid; p < entries; p += stride) {
+    TcPrep t;
+    t.next_id = DSA_INVALID; t.prev_id = DSA_INVALID; t.pn_norm2 = 0; t.cn_dot_pn = 0; t.norm = 0;
+    const uint32_t ci = io.d2c[p];
+    if ((ci >> 2) >= F || (ci & 3u) == 3u) { bad = true; prep[p] = t; continue; }
+    const uint32_t cn = qnext(ci), cp = qprev(ci);
+    const uint32_t vn = R::get_v(io.frec, cn), vp = R::get_v(io.frec, cp);
+    if (vn >= io.NV || vp >= io.NV) { bad = true; prep[p] = t; continue; }
+    const int32_t en = io.v2d[vn], ep = io.v2d[vp];
+    if (en >= 0 && (uint32_t)en < p) t.next_id = (uint32_t)en;
+    if (ep >= 0 && (uint32_t)ep < p) t.prev_id = (uint32_t)ep;
+    if (t.next_id != DSA_INVALID && t.prev_id != DSA_INVALID) {
+      // the position of an entry of THIS attribute = the position at the corner the entry was reached through
+      auto position = [&](uint32_t corner, int64_t dst[3]) {
+        const uint32_t v = (corner >> 2) < F && (corner & 3u) != 3u ? R::get_v(frec_pos, corner) : DSA_INVALID;
+        const int32_t e = v < NVP ? v2d_pos[v] : -1;
+        if (e < 0 || (uint32_t)e >= pos_entries) { bad = true; dst[0] = dst[1] = dst[2] = 0; return; }
+        for (int k = 0; k < 3; ++k) dst[k] = posv[(size_t)e * 3 + k];
+      };
+      int64_t tip[3], np[3], pp[3];
+      position(ci, tip); position(io.d2c[t.next_id], np); position(io.d2c[t.prev_id], pp);
+      // (64-bit wrap-around arithmetic, as the reference's)
+      uint64_t pn[3], cnv[3];
+      for (int k = 0; k < 3; ++k) { pn[k] = (uint64_t)pp[k] - (uint64_t)np[k]; cnv[k] = (uint64_t)tip[k] - (uint64_t)np[k]; }
+      const int64_t pn_norm2 = (int64_t)(pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2]);
+      t.pn_norm2 = pn_norm2;
+      if (pn_norm2 != 0) {
+        const int64_t cn_dot_pn = (int64_t)(pn[0] * cnv[0] + pn[1] * cnv[1] + pn[2] * cnv[2]);
+        t.cn_dot_pn = cn_dot_pn;
+        uint64_t cx2 = 0;
+        for (int k = 0; k < 3; ++k) {
+          const int64_t x_pos = (int64_t)((uint64_t)np[k] + (uint64_t)div_trunc((int64_t)((uint64_t)cn_dot_pn * pn[k]), pn_norm2));
+          const uint64_t cx = (uint64_t)tip[k] - (uint64_t)x_pos;
+          cx2 += cx * cx;
+        }
+        t.norm = (int64_t)isqrt_floor(cx2 * (uint64_t)pn_norm2);
+      }
+    }
+    prep[p] = t;
+  }
+  if (bad) fail(D, ST_INVALID, 671);
+}
+__global__ __launch_bounds__(256) void k_texcoords_prepare(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  const uint32_t mesh = blockIdx.y, ai = blockIdx.z;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (status_of(D) != ST_OK || D->general || ai >= D->num_attributes) return;
+  const AttrDesc &a = D->att[ai];
+  const MeshLayout &L = layouts[mesh];
+  if (!a.have_scheme || a.pred_kind != 3 || a.source == SRC_BYTES || a.num_entries == 0 || L.tc[ai] == 0) return;
+  int pa = -1;                                              // parent: the portable positions (k_locate checked that they are there)
+  for (uint32_t k = 0; k < ai; ++k) if (D->att[k].att_type == 0 && D->att[k].seq_type != 0) { pa = (int)k; break; }
+  if (pa < 0) { fail(D, ST_INVALID, 667); return; }
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  if (L.rec_compact) texcoords_prepare_entries<true>(arena, L, D, ai, (uint32_t)pa, tid, stride);
+  else texcoords_prepare_entries<false>(arena, L, D, ai, (uint32_t)pa, tid, stride);
+}
+
+// The chain: one lane per (mesh, attribute).
+__global__ __launch_bounds__(WAVE) void k_texcoords(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  const uint32_t mesh = blockIdx.x * WAVE + lane_id(), ai = blockIdx.y;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (status_of(D) != ST_OK || D->general || ai >= D->num_attributes) return;
+  const AttrDesc &a = D->att[ai];
+  const MeshLayout &L = layouts[mesh];
+  if (!a.have_scheme || a.pred_kind != 3 || a.source == SRC_BYTES || a.num_entries == 0 || L.tc[ai] == 0) return;
+  const TcPrep *prep = (const TcPrep *)(arena + L.tc[ai]);
+  int32_t *w = (int32_t *)(arena + L.work[ai]);
+  uint32_t cap;
+  const uint32_t *obits = orient_bits_of(arena, L, D, ai, &cap);
+  const uint32_t entries = a.num_entries;
+  const int32_t mn = a.wrap_min, mx = a.wrap_max, max_dif = 1 + mx - mn;
+  uint32_t left = a.num_orient;                           // orientations are taken from the back of the list (:111-113)
+  bool ran_out = false;
+  for (uint32_t p = 0; p < entries; ++p) {
+    const TcPrep t = prep[p];
+    const int2 corr = *(const int2 *)(w + 2 * (size_t)p);
+    int32_t pu = 0, pv = 0;
+    bool done = false;
+    if (t.next_id != DSA_INVALID && t.prev_id != DSA_INVALID) {
+      const int2 nuv = *(const int2 *)(w + 2 * (size_t)t.next_id), puv = *(const int2 *)(w + 2 * (size_t)t.prev_id);
+      if (puv.x == nuv.x && puv.y == nuv.y) { pu = puv.x; pv = puv.y; done = true; }
+      else if (t.pn_norm2 != 0) {
+        const uint64_t pnu = (uint64_t)((int64_t)puv.x - (int64_t)nuv.x), pnv = (uint64_t)((int64_t)puv.y - (int64_t)nuv.y);
+        const uint64_t xu = (uint64_t)(int64_t)nuv.x * (uint64_t)t.pn_norm2 + (uint64_t)t.cn_dot_pn * pnu;
+        const uint64_t xv = (uint64_t)(int64_t)nuv.y * (uint64_t)t.pn_norm2 + (uint64_t)t.cn_dot_pn * pnv;
+        const uint64_t cxu = pnv * (uint64_t)t.norm, cxv = ((uint64_t)0 - pnu) * (uint64_t)t.norm;
+        bool orientation = false;
+        if (left == 0) ran_out = true;
+        else { --left; orientation = ((obits[left >> 5] >> (left & 31u)) & 1u) != 0; }
+        const int64_t su = (int64_t)(orientation ? xu + cxu : xu - cxu), sv = (int64_t)(orientation ? xv + cxv : xv - cxv);
+        pu = (int32_t)div_trunc(su, t.pn_norm2);
+        pv = (int32_t)div_trunc(sv, t.pn_norm2);
+        done = true;
+      }
+    }
+    if (!done) {
+      // the fallback chain of the predictor, as written there (:129-149): the entry at Next if it is decoded, else the entry before
+      if (t.next_id != DSA_INVALID) { const int2 q = *(const int2 *)(w + 2 * (size_t)t.next_id); pu = q.x; pv = q.y; }
+      else if (p > 0) { const int2 q = *(const int2 *)(w + 2 * (size_t)(p - 1)); pu = q.x; pv = q.y; }
+    }
+    int2 o;
+    o.x = wrap_original(pu, corr.x, mn, mx, max_dif);
+    o.y = wrap_original(pv, corr.y, mn, mx, max_dif);
+    *(int2 *)(w + 2 * (size_t)p) = o;
+  }
+  if (ran_out) fail(D, ST_INVALID, 672);
+}
+
+}  // namespace dsa

@@ -26,7 +26,8 @@ struct AttrDesc {
   uint8_t seq_type;        // SequentialAttributeEncoderType 0..3
   int8_t decoder_id;
   int8_t pred_method;      // PredictionSchemeMethod as stored in the stream
-  int8_t pred_kind;        // scheme that runs: 0 delta, 1 parallelogram, 2 geometric normal (PredictionSchemeDecoderFactory.cs:24-36)
+  int8_t pred_kind;        // scheme that runs: 0 delta, 1 parallelogram, 2 geometric normal, 3 texture coordinates (portable)
+                           // (PredictionSchemeDecoderFactory.cs:24-36)
   int8_t pred_transform;   // PredictionSchemeTransformType
   uint8_t nc_portable;
   uint8_t source;          // SRC_*
@@ -36,6 +37,8 @@ struct AttrDesc {
   uint8_t q_bits;          // quantisation bits / octahedron bits
   uint8_t early_done;      // the symbol wave itself predicted and dequantised the attribute (k_predict / k_finalize of phase 0 skip it)
   uint8_t tags_done;       // tagged scheme: k_tags decoded the tag stream (tags in the output region, their bit total in `table`)
+  int8_t corner_data;      // attribute data id + 1 when the attribute's decoder is a corner-attribute decoder (it has a corner table
+                           // of its own, cut along the attribute's seams: MeshAttributeCornerTable.cs), else 0
   uint32_t unique_id;
   uint32_t num_symbols;    // alphabet size
   uint32_t off_table;      // stream offset of the first probability-table byte
@@ -49,7 +52,9 @@ struct AttrDesc {
   float q_range;
   uint32_t num_entries;
   uint32_t num_distinct;   // raw scheme: symbols of the alphabet with a non-zero frequency (k_locate counts them while it skips the table)
-  uint32_t off_flips;      // geometric normal: stream offset of the rABS block of flip bits (probability byte first)
+  uint32_t off_flips;      // geometric normal: stream offset of the rABS block of flip bits (probability byte first);
+                           // texture coordinates (portable): of the rABS block of orientation bits
+  uint32_t num_orient;     // texture coordinates (portable): orientations in that block (MeshPredictionSchemeTexCoordsPortableDecoder.cs:66-85)
   uint64_t table;          // arena offset of a cumulative table taken from the batch pool (large alphabets), else 0
 };
 
@@ -92,7 +97,11 @@ struct MeshDesc {
   uint32_t val_lists_done; // bit c: k_valence_lists decoded list c into the face-output region
   uint8_t val_prec[6];
   uint8_t geo_wide;        // k_vertex_positions: some position is not below 2^30 in magnitude (k_predict_geometric then keeps 64-bit edge vectors)
-  uint8_t pad_val;
+  uint8_t seam_fast;       // the mesh has corner-attribute decoders and the fast kernels take it (k_seam_tables, k_traverse_att)
+  // attribute seams on the fast kernels
+  uint16_t corner_mask;    // bit d: attribute data d belongs to a corner-attribute decoder
+  uint16_t pad_seam;
+  uint32_t seam_nv[DSA_MAX_ATT_DATA];      // vertices of attribute data d's corner table (= entries of its decoder), by k_seam_tables
   uint32_t dbg[20];        // diagnostics of the per-mesh kernels (tools/dbg_phases.py, bench.py): s_memtime deltas between phases;
                            // k_connectivity: [13] its s_memtime ticks, [14] its start and [15] its duration in s_memrealtime ticks
                            // (100 MHz); k_traverse: [6] ticks, [16] start, [17] duration: ticks / duration = the shader clock
@@ -162,6 +171,67 @@ inline GenLayout gen_layout(uint64_t F, uint64_t V, uint64_t S, uint64_t A, uint
   return g;
 }
 
+// Scratch of the fast seam path inside MeshLayout::seam (byte offsets): what a mesh with corner-attribute decoders needs beside
+// the position tables.  `eseam` is per mesh; then one block per attribute data.  F faces, NVA = 3F: an attribute vertex per corner
+// at most.  rec: the attribute's "virtual mesh" -- face records like MeshLayout::frec whose vertices are the ATTRIBUTE's vertices
+// and whose opposites are cut along the attribute's seams, so that traverse_wave, the parallelogram operands and the prediction
+// kernels run on it unchanged.
+struct SeamLayout {
+  uint64_t eseam;      // u32[F]  per face: byte k = for corner k the mask of attribute data for which the edge opposite the corner is a seam
+  uint64_t vseam;      // u8[V]   vertex touches a seam of some attribute data or the boundary: its corners are numbered by a walk around it
+  uint64_t pbase;      // u32[V]  first point of the vertex
+  uint64_t data;       // first per-attribute-data block
+  uint64_t data_stride;
+  // inside a block
+  uint64_t bits;       // u32[ceil(3F/2 / 32) + 4]  the seam bits of the stream, one per interior edge in decoder order (k_conn_checks)
+  uint64_t rec;        // 16 B x F (compact) / 32 B x F
+  uint64_t vbase;      // u32[V]    first attribute vertex of the position vertex
+  uint64_t vflag;      // u8[NVA]   bit0 visited, bit1 on the boundary of the attribute's table
+  uint64_t d2c;        // u32[NVA]  entry -> corner
+  uint64_t v2d;        // i32[NVA]  attribute vertex -> entry
+  uint64_t fvis;       // u8[F]
+  uint64_t stack;      // u32[F]    DFS stack of the traversal
+  uint64_t para;       // u32[3 NVA] parallelogram operands per entry
+  uint64_t orient;     // u32[NVA / 32 + 1]  orientation bits of a texture-coordinate attribute of this decoder (k_flip_bits)
+  uint64_t total;
+};
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline SeamLayout seam_layout(uint64_t F, uint64_t V, uint64_t A, bool compact) {
+  SeamLayout g;
+  const uint64_t NVA = 3 * F;
+  uint64_t cur = 0;
+  auto take = [&](uint64_t bytes) { uint64_t at = cur; cur = (cur + bytes + 16 + 255) & ~255ull; return at; };
+  g.eseam = take(4 * F);
+  g.vseam = take(V);
+  g.pbase = take(4 * V);
+  g.data = cur;
+  cur = 0;
+  g.bits = take(4 * ((3 * F / 2 + 31) / 32 + 4));
+  g.rec = take((compact ? 16 : 32) * F);
+  g.vbase = take(4 * V);
+  g.vflag = take(NVA);
+  g.d2c = take(4 * NVA);
+  g.v2d = take(4 * NVA);
+  g.fvis = take(F);
+  g.stack = take(4 * F);
+  g.para = take(12 * NVA);
+  g.orient = take(4 * (NVA / 32 + 1));
+  g.data_stride = cur;
+  g.total = g.data + A * g.data_stride;
+  return g;
+}
+
+// What k_texcoords_prepare leaves for the serial chain of k_texcoords, per entry of a TexCoordsPortable attribute: everything of
+// MeshPredictionSchemeTexCoordsPortablePredictor.cs:46-150 that depends on the mesh and the positions only.
+struct TcPrep {
+  uint32_t next_id, prev_id;   // entries at Next / Previous of the entry's corner; DSA_INVALID: none, or not decoded before this entry
+  int64_t pn_norm2;            // |P(prev) - P(next)|^2
+  int64_t cn_dot_pn;           // (P(tip) - P(next)) . (P(prev) - P(next))
+  int64_t norm;                // IntSqrt(|C - X|^2 * pn_norm2), X = the foot of the tip on the edge
+};
+
 // Batch-wide device state.
 struct BatchGlobals {
   uint64_t pool;                    // arena offset of the table pool
@@ -201,4 +271,9 @@ struct MeshLayout {
   uint64_t gen_bytes;
   uint32_t cap_points;     // u32 entries of every map[] (3F when the mesh can have seams, else cap_vertices)
   uint32_t pad2;
+  // Fast seam path (corner-attribute decoders on the wave-per-mesh kernels): SeamLayout region; seam_bytes == 0: none
+  uint64_t seam;
+  uint64_t seam_bytes;
+  uint64_t tc[DSA_MAX_ATT];     // TcPrep[entry capacity] of every two-component integer / quantised attribute (it may turn out to be
+                                // predicted by TexCoordsPortable: the scheme is written behind the symbol stream), else 0
 };

@@ -59,7 +59,7 @@ def assert_equals_oracle(got, ref):
 
 
 def test_house04_through_the_general_path_source(exe, house04_bytes, tmp_path):
-    status, detail, got = host_decode(exe, house04_bytes, tmp_path, force=False)
+    status, detail, got = host_decode(exe, house04_bytes, tmp_path, force=True)     # (seams take the fast kernels unless forced)
     assert status == 0, detail
     assert_equals_oracle(got, oracle.decode(house04_bytes))
 
@@ -113,7 +113,7 @@ def test_corrupt_streams_never_leave_their_regions(exe, house04_bytes, tmp_path)
     """Bit flips, random bytes, truncations and bursts: every gap between arena regions is poisoned, so any
     out-of-bounds access of the general path aborts the run."""
     pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 10, 8, 3)
-    cases = [(house04_bytes, 3000, False), (synth.encode_mesh(pos, faces, nrm, uv), 1500, True),
+    cases = [(house04_bytes, 3000, True), (synth.encode_mesh(pos, faces, nrm, uv), 1500, True),
              (synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(force_scheme=0, single_connectivity=1)), 1500, True),
              (synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(normal_prediction=6)), 1500, True),
              (synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, uv_prediction=5)), 1500, True),

@@ -78,7 +78,7 @@ def test_seamed_streams_through_the_general_path_source(kind, nx, ny, tmp_path):
         args = seamed_mesh(synth, kind, nx, ny, 7, *charts)
         for opt in (dict(), dict(predictive_connectivity=2, uv_prediction=5, normal_prediction=6), dict(uv_prediction=4, pos_prediction=2, force_scheme=0)):
             data = synth.encode_mesh_corners(*args, opt=synth.options(**opt))
-            status, detail, got = th.host_decode(exe, data, tmp_path, force=False)
+            status, detail, got = th.host_decode(exe, data, tmp_path, force=True)
             assert status == 0, (charts, opt, detail)
             th.assert_equals_oracle(got, oracle.decode(data))
 
@@ -102,7 +102,7 @@ def test_corrupt_seamed_streams_never_leave_their_regions(tmp_path):
         data = synth.encode_mesh_corners(*args, opt=synth.options(predictive_connectivity=2 * k, uv_prediction=5 if k else 1))
         src = tmp_path / ("fuzz%d.drc" % k)
         src.write_bytes(data)
-        r = subprocess.run([exe, "fuzz", str(src), "1500", str(41 + k)], capture_output=True, text=True)
+        r = subprocess.run([exe, "fuzz", str(src), "1500", str(41 + k), "force"], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         counts = dict(zip(r.stdout.split()[::2], map(int, r.stdout.split()[1::2])))
         assert counts["ok"] + counts["invalid"] + counts["notimpl"] + counts["notgeneral"] == 1500 and counts["invalid"] > 0
