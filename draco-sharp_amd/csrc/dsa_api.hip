@@ -605,12 +605,12 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     if (b->any_seamed) {
       // corner attributes: seam edges, attribute vertices and points per corner from the connectivity and the seam bits; then, beside
       // the position traversal, the traversal of every seamed attribute on its own table (third stream) and its symbols (below)
-      HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_seambits, 0));
-      k_begin(KT_SEAM_TABLES, st);
-      hipLaunchKernelGGL(dsa::k_seam_tables, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
-      k_end(KT_SEAM_TABLES, st);
-      HIP_TRY(ctx, hipEventRecord(S.ev_tables, st));
-      HIP_TRY(ctx, hipStreamWaitEvent(st3, S.ev_tables, 0));
+      // (both on the third stream, behind k_faces there -- which waited for the connectivity -- so that the position traversal
+      // starts at once on the main stream)
+      k_begin(KT_SEAM_TABLES, st3);
+      hipLaunchKernelGGL(dsa::k_seam_tables, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+      k_end(KT_SEAM_TABLES, st3);
+      HIP_TRY(ctx, hipEventRecord(S.ev_tables, st3));
       k_begin(KT_TRAVERSE_ATT, st3);
       hipLaunchKernelGGL(dsa::k_traverse_att, dim3(n, std::max<uint32_t>(1, b->max_att_data)), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
       k_end(KT_TRAVERSE_ATT, st3);

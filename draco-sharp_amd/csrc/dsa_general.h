@@ -1465,7 +1465,7 @@ __device__ __forceinline__ bool mesh_attributes(uint8_t *arena, const MeshLayout
     dec[i].att_data_id = (int8_t)r.u8();
     dec[i].element_type = r.u8();
     const uint32_t traversal_method = r.u8();
-    GREQ(r.ok && traversal_method < 2 && dec[i].element_type < 2, 123);
+    GREQ(r.ok && traversal_method < 2, 123);                // (any element type but "vertex" is a corner attribute, :666-701)
     if (dec[i].att_data_id >= 0) {
       GREQ((uint32_t)dec[i].att_data_id < nad && data_decoder[dec[i].att_data_id] < 0, 124);
       data_decoder[dec[i].att_data_id] = (int)i;

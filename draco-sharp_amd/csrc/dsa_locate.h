@@ -285,6 +285,48 @@ __device__ __forceinline__ int locate_attribute_section(Rd &r, MeshDesc *D, Attr
 #undef RET
 #define RET
 
+// A context list of valence-coded connectivity under the TAGGED symbol scheme (Entropy/SymbolDecoding.cs:30-50: a rANS stream of bit
+// lengths, then the values as bit fields) -- what encoders write for the lists of small meshes (the reference's house_04 sample).
+// Decoded by the walking lane itself, into the place k_valence_lists / the connectivity wave would put it; such lists are short
+// (longer ones go to the general path).  `r` stands behind the scheme byte; on success it stands behind the list.
+#define LOC_VAL_TAGGED_MAX 16384u
+#undef RET
+#define RET false
+__device__ inline bool locate_tagged_valence_list(Rd &r, MeshDesc *D, uint32_t count, uint32_t *out) {
+  uint32_t cum[LOC_MAX_TAGS + 1];
+  const uint64_t ns = r.varint();
+  REQUIRE(r.ok && ns >= 1 && ns <= LOC_MAX_TAGS, 151);
+  REQUIRE(read_prob_table(r, (uint32_t)ns, cum), 152);
+  uint32_t c = 0;
+  for (uint32_t i = 0; i < (uint32_t)ns; ++i) { const uint32_t pr = cum[i]; REQUIRE(pr <= 4096u - c, 153); cum[i] = c; c += pr; }
+  cum[ns] = c;
+  REQUIRE(c == 4096, 153);
+  const uint64_t size = r.varint();
+  REQUIRE(r.ok && size >= 1 && size <= (uint64_t)(r.n - r.pos), 154);
+  const uint8_t *buf = r.p + r.pos;
+  r.skip(size);
+  uint32_t state, off;
+  REQUIRE(rans_init(buf, (uint32_t)size, 16384, &state, &off), 156);
+  const uint8_t *bits = r.p + r.pos;
+  const uint32_t nbytes = r.n - r.pos;
+  uint64_t bitpos = 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    while (state < 16384 && off > 0) state = state * 256 + buf[--off];
+    const uint32_t rem = state & 4095u;
+    uint32_t tag = 0;
+    while (tag + 1 < (uint32_t)ns && cum[tag + 1] <= rem) ++tag;
+    state = (state >> 12) * (cum[tag + 1] - cum[tag]) + rem - cum[tag];
+    REQUIRE(tag <= 32, 157);
+    out[i] = tag ? read_bits(bits, nbytes, bitpos, tag) : 0u;
+    bitpos += tag;
+  }
+  r.skip((bitpos + 7) >> 3);
+  REQUIRE(r.ok, 158);
+  return true;
+}
+#undef RET
+#define RET
+
 // First half of the walk: header, metadata, connectivity sections (up to the attribute section).
 __device__ inline void locate_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc *D) {
   const uint8_t *s = arena + L.stream;
@@ -400,7 +442,13 @@ __device__ inline void locate_mesh(uint8_t *arena, const MeshLayout &L, MeshDesc
         if (num == 0) continue;
         const uint32_t scheme = r.u8();
         REQUIRE(r.ok && scheme <= 1, 146);
-        if (scheme != 1) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+        if (scheme != 1) {
+          if (num > LOC_VAL_TAGGED_MAX) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+          if (!locate_tagged_valence_list(r, D, (uint32_t)num, (uint32_t *)(arena + L.faces) + (total - num))) return;
+          D->val_prec[c] = 0;                      // (not a stream for k_valence_lists)
+          D->val_lists_done |= 1u << c;
+          continue;
+        }
         const uint32_t mbl = r.u8();
         REQUIRE(r.ok && mbl >= 1 && mbl <= 18, 147);
         D->val_prec[c] = (uint8_t)rans_precision_bits(mbl);

@@ -33,6 +33,7 @@ __device__ __forceinline__ void vrec_set_compact(uint32_t *rec, uint32_t c, uint
 
 #define SM_FAIL(code_, site_) { if (lane == 0) fail(D, (code_), (site_)); return; }
 #define SM_SYNC() { WAIT_VM0(); __threadfence_block(); }
+#define SM_U 4u      // chunks of 64 elements a pass keeps in flight
 
 // One wave per mesh, behind the connectivity (k_connectivity) and the seam bits (k_conn_checks).
 template <bool CP>
@@ -62,81 +63,97 @@ __device__ __forceinline__ void seam_tables_wave(uint8_t *arena, const MeshLayou
   auto corner_ok = [&](uint32_t c) -> bool { return c < 4u * F && (c & 3u) != 3u; };
 
   // ---- A. faces: which seam bit belongs to which corner (one bit per interior edge, at the lower of its two faces, in corner
-  // order: a prefix count), and from the bits the seam mask of that corner
+  // order: a prefix count), and from the bits the seam mask of that corner.  (Every pass of this kernel keeps four chunks of 64
+  // elements in flight: a lone wave waits a microsecond for each dependent load, and there are a dozen passes.)
   {
     uint32_t base = 0;
     bool bad = false, weird = false;
-    for (uint32_t f0 = 0; f0 < F; f0 += WAVE) {
-      const uint32_t f = f0 + lane;
-      const bool live = f < F;
-      const Raw r = R::load(frec, live ? f : 0u);
-      uint32_t o[3], cnt = 0;
-      bool own[3];
+    for (uint32_t f0 = 0; f0 < F; f0 += SM_U * WAVE) {
+      Raw r[SM_U];
 #pragma unroll
-      for (uint32_t k = 0; k < 3; ++k) {
-        o[k] = live ? R::opp(r, k) : DSA_INVALID;
-        const bool has = o[k] != DSA_INVALID;
-        if (has && !corner_ok(o[k])) { bad = true; o[k] = DSA_INVALID; }
-        if (has && (o[k] >> 2) == f) weird = true;           // a face glued to itself: the general path's business
-        own[k] = o[k] != DSA_INVALID && (o[k] >> 2) >= f;
-        cnt += own[k] ? 1u : 0u;
-      }
-      uint32_t total;
-      uint32_t idx = base + wave_excl_scan(cnt, &total);
-      base += total;
-      uint32_t word = 0;
+      for (uint32_t u = 0; u < SM_U; ++u) { const uint32_t f = f0 + u * WAVE + lane; r[u] = R::load(frec, f < F ? f : 0u); }
+      uint32_t o[SM_U][3], idx[SM_U];
+      bool own[SM_U][3];
 #pragma unroll
-      for (uint32_t k = 0; k < 3; ++k) {
-        uint32_t m = 0;
-        if (live && o[k] == DSA_INVALID) m = 0xFFu;          // boundary edges are seams of every attribute data (:516-522)
-        else if (own[k]) {
-          for (uint32_t d = 0; d < nad; ++d) m |= ((((const uint32_t *)(SM_BLK(d) + g.bits))[idx >> 5] >> (idx & 31u)) & 1u) << d;
-          ++idx;
+      for (uint32_t u = 0; u < SM_U; ++u) {
+        const uint32_t f = f0 + u * WAVE + lane;
+        const bool live = f < F;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 3; ++k) {
+          o[u][k] = live ? R::opp(r[u], k) : DSA_INVALID;
+          const bool has = o[u][k] != DSA_INVALID;
+          if (has && !corner_ok(o[u][k])) { bad = true; o[u][k] = DSA_INVALID; }
+          if (has && (o[u][k] >> 2) == f) weird = true;      // a face glued to itself: the general path's business
+          own[u][k] = o[u][k] != DSA_INVALID && (o[u][k] >> 2) >= f;
+          cnt += own[u][k] ? 1u : 0u;
         }
-        word |= m << (8u * k);
+        uint32_t total;
+        idx[u] = base + wave_excl_scan(cnt, &total);
+        base += total;
       }
-      if (live) eseam32[f] = word;
+      // the bits of the owned corners: every load of the four chunks issued before the first is used
+      uint32_t bitsv[SM_U][3];
+#pragma unroll
+      for (uint32_t u = 0; u < SM_U; ++u) {
+        uint32_t ix = idx[u];
+#pragma unroll
+        for (uint32_t k = 0; k < 3; ++k) {
+          uint32_t m = 0;
+          if (own[u][k]) {
+            for (uint32_t d = 0; d < nad; ++d) m |= ((((const uint32_t *)(SM_BLK(d) + g.bits))[ix >> 5] >> (ix & 31u)) & 1u) << d;
+            ++ix;
+          }
+          bitsv[u][k] = m;
+        }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < SM_U; ++u) {
+        const uint32_t f = f0 + u * WAVE + lane;
+        if (f >= F) continue;
+        uint32_t word = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 3; ++k) word |= (o[u][k] == DSA_INVALID ? 0xFFu : bitsv[u][k]) << (8u * k);      // boundary edges are seams of every attribute data (:516-522)
+        eseam32[f] = word;
+      }
     }
     if (__ballot(bad)) SM_FAIL(ST_INVALID, 681);
     if (__ballot(weird)) SM_FAIL(ST_NOTIMPL, DSA_SITE_RETRY_GENERAL);
     if (2u * base != D->interior_corners) SM_FAIL(ST_INVALID, 263);      // (the census of k_faces / k_seal, seen from here)
   }
   SM_SYNC();
-  // ---- B. faces: the other side of every edge takes the mask over; vertices at the ends of cut edges are marked; the virtual
-  // records of the corner-attribute data: opposites cut, vertices unset
-  for (uint32_t f0 = 0; f0 < F; f0 += WAVE) {
-    const uint32_t f = f0 + lane;
-    if (f >= F) continue;
-    const Raw r = R::load(frec, f);
-    uint32_t word = eseam32[f];
-    uint32_t o[3], v[3];
+  // ---- B. faces: the other side of every edge takes the mask over; vertices at the ends of cut edges are marked
+  for (uint32_t f0 = 0; f0 < F; f0 += SM_U * WAVE) {
+    Raw r[SM_U];
+    uint32_t word[SM_U], om[SM_U][3];
 #pragma unroll
-    for (uint32_t k = 0; k < 3; ++k) {
-      o[k] = R::opp(r, k); v[k] = R::vertex(r, k);
-      if (o[k] != DSA_INVALID && corner_ok(o[k]) && (o[k] >> 2) < f) word |= (uint32_t)eseam8[o[k]] << (8u * k);
-    }
-    eseam32[f] = word;
+    for (uint32_t u = 0; u < SM_U; ++u) { const uint32_t f = f0 + u * WAVE + lane, fc = f < F ? f : 0u; r[u] = R::load(frec, fc); word[u] = eseam32[fc]; }
 #pragma unroll
-    for (uint32_t k = 0; k < 3; ++k) {
-      const uint32_t m = (word >> (8u * k)) & 0xFFu;
-      if (m == 0xFFu || (m & allmask)) {                     // the edge opposite corner k: its end points are at the other two corners
-        const uint32_t va = v[k_next(k)], vb = v[k_prev(k)];
-        if (va < NVALL) vseam[va] = 1;
-        if (vb < NVALL) vseam[vb] = 1;
+    for (uint32_t u = 0; u < SM_U; ++u) {
+      const uint32_t f = f0 + u * WAVE + lane;
+#pragma unroll
+      for (uint32_t k = 0; k < 3; ++k) {
+        const uint32_t o = R::opp(r[u], k);
+        om[u][k] = (f < F && o != DSA_INVALID && corner_ok(o) && (o >> 2) < f) ? (uint32_t)eseam8[o] : 0u;
       }
     }
-    for (uint32_t d = 0; d < nad; ++d) {
-      if (!((cmask >> d) & 1u)) continue;
-      uint32_t oc[3];
 #pragma unroll
-      for (uint32_t k = 0; k < 3; ++k) oc[k] = ((word >> (8u * k + d)) & 1u) ? DSA_INVALID : o[k];
-      uint32_t *rec = SM_REC(d);
-      if (CP) {
-        const uint64_t oo = Rec<true>::pack(oc[0], oc[1], oc[2]) | (~0ull << 63);
-        ((uint4 *)rec)[f] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, (uint32_t)oo, (uint32_t)(oo >> 32));
-      } else {
-        ((uint4 *)rec)[(size_t)f * 2] = make_uint4(DSA_INVALID, DSA_INVALID, DSA_INVALID, 0u);
-        ((uint4 *)rec)[(size_t)f * 2 + 1] = make_uint4(oc[0], oc[1], oc[2], 0u);
+    for (uint32_t u = 0; u < SM_U; ++u) {
+      const uint32_t f = f0 + u * WAVE + lane;
+      if (f >= F) continue;
+      uint32_t v[3];
+      uint32_t w = word[u];
+#pragma unroll
+      for (uint32_t k = 0; k < 3; ++k) { v[k] = R::vertex(r[u], k); w |= om[u][k] << (8u * k); }
+      eseam32[f] = w;
+#pragma unroll
+      for (uint32_t k = 0; k < 3; ++k) {
+        const uint32_t m = (w >> (8u * k)) & 0xFFu;
+        if (m == 0xFFu || (m & allmask)) {                   // the edge opposite corner k: its end points are at the other two corners
+          const uint32_t va = v[k_next(k)], vb = v[k_prev(k)];
+          if (va < NVALL) vseam[va] = 1;
+          if (vb < NVALL) vseam[vb] = 1;
+        }
       }
     }
   }
@@ -145,26 +162,31 @@ __device__ __forceinline__ void seam_tables_wave(uint8_t *arena, const MeshLayou
   // on a list) or it has no corner at all (none)
   uint32_t nlist = 0;
   {
-    bool bad = false;
-    for (uint32_t v0 = 0; v0 < NVALL; v0 += WAVE) {
-      const uint32_t v = v0 + lane;
-      const bool live = v < NVALL;
-      const uint32_t x = live ? vrec[v].x : DSA_INVALID;
-      const uint32_t lm = x == DSA_INVALID ? DSA_INVALID : (val ? (x & 0x1FFFFFu) : x);
-      if (lm != DSA_INVALID && !corner_ok(lm)) bad = true;
-      const bool has = lm != DSA_INVALID;
-      const bool seamv = has && vseam[live ? v : 0u] != 0;
-      const uint64_t m = __ballot(seamv);
-      if (nlist + (uint32_t)__popcll(m) > 3u * F) { bad = true; break; }      // (more vertices with a corner than corners)
-      if (seamv) list[nlist + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
-      nlist += (uint32_t)__popcll(m);
-      if (live && !seamv) {
-        const uint32_t one = has ? 1u : 0u;
-        for (uint32_t d = 0; d < nad; ++d) if ((cmask >> d) & 1u) SM_VBASE(d)[v] = one;
-        pbase[v] = one;
+    bool bad = false, full = false;          // full: wave-uniform
+    for (uint32_t v0 = 0; v0 < NVALL && !full; v0 += SM_U * WAVE) {
+      uint32_t x[SM_U], sv[SM_U];
+#pragma unroll
+      for (uint32_t u = 0; u < SM_U; ++u) { const uint32_t v = v0 + u * WAVE + lane, vc = v < NVALL ? v : 0u; x[u] = v < NVALL ? vrec[vc].x : DSA_INVALID; sv[u] = vseam[vc]; }
+#pragma unroll
+      for (uint32_t u = 0; u < SM_U; ++u) {
+        const uint32_t v = v0 + u * WAVE + lane;
+        const bool live = v < NVALL;
+        const uint32_t lm = x[u] == DSA_INVALID ? DSA_INVALID : (val ? (x[u] & 0x1FFFFFu) : x[u]);
+        if (lm != DSA_INVALID && !corner_ok(lm)) bad = true;
+        const bool has = lm != DSA_INVALID;
+        const bool seamv = has && sv[u] != 0;
+        const uint64_t m = __ballot(seamv);
+        if (nlist + (uint32_t)__popcll(m) > 3u * F) { full = true; break; }      // (more vertices with a corner than corners)
+        if (seamv) list[nlist + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
+        nlist += (uint32_t)__popcll(m);
+        if (live && !seamv) {
+          const uint32_t one = has ? 1u : 0u;
+          for (uint32_t d = 0; d < nad; ++d) if ((cmask >> d) & 1u) SM_VBASE(d)[v] = one;
+          pbase[v] = one;
+        }
       }
     }
-    if (__ballot(bad)) SM_FAIL(ST_INVALID, 651);
+    if (__ballot(bad) || full) SM_FAIL(ST_INVALID, 651);
   }
   SM_SYNC();
   // ---- P1. the listed vertices: a walk around each counts the cuts per attribute data (k_d cuts make max(k_d, 1) attribute
@@ -219,32 +241,103 @@ __device__ __forceinline__ void seam_tables_wave(uint8_t *arena, const MeshLayou
   // ---- P2. counts -> first ids (exclusive prefix sums over the vertices, one per attribute data and one for the points); the
   // boundary flag of every attribute vertex (MeshAttributeCornerTable.cs IsOnBoundary: a cut or the mesh boundary at the vertex)
   uint32_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ptotal = 0;
-  for (uint32_t v0 = 0; v0 < NVALL; v0 += WAVE) {
-    const uint32_t v = v0 + lane;
-    const bool live = v < NVALL;
-    const uint32_t km = live ? (uint32_t)vseam[v] : 0u;
+  for (uint32_t v0 = 0; v0 < NVALL; v0 += SM_U * WAVE) {
+    uint32_t km[SM_U], np[SM_U];
+#pragma unroll
+    for (uint32_t u = 0; u < SM_U; ++u) { const uint32_t v = v0 + u * WAVE + lane; km[u] = v < NVALL ? (uint32_t)vseam[v] : 0u; np[u] = v < NVALL ? pbase[v] : 0u; }
     for (uint32_t d = 0; d < nad; ++d) {
       if (!((cmask >> d) & 1u)) continue;
       uint32_t *vb = SM_VBASE(d);
-      const uint32_t n = live ? vb[v] : 0u;
-      uint32_t total;
-      const uint32_t first = totals[d] + wave_excl_scan(n, &total);
-      totals[d] += total;
-      if (live) vb[v] = first;
-      if (first + n <= 3u * F) {
-        uint8_t *avf = SM_BLK(d) + g.vflag;
-        const uint8_t fl = ((km >> d) & 1u) ? 2 : 0;
-        for (uint32_t j = 0; j < n; ++j) avf[first + j] = fl;
+      uint8_t *avf = SM_BLK(d) + g.vflag;
+      uint32_t nn[SM_U];
+#pragma unroll
+      for (uint32_t u = 0; u < SM_U; ++u) { const uint32_t v = v0 + u * WAVE + lane; nn[u] = v < NVALL ? vb[v] : 0u; }
+#pragma unroll
+      for (uint32_t u = 0; u < SM_U; ++u) {
+        const uint32_t v = v0 + u * WAVE + lane;
+        uint32_t total;
+        const uint32_t first = totals[d] + wave_excl_scan(nn[u], &total);
+        totals[d] += total;
+        if (v < NVALL) vb[v] = first;
+        if (first + nn[u] <= 3u * F) {
+          const uint8_t fl = ((km[u] >> d) & 1u) ? 2 : 0;
+          for (uint32_t j = 0; j < nn[u]; ++j) avf[first + j] = fl;
+        }
       }
     }
-    const uint32_t n = live ? pbase[v] : 0u;
-    uint32_t total;
-    const uint32_t first = ptotal + wave_excl_scan(n, &total);
-    ptotal += total;
-    if (live) pbase[v] = first;
+#pragma unroll
+    for (uint32_t u = 0; u < SM_U; ++u) {
+      const uint32_t v = v0 + u * WAVE + lane;
+      uint32_t total;
+      const uint32_t first = ptotal + wave_excl_scan(np[u], &total);
+      ptotal += total;
+      if (v < NVALL) pbase[v] = first;
+    }
   }
   for (uint32_t d = 0; d < nad; ++d) if (((cmask >> d) & 1u) && totals[d] > 3u * F) SM_FAIL(ST_INVALID, 650);
   if (ptotal > L.cap_points) SM_FAIL(ST_INVALID, 662);
+  SM_SYNC();
+  // ---- P4. faces: the virtual records of the corner-attribute data -- opposites cut at the attribute's seams, vertices: the one
+  // id of every vertex that is not listed (the listed ones' fields stay "unset", all ones, for the walks of P3) -- and the one
+  // point of those vertices
+  {
+    bool bad = false;
+    for (uint32_t f0 = 0; f0 < F; f0 += SM_U * WAVE) {
+      Raw r[SM_U];
+      uint32_t word[SM_U];
+#pragma unroll
+      for (uint32_t u = 0; u < SM_U; ++u) { const uint32_t f = f0 + u * WAVE + lane, fc = f < F ? f : 0u; r[u] = R::load(frec, fc); word[u] = eseam32[fc]; }
+      uint32_t sv[SM_U][3];
+#pragma unroll
+      for (uint32_t u = 0; u < SM_U; ++u) {
+        const uint32_t f = f0 + u * WAVE + lane;
+#pragma unroll
+        for (uint32_t k = 0; k < 3; ++k) {
+          const uint32_t v = R::vertex(r[u], k);
+          if (f < F && v >= NVALL) bad = true;
+          sv[u][k] = (f < F && v < NVALL) ? (uint32_t)vseam[v] : 1u;
+        }
+      }
+      uint32_t pb[SM_U][3];
+#pragma unroll
+      for (uint32_t u = 0; u < SM_U; ++u)
+#pragma unroll
+        for (uint32_t k = 0; k < 3; ++k) pb[u][k] = sv[u][k] == 0 ? pbase[R::vertex(r[u], k)] : 0u;
+      for (uint32_t d = 0; d < nad; ++d) {
+        if (!((cmask >> d) & 1u)) continue;
+        const uint32_t *vb = SM_VBASE(d);
+        uint32_t *rec = SM_REC(d);
+        uint32_t id[SM_U][3];
+#pragma unroll
+        for (uint32_t u = 0; u < SM_U; ++u)
+#pragma unroll
+          for (uint32_t k = 0; k < 3; ++k) id[u][k] = sv[u][k] == 0 ? vb[R::vertex(r[u], k)] : DSA_INVALID;
+#pragma unroll
+        for (uint32_t u = 0; u < SM_U; ++u) {
+          const uint32_t f = f0 + u * WAVE + lane;
+          if (f >= F) continue;
+          uint32_t oc[3];
+#pragma unroll
+          for (uint32_t k = 0; k < 3; ++k) oc[k] = ((word[u] >> (8u * k + d)) & 1u) ? DSA_INVALID : R::opp(r[u], k);
+          if (CP) {
+            const uint64_t vv = Rec<true>::pack(id[u][0], id[u][1], id[u][2]) | (~0ull << 63), oo = Rec<true>::pack(oc[0], oc[1], oc[2]) | (~0ull << 63);
+            ((uint4 *)rec)[f] = make_uint4((uint32_t)vv, (uint32_t)(vv >> 32), (uint32_t)oo, (uint32_t)(oo >> 32));
+          } else {
+            ((uint4 *)rec)[(size_t)f * 2] = make_uint4(id[u][0], id[u][1], id[u][2], 0u);
+            ((uint4 *)rec)[(size_t)f * 2 + 1] = make_uint4(oc[0], oc[1], oc[2], 0u);
+          }
+        }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < SM_U; ++u) {
+        const uint32_t f = f0 + u * WAVE + lane;
+        if (f >= F) continue;
+#pragma unroll
+        for (uint32_t k = 0; k < 3; ++k) if (sv[u][k] == 0) c2p[3u * f + k] = (int32_t)pb[u][k];
+      }
+    }
+    if (__ballot(bad)) SM_FAIL(ST_INVALID, 681);
+  }
   SM_SYNC();
   // ---- P3. the listed vertices again: ids per corner by a walk.  With cum = cuts met so far (the corner's own left edge
   // included) and s = 1 if the walk starts on a cut: attribute vertex = first + (cum - s) mod n (RecomputeVertices numbers from the
@@ -323,39 +416,6 @@ __device__ __forceinline__ void seam_tables_wave(uint8_t *arena, const MeshLayou
       }
     }
     if (__ballot(bad)) SM_FAIL(ST_INVALID, 651);
-  }
-  // ---- P4. faces: the corners of every vertex that is not listed take the vertex's one id and its one point
-  {
-    bool bad = false;
-    for (uint32_t f0 = 0; f0 < F; f0 += WAVE) {
-      const uint32_t f = f0 + lane;
-      if (f >= F) continue;
-      const uint4 vv = R::vertices_of(frec, f);
-      const uint32_t v[3] = {vv.x, vv.y, vv.z};
-      bool plain[3];
-#pragma unroll
-      for (uint32_t k = 0; k < 3; ++k) {
-        if (v[k] >= NVALL) { bad = true; plain[k] = false; continue; }
-        plain[k] = vseam[v[k]] == 0;
-        if (plain[k]) c2p[3u * f + k] = (int32_t)pbase[v[k]];
-      }
-      for (uint32_t d = 0; d < nad; ++d) {
-        if (!((cmask >> d) & 1u)) continue;
-        const uint32_t *vb = SM_VBASE(d);
-        uint32_t id[3];
-#pragma unroll
-        for (uint32_t k = 0; k < 3; ++k) id[k] = plain[k] ? vb[v[k]] : 0x1FFFFFu;
-        uint32_t *rec = SM_REC(d);
-        if (CP) {
-          if (plain[0] || plain[1] || plain[2])
-            atomicAnd((unsigned long long *)rec + (size_t)f * 2, Rec<true>::pack(id[0], id[1], id[2]) | (~0ull << 63));
-        } else {
-#pragma unroll
-          for (uint32_t k = 0; k < 3; ++k) if (plain[k]) rec[fv_idx(4u * f + k)] = id[k];
-        }
-      }
-    }
-    if (__ballot(bad)) SM_FAIL(ST_INVALID, 681);
   }
   // ---- results: points of the mesh, vertices of every attribute table = entries of its decoder's attributes
   if (lane == 0) {
@@ -452,6 +512,7 @@ __global__ __launch_bounds__(256) void k_seam_maps(uint8_t *arena, const MeshLay
 
 #undef SM_FAIL
 #undef SM_SYNC
+#undef SM_U
 
 // =========================================================================
 // TexCoordsPortable (MeshPredictionSchemeTexCoordsPortableDecoder.cs:50-85, ...PortablePredictor.cs:46-150; what stock encoders
@@ -582,9 +643,43 @@ __global__ __launch_bounds__(256) void k_texcoords_prepare(uint8_t *arena, const
   else texcoords_prepare_entries<false>(arena, L, D, ai, (uint32_t)pa, tid, stride);
 }
 
-// The chain: one lane per (mesh, attribute).
+// The chain: one lane per (mesh, attribute).  A step needs the entry's TcPrep record, its correction and the decoded texture
+// coordinates of two earlier entries -- loads that a lone lane would wait a microsecond for, 33 000 times.  None of their addresses
+// depends on the chain, so they are requested ahead: entries are taken in groups of TC_G; while group g is computed the records of
+// group g + 2 and the operands of group g + 1 are on their way.  An operand that is not final when it would have to be requested
+// (an entry of group g or g + 1 itself: the usual case for one of the two, the strip's previous entry) comes from a register window
+// of the last 2 TC_G results instead.
+#define TC_G 4
+// su / d truncated toward zero (the C# operator) for the chain: the quotient from a double multiplication with 1 / d, put right by
+// the remainder -- exact while d fits 32 bits and the quotient 31 (anything else takes the operator's long road)
+__device__ __noinline__ int64_t tc_div_slow(int64_t x, int64_t y) { return x / y; }      // (one copy: the chain is unrolled twelve entries deep)
+__device__ __forceinline__ int32_t tc_div(int64_t su, int64_t d, double inv, bool d_small) {
+  const double sd = __fma_rn((double)(int32_t)(su >> 32), 4294967296.0, (double)(uint32_t)su);      // exact below 2^53
+  const double qe = sd * inv;
+  if (!d_small || !(qe > -2147483000.0 && qe < 2147483000.0) || !(sd > -4.0e15 && sd < 4.0e15)) return (int32_t)tc_div_slow(su, d);
+  int32_t q = (int32_t)qe;                                 // toward zero; off by one at most
+  int64_t r = su - (int64_t)q * d;
+  if (su >= 0) {
+    if (r < 0) { --q; r += d; }
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+    if (r >= d) { ++q; r -= d; }
+  } else {
+    if (r > 0) { ++q; r -= d; }
+    if (r > 0) { ++q; r -= d; }
+    if (r <= -d) { --q; r += d; }
+    if (r <= -d) { --q; r += d; }
+  }
+  return q;
+}
+// The loop body has no memory load inside a branch: every request is issued in straight-line code, so that the waits the compiler
+// places count exactly the younger requests (vmcnt is one in-order counter) instead of draining everything that is in flight.
+#define TC_DEPTH 3        // groups of records in flight
+#define TC_RING 8         // results of a lane kept in LDS (the operands too recent to have been requested: < TC_G + TC_G back)
 __global__ __launch_bounds__(WAVE) void k_texcoords(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
-  const uint32_t mesh = blockIdx.x * WAVE + lane_id(), ai = blockIdx.y;
+  __shared__ int2 ring[TC_RING][WAVE];
+  const uint32_t lane = lane_id();
+  const uint32_t mesh = blockIdx.x * WAVE + lane, ai = blockIdx.y;
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
   if (status_of(D) != ST_OK || D->general || ai >= D->num_attributes) return;
@@ -592,46 +687,106 @@ __global__ __launch_bounds__(WAVE) void k_texcoords(uint8_t *arena, const MeshLa
   const MeshLayout &L = layouts[mesh];
   if (!a.have_scheme || a.pred_kind != 3 || a.source == SRC_BYTES || a.num_entries == 0 || L.tc[ai] == 0) return;
   const TcPrep *prep = (const TcPrep *)(arena + L.tc[ai]);
-  int32_t *w = (int32_t *)(arena + L.work[ai]);
+  int2 *w2 = (int2 *)(arena + L.work[ai]);
   uint32_t cap;
   const uint32_t *obits = orient_bits_of(arena, L, D, ai, &cap);
-  const uint32_t entries = a.num_entries;
+  const uint32_t entries = a.num_entries, lastp = entries - 1;
   const int32_t mn = a.wrap_min, mx = a.wrap_max, max_dif = 1 + mx - mn;
-  uint32_t left = a.num_orient;                           // orientations are taken from the back of the list (:111-113)
+  // Orientations are taken from the back of the list (:111-113).  The word in use and the two below it are kept in registers; the
+  // two lower ones are requested anew at every group's turn (for the word index of that moment) and taken over at the next turn,
+  // where the index has moved by one word at most (a group consumes four orientations at most).
+  uint32_t left = a.num_orient;
+  uint32_t ow_idx = left ? (left - 1) >> 5 : 0u;
+  uint32_t ow_cur = left ? obits[ow_idx] : 0u, ow_n1 = obits[ow_idx ? ow_idx - 1 : 0u], ow_n2 = obits[ow_idx > 1 ? ow_idx - 2 : 0u];
+  uint32_t ldA = ow_n1, ldB = ow_n2, ld_base = ow_idx;
   bool ran_out = false;
-  for (uint32_t p = 0; p < entries; ++p) {
-    const TcPrep t = prep[p];
-    const int2 corr = *(const int2 *)(w + 2 * (size_t)p);
-    int32_t pu = 0, pv = 0;
-    bool done = false;
-    if (t.next_id != DSA_INVALID && t.prev_id != DSA_INVALID) {
-      const int2 nuv = *(const int2 *)(w + 2 * (size_t)t.next_id), puv = *(const int2 *)(w + 2 * (size_t)t.prev_id);
-      if (puv.x == nuv.x && puv.y == nuv.y) { pu = puv.x; pv = puv.y; done = true; }
-      else if (t.pn_norm2 != 0) {
-        const uint64_t pnu = (uint64_t)((int64_t)puv.x - (int64_t)nuv.x), pnv = (uint64_t)((int64_t)puv.y - (int64_t)nuv.y);
-        const uint64_t xu = (uint64_t)(int64_t)nuv.x * (uint64_t)t.pn_norm2 + (uint64_t)t.cn_dot_pn * pnu;
-        const uint64_t xv = (uint64_t)(int64_t)nuv.y * (uint64_t)t.pn_norm2 + (uint64_t)t.cn_dot_pn * pnv;
+  TcPrep rt[TC_DEPTH][TC_G];
+  int2 rc[TC_DEPTH][TC_G], cfn[TC_G], cfp[TC_G], nfn[TC_G], nfp[TC_G];
+  int2 o1 = make_int2(0, 0);                                // the result of entry p - 1
+#pragma unroll
+  for (int k = 0; k < TC_DEPTH; ++k)
+#pragma unroll
+    for (int u = 0; u < TC_G; ++u) {
+      const uint32_t p = (uint32_t)(k * TC_G + u) <= lastp ? (uint32_t)(k * TC_G + u) : lastp;
+      rt[k][u] = prep[p]; rc[k][u] = w2[p];
+    }
+#pragma unroll
+  for (int u = 0; u < TC_G; ++u) { nfn[u] = make_int2(0, 0); nfp[u] = make_int2(0, 0); }
+#pragma unroll
+  for (int i = 0; i < TC_RING; ++i) ring[i][lane] = make_int2(0, 0);
+  for (uint32_t gbase = 0; gbase <= lastp; gbase += TC_DEPTH * TC_G) {
+#pragma unroll
+    for (int k = 0; k < TC_DEPTH; ++k) {
+      const uint32_t g0 = gbase + (uint32_t)k * TC_G;      // first entry of the group whose turn it is (slot k)
+      const int kn = (k + 1) % TC_DEPTH;                   // (a constant once the loop is unrolled)
+      // ---- the turn starts: take over what the last turn requested, request for the next one
+#pragma unroll
+      for (int u = 0; u < TC_G; ++u) { cfn[u] = nfn[u]; cfp[u] = nfp[u]; }
+      { const bool same = ld_base == ow_idx; ow_n1 = same ? ldA : ldB; ow_n2 = same ? ldB : ow_n2; }
+#pragma unroll
+      for (int u = 0; u < TC_G; ++u) {                     // the next group's operands that are final by now (entries < g0)
+        nfn[u] = w2[rt[kn][u].next_id < g0 ? rt[kn][u].next_id : 0u];
+        nfp[u] = w2[rt[kn][u].prev_id < g0 ? rt[kn][u].prev_id : 0u];
+      }
+      ldA = obits[ow_idx ? ow_idx - 1 : 0u]; ldB = obits[ow_idx > 1 ? ow_idx - 2 : 0u]; ld_base = ow_idx;
+      const uint32_t far_limit = g0 >= TC_G ? g0 - TC_G : 0u;     // what this group's request (a turn ago) covered
+      // ---- the entries of the group, one after the other
+#pragma unroll
+      for (int u = 0; u < TC_G; ++u) {
+        const uint32_t p = g0 + u;
+        const bool live = p <= lastp;
+        const TcPrep t = rt[k][u];
+        const bool hn = t.next_id != DSA_INVALID, hp = t.prev_id != DSA_INVALID, both = hn && hp;
+        // operands: the previous result, a recent one from the ring, or what was requested a turn ago
+        const int2 ln = ring[t.next_id & (TC_RING - 1)][lane], lp = ring[t.prev_id & (TC_RING - 1)][lane];
+        const int2 nuv = p - t.next_id == 1u ? o1 : (t.next_id >= far_limit ? ln : cfn[u]);
+        const int2 puv = p - t.prev_id == 1u ? o1 : (t.prev_id >= far_limit ? lp : cfp[u]);
+        const bool equal = puv.x == nuv.x && puv.y == nuv.y;
+        const int64_t d = t.pn_norm2;
+        const bool geo = both && !equal && d != 0;
+        const bool d_small = d > 0 && d < (int64_t)0x100000000ll;
+        const double inv = __drcp_rn((double)(uint32_t)d);
+        const int32_t dpu = (int32_t)((uint32_t)puv.x - (uint32_t)nuv.x), dpv = (int32_t)((uint32_t)puv.y - (uint32_t)nuv.y);
+        const uint64_t pnu = (uint64_t)(int64_t)dpu, pnv = (uint64_t)(int64_t)dpv;
+        const uint64_t xu = (uint64_t)(int64_t)nuv.x * (uint64_t)d + (uint64_t)t.cn_dot_pn * pnu;
+        const uint64_t xv = (uint64_t)(int64_t)nuv.y * (uint64_t)d + (uint64_t)t.cn_dot_pn * pnv;
         const uint64_t cxu = pnv * (uint64_t)t.norm, cxv = ((uint64_t)0 - pnu) * (uint64_t)t.norm;
-        bool orientation = false;
-        if (left == 0) ran_out = true;
-        else { --left; orientation = ((obits[left >> 5] >> (left & 31u)) & 1u) != 0; }
+        // the orientation (consumed by this entry only when it takes the geometric prediction)
+        const bool take = geo && live;
+        ran_out = ran_out || (take && left == 0);
+        const uint32_t nl = take && left ? left - 1 : left;
+        const bool cross = (nl >> 5) != ow_idx && take && left;
+        ow_idx = cross ? nl >> 5 : ow_idx;
+        ow_cur = cross ? ow_n1 : ow_cur;
+        ow_n1 = cross ? ow_n2 : ow_n1;
+        left = nl;
+        const bool orientation = ((ow_cur >> (left & 31u)) & 1u) != 0;
         const int64_t su = (int64_t)(orientation ? xu + cxu : xu - cxu), sv = (int64_t)(orientation ? xv + cxv : xv - cxv);
-        pu = (int32_t)div_trunc(su, t.pn_norm2);
-        pv = (int32_t)div_trunc(sv, t.pn_norm2);
-        done = true;
+        int32_t gu = 0, gv = 0;
+        if (geo) { gu = tc_div(su, d, inv, d_small); gv = tc_div(sv, d, inv, d_small); }
+        // the fallback chain of the predictor, as written there (:129-149): the entry at Next if it is decoded, else the entry before
+        const int2 fb = hn ? nuv : (p > 0 ? o1 : make_int2(0, 0));
+        const int32_t pu = both && equal ? puv.x : (geo ? gu : fb.x), pv = both && equal ? puv.y : (geo ? gv : fb.y);
+        int2 o;
+        o.x = wrap_original(pu, rc[k][u].x, mn, mx, max_dif);
+        o.y = wrap_original(pv, rc[k][u].y, mn, mx, max_dif);
+        o = live ? o : o1;                                 // (behind the last entry: it is written again)
+        w2[live ? p : lastp] = o;
+        ring[p & (TC_RING - 1)][lane] = o;
+        o1 = o;
+      }
+      // ---- the slot is free: the records of the group TC_DEPTH turns ahead
+#pragma unroll
+      for (int u = 0; u < TC_G; ++u) {
+        const uint32_t p2 = g0 + TC_DEPTH * TC_G + u <= lastp ? g0 + TC_DEPTH * TC_G + u : lastp;
+        rt[k][u] = prep[p2]; rc[k][u] = w2[p2];
       }
     }
-    if (!done) {
-      // the fallback chain of the predictor, as written there (:129-149): the entry at Next if it is decoded, else the entry before
-      if (t.next_id != DSA_INVALID) { const int2 q = *(const int2 *)(w + 2 * (size_t)t.next_id); pu = q.x; pv = q.y; }
-      else if (p > 0) { const int2 q = *(const int2 *)(w + 2 * (size_t)(p - 1)); pu = q.x; pv = q.y; }
-    }
-    int2 o;
-    o.x = wrap_original(pu, corr.x, mn, mx, max_dif);
-    o.y = wrap_original(pv, corr.y, mn, mx, max_dif);
-    *(int2 *)(w + 2 * (size_t)p) = o;
   }
   if (ran_out) fail(D, ST_INVALID, 672);
 }
+#undef TC_DEPTH
+#undef TC_RING
+#undef TC_G
 
 }  // namespace dsa

@@ -405,9 +405,10 @@ def test_many_large_alphabets_in_one_batch(ctx):
 
 def test_schemes_behind_the_symbol_streams_take_the_second_chance(ctx):
     """Which prediction scheme an attribute uses stands behind its symbol stream, where the host parse does not go.
-    GeometricNormal (method 6) runs on the fast kernels (k_flip_bits, k_predict_geometric); TexCoordsPortable and the
-    multi-parallelogram schemes need the general path's tables: k_locate hands such meshes back (DSA_SITE_RETRY_GENERAL) and
-    dsa_batch_wait decodes them again through k_general, next to meshes that stay on the fast kernels."""
+    GeometricNormal (method 6) and TexCoordsPortable (method 5) run on the fast kernels (k_flip_bits + k_predict_geometric,
+    k_orient_bits + k_texcoords_prepare + k_texcoords); the multi-parallelogram schemes need the general path's tables: k_locate
+    hands such meshes back (DSA_SITE_RETRY_GENERAL) and dsa_batch_wait decodes them again through k_general, next to meshes that
+    stay on the fast kernels."""
     streams, geo = [], []
     for k, (kind, nx, ny) in enumerate(KINDS):
         pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 21)
@@ -415,12 +416,12 @@ def test_schemes_behind_the_symbol_streams_take_the_second_chance(ctx):
         streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(normal_prediction=6 if g else 0, single_connectivity=k & 1,
                                                                                   pos_bits=11 + k, normal_bits=8 + (k % 5))))
         geo.append(False)
-    # TexCoordsPortable with standard traversal goes to the general path
+    # TexCoordsPortable stays on the fast kernels too (round 4)
     pos, nrm, uv, faces = synth.make_mesh(synth.HOLES, 20, 16, 22)
     for npred in (0, 6):
-        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(uv_prediction=5, normal_prediction=npred)))
-        geo.append(True)
-    # and so do the multi-parallelogram schemes
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(uv_prediction=5, normal_prediction=npred, force_scheme=1)))
+        geo.append(False)
+    # the multi-parallelogram schemes go to the general path
     for ppred, upred in ((2, 1), (4, 4), (1, 2)):
         streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=ppred, uv_prediction=upred)))
         geo.append(True)
@@ -428,7 +429,7 @@ def test_schemes_behind_the_symbol_streams_take_the_second_chance(ctx):
     for i, sbytes in enumerate(streams):
         assert b.status(i) == 0, (i, b.status(i), b.mesh_info(i).detail)
         ref = oracle.decode(sbytes)
-        assert any(x.pred_method in (2, 4, 5) for x in ref.attributes) == geo[i]
+        assert any(x.pred_method in (2, 4) for x in ref.attributes) == geo[i]
         assert_same(b.result(i), ref, b, i)
         assert (b.debug_array(i, 4, np.uint32, 12)[6] == 0) == geo[i]      # decoded by k_general / by the fast kernels
     # decoding the same batch again rebuilds the second-chance batch

@@ -161,10 +161,37 @@ def test_gpu_seamed_meshes_with_every_scheme(ctx):
 
 
 @pytest.mark.gpu
+def test_gpu_seams_take_the_fast_kernels(ctx, house04_bytes):
+    """Corner-attribute decoders run on the wave-per-mesh kernels (k_seam_tables, k_traverse_att, k_seam_maps; TexCoordsPortable by
+    k_texcoords): decode_path 0 for raw-coded seamed streams of every topology, standard and valence connectivity, one and two
+    seamed attributes -- and for the reference's own sample, house_04 (valence symbols in tagged context lists, 59 topology splits,
+    UV seams, TexCoordsPortable).  What still takes the second chance: corner attributes whose symbols are tagged (their extent is
+    the entry count, which only k_seam_tables knows), normals with seams under GeometricNormal, the multi-parallelogram schemes."""
+    import draco_sharp_amd as dsa
+    from test_gpu_parity import assert_same
+    cases = []
+    for kind, nx, ny in TOPOLOGIES + [(synth.GRID, 40, 33)]:
+        for charts in ((None, "stripes"), ("checker", "island"), ("random", "random")):
+            for opt in (dict(), dict(uv_prediction=5), dict(predictive_connectivity=2, uv_prediction=5)):
+                args = seamed_mesh(synth, kind, nx, ny, 13, *charts)
+                cases.append((args, synth.encode_mesh_corners(*args, opt=synth.options(force_scheme=1, **opt))))
+    paths = _gpu_check(ctx, cases)
+    assert set(paths) == {0}, paths
+    # tagged symbols in a corner attribute: handed back by k_locate, decoded by the general path, equal all the same
+    args = seamed_mesh(synth, synth.TORUS, 10, 8, 13, None, "stripes")
+    assert _gpu_check(ctx, [(args, synth.encode_mesh_corners(*args, opt=synth.options(force_scheme=0)))]) == [2]
+    b = dsa.Batch(ctx, [house04_bytes])
+    b.decode()
+    assert b.status(0) == 0 and b.mesh_info(0).decode_path == 0
+    assert_same(b.result(0), oracle.decode(house04_bytes))
+    b.close()
+
+
+@pytest.mark.gpu
 def test_gpu_seams_at_64k_triangles(ctx):
     cases = []
     for kind, charts, opt in ((synth.GRID, ("stripes", "checker"), dict(predictive_connectivity=2, uv_prediction=5)),
                               (synth.TORUS, (None, "island"), dict()), (synth.GRID, ("random", "random"), dict(force_scheme=0))):
         args = seamed_mesh(synth, kind, 128, 256, 9, *charts)
         cases.append((args, synth.encode_mesh_corners(*args, opt=synth.options(**opt))))
-    _gpu_check(ctx, cases)
+    assert _gpu_check(ctx, cases) == [0, 0, 2]         # the fast kernels, but for the stream with tagged symbols in its corner attributes
