@@ -235,6 +235,52 @@ def sustained_leg(dsa, ctx, blob, offsets, steps, warmup, comm, barrier, world):
             "what": "the same device-resident decode as `value`, two batches in flight on the context's two stream sets (no wait between steps)"}
 
 
+def dialects_leg(dsa, synth, ctx, nx, ny, n, steps):
+    """The same batch size in the dialects stock encoders write, device-resident like `value`: texture coordinates given per corner
+    (three UV charts: attribute seams, an attribute corner table, a corner attribute) and the prediction schemes of the default
+    encoder settings (TexCoordsPortable, GeometricNormal, valence-coded connectivity).  The batch cycles through 32 distinct
+    meshes (the writer is the CPU coder driven from Python); three meshes of every variant are compared with the oracle."""
+    import numpy as np
+    import oracle
+    from meshutil import seamed_mesh
+    variants = [("uv_seams", (None, "stripes"), dict()),
+                ("uv_seams_texcoords_portable", (None, "stripes"), dict(uv_prediction=5)),
+                ("stock_default_per_vertex", None, dict(uv_prediction=5, predictive_connectivity=2, normal_prediction=6)),
+                ("stock_default_uv_seams", (None, "stripes"), dict(uv_prediction=5, predictive_connectivity=2, normal_prediction=6))]
+    out = {}
+    for name, charts, opt in variants:
+        distinct = []
+        for k in range(32):
+            if charts is None:
+                pos, nrm, uv, faces = synth.make_mesh(synth.GRID, nx, ny, 1000 + k)
+                distinct.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(**opt)))
+            else:
+                distinct.append(synth.encode_mesh_corners(*seamed_mesh(synth, synth.GRID, nx, ny, 1000 + k, *charts), opt=synth.options(**opt)))
+        streams = [distinct[i % 32] for i in range(n)]
+        b = dsa.Batch(ctx, streams)
+        b.decode()
+        b.decode()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            b.decode()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        failed = sum(1 for i in range(n) if b.status(i) != 0)
+        paths = sorted(set(int(b.mesh_info(i).decode_path) for i in range(0, n, 61)))
+        equal = True
+        for i in (0, 1, 31):
+            ref = oracle.decode(streams[i])
+            m = b.result(i).ConnectedData
+            ok = np.array_equal(m.Faces, ref.faces) and len(m.Attributes) == len(ref.attributes)
+            for a, r in zip(m.Attributes, ref.attributes):
+                ok = ok and np.array_equal(a.PortableValues, r.portable) and np.array_equal(a.PointMap, r.point_map) and a.Values.tobytes() == r.values.tobytes()
+            equal = equal and ok
+        out[name] = {"meshes_per_s": n / ms * 1e3, "ms_per_step": ms, "decode_paths": paths, "failed": failed, "equal_to_oracle": bool(equal),
+                     "bytes_per_mesh": len(distinct[0]), "kernels_ms": {k: round(v, 2) for k, v in b.kernel_times().items()}}
+        b.close()
+        ctx.trim()
+    return out
+
+
 def oracle_check(batch, blob, offsets, indices):
     """Outside the timed region: the decoded results of `indices` equal the CPU oracle's (faces, portable integers,
     point maps, floats bit for bit)."""
@@ -266,6 +312,7 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-pool", action="store_true")
     ap.add_argument("--no-sustained", action="store_true")
+    ap.add_argument("--no-dialects", action="store_true")
     ap.add_argument("--e2e-batches", type=int, default=6)
     ap.add_argument("--encode-meshes", type=int, default=4096, help="meshes per GPU of the encode leg (BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -317,6 +364,7 @@ def main():
         os.environ.setdefault("DSA_HOST_THREADS", str(max(2, min(32, host_cores // world))))
     ctx = dsa.Context(local_rank)
     ctx.set_profiling(True)
+    schedule_note = ctx.schedule_note()
 
     def barrier():
         comm.barrier()
@@ -445,6 +493,9 @@ def main():
     sustained = None
     if not args.no_sustained and weak_blob is not None:
         sustained = sustained_leg(dsa, ctx, weak_blob, weak_offsets, max(4, args.steps), args.warmup, comm if world > 1 else None, barrier, world)
+    dialects = None
+    if not args.no_dialects and world == 1 and weak_blob is not None:
+        dialects = dialects_leg(dsa, synth, ctx, nx, ny, args.meshes, 3)
     encode = None
     if not args.no_encode:                                           # every rank: the leg's clock is the slowest rank's
         encode = encode_leg(dsa, synth, ctx, nx, ny, args.encode_meshes, comm if world > 1 else None, barrier if world > 1 else None, world)
@@ -493,6 +544,9 @@ def main():
             out["roofline"]["leg"] = "weak (a full %d-mesh batch per GPU): the kernels' roofline does not depend on the partition" % args.meshes
         if sustained is not None:
             out["sustained"] = sustained
+        if dialects is not None:
+            out["dialects"] = dialects
+        out["schedule_note"] = schedule_note
         if encode is not None:
             out["encode"] = encode
         if e2e is not None:

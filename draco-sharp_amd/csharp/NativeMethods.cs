@@ -120,6 +120,7 @@ internal static unsafe partial class NativeMethods
     [DllImport(Lib)] internal static extern DsaStatus dsa_batch_stage_times(IntPtr batch, float* ms, IntPtr* names);
     [DllImport(Lib)] internal static extern DsaStatus dsa_batch_kernel_times(IntPtr batch, float* ms, IntPtr* names, uint capacity, out uint count);
     [DllImport(Lib)] internal static extern DsaStatus dsa_context_trim(IntPtr ctx);
+    [DllImport(Lib)] internal static extern IntPtr dsa_context_schedule_note(IntPtr ctx);
 
     // encode direction (DracoEncoder.Encode, src/Draco/IO/DracoEncoder.cs:22-41)
     [DllImport(Lib)] internal static extern void dsa_encode_default_options(out DsaEncodeOptions options);

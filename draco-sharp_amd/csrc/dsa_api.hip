@@ -83,6 +83,8 @@ struct StreamSet {
   hipStream_t stream2 = nullptr;     // symbol decode runs here, concurrently with connectivity + traversal
   hipStream_t stream3 = nullptr;     // connectivity validation (link symmetry, seam streams)
   hipStream_t stream4 = nullptr;     // early attributes: symbols, prediction, dequantisation (dispatch priority)
+  hipStream_t stream5 = nullptr;     // the serial bit streams of the late prediction schemes (flip bits, orientation bits): wanted late, so
+                                     // they must not stand in front of anything on another stream
   hipEvent_t ev_join3 = nullptr, ev_trav = nullptr, ev_maps = nullptr, ev_early = nullptr, ev_flips = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_conn = nullptr;
   hipEvent_t ev_seambits = nullptr, ev_tables = nullptr, ev_att = nullptr;      // fast seam path: seam bits decoded, seam tables built, attribute traversals done
@@ -96,13 +98,14 @@ struct StreamSet {
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&stream4, hipStreamNonBlocking, (least + greatest) / 2);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, least);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream5, hipStreamNonBlocking);
     for (hipEvent_t *ev : {&ev_join3, &ev_trav, &ev_maps, &ev_flips, &ev_early, &ev_fork, &ev_join, &ev_conn, &ev_seambits, &ev_tables, &ev_att})
       if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     return e;
   }
   void destroy() {
     for (hipEvent_t *ev : {&ev_join3, &ev_trav, &ev_maps, &ev_flips, &ev_early, &ev_fork, &ev_join, &ev_conn, &ev_seambits, &ev_tables, &ev_att}) { if (*ev) (void)hipEventDestroy(*ev); *ev = nullptr; }
-    for (hipStream_t *s : {&stream2, &stream3, &stream4}) { if (*s) (void)hipStreamDestroy(*s); *s = nullptr; }
+    for (hipStream_t *s : {&stream2, &stream3, &stream4, &stream5}) { if (*s) (void)hipStreamDestroy(*s); *s = nullptr; }
     if (own_stream && stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
   }
@@ -132,6 +135,11 @@ struct dsa_context {
   // worker threads and from whichever thread frees a job while the next decode runs (dsa_pool.h): one lock for all of them.
   std::mutex mu;
   std::vector<std::unique_ptr<EncLane>> enc_lanes;    // kept between dsa_encode_batch calls (pinning their staging costs more than a small batch)
+  // k_register_gate holds the late symbol kernel back by asking for more registers than a SIMD has left beside four chain waves and
+  // three entropy decoders.  That is occupancy arithmetic on THIS build's register counts: checked once per context (gate_check),
+  // and the gate is left out -- with a note here -- when the numbers no longer add up.
+  bool gate_ok = false;
+  std::string gate_note;
 };
 
 struct dsa_batch {
@@ -372,6 +380,29 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
   return DSA_OK;
 }
 
+// The register arithmetic k_register_gate rests on (dsa_kernels.h): a SIMD's 512 vector registers hold four
+// k_chain waves and three k_symbols_reg waves, and what is left is less than one k_register_gate wave asks for -- so the gate's idle
+// waves find room only when decoders leave.  Allocation granularity 8 registers.
+void gate_check(dsa_context *c) {
+  hipFuncAttributes chain{}, reg{}, gate{};
+  if (hipFuncGetAttributes(&chain, (const void *)dsa::k_chain) != hipSuccess || hipFuncGetAttributes(&reg, (const void *)dsa::k_symbols_reg) != hipSuccess ||
+      hipFuncGetAttributes(&gate, (const void *)dsa::k_register_gate) != hipSuccess) {
+    (void)hipGetLastError();
+    c->gate_ok = false; c->gate_note = "k_register_gate left out: kernel attributes not available";
+    return;
+  }
+  auto up8 = [](int r) { return (r + 7) / 8 * 8; };
+  const int rc = up8(chain.numRegs), rr = up8(reg.numRegs), rg = up8(gate.numRegs), simd = 512;
+  const int left = simd - 4 * rc - 3 * rr;                 // beside four chain waves and three decoders
+  // the gate must not fit there, nor a fourth decoder (else the machine is not the one the schedule was measured on), but must
+  // fit once the decoders have left
+  c->gate_ok = left >= 0 && rg > left && rr > left && rg <= left + 3 * rr;
+  char buf[256];
+  snprintf(buf, sizeof(buf), "k_register_gate %s: registers k_chain %d, k_symbols_reg %d, k_register_gate %d; %d left beside 4 + 3 waves of a SIMD",
+           c->gate_ok ? "in use" : "left out", chain.numRegs, reg.numRegs, gate.numRegs, left);
+  c->gate_note = buf;
+}
+
 }  // namespace
 
 extern "C" {
@@ -401,6 +432,7 @@ dsa_status dsa_context_create(int device, void *stream, dsa_context **out) {
     if (c->sets[k].create(k == 0 ? (hipStream_t)stream : nullptr, least, greatest) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
   if (hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
+  gate_check(c);
   *out = c;
   return DSA_OK;
 }
@@ -566,10 +598,12 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     uint32_t lpm = 1;
     while (lpm < na) lpm *= 2;
     const uint32_t per_wave = WAVE / lpm;
-    hipLaunchKernelGGL(dsa::k_flip_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, lpm);
+    hipStream_t st5 = serial ? st : S.stream5;
+    HIP_TRY(ctx, hipStreamWaitEvent(st5, S.ev_fork, 0));
+    hipLaunchKernelGGL(dsa::k_flip_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st5, b->arena, b->d_layouts, b->d_descs, n, lpm);
     // and the orientation bits of TexCoordsPortable attributes, the same way
-    hipLaunchKernelGGL(dsa::k_orient_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, lpm);
-    HIP_TRY(ctx, hipEventRecord(S.ev_flips, st3));
+    hipLaunchKernelGGL(dsa::k_orient_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st5, b->arena, b->d_layouts, b->d_descs, n, lpm);
+    HIP_TRY(ctx, hipEventRecord(S.ev_flips, st5));
   }
   // parallelogram operands: by the traversal waves themselves when the batch keeps the machine busy anyway, by an
   // element-parallel kernel behind the traversal when it does not
@@ -692,7 +726,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     // Until the registers of the 16 KB tier were put right its idle waves did this by accident.)
     HIP_TRY(ctx, hipStreamWaitEvent(st4, S.ev_conn, 0));
     launch_symbols(st4, lane_flags | SYM_EARLY_ONLY | early_fuse);
-    launch_symbols(st2, lane_flags | SYM_LATE_ONLY, true);
+    launch_symbols(st2, lane_flags | SYM_LATE_ONLY, ctx->gate_ok);
   } else if (sym_split) {                      // both at once, the early ones on the stream with priority
     HIP_TRY(ctx, hipStreamWaitEvent(st4, S.ev_conn, 0));
     launch_symbols(st4, lane_flags | SYM_EARLY_ONLY | early_fuse);
@@ -1163,6 +1197,8 @@ dsa_status dsa_batch_kernel_times(const dsa_batch *b, float *ms, const char **na
   *count = k_out;
   return DSA_OK;
 }
+
+const char *dsa_context_schedule_note(const dsa_context *ctx) { return ctx ? ctx->gate_note.c_str() : ""; }
 
 dsa_status dsa_context_trim(dsa_context *ctx) {
   if (!ctx) return DSA_ERR_INVALID_ARGUMENT;

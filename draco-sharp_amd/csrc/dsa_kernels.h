@@ -194,6 +194,42 @@ __device__ __forceinline__ const uint32_t *att_para(uint8_t *arena, const MeshLa
 }
 
 
+// A whole rABS block (RAnsBitDecoder.cs:12-24, AnsDecoder.cs:42-56) decoded by ONE LANE into bit words -- the seam bits of an
+// attribute data, the flip bits of a GeometricNormal attribute, the orientation bits of a TexCoordsPortable one: serial streams
+// that 64 lanes of a wave decode side by side, each its own.  Two things keep the shared instruction stream short: every lane is
+// at the same bit index (one loop, one store per 32 bits, no group-of-zeros shortcut that would send the lanes down different
+// paths), and the stream bytes come from two aligned words held in registers, the lower one requested a word ahead of its use
+// (a load inside the renormalisation branch would make the whole wave wait for memory at nearly every bit: some lane always
+// renormalises).  TOGGLE: a decoded bit says "same as the one before" (MeshPredictionSchemeTexCoordsPortableDecoder.cs:66-85).
+// Returns the index of the first set bit (DSA_INVALID: none).
+template <bool TOGGLE>
+__device__ __forceinline__ uint32_t rabs_block_to_words(const Rabs &rb, uint32_t count, uint32_t *words) {
+  uint32_t state = rb.state, left = rb.off, first = DSA_INVALID;
+  const uint32_t p = rb.p;
+  // the next byte to take is buf[left - 1]
+  const uintptr_t a0 = (uintptr_t)rb.buf + (left ? left - 1u : 0u);
+  const uint32_t *wp = (const uint32_t *)(a0 & ~(uintptr_t)3);
+  uint32_t sh = (uint32_t)(a0 & 3u) * 8u;
+  uint32_t cur = wp[0], nxt = wp[-1];                      // (reads below the block stay inside the arena: layouts and streams precede it)
+  uint32_t word = 0, last = 1;
+  for (uint32_t i = 0; i < count; ++i) {
+    if (state < 4096u && left > 0u) {
+      state = state * 256u + ((cur >> sh) & 255u);
+      --left;
+      if (sh == 0u) { sh = 24u; cur = nxt; --wp; nxt = wp[-1]; } else sh -= 8u;
+    }
+    const uint32_t quot = state >> 8, rem = state & 255u, xn = quot * p;
+    const bool val = rem < p;
+    state = val ? xn + rem : state - xn - p;
+    if (val && first == DSA_INVALID) first = i;
+    if (TOGGLE) { last ^= val ? 0u : 1u; word |= last << (i & 31u); }
+    else word |= (val ? 1u : 0u) << (i & 31u);
+    if ((i & 31u) == 31u) { words[i >> 5] = word; word = 0; }
+  }
+  if (count & 31u) words[count >> 5] = word;
+  return first;
+}
+
 // =========================================================================
 // k_locate, k_locate_resume: one wave per mesh, lane 0 walks the stream (dsa_locate.h).  k_locate goes to the end of the stream
 // or to the first tagged symbol stream; k_tags (below, with the symbol kernels) decodes that tag stream on the whole wave, and
@@ -999,6 +1035,9 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
   const MeshLayout &L = layouts[mesh];
   MeshDesc *D = &descs[mesh];
   if (status_of(D) != ST_OK || D->encoder_type == 0 || D->general || d >= D->num_att_data) return;
+  // the seam bits of a mesh with corner attributes gate its seam tables: a hundred thousand dependent steps on a handful of waves,
+  // which must not wait twenty cycles for every issue slot behind the entropy decoders
+  if (L.seam_bytes) __builtin_amdgcn_s_setprio(DSA_CHAIN_PRIO);
   const uint8_t *s = arena + L.stream;
   // One seam bit per interior edge and attribute data.  How many edges are interior is the connectivity's result, which this
   // kernel does not wait for: it looks for the first set bit among as many bits as a mesh of F faces can have (3F / 2) and
@@ -1019,6 +1058,10 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
     const SeamLayout g = seam_layout(L.cap_faces, L.cap_vertices, D->num_att_data, L.rec_compact != 0);
     store = (uint32_t *)(seam_block(arena, L, g, d) + g.bits);
   }
+  if (store) {       // (every lane of the wave at the same bit: see rabs_block_to_words)
+    D->seam_first[d] = rabs_block_to_words<false>(rb, edges, store);
+    return;
+  }
   while (i < edges) {
     if (state < 4096 && off > 0) state = state * 256 + rb.buf[--off];
     if (p <= 16 && state >= 8192 && i + 8 <= edges) {
@@ -1037,12 +1080,8 @@ __global__ __launch_bounds__(WAVE) void k_conn_checks(uint8_t *arena, const Mesh
     }
     const uint32_t quot = state >> 8, rem = state & 255u, xn = quot * p;
     const bool val = rem < p;
-    if (val) {
-      if (first == DSA_INVALID) first = i;
-      if (!store) break;
-      store[i >> 5] |= 1u << (i & 31u);
-      state = xn + rem;                      // AnsDecoder.cs:49-52: the set bit's successor
-    } else state = state - xn - p;
+    if (val) { first = i; break; }
+    state = state - xn - p;
     ++i;
   }
   D->seam_first[d] = first;
@@ -3152,12 +3191,7 @@ __global__ __launch_bounds__(WAVE) void k_flip_bits(uint8_t *arena, const MeshLa
   uint32_t *bits = flip_bits_of(arena, L, ai);
   const uint32_t entries = a.num_entries;
   if (entries > L.cap_vertices) { fail(D, ST_INVALID, 657); return; }
-  uint32_t word = 0;
-  for (uint32_t p = 0; p < entries; ++p) {              // RAnsBitDecoder.cs:12-24, AnsDecoder.cs:42-56
-    word |= rb.next() << (p & 31u);
-    if ((p & 31u) == 31u) { bits[p >> 5] = word; word = 0; }
-  }
-  if (entries & 31u) bits[entries >> 5] = word;
+  (void)rabs_block_to_words<false>(rb, entries, bits);
 }
 
 // NARROW: the positions are quantised (below 2^30), so the edge vectors fit 32 bits and a term of the cross product is one

@@ -442,6 +442,7 @@ __global__ __launch_bounds__(WAVE) void k_seam_tables(uint8_t *arena, const Mesh
   if (status_of(D) != ST_OK || D->general || !D->seam_fast || D->encoder_type == 0) return;
   const MeshLayout &L = layouts[mesh];
   if (L.seam_bytes == 0) return;
+  __builtin_amdgcn_s_setprio(DSA_CHAIN_PRIO);              // on the critical path of a seamed mesh, like the connectivity before it
   if (L.rec_compact) seam_tables_wave<true>(arena, L, D);
   else seam_tables_wave<false>(arena, L, D);
 }
@@ -564,13 +565,7 @@ __global__ __launch_bounds__(WAVE) void k_orient_bits(uint8_t *arena, const Mesh
   uint32_t *bits = orient_bits_of(arena, L, D, ai, &cap);
   const uint32_t count = a.num_orient;
   if (count > cap) { fail(D, ST_INVALID, 668); return; }
-  uint32_t word = 0, last = 1;
-  for (uint32_t p = 0; p < count; ++p) {
-    if (rb.next() == 0) last ^= 1u;
-    word |= last << (p & 31u);
-    if ((p & 31u) == 31u) { bits[p >> 5] = word; word = 0; }
-  }
-  if (count & 31u) bits[count >> 5] = word;
+  (void)rabs_block_to_words<true>(rb, count, bits);
 }
 
 template <bool CP>

@@ -243,6 +243,10 @@ class Context:
     def set_profiling(self, on=True):
         self._L.dsa_context_set_profiling(self._h, 1 if on else 0)
 
+    def schedule_note(self):
+        """What the context found when it checked its schedule's assumptions (register counts behind k_register_gate)."""
+        return self._L.dsa_context_schedule_note(self._h).decode()
+
     def trim(self):
         """Releases the arenas, pinned mirrors and encoder lanes the context keeps between calls."""
         self._L.dsa_context_trim(self._h)

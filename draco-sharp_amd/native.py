@@ -19,7 +19,7 @@ EXPORTS = [
     "dsa_batch_copy_portable_values", "dsa_batch_device_faces", "dsa_batch_device_attribute_values",
     "dsa_batch_device_point_map", "dsa_batch_output_bytes", "dsa_batch_download", "dsa_batch_host_output", "dsa_batch_output_layout",
     "dsa_host_alloc", "dsa_host_free", "dsa_host_register", "dsa_host_unregister", "dsa_batch_copy_metadata", "dsa_batch_copy_debug", "dsa_context_set_profiling", "dsa_batch_stage_times",
-    "dsa_batch_kernel_times", "dsa_context_trim",
+    "dsa_batch_kernel_times", "dsa_context_trim", "dsa_context_schedule_note",
     "dsa_encode_default_options", "dsa_encode_batch", "dsa_encoded_size", "dsa_encoded_stream", "dsa_encoded_free",
     "dsa_pool_create", "dsa_pool_destroy", "dsa_pool_size", "dsa_pool_last_error", "dsa_pool_decode", "dsa_pool_job_locate",
     "dsa_pool_job_chunks", "dsa_pool_job_free", "dsa_pool_plan",
@@ -120,6 +120,8 @@ def lib():
         L.dsa_batch_stage_times.argtypes = [vp, C.POINTER(C.c_float * DSA_NUM_STAGES), C.POINTER(C.c_char_p * DSA_NUM_STAGES)]
         L.dsa_batch_kernel_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_uint32)]
         L.dsa_context_trim.argtypes = [vp]
+        L.dsa_context_schedule_note.restype = C.c_char_p
+        L.dsa_context_schedule_note.argtypes = [vp]
         L.dsa_encode_default_options.argtypes = [C.POINTER(EncodeOptions)]
         L.dsa_encode_default_options.restype = None
         L.dsa_encode_batch.argtypes = [vp, u32, C.POINTER(MeshInput), C.POINTER(EncodeOptions), C.POINTER(vp)]

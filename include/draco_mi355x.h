@@ -201,6 +201,10 @@ dsa_status dsa_batch_kernel_times(const dsa_batch *batch, float *ms, const char 
 /* Releases what the context keeps between calls: arenas, pinned mirrors and descriptor zones of freed batches, the
  * encoder's lanes (device buffers + pinned staging).  The library does this itself when an allocation fails. */
 dsa_status dsa_context_trim(dsa_context *ctx);
+/* What the context found when it checked the assumptions its kernel schedule rests on (static string owned by the context): the
+ * register counts of the kernels whose occupancy the late symbol launch of a crowded batch is timed by, and whether that
+ * mechanism (k_register_gate) is in use or was left out because the counts of this build no longer add up. */
+const char *dsa_context_schedule_note(const dsa_context *ctx);
 
 /* ------------------------------------------------------------------ encode direction
  * Drop-in for DracoEncoder.Encode(BinaryWriter, Config, PointCloud, attributes)   src/Draco/IO/DracoEncoder.cs:22-41

@@ -292,7 +292,7 @@ def test_corrupt_streams_agree_with_the_oracle(ctx, house04_bytes):
     # method byte above 1, which the oracle reads as depth-first), 263 (the census of linked corners) and 681 (the general path's
     # bound on attribute seam data).  Four seeds of this mix gave 0 - 1 such streams of 292 (sites 123, 681); anything else, or
     # more than a handful, is a difference to look at.  (454 streams with the GeometricNormal and the large tagged family.)
-    assert set(stricter_sites) <= {(1, 123), (1, 263), (1, 681)}, stricter_sites
+    assert set(stricter_sites) <= {(1, 123), (1, 263), (1, 681), (1, 668)}, stricter_sites      # 668: more orientation bits than entries
     assert gpu_stricter <= 4, (agree_ok, agree_bad, stricter_sites)
     b.close()
 
@@ -803,6 +803,15 @@ def test_decodes_alternate_between_the_two_stream_sets(ctx):
             assert b.status(i) == 0, (i, b.mesh_info(i).detail)
             assert_same(b.result(i), oracle.decode(s), b, i)
         b.close()
+
+
+def test_the_schedule_checks_its_own_assumptions(ctx):
+    """k_register_gate times the late symbol launch of a crowded batch by occupancy arithmetic on three kernels' register counts;
+    the context checks that arithmetic against this build's counts when it is created and says what it found."""
+    note = ctx.schedule_note()
+    assert note.startswith("k_register_gate in use") or note.startswith("k_register_gate left out"), note
+    assert "k_chain" in note and "k_symbols_reg" in note
+    print(note)
 
 
 def test_the_bench_batch_at_full_size(ctx):

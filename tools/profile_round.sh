@@ -7,7 +7,7 @@ tag=${1:-r04}
 R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-encode --no-end-to-end --no-pool --no-sustained --check 0 --scaling weak"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-encode --no-end-to-end --no-pool --no-sustained --no-dialects --check 0 --scaling weak"
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
 echo "bench done"

@@ -1,7 +1,9 @@
 """Which kernels decode seamed / TexCoordsPortable streams: decode_path per case (0 = the wave-per-mesh kernels, 2 = second chance on
 the general path) and equality with the oracle.  usage: python tools/seam_paths.py"""
 import sys
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import oracle
 import draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
@@ -19,7 +21,7 @@ for kind, nx, ny in [(synth.GRID, 12, 9), (synth.TORUS, 24, 40), (synth.HOLES, 2
     for opt in [dict(uv_prediction=5), dict(uv_prediction=5, predictive_connectivity=2), dict(uv_prediction=5, single_connectivity=1), dict(uv_prediction=5, normal_prediction=6, predictive_connectivity=2)]:
         pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 3)
         cases.append(((kind, nx, ny, "per-vertex", opt), synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(**opt))))
-cases.append((("house_04.obj.drc",), open("tests/golden/house_04.obj.drc", "rb").read()))
+cases.append((("house_04.obj.drc",), open(os.path.join(ROOT, "tests", "golden", "house_04.obj.drc"), "rb").read()))
 b = dsa.Batch(ctx, [s for _, s in cases])
 b.decode()
 bad = 0

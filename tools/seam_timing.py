@@ -3,7 +3,9 @@ optionally normals) are given per corner (three UV charts: seams from boundary t
 prediction, standard or valence connectivity.  The batch cycles through 32 distinct meshes (the writer is the Python-driven CPU
 coder).  usage: python tools/seam_timing.py [meshes]"""
 import sys, time
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import oracle
 import draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
