@@ -98,7 +98,9 @@ struct StreamSet {
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&stream4, hipStreamNonBlocking, (least + greatest) / 2);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, least);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream3, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream5, hipStreamNonBlocking);
+    // (low priority, beside stream2: the streams of one priority class share four hardware queues, and the default class already
+    // holds stream3, stream4 and the two copy streams -- a fifth there waits behind one of them)
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&stream5, hipStreamNonBlocking, least);
     for (hipEvent_t *ev : {&ev_join3, &ev_trav, &ev_maps, &ev_flips, &ev_early, &ev_fork, &ev_join, &ev_conn, &ev_seambits, &ev_tables, &ev_att})
       if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     return e;
@@ -114,7 +116,11 @@ struct StreamSet {
 struct dsa_context {
   int device = 0;
   StreamSet sets[2];
-  int num_sets = 0, next_set = 0;
+  int num_sets = 0;                  // sets this context may use (1 on a caller's stream); the second is created when first wanted
+  bool set1_made = false;
+  int prio_least = 0, prio_greatest = 0;
+  int last_set = 0;                  // the set of the most recent decode, and that decode's end
+  hipEvent_t last_done = nullptr;
   hipStream_t up = nullptr;          // host -> device: compressed streams of the next batch, beside the kernels of this one
   hipStream_t down = nullptr;        // device -> host: the output block and the mesh descriptors of the previous one
   bool profiling = false;
@@ -428,10 +434,11 @@ dsa_status dsa_context_create(int device, void *stream, dsa_context **out) {
   (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
   // a caller's stream: every decode runs in its order; otherwise two stream sets used in turn (see StreamSet)
   c->num_sets = stream ? 1 : 2;
-  for (int k = 0; k < c->num_sets; ++k)
-    if (c->sets[k].create(k == 0 ? (hipStream_t)stream : nullptr, least, greatest) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
+  c->prio_least = least; c->prio_greatest = greatest;
+  if (c->sets[0].create((hipStream_t)stream, least, greatest) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
   if (hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
+      hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->last_done, hipEventDisableTiming) != hipSuccess) { dsa_context_destroy(c); return DSA_ERR_DEVICE; }
   gate_check(c);
   *out = c;
   return DSA_OK;
@@ -450,6 +457,7 @@ void dsa_context_destroy(dsa_context *ctx) {
   drop_spares(ctx, ctx->spare_mirrors, true);
   drop_spares(ctx, ctx->spare_descs, true);
   for (StreamSet &set : ctx->sets) set.destroy();
+  if (ctx->last_done) (void)hipEventDestroy(ctx->last_done);
   delete ctx;
 }
 
@@ -496,8 +504,23 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   b->collected = false;
   if (b->retry) { dsa_batch_free(b->retry); b->retry = nullptr; }
   b->retry_index.clear();
-  int set_turn;
-  { std::lock_guard<std::mutex> g(ctx->mu); set_turn = ctx->next_set; ctx->next_set = (ctx->next_set + 1) % ctx->num_sets; }
+  // Which stream set: the first, unless the context's previous decode is still running -- then the other one, so that this decode
+  // does not stand behind that one's tail on the same in-order streams.  (The second set is made when first wanted: its streams
+  // share the hardware queues of their priority classes with the first set's, which a context that decodes one batch at a time
+  // should not pay for.)
+  int set_turn = 0;
+  {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (ctx->num_sets > 1 && ctx->last_done && hipEventQuery(ctx->last_done) == hipErrorNotReady) {
+      set_turn = ctx->last_set ^ 1;
+      if (set_turn == 1 && !ctx->set1_made) {
+        if (ctx->sets[1].create(nullptr, ctx->prio_least, ctx->prio_greatest) == hipSuccess) ctx->set1_made = true;
+        else { (void)hipGetLastError(); ctx->sets[1].destroy(); set_turn = 0; }
+      }
+    }
+    (void)hipGetLastError();
+    ctx->last_set = set_turn;
+  }
   StreamSet &S = ctx->sets[set_turn];
   hipStream_t st = S.stream;
   if (n == 0) {
@@ -824,6 +847,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   HIP_TRY(ctx, hipGetLastError());
   // every other stream has joined `st` by now: this event is the whole decode.  The descriptors follow on the download stream.
   HIP_TRY(ctx, hipEventRecord(b->ev_done, st));
+  if (ctx->last_done) HIP_TRY(ctx, hipEventRecord(ctx->last_done, st));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->down, b->ev_done, 0));
   HIP_TRY(ctx, hipMemcpyAsync(b->descs_pin, b->d_descs, sizeof(MeshDesc) * n, hipMemcpyDeviceToHost, ctx->down));
   HIP_TRY(ctx, hipEventRecord(b->ev_descs, ctx->down));
