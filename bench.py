@@ -128,7 +128,7 @@ def encode_leg(dsa, synth, ctx, nx, ny, count, comm=None, barrier=None, world=1)
             "round_trip_ok": bool(ok), "byte_identical_to_cpu_coder": bool(identical)}
 
 
-def end_to_end_leg(dsa, ctx, blob, offsets, batches, in_flight, comm, barrier, world):
+def end_to_end_leg(dsa, ctx, blob, offsets, batches, in_flight, comm, barrier, world, compact=True):
     """What a draco-sharp caller sees (DracoDecoder.cs:19-42 takes host bytes and returns host objects): `batches` batches of
     this rank's streams, each host bytes -> dsa_batch_create (pinned staging, upload on the copy stream) -> dsa_batch_decode ->
     dsa_batch_download (ONE transfer of faces + values + point maps into a pinned mirror) -> dsa_batch_wait, `in_flight` batches
@@ -140,22 +140,23 @@ def end_to_end_leg(dsa, ctx, blob, offsets, batches, in_flight, comm, barrier, w
     def submit():
         b = dsa.Batch(ctx, blob=blob, offsets=offsets)
         b.decode(wait=False)
-        b.download(wait=False)
+        b.download(wait=False, compact=compact)
         return b
 
     def finish(b):
         b.wait()
         v0, v1 = b.host_views(0), b.host_views(n - 1)        # views into the mirror: the arrays are on the host
-        tag = int(v0["faces"][0, 0]) + int(v1["faces"][-1, -1]) + int(v1["attributes"][0]["point_map"][-1])
+        pm = v1["attributes"][0]["point_map"]
+        tag = int(v0["faces"][0, 0]) + int(v1["faces"][-1, -1]) + (int(pm[-1]) if pm is not None else 0)
         b.close()
         return tag
 
     # warm-up: the context's caches (arenas, pinned mirrors, staging) fill; also the stand-alone link times
     t0 = time.perf_counter(); b = dsa.Batch(ctx, blob=blob, offsets=offsets); b.decode(wait=True); t_up_decode = time.perf_counter() - t0
-    out_bytes = b.output_bytes
-    b.download(wait=True)                                    # first use pins the mirror
+    out_bytes = b.compact_bytes if compact else b.output_bytes
+    b.download(wait=True, compact=compact)                   # first use pins the mirror
     t0 = time.perf_counter(); b.decode(wait=True); t_dec = time.perf_counter() - t0
-    t0 = time.perf_counter(); b.download(wait=True); t_d2h = time.perf_counter() - t0
+    t0 = time.perf_counter(); b.download(wait=True, compact=compact); t_d2h = time.perf_counter() - t0
     b.close()
     live = [submit() for _ in range(in_flight)]
     for b in live:
@@ -180,6 +181,7 @@ def end_to_end_leg(dsa, ctx, blob, offsets, batches, in_flight, comm, barrier, w
             "gb_per_s_out": world * batches * out_bytes / dt / 1e9,
             "h2d_s": t_h2d, "h2d_gb_per_s": int(offsets[-1]) / t_h2d / 1e9, "d2h_s": t_d2h, "d2h_gb_per_s": out_bytes / t_d2h / 1e9,
             "decode_s": t_dec, "first_batch_s_cold": t_up_decode,
+            "layout": "compact (uint16 faces, one point map per distinct map: dsa_batch_download_compact)" if compact else "full (int32 faces, a point map per attribute)",
             "what": "host .drc bytes -> host arrays (faces, attribute values, point maps of every mesh), pinned staging + one download per batch, %d batches in flight" % in_flight}
 
 
@@ -501,7 +503,8 @@ def main():
         encode = encode_leg(dsa, synth, ctx, nx, ny, args.encode_meshes, comm if world > 1 else None, barrier if world > 1 else None, world)
     e2e = None
     if not args.no_end_to_end and weak_blob is not None:             # every rank its own batches: the clock is the slowest rank's
-        e2e = end_to_end_leg(dsa, ctx, weak_blob, weak_offsets, args.e2e_batches, 2, comm if world > 1 else None, barrier if world > 1 else None, world)
+        e2e = end_to_end_leg(dsa, ctx, weak_blob, weak_offsets, args.e2e_batches, 2, comm if world > 1 else None, barrier if world > 1 else None, world, compact=True)
+        e2e["full_layout"] = end_to_end_leg(dsa, ctx, weak_blob, weak_offsets, args.e2e_batches, 2, comm if world > 1 else None, barrier if world > 1 else None, world, compact=False)
     pool = None
     if not args.no_pool:
         # the in-library work queue over all GPUs of the job, from rank 0 alone (the other ranks have released their contexts'

@@ -60,7 +60,9 @@ public sealed unsafe class GpuDracoDecoder : IDisposable
             fixed (nuint* l = lens)
                 NativeMethods.Check(NativeMethods.dsa_batch_create(_ctx, (uint)streams.Count, p, l, out batch), _ctx, "dsa_batch_create");   // the streams are staged before this returns
             NativeMethods.Check(NativeMethods.dsa_batch_decode(batch), _ctx, "dsa_batch_decode");
-            NativeMethods.Check(NativeMethods.dsa_batch_download(batch, null, 0), _ctx, "dsa_batch_download");
+            // compact: uint16 faces where they fit, one point map per distinct map -- a third less on the link; the dsa_batch_copy_* calls
+            // of Materialize widen from the host copy
+            NativeMethods.Check(NativeMethods.dsa_batch_download_compact(batch, null, 0), _ctx, "dsa_batch_download_compact");
             return batch;
         }
         catch { if (batch != IntPtr.Zero) NativeMethods.dsa_batch_free(batch); throw; }
@@ -102,8 +104,9 @@ public sealed unsafe class GpuDracoDecoder : IDisposable
             }
             NativeMethods.Check(NativeMethods.dsa_batch_decode(batch), _ctx, "dsa_batch_decode");
             // every output array of the batch in ONE device -> host transfer into a pinned mirror, queued behind the kernels; the
-            // per-array copies of Materialize below are then served from that host copy (dsa_batch_copy_* after a download)
-            NativeMethods.Check(NativeMethods.dsa_batch_download(batch, null, 0), _ctx, "dsa_batch_download");
+            // per-array copies of Materialize below are then served from that host copy (dsa_batch_copy_* after a download); the compact
+            // form of the transfer: faces as uint16 where a mesh has at most 65 536 points, one point map per distinct map
+            NativeMethods.Check(NativeMethods.dsa_batch_download_compact(batch, null, 0), _ctx, "dsa_batch_download_compact");
             NativeMethods.Check(NativeMethods.dsa_batch_wait(batch), _ctx, "dsa_batch_wait");
             var results = new Draco[streams.Count];
             for (uint i = 0; i < streams.Count; ++i) results[i] = Materialize(batch, i);

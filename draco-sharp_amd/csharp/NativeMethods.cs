@@ -53,7 +53,7 @@ internal unsafe struct DsaAttributeInfo
 internal unsafe struct DsaMeshOutput       // byte offsets of a mesh's arrays inside the batch's output block (dsa_batch_download)
 {
     public uint Block;        // 0: the batch's block, 1: the block of the meshes decoded a second time (general path)
-    public uint Reserved;
+    public uint Flags;            // DSA_OUTPUT_FACES_U16 = 1 (compact download)
     public ulong Faces;
     public fixed ulong Values[16];
     public fixed ulong PointMap[16];
@@ -108,6 +108,8 @@ internal static unsafe partial class NativeMethods
     // whole-batch copy-out: one transfer of every output array into a pinned mirror (or caller memory), beside the next batch's kernels
     [DllImport(Lib)] internal static extern ulong dsa_batch_output_bytes(IntPtr batch);
     [DllImport(Lib)] internal static extern DsaStatus dsa_batch_download(IntPtr batch, void* dst, nuint dstBytes);
+    [DllImport(Lib)] internal static extern DsaStatus dsa_batch_download_compact(IntPtr batch, void* dst, nuint dstBytes);
+    [DllImport(Lib)] internal static extern ulong dsa_batch_compact_bytes(IntPtr batch);
     [DllImport(Lib)] internal static extern IntPtr dsa_batch_host_output(IntPtr batch, uint block);
     [DllImport(Lib)] internal static extern DsaStatus dsa_batch_output_layout(IntPtr batch, uint mesh, out DsaMeshOutput layout);
     [DllImport(Lib)] internal static extern IntPtr dsa_host_alloc(nuint bytes);

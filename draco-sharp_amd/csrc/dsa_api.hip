@@ -132,7 +132,7 @@ struct dsa_context {
   // Arenas and pinned mirrors of freed batches are kept for the next batch of the context: hipMalloc / hipFree of tens of GB and
   // pinning GBs of host memory cost as much as the decode itself.  Three of each: two batches in flight + one being built.
   struct Spare { uint8_t *p; uint64_t bytes; };
-  std::vector<Spare> spare_arenas, spare_mirrors, spare_descs;   // spare_descs: pinned landing zones of the mesh descriptors
+  std::vector<Spare> spare_arenas, spare_mirrors, spare_descs, spare_packed;   // spare_descs: pinned landing zones of the mesh descriptors; spare_packed: packed blocks of compact downloads
   static constexpr size_t kSpares = 3;
   // batches point at their context: a context destroyed first lives on until its last batch is freed
   std::atomic<int> live_batches{0};
@@ -160,7 +160,17 @@ struct dsa_batch {
   MeshDesc *d_descs = nullptr;
   BatchGlobals *d_globals = nullptr;
   BatchGlobals globals = {};
-  uint64_t out_base = 0, out_bytes = 0;   // the output block: faces, attribute values and point maps of every mesh
+  uint64_t out_base = 0, out_bytes = 0;   // the output block: faces, attribute values and point maps of every mesh, in three
+  uint64_t out_values = 0, out_values_bytes = 0;   // sub-blocks (offsets of the values sub-block inside the output block)
+  // Compact download: the values sub-block as it is + a packed block made on the device (faces as uint16 where every point id
+  // fits, one point map per distinct map).  Layout per mesh from the header's counts; the device copy of it and the packed block
+  // are made at the first compact download.
+  std::vector<CompactMesh> compact;       // host copy; the device's is part of the arena's uploaded head
+  CompactMesh *d_compact = nullptr;
+  uint64_t packed_bytes = 0;
+  uint8_t *d_packed = nullptr;            // the packed block, from the context's cache at the first compact download
+  uint64_t d_packed_cap = 0;
+  bool mirror_compact = false;
   uint32_t max_faces = 0, max_vertices = 0, max_atts = 0, max_att_data = 0;
   uint64_t sum_vertices = 0;
   bool any_general = false, any_valence = false, any_seamed = false;
@@ -270,7 +280,8 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
   b->descs.resize(n);
   // ---- arena layout: [layouts | globals | streams | slack | descs | per-mesh scratch | table pool | output block]
   const uint64_t off_layouts = 0, off_globals = align_up(sizeof(MeshLayout) * (uint64_t)n, 256);
-  uint64_t cur = align_up(off_globals + sizeof(BatchGlobals), 256);
+  const uint64_t off_compact = align_up(off_globals + sizeof(BatchGlobals), 256);
+  uint64_t cur = align_up(off_compact + sizeof(CompactMesh) * (uint64_t)n, 256);
   for (uint32_t i = 0; i < n; ++i) {
     if (lengths[i] > 0xFFFFFF00u) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "stream %u longer than 4 GiB", i);
     MeshLayout &L = b->layouts[i];
@@ -292,7 +303,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
   std::vector<uint64_t> claim(n, 0);
   for (;;) {
     cur = scratch_begin;
-    uint64_t ocur = 0;
+    OutCursors ocur;
     b->max_faces = b->max_vertices = b->max_atts = b->max_att_data = 0;
     b->sum_vertices = 0;
     b->any_general = false;
@@ -302,13 +313,13 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
       HostMesh &h = b->host[i];
       MeshLayout &L = b->layouts[i];
       if (h.status != 0) { h.faces = 0; h.enc_vertices = 0; h.split_symbols = 0; h.splits = 0; h.atts.clear(); h.general = false; }
-      const uint64_t F = h.faces, V = (uint64_t)h.enc_vertices + h.split_symbols, before = cur, obefore = ocur;
+      const uint64_t F = h.faces, V = (uint64_t)h.enc_vertices + h.split_symbols, before = cur, obefore = ocur.faces + ocur.values + ocur.maps;
       const uint64_t stream_off = L.stream;
       const uint32_t stream_len = L.stream_len;
       memset(&L, 0, sizeof(L));
       L.stream = stream_off; L.stream_len = stream_len;
       cur = layout_mesh(h, lengths[i], L, cur, 16, nullptr, &ocur);
-      claim[i] = (cur - before) + (ocur - obefore);
+      claim[i] = (cur - before) + (ocur.faces + ocur.values + ocur.maps - obefore);
       b->max_faces = std::max<uint32_t>(b->max_faces, (uint32_t)F);
       b->max_vertices = std::max<uint32_t>(b->max_vertices, (uint32_t)V);
       b->sum_vertices += V;
@@ -328,13 +339,16 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
     }
     // the output block behind everything else; the offsets layout_mesh handed out were relative to it
     b->out_base = align_up(cur, 4096);
-    b->out_bytes = ocur;
+    b->out_values = align_up(ocur.faces, 4096);
+    b->out_values_bytes = ocur.values;
+    const uint64_t out_maps = align_up(b->out_values + ocur.values, 4096);
+    b->out_bytes = out_maps + ocur.maps;
     for (uint32_t i = 0; i < n; ++i) {
       MeshLayout &L = b->layouts[i];
       L.faces += b->out_base;
-      for (uint32_t a = 0; a < L.cap_attributes; ++a) { L.out[a] += b->out_base; L.map[a] += b->out_base; }
+      for (uint32_t a = 0; a < L.cap_attributes; ++a) { L.out[a] += b->out_base + b->out_values; L.map[a] += b->out_base + out_maps; }
     }
-    b->arena_bytes = b->out_base + align_up(ocur, 256) + 256;
+    b->arena_bytes = b->out_base + align_up(b->out_bytes, 256) + 256;
     e = arena_alloc(ctx, b->arena_bytes, &b->arena, &b->arena_cap);
     if (e == hipSuccess) break;
     (void)hipGetLastError();
@@ -347,6 +361,34 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
   if (e != hipSuccess) return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "hipMalloc of %llu-byte arena failed: %s", (unsigned long long)b->arena_bytes, hipGetErrorString(e));
   b->d_layouts = (MeshLayout *)(b->arena + off_layouts);
   b->d_globals = (BatchGlobals *)(b->arena + off_globals);
+  b->d_compact = (CompactMesh *)(b->arena + off_compact);
+  {   // the packed block of a compact download, from the header's counts
+    b->compact.assign(n, CompactMesh());
+    uint64_t pcur = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      const HostMesh &h = b->host[i];
+      const MeshLayout &L = b->layouts[i];
+      CompactMesh &c = b->compact[i];
+      c.u16 = L.cap_points <= 65536u ? 1u : 0u; c.pad = 0;
+      c.faces = pcur;
+      pcur = align_up(pcur + (uint64_t)L.cap_faces * (c.u16 ? 6 : 12), 64);
+      const bool identity = h.faces == 0 && !h.general;          // point clouds: linear sequencing, point i = entry i
+      int key_of[DSA_MAX_ATT];
+      for (uint32_t a = 0; a < DSA_MAX_ATT; ++a) c.map[a] = ~0ull;
+      for (uint32_t a = 0; a < L.cap_attributes && a < DSA_MAX_ATT; ++a) {
+        if (identity) continue;
+        // attributes decoded in one traversal order share their map: all vertex attributes of a fast-path mesh, the attributes of
+        // one corner-attribute decoder; a general-path mesh keeps one map per attribute
+        key_of[a] = h.general ? 1000 + (int)a : (h.atts[a].corner ? 1 + (int)h.atts[a].dec : 0);
+        uint32_t rep = a;
+        for (uint32_t k = 0; k < a; ++k) if (key_of[k] == key_of[a]) { rep = k; break; }
+        if (rep != a) { c.map[a] = c.map[rep]; continue; }
+        c.map[a] = pcur;
+        pcur = align_up(pcur + 4ull * L.cap_points, 64);
+      }
+    }
+    b->packed_bytes = pcur;
+  }
   b->d_descs = (MeshDesc *)(b->arena + off_descs);
   HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_uploaded, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming));
@@ -372,6 +414,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
     memcpy(h + off_globals, &b->globals, sizeof(BatchGlobals));
     const uint64_t first = n ? b->layouts[0].stream : upload_bytes;
     memset(h + off_globals + sizeof(BatchGlobals), 0, (size_t)(first - off_globals - sizeof(BatchGlobals)));
+    if (n) memcpy(h + off_compact, b->compact.data(), sizeof(CompactMesh) * (size_t)n);
     hostutil::parallel_for(n, [&](uint32_t i) {       // stream i and the zero gap up to the next one
       const uint64_t at = b->layouts[i].stream, end = at + lengths[i], next = i + 1 < n ? b->layouts[i + 1].stream : upload_bytes;
       if (lengths[i]) memcpy(h + at, streams[i], lengths[i]);
@@ -454,6 +497,7 @@ void dsa_context_destroy(dsa_context *ctx) {
   if (ctx->up) { (void)hipStreamSynchronize(ctx->up); (void)hipStreamDestroy(ctx->up); }
   if (ctx->down) { (void)hipStreamSynchronize(ctx->down); (void)hipStreamDestroy(ctx->down); }
   drop_spares(ctx, ctx->spare_arenas, false);
+  drop_spares(ctx, ctx->spare_packed, false);
   drop_spares(ctx, ctx->spare_mirrors, true);
   drop_spares(ctx, ctx->spare_descs, true);
   for (StreamSet &set : ctx->sets) set.destroy();
@@ -933,6 +977,7 @@ void dsa_batch_free(dsa_batch *b) {
   give_spare(b->ctx, b->ctx->spare_descs, (uint8_t *)b->descs_pin, b->descs_pin_bytes, [](uint8_t *p) { (void)hipHostFree(p); });
   if (b->mirror && b->mirror_owned) give_spare(b->ctx, b->ctx->spare_mirrors, b->mirror, b->mirror_bytes, [](uint8_t *p) { (void)hipHostFree(p); });
   give_spare(b->ctx, b->ctx->spare_arenas, b->arena, b->arena_cap, [](uint8_t *p) { (void)hipFree(p); });
+  give_spare(b->ctx, b->ctx->spare_packed, b->d_packed, b->d_packed_cap, [](uint8_t *p) { (void)hipFree(p); });
   dsa_context *ctx = b->ctx;
   delete b;
   bool last;
@@ -1008,7 +1053,7 @@ dsa_status dsa_batch_attribute_info(const dsa_batch *b, uint32_t mesh, uint32_t 
 static dsa_status copy_out(const dsa_batch *b, void *dst, uint64_t off, uint64_t bytes) {
   if (!dst) return DSA_ERR_INVALID_ARGUMENT;
   if (bytes == 0) return DSA_OK;
-  if (b->downloaded && off >= b->out_base && off + bytes <= b->out_base + b->out_bytes) {     // already on the host
+  if (b->downloaded && !b->mirror_compact && off >= b->out_base && off + bytes <= b->out_base + b->out_bytes) {     // already on the host
     memcpy(dst, b->mirror + (off - b->out_base), (size_t)bytes);
     return DSA_OK;
   }
@@ -1021,17 +1066,39 @@ dsa_status dsa_batch_copy_faces(const dsa_batch *b, uint32_t mesh, int32_t *dst)
   FOLLOW_RETRY(b, mesh, dsa_batch_copy_faces(rb_, rm_, dst));
   CHECK_MESH(b, mesh);
   if (b->descs[mesh].status != ST_OK) return set_err(b->ctx, (dsa_status)b->descs[mesh].status, "mesh %u failed to decode", mesh);
+  if (b->downloaded && b->mirror_compact) {          // from the packed host copy: widened
+    if (!dst) return DSA_ERR_INVALID_ARGUMENT;
+    const CompactMesh &c = b->compact[mesh];
+    const uint8_t *src = b->mirror + align_up(b->out_values_bytes, 4096) + c.faces;
+    const size_t ncorn = 3ull * b->descs[mesh].num_faces;
+    if (c.u16) for (size_t i = 0; i < ncorn; ++i) dst[i] = (int32_t)((const uint16_t *)src)[i];
+    else memcpy(dst, src, 4 * ncorn);
+    return DSA_OK;
+  }
   return copy_out(b, dst, b->layouts[mesh].faces, 12ull * b->descs[mesh].num_faces);
 }
 dsa_status dsa_batch_copy_attribute_values(const dsa_batch *b, uint32_t mesh, uint32_t a, void *dst) {
   FOLLOW_RETRY(b, mesh, dsa_batch_copy_attribute_values(rb_, rm_, a, dst));
   CHECK_ATTR(b, mesh, a);
   const AttrDesc &A = b->descs[mesh].att[a];
+  if (b->downloaded && b->mirror_compact) {          // the values sub-block heads the compact host copy
+    if (!dst) return DSA_ERR_INVALID_ARGUMENT;
+    memcpy(dst, b->mirror + (b->layouts[mesh].out[a] - b->out_base - b->out_values), (size_t)A.num_entries * A.nc * dt_len(A.data_type));
+    return DSA_OK;
+  }
   return copy_out(b, dst, b->layouts[mesh].out[a], (uint64_t)A.num_entries * A.nc * dt_len(A.data_type));
 }
 dsa_status dsa_batch_copy_point_map(const dsa_batch *b, uint32_t mesh, uint32_t a, uint32_t *dst) {
   FOLLOW_RETRY(b, mesh, dsa_batch_copy_point_map(rb_, rm_, a, dst));
   CHECK_ATTR(b, mesh, a);
+  if (b->downloaded && b->mirror_compact) {
+    if (!dst) return DSA_ERR_INVALID_ARGUMENT;
+    const CompactMesh &c = b->compact[mesh];
+    const uint32_t npts = b->descs[mesh].num_points;
+    if (c.map[a] == ~0ull) for (uint32_t p = 0; p < npts; ++p) dst[p] = p;
+    else memcpy(dst, b->mirror + align_up(b->out_values_bytes, 4096) + c.map[a], 4ull * npts);
+    return DSA_OK;
+  }
   return copy_out(b, dst, b->layouts[mesh].map[a], 4ull * b->descs[mesh].num_points);
 }
 dsa_status dsa_batch_copy_portable_values(const dsa_batch *b, uint32_t mesh, uint32_t a, int32_t *dst) {
@@ -1061,17 +1128,40 @@ const uint32_t *dsa_batch_device_point_map(const dsa_batch *b, uint32_t mesh, ui
 // ---- whole-batch results on the host: one transfer of the output block
 uint64_t dsa_batch_output_bytes(const dsa_batch *b) { return b ? b->out_bytes : 0; }
 
+uint64_t dsa_batch_compact_bytes(const dsa_batch *b) { return b ? align_up(b->out_values_bytes, 4096) + b->packed_bytes : 0; }
+
+static dsa_status batch_download(dsa_batch *b, void *dst, size_t dst_bytes, bool compact);
 dsa_status dsa_batch_download(dsa_batch *b, void *dst, size_t dst_bytes) {
   if (!b) return DSA_ERR_INVALID_ARGUMENT;
+  DSA_GUARD(b->ctx, batch_download(b, dst, dst_bytes, false));
+}
+dsa_status dsa_batch_download_compact(dsa_batch *b, void *dst, size_t dst_bytes) {
+  if (!b) return DSA_ERR_INVALID_ARGUMENT;
+  DSA_GUARD(b->ctx, batch_download(b, dst, dst_bytes, true));
+}
+static dsa_status batch_download(dsa_batch *b, void *dst, size_t dst_bytes, bool compact) {
   dsa_context *ctx = b->ctx;
   if (!b->decoded) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "dsa_batch_decode was not called");
   if (b->download_queued) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "the batch is already being downloaded");
-  if (dst && dst_bytes < b->out_bytes) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "destination smaller than dsa_batch_output_bytes");
+  const uint64_t host_bytes = compact ? dsa_batch_compact_bytes(b) : b->out_bytes;
+  if (dst && dst_bytes < host_bytes) return set_err(ctx, DSA_ERR_INVALID_ARGUMENT, "destination smaller than the host copy (dsa_batch_output_bytes / dsa_batch_compact_bytes)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (compact && !b->d_packed && b->packed_bytes) {     // the packed block: from the context's cache, like arenas
+    uint64_t cap = 0;
+    uint8_t *p = take_spare(ctx, ctx->spare_packed, b->packed_bytes, &cap);
+    if (!p) {
+      hipError_t e = hipMalloc((void **)&p, b->packed_bytes);
+      if (e != hipSuccess) { (void)hipGetLastError(); drop_spares(ctx, ctx->spare_packed, false); drop_spares(ctx, ctx->spare_arenas, false); e = hipMalloc((void **)&p, b->packed_bytes); }
+      if (e != hipSuccess) { (void)hipGetLastError(); return set_err(ctx, DSA_ERR_OUT_OF_MEMORY, "packed block of %llu bytes: %s", (unsigned long long)b->packed_bytes, hipGetErrorString(e)); }
+      cap = b->packed_bytes;
+    }
+    b->d_packed = p; b->d_packed_cap = cap;
+  }
   if (b->mirror && b->mirror_owned && dst) { give_spare(ctx, ctx->spare_mirrors, b->mirror, b->mirror_bytes, [](uint8_t *p) { (void)hipHostFree(p); }); b->mirror = nullptr; }
   if (dst) { b->mirror = (uint8_t *)dst; b->mirror_bytes = dst_bytes; b->mirror_owned = false; }
-  else if (!b->mirror || !b->mirror_owned) {
-    const uint64_t need = b->out_bytes ? b->out_bytes : 256;
+  else if (!b->mirror || !b->mirror_owned || b->mirror_bytes < host_bytes) {
+    if (b->mirror && b->mirror_owned) { give_spare(ctx, ctx->spare_mirrors, b->mirror, b->mirror_bytes, [](uint8_t *p) { (void)hipHostFree(p); }); b->mirror = nullptr; }
+    const uint64_t need = host_bytes ? host_bytes : 256;
     uint64_t got = 0;
     uint8_t *p = take_spare(ctx, ctx->spare_mirrors, need, &got);
     if (!p) {
@@ -1085,12 +1175,29 @@ dsa_status dsa_batch_download(dsa_batch *b, void *dst, size_t dst_bytes) {
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->down, b->ev_done, 0));
   // in pieces, so that a transfer of gigabytes does not hold the engine against the descriptors of the batch behind it
   const uint64_t piece = 256ull << 20;
-  for (uint64_t at = 0; at < b->out_bytes; at += piece)
-    HIP_TRY(ctx, hipMemcpyAsync(b->mirror + at, b->arena + b->out_base + at, (size_t)std::min(piece, b->out_bytes - at), hipMemcpyDeviceToHost, ctx->down));
+  auto copy_down = [&](uint8_t *to, const uint8_t *from, uint64_t bytes) -> hipError_t {
+    for (uint64_t at = 0; at < bytes; at += piece) {
+      const hipError_t e = hipMemcpyAsync(to + at, from + at, (size_t)std::min(piece, bytes - at), hipMemcpyDeviceToHost, ctx->down);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  };
+  if (!compact) HIP_TRY(ctx, copy_down(b->mirror, b->arena + b->out_base, b->out_bytes));
+  else {
+    // the values as they are; faces and point maps packed by a kernel on the download stream (the copy of the values runs beside it)
+    if (b->n && b->packed_bytes) {
+      const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
+      hipLaunchKernelGGL(dsa::k_pack_output, dim3(gx, b->n), dim3(256), 0, ctx->down, b->arena, b->d_layouts, b->d_descs, b->n, b->d_compact, b->d_packed);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, copy_down(b->mirror, b->arena + b->out_base + b->out_values, b->out_values_bytes));
+    HIP_TRY(ctx, copy_down(b->mirror + align_up(b->out_values_bytes, 4096), b->d_packed, b->packed_bytes));
+  }
   HIP_TRY(ctx, hipEventRecord(b->ev_down, ctx->down));
   b->download_queued = true;
   b->downloaded = false;
-  if (b->retry && !b->retry->download_queued) return dsa_batch_download(b->retry, nullptr, 0);   // block 1: the meshes decoded a second time
+  b->mirror_compact = compact;
+  if (b->retry && !b->retry->download_queued) return dsa_batch_download(b->retry, nullptr, 0);   // block 1: the meshes decoded a second time (always the full layout)
   return DSA_OK;
 }
 
@@ -1109,6 +1216,17 @@ dsa_status dsa_batch_output_layout(const dsa_batch *b, uint32_t mesh, dsa_mesh_o
   uint32_t m = mesh;
   if (b->retry && b->retry_index[mesh] >= 0) { src = b->retry; m = (uint32_t)b->retry_index[mesh]; out->block = 1; }
   const MeshLayout &L = src->layouts[m];
+  if (src->mirror_compact && src->download_queued) {       // the host copy of a compact download: [values sub-block | packed block]
+    const CompactMesh &c = src->compact[m];
+    const uint64_t pk = align_up(src->out_values_bytes, 4096);
+    out->flags = c.u16 ? DSA_OUTPUT_FACES_U16 : 0u;
+    out->faces = pk + c.faces;
+    for (uint32_t a = 0; a < L.cap_attributes && a < DSA_MAX_ATTRIBUTES; ++a) {
+      out->values[a] = L.out[a] - src->out_base - src->out_values;
+      out->point_map[a] = c.map[a] == ~0ull ? ~0ull : pk + c.map[a];
+    }
+    return DSA_OK;
+  }
   out->faces = L.faces - src->out_base;
   for (uint32_t a = 0; a < L.cap_attributes && a < DSA_MAX_ATTRIBUTES; ++a) { out->values[a] = L.out[a] - src->out_base; out->point_map[a] = L.map[a] - src->out_base; }
   return DSA_OK;
@@ -1228,6 +1346,7 @@ dsa_status dsa_context_trim(dsa_context *ctx) {
   if (!ctx) return DSA_ERR_INVALID_ARGUMENT;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   drop_spares(ctx, ctx->spare_arenas, false);
+  drop_spares(ctx, ctx->spare_packed, false);
   drop_spares(ctx, ctx->spare_mirrors, true);
   drop_spares(ctx, ctx->spare_descs, true);
   { std::lock_guard<std::mutex> g(ctx->mu); ctx->enc_lanes.clear(); }      // dsa_encode_batch is synchronous: its lanes are idle between calls

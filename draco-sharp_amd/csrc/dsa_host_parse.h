@@ -17,7 +17,7 @@
 namespace {
 
 // What the host learns from the fixed part of a stream; used only to size the arena.
-struct HostAttr { uint8_t att_type, data_type, nc, seq_type; bool corner = false; };
+struct HostAttr { uint8_t att_type, data_type, nc, seq_type; bool corner = false; uint8_t dec = 0; };
 struct HostMesh {
   int status = 0;   // failure of the sizing parse (the device parse decides the reported status)
   uint32_t faces = 0, enc_vertices = 0, split_symbols = 0, splits = 0, num_att_data = 0;
@@ -214,6 +214,7 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m, bool want_gene
       (void)r.varint();
       a.seq_type = 0;
       a.corner = corner_dec[i];
+      a.dec = (uint8_t)i;
       m.atts.push_back(a);
     }
     for (uint64_t j = 0; j < k; ++j) m.atts[first + j].seq_type = (uint8_t)r.u8();
@@ -226,17 +227,20 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 
 // Places the regions of one mesh behind `cur` (arena offset) and returns the new end.  `slack` bytes are left
 // after every region (the kernels over-read whole 16-byte words; the host check passes a larger red zone).
-// `out_cur` (optional): the arrays a caller receives -- faces, attribute values, point maps -- are placed behind *out_cur instead
-// (offsets relative to the batch's output block, which dsa_api.hip puts behind all scratch so that one transfer downloads it).
+// `out_cur` (optional): the arrays a caller receives -- faces, attribute values, point maps -- are placed behind the cursors of
+// *out_cur instead, one cursor per kind: the batch's output block (which dsa_api.hip puts behind all scratch so that one transfer
+// downloads it) is three sub-blocks, every mesh's faces, then every mesh's values, then every mesh's maps -- the compact download
+// takes the values as they are and packs the other two.  Offsets relative to the respective sub-block.
+struct OutCursors { uint64_t faces = 0, values = 0, maps = 0; };
 static inline uint64_t layout_mesh(const HostMesh &h, uint64_t stream_len, MeshLayout &L, uint64_t cur, uint64_t slack,
-                                   std::vector<std::pair<uint64_t, uint64_t>> *regions = nullptr, uint64_t *out_cur = nullptr) {
+                                   std::vector<std::pair<uint64_t, uint64_t>> *regions = nullptr, OutCursors *out_cur = nullptr) {
   const uint64_t F = h.faces, V = (uint64_t)h.enc_vertices + h.split_symbols;
   L.cap_faces = (uint32_t)F;
   L.cap_vertices = (uint32_t)V;
   L.cap_attributes = (uint32_t)h.atts.size();
   L.cap_splits = h.splits;
   auto take = [&](uint64_t bytes) { uint64_t at = cur; cur = align_up(cur + bytes + slack, 256); if (regions) regions->push_back({at, bytes}); return at; };
-  auto take_out = [&](uint64_t bytes) { if (!out_cur) return take(bytes); uint64_t at = *out_cur; *out_cur = align_up(*out_cur + bytes + slack, 256); return at; };
+  auto take_out = [&](uint64_t bytes, uint64_t OutCursors::*which) { if (!out_cur) return take(bytes); uint64_t at = out_cur->*which; out_cur->*which = align_up(at + bytes + slack, 256); return at; };
   // the fast kernels' face records: 16 bytes while every id fits 20 bits (the general path keeps plain arrays here: 24 F)
   L.rec_compact = (!h.general && 4 * F <= (1u << 20) && V < (1u << 20)) ? 1u : 0u;
   L.frec = take(L.rec_compact ? 16 * F : 32 * F);
@@ -246,7 +250,7 @@ static inline uint64_t layout_mesh(const HostMesh &h, uint64_t stream_len, MeshL
   L.fstamp = take(4 * F); L.vstamp = take(4 * V);
   L.splits = take(16ull * h.splits);
   L.vrank = take(4 * V); L.para = take(12 * V);
-  L.faces = take_out(12 * F);
+  L.faces = take_out(12 * F, &OutCursors::faces);
   // corner attributes carry up to 3F entries, and seams up to 3F points
   const uint64_t P = ((h.general || h.seamed) && h.num_att_data > 0) ? std::max<uint64_t>(3 * F, V) : V;
   L.cap_points = (uint32_t)P;
@@ -267,8 +271,8 @@ static inline uint64_t layout_mesh(const HostMesh &h, uint64_t stream_len, MeshL
     uint64_t wcap = E * ncp, ocap = E * A.nc * dt_len(A.data_type);
     if (ocap < V) ocap = V;                  // tag bytes of the tagged scheme are staged here
     L.work[a] = take(4 * wcap); L.work_cap[a] = (uint32_t)wcap;
-    L.out[a] = take_out(ocap); L.out_cap[a] = (uint32_t)(ocap > 0xFFFFFFFFu ? 0xFFFFFFFFu : ocap);
-    L.map[a] = take_out(4 * P);
+    L.out[a] = take_out(ocap, &OutCursors::values); L.out_cap[a] = (uint32_t)(ocap > 0xFFFFFFFFu ? 0xFFFFFFFFu : ocap);
+    L.map[a] = take_out(4 * P, &OutCursors::maps);
     L.tc[a] = (h.faces != 0 && A.nc == 2 && (A.seq_type == 1 || A.seq_type == 2)) ? take(sizeof(TcPrep) * E) : 0;
   }
   return cur;

@@ -785,3 +785,39 @@ __global__ __launch_bounds__(WAVE) void k_texcoords(uint8_t *arena, const MeshLa
 #undef TC_G
 
 }  // namespace dsa
+
+namespace dsa {
+// k_pack_output: the packed block of a compact download (dsa_batch_download_compact) -- faces narrowed to uint16 where every point
+// id of the mesh fits, one point map per distinct map (CompactMesh).  Behind the decode, on the download stream.
+__global__ __launch_bounds__(256) void k_pack_output(const uint8_t *arena, const MeshLayout *layouts, const MeshDesc *descs, uint32_t n, const CompactMesh *table,
+                                                     uint8_t *packed) {
+  const uint32_t mesh = blockIdx.y;
+  if (mesh >= n) return;
+  const MeshDesc *D = &descs[mesh];
+  if (D->status != ST_OK) return;
+  const MeshLayout &L = layouts[mesh];
+  const CompactMesh &c = table[mesh];
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  const uint32_t nc = 3u * D->num_faces, npts = D->num_points;
+  const int32_t *faces = (const int32_t *)(arena + L.faces);
+  if (c.u16) {
+    uint32_t *dst = (uint32_t *)(packed + c.faces);                  // two corners to a word
+    for (uint32_t w = tid; w < (nc + 1) / 2; w += stride) {
+      const uint32_t lo = (uint32_t)faces[2 * w], hi = 2 * w + 1 < nc ? (uint32_t)faces[2 * w + 1] : 0u;
+      dst[w] = (lo & 0xFFFFu) | (hi << 16);
+    }
+  } else {
+    int32_t *dst = (int32_t *)(packed + c.faces);
+    for (uint32_t i = tid; i < nc; i += stride) dst[i] = faces[i];
+  }
+  for (uint32_t a = 0; a < D->num_attributes && a < DSA_MAX_ATT; ++a) {
+    if (c.map[a] == ~0ull) continue;
+    bool rep = true;
+    for (uint32_t k = 0; k < a; ++k) rep = rep && c.map[k] != c.map[a];
+    if (!rep) continue;
+    const uint32_t *src = (const uint32_t *)(arena + L.map[a]);
+    uint32_t *dst = (uint32_t *)(packed + c.map[a]);
+    for (uint32_t p = tid; p < npts; p += stride) dst[p] = src[p];
+  }
+}
+}  // namespace dsa

@@ -232,6 +232,14 @@ struct TcPrep {
   int64_t norm;                // IntSqrt(|C - X|^2 * pn_norm2), X = the foot of the tip on the edge
 };
 
+// Compact download (dsa_batch_download_compact): where a mesh's faces and point maps go in the packed block the device makes for
+// it -- faces as uint16 when every point id fits, one point map per distinct map (attributes under one connectivity share theirs).
+struct CompactMesh {
+  uint64_t faces;                 // offset inside the packed block
+  uint32_t u16, pad;              // faces stored as uint16
+  uint64_t map[DSA_MAX_ATT];      // offset of attribute a's map; equal offsets: shared; ~0: the identity (not stored)
+};
+
 // Batch-wide device state.
 struct BatchGlobals {
   uint64_t pool;                    // arena offset of the table pool

@@ -298,11 +298,13 @@ class Batch:
         if st != 0:
             _raise(st, self.ctx.error())
 
-    def download(self, wait=True):
+    def download(self, wait=True, compact=False):
         """Queues ONE device -> host transfer of every output array of the batch (faces, attribute values, point maps) into a
         pinned mirror the library owns, behind the batch's kernels (dsa_batch_download); result() and host_views() then read the
         mirror instead of copying array by array."""
-        st = self._L.dsa_batch_download(self._h, None, 0)
+        # compact=True (dsa_batch_download_compact): less on the link -- faces as uint16 where a mesh has at most 65 536 points, one
+        # point map per distinct map; host_views() then returns the arrays as they were stored (see there), result() widens.
+        st = (self._L.dsa_batch_download_compact if compact else self._L.dsa_batch_download)(self._h, None, 0)
         if st != 0:
             _raise(st, self.ctx.error())
         if wait:
@@ -311,6 +313,10 @@ class Batch:
     @property
     def output_bytes(self):
         return int(self._L.dsa_batch_output_bytes(self._h))
+
+    @property
+    def compact_bytes(self):
+        return int(self._L.dsa_batch_compact_bytes(self._h))
 
     def host_views(self, i):
         """Zero-copy numpy views of mesh i's arrays in the downloaded output block: {"faces": int32[F, 3], "attributes":
@@ -333,7 +339,10 @@ class Batch:
             nbytes = count * np.dtype(dtype).itemsize
             return np.frombuffer((C.c_uint8 * nbytes).from_address(base + off), dtype, count).reshape(shape)
 
-        out = {"faces": view(lay.faces, info.num_faces * 3, np.int32, (info.num_faces, 3)), "attributes": []}
+        # after a compact download: faces may be uint16; attributes decoded in one order share one map array; a point cloud's
+        # identity map is not stored ("point_map": None)
+        fdt = np.uint16 if lay.flags & native.DSA_OUTPUT_FACES_U16 else np.int32
+        out = {"faces": view(lay.faces, info.num_faces * 3, fdt, (info.num_faces, 3)), "attributes": []}
         for a in range(info.num_attributes):
             ai = native.AttributeInfo()
             st = L.dsa_batch_attribute_info(self._h, i, a, C.byref(ai))
@@ -342,7 +351,7 @@ class Batch:
             out["attributes"].append({
                 "info": ai,
                 "values": view(lay.values[a], ai.num_entries * ai.num_components, _DT_NUMPY[ai.data_type], (ai.num_entries, ai.num_components)),
-                "point_map": view(lay.point_map[a], info.num_points, np.uint32, (info.num_points,))})
+                "point_map": None if lay.point_map[a] == native.NO_MAP else view(lay.point_map[a], info.num_points, np.uint32, (info.num_points,))})
         return out
 
     @property

@@ -9,6 +9,8 @@ LIB_PATH = os.environ.get("DSA_LIB") or os.path.join(_DIR, "libdraco_mi355x.so")
 
 DSA_OK, DSA_ERR_INVALID_DATA, DSA_ERR_NOT_IMPLEMENTED, DSA_ERR_INVALID_ARGUMENT, DSA_ERR_DEVICE, DSA_ERR_OUT_OF_MEMORY = range(6)
 DSA_NUM_STAGES = 8
+DSA_OUTPUT_FACES_U16 = 1
+NO_MAP = 0xFFFFFFFFFFFFFFFF   # dsa_mesh_output.point_map: the identity map, not stored (compact download)
 
 # every symbol include/draco_mi355x.h declares
 EXPORTS = [
@@ -17,7 +19,7 @@ EXPORTS = [
     "dsa_batch_size", "dsa_batch_algorithmic_bytes", "dsa_batch_arena_bytes", "dsa_batch_mesh_info",
     "dsa_batch_attribute_info", "dsa_batch_copy_faces", "dsa_batch_copy_attribute_values", "dsa_batch_copy_point_map",
     "dsa_batch_copy_portable_values", "dsa_batch_device_faces", "dsa_batch_device_attribute_values",
-    "dsa_batch_device_point_map", "dsa_batch_output_bytes", "dsa_batch_download", "dsa_batch_host_output", "dsa_batch_output_layout",
+    "dsa_batch_device_point_map", "dsa_batch_output_bytes", "dsa_batch_download", "dsa_batch_compact_bytes", "dsa_batch_download_compact", "dsa_batch_host_output", "dsa_batch_output_layout",
     "dsa_host_alloc", "dsa_host_free", "dsa_host_register", "dsa_host_unregister", "dsa_batch_copy_metadata", "dsa_batch_copy_debug", "dsa_context_set_profiling", "dsa_batch_stage_times",
     "dsa_batch_kernel_times", "dsa_context_trim", "dsa_context_schedule_note",
     "dsa_encode_default_options", "dsa_encode_batch", "dsa_encoded_size", "dsa_encoded_stream", "dsa_encoded_free",
@@ -45,7 +47,7 @@ class MeshInfo(C.Structure):
 
 
 class MeshOutput(C.Structure):
-    _fields_ = [("block", C.c_uint32), ("reserved", C.c_uint32), ("faces", C.c_uint64), ("values", C.c_uint64 * 16), ("point_map", C.c_uint64 * 16)]
+    _fields_ = [("block", C.c_uint32), ("flags", C.c_uint32), ("faces", C.c_uint64), ("values", C.c_uint64 * 16), ("point_map", C.c_uint64 * 16)]
 
 
 class AttributeInfo(C.Structure):
@@ -105,6 +107,9 @@ def lib():
         L.dsa_batch_output_bytes.restype = C.c_uint64
         L.dsa_batch_output_bytes.argtypes = [vp]
         L.dsa_batch_download.argtypes = [vp, vp, C.c_size_t]
+        L.dsa_batch_download_compact.argtypes = [vp, vp, C.c_size_t]
+        L.dsa_batch_compact_bytes.restype = C.c_uint64
+        L.dsa_batch_compact_bytes.argtypes = [vp]
         L.dsa_batch_host_output.restype = vp
         L.dsa_batch_host_output.argtypes = [vp, u32]
         L.dsa_batch_output_layout.argtypes = [vp, u32, C.POINTER(MeshOutput)]

@@ -153,15 +153,25 @@ dsa_status dsa_batch_copy_portable_values(const dsa_batch *batch, uint32_t mesh,
  * dsa_batch_attribute_info).  Meshes that were decoded a second time through the general path
  * live in a second block (block == 1), always mirrored by the library.  After a download the dsa_batch_copy_* calls above
  * are served from the host copy. */
+#define DSA_OUTPUT_FACES_U16 1u                 /* dsa_mesh_output.flags: the faces of this mesh are uint16 (compact download, <= 65 536 points) */
 typedef struct dsa_mesh_output {
   uint32_t block;                               /* 0: the batch's block (dst / mirror), 1: the block of the re-decoded meshes */
-  uint32_t reserved;
-  uint64_t faces;                               /* int32[num_faces * 3] */
+  uint32_t flags;                               /* DSA_OUTPUT_* (0 after a full download) */
+  uint64_t faces;                               /* int32[num_faces * 3], or uint16[num_faces * 3] with DSA_OUTPUT_FACES_U16 */
   uint64_t values[DSA_MAX_ATTRIBUTES];          /* attribute a: num_entries * byte_stride bytes */
-  uint64_t point_map[DSA_MAX_ATTRIBUTES];       /* attribute a: uint32[num_points] */
+  uint64_t point_map[DSA_MAX_ATTRIBUTES];       /* attribute a: uint32[num_points]; compact download: attributes decoded in one order
+                                                 * share one map (equal offsets), UINT64_MAX: the identity (point i = entry i), not stored */
 } dsa_mesh_output;
 uint64_t dsa_batch_output_bytes(const dsa_batch *batch);
 dsa_status dsa_batch_download(dsa_batch *batch, void *dst, size_t dst_bytes);
+/* The same with less on the link (ABI 3): the attribute values as they are, the faces as uint16 wherever a mesh has at most 65 536
+ * points, and one point map per DISTINCT map -- the attributes of a mesh that were decoded in one traversal order (all per-vertex
+ * attributes; the attributes of one corner-attribute decoder) share theirs, the identity map of a point cloud is not stored.  The
+ * packing runs on the device behind the decode; dsa_batch_output_layout then describes the compact host copy (flags, shared /
+ * absent maps) and the dsa_batch_copy_* calls widen from it.  Meshes decoded a second time (block 1) keep the full layout.
+ * 2.25 -> 1.59 MB for a 64k-triangle mesh with three per-vertex attributes. */
+uint64_t dsa_batch_compact_bytes(const dsa_batch *batch);
+dsa_status dsa_batch_download_compact(dsa_batch *batch, void *dst, size_t dst_bytes);
 const void *dsa_batch_host_output(const dsa_batch *batch, uint32_t block);   /* NULL until dsa_batch_wait has seen the download finish */
 dsa_status dsa_batch_output_layout(const dsa_batch *batch, uint32_t mesh, dsa_mesh_output *out);
 /* Pinned host memory for download destinations (and for inputs a caller reuses). */

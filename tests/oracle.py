@@ -167,5 +167,16 @@ class OracleMesh:
             L.orc_free(h)
 
 
+def _decoders_of_attributes(self):
+    """Per attribute the index of the attributes decoder it belongs to."""
+    out = []
+    for d, dec in enumerate(self.decoders):
+        out += [d if dec["element_type"] else 0] * dec["num_attributes"]
+    return out
+
+
+OracleMesh.decoders_of_attributes = _decoders_of_attributes
+
+
 def decode(data: bytes) -> OracleMesh:
     return OracleMesh(data)

@@ -35,7 +35,7 @@ def streams_mixed(seed):
     return out
 
 
-def check_views(b, streams):
+def check_views(b, streams, compact=False):
     for i, s in enumerate(streams):
         try:
             ref = oracle.decode(s)
@@ -48,9 +48,19 @@ def check_views(b, streams):
         v = b.host_views(i)
         assert np.array_equal(v["faces"], ref.faces)
         assert len(v["attributes"]) == len(ref.attributes)
+        ident = np.arange(ref.num_points, dtype=np.uint32)
         for a, r in zip(v["attributes"], ref.attributes):
             assert a["values"].tobytes() == r.values.tobytes()
-            assert np.array_equal(a["point_map"], r.point_map if len(r.point_map) else np.arange(ref.num_points, dtype=np.uint32))
+            assert np.array_equal(ident if a["point_map"] is None else a["point_map"], r.point_map if len(r.point_map) else ident)
+        if compact and b.mesh_info(i).decode_path != 2:        # (meshes decoded a second time keep the full layout)
+            # the compact host copy: uint16 faces where the points fit, one map array for attributes decoded in one order
+            assert v["faces"].dtype == (np.uint16 if ref.num_points <= 65536 and len(ref.faces) else v["faces"].dtype)
+            maps = [a["point_map"] for a in v["attributes"]]
+            if ref.encoder_type == 0:
+                assert all(m is None for m in maps)
+            elif b.mesh_info(i).decode_path == 0:
+                pos_like = [m for m, d in zip(maps, ref.decoders_of_attributes()) if d == 0]
+                assert all(m.ctypes.data == pos_like[0].ctypes.data for m in pos_like)
         # and the per-array accessors, now served from the host copy, agree
         m = b.result(i).ConnectedData
         assert np.array_equal(getattr(m, "Faces", np.zeros((0, 3), np.int32)), ref.faces)
@@ -75,6 +85,27 @@ def test_download_delivers_every_array(ctx):
     b2.download()
     check_views(b2, streams)
     b.close(); b2.close()
+
+
+def test_compact_download_delivers_every_array(ctx):
+    """dsa_batch_download_compact: a third less on the link for the same arrays -- uint16 faces, shared maps, no identity maps --
+    through the zero-copy views and, widened, through the per-array accessors; seamed meshes keep a map per corner decoder."""
+    from meshutil import seamed_mesh
+    streams = streams_mixed(9)
+    streams.append(synth.encode_mesh_corners(*seamed_mesh(synth, synth.GRID, 40, 33, 3, "checker", "stripes"), opt=synth.options(force_scheme=1)))
+    b = dsa.Batch(ctx, streams)
+    b.decode(wait=False)
+    b.download(wait=False, compact=True)
+    b.wait()
+    assert 0 < b.compact_bytes < b.output_bytes
+    check_views(b, streams, compact=True)
+    b.decode(wait=False)                      # and the full layout again on the same batch
+    b.download(compact=False)
+    check_views(b, streams)
+    b.decode(wait=False)
+    b.download(compact=True)
+    check_views(b, streams, compact=True)
+    b.close()
 
 
 def test_two_batches_in_flight(ctx):
