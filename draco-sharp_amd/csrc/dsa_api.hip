@@ -658,7 +658,6 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     while (lpm < b->max_att_data) lpm *= 2;
     const uint32_t per_wave = WAVE / lpm;
     hipLaunchKernelGGL(dsa::k_conn_checks, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, lpm);
-    if (b->any_seamed) HIP_TRY(ctx, hipEventRecord(S.ev_seambits, st3));      // the seam bits of the meshes with corner attributes are stored
   }
   {
     // the flip bits of GeometricNormal attributes (one serial rABS stream per attribute), beside everything else
@@ -667,9 +666,9 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     const uint32_t per_wave = WAVE / lpm;
     hipStream_t st5 = serial ? st : S.stream5;
     HIP_TRY(ctx, hipStreamWaitEvent(st5, S.ev_fork, 0));
-    hipLaunchKernelGGL(dsa::k_flip_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st5, b->arena, b->d_layouts, b->d_descs, n, lpm);
+    hipLaunchKernelGGL(dsa::k_flip_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st5, b->arena, b->d_layouts, b->d_descs, n, lpm, 0u);
     // and the orientation bits of TexCoordsPortable attributes, the same way
-    hipLaunchKernelGGL(dsa::k_orient_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st5, b->arena, b->d_layouts, b->d_descs, n, lpm);
+    hipLaunchKernelGGL(dsa::k_orient_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st5, b->arena, b->d_layouts, b->d_descs, n, lpm, 0u);
     HIP_TRY(ctx, hipEventRecord(S.ev_flips, st5));
   }
   // parallelogram operands: by the traversal waves themselves when the batch keeps the machine busy anyway, by an
@@ -702,20 +701,39 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     k_begin(KT_CONNECTIVITY, st);
     hipLaunchKernelGGL(dsa::k_connectivity, dim3(n), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     k_end(KT_CONNECTIVITY, st);
-    HIP_TRY(ctx, launch_faces());                      // beside the traversal
+    if (!b->any_seamed) HIP_TRY(ctx, launch_faces());  // beside the traversal
     if (b->any_seamed) {
       // corner attributes: seam edges, attribute vertices and points per corner from the connectivity and the seam bits; then, beside
-      // the position traversal, the traversal of every seamed attribute on its own table (third stream) and its symbols (below)
-      // (both on the third stream, behind k_faces there -- which waited for the connectivity -- so that the position traversal
-      // starts at once on the main stream)
+      // the position traversal, the traversal of every seamed attribute on its own table and its symbols (below).  Both on the third
+      // stream, so that the position traversal starts at once on the main stream -- and in FRONT of k_faces there (which only takes
+      // the census of such meshes: on the loaded machine it needs 12 ms that the seam tables must not wait for)
+      HIP_TRY(ctx, hipEventRecord(S.ev_trav, st));
+      HIP_TRY(ctx, hipStreamWaitEvent(st3, S.ev_trav, 0));
       k_begin(KT_SEAM_TABLES, st3);
       hipLaunchKernelGGL(dsa::k_seam_tables, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
       k_end(KT_SEAM_TABLES, st3);
+      // a corner attribute whose extent is its entry count (tagged symbols, uncompressed integers) stopped the walk of its mesh: it
+      // is taken up here, as many rounds of {tag stream, walk} as a mesh has attributes (nothing to do for most batches)
+      for (uint32_t r = 0; r < std::max<uint32_t>(1, b->max_atts); ++r) {
+        hipLaunchKernelGGL(dsa::k_tags, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+        hipLaunchKernelGGL(dsa::k_locate_resume, dim3(n), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n, b->d_globals);
+      }
       HIP_TRY(ctx, hipEventRecord(S.ev_tables, st3));
       k_begin(KT_TRAVERSE_ATT, st3);
       hipLaunchKernelGGL(dsa::k_traverse_att, dim3(n, std::max<uint32_t>(1, b->max_att_data)), dim3(WAVE), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
       k_end(KT_TRAVERSE_ATT, st3);
       HIP_TRY(ctx, hipEventRecord(S.ev_att, st3));
+      HIP_TRY(ctx, launch_faces());
+      {   // the flip bits of GeometricNormal attributes with seams: as many as the attribute has entries, which the seam tables counted
+        uint32_t lpm = 1;
+        while (lpm < na) lpm *= 2;
+        const uint32_t per_wave = WAVE / lpm;
+        hipStream_t st5 = serial ? st : S.stream5;
+        HIP_TRY(ctx, hipStreamWaitEvent(st5, S.ev_tables, 0));
+        hipLaunchKernelGGL(dsa::k_flip_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st5, b->arena, b->d_layouts, b->d_descs, n, lpm, 1u);
+        hipLaunchKernelGGL(dsa::k_orient_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st5, b->arena, b->d_layouts, b->d_descs, n, lpm, 1u);
+        HIP_TRY(ctx, hipEventRecord(S.ev_flips, st5));
+      }
     }
     HIP_TRY(ctx, mark());
     const uint32_t per = (n + (uint32_t)trav_split - 1) / (uint32_t)trav_split;
@@ -725,6 +743,15 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
       hipLaunchKernelGGL(dsa::k_traverse, dim3(cnt), dim3(WAVE), 0, st, b->arena, b->d_layouts + m0, b->d_descs + m0, cnt, trav_flags);
     }
     k_end(KT_TRAVERSE, st);
+    if (b->any_seamed) {
+      // point -> entry maps of the meshes with corner attributes, from the corners: behind both kinds of traversal, on the third
+      // stream beside the late prediction (k_seal waits for ev_maps)
+      HIP_TRY(ctx, hipEventRecord(S.ev_seambits, st));       // (the event is free by now: the position traversal is queued)
+      HIP_TRY(ctx, hipStreamWaitEvent(st3, S.ev_seambits, 0));
+      const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
+      hipLaunchKernelGGL(dsa::k_seam_maps, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+      HIP_TRY(ctx, hipEventRecord(S.ev_maps, st3));
+    }
   }
   HIP_TRY(ctx, mark());
   if (prof) HIP_TRY(ctx, hipEventRecord(b->ev_sym[0], st2));
@@ -874,16 +901,12 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     // decoded texture coordinates, one lane per attribute
     hipLaunchKernelGGL(dsa::k_texcoords_prepare, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     k_begin(KT_TEXCOORDS, st);
-    hipLaunchKernelGGL(dsa::k_texcoords, dim3((n + WAVE - 1) / WAVE, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+    hipLaunchKernelGGL(dsa::k_texcoords, dim3((2 * n + WAVE - 1) / WAVE, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);      // two lanes per attribute
     k_end(KT_TEXCOORDS, st);
   }
   {
     uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((3 * b->max_faces + 65535) / 65536, 4));
     hipLaunchKernelGGL(dsa::k_finalize, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags);
-  }
-  if (b->any_seamed) {       // point -> entry maps of the meshes with corner attributes, from the corners
-    const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
-    hipLaunchKernelGGL(dsa::k_seam_maps, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   }
   HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_maps, 0));
   hipLaunchKernelGGL(dsa::k_seal, dim3((n + 255) / 256), dim3(256), 0, st, b->d_descs, n);

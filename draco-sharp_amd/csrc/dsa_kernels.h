@@ -64,9 +64,10 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uin
 #define SYM_EARLY_ONLY 0x100u
 #define SYM_LATE_ONLY 0x200u
 #define SYM_CORNER 0x1000u     // the launch for corner attributes (behind k_seam_tables, which counts their entries); every other launch skips them
-__device__ __forceinline__ bool att_is_late(const AttrDesc &a) { return (a.have_scheme && a.pred_kind != 0) || a.corner_data != 0; }
+__device__ __forceinline__ bool att_behind_tables(const AttrDesc &a) { return a.corner_data != 0 || a.late_located != 0; }
+__device__ __forceinline__ bool att_is_late(const AttrDesc &a) { return (a.have_scheme && a.pred_kind != 0) || att_behind_tables(a); }
 __device__ __forceinline__ bool sym_filtered(const AttrDesc &a, uint32_t flags) {
-  if (a.corner_data != 0) return !(flags & SYM_CORNER);
+  if (att_behind_tables(a)) return !(flags & SYM_CORNER);
   if (flags & SYM_CORNER) return true;
   const bool late = a.have_scheme && a.pred_kind != 0;      // parallelogram, geometric normal, texture coordinates: after the traversal
   return ((flags & SYM_EARLY_ONLY) && late) || ((flags & SYM_LATE_ONLY) && !late);
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_locate_resume(uint8_t *arena, const
   if (mesh >= n || threadIdx.x != 0) return;
   MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK || D->general || !D->values_pending) return;
+  if (D->values_pending == 2 && !D->seam_tables_done) return;      // waits for the entry count of a corner attribute (k_seam_tables)
   locate_attribute_values(arena, layouts[mesh], D, G, s_cum, s_lut, LOC_RESUME);
 }
 
@@ -2321,6 +2323,7 @@ __global__ __launch_bounds__(WAVE, 6) void k_tags(uint8_t *arena, const MeshLayo
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
   if (D->status != ST_OK || D->general || !D->values_pending || D->resume_att >= D->num_attributes) return;
+  if (D->values_pending == 2) return;                                // (not stopped in front of a tag stream)
   reg_decode_stream<REG_TAGS>(arena, layouts[mesh], D, D->resume_att, 0u);
 }
 // The six context lists of valence-coded connectivity, a wave per list, in front of the connectivity waves that read them.
@@ -3175,7 +3178,19 @@ __global__ __launch_bounds__(256) void k_finalize(uint8_t *arena, const MeshLayo
 __device__ __forceinline__ uint32_t *flip_bits_of(uint8_t *arena, const MeshLayout &L, uint32_t ai) {
   return (uint32_t *)(arena + L.vstamp) + (size_t)ai * ((L.cap_vertices + 31u) / 32u);
 }
-__global__ __launch_bounds__(WAVE) void k_flip_bits(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t lanes_per_mesh) {
+// The bit array of an attribute's serial side stream (flip bits of GeometricNormal, orientation bits of TexCoordsPortable) and its
+// capacity in bits: the vertex-stamp slot of a vertex attribute, the `orient` region of its attribute data block for a corner
+// attribute (whose entries are not bounded by the vertex count; k_locate sees to it that one attribute per block uses it).
+__device__ __forceinline__ uint32_t *orient_bits_of(uint8_t *arena, const MeshLayout &L, const MeshDesc *D, uint32_t ai, uint32_t *capacity) {
+  const AttrDesc &a = D->att[ai];
+  if (a.corner_data == 0) { *capacity = L.cap_vertices; return flip_bits_of(arena, L, ai); }
+  const SeamLayout g = seam_layout(L.cap_faces, L.cap_vertices, D->num_att_data, L.rec_compact != 0);
+  *capacity = 3u * L.cap_faces;
+  return (uint32_t *)(seam_block(arena, L, g, (uint32_t)a.corner_data - 1u) + g.orient);
+}
+// corner_pass: 0 the attributes located at the start of the decode, 1 those of corner-attribute decoders (behind k_seam_tables,
+// which counts their entries = their flip bits) and what the walk located only then
+__global__ __launch_bounds__(WAVE) void k_flip_bits(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t lanes_per_mesh, uint32_t corner_pass) {
   const uint32_t lane = lane_id();
   const uint32_t mesh = blockIdx.x * (WAVE / lanes_per_mesh) + lane / lanes_per_mesh, ai = lane % lanes_per_mesh;
   if (mesh >= n) return;
@@ -3183,14 +3198,15 @@ __global__ __launch_bounds__(WAVE) void k_flip_bits(uint8_t *arena, const MeshLa
   MeshDesc *D = &descs[mesh];
   if (status_of(D) != ST_OK || D->general || ai >= D->num_attributes) return;
   const AttrDesc &a = D->att[ai];
-  if (!a.have_scheme || a.pred_kind != 2 || a.source == SRC_BYTES) return;
+  if (!a.have_scheme || a.pred_kind != 2 || a.source == SRC_BYTES || att_behind_tables(a) != (corner_pass != 0)) return;
   Rabs rb;
   uint32_t endp;
   rb.start(arena + L.stream, L.stream_len, a.off_flips, &endp);
   if (!rb.ok) { fail(D, ST_INVALID, 655); return; }
-  uint32_t *bits = flip_bits_of(arena, L, ai);
+  uint32_t cap;
+  uint32_t *bits = orient_bits_of(arena, L, D, ai, &cap);
   const uint32_t entries = a.num_entries;
-  if (entries > L.cap_vertices) { fail(D, ST_INVALID, 657); return; }
+  if (entries > cap) { fail(D, ST_INVALID, 657); return; }
   (void)rabs_block_to_words<false>(rb, entries, bits);
 }
 
@@ -3202,9 +3218,20 @@ __device__ __forceinline__ void geometric_entries(uint8_t *arena, const MeshLayo
   typedef Rec<CP> R;
   const AttrDesc &a = D->att[ai];
   const uint32_t *frec = (const uint32_t *)(arena + L.frec);
-  const uint32_t *d2c = (const uint32_t *)(arena + L.d2c);
+  // a corner attribute (normals with seams): the fan around the entry's corner ends at the attribute's seams -- the opposites of the
+  // attribute's own records --, the positions are those of the position vertices at the same corners
+  const bool corner_att = a.corner_data != 0;
+  const TravIO aio = corner_att ? trav_attribute(arena, L, D, (uint32_t)a.corner_data - 1u) : trav_position(arena, L, D);
+  const uint32_t *arec = aio.frec;
+  const uint32_t *d2c = aio.d2c;
   const int32_t *posv = (const int32_t *)(arena + L.para);       // k_vertex_positions
-  const uint32_t *bits = flip_bits_of(arena, L, ai);
+  uint32_t bits_cap;
+  const uint32_t *bits = orient_bits_of(arena, L, D, ai, &bits_cap);
+  auto load_rec = [&](uint32_t f) -> typename R::Raw {
+    typename R::Raw r = R::load(frec, f);
+    if (corner_att) { const typename R::Raw q = R::load(arec, f); r.o = q.o; }
+    return r;
+  };
   int32_t *w = (int32_t *)(arena + L.work[ai]);
   const uint32_t entries = a.num_entries, NV = D->num_vertices, F = D->num_faces;
   OctParams o;
@@ -3223,7 +3250,7 @@ __device__ __forceinline__ void geometric_entries(uint8_t *arena, const MeshLayo
     if (ok) {
       // One record load per face of the fan (its vertices and its opposites), one new position per face: two faces in a row
       // share an edge, so going left the vertex behind the corner becomes the one ahead of it, going right the other way round.
-      typename R::Raw rec = R::load(frec, ci >> 2);
+      typename R::Raw rec = load_rec(ci >> 2);
       const typename R::Raw first = rec;
       coord center[3], pn[3], pp[3], pn0[3];
       position(R::vertex(rec, ci & 3u), center);
@@ -3245,7 +3272,7 @@ __device__ __forceinline__ void geometric_entries(uint8_t *arena, const MeshLayo
             c = qnext(ol);
             if (c == ci) break;                                               // all the way round
             if ((c >> 2) >= F || (c & 3u) == 3u) { ok = false; break; }
-            rec = R::load(frec, c >> 2);
+            rec = load_rec(c >> 2);
             for (int k = 0; k < 3; ++k) pn[k] = pp[k];                         // the shared edge's far vertex is now ahead of the corner
             position(R::vertex(rec, k_prev(c & 3u)), pp);
             continue;
@@ -3258,7 +3285,7 @@ __device__ __forceinline__ void geometric_entries(uint8_t *arena, const MeshLayo
         if (orr == DSA_INVALID) break;
         c = qprev(orr);
         if ((c >> 2) >= F || (c & 3u) == 3u) { ok = false; break; }
-        rec = R::load(frec, c >> 2);
+        rec = load_rec(c >> 2);
         for (int k = 0; k < 3; ++k) pp[k] = pn[k];                             // the shared edge's far vertex is now behind the corner
         position(R::vertex(rec, k_next(c & 3u)), pn);
       }

@@ -30,15 +30,16 @@ static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long 
 #define RET 0
 // A corner attribute (a.corner_data != 0) has one entry per vertex of its own corner table, which only k_seam_tables knows (behind
 // the connectivity): its section is walked with the count open (`num_entries` = LOC_COUNT_OPEN).  That works for what carries its
-// own length -- a raw-coded symbol stream, the prediction data -- and sends anything else (raw bytes, tagged symbols, uncompressed
-// integers: their extent IS the count) to the general path.
+// own length -- a raw-coded symbol stream, the prediction data.  Anything else (raw bytes, tagged symbols, uncompressed integers:
+// their extent IS the count) stops the walk in front of the attribute (return value 3); k_locate_resume takes it up behind
+// k_seam_tables with the count known, and what it locates then is marked late_located.
 #define LOC_COUNT_OPEN 0xFFFFFFFFu
 __device__ __forceinline__ int locate_attribute_section(Rd &r, MeshDesc *D, AttrDesc &a, const MeshLayout &L, int ai, uint8_t *arena,
                                         uint32_t *s_cum, uint32_t *s_lut, uint32_t num_entries, BatchGlobals *G, int tags) {
   const uint8_t *s = r.p;
   const bool open = num_entries == LOC_COUNT_OPEN;
   a.num_entries = open ? 0u : num_entries;
-  if (open && a.seq_type == 0) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+  if (open && a.seq_type == 0) return 3;
   if (a.seq_type == 0) {   // generic: raw bytes, SequentialAttributeDecoder.cs:75-86
     a.source = SRC_BYTES;
     a.nc_portable = a.nc;
@@ -100,7 +101,7 @@ __device__ __forceinline__ int locate_attribute_section(Rd &r, MeshDesc *D, Attr
         REQUIRE(r.ok && size >= 1, 150);
         a.size_rans = (uint32_t)size;
       } else {
-        if (open) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+        if (open) return 3;
         a.source = SRC_TAGGED;
         a.precision_bits = 12;   // SymbolDecoding.cs:34: tag alphabet is 5 bits wide
         uint64_t ns = r.varint();
@@ -209,7 +210,7 @@ __device__ __forceinline__ int locate_attribute_section(Rd &r, MeshDesc *D, Attr
       a.num_symbols = 0;
     }
   } else {
-    if (open) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+    if (open) return 3;
     a.source = SRC_FIXED;
     uint32_t nb = r.u8();
     REQUIRE(r.ok && nb >= 1 && nb <= 4, 159);
@@ -246,12 +247,13 @@ __device__ __forceinline__ int locate_attribute_section(Rd &r, MeshDesc *D, Attr
         a.off_flips = r.pos;
         a.num_orient = (uint32_t)num_or;
         r.pos = endp;
+        if (a.corner_data != 0) for (int k = 0; k < ai; ++k) if (D->att[k].corner_data == a.corner_data && D->att[k].have_scheme && (D->att[k].pred_kind == 2 || D->att[k].pred_kind == 3)) NOTIMPL(DSA_SITE_RETRY_GENERAL);
       }
     } else {
       // GeometricNormal (MeshPredictionSchemeGeometricNormalDecoder.cs:44-82): predicted from the decoded positions, entry by entry
       // independently (k_predict_geometric); needs the portable positions before it in the same decoder
       a.pred_kind = method == 6 ? 2 : 0;
-      if (a.pred_kind == 2 && a.corner_data != 0) NOTIMPL(DSA_SITE_RETRY_GENERAL);    // normals with seams under GeometricNormal: general path
+      // (normals with seams: the fan of an entry ends at the attribute's seams, k_predict_geometric walks the attribute's own records)
     }
     if (a.pred_transform == 1) {           // PredictionSchemeWrapDecodingTransform.cs:69-75
       a.wrap_min = (int32_t)r.u32();
@@ -276,7 +278,10 @@ __device__ __forceinline__ int locate_attribute_section(Rd &r, MeshDesc *D, Attr
         int pa = -1;                       // parent = portable positions, SequentialAttributeDecoder.cs:58-73
         for (int k = 0; k < ai; ++k) if (D->att[k].att_type == 0 && D->att[k].seq_type != 0) { pa = k; break; }
         REQUIRE(pa >= 0 && D->att[pa].nc_portable == 3, 656);
-        REQUIRE(num_entries <= L.cap_vertices, 657);                  // the decoded flip bits wait in the vertex-stamp region
+        if (D->att[pa].corner_data != 0) NOTIMPL(DSA_SITE_RETRY_GENERAL);     // positions with a corner table of their own: no encoder writes that
+        REQUIRE(a.corner_data != 0 || num_entries <= L.cap_vertices, 657);   // the decoded flip bits wait in the vertex-stamp region (corner attributes: their block's, k_flip_bits checks)
+        // one bit array per attribute data block: a second attribute of the same corner decoder that wants one goes to the general path
+        if (a.corner_data != 0) for (int k = 0; k < ai; ++k) if (D->att[k].corner_data == a.corner_data && D->att[k].have_scheme && (D->att[k].pred_kind == 2 || D->att[k].pred_kind == 3)) NOTIMPL(DSA_SITE_RETRY_GENERAL);
       }
     }
   }
@@ -575,10 +580,18 @@ __device__ inline void locate_attribute_values(uint8_t *arena, const MeshLayout 
       // a tag stream ahead is left to k_tags -- unless this IS the attribute the walk stopped at and k_tags did not take it
       // (a stream it is not made for): then its tags are decoded here
       const bool again = mode == LOC_RESUME && i == i0 && ai == a0;
-      const int rc = locate_attribute_section(r, D, D->att[ai], L, (int)ai, arena, s_cum, s_lut, D->att[ai].corner_data ? LOC_COUNT_OPEN : num_entries, G,
+      AttrDesc &A = D->att[ai];
+      const uint32_t count = !A.corner_data ? num_entries : (D->seam_tables_done ? D->seam_nv[(uint32_t)A.corner_data - 1u] : LOC_COUNT_OPEN);
+      if (D->seam_tables_done) A.late_located = 1;
+      const int rc = locate_attribute_section(r, D, A, L, (int)ai, arena, s_cum, s_lut, count, G,
                                               mode == LOC_WHOLE || again ? LOC_TAGS_HERE : LOC_TAGS_LATER);
       if (rc == 0) return;
       if (rc == 2) { D->resume_dec = (uint8_t)i; D->resume_att = (uint8_t)ai; D->resume_pos = at; D->values_pending = 1; return; }
+      if (rc == 3) {     // behind k_seam_tables; everything from here on is marked now, so that no early kernel mistakes a half-written descriptor for its own
+        for (uint32_t k = ai; k < D->num_attributes; ++k) D->att[k].late_located = 1;
+        D->resume_dec = (uint8_t)i; D->resume_att = (uint8_t)ai; D->resume_pos = at; D->values_pending = 2;
+        return;
+      }
     }
     for (uint32_t ai = first_att[i]; ai < first_att[i + 1]; ++ai) {
       AttrDesc &a = D->att[ai];

@@ -420,6 +420,7 @@ __device__ __forceinline__ void seam_tables_wave(uint8_t *arena, const MeshLayou
   // ---- results: points of the mesh, vertices of every attribute table = entries of its decoder's attributes
   if (lane == 0) {
     D->num_points = ptotal;
+    D->seam_tables_done = 1;
     for (uint32_t d = 0; d < nad; ++d) D->seam_nv[d] = totals[d];
     for (uint32_t ai = 0; ai < D->num_attributes; ++ai) {
       AttrDesc &a = D->att[ai];
@@ -538,16 +539,8 @@ __device__ __forceinline__ uint64_t isqrt_floor(uint64_t n) {   // = Core/MathUt
 }
 __device__ __forceinline__ int64_t div_trunc(int64_t x, int64_t y) { return y > 0 ? div_trunc_pos(x, y) : x / y; }
 
-__device__ __forceinline__ uint32_t *orient_bits_of(uint8_t *arena, const MeshLayout &L, const MeshDesc *D, uint32_t ai, uint32_t *capacity) {
-  const AttrDesc &a = D->att[ai];
-  if (a.corner_data == 0) { *capacity = L.cap_vertices; return flip_bits_of(arena, L, ai); }
-  const SeamLayout g = seam_layout(L.cap_faces, L.cap_vertices, D->num_att_data, L.rec_compact != 0);
-  *capacity = 3u * L.cap_faces;
-  return (uint32_t *)(seam_block(arena, L, g, (uint32_t)a.corner_data - 1u) + g.orient);
-}
-
 // The orientation bits as the decoder will use them (:66-85: a bit says "same as the one before", starting from true).
-__global__ __launch_bounds__(WAVE) void k_orient_bits(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t lanes_per_mesh) {
+__global__ __launch_bounds__(WAVE) void k_orient_bits(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t lanes_per_mesh, uint32_t late_pass) {
   const uint32_t lane = lane_id();
   const uint32_t mesh = blockIdx.x * (WAVE / lanes_per_mesh) + lane / lanes_per_mesh, ai = lane % lanes_per_mesh;
   if (mesh >= n) return;
@@ -555,7 +548,9 @@ __global__ __launch_bounds__(WAVE) void k_orient_bits(uint8_t *arena, const Mesh
   MeshDesc *D = &descs[mesh];
   if (status_of(D) != ST_OK || D->general || ai >= D->num_attributes) return;
   const AttrDesc &a = D->att[ai];
-  if (!a.have_scheme || a.pred_kind != 3 || a.source == SRC_BYTES) return;
+  // late_pass: 1 the attributes the walk located only behind k_seam_tables (a corner attribute's own orientation block is known from
+  // the start: its place does not depend on the entry count once the walk got there)
+  if (!a.have_scheme || a.pred_kind != 3 || a.source == SRC_BYTES || (a.late_located != 0) != (late_pass != 0)) return;
   if (L.tc[ai] == 0) { fail(D, ST_NOTIMPL, DSA_SITE_RETRY_GENERAL); return; }
   Rabs rb;
   uint32_t endp;
@@ -671,10 +666,14 @@ __device__ __forceinline__ int32_t tc_div(int64_t su, int64_t d, double inv, boo
 // places count exactly the younger requests (vmcnt is one in-order counter) instead of draining everything that is in flight.
 #define TC_DEPTH 3        // groups of records in flight
 #define TC_RING 8         // results of a lane kept in LDS (the operands too recent to have been requested: < TC_G + TC_G back)
+// TWO lanes per attribute, one for u and one for v (lanes 2j and 2j + 1): the two halves of the prediction are the same program on
+// different components, and what one needs of the other -- the other component of pn_uv, whether its coordinates were equal too --
+// is a neighbour exchange in the quad (one DPP move).  Half the instructions per entry on the chain.
+__device__ __forceinline__ uint32_t tc_partner(uint32_t x) { return dpp_mov<0xB1>(x); }      // quad_perm [1, 0, 3, 2]
 __global__ __launch_bounds__(WAVE) void k_texcoords(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
-  __shared__ int2 ring[TC_RING][WAVE];
+  __shared__ int32_t ring[TC_RING][WAVE];
   const uint32_t lane = lane_id();
-  const uint32_t mesh = blockIdx.x * WAVE + lane, ai = blockIdx.y;
+  const uint32_t mesh = (blockIdx.x * WAVE + lane) >> 1, comp = lane & 1u, ai = blockIdx.y;
   if (mesh >= n) return;
   MeshDesc *D = &descs[mesh];
   if (status_of(D) != ST_OK || D->general || ai >= D->num_attributes) return;
@@ -682,7 +681,7 @@ __global__ __launch_bounds__(WAVE) void k_texcoords(uint8_t *arena, const MeshLa
   const MeshLayout &L = layouts[mesh];
   if (!a.have_scheme || a.pred_kind != 3 || a.source == SRC_BYTES || a.num_entries == 0 || L.tc[ai] == 0) return;
   const TcPrep *prep = (const TcPrep *)(arena + L.tc[ai]);
-  int2 *w2 = (int2 *)(arena + L.work[ai]);
+  int32_t *w = (int32_t *)(arena + L.work[ai]) + comp;      // this lane's component of entry e: w[2 e]
   uint32_t cap;
   const uint32_t *obits = orient_bits_of(arena, L, D, ai, &cap);
   const uint32_t entries = a.num_entries, lastp = entries - 1;
@@ -696,19 +695,19 @@ __global__ __launch_bounds__(WAVE) void k_texcoords(uint8_t *arena, const MeshLa
   uint32_t ldA = ow_n1, ldB = ow_n2, ld_base = ow_idx;
   bool ran_out = false;
   TcPrep rt[TC_DEPTH][TC_G];
-  int2 rc[TC_DEPTH][TC_G], cfn[TC_G], cfp[TC_G], nfn[TC_G], nfp[TC_G];
-  int2 o1 = make_int2(0, 0);                                // the result of entry p - 1
+  int32_t rc[TC_DEPTH][TC_G], cfn[TC_G], cfp[TC_G], nfn[TC_G], nfp[TC_G];
+  int32_t o1 = 0;                                            // the result of entry p - 1 (this lane's component)
 #pragma unroll
   for (int k = 0; k < TC_DEPTH; ++k)
 #pragma unroll
     for (int u = 0; u < TC_G; ++u) {
       const uint32_t p = (uint32_t)(k * TC_G + u) <= lastp ? (uint32_t)(k * TC_G + u) : lastp;
-      rt[k][u] = prep[p]; rc[k][u] = w2[p];
+      rt[k][u] = prep[p]; rc[k][u] = w[2 * (size_t)p];
     }
 #pragma unroll
-  for (int u = 0; u < TC_G; ++u) { nfn[u] = make_int2(0, 0); nfp[u] = make_int2(0, 0); }
+  for (int u = 0; u < TC_G; ++u) { nfn[u] = 0; nfp[u] = 0; }
 #pragma unroll
-  for (int i = 0; i < TC_RING; ++i) ring[i][lane] = make_int2(0, 0);
+  for (int i = 0; i < TC_RING; ++i) ring[i][lane] = 0;
   for (uint32_t gbase = 0; gbase <= lastp; gbase += TC_DEPTH * TC_G) {
 #pragma unroll
     for (int k = 0; k < TC_DEPTH; ++k) {
@@ -720,8 +719,8 @@ __global__ __launch_bounds__(WAVE) void k_texcoords(uint8_t *arena, const MeshLa
       { const bool same = ld_base == ow_idx; ow_n1 = same ? ldA : ldB; ow_n2 = same ? ldB : ow_n2; }
 #pragma unroll
       for (int u = 0; u < TC_G; ++u) {                     // the next group's operands that are final by now (entries < g0)
-        nfn[u] = w2[rt[kn][u].next_id < g0 ? rt[kn][u].next_id : 0u];
-        nfp[u] = w2[rt[kn][u].prev_id < g0 ? rt[kn][u].prev_id : 0u];
+        nfn[u] = w[2 * (size_t)(rt[kn][u].next_id < g0 ? rt[kn][u].next_id : 0u)];
+        nfp[u] = w[2 * (size_t)(rt[kn][u].prev_id < g0 ? rt[kn][u].prev_id : 0u)];
       }
       ldA = obits[ow_idx ? ow_idx - 1 : 0u]; ldB = obits[ow_idx > 1 ? ow_idx - 2 : 0u]; ld_base = ow_idx;
       const uint32_t far_limit = g0 >= TC_G ? g0 - TC_G : 0u;     // what this group's request (a turn ago) covered
@@ -732,21 +731,23 @@ __global__ __launch_bounds__(WAVE) void k_texcoords(uint8_t *arena, const MeshLa
         const bool live = p <= lastp;
         const TcPrep t = rt[k][u];
         const bool hn = t.next_id != DSA_INVALID, hp = t.prev_id != DSA_INVALID, both = hn && hp;
-        // operands: the previous result, a recent one from the ring, or what was requested a turn ago
-        const int2 ln = ring[t.next_id & (TC_RING - 1)][lane], lp = ring[t.prev_id & (TC_RING - 1)][lane];
-        const int2 nuv = p - t.next_id == 1u ? o1 : (t.next_id >= far_limit ? ln : cfn[u]);
-        const int2 puv = p - t.prev_id == 1u ? o1 : (t.prev_id >= far_limit ? lp : cfp[u]);
-        const bool equal = puv.x == nuv.x && puv.y == nuv.y;
+        // operands (this lane's component): the previous result, a recent one from the ring, or what was requested a turn ago
+        const int32_t ln = ring[t.next_id & (TC_RING - 1)][lane], lp = ring[t.prev_id & (TC_RING - 1)][lane];
+        const int32_t nc = p - t.next_id == 1u ? o1 : (t.next_id >= far_limit ? ln : cfn[u]);
+        const int32_t pc = p - t.prev_id == 1u ? o1 : (t.prev_id >= far_limit ? lp : cfp[u]);
+        const uint32_t eq_own = pc == nc ? 1u : 0u;
+        const uint32_t eq_other = tc_partner(eq_own);
+        const bool equal = (eq_own & eq_other) != 0;
         const int64_t d = t.pn_norm2;
         const bool geo = both && !equal && d != 0;
         const bool d_small = d > 0 && d < (int64_t)0x100000000ll;
         const double inv = __drcp_rn((double)(uint32_t)d);
-        const int32_t dpu = (int32_t)((uint32_t)puv.x - (uint32_t)nuv.x), dpv = (int32_t)((uint32_t)puv.y - (uint32_t)nuv.y);
-        const uint64_t pnu = (uint64_t)(int64_t)dpu, pnv = (uint64_t)(int64_t)dpv;
-        const uint64_t xu = (uint64_t)(int64_t)nuv.x * (uint64_t)d + (uint64_t)t.cn_dot_pn * pnu;
-        const uint64_t xv = (uint64_t)(int64_t)nuv.y * (uint64_t)d + (uint64_t)t.cn_dot_pn * pnv;
-        const uint64_t cxu = pnv * (uint64_t)t.norm, cxv = ((uint64_t)0 - pnu) * (uint64_t)t.norm;
-        // the orientation (consumed by this entry only when it takes the geometric prediction)
+        const int32_t d_own = (int32_t)((uint32_t)pc - (uint32_t)nc);
+        const int32_t d_other = (int32_t)tc_partner((uint32_t)d_own);
+        // x = n d + (cn . pn) pn_uv (own component); cx = (pn_v, -pn_u) norm: the other component's difference, negated for v
+        const uint64_t x = (uint64_t)(int64_t)nc * (uint64_t)d + (uint64_t)t.cn_dot_pn * (uint64_t)(int64_t)d_own;
+        const uint64_t cx = (uint64_t)(int64_t)(comp ? -(int64_t)d_other : (int64_t)d_other) * (uint64_t)t.norm;
+        // the orientation (consumed by this entry only when it takes the geometric prediction); both lanes keep the same books
         const bool take = geo && live;
         ran_out = ran_out || (take && left == 0);
         const uint32_t nl = take && left ? left - 1 : left;
@@ -756,17 +757,15 @@ __global__ __launch_bounds__(WAVE) void k_texcoords(uint8_t *arena, const MeshLa
         ow_n1 = cross ? ow_n2 : ow_n1;
         left = nl;
         const bool orientation = ((ow_cur >> (left & 31u)) & 1u) != 0;
-        const int64_t su = (int64_t)(orientation ? xu + cxu : xu - cxu), sv = (int64_t)(orientation ? xv + cxv : xv - cxv);
-        int32_t gu = 0, gv = 0;
-        if (geo) { gu = tc_div(su, d, inv, d_small); gv = tc_div(sv, d, inv, d_small); }
+        const int64_t sx = (int64_t)(orientation ? x + cx : x - cx);
+        int32_t g = 0;
+        if (geo) g = tc_div(sx, d, inv, d_small);
         // the fallback chain of the predictor, as written there (:129-149): the entry at Next if it is decoded, else the entry before
-        const int2 fb = hn ? nuv : (p > 0 ? o1 : make_int2(0, 0));
-        const int32_t pu = both && equal ? puv.x : (geo ? gu : fb.x), pv = both && equal ? puv.y : (geo ? gv : fb.y);
-        int2 o;
-        o.x = wrap_original(pu, rc[k][u].x, mn, mx, max_dif);
-        o.y = wrap_original(pv, rc[k][u].y, mn, mx, max_dif);
+        const int32_t fb = hn ? nc : (p > 0 ? o1 : 0);
+        const int32_t pred = both && equal ? pc : (geo ? g : fb);
+        int32_t o = wrap_original(pred, rc[k][u], mn, mx, max_dif);
         o = live ? o : o1;                                 // (behind the last entry: it is written again)
-        w2[live ? p : lastp] = o;
+        w[2 * (size_t)(live ? p : lastp)] = o;
         ring[p & (TC_RING - 1)][lane] = o;
         o1 = o;
       }
@@ -774,11 +773,11 @@ __global__ __launch_bounds__(WAVE) void k_texcoords(uint8_t *arena, const MeshLa
 #pragma unroll
       for (int u = 0; u < TC_G; ++u) {
         const uint32_t p2 = g0 + TC_DEPTH * TC_G + u <= lastp ? g0 + TC_DEPTH * TC_G + u : lastp;
-        rt[k][u] = prep[p2]; rc[k][u] = w2[p2];
+        rt[k][u] = prep[p2]; rc[k][u] = w[2 * (size_t)p2];
       }
     }
   }
-  if (ran_out) fail(D, ST_INVALID, 672);
+  if (ran_out && comp == 0) fail(D, ST_INVALID, 672);
 }
 #undef TC_DEPTH
 #undef TC_RING

@@ -39,6 +39,8 @@ struct AttrDesc {
   uint8_t tags_done;       // tagged scheme: k_tags decoded the tag stream (tags in the output region, their bit total in `table`)
   int8_t corner_data;      // attribute data id + 1 when the attribute's decoder is a corner-attribute decoder (it has a corner table
                            // of its own, cut along the attribute's seams: MeshAttributeCornerTable.cs), else 0
+  uint8_t late_located;    // the walk reached this attribute only behind k_seam_tables (it stands behind a corner attribute whose extent
+                           // is its entry count): its symbols, bits and prediction are the late launches'
   uint32_t unique_id;
   uint32_t num_symbols;    // alphabet size
   uint32_t off_table;      // stream offset of the first probability-table byte
@@ -100,7 +102,8 @@ struct MeshDesc {
   uint8_t seam_fast;       // the mesh has corner-attribute decoders and the fast kernels take it (k_seam_tables, k_traverse_att)
   // attribute seams on the fast kernels
   uint16_t corner_mask;    // bit d: attribute data d belongs to a corner-attribute decoder
-  uint16_t pad_seam;
+  uint8_t seam_tables_done;    // k_seam_tables has counted the vertices of the attribute tables (seam_nv)
+  uint8_t pad_seam;
   uint32_t seam_nv[DSA_MAX_ATT_DATA];      // vertices of attribute data d's corner table (= entries of its decoder), by k_seam_tables
   uint32_t dbg[20];        // diagnostics of the per-mesh kernels (tools/dbg_phases.py, bench.py): s_memtime deltas between phases;
                            // k_connectivity: [13] its s_memtime ticks, [14] its start and [15] its duration in s_memrealtime ticks

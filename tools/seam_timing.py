@@ -23,7 +23,8 @@ variants = [("per-vertex, parallelogram (the bench batch)", None, dict()),
             ("UV seams, TexCoordsPortable, valence", (None, "stripes"), dict(uv_prediction=5, predictive_connectivity=2)),
             ("per-vertex, TexCoordsPortable", None, dict(uv_prediction=5)),
             ("stock default: valence + GeometricNormal + TexCoordsPortable, per vertex", None, dict(uv_prediction=5, predictive_connectivity=2, normal_prediction=6)),
-            ("stock default with UV seams", (None, "stripes"), dict(uv_prediction=5, predictive_connectivity=2, normal_prediction=6))]
+            ("stock default with UV seams", (None, "stripes"), dict(uv_prediction=5, predictive_connectivity=2, normal_prediction=6)),
+            ("stock default with UV and normal seams (3 charts each)", ("stripes", "stripes"), dict(uv_prediction=5, predictive_connectivity=2, normal_prediction=6))]
 for vi, (name, charts, opt) in enumerate(variants):
     if only is not None and vi not in only:
         continue
