@@ -201,3 +201,49 @@ def test_gpu_seams_at_64k_triangles(ctx):
         args = seamed_mesh(synth, kind, 128, 256, 9, *charts)
         cases.append((args, synth.encode_mesh_corners(*args, opt=synth.options(**opt))))
     assert _gpu_check(ctx, cases) == [0, 0, 0]         # the fast kernels throughout (the last stream has tagged symbols in its corner attributes)
+
+
+@pytest.mark.gpu
+def test_gpu_corrupt_seamed_streams_agree_with_the_oracle(ctx, house04_bytes):
+    """A slice of tools/fuzz_seams.py in the suite: corrupted seamed / TexCoordsPortable / GeometricNormal streams through the fast
+    seam kernels -- where the oracle decodes, the device decodes the same or refuses by one of its own checks; where the oracle
+    refuses, the device does not succeed."""
+    import draco_sharp_amd as dsa
+    from test_gpu_parity import _corruptions, assert_same
+    families = []
+    for k, (kind, nx, ny, charts, opt) in enumerate([
+            (synth.TORUS, 12, 10, ("checker", "stripes"), dict(force_scheme=1, uv_prediction=5, normal_prediction=6)),
+            (synth.HOLES, 20, 16, (None, "random"), dict(predictive_connectivity=2)),
+            (synth.GRID, 24, 20, ("stripes", "island"), dict(force_scheme=0, uv_prediction=5)),
+            (synth.SPHERE, 10, 9, (None, "checker"), dict(raw_integers=2))]):
+        families.append(synth.encode_mesh_corners(*seamed_mesh(synth, kind, nx, ny, 5 + k, *charts), opt=synth.options(**opt)))
+    families.append(house04_bytes)
+    streams = []
+    for k, f in enumerate(families):
+        streams += _corruptions(f, 80, 300 + k) + [f]
+    b = dsa.Batch(ctx, streams)
+    b.decode()
+    equal = refused = stricter = 0
+    sites = set()
+    for i, sbytes in enumerate(streams):
+        try:
+            ref = oracle.decode(sbytes)
+        except oracle.OracleError:
+            ref = None
+        st = b.status(i)
+        if ref is not None and st == 0:
+            assert_same(b.result(i), ref)
+            equal += 1
+        elif ref is None:
+            assert st != 0, (i, "the device accepted a stream the oracle rejects")
+            refused += 1
+        else:
+            stricter += 1
+            info = b.mesh_info(i)
+            sites.add((info.status, info.detail))
+    assert equal >= len(families) and refused > 0
+    # the device's own checks that the oracle does not make: the census of linked corners (263), an attribute traversal that does not
+    # reach every attribute vertex (305), more orientation / flip bits than entries (668, 657), the bound on seam data (681)
+    assert sites <= {(1, 263), (1, 305), (1, 668), (1, 657), (1, 681), (1, 123)}, sites
+    assert stricter <= 8, (equal, refused, stricter, sites)
+    b.close()
