@@ -1124,8 +1124,9 @@ __global__ __launch_bounds__(256) void k_init(uint8_t *arena, const MeshLayout *
                                          // vertex -> entry of the attribute's traversal; per mesh the "touches a seam" flags
     const uint32_t nad = (uint32_t)((L.seam_bytes - seam_layout(F, V, 0, L.rec_compact != 0).total) / seam_layout(F, V, 1, L.rec_compact != 0).data_stride);
     const SeamLayout g = seam_layout(F, V, nad, L.rec_compact != 0);
-    uint32_t *vseam4 = (uint32_t *)(arena + L.seam + g.vseam);
+    uint32_t *vseam4 = (uint32_t *)(arena + L.seam + g.vseam), *eseam4 = (uint32_t *)(arena + L.seam + g.eseam);
     for (uint32_t w4 = tid; w4 < (V + 3) / 4; w4 += stride) vseam4[w4] = 0;
+    for (uint32_t f = tid; f < F; f += stride) eseam4[f] = 0;           // seam masks: k_seam_tables writes the non-zero bytes only
     for (uint32_t d = 0; d < nad; ++d) {
       uint8_t *blk = seam_block(arena, L, g, d);
       uint32_t *bits = (uint32_t *)(blk + g.bits), *fv4 = (uint32_t *)(blk + g.fvis);

@@ -63,9 +63,12 @@ __device__ __forceinline__ void seam_tables_wave(uint8_t *arena, const MeshLayou
   auto corner_ok = [&](uint32_t c) -> bool { return c < 4u * F && (c & 3u) != 3u; };
 
   // ---- A. faces: which seam bit belongs to which corner (one bit per interior edge, at the lower of its two faces, in corner
-  // order: a prefix count), and from the bits the seam mask of that corner.  (Every pass of this kernel keeps four chunks of 64
-  // elements in flight: a lone wave waits a microsecond for each dependent load, and there are a dozen passes.)
+  // order: a prefix count), and from the bits the seam mask of the edge -- written to the bytes of BOTH corners the edge lies
+  // opposite of (every byte has one writer: the edge's owner, or the corner itself on the boundary; k_init zeroed the words) --;
+  // the vertices at the ends of cut edges are marked.  (Every pass of this kernel keeps four chunks of 64 elements in flight: a
+  // lone wave waits a microsecond for each dependent load, and there are ten passes.)
   {
+    uint8_t *eseam_w = S + g.eseam;
     uint32_t base = 0;
     bool bad = false, weird = false;
     for (uint32_t f0 = 0; f0 < F; f0 += SM_U * WAVE) {
@@ -111,51 +114,25 @@ __device__ __forceinline__ void seam_tables_wave(uint8_t *arena, const MeshLayou
       for (uint32_t u = 0; u < SM_U; ++u) {
         const uint32_t f = f0 + u * WAVE + lane;
         if (f >= F) continue;
-        uint32_t word = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 3; ++k) word |= (o[u][k] == DSA_INVALID ? 0xFFu : bitsv[u][k]) << (8u * k);      // boundary edges are seams of every attribute data (:516-522)
-        eseam32[f] = word;
+        for (uint32_t k = 0; k < 3; ++k) {
+          const bool boundary = o[u][k] == DSA_INVALID;      // boundary edges are seams of every attribute data (:516-522)
+          if (!boundary && !own[u][k]) continue;             // (the owner writes this corner's byte)
+          const uint32_t m = boundary ? 0xFFu : bitsv[u][k];
+          if (m) {
+            eseam_w[4u * f + k] = (uint8_t)m;
+            if (!boundary) eseam_w[o[u][k]] = (uint8_t)m;
+            // the edge opposite corner k: its end points are at the other two corners
+            const uint32_t va = R::vertex(r[u], k_next(k)), vb = R::vertex(r[u], k_prev(k));
+            if (va < NVALL) vseam[va] = 1;
+            if (vb < NVALL) vseam[vb] = 1;
+          }
+        }
       }
     }
     if (__ballot(bad)) SM_FAIL(ST_INVALID, 681);
     if (__ballot(weird)) SM_FAIL(ST_NOTIMPL, DSA_SITE_RETRY_GENERAL);
     if (2u * base != D->interior_corners) SM_FAIL(ST_INVALID, 263);      // (the census of k_faces / k_seal, seen from here)
-  }
-  SM_SYNC();
-  // ---- B. faces: the other side of every edge takes the mask over; vertices at the ends of cut edges are marked
-  for (uint32_t f0 = 0; f0 < F; f0 += SM_U * WAVE) {
-    Raw r[SM_U];
-    uint32_t word[SM_U], om[SM_U][3];
-#pragma unroll
-    for (uint32_t u = 0; u < SM_U; ++u) { const uint32_t f = f0 + u * WAVE + lane, fc = f < F ? f : 0u; r[u] = R::load(frec, fc); word[u] = eseam32[fc]; }
-#pragma unroll
-    for (uint32_t u = 0; u < SM_U; ++u) {
-      const uint32_t f = f0 + u * WAVE + lane;
-#pragma unroll
-      for (uint32_t k = 0; k < 3; ++k) {
-        const uint32_t o = R::opp(r[u], k);
-        om[u][k] = (f < F && o != DSA_INVALID && corner_ok(o) && (o >> 2) < f) ? (uint32_t)eseam8[o] : 0u;
-      }
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < SM_U; ++u) {
-      const uint32_t f = f0 + u * WAVE + lane;
-      if (f >= F) continue;
-      uint32_t v[3];
-      uint32_t w = word[u];
-#pragma unroll
-      for (uint32_t k = 0; k < 3; ++k) { v[k] = R::vertex(r[u], k); w |= om[u][k] << (8u * k); }
-      eseam32[f] = w;
-#pragma unroll
-      for (uint32_t k = 0; k < 3; ++k) {
-        const uint32_t m = (w >> (8u * k)) & 0xFFu;
-        if (m == 0xFFu || (m & allmask)) {                   // the edge opposite corner k: its end points are at the other two corners
-          const uint32_t va = v[k_next(k)], vb = v[k_prev(k)];
-          if (va < NVALL) vseam[va] = 1;
-          if (vb < NVALL) vseam[vb] = 1;
-        }
-      }
-    }
   }
   SM_SYNC();
   // ---- P0. vertices in order: one attribute vertex and one point each, unless a seam or the boundary touches the vertex (those go
