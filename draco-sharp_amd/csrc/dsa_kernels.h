@@ -2423,16 +2423,19 @@ __global__ __launch_bounds__(WAVE) void k_symbols_wide(uint8_t *arena, const Mes
   __threadfence_block();
   __syncthreads();
   // 3. the table into registers: register r, lane l = {cum, freq} of entry 64 r + l in 16 + 16 bits (precision <= 16; a frequency of
-  // 2^16 would be a one-symbol alphabet, which never comes here); beyond the alphabet cum = 0xFFFF.. compares false
+  // 2^16 would be a one-symbol alphabet, which never comes here); beyond the alphabet 0xFFFFFFFF compares false.  Up to 15 bits of
+  // precision the cumulative frequency is the HIGH half: one unsigned compare of the whole word with {rem, 0xFFFF} finds the
+  // entries at or below rem, and the padding is above every such key (the hand-scheduled block below); at 16 bits the low half.
   const uint32_t nblocks = (nsym + WAVE - 1) / WAVE;
+  const bool hand = uni(P) <= 15u;
   v32u tab;
 #pragma unroll
   for (int r = 0; r < 32; ++r) {
     const uint32_t i = (uint32_t)r * WAVE + lane;
-    const uint32_t c0 = i < nsym ? gtab[i] : 0x1FFFFu, c1 = i < nsym ? gtab[i + 1] : 0x1FFFFu;      // gtab[nsym] = precision (set below)
+    const uint32_t c0 = i < nsym ? gtab[i] : 0x1FFFFu, c1 = i < nsym ? gtab[i + 1] : 0x1FFFFu;      // gtab[nsym] = precision
     // entries of zero frequency at the end of a non-compact table have cum = precision: at 16 bits that is 0x10000, whose low half
     // (0) would count for every rem -- they are padding as well (the reference's slot table, RAnsSymbolDecoder.cs:50-59, never maps to them)
-    tab[r] = (i < nsym && c0 < 0x10000u) ? (c0 | ((c1 - c0) << 16)) : 0xFFFFFFFFu;
+    tab[r] = (i < nsym && c0 < 0x10000u && !(hand && c0 >= precision)) ? (hand ? ((c0 << 16) | (c1 - c0)) : (c0 | ((c1 - c0) << 16))) : 0xFFFFFFFFu;
   }
   const uint32_t coarse = lane < nblocks ? gtab[lane * WAVE] : 0xFFFFFFFFu;     // lane l: first cumulative frequency of block l
   // 4. initial state from the stream tail
@@ -2450,6 +2453,126 @@ __global__ __launch_bounds__(WAVE) void k_symbols_wide(uint8_t *arena, const Mes
   uint32_t chunk = 0xFFFFFFFFu, W = 0;
   const uint32_t mask = precision - 1;
   uint32_t mine = 0;
+  if (hand) {
+    // The search as a hand-scheduled block in the manner of k_symbols_reg's (see there for the state / reservoir pair in s[20:21], the
+    // computed entry into 64 unrolled steps, the refill from the window W): per symbol 16 scalar + 5 vector instructions where the
+    // compiler's loop below issues 48 -- rem = x & mask; block b = count of block starts <= rem (one compare on `coarse`, s_bcnt1);
+    // the block's register fetched through the index window (v_or with the indexed src1; v15 + b names it: b is 1-based);
+    // entry = count of words <= {rem, 0xFFFF}; its word by v_readlane; x = freq (x >> P) + rem - cum on the scalar unit.
+    // Parked per position: 64 b + entry (the post-pass takes the 64 off).
+    uint64_t PR = (uint64_t)x << 32;
+    uint32_t rc = 0, dl = 0;
+    bool exhausted = false;
+    const uint32_t lb = uni(l_base), mk = uni(mask), pb = uni(P);
+    WAIT_VM0();
+    for (uint32_t i0 = 0; i0 < num_values; i0 += WAVE) {
+      const uint32_t cnt = uni(num_values - i0 < WAVE ? num_values - i0 : WAVE);
+      uint32_t j = 0;
+      while (j < cnt) {
+        if (!exhausted) {
+          {
+            uint32_t k6, rem, key, bb, q, t, jj, e, f, tmp;
+            uint32_t js = uni(j);
+            rc = uni(rc); off = uni(off); dl = uni(dl);
+            PR = ((uint64_t)uni((uint32_t)(PR >> 32)) << 32) | uni((uint32_t)PR);
+            asm volatile(
+                " s_getpc_b64 s[22:23]\n"
+                "Lwpc%=:\n"
+                " s_mul_i32 %[k6], %[j], Lws1_%=-Lws0_%=\n"
+                " s_add_u32 s22, s22, Lws0_%=-Lwpc%=\n"
+                " s_addc_u32 s23, s23, 0\n"
+                " s_add_u32 s22, s22, %[k6]\n"
+                " s_addc_u32 s23, s23, 0\n"
+                " s_set_gpr_idx_on s22, gpr_idx(SRC1)\n"
+                " s_setpc_b64 s[22:23]\n"
+                ".irp J,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63\n"
+                "Lws\\J\\()_%=:\n"
+                " s_cmp_lt_u32 s21, %[lb]\n"
+                " s_cbranch_scc1 Lwr\\J\\()_%=\n"
+                "Lwk\\J\\()_%=:\n"
+                " s_and_b32 %[rem], s21, %[mk]\n"
+                " v_cmp_le_u32_e64 vcc, %[coarse], %[rem]\n"
+                " s_pack_ll_b32_b16 %[key], 0xffff, %[rem]\n"
+                " s_lshr_b32 %[q], s21, %[pb]\n"
+                " s_bcnt1_i32_b64 %[bb], vcc\n"
+                " s_set_gpr_idx_idx %[bb]\n"
+                " s_lshl_b32 %[t], %[bb], 6\n"
+                " v_or_b32_e32 %[tmp], 0, v15\n"
+                " v_cmp_le_u32_e64 vcc, %[tmp], %[key]\n"
+                " s_bcnt1_i32_b64 %[jj], vcc\n"
+                " s_sub_u32 %[jj], %[jj], 1\n"
+                " v_readlane_b32 %[e], %[tmp], %[jj]\n"
+                " s_add_u32 %[t], %[t], %[jj]\n"
+                " v_writelane_b32 %[mine], %[t], \\J\n"
+                " s_and_b32 %[f], %[e], 0xffff\n"
+                " s_lshr_b32 %[e], %[e], 16\n"
+                " s_mul_i32 %[q], %[q], %[f]\n"
+                " s_sub_u32 %[rem], %[rem], %[e]\n"
+                " s_add_u32 s21, %[q], %[rem]\n"
+                ".endr\n"
+                " s_movk_i32 %[j], 64\n"
+                " s_branch Lwend%=\n"
+                ".irp J,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63\n"
+                "Lwr\\J\\()_%=:\n"
+                " s_sub_u32 %[rc], %[rc], 1\n"
+                " s_cbranch_scc1 Lwe\\J\\()_%=\n"
+                " s_lshl_b64 s[20:21], s[20:21], 8\n"
+                " s_cmp_lt_u32 s21, %[lb]\n"
+                " s_cbranch_scc0 Lwk\\J\\()_%=\n"
+                " s_branch Lwr\\J\\()_%=\n"
+                "Lwe\\J\\()_%=:\n"
+                " s_cmp_lt_u32 %[off], 4\n"
+                " s_cbranch_scc1 Lwl\\J\\()_%=\n"
+                " s_sub_u32 %[dl], %[dl], 1\n"
+                " s_cbranch_scc1 Lwl\\J\\()_%=\n"
+                " v_readlane_b32 s20, %[W], %[dl]\n"
+                " s_sub_u32 %[off], %[off], 4\n"
+                " s_mov_b32 %[rc], 3\n"
+                " s_lshl_b64 s[20:21], s[20:21], 8\n"
+                " s_cmp_lt_u32 s21, %[lb]\n"
+                " s_cbranch_scc0 Lwk\\J\\()_%=\n"
+                " s_branch Lwr\\J\\()_%=\n"
+                "Lwl\\J\\()_%=:\n"
+                " s_movk_i32 %[j], \\J\n"
+                " s_branch Lwempty%=\n"
+                ".endr\n"
+                "Lwempty%=:\n"
+                " s_mov_b32 %[rc], 0\n"
+                "Lwend%=:\n"
+                " s_set_gpr_idx_off\n"
+                : "+{s[20:21]}"(PR), [rc] "+s"(rc), [j] "+s"(js), [mine] "+v"(mine), [k6] "=&s"(k6), [rem] "=&s"(rem), [key] "=&s"(key), [bb] "=&s"(bb),
+                  [q] "=&s"(q), [t] "=&s"(t), [jj] "=&s"(jj), [e] "=&s"(e), [f] "=&s"(f), [tmp] "=&v"(tmp), [off] "+s"(off), [dl] "+s"(dl)
+                : "{v[16:47]}"(tab), [W] "v"(W), [coarse] "v"(coarse), [lb] "s"(lb), [mk] "s"(mk), [pb] "s"(pb)
+                : "vcc", "scc", "s22", "s23");
+            j = js;
+          }
+          if (j < cnt) {                         // the state needs a byte and the reservoir is empty
+            if (off == 0) exhausted = true;      // RAnsDecoder.cs:58-61: no bytes left, the state stays as it is
+            else {
+              const uint32_t end = off + mis;    // one past the next byte, in abuf coordinates
+              const uint32_t d = (end - 1) >> 2, r = end - 4 * d, ch = d >> 6;
+              if (ch != chunk) { chunk = ch; W = abuf[(size_t)ch * 64 + lane]; WAIT_VM0(); }
+              const uint32_t res = uni(rdlane(W, d & 63u) << (8 * (4 - r)));
+              rc = uni(r < off ? r : off);
+              off -= rc;
+              dl = uni(d & 63u);
+              PR = (PR & 0xFFFFFFFF00000000ull) | res;
+            }
+          }
+        } else {
+          const uint32_t xs = uni((uint32_t)(PR >> 32)), rem = xs & mk;
+          const uint32_t b = uni((uint32_t)__popcll(__ballot(coarse <= rem)) - 1u);
+          const uint32_t v = tab[b];
+          const uint32_t jx = uni((uint32_t)__popcll(__ballot(v <= ((rem << 16) | 0xFFFFu))) - 1u);
+          const uint32_t e = rdlane(v, jx);
+          mine = (lane == j) ? (b + 1u) * WAVE + jx : mine;
+          PR = (uint64_t)uni((e & 0xFFFFu) * (xs >> pb) + rem - (e >> 16)) << 32;
+          ++j;
+        }
+      }
+      if (lane < cnt) out[i0 + lane] = mine - WAVE;
+    }
+  } else {
   uint32_t res = 0, rc = 0;               // up to four bytes of the stream, the next one in the top bits (RAnsDecoder.cs:56-67 reads them one by one)
   for (uint32_t i = 0; i < num_values; ++i) {
     while (x < l_base) {
@@ -2478,6 +2601,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols_wide(uint8_t *arena, const Mes
   }
   const uint32_t tail = num_values & 63u;
   if (tail && lane < tail) out[num_values - tail + lane] = mine;
+  }
   WAIT_VM0();
   __threadfence_block();
   __syncthreads();
