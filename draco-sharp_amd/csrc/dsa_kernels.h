@@ -2455,8 +2455,8 @@ __global__ __launch_bounds__(WAVE) void k_symbols_wide(uint8_t *arena, const Mes
   uint32_t mine = 0;
   if (hand) {
     // The search as a hand-scheduled block in the manner of k_symbols_reg's (see there for the state / reservoir pair in s[20:21], the
-    // computed entry into 64 unrolled steps, the refill from the window W): per symbol 16 scalar + 5 vector instructions where the
-    // compiler's loop below issues 48 -- rem = x & mask; block b = count of block starts <= rem (one compare on `coarse`, s_bcnt1);
+    // computed entry into 64 unrolled steps, the refill from the window W): per symbol 17 scalar + 5 vector instructions (10 for the
+    // most frequent symbol, see below) where the compiler's loop below issues 48 -- rem = x & mask; block b = count of block starts <= rem (one compare on `coarse`, s_bcnt1);
     // the block's register fetched through the index window (v_or with the indexed src1; v15 + b names it: b is 1-based);
     // entry = count of words <= {rem, 0xFFFF}; its word by v_readlane; x = freq (x >> P) + rem - cum on the scalar unit.
     // Parked per position: 64 b + entry (the post-pass takes the 64 off).
@@ -2464,6 +2464,17 @@ __global__ __launch_bounds__(WAVE) void k_symbols_wide(uint8_t *arena, const Mes
     uint32_t rc = 0, dl = 0;
     bool exhausted = false;
     const uint32_t lb = uni(l_base), mk = uni(mask), pb = uni(P);
+    // the most frequent symbol is tried first, on the scalar unit alone (x = freq (x >> P) + rem - cum if rem - cum < freq: 10
+    // instructions with the renormalisation test) -- two thirds of the corrections of 14-bit positions are one symbol
+    uint32_t best = 0;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const uint32_t w = tab[r], k = w == 0xFFFFFFFFu ? 0u : (((w & 0xFFFFu) << 11) | (uint32_t)(31 - r) << 6 | (63u - lane));
+      best = k > best ? k : best;
+    }
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)best, d, WAVE); best = o > best ? o : best; }
+    const uint32_t idom = uni((31u - ((best >> 6) & 31u)) * WAVE + (63u - (best & 63u)));
+    const uint32_t fdom = uni(best >> 11), cdom = uni(gtab[idom]), tdom = uni(idom + WAVE);
     WAIT_VM0();
     for (uint32_t i0 = 0; i0 < num_values; i0 += WAVE) {
       const uint32_t cnt = uni(num_values - i0 < WAVE ? num_values - i0 : WAVE);
@@ -2491,6 +2502,19 @@ __global__ __launch_bounds__(WAVE) void k_symbols_wide(uint8_t *arena, const Mes
                 " s_cbranch_scc1 Lwr\\J\\()_%=\n"
                 "Lwk\\J\\()_%=:\n"
                 " s_and_b32 %[rem], s21, %[mk]\n"
+                " s_sub_u32 %[e], %[rem], %[cdom]\n"
+                " s_cmp_lt_u32 %[e], %[fdom]\n"
+                " s_cbranch_scc0 Lwq\\J\\()_%=\n"
+                " s_lshr_b32 %[q], s21, %[pb]\n"
+                " s_mul_i32 %[q], %[q], %[fdom]\n"
+                " v_writelane_b32 %[mine], %[tdom], \\J\n"
+                " s_add_u32 s21, %[q], %[e]\n"
+                "Lwn\\J\\()_%=:\n"
+                ".endr\n"
+                " s_movk_i32 %[j], 64\n"
+                " s_branch Lwend%=\n"
+                ".irp J,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63\n"
+                "Lwq\\J\\()_%=:\n"
                 " v_cmp_le_u32_e64 vcc, %[coarse], %[rem]\n"
                 " s_pack_ll_b32_b16 %[key], 0xffff, %[rem]\n"
                 " s_lshr_b32 %[q], s21, %[pb]\n"
@@ -2509,9 +2533,8 @@ __global__ __launch_bounds__(WAVE) void k_symbols_wide(uint8_t *arena, const Mes
                 " s_mul_i32 %[q], %[q], %[f]\n"
                 " s_sub_u32 %[rem], %[rem], %[e]\n"
                 " s_add_u32 s21, %[q], %[rem]\n"
+                " s_branch Lwn\\J\\()_%=\n"
                 ".endr\n"
-                " s_movk_i32 %[j], 64\n"
-                " s_branch Lwend%=\n"
                 ".irp J,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63\n"
                 "Lwr\\J\\()_%=:\n"
                 " s_sub_u32 %[rc], %[rc], 1\n"
@@ -2542,7 +2565,7 @@ __global__ __launch_bounds__(WAVE) void k_symbols_wide(uint8_t *arena, const Mes
                 " s_set_gpr_idx_off\n"
                 : "+{s[20:21]}"(PR), [rc] "+s"(rc), [j] "+s"(js), [mine] "+v"(mine), [k6] "=&s"(k6), [rem] "=&s"(rem), [key] "=&s"(key), [bb] "=&s"(bb),
                   [q] "=&s"(q), [t] "=&s"(t), [jj] "=&s"(jj), [e] "=&s"(e), [f] "=&s"(f), [tmp] "=&v"(tmp), [off] "+s"(off), [dl] "+s"(dl)
-                : "{v[16:47]}"(tab), [W] "v"(W), [coarse] "v"(coarse), [lb] "s"(lb), [mk] "s"(mk), [pb] "s"(pb)
+                : "{v[16:47]}"(tab), [W] "v"(W), [coarse] "v"(coarse), [lb] "s"(lb), [mk] "s"(mk), [pb] "s"(pb), [cdom] "s"(cdom), [fdom] "s"(fdom), [tdom] "s"(tdom)
                 : "vcc", "scc", "s22", "s23");
             j = js;
           }

@@ -1,6 +1,6 @@
 """Encode direction: N of the bench meshes through dsa_encode_batch, with the connectivity on the device (default) and on the
 host cores (DSA_ENC_HOST_CONN=1 in the environment).  usage: python tools/encode_timing.py [meshes ...]"""
-import sys, time; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import sys, time; import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
 counts = [int(x) for x in sys.argv[1:]] or [128, 512]
 ctx = dsa.Context(0)

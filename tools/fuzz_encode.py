@@ -1,7 +1,7 @@
 """Damaged meshes (flipped, rewired, duplicated, missing faces; random face soups) through dsa_encode_batch with the connectivity on the
 device and on the host: the same meshes must be coded (to the same bytes) and the same refused.  usage: python tools/fuzz_encode.py [count]"""
 import os, sys
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 rng = np.random.default_rng(11)

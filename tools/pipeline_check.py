@@ -2,7 +2,7 @@
 (entropy decode, connectivity) overlaps the tail of the previous one (prediction, finalisation).
 usage: python tools/pipeline_check.py [meshes] [in_flight ...]"""
 import sys, time
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 import draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
 

@@ -2,7 +2,7 @@
 scheme, prediction schemes, attribute order, Edgebreaker symbol coding, single / per-attribute connectivity) decoded
 in one batch and compared with the oracle.  usage: python tools/soak.py [count] [seed]"""
 import sys
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import oracle
 import draco_sharp_amd as dsa, draco_sharp_amd.synth as synth

@@ -1,7 +1,7 @@
 """Randomised differential run on larger meshes (6k-70k triangles, fast-path options): long symbol streams with
 many reservoir refills and window reloads at arbitrary alignments.  usage: python tools/soak_big.py [seed]"""
 import sys
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tools')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, 'tools')
 import numpy as np, oracle, draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 5)
 cases = []

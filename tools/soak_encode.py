@@ -3,7 +3,7 @@ connectivity and the symbol plans forced onto the device, byte for byte against 
 usage: python tools/soak_encode.py [count] [seed]"""
 import os, sys
 os.environ["DSA_ENC_HOST_CONN"] = "0"; os.environ["DSA_ENC_HOST_PLAN"] = "0"
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)

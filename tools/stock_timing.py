@@ -2,7 +2,7 @@
 parallelogram positions, GeometricNormal normals (UVs stay on the parallelogram: TexCoordsPortable needs the general path).
 Step time and which kernels decoded the meshes; a sample compared with the oracle.
 usage: python tools/stock_timing.py [meshes] [with_uv 0|1]"""
-import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import sys; import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import time
 import numpy as np, draco_sharp_amd as dsa, draco_sharp_amd.synth as synth, oracle
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

@@ -1,5 +1,5 @@
 """Attempt-by-attempt trace of the traversal of one bench mesh from a -DDSA_TRAV_TRACE build (DSA_LIB=build_abl/lib_trace.so)."""
-import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import sys; import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
 blob, offs = synth.make_batch(synth.GRID, 128, 256, 1000, 4)
 ctx = dsa.Context(0)

@@ -1,6 +1,6 @@
 """The bench batch re-encoded with valence Edgebreaker symbols (predictive_connectivity=2, what stock encoders write for larger
 meshes): step time on the fast kernels, every mesh compared... no: a sample compared with the oracle.  usage: python tools/valence_timing.py [meshes]"""
-import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import sys; import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import time
 import numpy as np, draco_sharp_amd as dsa, draco_sharp_amd.synth as synth, oracle
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

@@ -1,6 +1,6 @@
 """Step time of the bench batch under other encoder settings (diagnostics): python tools/variant_timing.py [meshes]
 Rows of profiles/README.md "Other precisions and symbol schemes"."""
-import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import sys; import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 only = sys.argv[2] if len(sys.argv) > 2 else ""

@@ -1,6 +1,6 @@
 """When the traversal / connectivity wave of every mesh of a batch started and how long it ran (s_memrealtime stamps, 100 MHz),
 against the kernel's duration: shows dispatch rounds and stragglers.  usage: python tools/wave_times.py [meshes]"""
-import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import sys; import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 blob, offs = synth.make_batch(synth.GRID, 128, 256, 1000, n)
