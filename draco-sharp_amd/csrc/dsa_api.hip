@@ -88,6 +88,7 @@ struct StreamSet {
   hipEvent_t ev_join3 = nullptr, ev_trav = nullptr, ev_maps = nullptr, ev_early = nullptr, ev_flips = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_conn = nullptr;
   hipEvent_t ev_seambits = nullptr, ev_tables = nullptr, ev_att = nullptr;      // fast seam path: seam bits decoded, seam tables built, attribute traversals done
+  hipEvent_t ev_pred = nullptr;                                                 // fast seam path: corrections of the attributes in front of the seam tables ready
   bool own_stream = false;
   hipError_t create(hipStream_t user, int least, int greatest) {
     // Dispatch priorities (numerically lower = higher): the stream of the per-mesh chain above the stream of the early attributes
@@ -101,12 +102,12 @@ struct StreamSet {
     // (low priority, beside stream2: the streams of one priority class share four hardware queues, and the default class already
     // holds stream3, stream4 and the two copy streams -- a fifth there waits behind one of them)
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&stream5, hipStreamNonBlocking, least);
-    for (hipEvent_t *ev : {&ev_join3, &ev_trav, &ev_maps, &ev_flips, &ev_early, &ev_fork, &ev_join, &ev_conn, &ev_seambits, &ev_tables, &ev_att})
+    for (hipEvent_t *ev : {&ev_join3, &ev_trav, &ev_maps, &ev_flips, &ev_early, &ev_fork, &ev_join, &ev_conn, &ev_seambits, &ev_tables, &ev_att, &ev_pred})
       if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
     return e;
   }
   void destroy() {
-    for (hipEvent_t *ev : {&ev_join3, &ev_trav, &ev_maps, &ev_flips, &ev_early, &ev_fork, &ev_join, &ev_conn, &ev_seambits, &ev_tables, &ev_att}) { if (*ev) (void)hipEventDestroy(*ev); *ev = nullptr; }
+    for (hipEvent_t *ev : {&ev_join3, &ev_trav, &ev_maps, &ev_flips, &ev_early, &ev_fork, &ev_join, &ev_conn, &ev_seambits, &ev_tables, &ev_att, &ev_pred}) { if (*ev) (void)hipEventDestroy(*ev); *ev = nullptr; }
     for (hipStream_t *s : {&stream2, &stream3, &stream4, &stream5}) { if (*s) (void)hipStreamDestroy(*s); *s = nullptr; }
     if (own_stream && stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
@@ -691,6 +692,16 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     if (e == hipSuccess) e = hipEventRecord(S.ev_maps, st3);
     return e;
   };
+  // (k_seam_maps, 5 - 7 ms, was also measured behind k_texcoords_prepare -- beside the chain of the texture coordinates -- and in
+  // front of the GeometricNormal kernels: within 2 ms of this placement either way, better for one dialect and worse for another)
+  auto launch_seam_maps = [&]() -> hipError_t {
+    hipError_t e = hipEventRecord(S.ev_seambits, st);       // (the event is free by now: the position traversal is queued)
+    if (e == hipSuccess) e = hipStreamWaitEvent(st3, S.ev_seambits, 0);
+    const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
+    hipLaunchKernelGGL(dsa::k_seam_maps, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
+    if (e == hipSuccess) e = hipEventRecord(S.ev_maps, st3);
+    return e;
+  };
   const bool chain_launched = chain;
   if (chain) {
     HIP_TRY(ctx, mark());                              // the connectivity stage has no time of its own
@@ -737,6 +748,8 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     }
     HIP_TRY(ctx, mark());
     const uint32_t per = (n + (uint32_t)trav_split - 1) / (uint32_t)trav_split;
+    // (seamed batches: the position traversal at low issue priority beside k_seam_tables measured no different, and started behind
+    // the tables it halves them (31 -> 18 ms) but runs beside the attribute traversals, 30 + 33 ms instead of 24 + 28: 1 - 2 ms)
     k_begin(KT_TRAVERSE, st);
     for (uint32_t m0 = 0; m0 < n; m0 += per) {
       const uint32_t cnt = std::min(per, n - m0);
@@ -746,11 +759,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     if (b->any_seamed) {
       // point -> entry maps of the meshes with corner attributes, from the corners: behind both kinds of traversal, on the third
       // stream beside the late prediction (k_seal waits for ev_maps)
-      HIP_TRY(ctx, hipEventRecord(S.ev_seambits, st));       // (the event is free by now: the position traversal is queued)
-      HIP_TRY(ctx, hipStreamWaitEvent(st3, S.ev_seambits, 0));
-      const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_faces + 16383) / 16384, 4));
-      hipLaunchKernelGGL(dsa::k_seam_maps, dim3(gx, n), dim3(256), 0, st3, b->arena, b->d_layouts, b->d_descs, n);
-      HIP_TRY(ctx, hipEventRecord(S.ev_maps, st3));
+      HIP_TRY(ctx, launch_seam_maps());
     }
   }
   HIP_TRY(ctx, mark());
@@ -827,6 +836,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     launch_symbols(st2, lane_flags | SYM_LATE_ONLY);
   } else launch_symbols(st2, lane_flags | early_fuse);
   if (b->any_seamed) {       // the symbols of corner attributes: their entry counts are k_seam_tables'
+    HIP_TRY(ctx, hipEventRecord(S.ev_pred, st2));           // (the corrections of everything else are ready)
     HIP_TRY(ctx, hipStreamWaitEvent(st2, S.ev_tables, 0));
     launch_symbols(st2, lane_flags | SYM_CORNER);
   }
@@ -872,6 +882,21 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_para_operands, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   }
   HIP_TRY(ctx, mark());
+  bool positions_by_vertex = false;
+  if (b->any_seamed && !(lane_flags & LN_FLAG_PREDICT)) {
+    // A batch with corner attributes: the attributes on the position connectivity are predicted behind the position traversal,
+    // while the seam tables and the attribute traversals (20 - 30 ms more) are still under way -- what comes behind those then
+    // finds the positions final (the TexCoordsPortable and GeometricNormal predictors read them)
+    HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_pred, 0));
+    if (lane_flags & PW_FLAG) hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags | PRED_FRONT);
+    hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags | PRED_FRONT);
+    HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_early, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_tables, 0));        // (which attributes are GeometricNormal: the walk of a mesh may end behind the tables)
+    const uint32_t gv = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 1023) / 1024, 64));
+    hipLaunchKernelGGL(dsa::k_vertex_positions, dim3(gv, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+    positions_by_vertex = true;
+  }
+  const uint32_t behind = positions_by_vertex ? PRED_BEHIND : 0u;
   HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_join, 0));   // join: corrections are ready
   if (b->any_seamed) HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_att, 0));      // join: orders and operands of the seamed attributes
   if (b->any_general) HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_join3, 0));   // join: the general path's integers are ready
@@ -883,10 +908,10 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   {
     if (lane_flags & PW_FLAG) {
       k_begin(KT_PREDICT_WRAP_LATE, st);
-      hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags);
+      hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags | behind);
       k_end(KT_PREDICT_WRAP_LATE, st);
     }
-    hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags);
+    hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags | behind);
   }
   HIP_TRY(ctx, mark());
   {
@@ -895,7 +920,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_flips, 0));
     const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 1023) / 1024, 32));     // four entries per thread: 11.6 -> 9.7 ms against sixteen
     const uint32_t gv = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 1023) / 1024, 64));     // two dependent gathers per vertex: many short threads
-    hipLaunchKernelGGL(dsa::k_vertex_positions, dim3(gv, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+    if (!positions_by_vertex) hipLaunchKernelGGL(dsa::k_vertex_positions, dim3(gv, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_predict_geometric, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     // TexCoordsPortable attributes: what depends on the mesh and the positions for every entry at once, then the chain over the
     // decoded texture coordinates, one lane per attribute

@@ -64,8 +64,15 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uin
 #define SYM_EARLY_ONLY 0x100u
 #define SYM_LATE_ONLY 0x200u
 #define SYM_CORNER 0x1000u     // the launch for corner attributes (behind k_seam_tables, which counts their entries); every other launch skips them
+// late prediction of a batch with corner attributes, in two launches: what only waits for the position traversal / what waits for
+// the seam tables and the attribute traversals as well
+#define PRED_FRONT 0x10000u
+#define PRED_BEHIND 0x20000u
 __device__ __forceinline__ bool att_behind_tables(const AttrDesc &a) { return a.corner_data != 0 || a.late_located != 0; }
 __device__ __forceinline__ bool att_is_late(const AttrDesc &a) { return (a.have_scheme && a.pred_kind != 0) || att_behind_tables(a); }
+__device__ __forceinline__ bool pred_filtered(const AttrDesc &a, uint32_t flags) {
+  return ((flags & PRED_FRONT) && att_behind_tables(a)) || ((flags & PRED_BEHIND) && !att_behind_tables(a));
+}
 __device__ __forceinline__ bool sym_filtered(const AttrDesc &a, uint32_t flags) {
   if (att_behind_tables(a)) return !(flags & SYM_CORNER);
   if (flags & SYM_CORNER) return true;
@@ -2760,7 +2767,7 @@ __device__ __forceinline__ void predict_wave(uint8_t *arena, const MeshLayout &L
   if (lanes::ln_oct_eligible(a, flags)) return;          // k_predict_oct_lanes
   if ((flags & OS_FLAG) && oct_stream_eligible(a)) return;   // k_predict_oct_streams
   if (a.pred_kind == 2 || a.pred_kind == 3) return;            // k_predict_geometric, k_texcoords
-  if (att_is_late(a) != (phase == 1)) return;
+  if (att_is_late(a) != (phase == 1) || pred_filtered(a, flags)) return;
   int32_t *w = (int32_t *)(arena + L.work[ai]);
   const uint32_t nc = a.nc_portable, entries = a.num_entries;
   const uint32_t lane = lane_id();
@@ -3212,7 +3219,7 @@ __device__ __forceinline__ void predict_wrap_wave(int32_t *w, const uint32_t *pa
 
 __device__ __forceinline__ void predict_wrap_attribute(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t phase, uint32_t flags) {
   const AttrDesc &a = D->att[ai];
-  if (!wrap_fast_ok(a, flags) || att_is_late(a) != (phase == 1)) return;
+  if (!wrap_fast_ok(a, flags) || att_is_late(a) != (phase == 1) || pred_filtered(a, flags)) return;
   int32_t *w = (int32_t *)(arena + L.work[ai]);
   const uint32_t *para = att_para(arena, L, D, a);
   const uint32_t e = a.num_entries, nc = a.nc_portable;
