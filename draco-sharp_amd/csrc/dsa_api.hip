@@ -624,7 +624,9 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   static const uint32_t wide_flag = env_int("DSA_SYM_WIDE", 1) ? SYM_WIDE : 0u;
   static const bool early_fuse_on = env_int("DSA_EARLY_FUSE", 0) != 0;
   static const uint32_t oct_lpw = (uint32_t)env_int("DSA_OCT_LPW", 16);
+  static const bool handoff_on = env_int("DSA_LATE_HANDOFF", 0) != 0;
 #else
+  const bool handoff_on = false;      // measured: 40.0 - 40.9 -> 44.5 ms (profiles/README.md)
   const int fuse_choice = -1, chain_choice = -1, trav_split = 1, split_mode = 1;
   const uint32_t lane_flags = PW_FLAG, wide_flag = SYM_WIDE;
   const bool run_window = true, early_fuse_on = false;
@@ -675,7 +677,10 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // parallelogram operands: by the traversal waves themselves when the batch keeps the machine busy anyway, by an
   // element-parallel kernel behind the traversal when it does not
   const bool fuse_operands = fuse_choice >= 0 ? fuse_choice != 0 : n >= 2048;
-  const uint32_t trav_flags = (fuse_operands ? 1u : 0u) | (run_window ? 2u : 0u);   // bit 1: adaptive run window
+  // late attributes predicted by the second of their producers to finish (dsa_kernels.h: late_handoff) -- with the operands written
+  // by the traversal waves, on the wave-per-mesh kernels, corrections and order on one connectivity
+  const bool handoff = fuse_operands && !serial && (lane_flags & PW_FLAG) && !(lane_flags & (LN_FLAG_SYMBOLS | LN_FLAG_PREDICT)) && !b->any_seamed && handoff_on;
+  const uint32_t trav_flags = (fuse_operands ? 1u : 0u) | (run_window ? 2u : 0u) | (handoff ? 8u : 0u);   // bit 1: adaptive run window
   // connectivity and traversal of a mesh by one wave (k_chain) unless DSA_CHAIN=0 asks for the two kernels: as two kernels,
   // the slots the connectivity waves leave go to waiting entropy-decode waves and most traversal waves start late
   // (a small batch leaves slots free anyway, and is quicker with the faces converted beside the traversal)
@@ -813,11 +818,12 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   // dequantises it -- the octahedral prediction leaves the tail (7.5 -> 4.7 ms) but its waves keep 80-register slots twice as
   // long and the late symbols end 4.7 ms later
   const uint32_t early_fuse = early_fuse_on && !(lane_flags & (LN_FLAG_PREDICT | LN_FLAG_OCT)) ? SYM_EARLY_FUSE : 0u;
+  const uint32_t hand = handoff ? LATE_HANDOFF : 0u;
   if (sym_split && split_mode == 2) {          // early attributes first, then the late ones beside the early prediction
     launch_symbols(st2, lane_flags | SYM_EARLY_ONLY | early_fuse);
     HIP_TRY(ctx, hipEventRecord(S.ev_conn, st2));
     HIP_TRY(ctx, hipStreamWaitEvent(st4, S.ev_conn, 0));
-    launch_symbols(st2, lane_flags | SYM_LATE_ONLY);
+    launch_symbols(st2, lane_flags | SYM_LATE_ONLY | hand);
   } else if (sym_split && oct_flag) {
     // The early attributes have the longer tail behind their symbols when the octahedral delta runs one lane per stream (a
     // chain of 10 - 14 ms), so they get a head start: the late attributes' 12-bit kernel stands behind k_register_gate, idle
@@ -829,12 +835,12 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     // Until the registers of the 16 KB tier were put right its idle waves did this by accident.)
     HIP_TRY(ctx, hipStreamWaitEvent(st4, S.ev_conn, 0));
     launch_symbols(st4, lane_flags | SYM_EARLY_ONLY | early_fuse);
-    launch_symbols(st2, lane_flags | SYM_LATE_ONLY, ctx->gate_ok);
+    launch_symbols(st2, lane_flags | SYM_LATE_ONLY | hand, ctx->gate_ok);
   } else if (sym_split) {                      // both at once, the early ones on the stream with priority
     HIP_TRY(ctx, hipStreamWaitEvent(st4, S.ev_conn, 0));
     launch_symbols(st4, lane_flags | SYM_EARLY_ONLY | early_fuse);
-    launch_symbols(st2, lane_flags | SYM_LATE_ONLY);
-  } else launch_symbols(st2, lane_flags | early_fuse);
+    launch_symbols(st2, lane_flags | SYM_LATE_ONLY | hand);
+  } else launch_symbols(st2, lane_flags | early_fuse | hand);
   if (b->any_seamed) {       // the symbols of corner attributes: their entry counts are k_seam_tables'
     HIP_TRY(ctx, hipEventRecord(S.ev_pred, st2));           // (the corrections of everything else are ready)
     HIP_TRY(ctx, hipStreamWaitEvent(st2, S.ev_tables, 0));

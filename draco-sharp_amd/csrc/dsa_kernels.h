@@ -70,6 +70,9 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uin
 #define PRED_BEHIND 0x20000u
 __device__ __forceinline__ bool att_behind_tables(const AttrDesc &a) { return a.corner_data != 0 || a.late_located != 0; }
 __device__ __forceinline__ bool att_is_late(const AttrDesc &a) { return (a.have_scheme && a.pred_kind != 0) || att_behind_tables(a); }
+#define PW_FLAG 4u             // DSA_LANES bit 2: wrap schemes by k_predict_wrap (default on)
+#define LATE_HANDOFF 0x40000u  // late attributes are predicted by the second of their two producers to finish (late_handoff below)
+__device__ __forceinline__ void late_handoff(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t flags, uint32_t bit);
 __device__ __forceinline__ bool pred_filtered(const AttrDesc &a, uint32_t flags) {
   return ((flags & PRED_FRONT) && att_behind_tables(a)) || ((flags & PRED_BEHIND) && !att_behind_tables(a));
 }
@@ -1872,6 +1875,10 @@ __global__ __launch_bounds__(WAVE, 8) void k_chain(uint8_t *arena, const MeshLay
   const TravIO io = trav_position(arena, L, D);
   if (compact) traverse_wave<true>(arena, L, D, io, fuse_operands, sh_tf, sh_tv, sh_hist);
   else traverse_wave<false>(arena, L, D, io, fuse_operands, sh_tf, sh_tv, sh_hist);
+  if ((fuse_operands & 1u) && (fuse_operands & 8u) && status_of(D) == ST_OK) {      // bit 3: late_handoff (with the operands written by this wave)
+    const uint32_t na = uni(D->num_attributes);
+    for (uint32_t ai = 0; ai < na && ai < DSA_MAX_ATT; ++ai) late_handoff(arena, L, D, ai, PW_FLAG | LATE_HANDOFF, 2u);
+  }
 }
 
 
@@ -2044,6 +2051,31 @@ __device__ __forceinline__ void early_tail(uint8_t *arena, const MeshLayout &L, 
   if (status_of(D) != ST_OK) return;
   finalize_attribute(arena, L, D, ai, 0u, flags, lane_id(), WAVE);
   if (lane_id() == 0) D->att[ai].early_done = 1;
+}
+
+// Late attributes of a crowded batch (parallelogram on the position connectivity) are predicted by whichever of their two producers
+// finishes second -- the wave that decoded the corrections or the wave that traversed the mesh -- instead of by a kernel behind
+// both launches: the prediction of a mesh then starts when ITS inputs are there (the position streams are decoded ten milliseconds
+// before the traversals end; the traversals end three before the last texture-coordinate streams), in the shadow of the other
+// meshes' work, and the k_predict_wrap launch behind everything finds little left.  `bit`: 1 = corrections, 2 = order and operands.
+// Release / acquire at agent scope around the flag: the two waves may sit on different XCDs (an L2 each).
+__device__ __forceinline__ bool wrap_fast_ok(const AttrDesc &a, uint32_t flags);
+__device__ __forceinline__ void late_handoff(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t flags, uint32_t bit) {
+  if (!(flags & LATE_HANDOFF) || D->general) return;
+  AttrDesc &a = D->att[ai];
+  if (!wrap_fast_ok(a, flags) || !att_is_late(a) || att_behind_tables(a) || a.pred_kind != 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  uint32_t old = 0;
+  if (lane_id() == 0) old = __hip_atomic_fetch_or(&a.late_ready, bit, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  old = uni(old);
+  if (!(old & (3u ^ bit))) return;                   // the other wave will find this one's bit
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (status_of(D) != ST_OK) return;
+  predict_wrap_attribute(arena, L, D, ai, 1u, flags);
+  WAIT_VM0();
+  __syncthreads();
+  if (lane_id() == 0) a.late_ready = 7u;
 }
 
 // The decoder serves three kinds of 12-bit-precision streams (MODE):
@@ -2316,6 +2348,7 @@ __device__ __forceinline__ void reg_decode_stream(uint8_t *arena, const MeshLayo
     out[i] = positive ? v : ((v & 1u) ? (uint32_t)(-(int32_t)(v >> 1) - 1) : (v >> 1));
   }
   early_tail(arena, L, D, ai, flags);
+  late_handoff(arena, L, D, ai, flags, 1u);
 }
 
 __global__ __launch_bounds__(WAVE, 6) void k_symbols_reg(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t flags) {
@@ -3097,7 +3130,6 @@ __global__ __launch_bounds__(WAVE, 8) void k_predict_oct_streams(uint8_t *arena,
 // finished entries, lanes 1.. join while their prediction is "previous entry + (finished - finished)", every lane
 // re-evaluates the sequential step from its neighbour's value and the run is cut at the first disagreement.
 // =========================================================================
-#define PW_FLAG 4u    // DSA_LANES bit 2: wrap schemes by k_predict_wrap (default on)
 __device__ __forceinline__ bool pw_dequant_fused(const AttrDesc &a, uint32_t flags) {
   return wrap_fast_ok(a, flags) && a.seq_type == 2 && a.nc == a.nc_portable && a.q_bits >= 1 && a.q_bits <= 30;
 }
@@ -3142,7 +3174,11 @@ __device__ __forceinline__ void predict_wrap_wave(int32_t *w, const uint32_t *pa
     // prediction = base + (o[ga] - o[gb]); a delta entry takes o[0] - o[0]
     uint32_t ga = is_delta ? 0u : (n_prev ? ep : en), gb = is_delta ? 0u : eo;
     const bool near_prev = is_delta || n_prev || p_prev;
-    bool chain = live && near_prev && (is_delta || (ga < p0 && gb < p0));
+    // "zig-zag" entries -- a strip both of whose rows are new: prediction = o[p-1] + o[p-2] - o[p-3], every operand inside the run.
+    // In first differences e[p] = o[p] - o[p-1] that is e[p] = e[p-2] + corr: a segmented scan over the lanes of one parity
+    // (the other lanes, whose differences are known from finished entries, are its segment heads), then the sum as before.
+    const bool zig = PARA && live && !is_delta && (n_prev || p_prev) && lane >= 2 && pc >= 3 && ga == pc - 2 && gb == pc - 3;
+    bool chain = live && near_prev && (is_delta || (ga < p0 && gb < p0) || zig);
     // lane 0 whose parallelogram is made of three older entries: base = o[next], g = o[prev] - o[opposite]
     const bool far0 = lane == 0 && !near_prev;
     if (far0) { ga = ep; gb = eo; }
@@ -3160,9 +3196,10 @@ __device__ __forceinline__ void predict_wrap_wave(int32_t *w, const uint32_t *pa
     }
     int32_t g[NC], o[NC];
     bool irregular = false;
+    const bool any_zig = PARA && (__ballot(zig && lane < run) != 0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      g[c] = (int32_t)((uint32_t)va.v[c] - (uint32_t)vb.v[c]);
+      g[c] = zig ? 0 : (int32_t)((uint32_t)va.v[c] - (uint32_t)vb.v[c]);      // (a zig-zag lane loaded entries that are not final: its g follows below)
       // lane 0: the reference's step from finished entries, exact whatever happens to the rest of the run
       const int32_t o0 = wrap_original((int32_t)((uint32_t)base[c] + (uint32_t)g[c]), corr.v[c], mn, mx, max_dif);
       const uint32_t x0 = (uint32_t)o0 - (uint32_t)mn;
@@ -3172,6 +3209,22 @@ __device__ __forceinline__ void predict_wrap_wave(int32_t *w, const uint32_t *pa
       uint32_t r = t - (uint32_t)((float)t * inv_m) * M;
       r = (int32_t)r < 0 ? r + M : r;
       r = r >= M ? r - M : r;
+      if (any_zig) {                               // wave-uniform: most steps have no such lane
+        // lane 0's difference from the entry before the run; zig-zag lanes add the difference two lanes below to their correction
+        uint32_t e0 = x0 + M - (uint32_t)(last[c] - mn);
+        e0 = e0 >= M ? e0 - M : e0;
+        uint32_t pk = (lane == 0 ? e0 : r) | (zig ? 0u : 0x80000000u);      // value (< M <= 2^25; 32 of them stay below 2^31) | segment head
+#pragma unroll
+        for (int d = 2; d <= 32; d <<= 1) {
+          const uint32_t pv = (uint32_t)__shfl_up((int)pk, d, WAVE);
+          if (lane >= (uint32_t)d && !(pk >> 31)) pk = (pk + (pv & 0x7FFFFFFFu)) | (pv & 0x80000000u);
+        }
+        const uint32_t e = pk & 0x7FFFFFFFu;
+        uint32_t er = e - (uint32_t)((float)e * inv_m) * M;
+        er = (int32_t)er < 0 ? er + M : er;
+        er = er >= M ? er - M : er;
+        r = zig ? er : r;
+      }
       uint32_t x = lane == 0 ? x0 : r;
       irregular = irregular || (lane == 0 ? x0 >= M : wild);
       o[c] = o0;
@@ -3190,6 +3243,15 @@ __device__ __forceinline__ void predict_wrap_wave(int32_t *w, const uint32_t *pa
     }
     // every lane re-evaluates the sequential step from its neighbour's value (the sums above included lanes that the
     // irregular cut has just dropped: their successors fail here, as they must)
+    if (any_zig) {                                 // what a zig-zag lane's parallelogram really is, from the candidates two and three lanes below
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int32_t o2 = __shfl_up(o[c], 2, WAVE);
+        int32_t o3 = __shfl_up(o[c], 3, WAVE);
+        o3 = lane == 2 ? last[c] : o3;
+        if (zig) g[c] = (int32_t)((uint32_t)o2 - (uint32_t)o3);
+      }
+    }
     bool good = true;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -3220,6 +3282,7 @@ __device__ __forceinline__ void predict_wrap_wave(int32_t *w, const uint32_t *pa
 __device__ __forceinline__ void predict_wrap_attribute(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t phase, uint32_t flags) {
   const AttrDesc &a = D->att[ai];
   if (!wrap_fast_ok(a, flags) || att_is_late(a) != (phase == 1) || pred_filtered(a, flags)) return;
+  if (phase == 1 && (flags & LATE_HANDOFF) == 0 && (a.late_ready & 4u)) return;        // (the kernel's launch: predicted by one of its producers already)
   int32_t *w = (int32_t *)(arena + L.work[ai]);
   const uint32_t *para = att_para(arena, L, D, a);
   const uint32_t e = a.num_entries, nc = a.nc_portable;

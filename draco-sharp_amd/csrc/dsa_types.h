@@ -57,6 +57,9 @@ struct AttrDesc {
   uint32_t off_flips;      // geometric normal: stream offset of the rABS block of flip bits (probability byte first);
                            // texture coordinates (portable): of the rABS block of orientation bits
   uint32_t num_orient;     // texture coordinates (portable): orientations in that block (MeshPredictionSchemeTexCoordsPortableDecoder.cs:66-85)
+  uint32_t late_ready;     // a late attribute on the position connectivity, crowded batch: bit 0 its corrections are stored (symbol wave),
+                           // bit 1 the order and the operands are (traversal wave) -- set with atomicOr, and the wave that finds the other
+                           // bit set predicts the attribute there and then (bit 2: done; k_predict_wrap of phase 1 skips it)
   uint64_t table;          // arena offset of a cumulative table taken from the batch pool (large alphabets), else 0
 };
 
