@@ -48,6 +48,19 @@ for vi, (name, charts, opt) in enumerate(variants):
     for i in (0, 1, 31):
         assert_same(b.result(i), oracle.decode(streams[i]))
     kt = {k: round(v, 2) for k, v in b.kernel_times().items()}
+    if os.environ.get("SEAM_TIMING_PAIR"):            # two batches of the same streams in flight (the context's two stream sets)
+        b2 = dsa.Batch(ctx, streams)
+        pair = [b, b2]
+        for k in range(2): pair[k].decode(wait=False)
+        for x in pair: x.wait()
+        t0 = time.perf_counter()
+        for k in range(6): pair[k % 2].decode(wait=False)
+        for x in pair: x.wait()
+        ms2 = (time.perf_counter() - t0) / 6 * 1e3
+        bad2 = sum(1 for x in pair for i in range(0, n, 16) if x.status(i) != 0)
+        assert_same(b2.result(1), oracle.decode(streams[1]))
+        kt["pair_ms_per_step"] = round(ms2, 2); kt["pair_meshes_per_s"] = round(n / ms2 * 1e3); kt["pair_failed"] = bad2
+        b2.close()
     print("%-75s %7.2f ms  %7.0f meshes/s  paths %s failed %d  bytes/mesh %d\n    %s" % (name, ms, n / ms * 1e3, paths, bad, len(distinct[0]), kt), flush=True)
     b.close()
     ctx.trim()
