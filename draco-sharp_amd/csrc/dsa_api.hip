@@ -174,7 +174,7 @@ struct dsa_batch {
   bool mirror_compact = false;
   uint32_t max_faces = 0, max_vertices = 0, max_atts = 0, max_att_data = 0;
   uint64_t sum_vertices = 0;
-  bool any_general = false, any_valence = false, any_seamed = false;
+  bool any_general = false, any_valence = false, any_seamed = false, any_multipara = false;
   bool decoded = false, collected = false;
   hipEvent_t ev[DSA_NUM_STAGES + 1] = {};
   hipEvent_t ev_sym[2] = {};
@@ -309,7 +309,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
     b->sum_vertices = 0;
     b->any_general = false;
     b->any_valence = false;
-    b->any_seamed = false;
+    b->any_seamed = false; b->any_multipara = false;
     for (uint32_t i = 0; i < n; ++i) {
       HostMesh &h = b->host[i];
       MeshLayout &L = b->layouts[i];
@@ -329,6 +329,7 @@ dsa_status build_batch(dsa_context *ctx, uint32_t n, const uint8_t *const *strea
       b->any_general = b->any_general || h.general;
       b->any_valence = b->any_valence || (h.valence && !h.general);
       b->any_seamed = b->any_seamed || (h.seamed && !h.general);
+      b->any_multipara = b->any_multipara || L.mp_att != 0;
     }
     // pool for the cumulative tables of large-alphabet streams (bump-allocated by k_locate)
     {
@@ -672,6 +673,8 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_flip_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st5, b->arena, b->d_layouts, b->d_descs, n, lpm, 0u);
     // and the orientation bits of TexCoordsPortable attributes, the same way
     hipLaunchKernelGGL(dsa::k_orient_bits, dim3((n + per_wave - 1) / per_wave), dim3(WAVE), 0, st5, b->arena, b->d_layouts, b->d_descs, n, lpm, 0u);
+    // and the crease flags of ConstrainedMultiParallelogram attributes: four streams each (only where the host parse saw the scheme)
+    if (b->any_multipara) hipLaunchKernelGGL(dsa::k_crease_bits, dim3((n + WAVE / (4 * lpm) - 1) / (WAVE / (4 * lpm))), dim3(WAVE), 0, st5, b->arena, b->d_layouts, b->d_descs, n, lpm);
     HIP_TRY(ctx, hipEventRecord(S.ev_flips, st5));
   }
   // parallelogram operands: by the traversal waves themselves when the batch keeps the machine busy anyway, by an
@@ -889,7 +892,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
   }
   HIP_TRY(ctx, mark());
   bool positions_by_vertex = false;
-  if (b->any_seamed && !(lane_flags & LN_FLAG_PREDICT)) {
+  if (b->any_seamed && !b->any_multipara && !(lane_flags & LN_FLAG_PREDICT)) {
     // A batch with corner attributes: the attributes on the position connectivity are predicted behind the position traversal,
     // while the seam tables and the attribute traversals (20 - 30 ms more) are still under way -- what comes behind those then
     // finds the positions final (the TexCoordsPortable and GeometricNormal predictors read them)
@@ -926,6 +929,12 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_flips, 0));
     const uint32_t gx = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 1023) / 1024, 32));     // four entries per thread: 11.6 -> 9.7 ms against sixteen
     const uint32_t gv = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 1023) / 1024, 64));     // two dependent gathers per vertex: many short threads
+    // ConstrainedMultiParallelogram attributes: the parallelograms of every entry at once, then the chain -- in front of the
+    // predictors that read the positions
+    if (b->any_multipara) {
+      hipLaunchKernelGGL(dsa::k_multipara_prepare, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+      hipLaunchKernelGGL(dsa::k_multipara, dim3((n + 3) / 4, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+    }
     if (!positions_by_vertex) hipLaunchKernelGGL(dsa::k_vertex_positions, dim3(gv, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_predict_geometric, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     // TexCoordsPortable attributes: what depends on the mesh and the positions for every entry at once, then the chain over the

@@ -25,6 +25,7 @@ struct HostMesh {
   bool valence = false;   // valence-coded connectivity on the fast kernels (k_valence_lists in front of the connectivity waves)
   bool seamed = false;    // corner-attribute decoders (attribute seams) on the fast kernels (k_seam_tables, k_traverse_att)
   uint32_t meta_off = 0, meta_len = 0;   // metadata block of the stream (flag 0x8000), for dsa_batch_copy_metadata
+  int first_method = -128;               // prediction method byte of the first attribute (the values of the first decoder start with it), -128: none
   std::vector<HostAttr> atts;
 };
 
@@ -221,6 +222,8 @@ static void host_parse(const uint8_t *s, size_t len, HostMesh &m, bool want_gene
   }
   if (!r.ok) return bad(ST_INVALID);
   for (auto &a : m.atts) if (a.nc == 0 || dt_len(a.data_type) == 0 || a.seq_type > 3) return bad(ST_INVALID);
+  // SequentialIntegerAttributeDecoder.cs:70-76: the values of an integer / quantised attribute start with its prediction method
+  if (!linear && !m.atts.empty() && m.atts[0].seq_type != 0 && r.pos < r.n) m.first_method = (int8_t)r.p[r.pos];
 }
 
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
@@ -231,6 +234,9 @@ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 // *out_cur instead, one cursor per kind: the batch's output block (which dsa_api.hip puts behind all scratch so that one transfer
 // downloads it) is three sub-blocks, every mesh's faces, then every mesh's values, then every mesh's maps -- the compact download
 // takes the values as they are and packs the other two.  Offsets relative to the respective sub-block.
+// MpPrep records of E entries, then the crease flags: at most 4 E bits in four arrays of whole words
+static inline uint64_t mp_crease_words(uint64_t E) { return (4 * E + 31) / 32 + 4; }
+static inline uint64_t mp_region_bytes(uint64_t E) { return sizeof(MpPrep) * E + 4 * mp_crease_words(E); }
 struct OutCursors { uint64_t faces = 0, values = 0, maps = 0; };
 static inline uint64_t layout_mesh(const HostMesh &h, uint64_t stream_len, MeshLayout &L, uint64_t cur, uint64_t slack,
                                    std::vector<std::pair<uint64_t, uint64_t>> *regions = nullptr, OutCursors *out_cur = nullptr) {
@@ -273,7 +279,11 @@ static inline uint64_t layout_mesh(const HostMesh &h, uint64_t stream_len, MeshL
     L.work[a] = take(4 * wcap); L.work_cap[a] = (uint32_t)wcap;
     L.out[a] = take_out(ocap, &OutCursors::values); L.out_cap[a] = (uint32_t)(ocap > 0xFFFFFFFFu ? 0xFFFFFFFFu : ocap);
     L.map[a] = take_out(4 * P, &OutCursors::maps);
-    L.tc[a] = (h.faces != 0 && A.nc == 2 && (A.seq_type == 1 || A.seq_type == 2)) ? take(sizeof(TcPrep) * E) : 0;
+    const bool mp = a == 0 && h.faces != 0 && !h.general && h.first_method == 4 && !A.corner && ncp <= 4;
+    uint64_t prep = (h.faces != 0 && A.nc == 2 && (A.seq_type == 1 || A.seq_type == 2)) ? sizeof(TcPrep) * E : 0;
+    if (mp) prep = std::max<uint64_t>(prep, mp_region_bytes(E));
+    L.tc[a] = prep ? take(prep) : 0;
+    if (mp) L.mp_att |= 1u << a;
   }
   return cur;
 }

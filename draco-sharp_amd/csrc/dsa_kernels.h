@@ -2799,7 +2799,7 @@ __device__ __forceinline__ void predict_wave(uint8_t *arena, const MeshLayout &L
   if (wrap_fast_ok(a, flags)) return;                    // k_predict_wrap
   if (lanes::ln_oct_eligible(a, flags)) return;          // k_predict_oct_lanes
   if ((flags & OS_FLAG) && oct_stream_eligible(a)) return;   // k_predict_oct_streams
-  if (a.pred_kind == 2 || a.pred_kind == 3) return;            // k_predict_geometric, k_texcoords
+  if (a.pred_kind == 2 || a.pred_kind == 3 || a.pred_kind == 4) return;            // k_predict_geometric, k_texcoords, k_multipara
   if (att_is_late(a) != (phase == 1) || pred_filtered(a, flags)) return;
   int32_t *w = (int32_t *)(arena + L.work[ai]);
   const uint32_t nc = a.nc_portable, entries = a.num_entries;
@@ -3134,7 +3134,7 @@ __device__ __forceinline__ bool pw_dequant_fused(const AttrDesc &a, uint32_t fla
   return wrap_fast_ok(a, flags) && a.seq_type == 2 && a.nc == a.nc_portable && a.q_bits >= 1 && a.q_bits <= 30;
 }
 __device__ __forceinline__ bool wrap_fast_ok(const AttrDesc &a, uint32_t flags) {
-  return (flags & PW_FLAG) && a.have_scheme && a.source != SRC_BYTES && a.pred_transform == 1 && a.pred_kind != 3 && a.nc_portable >= 1 && a.nc_portable <= 4 &&
+  return (flags & PW_FLAG) && a.have_scheme && a.source != SRC_BYTES && a.pred_transform == 1 && a.pred_kind != 3 && a.pred_kind != 4 && a.nc_portable >= 1 && a.nc_portable <= 4 &&
          (uint32_t)(1 + a.wrap_max - a.wrap_min) < (1u << 25) && a.num_entries != 0;
 }
 // inclusive wave64 prefix sum, one v_add with a DPP operand per step where the backend fuses them

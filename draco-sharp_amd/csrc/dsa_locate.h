@@ -227,9 +227,32 @@ __device__ __forceinline__ int locate_attribute_section(Rd &r, MeshDesc *D, Attr
     // need the general path's tables send the mesh there: the host decodes it again (site DSA_SITE_RETRY_GENERAL).
     if (D->encoder_type == 0) a.pred_kind = 0;
     else if (a.pred_transform == 1) {
-      if (method == 2 || method == 4) NOTIMPL(DSA_SITE_RETRY_GENERAL);
-      if (!(method == 0 || method == 1 || method == 5 || method == 6)) NOTIMPL(161);
-      a.pred_kind = method == 1 ? 1 : (method == 5 ? 3 : 0);
+      if (method == 2) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+      // ConstrainedMultiParallelogram on the fast kernels where the host parse set its records aside (the first attribute; at most
+      // four components; located in the first pass) -- k_crease_bits, k_multipara_prepare, k_multipara (dsa_seams.h)
+      if (method == 4 && (!((L.mp_att >> ai) & 1u) || L.tc[ai] == 0 || nc > 4 || a.corner_data != 0 || a.late_located != 0)) NOTIMPL(DSA_SITE_RETRY_GENERAL);
+      if (!(method == 0 || method == 1 || method == 4 || method == 5 || method == 6)) NOTIMPL(161);
+      a.pred_kind = method == 1 ? 1 : (method == 5 ? 3 : (method == 4 ? 4 : 0));
+      if (a.pred_kind == 4) {
+        // MeshPredictionSchemeConstrainedMultiParallelogramDecoder.cs:110-134 (v2.2: no mode byte): per context the number of crease
+        // flags and, if any, an rABS block of them
+        uint64_t total = 0;
+        for (int k = 0; k < 4; ++k) {
+          const uint64_t nf = r.varint();
+          REQUIRE(r.ok && nf <= 4ull * L.cap_vertices, 673);
+          a.num_crease[k] = (uint32_t)nf; a.off_crease[k] = 0;
+          total += nf;
+          if (nf > 0) {
+            Rabs rd;
+            uint32_t endp;
+            rd.start(s, L.stream_len, r.pos, &endp);
+            REQUIRE(rd.ok, 674);
+            a.off_crease[k] = r.pos;
+            r.pos = endp;
+          }
+        }
+        REQUIRE(total <= 4ull * L.cap_vertices, 673);             // (a parallelogram of an entry takes a flag: four per entry at most)
+      }
       if (a.pred_kind == 3) {
         // MeshPredictionSchemeTexCoordsPortableDecoder.cs:66-85: the orientation count and an rABS block of their deltas, in front of
         // the transform data; the scheme needs two components and the portable positions (three) decoded before it

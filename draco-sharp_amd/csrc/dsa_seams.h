@@ -760,6 +760,223 @@ __global__ __launch_bounds__(WAVE) void k_texcoords(uint8_t *arena, const MeshLa
 #undef TC_RING
 #undef TC_G
 
+
+// =========================================================================
+// ConstrainedMultiParallelogram (MeshPredictionSchemeConstrainedMultiParallelogramDecoder.cs:28-136; what stock encoders pick for
+// positions and generic attributes at their two highest compression levels) on the fast kernels.
+// The prediction of an entry is the average of up to four parallelograms -- those found while swinging left, then right, around the
+// entry's vertex whose three other corners are decoded already -- each kept or dropped by a crease flag from the bit array of
+// its context (= the number found - 1).  Which parallelograms an entry has, and which flags are its own, depends on the mesh and
+// the traversal order only; the values form a chain (every entry reads DECODED entries).  So:
+//   k_crease_bits          the four flag arrays (one serial rABS stream each, one lane per stream), from the start of the decode
+//   k_multipara_prepare    one thread per entry, behind the traversal: MpPrep (the parallelograms as entry ids)
+//   k_multipara            the chain, SIXTEEN lanes per attribute: lane (i, c) gathers the three operands of parallelogram i,
+//                          component c from a window of the last 1024 results in LDS (the reach of a ring of a spiral or a strip of
+//                          a grid: an LDS round trip per entry where memory would take a microsecond), two exchanges add the four
+//                          parallelograms up, every lane divides and applies the wrap transform for its component.
+// =========================================================================
+__device__ __forceinline__ uint32_t *mp_crease_words_of(uint8_t *arena, const MeshLayout &L, uint32_t ai, uint32_t cap_entries) {
+  return (uint32_t *)(arena + L.tc[ai] + sizeof(MpPrep) * (size_t)cap_entries);
+}
+__device__ __forceinline__ uint32_t mp_crease_base(const AttrDesc &a, uint32_t ctx) {       // first word of a context's flags
+  uint32_t w = 0;
+  for (uint32_t k = 0; k < ctx; ++k) w += (a.num_crease[k] + 31u) >> 5;
+  return w;
+}
+__global__ __launch_bounds__(WAVE) void k_crease_bits(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, uint32_t lanes_per_mesh) {
+  const uint32_t lane = lane_id();
+  const uint32_t per = 4u * lanes_per_mesh;                  // (mesh, attribute, context)
+  const uint32_t mesh = blockIdx.x * (WAVE / per) + lane / per, ai = (lane % per) >> 2, ctx = lane & 3u;
+  if (mesh >= n) return;
+  const MeshLayout &L = layouts[mesh];
+  MeshDesc *D = &descs[mesh];
+  if (status_of(D) != ST_OK || D->general || ai >= D->num_attributes) return;
+  const AttrDesc &a = D->att[ai];
+  if (!a.have_scheme || a.pred_kind != 4 || a.source == SRC_BYTES || a.num_crease[ctx] == 0) return;
+  Rabs rb;
+  uint32_t endp;
+  rb.start(arena + L.stream, L.stream_len, a.off_crease[ctx], &endp);
+  if (!rb.ok) { fail(D, ST_INVALID, 674); return; }
+  (void)rabs_block_to_words<false>(rb, a.num_crease[ctx], mp_crease_words_of(arena, L, ai, L.cap_vertices) + mp_crease_base(a, ctx));
+}
+
+template <bool CP>
+__device__ __forceinline__ void multipara_prepare_entries(uint8_t *arena, const MeshLayout &L, MeshDesc *D, uint32_t ai, uint32_t tid, uint32_t stride) {
+  typedef Rec<CP> R;
+  const AttrDesc &a = D->att[ai];
+  const uint32_t entries = a.num_entries, F = D->num_faces;
+  const TravIO io = trav_position(arena, L, D);
+  MpPrep *prep = (MpPrep *)(arena + L.tc[ai]);
+  bool bad = false;
+  const uint32_t max_steps = 3u * F + 1u;
+  auto opposite = [&](uint32_t c) { return c == DSA_INVALID ? c : R::get_o_plain(io.frec, c); };
+  auto valid = [&](uint32_t c) { return c == DSA_INVALID || ((c >> 2) < F && (c & 3u) != 3u); };
+  for (uint32_t p = tid; p < entries; p += stride) {
+    // (the triples go straight to memory, the first word of each -- which carries the count -- at the end: a record held in a local
+    // array indexed by the count would live in scratch or LDS)
+    uint32_t *rec = &prep[p].id[0][0];
+    uint32_t first0 = 0, first1 = 0, first2 = 0, first3 = 0;
+    const uint32_t start = io.d2c[p];
+    uint32_t found = 0;
+    if ((start >> 2) >= F || (start & 3u) == 3u) bad = true;
+    else if (p > 0) {
+      uint32_t c = start, steps = 0;
+      bool first_pass = true;
+      while (c != DSA_INVALID) {
+        if (++steps > max_steps || !valid(c)) { bad = true; break; }
+        const uint32_t oc = opposite(c);
+        if (oc != DSA_INVALID) {
+          if (!valid(oc)) { bad = true; break; }
+          const uint32_t vo = R::get_v(io.frec, oc), vn = R::get_v(io.frec, qnext(oc)), vp = R::get_v(io.frec, qprev(oc));
+          if (vo < io.NV && vn < io.NV && vp < io.NV) {
+            const int32_t eo = io.v2d[vo], en = io.v2d[vn], ep = io.v2d[vp];
+            if (eo >= 0 && en >= 0 && ep >= 0 && (uint32_t)eo < p && (uint32_t)en < p && (uint32_t)ep < p) {
+              first0 = found == 0 ? (uint32_t)en : first0; first1 = found == 1 ? (uint32_t)en : first1;
+              first2 = found == 2 ? (uint32_t)en : first2; first3 = found == 3 ? (uint32_t)en : first3;
+              rec[3 * found + 1] = (uint32_t)ep; rec[3 * found + 2] = (uint32_t)eo;
+              if (++found == 4) break;
+            }
+          }
+        }
+        // SwingLeft = Next(Opposite(Next(c))), SwingRight = Previous(Opposite(Previous(c)))
+        if (first_pass) { const uint32_t o2 = opposite(qnext(c)); c = o2 == DSA_INVALID ? o2 : (valid(o2) ? qnext(o2) : (bad = true, DSA_INVALID)); }
+        else { const uint32_t o2 = opposite(qprev(c)); c = o2 == DSA_INVALID ? o2 : (valid(o2) ? qprev(o2) : (bad = true, DSA_INVALID)); }
+        if (c == start) break;
+        if (c == DSA_INVALID && first_pass && !bad) {
+          first_pass = false;
+          const uint32_t o2 = opposite(qprev(start));
+          c = o2 == DSA_INVALID ? o2 : (valid(o2) ? qprev(o2) : (bad = true, DSA_INVALID));
+        }
+      }
+    }
+    const uint32_t tag = found << MP_FOUND_SHIFT;
+    rec[0] = first0 | tag; rec[3] = first1 | tag; rec[6] = first2 | tag; rec[9] = first3 | tag;
+    // (the operand words of triples that were not found stay as they are: the chain reads them through a mask of their own)
+  }
+  if (bad) fail(D, ST_INVALID, 675);
+}
+__global__ __launch_bounds__(256) void k_multipara_prepare(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  const uint32_t mesh = blockIdx.y, ai = blockIdx.z;
+  if (mesh >= n) return;
+  MeshDesc *D = &descs[mesh];
+  if (status_of(D) != ST_OK || D->general || ai >= D->num_attributes) return;
+  const AttrDesc &a = D->att[ai];
+  const MeshLayout &L = layouts[mesh];
+  if (!a.have_scheme || a.pred_kind != 4 || a.source == SRC_BYTES || a.num_entries == 0) return;
+  if (a.num_entries > L.cap_vertices) { fail(D, ST_INVALID, 675); return; }
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  if (L.rec_compact) multipara_prepare_entries<true>(arena, L, D, ai, tid, stride);
+  else multipara_prepare_entries<false>(arena, L, D, ai, tid, stride);
+}
+
+// The chain.  Lane l of a wave: attribute slot l >> 4 (four meshes to a wave), component c = (l >> 2) & 3, parallelogram i = l & 3
+// (the four parallelograms of a component in one quad: their sum is two DPP adds).
+// Per entry: the lane's triple and the correction were requested MP_AHEAD entries ago; half that far ahead, with the record there,
+// the flag word of the lane's parallelogram (its place follows from the counts of the entries before it) and the three operands as
+// memory holds them -- final for every entry further back than the window, which is all they are used for.  Operands inside the
+// window (the last MP_WIN results of the attribute, in LDS) are read when the entry's turn comes.  No load stands in a branch.
+#define MP_WIN 256u
+#define MP_AHEAD 8
+__device__ __forceinline__ uint32_t mp_quad_sum(uint32_t x) {
+  x += dpp_mov<0xB1>(x);            // quad_perm [1, 0, 3, 2]
+  x += dpp_mov<0x4E>(x);            // quad_perm [2, 3, 0, 1]
+  return x;
+}
+__global__ __launch_bounds__(WAVE) void k_multipara(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+  __shared__ int32_t win[4][MP_WIN][4];
+  const uint32_t lane = lane_id(), slot = lane >> 4, comp = (lane >> 2) & 3u, pi = lane & 3u, ai = blockIdx.y;
+  const uint32_t mesh = blockIdx.x * 4u + slot;
+  // (lanes without work run along on entry 0 of a mesh that is there, and store nothing)
+  bool mine = mesh < n;
+  MeshDesc *D = &descs[mine ? mesh : 0];
+  mine = mine && status_of(D) == ST_OK && !D->general && ai < D->num_attributes;
+  const AttrDesc &a = D->att[mine ? ai : 0];
+  const MeshLayout &L = layouts[mine ? mesh : 0];
+  mine = mine && a.have_scheme && a.pred_kind == 4 && a.source != SRC_BYTES && a.num_entries != 0 && a.num_entries <= L.cap_vertices && L.tc[ai] != 0;
+  if (!__ballot(mine)) return;
+  const uint32_t nc = mine ? a.nc_portable : 1u;
+  const uint32_t entries = mine ? a.num_entries : 0u;
+  uint32_t most = entries;
+  for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)most, d, WAVE); most = o > most ? o : most; }
+  most = uni(most);
+  const uint32_t cc = comp < nc ? comp : 0u;                 // the component this lane reads (lanes beyond the last one shadow component 0)
+  const bool writer = mine && pi == 0 && comp < nc;
+  const MpPrep *prep = (const MpPrep *)(arena + (mine ? L.tc[ai] : L.stream));
+  int32_t *w = (int32_t *)(arena + (mine ? L.work[ai] : L.stream));
+  const uint32_t *cbits = mine ? mp_crease_words_of(arena, L, ai, L.cap_vertices) : (const uint32_t *)(arena + L.stream);
+  uint32_t cbase[4], cpos[4], cnum[4];
+  for (uint32_t k = 0; k < 4; ++k) { cbase[k] = mine ? mp_crease_base(a, k) : 0u; cpos[k] = 0; cnum[k] = mine ? a.num_crease[k] : 0u; }
+  const int32_t mn = mine ? a.wrap_min : 0, mx = mine ? a.wrap_max : 0, max_dif = 1 + mx - mn;
+  const uint32_t lastp = entries ? entries - 1u : 0u;
+  bool ran_out = false;
+  // rings of what was requested: [e % MP_AHEAD]
+  uint32_t rid0[MP_AHEAD], rid1[MP_AHEAD], rid2[MP_AHEAD], rword[MP_AHEAD], rbit[MP_AHEAD];
+  int32_t rcorr[MP_AHEAD], rg0[MP_AHEAD], rg1[MP_AHEAD], rg2[MP_AHEAD];
+  auto request_record = [&](uint32_t e, int s) {             // stage A: the triple of this lane's parallelogram and the correction
+    const uint32_t q = e <= lastp ? e : lastp;
+    const uint32_t *t = prep[q].id[pi];
+    rid0[s] = t[0]; rid1[s] = t[1]; rid2[s] = t[2];
+    rcorr[s] = w[(size_t)q * nc + cc];
+  };
+  auto request_rest = [&](uint32_t e, int s) {               // stage B: the record is here -- the place of this lane's flag and its word; the operands from memory
+    const uint32_t found = e <= lastp ? rid0[s] >> MP_FOUND_SHIFT : 0u;
+    const uint32_t ctx = found ? found - 1u : 0u;
+    uint32_t at = 0, nn = 0, base = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) if (k == ctx) { at = cpos[k]; nn = cnum[k]; base = cbase[k]; }
+    const uint32_t bit = at + pi;
+    ran_out = ran_out || (found != 0 && at + found > nn);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) if (k == ctx) cpos[k] += found;
+    rbit[s] = bit & 31u;
+    rword[s] = cbits[base + (bit < nn ? bit >> 5 : 0u)];
+    const uint32_t en = rid0[s] & MP_ID_MASK, ep = rid1[s], eo = rid2[s];       // (triples that were not found hold anything: clamped, and never used)
+    rg0[s] = w[(size_t)(en <= lastp ? en : lastp) * nc + cc];
+    rg1[s] = w[(size_t)(ep <= lastp ? ep : lastp) * nc + cc];
+    rg2[s] = w[(size_t)(eo <= lastp ? eo : lastp) * nc + cc];
+  };
+#pragma unroll
+  for (int s = 0; s < MP_AHEAD; ++s) request_record((uint32_t)s, s);
+#pragma unroll
+  for (int s = 0; s < MP_AHEAD / 2; ++s) request_rest((uint32_t)s, s);
+  int32_t o1 = 0;
+  int32_t (*mywin)[4] = win[slot];
+  for (uint32_t g0 = 0; g0 < most; g0 += MP_AHEAD) {
+#pragma unroll
+    for (int s = 0; s < MP_AHEAD; ++s) {
+      const uint32_t p = g0 + (uint32_t)s;
+      const bool live = p <= lastp && entries != 0;
+      const uint32_t found = rid0[s] >> MP_FOUND_SHIFT;
+      const uint32_t en = rid0[s] & MP_ID_MASK, ep = rid1[s], eo = rid2[s];
+      const bool crease = ((rword[s] >> rbit[s]) & 1u) != 0;
+      const bool used = pi < found && !crease && live;
+      // window for what is near (memory may not have it yet), memory for the rest (requested four entries ago, written hundreds ago)
+      const int32_t ln = mywin[en & (MP_WIN - 1u)][cc], lp = mywin[ep & (MP_WIN - 1u)][cc], lo = mywin[eo & (MP_WIN - 1u)][cc];
+      const int32_t vn = p - en > MP_WIN ? rg0[s] : ln, vp = p - ep > MP_WIN ? rg1[s] : lp, vo = p - eo > MP_WIN ? rg2[s] : lo;
+      const uint32_t sum = mp_quad_sum(used ? (uint32_t)vn + (uint32_t)vp - (uint32_t)vo : 0u);
+      const uint32_t cnt = mp_quad_sum(used ? 1u : 0u);
+      // the average, truncated toward zero (the C# operator on the wrapped sum)
+      const int32_t x = (int32_t)sum;
+      int32_t q = x;
+      if (cnt == 2u) q = (x + (int32_t)((uint32_t)x >> 31)) >> 1;
+      else if (cnt == 3u) q = (int32_t)(((int64_t)x * 0x55555556ll) >> 32) + (int32_t)((uint32_t)x >> 31);
+      else if (cnt == 4u) q = (x + ((x >> 31) & 3)) >> 2;
+      const int32_t pred = cnt ? q : (p ? o1 : 0);
+      int32_t o = wrap_original(pred, rcorr[s], mn, mx, max_dif);
+      o = live ? o : o1;
+      if (writer && live) w[(size_t)p * nc + comp] = o;
+      if (pi == 0) mywin[p & (MP_WIN - 1u)][comp] = o;
+      o1 = o;
+      // the ring slot is free: the record MP_AHEAD entries on; and the rest for the entry half that far on, whose record is here
+      request_record(p + MP_AHEAD, s);
+      request_rest(p + MP_AHEAD / 2, (s + MP_AHEAD / 2) % MP_AHEAD);
+    }
+  }
+  if (__ballot(ran_out && mine)) { if (ran_out && mine && pi == 0 && comp == 0) fail(D, ST_INVALID, 676); }
+}
+#undef MP_WIN
+#undef MP_AHEAD
+
 }  // namespace dsa
 
 namespace dsa {

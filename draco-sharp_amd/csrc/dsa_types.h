@@ -26,7 +26,7 @@ struct AttrDesc {
   uint8_t seq_type;        // SequentialAttributeEncoderType 0..3
   int8_t decoder_id;
   int8_t pred_method;      // PredictionSchemeMethod as stored in the stream
-  int8_t pred_kind;        // scheme that runs: 0 delta, 1 parallelogram, 2 geometric normal, 3 texture coordinates (portable)
+  int8_t pred_kind;        // scheme that runs: 0 delta, 1 parallelogram, 2 geometric normal, 3 texture coordinates (portable), 4 constrained multi-parallelogram
                            // (PredictionSchemeDecoderFactory.cs:24-36)
   int8_t pred_transform;   // PredictionSchemeTransformType
   uint8_t nc_portable;
@@ -57,6 +57,7 @@ struct AttrDesc {
   uint32_t off_flips;      // geometric normal: stream offset of the rABS block of flip bits (probability byte first);
                            // texture coordinates (portable): of the rABS block of orientation bits
   uint32_t num_orient;     // texture coordinates (portable): orientations in that block (MeshPredictionSchemeTexCoordsPortableDecoder.cs:66-85)
+  uint32_t off_crease[4], num_crease[4];   // constrained multi-parallelogram (pred_kind 4): the rABS blocks of the crease flags of the four contexts
   uint32_t late_ready;     // a late attribute on the position connectivity, crowded batch: bit 0 its corrections are stored (symbol wave),
                            // bit 1 the order and the operands are (traversal wave) -- set with atomicOr, and the wave that finds the other
                            // bit set predicts the attribute there and then (bit 2: done; k_predict_wrap of phase 1 skips it)
@@ -231,6 +232,15 @@ inline SeamLayout seam_layout(uint64_t F, uint64_t V, uint64_t A, bool compact) 
 
 // What k_texcoords_prepare leaves for the serial chain of k_texcoords, per entry of a TexCoordsPortable attribute: everything of
 // MeshPredictionSchemeTexCoordsPortablePredictor.cs:46-150 that depends on the mesh and the positions only.
+// What k_multipara_prepare leaves for the chain of k_multipara, per entry of a ConstrainedMultiParallelogram attribute: the (up to
+// four) parallelograms the reference finds while it swings around the entry's vertex (MeshPredictionSchemeConstrainedMulti-
+// ParallelogramDecoder.cs:46-70) as entry ids {next, prev, opposite}, all decoded before the entry; their number in the top three
+// bits of every triple's first word.  The crease flags of the attribute (four bit arrays, one per context, back to back in whole
+// words) follow the records of the region.
+struct MpPrep { uint32_t id[4][3]; };
+#define MP_FOUND_SHIFT 29u
+#define MP_ID_MASK 0x1FFFFFFFu
+
 struct TcPrep {
   uint32_t next_id, prev_id;   // entries at Next / Previous of the entry's corner; DSA_INVALID: none, or not decoded before this entry
   int64_t pn_norm2;            // |P(prev) - P(next)|^2
@@ -290,4 +300,7 @@ struct MeshLayout {
   uint64_t seam_bytes;
   uint64_t tc[DSA_MAX_ATT];     // TcPrep[entry capacity] of every two-component integer / quantised attribute (it may turn out to be
                                 // predicted by TexCoordsPortable: the scheme is written behind the symbol stream), else 0
+  uint32_t mp_att;              // bit a: tc[a] is sized for MpPrep records + crease flags (the host parse saw ConstrainedMultiParallelogram
+                                // at the head of the first attribute's values -- the one scheme byte it can reach without decoding)
+  uint32_t pad_mp;
 };

@@ -840,3 +840,101 @@ def test_the_bench_batch_at_full_size(ctx):
         assert_same(b.result(i), ref)
     b.close()
     ctx.trim()          # 26 GB of arena go back before the next test
+
+
+@pytest.mark.gpu
+def test_constrained_multi_parallelogram_positions_on_the_fast_kernels(ctx):
+    """What stock encoders write at their two highest compression levels: positions by ConstrainedMultiParallelogram (method 4), with
+    TexCoordsPortable / GeometricNormal / parallelogram beside it.  The host parse sees the scheme byte of the first attribute (the
+    values of the first decoder start with it) and sets the records aside; k_crease_bits, k_multipara_prepare and k_multipara decode
+    it: decode_path 0 on every topology, with standard and valence connectivity, every symbol scheme, one 64k-triangle mesh and a
+    crowded batch -- and a second attribute with the scheme still takes the general path."""
+    streams = []
+    for kind, nx, ny in KINDS + [(synth.HOLES, 40, 33), (synth.SPHERE, 30, 21)]:
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 31)
+        for opt in (dict(), dict(uv_prediction=5, normal_prediction=6), dict(predictive_connectivity=2, uv_prediction=5), dict(force_scheme=0),
+                    dict(pos_bits=14, uv_prediction=5, normal_prediction=6, predictive_connectivity=2), dict(raw_integers=4)):
+            streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, **opt)))
+        streams.append(synth.encode_mesh(pos, faces, None, None, opt=synth.options(pos_prediction=4)))
+    pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 128, 256, 5)
+    streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, uv_prediction=5, normal_prediction=6, predictive_connectivity=2)))
+    pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 128, 256, 6)
+    streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4)))
+    b = run_batch(ctx, streams)
+    for i, sbytes in enumerate(streams):
+        assert b.status(i) == 0, (i, b.status(i), b.mesh_info(i).detail)
+        ref = oracle.decode(sbytes)
+        assert ref.attributes[0].pred_method == 4
+        assert_same(b.result(i), ref, b, i)
+        assert b.mesh_info(i).decode_path == 0, (i, b.mesh_info(i).decode_path)
+    b.close()
+    # crowded: the chain's four meshes to a wave, ragged sizes
+    crowd = [streams[i % len(streams)] for i in range(300)]
+    b = run_batch(ctx, crowd)
+    for i in range(300):
+        assert b.status(i) == 0, (i, b.mesh_info(i).detail)
+    for i in list(range(0, 300, 7)) + [299]:
+        assert_same(b.result(i), oracle.decode(crowd[i]))
+        assert b.mesh_info(i).decode_path == 0
+    b.close()
+    # the scheme on a later attribute: the general path, as before
+    pos, nrm, uv, faces = synth.make_mesh(synth.HOLES, 20, 16, 22)
+    later = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=1, uv_prediction=4))
+    b = run_batch(ctx, [later, streams[0]])
+    assert b.status(0) == 0 and b.mesh_info(0).decode_path != 0 and b.mesh_info(1).decode_path == 0
+    assert_same(b.result(0), oracle.decode(later))
+    assert_same(b.result(1), oracle.decode(streams[0]))
+    b.close()
+
+
+@pytest.mark.gpu
+def test_constrained_multi_parallelogram_with_seams_and_corrupt_streams(ctx):
+    """Positions by ConstrainedMultiParallelogram in meshes whose other attributes have seams (corner-attribute decoders), and damaged
+    streams of the dialect: the device path and the oracle agree on which streams decode and on every value of those."""
+    import random
+    from meshutil import seamed_mesh
+    cases = []
+    for kind, nx, ny in ((synth.GRID, 24, 17), (synth.TORUS, 16, 12), (synth.HOLES, 20, 16), (synth.SPHERE, 12, 9)):
+        for charts, opt in (((None, "stripes"), dict(uv_prediction=5)), (("checker", "island"), dict(uv_prediction=5, normal_prediction=6, predictive_connectivity=2)),
+                            (("random", "random"), dict())):
+            args = seamed_mesh(synth, kind, nx, ny, 19, *charts)
+            cases.append(synth.encode_mesh_corners(*args, opt=synth.options(pos_prediction=4, **opt)))
+    b = run_batch(ctx, cases)
+    for i, sbytes in enumerate(cases):
+        assert b.status(i) == 0, (i, b.mesh_info(i).detail)
+        assert_same(b.result(i), oracle.decode(sbytes), b, i)
+        assert b.mesh_info(i).decode_path == 0
+    b.close()
+    rng = random.Random(77)
+    pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 10, 8, 3)
+    base = [synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, uv_prediction=5, normal_prediction=6)), cases[0], cases[4]]
+    damaged = []
+    for k in range(240):
+        d = bytearray(base[k % 3])
+        mode = k % 4
+        if mode == 0:
+            for _ in range(rng.randint(1, 3)):
+                d[rng.randrange(20, len(d))] ^= 1 << rng.randrange(8)
+        elif mode == 1:
+            at = rng.randrange(20, len(d)); d[at:at + rng.randint(1, 8)] = bytes(rng.randrange(256) for _ in range(rng.randint(1, 8)))
+        elif mode == 2:
+            d = d[:rng.randrange(30, len(d))]
+        else:
+            at = rng.randrange(len(d) // 2, len(d)); d[at] = rng.randrange(256)
+        damaged.append(bytes(d))
+    b = run_batch(ctx, damaged)
+    stricter = []
+    for i, sbytes in enumerate(damaged):
+        try:
+            ref = oracle.decode(sbytes)
+        except oracle.OracleError:
+            ref = None
+        if ref is None:
+            assert b.status(i) != 0, i
+        elif b.status(i) != 0:
+            stricter.append((b.status(i), b.mesh_info(i).detail))
+        else:
+            assert_same(b.result(i), ref)
+    # (the device path's own validations, as in the other corrupt-stream tests: counts that exceed what the mesh can hold)
+    assert set(stricter) <= {(1, 263), (1, 305), (1, 668), (1, 657), (1, 681), (1, 673), (1, 676)}, stricter
+    b.close()

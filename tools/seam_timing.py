@@ -24,7 +24,10 @@ variants = [("per-vertex, parallelogram (the bench batch)", None, dict()),
             ("per-vertex, TexCoordsPortable", None, dict(uv_prediction=5)),
             ("stock default: valence + GeometricNormal + TexCoordsPortable, per vertex", None, dict(uv_prediction=5, predictive_connectivity=2, normal_prediction=6)),
             ("stock default with UV seams", (None, "stripes"), dict(uv_prediction=5, predictive_connectivity=2, normal_prediction=6)),
-            ("stock default with UV and normal seams (3 charts each)", ("stripes", "stripes"), dict(uv_prediction=5, predictive_connectivity=2, normal_prediction=6))]
+            ("stock default with UV and normal seams (3 charts each)", ("stripes", "stripes"), dict(uv_prediction=5, predictive_connectivity=2, normal_prediction=6)),
+            ("positions by ConstrainedMultiParallelogram, rest as the bench batch", None, dict(pos_prediction=4)),
+            ("stock highest levels: valence + ConstrainedMultiParallelogram + GeometricNormal + TexCoordsPortable", None, dict(pos_prediction=4, uv_prediction=5, predictive_connectivity=2, normal_prediction=6)),
+            ("stock highest levels with UV seams", (None, "stripes"), dict(pos_prediction=4, uv_prediction=5, predictive_connectivity=2, normal_prediction=6))]
 for vi, (name, charts, opt) in enumerate(variants):
     if only is not None and vi not in only:
         continue
