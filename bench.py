@@ -248,7 +248,9 @@ def dialects_leg(dsa, synth, ctx, nx, ny, n, steps):
     variants = [("uv_seams", (None, "stripes"), dict()),
                 ("uv_seams_texcoords_portable", (None, "stripes"), dict(uv_prediction=5)),
                 ("stock_default_per_vertex", None, dict(uv_prediction=5, predictive_connectivity=2, normal_prediction=6)),
-                ("stock_default_uv_seams", (None, "stripes"), dict(uv_prediction=5, predictive_connectivity=2, normal_prediction=6))]
+                ("stock_default_uv_seams", (None, "stripes"), dict(uv_prediction=5, predictive_connectivity=2, normal_prediction=6)),
+                # compression level 9: positions by ConstrainedMultiParallelogram
+                ("stock_level9_per_vertex", None, dict(pos_prediction=4, uv_prediction=5, predictive_connectivity=2, normal_prediction=6))]
     out = {}
     for name, charts, opt in variants:
         distinct = []

@@ -811,41 +811,92 @@ __device__ __forceinline__ void multipara_prepare_entries(uint8_t *arena, const 
   const uint32_t max_steps = 3u * F + 1u;
   auto opposite = [&](uint32_t c) { return c == DSA_INVALID ? c : R::get_o_plain(io.frec, c); };
   auto valid = [&](uint32_t c) { return c == DSA_INVALID || ((c >> 2) < F && (c & 3u) != 3u); };
+  const uint32_t NVT = io.NV;
+  // one candidate: the face across corner oc has its three vertices decoded before entry p?  (ids out)
+  auto swing = [&](uint32_t c, bool left) {     // SwingLeft = Next(Opposite(Next(c))), SwingRight = Previous(Opposite(Previous(c)))
+    const uint32_t o2 = opposite(left ? qnext(c) : qprev(c));
+    if (o2 == DSA_INVALID) return o2;
+    if (!valid(o2)) { bad = true; return (uint32_t)DSA_INVALID; }
+    return left ? qnext(o2) : qprev(o2);
+  };
   for (uint32_t p = tid; p < entries; p += stride) {
-    // (the triples go straight to memory, the first word of each -- which carries the count -- at the end: a record held in a local
-    // array indexed by the count would live in scratch or LDS)
+    // Two phases, so that the dependent loads of an entry are the walk around its vertex alone (a record per step) and everything
+    // the candidates need -- the face across, the entries of its three vertices -- is requested for all of them at once: the walk
+    // collects the corners across (up to MP_FAN of them: the fan of nearly every vertex; a longer one is walked the plain way).
+    // The triples go straight to memory, the first word of each -- which carries the count -- at the end: a record held in a local
+    // array indexed by the count would live in scratch or LDS.
     uint32_t *rec = &prep[p].id[0][0];
     uint32_t first0 = 0, first1 = 0, first2 = 0, first3 = 0;
     const uint32_t start = io.d2c[p];
     uint32_t found = 0;
+    auto take = [&](uint32_t en, uint32_t ep, uint32_t eo) {
+      first0 = found == 0 ? en : first0; first1 = found == 1 ? en : first1;
+      first2 = found == 2 ? en : first2; first3 = found == 3 ? en : first3;
+      rec[3 * found + 1] = ep; rec[3 * found + 2] = eo;
+      ++found;
+    };
     if ((start >> 2) >= F || (start & 3u) == 3u) bad = true;
     else if (p > 0) {
-      uint32_t c = start, steps = 0;
-      bool first_pass = true;
-      while (c != DSA_INVALID) {
-        if (++steps > max_steps || !valid(c)) { bad = true; break; }
-        const uint32_t oc = opposite(c);
-        if (oc != DSA_INVALID) {
-          if (!valid(oc)) { bad = true; break; }
-          const uint32_t vo = R::get_v(io.frec, oc), vn = R::get_v(io.frec, qnext(oc)), vp = R::get_v(io.frec, qprev(oc));
-          if (vo < io.NV && vn < io.NV && vp < io.NV) {
-            const int32_t eo = io.v2d[vo], en = io.v2d[vn], ep = io.v2d[vp];
-            if (eo >= 0 && en >= 0 && ep >= 0 && (uint32_t)eo < p && (uint32_t)en < p && (uint32_t)ep < p) {
-              first0 = found == 0 ? (uint32_t)en : first0; first1 = found == 1 ? (uint32_t)en : first1;
-              first2 = found == 2 ? (uint32_t)en : first2; first3 = found == 3 ? (uint32_t)en : first3;
-              rec[3 * found + 1] = (uint32_t)ep; rec[3 * found + 2] = (uint32_t)eo;
-              if (++found == 4) break;
+      constexpr int MP_FAN = 8;
+      uint32_t cand[MP_FAN];
+      uint32_t c = start;
+      bool first_pass = true, done = false;
+#pragma unroll
+      for (int k = 0; k < MP_FAN; ++k) {
+        cand[k] = DSA_INVALID;
+        if (!done) {
+          const uint32_t oc = opposite(c);
+          if (oc != DSA_INVALID && !valid(oc)) { bad = true; done = true; }
+          else {
+            cand[k] = oc;
+            c = swing(c, first_pass);
+            if (c == start) done = true;
+            else if (c == DSA_INVALID) {
+              if (first_pass && !bad) { first_pass = false; c = swing(start, false); if (c == DSA_INVALID) done = true; }
+              else done = true;
             }
           }
         }
-        // SwingLeft = Next(Opposite(Next(c))), SwingRight = Previous(Opposite(Previous(c)))
-        if (first_pass) { const uint32_t o2 = opposite(qnext(c)); c = o2 == DSA_INVALID ? o2 : (valid(o2) ? qnext(o2) : (bad = true, DSA_INVALID)); }
-        else { const uint32_t o2 = opposite(qprev(c)); c = o2 == DSA_INVALID ? o2 : (valid(o2) ? qprev(o2) : (bad = true, DSA_INVALID)); }
-        if (c == start) break;
-        if (c == DSA_INVALID && first_pass && !bad) {
-          first_pass = false;
-          const uint32_t o2 = opposite(qprev(start));
-          c = o2 == DSA_INVALID ? o2 : (valid(o2) ? qprev(o2) : (bad = true, DSA_INVALID));
+      }
+      if (done) {
+        uint32_t vv[MP_FAN][3];
+#pragma unroll
+        for (int k = 0; k < MP_FAN; ++k) {
+          const uint32_t oc = cand[k] != DSA_INVALID ? cand[k] : start;            // (a corner that is there)
+          vv[k][0] = R::get_v(io.frec, qnext(oc)); vv[k][1] = R::get_v(io.frec, qprev(oc)); vv[k][2] = R::get_v(io.frec, oc);
+        }
+        int32_t ee[MP_FAN][3];
+#pragma unroll
+        for (int k = 0; k < MP_FAN; ++k)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) ee[k][j] = io.v2d[vv[k][j] < NVT ? vv[k][j] : 0u];
+#pragma unroll
+        for (int k = 0; k < MP_FAN; ++k) {
+          const bool ok = cand[k] != DSA_INVALID && vv[k][0] < NVT && vv[k][1] < NVT && vv[k][2] < NVT && ee[k][0] >= 0 && ee[k][1] >= 0 && ee[k][2] >= 0 &&
+                          (uint32_t)ee[k][0] < p && (uint32_t)ee[k][1] < p && (uint32_t)ee[k][2] < p;
+          if (ok && found < 4) take((uint32_t)ee[k][0], (uint32_t)ee[k][1], (uint32_t)ee[k][2]);
+        }
+      } else if (!bad) {
+        // a fan of more than MP_FAN corners: the reference's loop as it is written
+        uint32_t steps = 0;
+        c = start; first_pass = true;
+        while (c != DSA_INVALID) {
+          if (++steps > max_steps || !valid(c)) { bad = true; break; }
+          const uint32_t oc = opposite(c);
+          if (oc != DSA_INVALID) {
+            if (!valid(oc)) { bad = true; break; }
+            const uint32_t vo = R::get_v(io.frec, oc), vn = R::get_v(io.frec, qnext(oc)), vp = R::get_v(io.frec, qprev(oc));
+            if (vo < NVT && vn < NVT && vp < NVT) {
+              const int32_t eo = io.v2d[vo], en = io.v2d[vn], ep = io.v2d[vp];
+              if (eo >= 0 && en >= 0 && ep >= 0 && (uint32_t)eo < p && (uint32_t)en < p && (uint32_t)ep < p) {
+                take((uint32_t)en, (uint32_t)ep, (uint32_t)eo);
+                if (found == 4) break;
+              }
+            }
+          }
+          c = swing(c, first_pass);
+          if (c == start) break;
+          if (c == DSA_INVALID && first_pass && !bad) { first_pass = false; c = swing(start, false); }
         }
       }
     }
