@@ -166,7 +166,7 @@ def test_gpu_seams_take_the_fast_kernels(ctx, house04_bytes):
     k_texcoords): decode_path 0 for raw-coded seamed streams of every topology, standard and valence connectivity, one and two
     seamed attributes -- and for the reference's own sample, house_04 (valence symbols in tagged context lists, 59 topology splits,
     UV seams, TexCoordsPortable) -- GeometricNormal on normals with seams included (the fan of an entry ends at the seams).  What
-    still takes the second chance: the multi-parallelogram schemes, prediction-degree order."""
+    still takes the second chance: the multi-parallelogram schemes on a corner attribute, prediction-degree order."""
     import draco_sharp_amd as dsa
     from test_gpu_parity import assert_same
     cases = []
