@@ -23,6 +23,10 @@ for k, (kind, nx, ny, charts, opt) in enumerate([
     families.append(synth.encode_mesh_corners(*seamed_mesh(synth, kind, nx, ny, 5 + k, *charts), opt=synth.options(**opt)))
 pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 16, 12, 9)
 families.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(uv_prediction=5, normal_prediction=6, predictive_connectivity=2, force_scheme=1)))
+# ConstrainedMultiParallelogram positions (k_crease_bits, k_multipara_prepare, k_multipara), per vertex and beside seamed attributes
+families.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, uv_prediction=5, normal_prediction=6, predictive_connectivity=2)))
+families.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, force_scheme=0)))
+families.append(synth.encode_mesh_corners(*seamed_mesh(synth, synth.HOLES, 20, 16, 11, None, "stripes"), opt=synth.options(pos_prediction=4, uv_prediction=5)))
 families.append(open(os.path.join(ROOT, "tests", "golden", "house_04.obj.drc"), "rb").read())
 streams = []
 for k, f in enumerate(families):
