@@ -90,6 +90,17 @@ int main(int argc, char **argv) {
   if (argc < 4) { fprintf(stderr, "usage: general_host decode <in> <out> [force] | fuzz <in> <iterations> <seed> [force]\n"); return 2; }
   const std::string mode = argv[1];
   std::vector<uint8_t> in = read_file(argv[2]);
+  if (mode == "layout") {          // the sizing parse and the layout of a stream as the batch builder makes them: what the fast kernels are given
+    HostMesh h;
+    unsetenv("DSA_FORCE_GENERAL");
+    host_parse(in.data(), in.size(), h);
+    MeshLayout L;
+    memset(&L, 0, sizeof(L));
+    uint64_t end = h.status == 0 ? layout_mesh(h, in.size(), L, 0, 16) : 0;
+    printf("status %d general %d seamed %d first_method %d mp_att %u tc0 %llu tc0_bytes %llu cap_vertices %u end %llu\n", h.status, (int)h.general, (int)h.seamed, h.first_method,
+           L.mp_att, (unsigned long long)L.tc[0], (unsigned long long)(L.mp_att & 1u ? mp_region_bytes(L.cap_vertices) : 0), L.cap_vertices, (unsigned long long)end);
+    return 0;
+  }
   if (mode == "decode") {
     const bool force = argc > 4;
     Result R;

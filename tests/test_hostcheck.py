@@ -129,3 +129,25 @@ def test_corrupt_streams_never_leave_their_regions(exe, house04_bytes, tmp_path)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         counts = dict(zip(r.stdout.split()[::2], map(int, r.stdout.split()[1::2])))
         assert counts["ok"] + counts["invalid"] + counts["notimpl"] + counts["notgeneral"] == iters and counts["invalid"] > 0
+
+
+def test_the_sizing_parse_sets_the_multi_parallelogram_records_aside(exe, tmp_path):
+    """ConstrainedMultiParallelogram on the fast kernels needs 48 bytes per entry + the crease flags; the one scheme byte the host
+    parse can reach is the first attribute's, and only a stream that shows method 4 there gets the region (layout_mesh: mp_att)."""
+    pos, nrm, uv, faces = synth.make_mesh(synth.HOLES, 20, 16, 3)
+    def layout(data):
+        src = tmp_path / "l.drc"
+        src.write_bytes(data)
+        r = subprocess.run([exe, "layout", str(src), "-"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        w = r.stdout.split()
+        return dict(zip(w[::2], (int(x) for x in w[1::2])))
+    with_mp = layout(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, uv_prediction=5)))
+    assert with_mp["status"] == 0 and with_mp["first_method"] == 4 and with_mp["mp_att"] == 1 and with_mp["tc0"] != 0
+    assert with_mp["tc0_bytes"] >= 48 * with_mp["cap_vertices"] + with_mp["cap_vertices"] // 2
+    plain = layout(synth.encode_mesh(pos, faces, nrm, uv))
+    assert plain["first_method"] == 1 and plain["mp_att"] == 0 and plain["tc0"] == 0 and plain["end"] < with_mp["end"]
+    later = layout(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(uv_prediction=4)))       # the scheme on a later attribute: not seen
+    assert later["mp_att"] == 0
+    general = layout(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, traversal_method=1)))
+    assert general["general"] == 1 and general["mp_att"] == 0                                          # prediction-degree order: the general path
