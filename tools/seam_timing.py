@@ -1,7 +1,9 @@
 """Step time of the bench batch re-encoded with attribute seams: 4096 x 65 536-triangle meshes whose texture coordinates (and
 optionally normals) are given per corner (three UV charts: seams from boundary to boundary), with parallelogram or TexCoordsPortable
 prediction, standard or valence connectivity.  The batch cycles through 32 distinct meshes (the writer is the Python-driven CPU
-coder).  usage: python tools/seam_timing.py [meshes]"""
+coder).  Also: positions by ConstrainedMultiParallelogram (what stock encoders write at level 9).
+usage: python tools/seam_timing.py [meshes [variant numbers, comma separated]]; SEAM_TIMING_PAIR=1 in the environment adds the
+rate with two batches of the same streams in flight."""
 import sys, time
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
