@@ -938,7 +938,10 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     if (!positions_by_vertex) hipLaunchKernelGGL(dsa::k_vertex_positions, dim3(gv, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_predict_geometric, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     // TexCoordsPortable attributes: what depends on the mesh and the positions for every entry at once, then the chain over the
-    // decoded texture coordinates, one lane per attribute
+    // decoded texture coordinates, two lanes per attribute.  (The GeometricNormal kernels beside the chain, on another stream: the
+    // chain's 128 waves, placed while the machine is full, share SIMDs among themselves -- 16 -> 27 ms even when those kernels
+    // find nothing to do; kept one to a CU by an LDS allocation they still take 24 - 25 ms beside real GeometricNormal work,
+    // whose memory traffic outlasts the chain's request distance: 75 against 73 ms.  One after the other.)
     hipLaunchKernelGGL(dsa::k_texcoords_prepare, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     k_begin(KT_TEXCOORDS, st);
     hipLaunchKernelGGL(dsa::k_texcoords, dim3((2 * n + WAVE - 1) / WAVE, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);      // two lanes per attribute

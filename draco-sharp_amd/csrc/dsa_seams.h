@@ -649,6 +649,7 @@ __device__ __forceinline__ int32_t tc_div(int64_t su, int64_t d, double inv, boo
 __device__ __forceinline__ uint32_t tc_partner(uint32_t x) { return dpp_mov<0xB1>(x); }      // quad_perm [1, 0, 3, 2]
 __global__ __launch_bounds__(WAVE) void k_texcoords(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   __shared__ int32_t ring[TC_RING][WAVE];
+  __builtin_amdgcn_s_setprio(3);              // a handful of long chains: issue ahead of whatever shares the SIMD
   const uint32_t lane = lane_id();
   const uint32_t mesh = (blockIdx.x * WAVE + lane) >> 1, comp = lane & 1u, ai = blockIdx.y;
   if (mesh >= n) return;
@@ -935,6 +936,7 @@ __device__ __forceinline__ uint32_t mp_quad_sum(uint32_t x) {
 }
 __global__ __launch_bounds__(WAVE) void k_multipara(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
   __shared__ int32_t win[4][MP_WIN][4];
+  __builtin_amdgcn_s_setprio(3);              // long chains: issue ahead of whatever shares the SIMD
   const uint32_t lane = lane_id(), slot = lane >> 4, comp = (lane >> 2) & 3u, pi = lane & 3u, ai = blockIdx.y;
   const uint32_t mesh = blockIdx.x * 4u + slot;
   // (lanes without work run along on entry 0 of a mesh that is there, and store nothing)
