@@ -933,7 +933,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     // predictors that read the positions
     if (b->any_multipara) {
       hipLaunchKernelGGL(dsa::k_multipara_prepare, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
-      hipLaunchKernelGGL(dsa::k_multipara, dim3((n + 3) / 4, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+      hipLaunchKernelGGL(dsa::k_multipara, dim3((n + 3) / 4, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, b->d_globals);
     }
     if (!positions_by_vertex) hipLaunchKernelGGL(dsa::k_vertex_positions, dim3(gv, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_predict_geometric, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);

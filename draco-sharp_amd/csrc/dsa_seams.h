@@ -923,18 +923,20 @@ __global__ __launch_bounds__(256) void k_multipara_prepare(uint8_t *arena, const
 
 // The chain.  Lane l of a wave: attribute slot l >> 4 (four meshes to a wave), component c = (l >> 2) & 3, parallelogram i = l & 3
 // (the four parallelograms of a component in one quad: their sum is two DPP adds).
-// Per entry: the lane's triple and the correction were requested MP_AHEAD entries ago; half that far ahead, with the record there,
+// Per entry: the lane's triple was requested MP_AHEAD entries ago; half that far ahead, with the record there, the correction,
 // the flag word of the lane's parallelogram (its place follows from the counts of the entries before it) and the three operands as
 // memory holds them -- final for every entry further back than the window, which is all they are used for.  Operands inside the
 // window (the last MP_WIN results of the attribute, in LDS) are read when the entry's turn comes.  No load stands in a branch.
 #define MP_WIN 256u
-#define MP_AHEAD 8
+#define MP_AHEAD 16      // records requested this many entries ahead (the unrolled loop's length)
+#define MP_REST 8        // correction, flag word and operands from memory: this many ahead -- a request takes about as long as eight
+                         // entries, and a wave has 63 under way at most (16 x 1 + 8 x 5)
 __device__ __forceinline__ uint32_t mp_quad_sum(uint32_t x) {
   x += dpp_mov<0xB1>(x);            // quad_perm [1, 0, 3, 2]
   x += dpp_mov<0x4E>(x);            // quad_perm [2, 3, 0, 1]
   return x;
 }
-__global__ __launch_bounds__(WAVE) void k_multipara(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n) {
+__global__ __launch_bounds__(WAVE) void k_multipara(uint8_t *arena, const MeshLayout *layouts, MeshDesc *descs, uint32_t n, BatchGlobals *G) {
   __shared__ int32_t win[4][MP_WIN][4];
   __builtin_amdgcn_s_setprio(3);              // long chains: issue ahead of whatever shares the SIMD
   const uint32_t lane = lane_id(), slot = lane >> 4, comp = (lane >> 2) & 3u, pi = lane & 3u, ai = blockIdx.y;
@@ -953,7 +955,9 @@ __global__ __launch_bounds__(WAVE) void k_multipara(uint8_t *arena, const MeshLa
   for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)most, d, WAVE); most = o > most ? o : most; }
   most = uni(most);
   const uint32_t cc = comp < nc ? comp : 0u;                 // the component this lane reads (lanes beyond the last one shadow component 0)
-  const bool writer = mine && pi == 0 && comp < nc;
+  // where this lane's results go: its component of the attribute (a lane beyond the last component shadows component 0, value and all)
+  int32_t *wst = mine ? (int32_t *)(arena + L.work[ai]) + cc : (int32_t *)&G->pad;
+  const uint32_t wstride = mine ? nc : 0u;
   const MpPrep *prep = (const MpPrep *)(arena + (mine ? L.tc[ai] : L.stream));
   int32_t *w = (int32_t *)(arena + (mine ? L.work[ai] : L.stream));
   const uint32_t *cbits = mine ? mp_crease_words_of(arena, L, ai, L.cap_vertices) : (const uint32_t *)(arena + L.stream);
@@ -965,11 +969,10 @@ __global__ __launch_bounds__(WAVE) void k_multipara(uint8_t *arena, const MeshLa
   // rings of what was requested: [e % MP_AHEAD]
   uint32_t rid0[MP_AHEAD], rid1[MP_AHEAD], rid2[MP_AHEAD], rword[MP_AHEAD], rbit[MP_AHEAD];
   int32_t rcorr[MP_AHEAD], rg0[MP_AHEAD], rg1[MP_AHEAD], rg2[MP_AHEAD];
-  auto request_record = [&](uint32_t e, int s) {             // stage A: the triple of this lane's parallelogram and the correction
+  auto request_record = [&](uint32_t e, int s) {             // stage A: the triple of this lane's parallelogram
     const uint32_t q = e <= lastp ? e : lastp;
     const uint32_t *t = prep[q].id[pi];
     rid0[s] = t[0]; rid1[s] = t[1]; rid2[s] = t[2];
-    rcorr[s] = w[(size_t)q * nc + cc];
   };
   auto request_rest = [&](uint32_t e, int s) {               // stage B: the record is here -- the place of this lane's flag and its word; the operands from memory
     const uint32_t found = e <= lastp ? rid0[s] >> MP_FOUND_SHIFT : 0u;
@@ -983,6 +986,7 @@ __global__ __launch_bounds__(WAVE) void k_multipara(uint8_t *arena, const MeshLa
     for (uint32_t k = 0; k < 4; ++k) if (k == ctx) cpos[k] += found;
     rbit[s] = bit & 31u;
     rword[s] = cbits[base + (bit < nn ? bit >> 5 : 0u)];
+    rcorr[s] = w[(size_t)(e <= lastp ? e : lastp) * nc + cc];
     const uint32_t en = rid0[s] & MP_ID_MASK, ep = rid1[s], eo = rid2[s];       // (triples that were not found hold anything: clamped, and never used)
     rg0[s] = w[(size_t)(en <= lastp ? en : lastp) * nc + cc];
     rg1[s] = w[(size_t)(ep <= lastp ? ep : lastp) * nc + cc];
@@ -991,21 +995,31 @@ __global__ __launch_bounds__(WAVE) void k_multipara(uint8_t *arena, const MeshLa
 #pragma unroll
   for (int s = 0; s < MP_AHEAD; ++s) request_record((uint32_t)s, s);
 #pragma unroll
-  for (int s = 0; s < MP_AHEAD / 2; ++s) request_rest((uint32_t)s, s);
+  for (int s = 0; s < MP_REST; ++s) request_rest((uint32_t)s, s);
   int32_t o1 = 0;
   int32_t (*mywin)[4] = win[slot];
+  // The window reads of an entry are issued one entry early -- before the entry in front of it is finished -- so that the LDS round
+  // trip lies beside that entry's arithmetic instead of in the chain; what they cannot have seen, the result of the entry directly
+  // in front (the usual case for one operand: the strip's previous entry), comes from the register it was left in.
+  int32_t ln = 0, lp = 0, lo = 0;                            // (entry 0 has no operands)
   for (uint32_t g0 = 0; g0 < most; g0 += MP_AHEAD) {
 #pragma unroll
     for (int s = 0; s < MP_AHEAD; ++s) {
       const uint32_t p = g0 + (uint32_t)s;
       const bool live = p <= lastp && entries != 0;
+      // the window reads of entry p + 1 (its record arrived long ago: it was requested MP_AHEAD entries before its turn)
+      const int sn = (s + 1) % MP_AHEAD;
+      const uint32_t en1 = rid0[sn] & MP_ID_MASK, ep1 = rid1[sn], eo1 = rid2[sn];
+      const int32_t ln1 = mywin[en1 & (MP_WIN - 1u)][cc], lp1 = mywin[ep1 & (MP_WIN - 1u)][cc], lo1 = mywin[eo1 & (MP_WIN - 1u)][cc];
       const uint32_t found = rid0[s] >> MP_FOUND_SHIFT;
       const uint32_t en = rid0[s] & MP_ID_MASK, ep = rid1[s], eo = rid2[s];
       const bool crease = ((rword[s] >> rbit[s]) & 1u) != 0;
       const bool used = pi < found && !crease && live;
-      // window for what is near (memory may not have it yet), memory for the rest (requested four entries ago, written hundreds ago)
-      const int32_t ln = mywin[en & (MP_WIN - 1u)][cc], lp = mywin[ep & (MP_WIN - 1u)][cc], lo = mywin[eo & (MP_WIN - 1u)][cc];
-      const int32_t vn = p - en > MP_WIN ? rg0[s] : ln, vp = p - ep > MP_WIN ? rg1[s] : lp, vo = p - eo > MP_WIN ? rg2[s] : lo;
+      // the entry in front: the register; near: the window (memory may not have it yet); the rest: memory (requested four entries
+      // ago, written hundreds ago)
+      const int32_t vn = p - en == 1u ? o1 : (p - en > MP_WIN ? rg0[s] : ln);
+      const int32_t vp = p - ep == 1u ? o1 : (p - ep > MP_WIN ? rg1[s] : lp);
+      const int32_t vo = p - eo == 1u ? o1 : (p - eo > MP_WIN ? rg2[s] : lo);
       const uint32_t sum = mp_quad_sum(used ? (uint32_t)vn + (uint32_t)vp - (uint32_t)vo : 0u);
       const uint32_t cnt = mp_quad_sum(used ? 1u : 0u);
       // the average, truncated toward zero (the C# operator on the wrapped sum)
@@ -1017,18 +1031,23 @@ __global__ __launch_bounds__(WAVE) void k_multipara(uint8_t *arena, const MeshLa
       const int32_t pred = cnt ? q : (p ? o1 : 0);
       int32_t o = wrap_original(pred, rcorr[s], mn, mx, max_dif);
       o = live ? o : o1;
-      if (writer && live) w[(size_t)p * nc + comp] = o;
-      if (pi == 0) mywin[p & (MP_WIN - 1u)][comp] = o;
+      // (no store stands in a branch either: a join where the paths differ in what is under way makes the compiler wait for
+      // everything.  The four lanes of a quad hold the same result and write it to the same place; behind the last entry that
+      // entry is written again; lanes without an attribute write to a word of the batch's globals)
+      wst[(size_t)(live ? p : lastp) * wstride] = o;
+      mywin[p & (MP_WIN - 1u)][comp] = o;
       o1 = o;
+      ln = ln1; lp = lp1; lo = lo1;
       // the ring slot is free: the record MP_AHEAD entries on; and the rest for the entry half that far on, whose record is here
       request_record(p + MP_AHEAD, s);
-      request_rest(p + MP_AHEAD / 2, (s + MP_AHEAD / 2) % MP_AHEAD);
+      request_rest(p + MP_REST, (s + MP_REST) % MP_AHEAD);
     }
   }
   if (__ballot(ran_out && mine)) { if (ran_out && mine && pi == 0 && comp == 0) fail(D, ST_INVALID, 676); }
 }
 #undef MP_WIN
 #undef MP_AHEAD
+#undef MP_REST
 
 }  // namespace dsa
 
