@@ -1,5 +1,6 @@
 """Randomised differential run on larger meshes (6k-70k triangles, fast-path options): long symbol streams with
-many reservoir refills and window reloads at arbitrary alignments.  usage: python tools/soak_big.py [seed]"""
+many reservoir refills and window reloads at arbitrary alignments; the chains of TexCoordsPortable and ConstrainedMultiParallelogram
+over rings longer than their LDS windows.  usage: python tools/soak_big.py [seed]"""
 import sys
 import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, 'tools')
 import numpy as np, oracle, draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
@@ -10,7 +11,8 @@ for k in range(160):
     nx, ny = int(rng.integers(60, 220)), int(rng.integers(50, 160))
     opt = dict(pos_bits=int(rng.integers(8, 17)), uv_bits=int(rng.integers(8, 15)), normal_bits=int(rng.integers(6, 13)),
                single_connectivity=int(rng.integers(0, 2)), force_scheme=int(rng.choice([-1, -1, 1, 0])), compression_level=int(rng.integers(3, 9)),
-               pos_prediction=int(rng.choice([0, 1, 1])), uv_prediction=int(rng.choice([0, 1, 1])))
+               pos_prediction=int(rng.choice([0, 1, 1, 4])), uv_prediction=int(rng.choice([0, 1, 1, 5])),
+               normal_prediction=int(rng.choice([0, 0, 6])), predictive_connectivity=int(rng.choice([0, 0, 2])))
     pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, int(rng.integers(0, 1 << 30)))
     cases.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(**opt)))
 ctx = dsa.Context(0)
