@@ -1180,7 +1180,8 @@ static void plan_attributes(const MeshIn &in, const Options &opt, MeshPlan &pl) 
   { PortableAttr a; a.att_type = 0; a.nc = a.nc_out = 3; a.seq_type = 2; a.data_type = 9; a.prediction = opt.pos_prediction; a.bits = opt.pos_bits; pl.atts.push_back(a); }
   if (in.normals) { PortableAttr a; a.att_type = 1; a.nc_out = 3; a.nc = 2; a.seq_type = 3; a.data_type = 9; a.bits = opt.normal_bits; a.prediction = opt.normal_prediction == 6 ? 6 : 0; a.corner_value = in.normal_corners; pl.atts.push_back(a); }
   if (in.uvs) { PortableAttr a; a.att_type = 3; a.nc = a.nc_out = 2; a.seq_type = 2; a.data_type = 9; a.prediction = opt.uv_prediction; a.bits = opt.uv_bits; a.corner_value = in.uv_corners; pl.atts.push_back(a); }
-  if (in.generic) { PortableAttr a; a.att_type = 4; a.nc = a.nc_out = 1; a.seq_type = 1; a.data_type = 2; a.prediction = 1; pl.atts.push_back(a); }
+  // (the generic attribute takes the constrained multi-parallelogram scheme where the positions do: what an encoder at its highest levels writes)
+  if (in.generic) { PortableAttr a; a.att_type = 4; a.nc = a.nc_out = 1; a.seq_type = 1; a.data_type = 2; a.prediction = opt.pos_prediction == 4 ? 4 : 1; pl.atts.push_back(a); }
   pl.single = opt.single_connectivity != 0;
   pl.num_att_data = pl.single ? 0 : (uint32_t)pl.atts.size() - 1;
   pl.force_scheme = opt.force_scheme; pl.compression_level = opt.compression_level;

@@ -279,7 +279,10 @@ static inline uint64_t layout_mesh(const HostMesh &h, uint64_t stream_len, MeshL
     L.work[a] = take(4 * wcap); L.work_cap[a] = (uint32_t)wcap;
     L.out[a] = take_out(ocap, &OutCursors::values); L.out_cap[a] = (uint32_t)(ocap > 0xFFFFFFFFu ? 0xFFFFFFFFu : ocap);
     L.map[a] = take_out(4 * P, &OutCursors::maps);
-    const bool mp = a == 0 && h.faces != 0 && !h.general && h.first_method == 4 && !A.corner && ncp <= 4;
+    // ConstrainedMultiParallelogram records: the scheme shows at the head of the first attribute's values (positions), and an encoder
+    // that gives it to them gives it to every attribute the scheme applies to (integer / quantised, on the position connectivity,
+    // at most four components) -- those get the region too, whatever they turn out to use
+    const bool mp = h.faces != 0 && !h.general && h.first_method == 4 && !A.corner && ncp <= 4 && (A.seq_type == 1 || A.seq_type == 2);
     uint64_t prep = (h.faces != 0 && A.nc == 2 && (A.seq_type == 1 || A.seq_type == 2)) ? sizeof(TcPrep) * E : 0;
     if (mp) prep = std::max<uint64_t>(prep, mp_region_bytes(E));
     L.tc[a] = prep ? take(prep) : 0;

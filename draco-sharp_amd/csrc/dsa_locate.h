@@ -228,8 +228,9 @@ __device__ __forceinline__ int locate_attribute_section(Rd &r, MeshDesc *D, Attr
     if (D->encoder_type == 0) a.pred_kind = 0;
     else if (a.pred_transform == 1) {
       if (method == 2) NOTIMPL(DSA_SITE_RETRY_GENERAL);
-      // ConstrainedMultiParallelogram on the fast kernels where the host parse set its records aside (the first attribute; at most
-      // four components; located in the first pass) -- k_crease_bits, k_multipara_prepare, k_multipara (dsa_seams.h)
+      // ConstrainedMultiParallelogram on the fast kernels where the host parse set its records aside (a mesh whose first attribute
+      // shows the scheme: every attribute on the position connectivity with at most four components; located in the first pass)
+      // -- k_crease_bits, k_multipara_prepare, k_multipara (dsa_seams.h)
       if (method == 4 && (!((L.mp_att >> ai) & 1u) || L.tc[ai] == 0 || nc > 4 || a.corner_data != 0 || a.late_located != 0)) NOTIMPL(DSA_SITE_RETRY_GENERAL);
       if (!(method == 0 || method == 1 || method == 4 || method == 5 || method == 6)) NOTIMPL(161);
       a.pred_kind = method == 1 ? 1 : (method == 5 ? 3 : (method == 4 ? 4 : 0));

@@ -421,8 +421,8 @@ def test_schemes_behind_the_symbol_streams_take_the_second_chance(ctx):
     for npred in (0, 6):
         streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(uv_prediction=5, normal_prediction=npred, force_scheme=1)))
         geo.append(False)
-    # the multi-parallelogram schemes go to the general path
-    for ppred, upred in ((2, 1), (4, 4), (1, 2)):
+    # the plain multi-parallelogram scheme goes to the general path, and the constrained one where the first attribute does not show it
+    for ppred, upred in ((2, 1), (1, 4), (1, 2)):
         streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=ppred, uv_prediction=upred)))
         geo.append(True)
     b = run_batch(ctx, streams)
@@ -842,13 +842,18 @@ def test_the_bench_batch_at_full_size(ctx):
     ctx.trim()          # 26 GB of arena go back before the next test
 
 
+def k_scheme(i):
+    return (-1, 0, 1)[i % 3]
+
+
 @pytest.mark.gpu
 def test_constrained_multi_parallelogram_positions_on_the_fast_kernels(ctx):
     """What stock encoders write at their two highest compression levels: positions by ConstrainedMultiParallelogram (method 4), with
     TexCoordsPortable / GeometricNormal / parallelogram beside it.  The host parse sees the scheme byte of the first attribute (the
     values of the first decoder start with it) and sets the records aside; k_crease_bits, k_multipara_prepare and k_multipara decode
     it: decode_path 0 on every topology, with standard and valence connectivity, every symbol scheme, one 64k-triangle mesh and a
-    crowded batch -- and a second attribute with the scheme still takes the general path."""
+    crowded batch; texture coordinates and a generic attribute with the scheme beside such positions as well -- and a mesh whose first
+    attribute does not show the scheme still takes the general path for it."""
     streams = []
     for kind, nx, ny in KINDS + [(synth.HOLES, 40, 33), (synth.SPHERE, 30, 21)]:
         pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 31)
@@ -856,6 +861,10 @@ def test_constrained_multi_parallelogram_positions_on_the_fast_kernels(ctx):
                     dict(pos_bits=14, uv_prediction=5, normal_prediction=6, predictive_connectivity=2), dict(raw_integers=4)):
             streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, **opt)))
         streams.append(synth.encode_mesh(pos, faces, None, None, opt=synth.options(pos_prediction=4)))
+        # the scheme on the texture coordinates as well, and on a generic attribute (vertex colours of a scan): every attribute of the
+        # position connectivity gets its records where the first one shows the scheme
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, uv_prediction=4)))
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, generic=(np.arange(len(pos), dtype=np.int32) * 7919) % 251, opt=synth.options(pos_prediction=4, uv_prediction=4, force_scheme=k_scheme(len(streams)))))
     pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 128, 256, 5)
     streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, uv_prediction=5, normal_prediction=6, predictive_connectivity=2)))
     pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 128, 256, 6)
@@ -877,7 +886,7 @@ def test_constrained_multi_parallelogram_positions_on_the_fast_kernels(ctx):
         assert_same(b.result(i), oracle.decode(crowd[i]))
         assert b.mesh_info(i).decode_path == 0
     b.close()
-    # the scheme on a later attribute: the general path, as before
+    # the scheme on a later attribute of a mesh whose positions do not use it: the general path, as before
     pos, nrm, uv, faces = synth.make_mesh(synth.HOLES, 20, 16, 22)
     later = synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=1, uv_prediction=4))
     b = run_batch(ctx, [later, streams[0]])
