@@ -143,7 +143,9 @@ def test_the_sizing_parse_sets_the_multi_parallelogram_records_aside(exe, tmp_pa
         w = r.stdout.split()
         return dict(zip(w[::2], (int(x) for x in w[1::2])))
     with_mp = layout(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, uv_prediction=5)))
-    assert with_mp["status"] == 0 and with_mp["first_method"] == 4 and with_mp["mp_att"] == 1 and with_mp["tc0"] != 0
+    # positions (attribute 0) and texture coordinates (attribute 2: integer / quantised, on the position connectivity); not the
+    # octahedral normals (attribute 1)
+    assert with_mp["status"] == 0 and with_mp["first_method"] == 4 and with_mp["mp_att"] == 0b101 and with_mp["tc0"] != 0
     assert with_mp["tc0_bytes"] >= 48 * with_mp["cap_vertices"] + with_mp["cap_vertices"] // 2
     plain = layout(synth.encode_mesh(pos, faces, nrm, uv))
     assert plain["first_method"] == 1 and plain["mp_att"] == 0 and plain["tc0"] == 0 and plain["end"] < with_mp["end"]
