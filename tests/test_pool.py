@@ -76,3 +76,67 @@ def test_two_contexts_on_one_gpu_decode_a_job():
     for j in (job, job2, job3):
         j.close()
     pool.close()
+
+
+@pytest.mark.gpu
+def test_a_job_is_freed_while_the_next_one_decodes():
+    """The threading contract of include/draco_mi355x.h: jobs and batches of one context may be freed from another thread while the
+    context decodes (the caches of a context -- spare arenas, mirrors, descriptor blocks -- and its batch count are behind its
+    mutex).  A consumer thread closes job N while the pool decodes job N + 1 on the same contexts, sixteen times over; and batches
+    of one Context are dropped by one thread while another decodes on it."""
+    import threading
+    streams = []
+    for i in range(96):
+        kind = [synth.GRID, synth.TORUS, synth.HOLES, synth.SPHERE][i % 4]
+        pos, nrm, uv, faces = synth.make_mesh(kind, 16 + i % 20, 14 + (5 * i) % 17, 900 + i)
+        streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(uv_prediction=5 if i % 3 == 0 else 1)))
+    refs = [oracle.decode(s) for s in streams[:6]]
+    pool = dsa.Pool([0, 0], chunk_meshes=8)
+    errors = []
+    def check_and_close(job):
+        try:
+            for i in range(6):
+                assert job.status(i) == 0
+                m = job.result(i).ConnectedData
+                assert np.array_equal(m.Faces, refs[i].faces)
+                for a, r in zip(m.Attributes, refs[i].attributes):
+                    assert a.Values.tobytes() == r.values.tobytes()
+            job.close()
+        except Exception as e:                              # noqa: BLE001 (reported by the test thread)
+            errors.append(e)
+    prev = None
+    for round_ in range(16):
+        job = pool.decode(streams)                          # (runs its workers; the previous job is being read and freed meanwhile)
+        if prev is not None:
+            prev.join()
+        prev = threading.Thread(target=check_and_close, args=(job,))
+        prev.start()
+    prev.join()
+    pool.close()
+    assert not errors, errors[:2]
+    # one Context: a thread frees finished batches while the main thread builds and decodes new ones
+    ctx = dsa.Context(0)
+    done = []
+    lock = threading.Lock()
+    stop = threading.Event()
+    def reaper():
+        while not stop.is_set() or done:
+            with lock:
+                b = done.pop() if done else None
+            if b is not None:
+                try:
+                    assert b.status(0) == 0
+                    b.close()
+                except Exception as e:                      # noqa: BLE001
+                    errors.append(e)
+    t = threading.Thread(target=reaper)
+    t.start()
+    for k in range(40):
+        b = dsa.Batch(ctx, streams[(k * 7) % 64:(k * 7) % 64 + 24])
+        b.decode()
+        with lock:
+            done.append(b)
+    stop.set()
+    t.join()
+    ctx.close()
+    assert not errors, errors[:2]
