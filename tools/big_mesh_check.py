@@ -1,5 +1,5 @@
 """One-off: parity + stage times on multi-million-triangle meshes (single wave per mesh: latency-bound)."""
-import sys; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import sys, os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, time, oracle, draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
 import test_gpu_parity as T
 ctx = dsa.Context(0); ctx.set_profiling(True)

@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import sys, os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, draco_sharp_amd as dsa, draco_sharp_amd.synth as synth
 n = int(sys.argv[1]) if len(sys.argv)>1 else 512
 blob, offs = synth.make_batch(synth.GRID,128,256,1000,n)
