@@ -3478,34 +3478,38 @@ __device__ __forceinline__ void geometric_entries(uint8_t *arena, const MeshLayo
       uint32_t c = ci, steps = 0;
       bool left = true;
       while (ok) {
+        // Where the fan goes next follows from the record alone: the next face's record is requested BEFORE this face's cross
+        // product waits for its position -- one memory round trip per face in the chain of an entry instead of two.
+        uint32_t nc = DSA_INVALID;
+        bool nleft = left, done = false, restart = false;
+        if (left) {
+          const uint32_t ol = R::opp(rec, k_next(c & 3u));                    // SwingLeft: Next(Opposite(Next(c)))
+          if (ol != DSA_INVALID) { nc = qnext(ol); done = nc == ci; }         // (all the way round)
+          else { nleft = false; restart = true; }                             // a boundary: the rest of the fan to the right of the start corner
+        }
+        if (!nleft && !done) {
+          const uint32_t orr = restart ? R::opp(first, k_prev(ci & 3u)) : R::opp(rec, k_prev(c & 3u));     // SwingRight: Previous(Opposite(Previous(c)))
+          if (orr == DSA_INVALID) done = true; else nc = qprev(orr);
+        }
+        const bool nvalid = !done && (nc >> 2) < F && (nc & 3u) != 3u;
+        const typename R::Raw nrec = load_rec(nvalid ? nc >> 2 : ci >> 2);
         coord u[3], v[3];
         for (int k = 0; k < 3; ++k) { u[k] = pn[k] - center[k]; v[k] = pp[k] - center[k]; }
         nsum[0] += (uint64_t)((int64_t)u[1] * v[2]) - (uint64_t)((int64_t)u[2] * v[1]);
         nsum[1] += (uint64_t)((int64_t)u[2] * v[0]) - (uint64_t)((int64_t)u[0] * v[2]);
         nsum[2] += (uint64_t)((int64_t)u[0] * v[1]) - (uint64_t)((int64_t)u[1] * v[0]);
         if (++steps > 3u * F + 1u) { ok = false; break; }
-        if (left) {
-          const uint32_t ol = R::opp(rec, k_next(c & 3u));                    // SwingLeft: Next(Opposite(Next(c)))
-          if (ol != DSA_INVALID) {
-            c = qnext(ol);
-            if (c == ci) break;                                               // all the way round
-            if ((c >> 2) >= F || (c & 3u) == 3u) { ok = false; break; }
-            rec = load_rec(c >> 2);
-            for (int k = 0; k < 3; ++k) pn[k] = pp[k];                         // the shared edge's far vertex is now ahead of the corner
-            position(R::vertex(rec, k_prev(c & 3u)), pp);
-            continue;
-          }
-          left = false;                                                       // a boundary: the rest of the fan to the right of the start corner
-          c = ci; rec = first;
-          for (int k = 0; k < 3; ++k) pn[k] = pn0[k];
+        if (done) break;
+        if (!nvalid) { ok = false; break; }
+        if (nleft) {
+          for (int k = 0; k < 3; ++k) pn[k] = pp[k];                           // the shared edge's far vertex is now ahead of the corner
+          position(R::vertex(nrec, k_prev(nc & 3u)), pp);
+        } else {
+          if (restart) for (int k = 0; k < 3; ++k) pn[k] = pn0[k];
+          for (int k = 0; k < 3; ++k) pp[k] = pn[k];                           // the shared edge's far vertex is now behind the corner
+          position(R::vertex(nrec, k_next(nc & 3u)), pn);
         }
-        const uint32_t orr = R::opp(rec, k_prev(c & 3u));                     // SwingRight: Previous(Opposite(Previous(c)))
-        if (orr == DSA_INVALID) break;
-        c = qprev(orr);
-        if ((c >> 2) >= F || (c & 3u) == 3u) { ok = false; break; }
-        rec = load_rec(c >> 2);
-        for (int k = 0; k < 3; ++k) pp[k] = pn[k];                             // the shared edge's far vertex is now behind the corner
-        position(R::vertex(rec, k_next(c & 3u)), pn);
+        c = nc; rec = nrec; left = nleft;
       }
     }
     if (!ok) { fail(D, ST_INVALID, 650); continue; }
