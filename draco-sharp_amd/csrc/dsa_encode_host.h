@@ -704,6 +704,7 @@ struct Options {
   int32_t raw_integers = 0;          // 1 / 2 / 4: values of the difference / parallelogram attributes stored uncompressed at that many
                                      // bytes (SequentialIntegerAttributeDecoder.cs:68-84)
   int32_t no_prediction = 0;         // bit 0 positions, bit 1 texture coordinates, bit 2 normals: prediction method -2 (none)
+  int32_t generic_components = 1;    // components of the generic attribute (uint8 each: 4 = the RGBA colours of a scan); CPU coder only
 };
 
 // Octahedral quantisation (OctahedronToolBox.cs:28-119)
@@ -1181,7 +1182,7 @@ static void plan_attributes(const MeshIn &in, const Options &opt, MeshPlan &pl) 
   if (in.normals) { PortableAttr a; a.att_type = 1; a.nc_out = 3; a.nc = 2; a.seq_type = 3; a.data_type = 9; a.bits = opt.normal_bits; a.prediction = opt.normal_prediction == 6 ? 6 : 0; a.corner_value = in.normal_corners; pl.atts.push_back(a); }
   if (in.uvs) { PortableAttr a; a.att_type = 3; a.nc = a.nc_out = 2; a.seq_type = 2; a.data_type = 9; a.prediction = opt.uv_prediction; a.bits = opt.uv_bits; a.corner_value = in.uv_corners; pl.atts.push_back(a); }
   // (the generic attribute takes the constrained multi-parallelogram scheme where the positions do: what an encoder at its highest levels writes)
-  if (in.generic) { PortableAttr a; a.att_type = 4; a.nc = a.nc_out = 1; a.seq_type = 1; a.data_type = 2; a.prediction = opt.pos_prediction == 4 ? 4 : 1; pl.atts.push_back(a); }
+  if (in.generic) { PortableAttr a; a.att_type = 4; a.nc = a.nc_out = opt.generic_components >= 1 && opt.generic_components <= 4 ? opt.generic_components : 1; a.seq_type = 1; a.data_type = 2; a.prediction = opt.pos_prediction == 4 ? 4 : 1; pl.atts.push_back(a); }
   pl.single = opt.single_connectivity != 0;
   pl.num_att_data = pl.single ? 0 : (uint32_t)pl.atts.size() - 1;
   pl.force_scheme = opt.force_scheme; pl.compression_level = opt.compression_level;
@@ -1331,7 +1332,7 @@ static void encode_mesh(const MeshIn &in, const Options &opt, std::vector<uint8_
       a.vals.resize((size_t)n * 2);
       for (uint32_t v = 0; v < n; ++v) { int s, t; o.from_float_vector(in.normals + (size_t)v * 3, s, t); a.vals[(size_t)v * 2] = s; a.vals[(size_t)v * 2 + 1] = t; }
     } else if (a.att_type == 3) quantize(in.uvs, in.uv_corners ? in.nu : in.nv, 2, opt.uv_bits, a);
-    else { a.vals.resize(in.nv); for (uint32_t v = 0; v < in.nv; ++v) a.vals[v] = in.generic[v]; }
+    else { a.vals.resize((size_t)in.nv * a.nc); for (size_t k = 0; k < (size_t)in.nv * a.nc; ++k) a.vals[k] = in.generic[k]; }
   }
   ByteWriter w;
   write_stream(w, in, pl,

@@ -18,7 +18,8 @@ class Options(C.Structure):
                 ("single_connectivity", C.c_int32), ("force_scheme", C.c_int32),
                 ("compression_level", C.c_int32), ("pos_prediction", C.c_int32), ("uv_prediction", C.c_int32),
                 ("normal_prediction", C.c_int32), ("traversal_method", C.c_int32), ("predictive_connectivity", C.c_int32),
-                ("normal_transform", C.c_int32), ("raw_integers", C.c_int32), ("no_prediction", C.c_int32)]
+                ("normal_transform", C.c_int32), ("raw_integers", C.c_int32), ("no_prediction", C.c_int32),
+                ("generic_components", C.c_int32)]
 
 
 def build(force=False):

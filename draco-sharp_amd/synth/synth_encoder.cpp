@@ -116,7 +116,7 @@ extern "C" {
 
 struct synth_options {
   int32_t pos_bits, uv_bits, normal_bits, single_connectivity, force_scheme, compression_level, pos_prediction, uv_prediction, normal_prediction, traversal_method, predictive_connectivity,
-      normal_transform, raw_integers, no_prediction;
+      normal_transform, raw_integers, no_prediction, generic_components;
 };
 
 static thread_local char g_err[256];
@@ -130,7 +130,7 @@ static synth::Options to_opt(const synth_options *o) {
     r.compression_level = o->compression_level; r.pos_prediction = o->pos_prediction; r.uv_prediction = o->uv_prediction;
     r.normal_prediction = o->normal_prediction; r.traversal_method = o->traversal_method;
     r.predictive_connectivity = o->predictive_connectivity;
-    r.normal_transform = o->normal_transform; r.raw_integers = o->raw_integers; r.no_prediction = o->no_prediction;
+    r.normal_transform = o->normal_transform; r.raw_integers = o->raw_integers; r.no_prediction = o->no_prediction; r.generic_components = o->generic_components;
   }
   return r;
 }
@@ -140,7 +140,7 @@ void synth_default_options(synth_options *o) {
   o->force_scheme = d.force_scheme; o->compression_level = d.compression_level; o->pos_prediction = d.pos_prediction; o->uv_prediction = d.uv_prediction;
   o->normal_prediction = d.normal_prediction; o->traversal_method = d.traversal_method;
   o->predictive_connectivity = d.predictive_connectivity;
-  o->normal_transform = d.normal_transform; o->raw_integers = d.raw_integers; o->no_prediction = d.no_prediction;
+  o->normal_transform = d.normal_transform; o->raw_integers = d.raw_integers; o->no_prediction = d.no_prediction; o->generic_components = d.generic_components;
 }
 
 // Encodes one mesh.  normals/uvs/generic may be NULL.  *out is malloc'ed; free with synth_free.

@@ -865,6 +865,10 @@ def test_constrained_multi_parallelogram_positions_on_the_fast_kernels(ctx):
         # position connectivity gets its records where the first one shows the scheme
         streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, uv_prediction=4)))
         streams.append(synth.encode_mesh(pos, faces, nrm, uv, generic=(np.arange(len(pos), dtype=np.int32) * 7919) % 251, opt=synth.options(pos_prediction=4, uv_prediction=4, force_scheme=k_scheme(len(streams)))))
+        # four components (the RGBA colours of a scan) and two
+        for gc in (4, 2):
+            g = ((np.arange(len(pos) * gc, dtype=np.int64) * 7919) % 251).astype(np.uint8).reshape(-1, gc)
+            streams.append(synth.encode_mesh(pos, faces, nrm, uv, generic=g, opt=synth.options(pos_prediction=4, uv_prediction=5, normal_prediction=6, generic_components=gc)))
     pos, nrm, uv, faces = synth.make_mesh(synth.GRID, 128, 256, 5)
     streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(pos_prediction=4, uv_prediction=5, normal_prediction=6, predictive_connectivity=2)))
     pos, nrm, uv, faces = synth.make_mesh(synth.TORUS, 128, 256, 6)
@@ -946,4 +950,25 @@ def test_constrained_multi_parallelogram_with_seams_and_corrupt_streams(ctx):
             assert_same(b.result(i), ref)
     # (the device path's own validations, as in the other corrupt-stream tests: counts that exceed what the mesh can hold)
     assert set(stricter) <= {(1, 263), (1, 305), (1, 668), (1, 657), (1, 681), (1, 673), (1, 676)}, stricter
+    b.close()
+
+
+@pytest.mark.gpu
+def test_generic_attributes_of_one_to_four_components(ctx):
+    """Per-vertex uint8 attributes of 1 - 4 components (vertex colours) through the symbol, prediction and output kernels, with the
+    parallelogram scheme and with difference coding, tagged and raw symbols: equal to the oracle, on the wave-per-mesh kernels."""
+    streams = []
+    for kind, nx, ny in KINDS:
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 47)
+        for gc in (1, 2, 3, 4):
+            g = ((np.arange(len(pos) * gc, dtype=np.int64) * 104729 + 17 * gc) % 256).astype(np.uint8).reshape(-1, gc)
+            for opt in (dict(), dict(force_scheme=0), dict(pos_prediction=0), dict(predictive_connectivity=2, uv_prediction=5, normal_prediction=6)):
+                streams.append(synth.encode_mesh(pos, faces, nrm, uv, generic=g, opt=synth.options(generic_components=gc, **opt)))
+    b = run_batch(ctx, streams)
+    for i, sbytes in enumerate(streams):
+        assert b.status(i) == 0, (i, b.mesh_info(i).detail)
+        ref = oracle.decode(sbytes)
+        assert ref.attributes[-1].att_type == 4
+        assert_same(b.result(i), ref, b, i)
+        assert b.mesh_info(i).decode_path == 0
     b.close()

@@ -236,3 +236,18 @@ def test_rare_decoder_branches(kind, nx, ny, opt):
     assert np.array_equal(m.faces, ref.faces)
     for a, r in zip(m.attributes, ref.attributes):
         assert np.array_equal(a.portable, r.portable) and a.values.tobytes() == r.values.tobytes() and np.array_equal(a.point_map, r.point_map)
+
+
+def test_generic_attributes_of_several_components_round_trip():
+    """The writer's generic attribute with 1 - 4 uint8 components (vertex colours): the oracle returns the input values per point."""
+    pos, nrm, uv, faces = synth.make_mesh(synth.HOLES, 20, 16, 5)
+    for gc in (1, 2, 3, 4):
+        g = ((np.arange(len(pos) * gc, dtype=np.int64) * 7919 + gc) % 256).astype(np.uint8).reshape(-1, gc)
+        for opt in (dict(), dict(pos_prediction=4), dict(force_scheme=0), dict(single_connectivity=1)):
+            data = synth.encode_mesh(pos, faces, nrm, uv, generic=g, opt=synth.options(generic_components=gc, **opt))
+            m = oracle.decode(data)
+            a = m.attributes[-1]
+            assert a.att_type == 4 and a.num_components == gc and a.values.dtype == np.uint8
+            per_point = np.asarray(a.values).reshape(-1, gc)[a.point_map if len(a.point_map) else np.arange(m.num_points)]
+            # the points of a per-vertex mesh are its vertices in another order: the same rows
+            assert sorted(map(tuple, per_point.tolist())) == sorted(map(tuple, g.tolist()))
