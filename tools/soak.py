@@ -41,7 +41,13 @@ def random_case(rng):
         pos, faces, nrm, nid, uv, uid = seamed_mesh(synth, kind, nx, ny, mesh_seed, *charts)
         return synth.encode_mesh_corners(pos, faces, nrm if with_n else None, nid if with_n else None, uv if with_uv else None, uid if with_uv else None,
                                          opt=synth.options(**opt)), (kind, nx, ny, opt, with_n, with_uv, charts)
-    return synth.encode_mesh(pos, faces, nrm if with_n else None, uv if with_uv else None, opt=synth.options(**opt)), (kind, nx, ny, opt, with_n, with_uv)
+    # one per-vertex case in four carries a generic attribute of 1 - 4 uint8 components (vertex colours)
+    gen = None
+    if rng.integers(0, 4) == 0:
+        gc = int(rng.integers(1, 5))
+        opt["generic_components"] = gc
+        gen = rng.integers(0, 256, (len(pos), gc)).astype(np.uint8)
+    return synth.encode_mesh(pos, faces, nrm if with_n else None, uv if with_uv else None, generic=gen, opt=synth.options(**opt)), (kind, nx, ny, opt, with_n, with_uv)
 
 
 def run(count, seed, ctx=None):
