@@ -48,6 +48,9 @@ public sealed unsafe class GpuDracoEncoder : IDisposable
                 inputs[i].Positions = (float*)Pin(Floats(m, GeometryAttributeType.Position, 3), pins);
                 inputs[i].Normals = (float*)Pin(Floats(m, GeometryAttributeType.Normal, 3), pins);
                 inputs[i].Texcoords = (float*)Pin(Floats(m, GeometryAttributeType.TexCoord, 2), pins);
+                var generic = Bytes(m, GeometryAttributeType.Generic, out uint genericComponents);      // uint8 attributes of 1 - 4 components
+                inputs[i].Generic = (byte*)Pin(generic, pins);
+                inputs[i].GenericComponents = generic == null ? 0 : genericComponents;
                 var faces = new uint[m.FacesCount * 3];
                 for (int f = 0; f < m.FacesCount; ++f) { var face = m.GetFace((uint)f); faces[3 * f] = (uint)face[0]; faces[3 * f + 1] = (uint)face[1]; faces[3 * f + 2] = (uint)face[2]; }
                 inputs[i].Faces = (uint*)Pin(faces, pins);
@@ -77,6 +80,19 @@ public sealed unsafe class GpuDracoEncoder : IDisposable
         var v = new float[m.PointsCount * nc];
         for (uint p = 0; p < m.PointsCount; ++p)
             for (int c = 0; c < nc; ++c) v[p * nc + c] = a.Buffer!.Read<float>((int)(a.MappedIndex(p) * a.ByteStride + 4 * c));
+        return v;
+    }
+
+    // a uint8 attribute of 1 - 4 components per point (the first of its type), or null
+    private static byte[]? Bytes(Mesh.Mesh m, GeometryAttributeType type, out uint nc)
+    {
+        nc = 0;
+        var a = m.GetNamedAttribute(type);
+        if (a == null || a.DataType != DataType.UInt8 || a.NumComponents < 1 || a.NumComponents > 4) return null;
+        nc = (uint)a.NumComponents;
+        var v = new byte[m.PointsCount * nc];
+        for (uint p = 0; p < m.PointsCount; ++p)
+            for (int c = 0; c < nc; ++c) v[p * nc + c] = a.Buffer!.Read<byte>((int)(a.MappedIndex(p) * a.ByteStride + c));
         return v;
     }
 

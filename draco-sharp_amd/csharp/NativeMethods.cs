@@ -77,6 +77,9 @@ internal unsafe struct DsaMeshInput
     public uint* Faces;
     public float* Normals;
     public float* Texcoords;
+    public byte* Generic;           // ABI 4: num_vertices * GenericComponents bytes or null
+    public uint GenericComponents;
+    public uint Reserved;
 }
 
 internal static unsafe partial class NativeMethods

@@ -38,7 +38,7 @@ struct EncStream {                 // one per (mesh, attribute); lives in device
   uint64_t hist_raw;               // u32[hist_cap]
   uint64_t out_rans, out_bits;     // coded bytes
   uint64_t prob, cum;              // u32[num_symbols] (filled by the host between the two device phases)
-  uint32_t nv, nc_out, nc, kind;   // kind 0: quantised + wrap, 1: normals (octahedral, canonicalised delta)
+  uint32_t nv, nc_out, nc, kind;   // kind 0: quantised + wrap, 1: normals (octahedral, canonicalised delta), 2: uint8 integers + wrap (src: bytes)
   uint32_t bits, prediction, hist_cap, out_cap;
   float qmin[4], qrange;
   int32_t wrap_mn, wrap_mx;
@@ -124,6 +124,10 @@ __global__ __launch_bounds__(256) void k_enc_quantize(uint8_t *arena, EncStream 
       const float v = __fsub_rn(src[i], S.qmin[i % nc]);
       vals[i] = (int32_t)floorf(__fadd_rn(__fmul_rn(v, inv_delta), 0.5f));
     }
+  } else if (S.kind == 2) {         // an integer attribute: its values as they are (SequentialIntegerAttributeEncoder.cs: no transform)
+    const uint8_t *srcb = arena + S.src;
+    const uint32_t total = S.nv * S.nc;
+    for (uint32_t i = tid; i < total; i += stride) vals[i] = (int32_t)srcb[i];
   } else {
     for (uint32_t v = tid; v < S.nv; v += stride) {
       int32_t s, t;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void k_enc_corr(uint8_t *arena, EncStream *str
   const int32_t o_max_q = (1 << S.bits) - 1, o_center = (o_max_q - 1) / 2;
   for (uint32_t p = tid; p < S.nv; p += stride) {
     uint32_t mc = 0;
-    if (S.kind == 0) {
+    if (S.kind != 1) {
       int32_t vn = -1, vp = -1, vo = -1;
       if (S.prediction == 1 && p > 0) { vn = ops[3 * p]; vp = ops[3 * p + 1]; vo = ops[3 * p + 2]; }
       for (uint32_t c = 0; c < nc; ++c) {
@@ -513,13 +517,16 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, uint
   auto plan_one = [&](uint32_t i) {
     const dsa_mesh_input &m = meshes[i];
     synth::MeshIn &in = ins[i];
-    in.pos = m.positions; in.nv = m.num_vertices; in.faces = m.faces; in.nf = m.num_faces; in.normals = m.normals; in.uvs = m.texcoords; in.generic = nullptr;
+    in.pos = m.positions; in.nv = m.num_vertices; in.faces = m.faces; in.nf = m.num_faces; in.normals = m.normals; in.uvs = m.texcoords;
+    in.generic = (m.generic && m.generic_components >= 1 && m.generic_components <= 4) ? m.generic : nullptr;
     try {
       synth::check(m.positions && m.faces && m.num_vertices >= 3 && m.num_faces >= 1, "mesh needs positions and faces");
       for (size_t k = 0; k < (size_t)m.num_faces * 3; ++k) synth::check(m.faces[k] < m.num_vertices, "face index out of range");
       synth::check(host_conn || (uint64_t)m.num_faces * 3 <= (uint64_t)dsa::EC_CORNER_MASK, "mesh too large for the device connectivity coder");
-      if (!host_conn) { synth::plan_attributes(in, opt, plans[i]); return; }      // the rest of the plan comes from the device
-      synth::plan_mesh(in, opt, plans[i]);
+      synth::Options mo = opt;                                   // (the components of the generic attribute are the mesh's own)
+      mo.generic_components = in.generic ? (int32_t)m.generic_components : 1;
+      if (!host_conn) { synth::plan_attributes(in, mo, plans[i]); return; }       // the rest of the plan comes from the device
+      synth::plan_mesh(in, mo, plans[i]);
       const synth::MeshPlan &pl = plans[i];
       const uint32_t V = m.num_vertices;
       e2v[i].resize(V);
@@ -592,11 +599,13 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, uint
     for (auto &a : plans[i].atts) {
       dsa::EncStream S;
       memset(&S, 0, sizeof(S));
-      const float *src = a.att_type == 0 ? meshes[i].positions : (a.att_type == 1 ? meshes[i].normals : meshes[i].texcoords);
-      S.nv = V; S.nc_out = (uint32_t)a.nc_out; S.nc = (uint32_t)a.nc; S.kind = a.seq_type == 3 ? 1u : 0u;
-      S.bits = (uint32_t)a.bits; S.prediction = (uint32_t)a.prediction;
-      S.src = take_in(4ull * V * S.nc_out);
-      uploads.push_back({S.src, src, 4ull * V * S.nc_out, false});
+      const bool integer = a.att_type == 4;                  // the generic uint8 attribute
+      const void *src = a.att_type == 0 ? (const void *)meshes[i].positions : (a.att_type == 1 ? (const void *)meshes[i].normals : (integer ? (const void *)meshes[i].generic : (const void *)meshes[i].texcoords));
+      S.nv = V; S.nc_out = (uint32_t)a.nc_out; S.nc = (uint32_t)a.nc; S.kind = a.seq_type == 3 ? 1u : (integer ? 2u : 0u);
+      S.bits = integer ? 9u : (uint32_t)a.bits; S.prediction = (uint32_t)a.prediction;      // (9: the zig-zagged corrections of bytes are below 512)
+      const uint64_t src_bytes = (integer ? 1ull : 4ull) * V * S.nc_out;
+      S.src = take_in(src_bytes);
+      uploads.push_back({S.src, src, src_bytes, false});
       S.e2v = o_e2v; S.ops = o_ops;
       S.vals = take(4ull * V * S.nc); S.d = take(4ull * V * S.nc); S.syms = take(4ull * V * S.nc); S.bl = take(V);
       S.hist_cap = (1u << S.bits) + 2u;                      // zig-zag of a wrapped correction / a positive octahedral correction fits
@@ -903,7 +912,7 @@ static dsa_status encode_chunk(dsa_context *ctx, EncLane &lane, uint32_t n, uint
       [&](synth::ByteWriter &bw, size_t k) {               // AttributeQuantizationTransform.cs:123-134 / AttributeOctahedronTransform.cs:44-47
         const dsa::EncStream &S = hs[s0 + k];
         if (S.kind == 0) { for (uint32_t c = 0; c < S.nc_out; ++c) bw.f32(S.qmin[c]); bw.f32(S.qrange); bw.u8((uint8_t)S.bits); }
-        else bw.u8((uint8_t)S.bits);
+        else if (S.kind == 1) bw.u8((uint8_t)S.bits);            // (an integer attribute has no transform to describe)
       });
     } catch (const std::exception &e) { E->status[i] = DSA_ERR_INVALID_DATA; E->messages[i] = e.what(); return; }
     E->streams[i].swap(w.d);

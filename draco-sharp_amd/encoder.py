@@ -39,13 +39,21 @@ class Config:
 
 
 class MeshData:
-    """Triangle mesh with per-vertex attributes: positions (V,3) f32, faces (F,3) u32, optional normals (V,3), uvs (V,2)."""
+    """Triangle mesh with per-vertex attributes: positions (V,3) f32, faces (F,3) u32, optional normals (V,3), uvs (V,2) and one
+    generic uint8 attribute of 1 - 4 components (V,) or (V,C): vertex colours, ids (ABI 4)."""
 
-    def __init__(self, positions, faces, normals=None, texcoords=None):
+    def __init__(self, positions, faces, normals=None, texcoords=None, generic=None):
         self.positions = np.ascontiguousarray(positions, np.float32)
         self.faces = np.ascontiguousarray(faces, np.uint32)
         self.normals = None if normals is None else np.ascontiguousarray(normals, np.float32)
         self.texcoords = None if texcoords is None else np.ascontiguousarray(texcoords, np.float32)
+        self.generic = None
+        if generic is not None:
+            g = np.ascontiguousarray(generic, np.uint8)
+            g = g.reshape(len(g), -1)
+            if len(g) != len(self.positions) or not 1 <= g.shape[1] <= 4:
+                raise ValueError("generic attribute: one row of 1 - 4 uint8 components per vertex")
+            self.generic = g
 
 
 class EncodedStreams:
@@ -119,6 +127,9 @@ class DracoEncoder:
             arr[i].positions, arr[i].faces = m.positions.ctypes.data, m.faces.ctypes.data
             arr[i].normals = m.normals.ctypes.data if m.normals is not None else None
             arr[i].texcoords = m.texcoords.ctypes.data if m.texcoords is not None else None
+            g = getattr(m, "generic", None)
+            arr[i].generic = g.ctypes.data if g is not None else None
+            arr[i].generic_components = g.shape[1] if g is not None else 0
         opt = (config or Config())._native()
         h = C.c_void_p()
         t0 = time.perf_counter()

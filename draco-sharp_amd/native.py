@@ -36,7 +36,8 @@ class EncodeOptions(C.Structure):
 
 class MeshInput(C.Structure):
     _fields_ = [("num_vertices", C.c_uint32), ("num_faces", C.c_uint32), ("positions", C.c_void_p), ("faces", C.c_void_p),
-                ("normals", C.c_void_p), ("texcoords", C.c_void_p)]
+                ("normals", C.c_void_p), ("texcoords", C.c_void_p), ("generic", C.c_void_p), ("generic_components", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class MeshInfo(C.Structure):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DSA_ABI_VERSION 3
+#define DSA_ABI_VERSION 4
 #define DSA_MAX_ATTRIBUTES 16  /* attributes per mesh handled by the device path; more: DSA_ERR_NOT_IMPLEMENTED */
 #define DSA_NUM_STAGES 8
 
@@ -241,6 +241,12 @@ typedef struct dsa_mesh_input {
   const uint32_t *faces;       /* num_faces * 3 vertex indices; manifold, no isolated vertices */
   const float *normals;        /* num_vertices * 3 or NULL */
   const float *texcoords;      /* num_vertices * 2 or NULL */
+  /* ABI 4: one generic attribute of 1 - 4 uint8 components per vertex (vertex colours, material ids ...), coded as an integer
+   * attribute (SequentialAttributeEncoderType.Integer, GeometryAttributeType.Generic) with the prediction of the positions'
+   * family (difference / parallelogram); NULL / 0: none */
+  const uint8_t *generic;      /* num_vertices * generic_components or NULL */
+  uint32_t generic_components;
+  uint32_t reserved;
 } dsa_mesh_input;
 
 typedef struct dsa_encoded dsa_encoded;

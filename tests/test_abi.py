@@ -24,7 +24,7 @@ def test_header_symbols_are_exported():
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     assert sorted(names) == sorted(native.EXPORTS)
-    assert L.dsa_abi_version() == 3          # 3: dsa_batch_kernel_times, dsa_context_trim, two stream sets per context
+    assert L.dsa_abi_version() == 4          # 4: dsa_mesh_input carries a generic uint8 attribute (3: dsa_batch_kernel_times, dsa_context_trim, two stream sets)
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -280,3 +280,47 @@ def test_more_than_65536_vertices_keep_32_bit_faces(ctx, monkeypatch):
     got = enc.EncodeBatch([dsa.MeshData(p, f, n, u) for p, n, u, f in cases])
     for (p, n, u, f), g in zip(cases, got):
         assert g == synth.encode_mesh(p, f, n, u)
+
+
+def test_generic_uint8_attributes_through_the_device_encoder(ctx, monkeypatch):
+    """dsa_mesh_input.generic (ABI 4): one uint8 attribute of 1 - 4 components per vertex (vertex colours) -- coded as an integer
+    attribute by the HIP kernels, byte for byte what the CPU coder writes, with the connectivity on the device and on the host, and
+    back through the decoder to the input values."""
+    enc = dsa.DracoEncoder(ctx)
+    meshes, expect, inputs = [], [], []
+    k = 0
+    for kind, nx, ny in ((synth.GRID, 24, 17), (synth.TORUS, 16, 12), (synth.HOLES, 20, 16), (synth.SPHERE, 12, 9), (synth.TWO_PARTS, 9, 6), (synth.GRID, 128, 256)):
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, 61 + k)
+        for gc in (1, 3, 4, 2):
+            g = ((np.arange(len(pos) * gc, dtype=np.int64) * 104729 + 31 * k) % 256).astype(np.uint8).reshape(-1, gc)
+            cfg = [dsa.Config(), dsa.Config(symbol_scheme=0), dsa.Config(single_connectivity=True), dsa.Config(position_prediction=0, texcoord_prediction=0)][k % 4]
+            with_n, with_uv = k % 3 != 1, k % 5 != 2
+            meshes.append((dsa.MeshData(pos, faces, nrm if with_n else None, uv if with_uv else None, generic=g), cfg))
+            opt = synth.options(pos_bits=cfg.position_bits, uv_bits=cfg.texcoord_bits, normal_bits=cfg.normal_bits,
+                                single_connectivity=1 if cfg.single_connectivity else 0, force_scheme=cfg.symbol_scheme,
+                                compression_level=10 - cfg.speed, pos_prediction=cfg.position_prediction, uv_prediction=cfg.texcoord_prediction,
+                                generic_components=gc)
+            expect.append(synth.encode_mesh(pos, faces, nrm if with_n else None, uv if with_uv else None, generic=g, opt=opt))
+            inputs.append(g)
+            k += 1
+    for host_conn in ("1", "0"):
+        monkeypatch.setenv("DSA_ENC_HOST_CONN", host_conn)
+        monkeypatch.setenv("DSA_ENC_HOST_PLAN", host_conn)
+        for cfg_id in range(4):                      # one batch per configuration (the options are the batch's)
+            idx = [i for i in range(len(meshes)) if i % 4 == cfg_id]
+            out = enc.EncodeBatch([meshes[i][0] for i in idx], meshes[idx[0]][1])
+            for j, i in enumerate(idx):
+                assert out[j] == expect[i], (host_conn, i)
+    # and back: the decoder returns the generic values per point
+    b = dsa.Batch(ctx, expect)
+    b.decode()
+    for i, g in enumerate(inputs):
+        assert b.status(i) == 0
+        m = b.result(i).ConnectedData
+        a = m.Attributes[-1]
+        assert a.AttributeType == 4 and a.NumComponents == g.shape[1]
+        ref = oracle.decode(expect[i])
+        assert a.Values.tobytes() == ref.attributes[-1].values.tobytes()
+        per_point = np.asarray(a.Values).reshape(-1, g.shape[1])[a.PointMap]
+        assert sorted(map(tuple, per_point.tolist())) == sorted(map(tuple, g.tolist()))
+    b.close()
