@@ -20,12 +20,16 @@ while done < count:
         nx, ny = int(rng.integers(4, 70)), int(rng.integers(4, 60))
         if kind == synth.HOLES: nx, ny = max(nx, 12), max(ny, 12)
         pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, int(rng.integers(0, 1 << 30)))
-        group.append((pos, faces, nrm if rng.integers(0, 4) else None, uv if rng.integers(0, 4) else None))
+        gen = None
+        if rng.integers(0, 3) == 0:                  # a generic uint8 attribute of 1 - 4 components (ABI 4)
+            gen = rng.integers(0, 256, (len(pos), int(rng.integers(1, 5)))).astype(np.uint8)
+        group.append((pos, faces, nrm if rng.integers(0, 4) else None, uv if rng.integers(0, 4) else None, gen))
     got = enc.EncodeBatch([dsa.MeshData(*m) for m in group], cfg)
     opt = synth.options(pos_bits=cfg.position_bits, uv_bits=cfg.texcoord_bits, normal_bits=cfg.normal_bits, single_connectivity=1 if cfg.single_connectivity else 0,
                         force_scheme=cfg.symbol_scheme, compression_level=10 - cfg.speed, pos_prediction=cfg.position_prediction, uv_prediction=cfg.texcoord_prediction)
-    for (p, f, n, u), g in zip(group, got):
-        if g != synth.encode_mesh(p, f, n, u, opt=opt):
+    for (p, f, n, u, gen), g in zip(group, got):
+        opt.generic_components = gen.shape[1] if gen is not None else 1
+        if g != synth.encode_mesh(p, f, n, u, generic=gen, opt=opt):
             bad += 1; print("differs:", cfg.__dict__, len(f))
     b = dsa.Batch(ctx, got); b.decode()
     bad += sum(1 for i in range(len(got)) if b.status(i) != 0)
