@@ -891,7 +891,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     hipLaunchKernelGGL(dsa::k_para_operands, dim3(gx, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
   }
   HIP_TRY(ctx, mark());
-  bool positions_by_vertex = false;
+  bool split_prediction = false;
   if (b->any_seamed && !b->any_multipara && !(lane_flags & LN_FLAG_PREDICT)) {
     // A batch with corner attributes: the attributes on the position connectivity are predicted behind the position traversal,
     // while the seam tables and the attribute traversals (20 - 30 ms more) are still under way -- what comes behind those then
@@ -899,13 +899,11 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
     HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_pred, 0));
     if (lane_flags & PW_FLAG) hipLaunchKernelGGL(dsa::k_predict_wrap, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags | PRED_FRONT);
     hipLaunchKernelGGL(dsa::k_predict, dim3(n, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, 1u, lane_flags | PRED_FRONT);
-    HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_early, 0));
-    HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_tables, 0));        // (which attributes are GeometricNormal: the walk of a mesh may end behind the tables)
-    const uint32_t gv = std::max<uint32_t>(1, std::min<uint32_t>((b->max_vertices + 1023) / 1024, 64));
-    hipLaunchKernelGGL(dsa::k_vertex_positions, dim3(gv, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
-    positions_by_vertex = true;
+    // (k_vertex_positions stays behind the second prediction launch: it leaves the positions by vertex in the operand region of the
+    // position connectivity, which an attribute of that connectivity located only behind the seam tables still reads there)
+    split_prediction = true;
   }
-  const uint32_t behind = positions_by_vertex ? PRED_BEHIND : 0u;
+  const uint32_t behind = split_prediction ? PRED_BEHIND : 0u;
   HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_join, 0));   // join: corrections are ready
   if (b->any_seamed) HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_att, 0));      // join: orders and operands of the seamed attributes
   if (b->any_general) HIP_TRY(ctx, hipStreamWaitEvent(st, S.ev_join3, 0));   // join: the general path's integers are ready
@@ -935,7 +933,7 @@ dsa_status dsa_batch_decode(dsa_batch *b) {
       hipLaunchKernelGGL(dsa::k_multipara_prepare, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
       hipLaunchKernelGGL(dsa::k_multipara, dim3((n + 3) / 4, na), dim3(WAVE), 0, st, b->arena, b->d_layouts, b->d_descs, n, b->d_globals);
     }
-    if (!positions_by_vertex) hipLaunchKernelGGL(dsa::k_vertex_positions, dim3(gv, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
+    hipLaunchKernelGGL(dsa::k_vertex_positions, dim3(gv, n), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     hipLaunchKernelGGL(dsa::k_predict_geometric, dim3(gx, n, na), dim3(256), 0, st, b->arena, b->d_layouts, b->d_descs, n);
     // TexCoordsPortable attributes: what depends on the mesh and the positions for every entry at once, then the chain over the
     // decoded texture coordinates, two lanes per attribute.  (The GeometricNormal kernels beside the chain, on another stream: the

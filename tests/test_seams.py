@@ -247,3 +247,19 @@ def test_gpu_corrupt_seamed_streams_agree_with_the_oracle(ctx, house04_bytes):
     assert sites <= {(1, 263), (1, 305), (1, 668), (1, 657), (1, 681), (1, 123)}, sites
     assert stricter <= 8, (equal, refused, stricter, sites)
     b.close()
+
+
+@pytest.mark.gpu
+def test_gpu_late_located_vertex_attribute_beside_geometric_normals(ctx):
+    """A parallelogram attribute on the POSITION connectivity that the walk locates only behind the seam tables (it stands behind a
+    corner attribute with tagged symbols or uncompressed integers) reads its operands from the operand region of the position
+    connectivity -- the region k_vertex_positions later fills with the positions by vertex for the GeometricNormal predictor.
+    (A build of round 4 ran k_vertex_positions in front of that attribute's prediction: decode_path 0, status 0, wrong values.)"""
+    cases = []
+    for kind, nx, ny in TOPOLOGIES:
+        for charts in (("random", None), ("stripes", None), ("checker", None)):
+            for opt in (dict(force_scheme=0, normal_prediction=6), dict(raw_integers=2, normal_prediction=6), dict(force_scheme=0, normal_prediction=6, predictive_connectivity=2),
+                        dict(force_scheme=0, normal_prediction=6, pos_prediction=0)):
+                args = seamed_mesh(synth, kind, nx, ny, 23, *charts)
+                cases.append((args, synth.encode_mesh_corners(*args, opt=synth.options(**opt))))
+    assert set(_gpu_check(ctx, cases)) == {0}

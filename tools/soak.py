@@ -38,6 +38,13 @@ def random_case(rng):
         patterns = ["stripes", "island", "checker", "random", "single", "none", None]
         charts = (str(rng.choice(patterns[:6])) if with_n and rng.integers(0, 2) else None, str(rng.choice(patterns[:6])) if with_uv and rng.integers(0, 2) else None)
         opt["single_connectivity"] = 0
+        # half of these stay on the wave-per-mesh kernels whatever else was drawn (depth-first order, no predictive symbols), and a
+        # third of those put tagged symbols into the corner attributes: the walk of the stream then stops in front of them and what
+        # follows is located behind the seam tables
+        if rng.integers(0, 2):
+            opt.update(traversal_method=0, predictive_connectivity=int(rng.choice([0, 2])), pos_prediction=int(rng.choice([0, 1, 4])), uv_prediction=int(rng.choice([0, 1, 5])))
+            if rng.integers(0, 3) == 0 and not opt.get("raw_integers"):
+                opt["force_scheme"] = 0
         pos, faces, nrm, nid, uv, uid = seamed_mesh(synth, kind, nx, ny, mesh_seed, *charts)
         return synth.encode_mesh_corners(pos, faces, nrm if with_n else None, nid if with_n else None, uv if with_uv else None, uid if with_uv else None,
                                          opt=synth.options(**opt)), (kind, nx, ny, opt, with_n, with_uv, charts)
