@@ -6,6 +6,8 @@ attributes per corner (synth.encode_mesh_corners), so every topology x seam patt
     rules of tests/meshutil.py (no decoder or writer code on the expected side);
   * CPU: the product's general-path source, compiled for the host under ASan / UBSan, equals the oracle;
   * GPU: the HIP path through the C-ABI equals the oracle bit for bit and the input per corner."""
+import os
+
 import numpy as np
 import pytest
 
@@ -263,3 +265,17 @@ def test_gpu_late_located_vertex_attribute_beside_geometric_normals(ctx):
                 args = seamed_mesh(synth, kind, nx, ny, 23, *charts)
                 cases.append((args, synth.encode_mesh_corners(*args, opt=synth.options(**opt))))
     assert set(_gpu_check(ctx, cases)) == {0}
+
+
+@pytest.mark.gpu
+def test_gpu_matrix_of_dialect_switches(ctx):
+    """tools/dialect_matrix.py: the full product of seam pattern per attribute x symbol scheme x prediction scheme per attribute x
+    connectivity symbols on four small topologies (2 592 streams) -- the combinations a random draw reaches rarely -- equal to the
+    oracle, most of them on the wave-per-mesh kernels."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dialect_matrix", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "dialect_matrix.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, bad, paths = mod.run(1, ctx)
+    assert n > 2000 and bad == 0
+    assert paths.get(0, 0) > 0.7 * n and set(paths) <= {0, 2}
