@@ -34,11 +34,34 @@ def run(seed=1, ctx=None):
                     except RuntimeError:
                         continue                                        # (a combination the writer refuses)
                     streams.append(s); labels.append((kind, n_chart, u_chart, opt))
+    # second family, attributes per vertex: quantisation bits (the rANS precision tiers), one decoder for all attributes or one each,
+    # a generic attribute of 0 / 1 / 4 components, the symbol scheme left to the writer
+    for ti, (kind, nx, ny) in enumerate(topologies[:3]):
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx + 6, ny + 5, seed + 10 + ti)
+        for bits, single, gc, scheme in itertools.product((dict(), dict(pos_bits=14, uv_bits=12, normal_bits=10)), (0, 1), (0, 1, 4), (-1, 0, 1)):
+            gen = None if gc == 0 else ((np.arange(len(pos) * gc, dtype=np.int64) * 7919 + ti) % 256).astype(np.uint8).reshape(-1, gc)
+            for pp, up, npred, conn in itertools.product((0, 1, 4), (0, 1, 5), (0, 6), (0, 2)):
+                if (ti + pp + up + npred + conn + single + gc) % 3:      # a third of the product per topology
+                    continue
+                opt = dict(pos_prediction=pp, uv_prediction=up, normal_prediction=npred, predictive_connectivity=conn, single_connectivity=single,
+                           force_scheme=scheme, generic_components=max(gc, 1), **bits)
+                try:
+                    s = synth.encode_mesh(pos, faces, nrm, uv, generic=gen, opt=synth.options(**opt))
+                except RuntimeError:
+                    continue
+                streams.append(s); labels.append((kind, None, None, opt))
     print(len(streams), "streams", flush=True)
     bad = 0
     paths = {}
-    for at in range(0, len(streams), 2048):
-        part = streams[at:at + 2048]
+    # in parts of at most 2048 (connectivity and traversal as two kernels) and, second pass, as one crowded batch (k_chain, the
+    # operands by the traversal waves, the octahedral streams kernel, the register gate)
+    parts = [(list(range(at, min(at + 2048, len(streams))))) for at in range(0, len(streams), 2048)] + [list(range(len(streams)))]
+    # third pass: the streams without corner attributes alone, five times over -- a crowded batch that takes k_chain
+    plain = [i for i, (_, n_chart, u_chart, _) in enumerate(labels) if n_chart is None and u_chart is None]
+    parts.append((plain * 5)[:max(2100, len(plain))] if len(plain) * 5 >= 2100 else plain * 5)
+    for idx in parts:
+        part = [streams[i] for i in idx]
+        at = None
         b = dsa.Batch(ctx, part)
         b.decode()
         for i, s in enumerate(part):
@@ -51,9 +74,9 @@ def run(seed=1, ctx=None):
             except AssertionError as e:
                 bad += 1
                 if bad <= 12:
-                    print("BAD", labels[at + i], "path", info.decode_path, str(e)[:100], flush=True)
+                    print("BAD", labels[idx[i]], "path", info.decode_path, "batch of", len(part), str(e)[:100], flush=True)
         b.close()
-    print("%d streams, %d bad, decode paths %s" % (len(streams), bad, paths))
+    print("%d streams (%d decodes in %d batches), %d bad, decode paths %s" % (len(streams), sum(len(x) for x in parts), len(parts), bad, paths))
     if own:
         ctx.close()
     return len(streams), bad, paths
