@@ -2,7 +2,7 @@
 x symbol scheme (raw, tagged, uncompressed integers) x prediction of positions (difference, parallelogram, constrained
 multi-parallelogram), texture coordinates (difference, parallelogram, TexCoordsPortable, constrained multi-parallelogram) and normals
 (difference, GeometricNormal) x connectivity symbols (standard, valence) x attribute subset -- the combinations a random draw
-reaches rarely (a late-located attribute beside a scheme that reuses a region, say).  usage: python tools/dialect_matrix.py [seed]"""
+reaches rarely (a late-located attribute beside a scheme that reuses a region, say).  usage: python tools/dialect_matrix.py [seed [big]]"""
 import itertools, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -10,7 +10,7 @@ import numpy as np, oracle, draco_sharp_amd as dsa, draco_sharp_amd.synth as syn
 from meshutil import seamed_mesh
 from test_gpu_parity import assert_same
 
-def run(seed=1, ctx=None):
+def run(seed=1, ctx=None, big=False):
     own = ctx is None
     if own:
         ctx = dsa.Context(0)
@@ -50,6 +50,14 @@ def run(seed=1, ctx=None):
                 except RuntimeError:
                     continue
                 streams.append(s); labels.append((kind, None, None, opt))
+    # third family (big=True): 65 536-triangle meshes, where rings are longer than the chains' LDS windows and ids need all their bits
+    if big:
+        for ti, kind in enumerate((synth.GRID, synth.TORUS)):
+            for u_chart in (None, "stripes"):
+                args = seamed_mesh(synth, kind, 128, 256, seed + 20 + ti, None, u_chart)
+                for pp, up, npred, conn, scheme in itertools.product((1, 4), (1, 5), (0, 6), (0, 2), (-1, 0)):
+                    opt = dict(pos_prediction=pp, uv_prediction=up, normal_prediction=npred, predictive_connectivity=conn, force_scheme=scheme)
+                    streams.append(synth.encode_mesh_corners(*args, opt=synth.options(**opt))); labels.append((kind, None, u_chart, opt))
     print(len(streams), "streams", flush=True)
     bad = 0
     paths = {}
@@ -83,5 +91,5 @@ def run(seed=1, ctx=None):
 
 
 if __name__ == "__main__":
-    n, bad, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+    n, bad, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 1, big=len(sys.argv) > 2 and sys.argv[2] == "big")
     sys.exit(1 if bad else 0)
