@@ -30,6 +30,11 @@ def streams_mixed(seed):
         out.append(f.read())                                           # general path (valence, seams)
     pos, nrm, uv, faces = synth.make_mesh(synth.HOLES, 14, 12, seed)
     out.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(normal_prediction=6)))   # second chance: block 1
+    # stock level 9 with vertex colours: ConstrainedMultiParallelogram positions and a four-component uint8 attribute (its rows are
+    # 4 bytes in the value block, not 4 x 4)
+    gen = ((np.arange(len(pos) * 4, dtype=np.int64) * 7919 + seed) % 256).astype(np.uint8).reshape(-1, 4)
+    out.append(synth.encode_mesh(pos, faces, nrm, uv, generic=gen, opt=synth.options(pos_prediction=4, uv_prediction=5, normal_prediction=6, predictive_connectivity=2,
+                                                                                     generic_components=4)))
     out.append(b"DRACO\x02\x02\x01\x01\x00\x00garbage")               # a bad stream fails alone
     out.append(synth.encode_point_cloud(np.random.default_rng(seed).random((500, 3), np.float32)))
     return out
