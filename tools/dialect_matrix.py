@@ -50,6 +50,14 @@ def run(seed=1, ctx=None, big=False):
                 except RuntimeError:
                     continue
                 streams.append(s); labels.append((kind, None, None, opt))
+    # fourth family: quantisation bits and compression levels on meshes large enough for wide alphabets -- every rANS precision from 12
+    # to 18 bits (Entropy/RAnsSymbolCoding.cs:10-27), the hand-scheduled decoders of 12 and of 13 - 15 bits, the compiled one above
+    for ti, (kind, nx, ny) in enumerate(((synth.GRID, 70, 60), (synth.HOLES, 64, 50))):
+        pos, nrm, uv, faces = synth.make_mesh(kind, nx, ny, seed + 30 + ti)
+        for k in range(36):
+            opt = dict(pos_bits=8 + k % 11, uv_bits=8 + (k * 3) % 9, normal_bits=6 + (k * 5) % 9, compression_level=(0, 5, 7, 10)[k % 4], force_scheme=(1, -1)[k % 2],
+                       pos_prediction=(1, 0, 4)[k % 3], predictive_connectivity=(0, 2)[(k // 2) % 2])
+            streams.append(synth.encode_mesh(pos, faces, nrm, uv, opt=synth.options(**opt))); labels.append((kind, None, None, opt))
     # third family (big=True): 65 536-triangle meshes, where rings are longer than the chains' LDS windows and ids need all their bits
     if big:
         for ti, kind in enumerate((synth.GRID, synth.TORUS)):
@@ -61,6 +69,7 @@ def run(seed=1, ctx=None, big=False):
     print(len(streams), "streams", flush=True)
     bad = 0
     paths = {}
+    precisions = set()
     # in parts of at most 2048 (connectivity and traversal as two kernels) and, second pass, as one crowded batch (k_chain, the
     # operands by the traversal waves, the octahedral streams kernel, the register gate)
     parts = [(list(range(at, min(at + 2048, len(streams))))) for at in range(0, len(streams), 2048)] + [list(range(len(streams)))]
@@ -76,6 +85,10 @@ def run(seed=1, ctx=None, big=False):
             ref = oracle.decode(s)
             info = b.mesh_info(i)
             paths[info.decode_path] = paths.get(info.decode_path, 0) + 1
+            if info.decode_path == 0:
+                for src, _, prec, _ in b.debug_array(i, 5, np.uint32, 64).reshape(16, 4)[:len(ref.attributes)]:
+                    if src == 1:
+                        precisions.add(int(prec))
             try:
                 assert b.status(i) == 0, (b.status(i), info.detail)
                 assert_same(b.result(i), ref)
@@ -84,7 +97,7 @@ def run(seed=1, ctx=None, big=False):
                 if bad <= 12:
                     print("BAD", labels[idx[i]], "path", info.decode_path, "batch of", len(part), str(e)[:100], flush=True)
         b.close()
-    print("%d streams (%d decodes in %d batches), %d bad, decode paths %s" % (len(streams), sum(len(x) for x in parts), len(parts), bad, paths))
+    print("%d streams (%d decodes in %d batches), %d bad, decode paths %s, rANS precisions of raw streams on the fast kernels %s" % (len(streams), sum(len(x) for x in parts), len(parts), bad, paths, sorted(precisions)))
     if own:
         ctx.close()
     return len(streams), bad, paths
