@@ -554,7 +554,7 @@ __device__ __forceinline__ void texcoords_prepare_entries(uint8_t *arena, const 
   bool bad = false;
   for (uint32_t p = tid; p < entries; p += stride) {
     TcPrep t;
-    t.next_id = DSA_INVALID; t.prev_id = DSA_INVALID; t.pn_norm2 = 0; t.cn_dot_pn = 0; t.norm = 0;
+    t.next_id = DSA_INVALID; t.prev_id = DSA_INVALID; t.pn_norm2 = 0; t.cn_dot_pn = 0; t.norm = 0; t.inv = 0.0;
     const uint32_t ci = io.d2c[p];
     if ((ci >> 2) >= F || (ci & 3u) == 3u) { bad = true; prep[p] = t; continue; }
     const uint32_t cn = qnext(ci), cp = qprev(ci);
@@ -578,6 +578,7 @@ __device__ __forceinline__ void texcoords_prepare_entries(uint8_t *arena, const 
       for (int k = 0; k < 3; ++k) { pn[k] = (uint64_t)pp[k] - (uint64_t)np[k]; cnv[k] = (uint64_t)tip[k] - (uint64_t)np[k]; }
       const int64_t pn_norm2 = (int64_t)(pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2]);
       t.pn_norm2 = pn_norm2;
+      t.inv = __drcp_rn((double)(uint32_t)pn_norm2);         // (taken by the chain only where pn_norm2 fits 32 bits and is not zero)
       if (pn_norm2 != 0) {
         const int64_t cn_dot_pn = (int64_t)(pn[0] * cnv[0] + pn[1] * cnv[1] + pn[2] * cnv[2]);
         t.cn_dot_pn = cn_dot_pn;
@@ -624,19 +625,12 @@ __device__ __forceinline__ int32_t tc_div(int64_t su, int64_t d, double inv, boo
   const double sd = __fma_rn((double)(int32_t)(su >> 32), 4294967296.0, (double)(uint32_t)su);      // exact below 2^53
   const double qe = sd * inv;
   if (!d_small || !(qe > -2147483000.0 && qe < 2147483000.0) || !(sd > -4.0e15 && sd < 4.0e15)) return (int32_t)tc_div_slow(su, d);
-  int32_t q = (int32_t)qe;                                 // toward zero; off by one at most
-  int64_t r = su - (int64_t)q * d;
-  if (su >= 0) {
-    if (r < 0) { --q; r += d; }
-    if (r < 0) { --q; r += d; }
-    if (r >= d) { ++q; r -= d; }
-    if (r >= d) { ++q; r -= d; }
-  } else {
-    if (r > 0) { ++q; r -= d; }
-    if (r > 0) { ++q; r -= d; }
-    if (r <= -d) { --q; r += d; }
-    if (r <= -d) { --q; r += d; }
-  }
+  // toward zero; off by one at most: sd is exact, `inv` and the product carry one rounding each (2^-53 relative), the quotient is
+  // below 2^31 -- the estimate is within 2^-20 of the true quotient, so its truncation is the true one or its neighbour
+  int32_t q = (int32_t)qe;
+  const int64_t r = su - (int64_t)q * d;
+  if (su >= 0) q += r < 0 ? -1 : (r >= d ? 1 : 0);
+  else q += r > 0 ? 1 : (r <= -d ? -1 : 0);
   return q;
 }
 // The loop body has no memory load inside a branch: every request is issued in straight-line code, so that the waits the compiler
@@ -719,7 +713,7 @@ __global__ __launch_bounds__(WAVE) void k_texcoords(uint8_t *arena, const MeshLa
         const int64_t d = t.pn_norm2;
         const bool geo = both && !equal && d != 0;
         const bool d_small = d > 0 && d < (int64_t)0x100000000ll;
-        const double inv = __drcp_rn((double)(uint32_t)d);
+        const double inv = t.inv;
         const int32_t d_own = (int32_t)((uint32_t)pc - (uint32_t)nc);
         const int32_t d_other = (int32_t)tc_partner((uint32_t)d_own);
         // x = n d + (cn . pn) pn_uv (own component); cx = (pn_v, -pn_u) norm: the other component's difference, negated for v

@@ -246,6 +246,7 @@ struct TcPrep {
   int64_t pn_norm2;            // |P(prev) - P(next)|^2
   int64_t cn_dot_pn;           // (P(tip) - P(next)) . (P(prev) - P(next))
   int64_t norm;                // IntSqrt(|C - X|^2 * pn_norm2), X = the foot of the tip on the edge
+  double inv;                  // 1 / pn_norm2 as the chain's division wants it (its low 32 bits as a double, reciprocal rounded to nearest)
 };
 
 // Compact download (dsa_batch_download_compact): where a mesh's faces and point maps go in the packed block the device makes for
