@@ -528,9 +528,9 @@ def main():
     if not args.no_end_to_end and weak_blob is not None:             # every rank its own batches: the clock is the slowest rank's
         e2e = end_to_end_leg(dsa, ctx, weak_blob, weak_offsets, args.e2e_batches, 2, comm if world > 1 else None, barrier if world > 1 else None, world, compact=True)
         e2e["full_layout"] = end_to_end_leg(dsa, ctx, weak_blob, weak_offsets, args.e2e_batches, 2, comm if world > 1 else None, barrier if world > 1 else None, world, compact=False)
-    # (behind the end-to-end leg: a context that has decoded a batch with corner attributes -- an arena of 120 GB for this batch size --
-    # pipelines upload / decode / download of later batches worse until it is recreated, 17 - 23 k meshes/s instead of 31 k; found on
-    # the last day of round 4, cause not established: profiles/README.md)
+    # (behind the end-to-end leg: the seamed batches of this leg have arenas of 120 GB at this batch size, and for seconds after such
+    # an arena is freed the downloads of the end-to-end pipeline run at half the link rate -- 17 - 23 k meshes/s instead of 31 k;
+    # profiles/README.md)
     dialects = None
     if not args.no_dialects and world == 1 and weak_blob is not None:
         dialects = dialects_leg(dsa, synth, ctx, nx, ny, args.meshes, 3)
